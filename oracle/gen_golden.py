@@ -1,0 +1,383 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+TEST INFRASTRUCTURE.  Imports /root/reference headless (oracle/_ref_import.py), feeds it
+seeded synthetic inputs/params from semireward_amd.utils.synth, and stores inputs-by-seed
+plus expected outputs.  Fixtures are data only; no reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [--only NAME]
+"""
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _ref_import as R  # noqa: E402
+from oracle import semireward_ref as S  # noqa: E402
+from oracle import vit_ref as V  # noqa: E402
+from semireward_amd.utils import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+def samp(a, n=1024):
+    """Strided sample + sums of a big tensor (keeps fixtures small)."""
+    a = np.asarray(a, dtype=np.float32).ravel()
+    st = max(1, a.size // n)
+    return dict(sample=a[::st].copy(), stride=np.int64(st), sum=np.float64(a.astype(np.float64).sum()),
+                abssum=np.float64(np.abs(a.astype(np.float64)).sum()))
+
+
+def flat(prefix, d, out):
+    for k, v in d.items():
+        out[f"{prefix}/{k}"] = v
+
+
+def load_module_params(mod, params):
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(T(params[n]))
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_rewarder():
+    sr = R.mod("semilearn.algorithms.semireward.semireward")
+    out = {}
+    cases = [("f384_b8", 384, 100, 8, 11), ("f128_b64", 128, 100, 64, 12), ("f768_b16_c200", 768, 200, 16, 13)]
+    for tag, Fd, C, B, seed in cases:
+        L = sr.label_dim(C)
+        rp = synth.synth_params(S.rewarder_shapes(Fd, C), seed)
+        gp = synth.synth_params(S.generator_shapes(Fd), seed + 100)
+        gp["fc_layers.6.bias"] = gp["fc_layers.6.bias"] + np.float32(2.6)   # make non-zero labels appear
+        rng = np.random.Generator(np.random.PCG64(seed + 200))
+        feats = rng.standard_normal((B, Fd)).astype(np.float32)
+        labels = rng.integers(0, C, size=(B,), dtype=np.int64)
+        rew = sr.Rewarder(L, 128, Fd)
+        gen = sr.Generator(Fd)
+        load_module_params(rew, rp)
+        load_module_params(gen, gp)
+        # scoring pass (srflexmatch.py:99-101)
+        with torch.no_grad():
+            r = rew(T(feats), T(labels))
+            avg = r.mean()
+            mask2 = torch.where(r >= avg, torch.tensor(1), torch.tensor(0)).squeeze().float()
+        out[f"{tag}/reward"] = r.numpy()
+        out[f"{tag}/mask2"] = mask2.numpy()
+        # generator (srflexmatch.py:158-159)
+        g = gen(T(feats))
+        gl = g.long()
+        out[f"{tag}/gen_out"] = g.detach().numpy()
+        out[f"{tag}/gen_label"] = gl.numpy()
+        # SR update, literally srflexmatch.py:195-208, two Adam steps
+        ropt = torch.optim.Adam(rew.parameters(), lr=5e-4)
+        gopt = torch.optim.Adam(gen.parameters(), lr=5e-4)
+        crit = torch.nn.MSELoss()
+        for step in range(2):
+            rew.train(); gen.train()
+            generated_label = gen(T(feats)).long()
+            reward = rew(T(feats), generated_label.squeeze(1))
+            gl1h = F.one_hot(generated_label.squeeze(1), num_classes=C)
+            real = F.one_hot(T(labels), num_classes=C)
+            cs = sr.cosine_similarity_n(gl1h.float(), real.float())
+            generator_loss = crit(reward, torch.ones_like(reward))
+            rewarder_loss = crit(reward, cs)
+            gopt.zero_grad(); ropt.zero_grad()
+            generator_loss.backward(retain_graph=True)
+            rewarder_loss.backward(retain_graph=True)
+            if step == 0:
+                out[f"{tag}/upd_reward"] = reward.detach().numpy()
+                out[f"{tag}/upd_target"] = cs.numpy()
+                out[f"{tag}/generator_loss"] = np.float32(generator_loss.item())
+                out[f"{tag}/rewarder_loss"] = np.float32(rewarder_loss.item())
+                for n, p in rew.named_parameters():
+                    flat(f"{tag}/grad/{n}", samp(p.grad.numpy()), out)
+                assert all(p.grad is None for p in gen.parameters())
+            gopt.step(); ropt.step()
+            for n, p in rew.named_parameters():
+                flat(f"{tag}/after{step + 1}/{n}", samp(p.detach().numpy()), out)
+        out[f"{tag}/meta"] = np.array([Fd, C, B, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "rewarder.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_hooks():
+    um = R.mod("semilearn.algorithms.srflexmatch.utils")
+    hk = R.mod("semilearn.algorithms.hooks")
+    out = {}
+    alg = types.SimpleNamespace(p_cutoff=0.95)
+    alg.compute_prob = lambda lg: torch.softmax(lg, dim=-1)
+    cases = [("c10_w", 10, 48, 8, 40, True, 31, 2, 25), ("c100_w", 100, 512, 64, 40, True, 32, 6, 40),
+             ("c10_nw", 10, 48, 8, 40, False, 33, 2, 25), ("c100_b256", 100, 50000, 256, 6, True, 34, 1, 9)]
+    for tag, C, U, Bu, steps, warm, seed, lo, hi in cases:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        hook = um.FlexMatchThresholdingHook(ulb_dest_len=U, num_classes=C, thresh_warmup=warm)
+        logits = (rng.standard_normal((steps, Bu, C)) * rng.uniform(lo, hi, size=(steps, Bu, 1))).astype(np.float32)
+        idx = np.stack([rng.permutation(U)[:Bu] for _ in range(steps)]).astype(np.int64)
+        masks, accs, pls, fixed, probs_all = [], [], [], [], []
+        for t in range(steps):
+            probs = torch.softmax(T(logits[t]), dim=-1)
+            m = hook.masking(alg, logits_x_ulb=probs, softmax_x_ulb=False, idx_ulb=T(idx[t]))
+            masks.append(m.numpy().copy()); accs.append(hook.classwise_acc.numpy().copy())
+            pls.append(hk.PseudoLabelingHook().gen_ulb_targets(alg, logits=probs, use_hard_label=True, T=0.5, softmax=False).numpy())
+            fixed.append(hk.FixedThresholdingHook().masking(alg, logits_x_ulb=probs, softmax_x_ulb=False).numpy())
+            probs_all.append(probs.numpy())
+        out[f"{tag}/logits"] = logits
+        out[f"{tag}/probs"] = np.stack(probs_all)
+        out[f"{tag}/idx"] = idx
+        out[f"{tag}/mask"] = np.stack(masks)
+        out[f"{tag}/classwise_acc"] = np.stack(accs)
+        out[f"{tag}/pseudo_label"] = np.stack(pls)
+        out[f"{tag}/fixed_mask"] = np.stack(fixed)
+        sel = hook.selected_label.numpy()
+        nz = np.nonzero(sel != -1)[0]
+        out[f"{tag}/sel_idx"] = nz.astype(np.int64)
+        out[f"{tag}/sel_val"] = sel[nz]
+        out[f"{tag}/meta"] = np.array([C, U, Bu, steps, int(warm), seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "hooks.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_losses():
+    cr = R.mod("semilearn.core.criterions")
+    out = {}
+    for tag, B, C, seed in [("b8_c100", 8, 100, 41), ("b64_c10", 64, 10, 42), ("b256_c100", 256, 100, 43)]:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        logits = (3 * rng.standard_normal((B, C))).astype(np.float32)
+        y = rng.integers(0, C, size=(B,), dtype=np.int64)
+        mask = (rng.random(B) < 0.6).astype(np.float32)
+        mask2 = (rng.random(B) < 0.5).astype(np.float32)
+        lg = T(logits).requires_grad_(True)
+        sup = cr.ce_loss(lg, T(y), reduction="mean")
+        sup.backward()
+        out[f"{tag}/sup"] = np.float32(sup.item()); out[f"{tag}/sup_grad"] = lg.grad.numpy().copy()
+        lg = T(logits).requires_grad_(True)
+        un = cr.consistency_loss(lg, T(y), "ce", mask=T(mask), mask2=T(mask2))
+        un.backward()
+        out[f"{tag}/unsup"] = np.float32(un.item()); out[f"{tag}/unsup_grad"] = lg.grad.numpy().copy()
+        lg = T(logits).requires_grad_(True)
+        un1 = cr.consistency_loss(lg, T(y), "ce", mask=T(mask))
+        out[f"{tag}/unsup_mask1"] = np.float32(un1.item())
+        for k, v in dict(logits=logits, y=y, mask=mask, mask2=mask2).items():
+            out[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def build_ref_vit(cfgd, C, params):
+    vit = R.mod("semilearn.nets.vit.vit")
+    m = vit.VisionTransformer(num_classes=C, **cfgd)
+    load_module_params(m, params)
+    return m
+
+
+def inject_droppath(model, dp):
+    """dp [depth,2,B] or None."""
+    for i, blk in enumerate(model.blocks):
+        for j, name in enumerate(("drop_path1", "drop_path2")):
+            mod = getattr(blk, name)
+            if hasattr(mod, "injected"):
+                mod.injected = None if dp is None else T(dp[i, j])
+            elif dp is not None:
+                assert np.all(dp[i, j] == 1.0), "Identity drop path (p=0) needs scale 1"
+
+
+def gen_vit():
+    out = {}
+    for tag, cfgd, C, B, seed in [("tiny", V.VIT_TINY_TEST, 10, 6, 51), ("small_p2_32", V.VIT_SMALL_P2_32, 100, 24, 52)]:
+        cfg = V.VitCfg(num_classes=C, **cfgd)
+        params = synth.synth_params(V.param_shapes(cfg), seed)
+        rng = np.random.Generator(np.random.PCG64(seed + 1))
+        x = rng.standard_normal((B, 3, cfg.img_size, cfg.img_size)).astype(np.float32)
+        y = rng.integers(0, C, size=(B,), dtype=np.int64)
+        w = rng.random(B).astype(np.float32)                      # per-row loss weights (stand-in for mask*mask2)
+        dp = synth.synth_droppath(seed + 2, V.drop_path_probs(cfg), B)
+        model = build_ref_vit(cfgd, C, params)
+        model.eval(); inject_droppath(model, None)
+        with torch.no_grad():
+            o = model(T(x))
+        out[f"{tag}/eval_logits"] = o["logits"].numpy(); out[f"{tag}/eval_feat"] = o["feat"].numpy()
+        model.train(); inject_droppath(model, dp)
+        o = model(T(x))
+        out[f"{tag}/train_logits"] = o["logits"].detach().numpy(); out[f"{tag}/train_feat"] = o["feat"].detach().numpy()
+        loss = (F.cross_entropy(o["logits"], T(y), reduction="none") * T(w)).mean()
+        loss.backward()
+        out[f"{tag}/loss"] = np.float32(loss.item())
+        for n, p in model.named_parameters():
+            flat(f"{tag}/grad/{n}", samp(p.grad.numpy(), 256), out)
+        out[f"{tag}/meta"] = np.array([C, B, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "vit.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_optim():
+    bu = R.mod("semilearn.core.utils.build")
+    out = {}
+    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
+    vit = R.mod("semilearn.nets.vit.vit")
+    model = vit.vit_small_patch2_32(num_classes=100)
+    opt = bu.get_optimizer(model, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    names, lrs, wds = [], [], []
+    for g in opt.param_groups:
+        for p in g["params"]:
+            names.append(id2name[id(p)]); lrs.append(g["lr"]); wds.append(g["weight_decay"])
+    out["small/names"] = np.array(names); out["small/lr"] = np.array(lrs, dtype=np.float64)
+    out["small/wd"] = np.array(wds, dtype=np.float64); out["small/num_groups"] = np.int64(len(opt.param_groups))
+    # scheduler factors
+    sch = bu.get_cosine_schedule_with_warmup(opt, 204800, num_warmup_steps=5120)
+    steps = np.array([0, 1, 100, 5119, 5120, 5121, 20000, 100000, 204799], dtype=np.int64)
+    out["sched/steps"] = steps
+    out["sched/factor"] = np.array([sch.lr_lambdas[0](int(s)) for s in steps], dtype=np.float64)
+    # AdamW numerics on the tiny ViT, 3 steps with seeded grads, warmup 2
+    cfgt = V.VitCfg(num_classes=10, **V.VIT_TINY_TEST)
+    params = synth.synth_params(V.param_shapes(cfgt), 61)
+    mt = build_ref_vit(V.VIT_TINY_TEST, 10, params)
+    ot = bu.get_optimizer(mt, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+    st = bu.get_cosine_schedule_with_warmup(ot, 10, num_warmup_steps=2)
+    for step in range(4):
+        g = synth.synth_params(V.param_shapes(cfgt), 70 + step)
+        for n, p in mt.named_parameters():
+            p.grad = T(g[n]) * 0.1
+        ot.step(); st.step(); mt.zero_grad()
+    for n, p in mt.named_parameters():
+        flat(f"adamw_tiny/{n}", samp(p.detach().numpy(), 128), out)
+    np.savez_compressed(os.path.join(OUT, "optim.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+class _PassModel(torch.nn.Module):
+    """Wraps the reference ViT so every forward uses the next injected DropPath mask set."""
+
+    def __init__(self, model, dps):
+        super().__init__()
+        self.model, self.dps, self.calls = model, dps, 0
+
+    def forward(self, x):
+        inject_droppath(self.model, self.dps[self.calls])
+        self.calls += 1
+        return self.model(x)
+
+
+TRACE = dict(num_train_iter=2000, start_timing=100, N_k=10, ulb_dest_len=256, C=10, Bl=4, Bu=4,
+             its=[0, 1, 99, 100, 101, 110, 300, 301], seed=81, num_warmup_iter=50)
+
+
+def build_headless_srflexmatch(model, C, Fd, tr):
+    srf = R.mod("semilearn.algorithms.srflexmatch.srflexmatch")
+    sr = R.mod("semilearn.algorithms.semireward.semireward")
+    um = R.mod("semilearn.algorithms.srflexmatch.utils")
+    hk = R.mod("semilearn.algorithms.hooks")
+    cr = R.mod("semilearn.core.criterions")
+    bu = R.mod("semilearn.core.utils.build")
+    alg = object.__new__(srf.SRFlexMatch)
+    alg.args = types.SimpleNamespace(ulb_dest_len=tr["ulb_dest_len"], thresh_warmup=True)
+    alg.num_classes, alg.use_cat, alg.amp_cm, alg.gpu = C, True, contextlib.nullcontext, None
+    alg.lambda_u, alg.num_train_iter, alg.it = 1.0, tr["num_train_iter"], 0
+    alg.model = model
+    alg.ce_loss, alg.consistency_loss = cr.CELoss(), cr.ConsistencyLoss()
+    alg.init(T=0.5, p_cutoff=0.95, hard_label=True, thresh_warmup=True)
+    alg.N_k, alg.start_timing = tr["N_k"], tr["start_timing"]
+    alg.rewarder = sr.Rewarder(sr.label_dim(C), 128, Fd)
+    alg.generator = sr.Generator(Fd)
+    alg.rewarder_optimizer = torch.optim.Adam(alg.rewarder.parameters(), lr=5e-4)
+    alg.generator_optimizer = torch.optim.Adam(alg.generator.parameters(), lr=5e-4)
+    alg.criterion = torch.nn.MSELoss()
+    alg.max_reward = -float("inf")
+    alg._hooks = []
+    from collections import OrderedDict
+    alg.hooks_dict = OrderedDict()
+    alg.register_hook(hk.PseudoLabelingHook(), "PseudoLabelingHook")
+    alg.register_hook(um.FlexMatchThresholdingHook(ulb_dest_len=tr["ulb_dest_len"], num_classes=C, thresh_warmup=True), "MaskingHook")
+    alg.optimizer = bu.get_optimizer(model, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+    alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
+    return alg
+
+
+def gen_trace():
+    tr = TRACE
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+    Fd = cfg.embed_dim
+    vp = synth.synth_params(V.param_shapes(cfg), seed)
+    rp = synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)
+    gp = synth.synth_params(S.generator_shapes(Fd), seed + 2)
+    model = build_ref_vit(V.VIT_TINY_TEST, C, vp)
+    model.train()
+    alg = build_headless_srflexmatch(model, C, Fd, tr)
+    load_module_params(alg.rewarder, rp)
+    load_module_params(alg.generator, gp)
+    out = {}
+    prev_it = -1
+    for n, it in enumerate(tr["its"]):
+        # advance the LambdaLR to iteration `it` (the reference steps it once per iteration)
+        for _ in range(it - prev_it - 1):
+            alg.scheduler.step()
+        prev_it = it
+        alg.it = it
+        K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        dps = [synth.synth_droppath(seed + 1000 * (n + 1) + k, V.drop_path_probs(cfg), Bl + 2 * Bu) for k in range(K + 1)]
+        alg.model = _PassModel(model, dps)
+        # ---- instrument: record per-call masks via hook wrappers
+        rec = dict(mask=[], acc=[])
+        mh = alg.hooks_dict["MaskingHook"]
+        orig = mh.masking
+
+        def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
+            m = _orig(algorithm, *a, **k)
+            _rec["mask"].append(m.numpy().copy()); _rec["acc"].append(mh.classwise_acc.numpy().copy())
+            return m
+        mh.masking = wrapped
+        rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
+        o, log = alg.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["idx_ulb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]))
+        mh.masking = orig
+        assert alg.model.calls == K + 1, (alg.model.calls, K)
+        o["loss"].backward()                      # ParamUpdateHook.after_train_step
+        p = f"it{it}"
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/grad/{nme}", samp(prm.grad.numpy(), 64), out)
+        out[f"{p}/lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / 5e-4)   # head group has scale 1
+        alg.optimizer.step(); alg.scheduler.step(); model.zero_grad()
+        for k_, v in log.items():
+            out[f"{p}/log/{k_.split('/')[-1]}"] = np.float64(v)
+        out[f"{p}/K"] = np.int64(K)
+        out[f"{p}/masks"] = np.stack(rec["mask"]); out[f"{p}/accs"] = np.stack(rec["acc"])
+        for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+            out[f"{p}/feat/{k_}"] = o["feat"][k_].detach().numpy()
+        changed = any(not torch.equal(rbefore[k_], v.detach()) for k_, v in alg.rewarder.named_parameters())
+        out[f"{p}/rewarder_updated"] = np.int64(changed)
+        for k_, v in alg.rewarder.named_parameters():
+            flat(f"{p}/rewarder/{k_}", samp(v.detach().numpy(), 64), out)
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
+        mr = alg.max_reward
+        out[f"{p}/max_reward"] = np.float64(float(mr))
+        sel = mh.selected_label.numpy(); nz = np.nonzero(sel != -1)[0]
+        out[f"{p}/sel_idx"] = nz.astype(np.int64); out[f"{p}/sel_val"] = sel[nz]
+    out["meta/its"] = np.array(tr["its"], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "srflexmatch_trace.npz"), **out)
+
+
+GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    assert R.available(), "reference tree not present: golden vectors can only be generated in the build container"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    for k, fn in GENS.items():
+        if a.only and a.only != k:
+            continue
+        print("generating", k, flush=True)
+        fn()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,63 @@
+"""Oracle: optimizer / scheduler semantics (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+  get_optimizer                    semilearn/core/utils/build.py:193-224
+  param_groups_layer_decay         semilearn/nets/utils.py:143-204 (+ group_matcher vit.py:311-320)
+  get_cosine_schedule_with_warmup  semilearn/core/utils/build.py:227-251
+  ParamUpdateHook.after_train_step semilearn/core/hooks/param_update.py:21-45
+  EMA.update                       semilearn/core/utils/misc.py:152-155
+"""
+import math
+import re
+
+import torch
+
+
+def vit_layer_id(name, depth):
+    """group_matcher (vit.py:311-320) + group_with_matcher(reverse=True): stem -> 0,
+    blocks.i -> i+1, final ``norm`` joins the previous group (MATCH_PREV_GROUP) == depth,
+    anything unmatched (head) -> layer_max == depth+1 (nets/utils.py:178)."""
+    if name in ("cls_token", "pos_embed") or name.startswith("patch_embed"):
+        return 0
+    m = re.match(r"^blocks\.(\d+)", name)
+    if m:
+        return int(m.group(1)) + 1
+    if name.startswith("norm"):
+        return depth
+    return depth + 1
+
+
+def vit_param_hparams(names_shapes, depth, lr, weight_decay, layer_decay,
+                      no_weight_decay=("pos_embed", "cls_token")):
+    """Per-tensor (lr, weight_decay) exactly as the 28 param groups of SURVEY A.11."""
+    layer_max = depth + 1
+    out = {}
+    for name, shape in names_shapes:
+        lid = vit_layer_id(name, depth)
+        scale = layer_decay ** (layer_max - lid)
+        wd = 0.0 if (len(shape) == 1 or name in no_weight_decay) else weight_decay
+        out[name] = (scale * lr, wd)
+    return out
+
+
+def cosine_warmup_factor(step, num_training_steps, num_warmup_steps=0, num_cycles=7.0 / 16.0):
+    """build.py:237-249.  LambdaLR applies factor(it) at 0-based iteration ``it``."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    t = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, math.cos(math.pi * num_cycles * t))
+
+
+def adamw_step(p, g, m, v, step, lr, wd, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.AdamW single-tensor math (decoupled decay first).  step is 1-based.  In place."""
+    p.mul_(1.0 - lr * wd)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def ema_update(shadow, p, decay):
+    """misc.py:152-155: shadow = (1-m)*p + m*shadow."""
+    return (1.0 - decay) * p + decay * shadow
