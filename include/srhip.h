@@ -1,0 +1,142 @@
+/* libsrhip -- C ABI of the MI355X (gfx950) SemiReward hot path.
+ *
+ * The reference (Westlake-AI/SemiReward) is 100 % Python on ATen; it has no FFI of its own.  The
+ * "interface each entry point replaces" is therefore the ATen op sequence at the cited reference
+ * call site (paths relative to the reference root; K-numbers = SURVEY.md section 2c).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes, no torch types.  Buffers are borrowed for the call.
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     returns immediately:  0 = ok, -1 = invalid argument, <= -2 = -(2 + hipError_t) launch failure.
+ *     Nothing throws across the boundary; nothing allocates; no host synchronisation.
+ *   - bf16 buffers are raw uint16 bit patterns (void*), row-major, 16-byte aligned.
+ *   - int64 index tensors keep the reference's dtype (torch.long) so no host-side conversion is needed.
+ *   - single thread per process / one process per GPU, like the reference (train.py:344).
+ */
+#ifndef SRHIP_H
+#define SRHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contractions (MFMA).  C[M,N] (+)= A[M,K] . B[N,K]^T, bf16 in, fp32 accumulate.
+ * Replaces nn.Linear forward/backward of the backbone:
+ *   qkv / proj   semilearn/nets/vit/vit.py:93-98, :105          (K3, K5)
+ *   fc1 / fc2    semilearn/nets/vit/vit.py:69-75                (K6)
+ * Requirements: K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc % 4 == 0.
+ */
+enum {
+  SRHIP_EPI_BF16 = 0,       /* C(bf16) = acc + bias                                              */
+  SRHIP_EPI_GELU_BF16 = 1,  /* C(bf16) = gelu_erf(acc + bias); aux_out(bf16) = acc + bias if set */
+  SRHIP_EPI_RESID_F32 = 2,  /* C(f32) = R + row_scale[m / rows_per_sample] * (acc + bias), R = aux_in (f32, ldaux) if set else C
+                               (DropPath + residual add, vit.py:164-165)                            */
+  SRHIP_EPI_DGELU_BF16 = 3, /* C(bf16) = acc * gelu_erf'(aux_in)                                 */
+  SRHIP_EPI_F32 = 4         /* C(f32) = alpha * acc + beta * C                                   */
+};
+int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                  const float* bias, const float* row_scale, int rows_per_sample, const void* aux_in, void* aux_out,
+                  int ldaux, float alpha, float beta, void* stream);
+
+/* Fused attention, head_dim 64.  qkv bf16 [B*N, 3*H*64] as written by the qkv Linear; out bf16 [B*N, H*64];
+ * lse fp32 [B,H,N] (NULL when no backward is needed).  Replaces vit.py:100-104 (K4).  N <= 512. */
+int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);
+/* dqkv bf16 [B*N, 3*H*64]; delta_ws fp32 [B,H,N] scratch.  Autograd backward of vit.py:100-104.  N <= 288. */
+int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, float* delta_ws,
+                   int B, int N, int H, float scale, void* stream);
+
+/* nn.LayerNorm over the last dim (vit.py:135,150,268; eps 1e-6 :222) (K2).  x fp32 [M,D] -> out bf16 [M,D];
+ * mean/rstd fp32 [M] are written when non-NULL (needed by the backward).  D in {128, 384, 768}. */
+int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* out, float* mean,
+                        float* rstd, int M, int D, void* stream);
+/* dx (fp32) += LN'(dy bf16); dgamma/dbeta (fp32) += column sums (atomic). */
+int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        float* dx, float* dgamma, float* dbeta, int M, int D, void* stream);
+
+/* PatchEmbed conv (kernel = stride = ps) + cls token + pos_embed (vit.py:39-44, :277-280) (K1).
+ * img fp32 [*, C, HW, HW]; img_index int32 [B] maps batch row -> image (NULL = identity; lets the K+1 passes of
+ * one SemiReward step share one copy of the images); x fp32 [B, N, D], N = (HW/ps)^2 + 1.  C*ps*ps <= 64. */
+int srhip_patch_embed_fwd(const float* img, const int* img_index, const float* Wp, const float* bp, const float* cls,
+                          const float* pos, float* x, int B, int C, int HW, int ps, int D, void* stream);
+/* all outputs are accumulated (+=). */
+int srhip_patch_embed_bwd(const float* dx, const float* img, const int* img_index, float* dWp, float* dbp, float* dcls,
+                          float* dpos, int B, int C, int HW, int ps, int D, void* stream);
+
+/* Final norm on the cls token, global_pool='token', classifier head (vit.py:282, :296-305) (K7).
+ * feat fp32 [B,D], logits fp32 [B,C]; xhat [B,D] / rstd [B] saved for the backward when non-NULL. */
+int srhip_cls_head_fwd(const float* x, const float* gamma, const float* beta, float eps, const float* Wh, const float* bh,
+                       float* feat, float* logits, float* xhat, float* rstd, int B, int N, int D, int C, void* stream);
+/* dx[b,0,:] = ...(rows other than the cls row are left untouched: zero dx first); dWh/dbh/dgamma/dbeta += */
+int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const float* gamma, const float* feat, const float* xhat,
+                       const float* rstd, float* dx, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int N,
+                       int D, int C, void* stream);
+
+/* glue feeding the GEMM: fp32 -> bf16 with optional per-sample (DropPath) scale; transposes with zero padding,
+ * optional exact-erf GELU, optional column sums (bias gradients, atomic +=); flat cast. */
+int srhip_cast_scale_rows(const float* x, const float* scale, int rows_per_sample, void* out, long M, int D, void* stream);
+int srhip_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, void* out, int ld_out, int M, int Mp, int C,
+                            int apply_gelu, float* colsum, void* stream);
+int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stream);
+/* timm DropPath (vit.py:148,161): out[depth,2,B] = Bernoulli(1-p_l)/(1-p_l), counter-based RNG. */
+int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Score filter (K8, K9, K11, K12, K13).
+ * srhip_row_max: softmax (compute_prob, semilearn/core/algorithmbase.py:332-333) + torch.max / argmax
+ *   (semilearn/algorithms/hooks/pseudo_label.py:40, srflexmatch/utils.py:50).  in fp32 [B,C] = logits
+ *   (in_is_probs = 0) or probabilities (1); probs_out optional. */
+int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B, int C,
+                  void* stream);
+/* FlexMatchThresholdingHook.masking + update (semilearn/algorithms/srflexmatch/utils.py:24-63).  State on device:
+ * selected_label int64 [ulb_dest_len] (-1 = unused), classwise_acc fp32 [C], hist int32 [C+1] (bin C = unused).
+ * idx_ulb must be unique within the batch (reference sampler property). */
+int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
+                         long long* selected_label, int* hist, float* classwise_acc, float* mask, int B, int C,
+                         int ulb_dest_len, int thresh_warmup, void* stream);
+int srhip_flexmatch_rebuild_hist(const long long* selected_label, int* hist, int ulb_dest_len, int C, void* stream);
+/* FixedThresholdingHook.masking (semilearn/algorithms/hooks/masking.py:42-57). */
+int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream);
+/* mask2 = (reward >= reward.mean()) per independent group of B rows (srflexmatch.py:100-101) (K11). */
+int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, int groups, int B, void* stream);
+/* ce_loss / consistency_loss forward + analytic backward (semilearn/core/criterions/cross_entropy.py:11-31,
+ * consistency.py:38-45): loss = mean_B(nll*mask*mask2); dlogits = grad_scale*(softmax-onehot)*mask*mask2/B. */
+int srhip_masked_ce(const float* logits, const long long* targets, const float* mask, const float* mask2, float grad_scale,
+                    float* loss_out, float* dlogits, int B, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rewarder / Generator (K10, K14, K15).  params: flat fp32 block in named_parameters() order.
+ * Rewarder.forward (semilearn/algorithms/semireward/semireward.py:52-72) for G independent groups of B rows
+ * (each group has its own softmax over its 2B rows): feats [G*B,F], labels int64 [G*B] -> reward [G*B].
+ * ws: fp32 scratch of srhip_rewarder_ws_floats(G,B) floats; save_for_bwd needs G == 1. */
+long srhip_rewarder_param_count(int F, int L);
+long srhip_rewarder_ws_floats(int G, int B);
+long srhip_generator_param_count(int F);
+int srhip_rewarder_fwd(const float* params, const float* feats, const long long* labels, float* reward, float* ws, int G,
+                       int B, int F, int L, int save_for_bwd, void* stream);
+/* Gradient of MSE(r,1) + MSE(r,target) w.r.t. every rewarder parameter (srflexmatch.py:183-190 / :198-205);
+ * grads is overwritten; losses[0..1] = (generator_loss, rewarder_loss) when non-NULL. */
+int srhip_rewarder_bwd(const float* params, const float* feats, const long long* labels, const float* target, float* ws,
+                       float* grads, float* losses, int B, int F, int L, void* stream);
+/* Generator.forward (semireward.py:21-24) and the .long() cast (srflexmatch.py:158-159). */
+int srhip_generator_fwd(const float* params, const float* x, float* out, long long* label, int B, int F, void* stream);
+/* (cosine_similarity_n(one_hot, one_hot)+1)/2 (semireward.py:130-139, srflexmatch.py:180-182): 1.0 / 0.5. */
+int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, void* stream);
+/* torch.optim.Adam step on a flat block (srflexmatch.py:54, :192-193). */
+int srhip_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                    int step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backbone optimizer (K16, K17): ParamUpdateHook (semilearn/core/hooks/param_update.py:33-40) with the AdamW
+ * param groups of semilearn/core/utils/build.py:193-224 + semilearn/nets/utils.py:143-204, fused with the bf16
+ * operand refresh, EMA.update (semilearn/core/utils/misc.py:152-155) and model.zero_grad().
+ * chunk_table int32 [n_chunks][4] = (offset, length, tensor id, 0); lr_t / wd_t fp32 per tensor;
+ * grad_scale multiplies g first (1/world_size after a data-parallel SUM all-reduce). */
+int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, float* ema, const int* chunk_table, int n_chunks,
+                     const float* lr_t, const float* wd_t, float lr_factor, float beta1, float beta2, float eps, int step,
+                     float ema_m, float grad_scale, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""ctypes binding of libsrhip.so -- the ONLY compute path of this package.
+
+There is deliberately no fallback: if the HIP library is missing or fails to load, importing an op
+raises.  Signatures mirror include/srhip.h one to one.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsrhip.so")
+
+EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_F32 = range(5)
+
+P, I, F, L = c_void_p, c_int, c_float, c_long
+SIGNATURES = {
+    "srhip_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, P, I, P, P, I, F, F, P]),
+    "srhip_attn_fwd": (I, [P, P, P, I, I, I, F, P]),
+    "srhip_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, F, P]),
+    "srhip_layernorm_fwd": (I, [P, P, P, F, P, P, P, I, I, P]),
+    "srhip_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P]),
+    "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_cls_head_fwd": (I, [P, P, P, F, P, P, P, P, P, P, I, I, I, I, P]),
+    "srhip_cls_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "srhip_cast_scale_rows": (I, [P, P, I, P, L, I, P]),
+    "srhip_transpose_to_bf16": (I, [P, I, I, P, I, I, I, I, I, P, P]),
+    "srhip_cast_f32_bf16": (I, [P, P, L, P]),
+    "srhip_droppath_fill": (I, [P, P, I, I, c_ulonglong, P]),
+    "srhip_row_max": (I, [P, I, P, P, P, I, I, P]),
+    "srhip_flexmatch_mask": (I, [P, P, P, F, P, P, P, P, I, I, I, I, P]),
+    "srhip_flexmatch_rebuild_hist": (I, [P, P, I, I, P]),
+    "srhip_fixed_mask": (I, [P, F, P, I, P]),
+    "srhip_reward_mask2": (I, [P, P, P, I, I, P]),
+    "srhip_masked_ce": (I, [P, P, P, P, F, P, P, I, I, P]),
+    "srhip_rewarder_param_count": (L, [I, I]),
+    "srhip_rewarder_ws_floats": (L, [I, I]),
+    "srhip_generator_param_count": (L, [I]),
+    "srhip_rewarder_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_rewarder_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "srhip_generator_fwd": (I, [P, P, P, P, I, I, P]),
+    "srhip_sr_target": (I, [P, P, P, I, P]),
+    "srhip_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P]),
+    "srhip_adamw_flat": (I, [P, P, P, P, P, P, P, I, P, P, F, F, F, F, I, F, F, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "semireward_amd: %s is missing -- the HIP extension is the only compute path. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError here == header / library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError("libsrhip: %s failed with code %d%s" % (
+            name, rc, " (invalid argument)" if rc == -1 else " (hip launch error %d)" % (-rc - 2)))

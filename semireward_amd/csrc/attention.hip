@@ -1,0 +1,365 @@
+// Fused multi-head self-attention (head_dim = 64), forward and backward, bf16 MFMA.
+//
+// Replaces reference semilearn/nets/vit/vit.py:100-104 (K4 in SURVEY.md 2c):
+//     attn = softmax((q @ k^T) * scale);  x = (attn @ v).transpose(1,2).reshape(B,N,C)
+// The reference materialises attn[B,H,N,N] in fp32 (38 MB / layer at Bt=24); here one
+// workgroup owns one (image, head): K and V^T of the head live in LDS, every wave walks
+// 16-query tiles, keeps the whole (padded) score row-set in registers, does the softmax with
+// two cross-lane shuffles, and feeds P straight back into the PV MFMA.  Nothing N x N ever
+// touches HBM.  Sequence lengths of the reference are short and fixed (257/197/199/<=512).
+//
+// MFMA layout facts used (16x16x32 bf16; lane l: l15 = l&15, g = l>>4):
+//   a-operand: row l15 of the 16 x 32 "A" tile, k-slots 8g..8g+7    (8 bf16 = 16 B)
+//   b-operand: col l15 of the 32 x 16 "B" tile, k-slots 8g..8g+7
+//   result   : D[4g + r][l15], r = 0..3
+// All products below are arranged so that (i) both operands are contiguous along the
+// reduction index, and (ii) the score tile S^T[key][query] comes out with the QUERY on l15:
+// the softmax statistics of a lane then belong to one query, and the 4 result registers of a
+// score tile (4 consecutive keys) are directly k-slots of the next MFMA's b-operand.
+// qkv layout: [B*N, 3*D] row-major (q | k | v, head-major inside each third) exactly as the
+// qkv Linear writes it (vit.py:93-98) -- no permute kernel.
+#include <type_traits>
+
+#include "common.h"
+#include "srhip.h"
+
+namespace {
+
+constexpr int HD = 64;        // head dim
+constexpr int KPAD = 72;      // row pitch (elements) of row-major [key][64] LDS tiles
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x4_t mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ s16x8_t ld16(const bf16_t* p) { return *reinterpret_cast<const s16x8_t*>(p); }
+
+// two 8-byte LDS reads -> one 8 x bf16 operand (k-slots 0-3 from p0, 4-7 from p1)
+__device__ __forceinline__ s16x8_t ld8x2(const bf16_t* p0, const bf16_t* p1) {
+  const uint2 a = *reinterpret_cast<const uint2*>(p0);
+  const uint2 b = *reinterpret_cast<const uint2*>(p1);
+  uint4 r = {a.x, a.y, b.x, b.y};
+  return __builtin_bit_cast(s16x8_t, r);
+}
+
+__device__ __forceinline__ s16x8_t pack8(const float* lo, const float* hi) {
+  uint4 r = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+  return __builtin_bit_cast(s16x8_t, r);
+}
+
+// Stage rows [0,N) of a [N][64] bf16 slice (row stride ld elements) into row-major LDS (pitch KPAD),
+// zero-filling rows [N, NP).
+__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, int ld, int N, int NP, int tid, int nthr) {
+  for (int c = tid; c < NP * 8; c += nthr) {
+    const int row = c >> 3, slot = c & 7;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (row < N) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + slot * 8);
+    *reinterpret_cast<uint4*>(dst + row * KPAD + slot * 8) = v;
+  }
+}
+
+// Stage the TRANSPOSE of a [N][64] slice into LDS as dst[d][row] (pitch TP), two rows per 32-bit write.
+__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, int ld, int N, int NP, int TP, int tid, int nthr) {
+  const int pairs = NP >> 1;
+  for (int c = tid; c < pairs * 8; c += nthr) {
+    const int pr = c % pairs, slot = c / pairs;
+    const int r0 = 2 * pr, r1 = r0 + 1;
+    uint4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+    if (r0 < N) a = *reinterpret_cast<const uint4*>(src + (size_t)r0 * ld + slot * 8);
+    if (r1 < N) b = *reinterpret_cast<const uint4*>(src + (size_t)r1 * ld + slot * 8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = (aw[j] & 0xffffu) | (bw[j] << 16);
+      const uint32_t hi = (aw[j] >> 16) | (bw[j] & 0xffff0000u);
+      *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j) * TP + r0) = lo;
+      *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j + 1) * TP + r0) = hi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid = B*H workgroups of 256 threads.  NKT = number of 16-key tiles (even), NP = 16*NKT.
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                      float* __restrict__ lse, int N, int H, float scale) {
+  constexpr int NP = NKT * 16, TP = NP + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][KPAD]
+  bf16_t* Vt = Ks + NP * KPAD;                        // [64][TP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+  stage_rows(Ks, base + D, ld, N, NP, tid, 256);
+  stage_transposed(Vt, base + 2 * D, ld, N, NP, TP, tid, 256);
+  __syncthreads();
+  const float sc2 = scale * LOG2E;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + l15, qc = min(q, N - 1);
+    const bf16_t* qp = base + (size_t)qc * ld + g * 8;
+    const s16x8_t q0 = ld16(qp), q1 = ld16(qp + 32);
+    f32x4_t s[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const bf16_t* kp = Ks + (t * 16 + l15) * KPAD + g * 8;
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+      a = mfma16(ld16(kp), q0, a);
+      a = mfma16(ld16(kp + 32), q1, a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + g * 4 + r;
+        a[r] = key < N ? a[r] * sc2 : -INFINITY;
+        mx = fmaxf(mx, a[r]);
+      }
+      s[t] = a;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(s[t][r] - mx);
+        s[t][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      float lo[4] = {s[2 * u][0], s[2 * u][1], s[2 * u][2], s[2 * u][3]};
+      float hi[4] = {s[2 * u + 1][0], s[2 * u + 1][1], s[2 * u + 1][2], s[2 * u + 1][3]};
+      const s16x8_t pb = pack8(lo, hi);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t* vp = Vt + (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
+        o[dt] = mfma16(ld8x2(vp, vp + 16), pb, o[dt]);
+      }
+    }
+    if (q < N) {
+      const float inv = 1.0f / sum;
+      bf16_t* op = out + ((size_t)b * N + q) * D + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 v = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
+        *reinterpret_cast<uint2*>(op + dt * 16) = v;
+      }
+      if (lse && g == 0) lse[((size_t)b * H + h) * N + q] = (mx + log2f(sum)) * LN2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: dQ.  One workgroup per (image, head); wave walks 16-query tiles.
+//   S^T, dP^T (query on l15) per key-tile pair -> P, dS (bf16) -> dQ^T[d][q] += K^T[d][keys] . dS^T[keys][q]
+// delta[q] = rowsum(dO[q] * O[q]) is computed in-kernel from the saved forward output.
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+                                                         const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
+                                                         bf16_t* __restrict__ dqkv, float* __restrict__ delta,
+                                                         int N, int H, float scale) {
+  constexpr int NP = NKT * 16, TP = NP + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][KPAD]
+  bf16_t* Vs = Ks + NP * KPAD;                        // [NP][KPAD]
+  bf16_t* Kt = Vs + NP * KPAD;                        // [64][TP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+  stage_rows(Ks, base + D, ld, N, NP, tid, 256);
+  stage_rows(Vs, base + 2 * D, ld, N, NP, tid, 256);
+  stage_transposed(Kt, base + D, ld, N, NP, TP, tid, 256);
+  __syncthreads();
+  const float sc2 = scale * LOG2E;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + l15, qc = min(q, N - 1);
+    const bf16_t* qp = base + (size_t)qc * ld + g * 8;
+    const s16x8_t q0 = ld16(qp), q1 = ld16(qp + 32);
+    const bf16_t* dop = d_out + ((size_t)b * N + qc) * D + h * HD + g * 8;
+    const bf16_t* op = o_fwd + ((size_t)b * N + qc) * D + h * HD + g * 8;
+    const s16x8_t do0 = ld16(dop), do1 = ld16(dop + 32);
+    // delta[q]: this lane holds d-slots 8g..8g+7 and 32+8g.. of row q
+    float dl = 0.f;
+    {
+      const s16x8_t o0 = ld16(op), o1 = ld16(op + 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        dl += bf2f((bf16_t)do0[j]) * bf2f((bf16_t)o0[j]) + bf2f((bf16_t)do1[j]) * bf2f((bf16_t)o1[j]);
+      dl += __shfl_xor(dl, 16, 64);
+      dl += __shfl_xor(dl, 32, 64);
+    }
+    const float lse2 = lse[((size_t)b * H + h) * N + qc] * LOG2E;
+    if (q < N && g == 0) delta[((size_t)b * H + h) * N + q] = dl;
+    f32x4_t dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u = 0; u < NKT / 2; ++u) {
+      float ds[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int t = 2 * u + e;
+        const bf16_t* kp = Ks + (t * 16 + l15) * KPAD + g * 8;
+        const bf16_t* vp = Vs + (t * 16 + l15) * KPAD + g * 8;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma16(ld16(kp), q0, s);
+        s = mfma16(ld16(kp + 32), q1, s);
+        dp = mfma16(ld16(vp), do0, dp);
+        dp = mfma16(ld16(vp + 32), do1, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * 16 + g * 4 + r;
+          const float p = key < N ? exp2f(s[r] * sc2 - lse2) : 0.f;
+          ds[e][r] = p * (dp[r] - dl) * scale;
+        }
+      }
+      const s16x8_t dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t* ktp = Kt + (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
+        dq[dt] = mfma16(ld8x2(ktp, ktp + 16), dsb, dq[dt]);
+      }
+    }
+    if (q < N) {
+      bf16_t* dqp = dqkv + ((size_t)b * N + q) * ld + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 v = {pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3])};
+        *reinterpret_cast<uint2*>(dqp + dt * 16) = v;
+      }
+    }
+  }
+}
+
+// backward, part 2: dK, dV.  One workgroup per (image, head); each wave owns 16-key tiles and
+// walks query-tile pairs:  S[q][key], dP[q][key] with the KEY on l15 ->
+//   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int NP = NKT * 16, TP = NP + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]
+  bf16_t* dOt = Qt + 64 * TP;                         // [64][TP]
+  float* lse_s = reinterpret_cast<float*>(dOt + 64 * TP);   // [NP]  (already * log2e)
+  float* dl_s = lse_s + NP;                                 // [NP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+  const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
+  stage_transposed(Qt, base, ld, N, NP, TP, tid, 256);
+  stage_transposed(dOt, dobase, D, N, NP, TP, tid, 256);
+  for (int i = tid; i < NP; i += 256) {
+    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : 0.f;
+    dl_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
+  }
+  __syncthreads();
+  const float sc2 = scale * LOG2E;
+  for (int kt = wave; kt < NKT; kt += 4) {
+    const int key = kt * 16 + l15, kc = min(key, N - 1);
+    if (kt * 16 >= N) break;
+    const bf16_t* kp = base + D + (size_t)kc * ld + g * 8;
+    const bf16_t* vp = base + 2 * D + (size_t)kc * ld + g * 8;
+    const s16x8_t k0 = ld16(kp), k1 = ld16(kp + 32), v0 = ld16(vp), v1 = ld16(vp + 32);
+    f32x4_t dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int u = 0; u < NKT / 2; ++u) {
+      float pp[2][4], ds[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int qrow = (2 * u + e) * 16 + l15, qc = min(qrow, N - 1);
+        const bf16_t* qp = base + (size_t)qc * ld + g * 8;
+        const bf16_t* dop = dobase + (size_t)qc * D + g * 8;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma16(ld16(qp), k0, s);            // a-operand rows = queries, b-operand cols = keys
+        s = mfma16(ld16(qp + 32), k1, s);
+        dp = mfma16(ld16(dop), v0, dp);
+        dp = mfma16(ld16(dop + 32), v1, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = (2 * u + e) * 16 + g * 4 + r;      // result row = query
+          const float p = (qq < N && key < N) ? exp2f(s[r] * sc2 - lse_s[qq]) : 0.f;
+          pp[e][r] = p;
+          ds[e][r] = p * (dp[r] - dl_s[qq]) * scale;
+        }
+      }
+      const s16x8_t pb = pack8(pp[0], pp[1]), dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int off = (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
+        dv[dt] = mfma16(ld8x2(dOt + off, dOt + off + 16), pb, dv[dt]);
+        dk[dt] = mfma16(ld8x2(Qt + off, Qt + off + 16), dsb, dk[dt]);
+      }
+    }
+    if (key < N) {
+      bf16_t* dkp = dqkv + ((size_t)b * N + key) * ld + D + h * HD + g * 4;
+      bf16_t* dvp = dkp + D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 a = {pack_bf2(dk[dt][0], dk[dt][1]), pack_bf2(dk[dt][2], dk[dt][3])};
+        uint2 c = {pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3])};
+        *reinterpret_cast<uint2*>(dkp + dt * 16) = a;
+        *reinterpret_cast<uint2*>(dvp + dt * 16) = c;
+      }
+    }
+  }
+}
+
+template <typename F>
+int dispatch_nkt(int N, F&& f) {
+  const int nkt = 2 * ((N + 31) / 32);
+  if (nkt <= 2) return f(std::integral_constant<int, 2>());
+  if (nkt <= 8) return f(std::integral_constant<int, 8>());
+  if (nkt <= 14) return f(std::integral_constant<int, 14>());
+  if (nkt <= 18) return f(std::integral_constant<int, 18>());
+  if (nkt <= 32) return f(std::integral_constant<int, 32>());
+  return SR_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || N > 512) return SR_EINVAL;
+  return dispatch_nkt(N, [&](auto nk) -> int {
+    constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
+    const size_t sm = (size_t)NP * KPAD * 2 + (size_t)64 * (NP + 8) * 2;
+    auto kern = attn_fwd_kernel<NKT>;
+    if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  });
+}
+
+extern "C" int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv,
+                              float* delta_ws, int B, int N, int H, float scale, void* stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || N > 512 || !lse || !delta_ws) return SR_EINVAL;
+  return dispatch_nkt(N, [&](auto nk) -> int {
+    constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
+    const size_t sm1 = (size_t)2 * NP * KPAD * 2 + (size_t)64 * (NP + 8) * 2;
+    const size_t sm2 = (size_t)2 * 64 * (NP + 8) * 2 + (size_t)2 * NP * 4;
+    if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;   // N > 288 backward: not in this round's scope
+    auto k1 = attn_bwd_dq_kernel<NKT>;
+    auto k2 = attn_bwd_dkv_kernel<NKT>;
+    if (sm1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    if (sm2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+    hipLaunchKernelGGL(k1, dim3(B * H), dim3(256), sm1, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale);
+    SR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k2, dim3(B * H), dim3(256), sm2, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)d_out, lse,
+                       (const float*)delta_ws, (bf16_t*)dqkv, N, H, scale);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  });
+}

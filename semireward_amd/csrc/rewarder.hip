@@ -1,0 +1,427 @@
+// SemiReward Rewarder / Generator: forward, hand-written backward, Adam.
+//
+// Reference (math restated in SURVEY.md Appendix D):
+//   Rewarder.forward   semilearn/algorithms/semireward/semireward.py:52-72
+//   Generator.forward  semilearn/algorithms/semireward/semireward.py:21-24  (+ .long() srflexmatch.py:158-159)
+//   SR update block    semilearn/algorithms/srflexmatch/srflexmatch.py:180-208  (two MSE losses, two backward(),
+//                      Adam(lr=sr_lr) -- the generator's step is a no-op: its graph is cut by .long())
+//
+// Everything is fp32 (136 962 parameters, batches of 8..256 rows): latency-bound, so the design is
+// "one wave per row, activations in LDS, weights streamed coalesced from L2, wave-shuffle reductions"
+// and -- the part that matters for the K-pass scoring loop -- ALL independent groups (the K passes of
+// one training step, each with its own softmax over its 2B rows) go through ONE launch.
+// Parameter block: flat fp32 in the reference's named_parameters() order (offsets in RewOff).
+#include "common.h"
+#include "srhip.h"
+
+namespace {
+
+constexpr int E = 128;  // embedding / hidden width fixed by the reference (semireward.py:34,37,41)
+
+struct RewOff {
+  int Wf, bf, gf, bef, Emb, gl, bl, wa, ba, W1, b1, W2, b2, W3, b3, w4, b4, total;
+  __host__ __device__ RewOff(int F, int L) {
+    int o = 0;
+    Wf = o; o += E * F; bf = o; o += E; gf = o; o += E; bef = o; o += E;
+    Emb = o; o += L * E; gl = o; o += E; bl = o; o += E;
+    wa = o; o += E; ba = o; o += 1;
+    W1 = o; o += 256 * E; b1 = o; o += 256; W2 = o; o += E * 256; b2 = o; o += E;
+    W3 = o; o += 64 * E; b3 = o; o += 64; w4 = o; o += 64; b4 = o; o += 1;
+    total = o;
+  }
+};
+
+// workspace layout (floats) for one call with G groups of B rows; R = G*B
+struct RewWs {
+  size_t z, slog, alpha, ctx, xhat, rstd, u, m1, m2, f1, r, dlogit, df1, dm2, dm1, du, dz, total;
+  __host__ __device__ RewWs(size_t G, size_t B) {
+    const size_t R = G * B;
+    size_t o = 0;
+    z = o; o += 2 * R * E; slog = o; o += 2 * R; alpha = o; o += 2 * R; ctx = o; o += G * E;
+    xhat = o; o += 2 * R * E; rstd = o; o += 2 * R;
+    u = o; o += R * E; m1 = o; o += R * 256; m2 = o; o += R * E; f1 = o; o += R * 64; r = o; o += R;
+    dlogit = o; o += R; df1 = o; o += R * 64; dm2 = o; o += R * E; dm1 = o; o += R * 256; du = o; o += R * E;
+    dz = o; o += 2 * R * E;
+    total = o;
+  }
+};
+
+// LDS hand-off between lanes of ONE wave: DS ops of a wave retire in issue order, so only the compiler
+// has to be kept from moving accesses across the hand-off point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// y[j] = act( sum_k x[k] * W[j*K + k] + b[j] ), x and y in LDS owned by this wave.  ACT: 0 none, 1 relu
+template <int ACT>
+__device__ __forceinline__ void wave_linear(const float* __restrict__ W, const float* __restrict__ b, const float* x, float* y,
+                                            int J, int K, int lane) {
+  for (int j = 0; j < J; ++j) {
+    const float* w = W + (size_t)j * K;
+    float a = 0.f;
+    for (int k = lane; k < K; k += 64) a += x[k] * w[k];
+    a = wave_sum(a);
+    if (lane == 0) { a += b[j]; y[j] = (ACT == 1) ? fmaxf(a, 0.f) : a; }
+  }
+  wave_lds_sync();
+}
+
+// 128-wide LayerNorm of the two values per lane (j = lane, lane + 64); eps 1e-5 (nn.LayerNorm default)
+__device__ __forceinline__ void wave_ln128(float v0, float v1, const float* g, const float* b, int lane, float& o0, float& o1,
+                                           float& xh0, float& xh1, float& rs) {
+  const float mu = wave_sum(v0 + v1) * (1.0f / E);
+  const float a = v0 - mu, c = v1 - mu;
+  rs = 1.0f / sqrtf(wave_sum(a * a + c * c) * (1.0f / E) + 1e-5f);
+  xh0 = a * rs; xh1 = c * rs;
+  o0 = xh0 * g[lane] + b[lane];
+  o1 = xh1 * g[lane + 64] + b[lane + 64];
+}
+
+// Kernel 1: rows 0..B-1 of a group = feature rows, B..2B-1 = label rows.  One wave per row.
+// grid = (ceil(2B/4), G), block 256.
+__global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict__ P, const float* __restrict__ feats,
+                                                       const long long* __restrict__ labels, float* __restrict__ ws,
+                                                       int G, int B, int F, int L, int save) {
+  const RewOff o(F, L);
+  const RewWs w(G, B);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave, grp = blockIdx.y;
+  if (row >= 2 * B) return;
+  float v0, v1;
+  const float *gam, *bet;
+  if (row < B) {
+    const float* x = feats + ((size_t)grp * B + row) * F;
+    float xr[16];                                   // F <= 1024
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xr[i] = (i * 64 + lane < F) ? x[i * 64 + lane] : 0.f;
+    v0 = 0.f; v1 = 0.f;
+    for (int j = 0; j < E; ++j) {
+      const float* wr = P + o.Wf + (size_t)j * F;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i * 64 < F) a += (i * 64 + lane < F) ? xr[i] * wr[i * 64 + lane] : 0.f;
+      a = wave_sum(a) + P[o.bf + j];
+      if ((j & 63) == lane) { if (j < 64) v0 = a; else v1 = a; }
+    }
+    gam = P + o.gf; bet = P + o.bef;
+  } else {
+    const long long y = labels[(size_t)grp * B + (row - B)];
+    const float* e = P + o.Emb + (size_t)y * E;
+    v0 = e[lane]; v1 = e[lane + 64];
+    gam = P + o.gl; bet = P + o.bl;
+  }
+  float z0, z1, xh0, xh1, rs;
+  wave_ln128(v0, v1, gam, bet, lane, z0, z1, xh0, xh1, rs);
+  const size_t zr = ((size_t)grp * 2 * B + row);
+  ws[w.z + zr * E + lane] = z0;
+  ws[w.z + zr * E + lane + 64] = z1;
+  const float s = wave_sum(z0 * P[o.wa + lane] + z1 * P[o.wa + lane + 64]) + P[o.ba];
+  if (lane == 0) ws[w.slog + zr] = s;
+  if (save) {
+    ws[w.xhat + zr * E + lane] = xh0;
+    ws[w.xhat + zr * E + lane + 64] = xh1;
+    if (lane == 0) ws[w.rstd + zr] = rs;
+  }
+}
+
+// Kernel 2: softmax over the group's 2B logits, context vector, then the per-row MLP/FFN head.
+// grid = (ceil(B/4), G), block 256 (one wave per row).  Every workgroup re-derives the group context
+// (2B x 128 reads) instead of paying a third launch.
+__global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict__ P, float* __restrict__ ws, float* __restrict__ reward,
+                                                       int G, int B, int F, int L, int save) {
+  const RewOff o(F, L);
+  const RewWs w(G, B);
+  __shared__ float ctx[E];
+  __shared__ float red[8];
+  __shared__ float buf[4][E + 256 + E + 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = blockIdx.y;
+  const float* sl = ws + w.slog + (size_t)grp * 2 * B;
+  const float* z = ws + w.z + (size_t)grp * 2 * B * E;
+  // --- softmax statistics over 2B rows (fixed reduction order)
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < 2 * B; i += 256) mx = fmaxf(mx, sl[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int i = threadIdx.x; i < 2 * B; i += 256) se += expf(sl[i] - mx);
+  se = wave_sum(se);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  // --- ctx[j] = sum_i alpha_i z[i][j]; threads 0..127 own a column, 128..255 help on the odd rows
+  {
+    const int j = threadIdx.x & (E - 1), half = threadIdx.x >> 7;
+    float a = 0.f;
+    for (int i = half; i < 2 * B; i += 2) a += expf(sl[i] - mx) * inv * z[(size_t)i * E + j];
+    if (half == 1) buf[0][j] = a;
+    __syncthreads();
+    if (half == 0) ctx[j] = a + buf[0][j];
+    __syncthreads();
+  }
+  if (save && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < 2 * B; i += 256) ws[w.alpha + (size_t)grp * 2 * B + i] = expf(sl[i] - mx) * inv;
+    if (threadIdx.x < E) ws[w.ctx + (size_t)grp * E + threadIdx.x] = ctx[threadIdx.x];
+  }
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= B) return;
+  float* u = buf[wave];
+  float* m1 = u + E;
+  float* m2 = m1 + 256;
+  float* f1 = m2 + E;
+  const float* e = z + (size_t)(B + row) * E;
+  u[lane] = e[lane] + ctx[lane];
+  u[lane + 64] = e[lane + 64] + ctx[lane + 64];
+  wave_lds_sync();
+  wave_linear<1>(P + o.W1, P + o.b1, u, m1, 256, E, lane);
+  wave_linear<0>(P + o.W2, P + o.b2, m1, m2, E, 256, lane);
+  wave_linear<1>(P + o.W3, P + o.b3, m2, f1, 64, E, lane);
+  const float lg = wave_sum(f1[lane] * P[o.w4 + lane]) + P[o.b4];
+  const float r = 1.0f / (1.0f + expf(-lg));
+  const size_t gr = (size_t)grp * B + row;
+  if (lane == 0) reward[gr] = r;
+  if (save) {
+    ws[w.u + gr * E + lane] = u[lane]; ws[w.u + gr * E + lane + 64] = u[lane + 64];
+    for (int j = lane; j < 256; j += 64) ws[w.m1 + gr * 256 + j] = m1[j];
+    ws[w.m2 + gr * E + lane] = m2[lane]; ws[w.m2 + gr * E + lane + 64] = m2[lane + 64];
+    ws[w.f1 + gr * 64 + lane] = f1[lane];
+    if (lane == 0) ws[w.r + gr] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward (single group, G = 1).  Step A, one wave per row: dL/dreward -> dlogit, df1, dm2, dm1, du.
+//   dL/dr_b = (2/B) * [(r_b - 1) + (r_b - t_b)]          (MSE(r,1) + MSE(r,t), both into the rewarder)
+__global__ __launch_bounds__(256) void rew_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ ws,
+                                                          const float* __restrict__ target, float* __restrict__ losses,
+                                                          int B, int F, int L) {
+  const RewOff o(F, L);
+  const RewWs w(1, B);
+  __shared__ float buf[4][64 + E + 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wave;
+  if (row >= B) return;
+  float* df1 = buf[wave];
+  float* dm2 = df1 + 64;
+  float* dm1 = dm2 + E;
+  const float r = ws[w.r + row], t = target[row];
+  const float dr = (2.0f / (float)B) * ((r - 1.0f) + (r - t));
+  const float dlg = dr * r * (1.0f - r);
+  if (lane == 0) ws[w.dlogit + row] = dlg;
+  // df1 = dlg * w4 * relu'(f1)
+  {
+    const float f = ws[w.f1 + (size_t)row * 64 + lane];
+    const float d = f > 0.f ? dlg * P[o.w4 + lane] : 0.f;
+    df1[lane] = d;
+    ws[w.df1 + (size_t)row * 64 + lane] = d;
+  }
+  wave_lds_sync();
+  // dm2[k] = sum_j df1[j] W3[j,k]
+  for (int k = lane; k < E; k += 64) {
+    float a = 0.f;
+    for (int j = 0; j < 64; ++j) a += df1[j] * P[o.W3 + (size_t)j * E + k];
+    dm2[k] = a;
+    ws[w.dm2 + (size_t)row * E + k] = a;
+  }
+  wave_lds_sync();
+  // dm1[k] = relu'(m1[k]) * sum_j dm2[j] W2[j,k]
+  for (int k = lane; k < 256; k += 64) {
+    float a = 0.f;
+    for (int j = 0; j < E; ++j) a += dm2[j] * P[o.W2 + (size_t)j * 256 + k];
+    a = ws[w.m1 + (size_t)row * 256 + k] > 0.f ? a : 0.f;
+    dm1[k] = a;
+    ws[w.dm1 + (size_t)row * 256 + k] = a;
+  }
+  wave_lds_sync();
+  // du[k] = sum_j dm1[j] W1[j,k]
+  for (int k = lane; k < E; k += 64) {
+    float a = 0.f;
+    for (int j = 0; j < 256; ++j) a += dm1[j] * P[o.W1 + (size_t)j * E + k];
+    ws[w.du + (size_t)row * E + k] = a;
+  }
+  (void)losses;
+}
+
+// Step B, ONE workgroup of 128 threads (thread j owns column j of the 128-wide vectors):
+//   dc = sum_b du_b ; ds_i = alpha_i * ((z_i - c) . dc) ; dz_i = alpha_i * dc + ds_i * wa (+ du for label rows)
+//   d(wa) = sum_i ds_i z_i ;  d(ba) = 0 exactly (cancels in the softmax)
+//   then LayerNorm backward of every row -> d(pre) written IN PLACE over dz, d(gamma/beta) for both norms,
+//   and the MSE losses.
+__global__ __launch_bounds__(128) void rew_bwd_ctx_kernel(const float* __restrict__ P, float* __restrict__ ws, float* __restrict__ G_,
+                                                         const float* __restrict__ target, float* __restrict__ losses,
+                                                         int B, int F, int L) {
+  const RewOff o(F, L);
+  const RewWs w(1, B);
+  __shared__ float sh[2];
+  const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
+  auto bsum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    return sh[0] + sh[1];
+  };
+  float dc = 0.f;
+  for (int b = 0; b < B; ++b) dc += ws[w.du + (size_t)b * E + j];
+  const float c = ws[w.ctx + j], wa = P[o.wa + j];
+  float dwa = 0.f, dgf = 0.f, dbf = 0.f, dgl = 0.f, dbl = 0.f;
+  for (int i = 0; i < 2 * B; ++i) {
+    const float zi = ws[w.z + (size_t)i * E + j], al = ws[w.alpha + i];
+    const float ds = al * bsum((zi - c) * dc);
+    dwa += ds * zi;
+    float dz = al * dc + ds * wa;
+    if (i >= B) dz += ws[w.du + (size_t)(i - B) * E + j];
+    // LayerNorm backward of row i (gamma of the matching norm)
+    const float gam = i < B ? P[o.gf + j] : P[o.gl + j];
+    const float xh = ws[w.xhat + (size_t)i * E + j], rs = ws[w.rstd + i];
+    const float gy = dz * gam;
+    const float c1 = bsum(gy) * (1.0f / E), c2 = bsum(gy * xh) * (1.0f / E);
+    ws[w.dz + (size_t)i * E + j] = rs * (gy - c1 - xh * c2);
+    if (i < B) { dgf += dz * xh; dbf += dz; } else { dgl += dz * xh; dbl += dz; }
+  }
+  G_[o.wa + j] = dwa;
+  if (j == 0) G_[o.ba] = 0.f;
+  G_[o.gf + j] = dgf; G_[o.bef + j] = dbf; G_[o.gl + j] = dgl; G_[o.bl + j] = dbl;
+  if (losses) {
+    float lg = 0.f, lr = 0.f;
+    for (int b = j; b < B; b += 128) {
+      const float r = ws[w.r + b], t = target[b];
+      lg += (r - 1.0f) * (r - 1.0f);
+      lr += (r - t) * (r - t);
+    }
+    lg = bsum(lg); lr = bsum(lr);
+    if (j == 0) { losses[0] = lg / (float)B; losses[1] = lr / (float)B; }
+  }
+}
+
+// Step C: dW[j,k] = sum_b dY[b,j] X[b,k] (+ db[j] = sum_b dY[b,j]).  grid = J, block = 256 over k.
+__global__ void small_dw_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, float* __restrict__ dW,
+                                float* __restrict__ db, int B, int K) {
+  const int j = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dY[(size_t)b * ldy + j] * X[(size_t)b * ldx + k];
+    dW[(size_t)j * K + k] = a;
+  }
+  if (db && threadIdx.x == 0) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dY[(size_t)b * ldy + j];
+    db[j] = a;
+  }
+}
+
+// Step D: label-embedding gradient, dEmb[y_b] += d(e_pre)_b  (duplicates -> atomics).  grid = B, block = 128
+__global__ void rew_emb_scatter_kernel(const float* __restrict__ dpre, const long long* __restrict__ labels, float* __restrict__ dEmb) {
+  const int b = blockIdx.x;
+  atomicAdd(dEmb + (size_t)labels[b] * E + threadIdx.x, dpre[(size_t)b * E + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generator: relu(L4(relu(L3(relu(L2(relu(L1 x))))))) -> (float, int64 label).  One wave per row.
+__global__ __launch_bounds__(256) void generator_kernel(const float* __restrict__ P, const float* __restrict__ x, float* __restrict__ out,
+                                                       long long* __restrict__ label, int B, int F) {
+  __shared__ float buf[4][1024 + 256 + 128 + 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wave;
+  if (row >= B) return;
+  float* x0 = buf[wave];
+  float* h1 = x0 + 1024;
+  float* h2 = h1 + 256;
+  float* h3 = h2 + 128;
+  for (int k = lane; k < F; k += 64) x0[k] = x[(size_t)row * F + k];
+  wave_lds_sync();
+  int off = 0;
+  const float* W1 = P + off; off += 256 * F; const float* b1 = P + off; off += 256;
+  const float* W2 = P + off; off += 128 * 256; const float* b2 = P + off; off += 128;
+  const float* W3 = P + off; off += 64 * 128; const float* b3 = P + off; off += 64;
+  const float* W4 = P + off; off += 64; const float* b4 = P + off;
+  wave_linear<1>(W1, b1, x0, h1, 256, F, lane);
+  wave_linear<1>(W2, b2, h1, h2, 128, 256, lane);
+  wave_linear<1>(W3, b3, h2, h3, 64, 128, lane);
+  const float v = fmaxf(wave_sum(h3[lane] * W4[lane]) + b4[0], 0.f);
+  if (lane == 0) { out[row] = v; label[row] = (long long)v; }   // .long(): truncation toward zero
+}
+
+// target_b = 1.0 if gen_b == ref_b else 0.5   ( (cos(one_hot, one_hot) + 1) / 2, srflexmatch.py:180-182 )
+__global__ void sr_target_kernel(const long long* __restrict__ gen, const long long* __restrict__ ref, float* __restrict__ target, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) target[i] = gen[i] == ref[i] ? 1.0f : 0.5f;
+}
+
+// torch.optim.Adam, flat fp32 block (betas 0.9/0.999, eps 1e-8, no weight decay)
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+
+}  // namespace
+
+extern "C" long srhip_rewarder_param_count(int F, int L) { return RewOff(F, L).total; }
+extern "C" long srhip_rewarder_ws_floats(int G, int B) { return (long)RewWs(G, B).total; }
+extern "C" long srhip_generator_param_count(int F) { return 256L * F + 256 + 128 * 256 + 128 + 64 * 128 + 64 + 64 + 1; }
+
+extern "C" int srhip_rewarder_fwd(const float* params, const float* feats, const long long* labels, float* reward, float* ws,
+                                  int G, int B, int F, int L, int save_for_bwd, void* stream) {
+  if (G <= 0 || B <= 0 || F <= 0 || F > 1024 || L <= 0 || (save_for_bwd && G != 1)) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rew_embed_kernel, dim3(cdiv(2 * B, 4), G), dim3(256), 0, s, params, feats, labels, ws, G, B, F, L, save_for_bwd);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rew_score_kernel, dim3(cdiv(B, 4), G), dim3(256), 0, s, params, ws, reward, G, B, F, L, save_for_bwd);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+// grads: flat block, same layout as params, fully overwritten (== zero_grad + the two backward() calls).
+extern "C" int srhip_rewarder_bwd(const float* params, const float* feats, const long long* labels, const float* target, float* ws,
+                                  float* grads, float* losses, int B, int F, int L, void* stream) {
+  if (B <= 0 || F <= 0 || F > 1024 || L <= 0) return SR_EINVAL;
+  const RewOff o(F, L);
+  const RewWs w(1, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grads + o.Emb, 0, (size_t)L * E * sizeof(float), s) != hipSuccess) return SR_ELAUNCH;
+  hipLaunchKernelGGL(rew_bwd_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, params, ws, target, losses, B, F, L);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rew_bwd_ctx_kernel, dim3(1), dim3(128), 0, s, params, ws, grads, target, losses, B, F, L);
+  SR_CHECK_LAUNCH();
+  // weight gradients of the per-row head
+  hipLaunchKernelGGL(small_dw_kernel, dim3(1), dim3(64), 0, s, ws + w.dlogit, 1, ws + w.f1, 64, grads + o.w4, grads + o.b4, B, 64);
+  hipLaunchKernelGGL(small_dw_kernel, dim3(64), dim3(128), 0, s, ws + w.df1, 64, ws + w.m2, E, grads + o.W3, grads + o.b3, B, E);
+  hipLaunchKernelGGL(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dm2, E, ws + w.m1, 256, grads + o.W2, grads + o.b2, B, 256);
+  hipLaunchKernelGGL(small_dw_kernel, dim3(256), dim3(128), 0, s, ws + w.dm1, 256, ws + w.u, E, grads + o.W1, grads + o.b1, B, E);
+  // feature_fc: d(pre) of the B feature rows sits in dz rows [0,B); label rows [B,2B) feed the embedding
+  hipLaunchKernelGGL(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dz, E, feats, F, grads + o.Wf, grads + o.bf, B, F);
+  hipLaunchKernelGGL(rew_emb_scatter_kernel, dim3(B), dim3(E), 0, s, ws + w.dz + (size_t)B * E, labels, grads + o.Emb);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_generator_fwd(const float* params, const float* x, float* out, long long* label, int B, int F, void* stream) {
+  if (B <= 0 || F <= 0 || F > 1024) return SR_EINVAL;
+  hipLaunchKernelGGL(generator_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, params, x, out, label, B, F);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, void* stream) {
+  if (B <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(sr_target_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, gen, ref, target, B);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                               int step, void* stream) {
+  if (n <= 0 || step <= 0) return SR_EINVAL;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, bc1, bc2s);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

@@ -1,0 +1,239 @@
+// The pseudo-label "score filter": softmax / argmax / confidence thresholds / FlexMatch state /
+// reward-mean mask / masked cross-entropy -- everything between the backbone logits and the loss.
+//
+// Reference call sites:
+//   compute_prob (softmax)            semilearn/core/algorithmbase.py:332-333
+//   PseudoLabelingHook (argmax)       semilearn/algorithms/hooks/pseudo_label.py:40
+//   FixedThresholdingHook.masking     semilearn/algorithms/hooks/masking.py:42-57
+//   FlexMatchThresholdingHook         semilearn/algorithms/srflexmatch/utils.py:24-63
+//   mask2 = reward >= reward.mean()   semilearn/algorithms/srflexmatch/srflexmatch.py:100-101
+//   ce_loss / consistency_loss        semilearn/core/criterions/cross_entropy.py:11-31, consistency.py:13-45
+//
+// These are latency-bound integer/compare kernels on [Bu, C] with Bu = 8..4096: one wave per row
+// with shuffle reductions, all state on device, no host round trip.  The reference rebuilds the
+// class histogram on the HOST from a 50 000-entry tolist() at every masking call; here the
+// histogram hist[C+1] (last bin = the "-1 / unused" bucket) is maintained incrementally by the
+// scatter itself (old label -> new label), which is bit-identical to a recount.
+// Bit-exactness: the threshold p_cutoff * (acc / (2 - acc)) is evaluated op by op
+// in fp32 with contraction disabled; classwise_acc = (float)((double)cnt / (double)max).
+#include "common.h"
+#include "srhip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// wave-level (value, index) max with first-index tie break (torch.max / argmax semantics)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+// One wave per row.  in_is_probs = 0: logits -> softmax (fp32) ; 1: rows are already probabilities.
+__global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ in, int in_is_probs, float* __restrict__ probs_out,
+                                                     float* __restrict__ max_probs, long long* __restrict__ max_idx, int B, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const float* r = in + (size_t)row * C;
+  float inv = 1.0f, mx = 0.f;
+  if (!in_is_probs) {
+    mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, r[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(r[c] - mx);
+    inv = 1.0f / wave_sum(s);
+  }
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float p = in_is_probs ? r[c] : expf(r[c] - mx) * inv;
+    if (probs_out) probs_out[(size_t)row * C + c] = p;
+    if (p > bv) { bv = p; bi = c; }
+  }
+  wave_argmax(bv, bi);
+  if (lane == 0) { max_probs[row] = bv; max_idx[row] = bi; }
+}
+
+// FlexMatch masking + state update.  ONE workgroup (the step is sequential by definition).
+//   mask[i]   = max_p[i] >= p_cutoff * (acc[idx] / (2 - acc[idx]))          (utils.py:53, BEFORE the update)
+//   select[i] = max_p[i] >= p_cutoff ; selected_label[idx_ulb[i]] = max_idx[i]   (utils.py:56-60)
+//   hist bookkeeping, then classwise_acc update                                (utils.py:24-35)
+__global__ __launch_bounds__(256) void flexmatch_mask_kernel(const float* __restrict__ max_probs, const long long* __restrict__ max_idx,
+                                                            const long long* __restrict__ idx_ulb, float p_cutoff,
+                                                            long long* __restrict__ selected_label, int* __restrict__ hist,
+                                                            float* __restrict__ classwise_acc, float* __restrict__ mask,
+                                                            int B, int C, int ulb_dest_len, int thresh_warmup) {
+  __shared__ int smax[2];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float mp = max_probs[i];
+    const int cls = (int)max_idx[i];
+    const float acc = classwise_acc[cls];
+    const float den = 2.0f - acc;
+    const float rat = acc / den;
+    const float thr = p_cutoff * rat;
+    mask[i] = mp >= thr ? 1.0f : 0.0f;
+    if (mp >= p_cutoff) {
+      const long long j = idx_ulb[i];
+      const long long old = selected_label[j];
+      if (old != cls) {
+        selected_label[j] = cls;
+        atomicSub(hist + (old < 0 ? C : (int)old), 1);
+        atomicAdd(hist + cls, 1);
+      }
+    }
+  }
+  if (threadIdx.x < 2) smax[threadIdx.x] = 0;
+  __threadfence_block();
+  __syncthreads();
+  int m = 0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) m = max(m, __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  atomicMax(&smax[0], m);
+  __syncthreads();
+  if (threadIdx.x == 0) smax[1] = max(smax[0], __hip_atomic_load(hist + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+  const int max_all = smax[1];
+  if (max_all < ulb_dest_len) {
+    const int den = thresh_warmup ? max_all : smax[0];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const int cnt = __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      classwise_acc[c] = (float)((double)cnt / (double)den);
+    }
+  }
+}
+
+// Rebuild hist[C+1] from selected_label (after construction / checkpoint load).
+__global__ void flexmatch_hist_kernel(const long long* __restrict__ selected_label, int* __restrict__ hist, int n, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long v = selected_label[i];
+  atomicAdd(hist + (v < 0 || v >= C ? C : (int)v), 1);
+}
+
+__global__ void fixed_mask_kernel(const float* __restrict__ max_probs, float p_cutoff, float* __restrict__ mask, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) mask[i] = max_probs[i] >= p_cutoff ? 1.0f : 0.0f;
+}
+
+// mask2[g, i] = reward[g, i] >= mean_i(reward[g, :]);  one workgroup per independent group g.
+// Mean: fp32, fixed order.  B <= 64: left-to-right (== torch CPU for the reference batch of 8);
+// larger B: per-lane strided partials then a fixed shuffle tree (deterministic).
+__global__ __launch_bounds__(64) void reward_mask2_kernel(const float* __restrict__ reward, float* __restrict__ mask2,
+                                                         float* __restrict__ mean_out, int B) {
+  const float* r = reward + (size_t)blockIdx.x * B;
+  const int lane = threadIdx.x;
+  float s;
+  if (B <= 64) {
+    s = 0.f;
+    for (int i = 0; i < B; ++i) s += r[i];
+  } else {
+    float p = 0.f;
+    for (int i = lane; i < B; i += 64) p += r[i];
+    s = wave_sum(p);
+  }
+  const float mean = s / (float)B;
+  for (int i = lane; i < B; i += 64) mask2[(size_t)blockIdx.x * B + i] = r[i] >= mean ? 1.0f : 0.0f;
+  if (mean_out && lane == 0) mean_out[blockIdx.x] = mean;
+}
+
+// Masked cross-entropy forward + analytic backward.  ONE workgroup (B is the per-GPU batch).
+//   loss = coef_out * mean_i( nll_i * mask_i * mask2_i )         (consistency.py:38-45: mean over ALL rows)
+//   dlogits[i, c] = grad_scale * (softmax_ic - [c == y_i]) * mask_i * mask2_i / B
+__global__ __launch_bounds__(256) void masked_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ targets,
+                                                       const float* __restrict__ mask, const float* __restrict__ mask2,
+                                                       float grad_scale, float* __restrict__ loss_out, float* __restrict__ dlogits,
+                                                       int B, int C) {
+  __shared__ float rowloss[1024];
+  __shared__ float part[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int row = wave; row < B; row += 4) {
+    const float* r = logits + (size_t)row * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, r[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(r[c] - mx);
+    s = wave_sum(s);
+    const int y = (int)targets[row];
+    float w = 1.0f;
+    if (mask) w *= mask[row];
+    if (mask2) w *= mask2[row];
+    const float nll = (mx + logf(s)) - r[y];
+    if (dlogits) {
+      const float k = grad_scale * w / (float)B, inv = 1.0f / s;
+      for (int c = lane; c < C; c += 64) dlogits[(size_t)row * C + c] = k * (expf(r[c] - mx) * inv - (c == y ? 1.0f : 0.0f));
+    }
+    if (lane == 0) {
+      if (B <= 1024) rowloss[row] = nll * w; else acc += nll * w;
+    }
+  }
+  __syncthreads();
+  if (B <= 1024) {              // fixed left-to-right order -> run-to-run identical
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < B; ++i) t += rowloss[i];
+      loss_out[0] = t / (float)B;
+    }
+  } else {
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)B;
+  }
+}
+
+}  // namespace
+
+extern "C" int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B,
+                             int C, void* stream) {
+  if (B <= 0 || C <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
+                                    long long* selected_label, int* hist, float* classwise_acc, float* mask, int B, int C,
+                                    int ulb_dest_len, int thresh_warmup, void* stream) {
+  if (B <= 0 || C <= 0 || ulb_dest_len <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
+                     selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_flexmatch_rebuild_hist(const long long* selected_label, int* hist, int ulb_dest_len, int C, void* stream) {
+  if (ulb_dest_len <= 0 || C <= 0) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(hist, 0, (size_t)(C + 1) * sizeof(int), s) != hipSuccess) return SR_ELAUNCH;
+  hipLaunchKernelGGL(flexmatch_hist_kernel, dim3(cdiv(ulb_dest_len, 256)), dim3(256), 0, s, selected_label, hist, ulb_dest_len, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream) {
+  if (B <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(fixed_mask_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, max_probs, p_cutoff, mask, B);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, int groups, int B, void* stream) {
+  if (groups <= 0 || B <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(reward_mask2_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, reward, mask2, mean_out, B);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_masked_ce(const float* logits, const long long* targets, const float* mask, const float* mask2,
+                               float grad_scale, float* loss_out, float* dlogits, int B, int C, void* stream) {
+  if (B <= 0 || C <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(masked_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, mask, mask2, grad_scale,
+                     loss_out, dlogits, B, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

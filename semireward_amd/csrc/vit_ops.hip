@@ -1,0 +1,468 @@
+// HBM-bound backbone kernels: LayerNorm fwd/bwd, patch embedding fwd/bwd, cls-pool + head fwd/bwd,
+// casts / transposes feeding the MFMA GEMM, DropPath mask generation.
+//
+// Reference call sites:
+//   K1  PatchEmbed + cls + pos     semilearn/nets/vit/vit.py:39-44, :277-280
+//   K2  nn.LayerNorm(eps=1e-6)     vit.py:135,150,268 (eps :222)
+//   K7  x[:,0] -> head             vit.py:296-305
+//   DropPath                       vit.py:148,161 (timm.models.layers.DropPath)
+// All of these move a few bytes per FLOP, so the design rules are: one wave per row with fp32
+// statistics via wave shuffles, 8-16 B per lane coalesced accesses, and fusing the dtype cast
+// (fp32 residual stream -> bf16 GEMM operand) into the producing kernel.
+#include "common.h"
+#include "srhip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward: x fp32 [M, D] -> out bf16 [M, D]; D = 128 * NV.  One wave per row.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps, bf16_t* __restrict__ out,
+                                                    float* __restrict__ mean, float* __restrict__ rstd, int M) {
+  constexpr int D = NV * 128;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+  float2 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { v[i] = xr[i * 64 + lane]; s += v[i].x + v[i].y; }
+  const float mu = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const float a = v[i].x - mu, b = v[i].y - mu; q += a * a + b * b; }
+  const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+  uint32_t* orow = reinterpret_cast<uint32_t*>(out + (size_t)row * D);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float2 g = reinterpret_cast<const float2*>(gamma)[i * 64 + lane];
+    const float2 b = reinterpret_cast<const float2*>(beta)[i * 64 + lane];
+    orow[i * 64 + lane] = pack_bf2((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y);
+  }
+  if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// LayerNorm backward: dx (fp32, +=) and dgamma/dbeta (fp32, atomic +=).  32 rows per workgroup.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, float* __restrict__ dx,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+  constexpr int D = NV * 128;
+  __shared__ float red[2][4][D];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float2 ag[NV], ab[NV], g[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ag[i] = make_float2(0.f, 0.f); ab[i] = make_float2(0.f, 0.f);
+    g[i] = reinterpret_cast<const float2*>(gamma)[i * 64 + lane];
+  }
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = blockIdx.x * 32 + wave * 8 + rr;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
+    const uint32_t* dr = reinterpret_cast<const uint32_t*>(dy + (size_t)row * D);
+    float2 xh[NV], gy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float2 xv = xr[i * 64 + lane];
+      const uint32_t d2 = dr[i * 64 + lane];
+      const float d0 = bf2f((bf16_t)(d2 & 0xffff)), d1 = bf2f((bf16_t)(d2 >> 16));
+      xh[i] = make_float2((xv.x - mu) * rs, (xv.y - mu) * rs);
+      gy[i] = make_float2(d0 * g[i].x, d1 * g[i].y);
+      s1 += gy[i].x + gy[i].y;
+      s2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y;
+      ag[i].x += d0 * xh[i].x; ag[i].y += d1 * xh[i].y;
+      ab[i].x += d0; ab[i].y += d1;
+    }
+    const float c1 = wave_sum(s1) * (1.0f / D), c2 = wave_sum(s2) * (1.0f / D);
+    float2* dxr = reinterpret_cast<float2*>(dx + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float2 o = dxr[i * 64 + lane];
+      o.x += rs * (gy[i].x - c1 - xh[i].x * c2);
+      o.y += rs * (gy[i].y - c1 - xh[i].y * c2);
+      dxr[i * 64 + lane] = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 2;
+    red[0][wave][c] = ag[i].x; red[0][wave][c + 1] = ag[i].y;
+    red[1][wave][c] = ab[i].x; red[1][wave][c + 1] = ab[i].y;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch embedding (small patches: K = C*p*p <= 48 is an HBM-bound VALU op, not a GEMM).
+// x[b, 0, :] = cls + pos[0];  x[b, 1+p, :] = patch(b,p) . Wp^T + bp + pos[1+p].   blockDim = D.
+constexpr int PE_TOK = 32;
+__global__ void patch_embed_fwd_kernel(const float* __restrict__ img, const int* __restrict__ img_index,
+                                       const float* __restrict__ Wp, const float* __restrict__ bp,
+                                       const float* __restrict__ cls, const float* __restrict__ pos,
+                                       float* __restrict__ x, int C, int HW, int ps, int D) {
+  extern __shared__ float patch[];     // [PE_TOK][K]
+  const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps;
+  const int b = blockIdx.y, t0 = blockIdx.x * PE_TOK, d = threadIdx.x;
+  const int bi = img_index ? img_index[b] : b;
+  const float* im = img + (size_t)bi * C * HW * HW;
+  for (int e = threadIdx.x; e < PE_TOK * K; e += blockDim.x) {
+    const int tt = e / K, k = e % K, t = t0 + tt;
+    float v = 0.f;
+    if (t >= 1 && t < N) {
+      const int p = t - 1, py = p / gw, px = p % gw;
+      const int c = k / (ps * ps), i = (k / ps) % ps, j = k % ps;
+      v = im[((size_t)c * HW + py * ps + i) * HW + px * ps + j];
+    }
+    patch[e] = v;
+  }
+  __syncthreads();
+  const float* w = Wp + (size_t)d * K;
+  const float bias = bp[d];
+  for (int tt = 0; tt < PE_TOK; ++tt) {
+    const int t = t0 + tt;
+    if (t >= N) break;
+    float acc;
+    if (t == 0) {
+      acc = cls[d];
+    } else {
+      acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += patch[tt * K + k] * w[k];
+      acc += bias;
+    }
+    x[((size_t)b * N + t) * D + d] = acc + pos[(size_t)t * D + d];
+  }
+}
+
+// dpos[t,d] += sum_b dx[b,t,d]; dcls[d] += sum_b dx[b,0,d].  grid = N, block = D.
+__global__ void patch_embed_bwd_pos_kernel(const float* __restrict__ dx, float* __restrict__ dpos, float* __restrict__ dcls,
+                                           int B, int N, int D) {
+  const int t = blockIdx.x, d = threadIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dx[((size_t)b * N + t) * D + d];
+  dpos[(size_t)t * D + d] += s;
+  if (t == 0) dcls[d] += s;
+}
+
+// dWp[d,k] += sum_{b,p} dx[b,1+p,d] * patch[b,p,k]; dbp[d] += sum dx.   grid = (chunks, B), block = D.
+__global__ void patch_embed_bwd_w_kernel(const float* __restrict__ dx, const float* __restrict__ img,
+                                         const int* __restrict__ img_index, float* __restrict__ dWp,
+                                         float* __restrict__ dbp, int C, int HW, int ps, int D) {
+  extern __shared__ float patch[];     // [PE_TOK][K]
+  const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps;
+  const int b = blockIdx.y, t0 = 1 + blockIdx.x * PE_TOK, d = threadIdx.x;
+  const int bi = img_index ? img_index[b] : b;
+  const float* im = img + (size_t)bi * C * HW * HW;
+  for (int e = threadIdx.x; e < PE_TOK * K; e += blockDim.x) {
+    const int tt = e / K, k = e % K, t = t0 + tt;
+    float v = 0.f;
+    if (t < N) {
+      const int p = t - 1, py = p / gw, px = p % gw;
+      const int c = k / (ps * ps), i = (k / ps) % ps, j = k % ps;
+      v = im[((size_t)c * HW + py * ps + i) * HW + px * ps + j];
+    }
+    patch[e] = v;
+  }
+  __syncthreads();
+  float accb = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {         // K is small; register-block 16 taps at a time
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int tt = 0; tt < PE_TOK; ++tt) {
+      const int t = t0 + tt;
+      if (t >= N) break;
+      const float g = dx[((size_t)b * N + t) * D + d];
+      if (k0 == 0) accb += g;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k0 + k < K) acc[k] += g * patch[tt * K + k0 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k0 + k < K) atomicAdd(dWp + (size_t)d * K + k0 + k, acc[k]);
+  }
+  atomicAdd(dbp + d, accb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cls pooling + final LayerNorm + classifier head (fp32 throughout: tiny, and keeps logits tight).
+// grid = B, block = 256.
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void cls_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                          float* __restrict__ feat, float* __restrict__ logits,
+                                                          float* __restrict__ xhat, float* __restrict__ rstd,
+                                                          int N, int D, int C) {
+  extern __shared__ float f[];        // [D] + 4
+  float* sh = f + D;
+  const int b = blockIdx.x;
+  const float* xr = x + (size_t)b * N * D;     // token 0 of image b
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) s += xr[d];
+  const float mu = block_sum(s, sh) / D;
+  float q = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) { const float a = xr[d] - mu; q += a * a; }
+  const float rs = rsqrtf(block_sum(q, sh) / D + eps);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float xh = (xr[d] - mu) * rs, v = xh * gamma[d] + beta[d];
+    f[d] = v;
+    feat[(size_t)b * D + d] = v;
+    if (xhat) xhat[(size_t)b * D + d] = xh;
+  }
+  if (rstd && threadIdx.x == 0) rstd[b] = rs;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = wave; c < C; c += 4) {
+    const float* w = Wh + (size_t)c * D;
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a += f[d] * w[d];
+    a = wave_sum(a);
+    if (lane == 0) logits[(size_t)b * C + c] = a + bh[c];
+  }
+}
+
+// backward A: grid = B.  dfeat = dlogits . Wh ; LN backward of the cls row -> dx[b, 0, :] (=), dgamma/dbeta (atomic +=)
+__global__ __launch_bounds__(256) void cls_head_bwd_x_kernel(const float* __restrict__ dlogits, const float* __restrict__ Wh,
+                                                            const float* __restrict__ gamma, const float* __restrict__ xhat,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int N, int D, int C) {
+  extern __shared__ float sm[];       // dl[C] + 4
+  float* dl = sm;
+  float* sh = sm + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) dl[c] = dlogits[(size_t)b * C + c];
+  __syncthreads();
+  float gy[4], xh[4], df[4];
+  float s1 = 0.f, s2 = 0.f;
+  int n = 0;
+  for (int d = threadIdx.x; d < D; d += 256, ++n) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += dl[c] * Wh[(size_t)c * D + d];
+    df[n] = a; xh[n] = xhat[(size_t)b * D + d]; gy[n] = a * gamma[d];
+    s1 += gy[n]; s2 += gy[n] * xh[n];
+  }
+  const float c1 = block_sum(s1, sh) / D, c2 = block_sum(s2, sh) / D, rs = rstd[b];
+  n = 0;
+  for (int d = threadIdx.x; d < D; d += 256, ++n) {
+    dx[(size_t)b * N * D + d] = rs * (gy[n] - c1 - xh[n] * c2);
+    atomicAdd(dgamma + d, df[n] * xh[n]);
+    atomicAdd(dbeta + d, df[n]);
+  }
+}
+
+// backward B: grid = C.  dWh[c,:] += sum_b dlogits[b,c] * feat[b,:]; dbh[c] += sum_b dlogits[b,c]
+__global__ __launch_bounds__(256) void cls_head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat,
+                                                            float* __restrict__ dWh, float* __restrict__ dbh, int B, int D, int C) {
+  const int c = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dlogits[(size_t)b * C + c] * feat[(size_t)b * D + d];
+    dWh[(size_t)c * D + d] += a;
+  }
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dlogits[(size_t)b * C + c];
+    dbh[c] += a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 [M, D] (x optional per-sample scale) -> bf16.  8 elements per thread.
+__global__ void cast_scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ scale, int rows_per_sample,
+                                       bf16_t* __restrict__ out, size_t n8, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+  float s = 1.0f;
+  if (scale) s = scale[(i * 8 / D) / rows_per_sample];
+  uint4 o = {pack_bf2(a.x * s, a.y * s), pack_bf2(a.z * s, a.w * s), pack_bf2(b.x * s, b.y * s), pack_bf2(b.z * s, b.w * s)};
+  reinterpret_cast<uint4*>(out)[i] = o;
+}
+
+// Transpose in [M, C] (bf16 or fp32, row stride ld_in) -> out bf16 [C, Mp] (row stride ld_out), zero-filling
+// columns m in [M, Mp).  Optional exact-erf GELU on the fly, optional column sums (bias gradients, atomic +=).
+// 64 x 64 tile through LDS.  grid = (ceil(Mp/64), C/64).
+template <typename TIN, bool GELU>
+__global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
+                                                       int M, int Mp, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63, m = m0 + r;
+    float v = 0.f;
+    if (m < M) {
+      if constexpr (sizeof(TIN) == 2) v = bf2f(in[(size_t)m * ld_in + c0 + c]);
+      else v = (float)in[(size_t)m * ld_in + c0 + c];
+      if (GELU) v = gelu_erf(v);
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+    const int c = e >> 5, rp = (e & 31) * 2, m = m0 + rp;
+    if (m < Mp) *reinterpret_cast<uint32_t*>(out + (size_t)(c0 + c) * ld_out + m) = pack_bf2(tile[rp][c], tile[rp + 1][c]);
+  }
+  if (colsum && threadIdx.x < 64) {
+    float s = 0.f;
+    for (int r = 0; r < 64; ++r) s += tile[r][threadIdx.x];
+    atomicAdd(colsum + c0 + threadIdx.x, s);
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i);
+    uint2 o = {pack_bf2(a.x, a.y), pack_bf2(a.z, a.w)};
+    *reinterpret_cast<uint2*>(out + i) = o;
+  } else {
+    for (size_t j = i; j < n; ++j) out[j] = f2bf(x[j]);
+  }
+}
+
+// DropPath per-sample scales: out[l, j, b] = Bernoulli(1 - p_l) / (1 - p_l), counter-based hash RNG.
+__global__ void droppath_fill_kernel(float* __restrict__ out, const float* __restrict__ probs, int depth, int B,
+                                     unsigned long long seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= depth * 2 * B) return;
+  const float p = probs[i / (2 * B)];
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  const float keep = 1.0f - p;
+  out[i] = (p <= 0.f) ? 1.0f : (u < keep ? 1.0f / keep : 0.0f);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* out,
+                                   float* mean, float* rstd, int M, int D, void* stream) {
+  if (M <= 0 || (D != 128 && D != 384 && D != 768) || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (D == 128) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  else if (D == 384) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  else hipLaunchKernelGGL(ln_fwd_kernel<6>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                   float* dx, float* dgamma, float* dbeta, int M, int D, void* stream) {
+  if (M <= 0 || (D != 128 && D != 384 && D != 768)) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(M, 32)), block(256);
+  if (D == 128) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
+  else if (D == 384) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
+  else hipLaunchKernelGGL(ln_bwd_kernel<6>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_patch_embed_fwd(const float* img, const int* img_index, const float* Wp, const float* bp, const float* cls,
+                                     const float* pos, float* x, int B, int C, int HW, int ps, int D, void* stream) {
+  if (B <= 0 || HW % ps || D % 64 || D > 1024 || C * ps * ps > 64) return SR_EINVAL;
+  const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps;
+  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(cdiv(N, PE_TOK), B), dim3(D), PE_TOK * K * sizeof(float), (hipStream_t)stream,
+                     img, img_index, Wp, bp, cls, pos, x, C, HW, ps, D);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_patch_embed_bwd(const float* dx, const float* img, const int* img_index, float* dWp, float* dbp,
+                                     float* dcls, float* dpos, int B, int C, int HW, int ps, int D, void* stream) {
+  if (B <= 0 || HW % ps || D % 64 || D > 1024 || C * ps * ps > 64) return SR_EINVAL;
+  const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(patch_embed_bwd_pos_kernel, dim3(N), dim3(D), 0, s, dx, dpos, dcls, B, N, D);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(patch_embed_bwd_w_kernel, dim3(cdiv(N - 1, PE_TOK), B), dim3(D), PE_TOK * K * sizeof(float), s, dx, img,
+                     img_index, dWp, dbp, C, HW, ps, D);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_cls_head_fwd(const float* x, const float* gamma, const float* beta, float eps, const float* Wh,
+                                  const float* bh, float* feat, float* logits, float* xhat, float* rstd, int B, int N, int D,
+                                  int C, void* stream) {
+  if (B <= 0 || D > 1024 || C <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream, x, gamma, beta, eps,
+                     Wh, bh, feat, logits, xhat, rstd, N, D, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const float* gamma, const float* feat,
+                                  const float* xhat, const float* rstd, float* dx, float* dWh, float* dbh, float* dgamma,
+                                  float* dbeta, int B, int N, int D, int C, void* stream) {
+  if (B <= 0 || D > 1024 || C <= 0) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cls_head_bwd_x_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, dlogits, Wh, gamma, xhat, rstd, dx,
+                     dgamma, dbeta, N, D, C);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, s, dlogits, feat, dWh, dbh, B, D, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_cast_scale_rows(const float* x, const float* scale, int rows_per_sample, void* out, long M, int D,
+                                     void* stream) {
+  if (M <= 0 || D % 8 || (scale && rows_per_sample <= 0)) return SR_EINVAL;
+  const size_t n8 = (size_t)M * D / 8;
+  hipLaunchKernelGGL(cast_scale_rows_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     rows_per_sample > 0 ? rows_per_sample : 1, (bf16_t*)out, n8, D);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, void* out, int ld_out, int M, int Mp, int C,
+                                       int apply_gelu, float* colsum, void* stream) {
+  if (M <= 0 || Mp < M || (Mp % 2) || (C % 64) || ld_out < Mp || (ld_out % 2)) return SR_EINVAL;
+  dim3 grid(cdiv(Mp, 64), C / 64), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_is_f32) {
+    if (apply_gelu) return SR_EINVAL;
+    hipLaunchKernelGGL((transpose_kernel<float, false>), grid, block, 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
+  } else if (apply_gelu) {
+    hipLaunchKernelGGL((transpose_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
+  } else {
+    hipLaunchKernelGGL((transpose_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
+  }
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stream) {
+  if (n <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, (size_t)n);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream) {
+  if (depth <= 0 || B <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

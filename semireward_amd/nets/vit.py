@@ -1,0 +1,322 @@
+"""ViT backbone engine on libsrhip: forward / backward over a flat parameter block.
+
+Mirrors the reference's ``semilearn/nets/vit/vit.py`` plugin surface (class name, builder names,
+``state_dict`` keys, ``{'logits','feat'}`` result dict, ``no_weight_decay`` / ``group_matcher``) but not
+its implementation: there is no nn.Module, no autograd.  Parameters, gradients, bf16 operand copies
+and Adam moments are each ONE contiguous device buffer (the layout is the reference's
+``named_parameters()`` order, so a reference checkpoint maps 1:1), every layer is a short list of
+HIP kernel launches, and the backward is hand-written.
+
+Data layout in HBM (B images, N tokens, D channels, M = B*N rows):
+  residual stream x         fp32 [M, D]      (in place when nothing is saved for a backward)
+  LN output / attn out      bf16 [M, D]      GEMM A-operands
+  qkv                       bf16 [M, 3D]     exactly as the qkv Linear writes it; attention indexes heads in place
+  MLP hidden                bf16 [M, 4D]
+  weights                   bf16 [out, in]   (+ transposed bf16 copies for the dX products)
+"""
+import math
+
+import torch
+
+from .. import ops
+
+
+class VitConfig:
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, drop_path_rate=0.0, eps=1e-6):
+        self.img_size, self.patch_size, self.in_chans, self.num_classes = img_size, patch_size, in_chans, num_classes
+        self.embed_dim, self.depth, self.num_heads, self.mlp_ratio = embed_dim, depth, num_heads, mlp_ratio
+        self.drop_path_rate, self.eps = drop_path_rate, eps
+        assert embed_dim % num_heads == 0 and embed_dim // num_heads == 64, "libsrhip attention is built for head_dim 64"
+        assert embed_dim in (128, 384, 768)
+
+    @property
+    def num_tokens(self):
+        return (self.img_size // self.patch_size) ** 2 + 1
+
+    @property
+    def hidden(self):
+        return int(self.embed_dim * self.mlp_ratio)
+
+
+def param_names_shapes(cfg):
+    """named_parameters() order of the reference VisionTransformer (vit.py:228-275)."""
+    D, Hd, p, C = cfg.embed_dim, cfg.hidden, cfg.patch_size, cfg.num_classes
+    out = [("cls_token", (1, 1, D)), ("pos_embed", (1, cfg.num_tokens, D)),
+           ("patch_embed.proj.weight", (D, cfg.in_chans, p, p)), ("patch_embed.proj.bias", (D,))]
+    for i in range(cfg.depth):
+        b = "blocks.%d." % i
+        out += [(b + "norm1.weight", (D,)), (b + "norm1.bias", (D,)),
+                (b + "attn.qkv.weight", (3 * D, D)), (b + "attn.qkv.bias", (3 * D,)),
+                (b + "attn.proj.weight", (D, D)), (b + "attn.proj.bias", (D,)),
+                (b + "norm2.weight", (D,)), (b + "norm2.bias", (D,)),
+                (b + "mlp.fc1.weight", (Hd, D)), (b + "mlp.fc1.bias", (Hd,)),
+                (b + "mlp.fc2.weight", (D, Hd)), (b + "mlp.fc2.bias", (D,))]
+    out += [("norm.weight", (D,)), ("norm.bias", (D,)), ("head.weight", (C, D)), ("head.bias", (C,))]
+    return out
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class FwdContext:
+    """Activations kept by a ``save=True`` forward for the hand-written backward."""
+    __slots__ = ("B", "img", "img_index", "dp", "xs", "xmid", "ln1", "ln2", "qkv", "ao", "lse", "pre", "st1", "st2",
+                 "feat", "xhat", "rstd")
+
+
+class VisionTransformer:
+    GEMM_WEIGHTS = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+
+    def __init__(self, cfg=None, device="cuda", **kw):
+        self.cfg = cfg if cfg is not None else VitConfig(**kw)
+        cfg = self.cfg
+        self.device = torch.device(device)
+        self.names_shapes = param_names_shapes(cfg)
+        self.offsets, o = {}, 0
+        for n, s in self.names_shapes:
+            self.offsets[n] = (o, s)
+            o += int(torch.Size(s).numel())
+        # 2-D GEMM weights must start on a 16-byte boundary in the bf16 copy (8 elements)
+        assert all(v[0] % 8 == 0 for k, v in self.offsets.items() if len(v[1]) == 2)
+        self.numel = o
+        self.flat = torch.zeros(o, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(o, dtype=torch.float32, device=self.device)
+        self.flat_bf16 = torch.zeros(o, dtype=torch.bfloat16, device=self.device)
+        self.wT = {}
+        for i in range(cfg.depth):
+            for w in self.GEMM_WEIGHTS:
+                n = "blocks.%d.%s" % (i, w)
+                r, c = self.offsets[n][1]
+                self.wT[n] = torch.zeros(c, r, dtype=torch.bfloat16, device=self.device)
+        self.dp_probs = torch.linspace(0, cfg.drop_path_rate, cfg.depth).to(self.device)    # vit.py:247-249
+        self.training = True
+        self._ws = {}
+        self._rng_calls = 0
+        self.seed = 0
+
+    # ---- parameter plumbing ---------------------------------------------------------------------
+    def p(self, name, buf=None):
+        o, s = self.offsets[name]
+        return (self.flat if buf is None else buf)[o:o + int(torch.Size(s).numel())]
+
+    def view(self, name, buf=None):
+        return self.p(name, buf).view(self.offsets[name][1])
+
+    def named_parameters(self):
+        return [(n, self.view(n)) for n, _ in self.names_shapes]
+
+    def named_grads(self):
+        return [(n, self.view(n, self.grad)) for n, _ in self.names_shapes]
+
+    def state_dict(self):
+        return {n: self.view(n).detach().clone() for n, _ in self.names_shapes}
+
+    def load_state_dict(self, sd, strict=True):
+        for n, s in self.names_shapes:
+            if n in sd:
+                self.view(n).copy_(torch.as_tensor(sd[n]).to(self.device, torch.float32).reshape(s))
+            elif strict:
+                raise KeyError(n)
+        self.refresh_operands()
+
+    def refresh_operands(self):
+        """bf16 operand copy of the whole block + transposed GEMM weights (after any parameter change)."""
+        ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        for n, t in self.wT.items():
+            r, c = self.offsets[n][1]
+            ops.transpose_to_bf16(self.p(n), True, c, t, r, r, r, c)
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    # ---- workspaces -------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype):
+        t = self._ws.get(key)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def make_droppath(self, B):
+        """timm DropPath scales [depth, 2, B] for one forward (vit.py:148,161)."""
+        dp = torch.empty(self.cfg.depth, 2, B, dtype=torch.float32, device=self.device)
+        self._rng_calls += 1
+        ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, (self.seed << 32) + self._rng_calls)
+        return dp
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None):
+        """img fp32 [n_img, C, H, W]; img_index int32 [B] (optional gather); droppath fp32 [depth,2,B] or None.
+        Returns (logits [B,C], feat [B,D], ctx or None)."""
+        cfg = self.cfg
+        D, N, H, Hd, C = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes
+        B = int(img_index.numel()) if img_index is not None else (B or img.shape[0])
+        M = B * N
+        f32, bf16 = torch.float32, torch.bfloat16
+        tag = "s" if save else "i"
+        ctx = None
+        if save:
+            ctx = FwdContext()
+            ctx.B, ctx.img, ctx.img_index, ctx.dp = B, img, img_index, droppath
+            ctx.xs = [torch.empty(M, D, dtype=f32, device=self.device) for _ in range(cfg.depth + 1)]
+            ctx.xmid = [torch.empty(M, D, dtype=f32, device=self.device) for _ in range(cfg.depth)]
+            ctx.ln1 = [torch.empty(M, D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
+            ctx.ln2 = [torch.empty(M, D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
+            ctx.qkv = [torch.empty(M, 3 * D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
+            ctx.ao = [torch.empty(M, D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
+            ctx.pre = [torch.empty(M, Hd, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
+            ctx.lse = [torch.empty(B, H, N, dtype=f32, device=self.device) for _ in range(cfg.depth)]
+            ctx.st1 = [torch.empty(2, M, dtype=f32, device=self.device) for _ in range(cfg.depth)]
+            ctx.st2 = [torch.empty(2, M, dtype=f32, device=self.device) for _ in range(cfg.depth)]
+            x = ctx.xs[0]
+        else:
+            x = self._buf(tag + "x", (M, D), f32)
+            ln = self._buf(tag + "ln", (M, D), bf16)
+            qkv = self._buf(tag + "qkv", (M, 3 * D), bf16)
+            ao = self._buf(tag + "ao", (M, D), bf16)
+        hbuf = self._buf(tag + "h", (M, Hd), bf16)
+        wb = self.flat_bf16
+        P = self.p
+        ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),
+                            P("pos_embed"), x, B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+        scale = 64 ** -0.5
+        for i in range(cfg.depth):
+            b = "blocks.%d." % i
+            s1 = droppath[i, 0] if droppath is not None else None
+            s2 = droppath[i, 1] if droppath is not None else None
+            if save:
+                ln, qkv, ao = ctx.ln1[i], ctx.qkv[i], ctx.ao[i]
+                ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
+            else:
+                ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, None, None, M, D)
+            ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
+            ops.attn_fwd(qkv, ao, ctx.lse[i] if save else None, B, N, H, scale)
+            if save:
+                xm = ctx.xmid[i]
+                ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), xm, M, D, D, bias=P(b + "attn.proj.bias"),
+                            row_scale=s1, rows_per_sample=N, aux_in=x, ldaux=D)
+                ln2 = ctx.ln2[i]
+                ops.layernorm_fwd(xm, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln2, ctx.st2[i][0], ctx.st2[i][1], M, D)
+                ops.gemm_nt(ops.EPI_GELU_BF16, ln2, P(b + "mlp.fc1.weight", wb), hbuf, M, Hd, D, bias=P(b + "mlp.fc1.bias"),
+                            aux_out=ctx.pre[i], ldaux=Hd)
+                xn = ctx.xs[i + 1]
+                ops.gemm_nt(ops.EPI_RESID_F32, hbuf, P(b + "mlp.fc2.weight", wb), xn, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
+                            row_scale=s2, rows_per_sample=N, aux_in=xm, ldaux=D)
+                x = xn
+            else:
+                ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), x, M, D, D, bias=P(b + "attn.proj.bias"),
+                            row_scale=s1, rows_per_sample=N)
+                ops.layernorm_fwd(x, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln, None, None, M, D)
+                ops.gemm_nt(ops.EPI_GELU_BF16, ln, P(b + "mlp.fc1.weight", wb), hbuf, M, Hd, D, bias=P(b + "mlp.fc1.bias"))
+                ops.gemm_nt(ops.EPI_RESID_F32, hbuf, P(b + "mlp.fc2.weight", wb), x, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
+                            row_scale=s2, rows_per_sample=N)
+        feat = torch.empty(B, D, dtype=f32, device=self.device)
+        logits = torch.empty(B, C, dtype=f32, device=self.device)
+        if save:
+            ctx.xhat = torch.empty(B, D, dtype=f32, device=self.device)
+            ctx.rstd = torch.empty(B, dtype=f32, device=self.device)
+            ctx.feat = feat
+        ops.cls_head_fwd(x, P("norm.weight"), P("norm.bias"), cfg.eps, P("head.weight"), P("head.bias"), feat, logits,
+                         ctx.xhat if save else None, ctx.rstd if save else None, B, N, D, C)
+        return logits, feat, ctx
+
+    def forward(self, x, only_fc=False, only_feat=False, **kw):
+        """Reference-compatible entry (vit.py:285-306): returns {'logits','feat'}.  Inference-style call
+        (DropPath active only in train mode, no activations kept)."""
+        assert not only_fc, "only_fc is not on the SemiReward hot path"
+        dp = self.make_droppath(x.shape[0]) if (self.training and self.cfg.drop_path_rate > 0) else None
+        logits, feat, _ = self.forward_features(x.contiguous(), None, dp, save=False)
+        return feat if only_feat else {"logits": logits, "feat": feat}
+
+    __call__ = forward
+
+    # ---- backward ---------------------------------------------------------------------------------
+    def backward(self, ctx, dlogits):
+        """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] for a save=True forward."""
+        cfg = self.cfg
+        D, N, H, Hd, C = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes
+        B = ctx.B
+        M = B * N
+        Mp = _round_up(M, 64)
+        f32, bf16 = torch.float32, torch.bfloat16
+        P, G, wb = self.p, (lambda n: self.p(n, self.grad)), self.flat_bf16
+        dx = self._buf("b_dx", (M, D), f32)
+        dx.zero_()
+        ops.cls_head_bwd(dlogits, P("head.weight"), P("norm.weight"), ctx.feat, ctx.xhat, ctx.rstd, dx, G("head.weight"),
+                         G("head.bias"), G("norm.weight"), G("norm.bias"), B, N, D, C)
+        g = self._buf("b_g", (M, D), bf16)
+        gT = self._buf("b_gT", (D, Mp), bf16)
+        aT = self._buf("b_aT", (D, Mp), bf16)
+        hT = self._buf("b_hT", (Hd, Mp), bf16)
+        dpre = self._buf("b_dpre", (M, Hd), bf16)
+        dpreT = self._buf("b_dpreT", (Hd, Mp), bf16)
+        dln = self._buf("b_dln", (M, D), bf16)
+        dao = self._buf("b_dao", (M, D), bf16)
+        dqkv = self._buf("b_dqkv", (M, 3 * D), bf16)
+        dqkvT = self._buf("b_dqkvT", (3 * D, Mp), bf16)
+        delta = self._buf("b_delta", (B, H, N), f32)
+        scale = 64 ** -0.5
+        dp = ctx.dp
+        for i in reversed(range(cfg.depth)):
+            b = "blocks.%d." % i
+            s1 = dp[i, 0] if dp is not None else None
+            s2 = dp[i, 1] if dp is not None else None
+            # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))))
+            ops.cast_scale_rows(dx, s2, N, g, M, D)
+            ops.transpose_to_bf16(g, False, D, gT, Mp, M, Mp, D, colsum=G(b + "mlp.fc2.bias"))
+            ops.transpose_to_bf16(ctx.pre[i], False, Hd, hT, Mp, M, Mp, Hd, apply_gelu=True)
+            ops.gemm_nt(ops.EPI_F32, gT, hT, G(b + "mlp.fc2.weight"), D, Hd, Mp, alpha=1.0, beta=1.0)
+            ops.gemm_nt(ops.EPI_DGELU_BF16, g, self.wT[b + "mlp.fc2.weight"], dpre, M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
+            ops.transpose_to_bf16(dpre, False, Hd, dpreT, Mp, M, Mp, Hd, colsum=G(b + "mlp.fc1.bias"))
+            ops.transpose_to_bf16(ctx.ln2[i], False, D, aT, Mp, M, Mp, D)
+            ops.gemm_nt(ops.EPI_F32, dpreT, aT, G(b + "mlp.fc1.weight"), Hd, D, Mp, alpha=1.0, beta=1.0)
+            ops.gemm_nt(ops.EPI_BF16, dpre, self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
+            ops.layernorm_bwd(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
+                              G(b + "norm2.bias"), M, D)
+            # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
+            ops.cast_scale_rows(dx, s1, N, g, M, D)
+            ops.transpose_to_bf16(g, False, D, gT, Mp, M, Mp, D, colsum=G(b + "attn.proj.bias"))
+            ops.transpose_to_bf16(ctx.ao[i], False, D, aT, Mp, M, Mp, D)
+            ops.gemm_nt(ops.EPI_F32, gT, aT, G(b + "attn.proj.weight"), D, D, Mp, alpha=1.0, beta=1.0)
+            ops.gemm_nt(ops.EPI_BF16, g, self.wT[b + "attn.proj.weight"], dao, M, D, D)
+            ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], dqkv, delta, B, N, H, scale)
+            ops.transpose_to_bf16(dqkv, False, 3 * D, dqkvT, Mp, M, Mp, 3 * D, colsum=G(b + "attn.qkv.bias"))
+            ops.transpose_to_bf16(ctx.ln1[i], False, D, aT, Mp, M, Mp, D)
+            ops.gemm_nt(ops.EPI_F32, dqkvT, aT, G(b + "attn.qkv.weight"), 3 * D, D, Mp, alpha=1.0, beta=1.0)
+            ops.gemm_nt(ops.EPI_BF16, dqkv, self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
+            ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
+                              G(b + "norm1.bias"), M, D)
+        ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
+                            G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+
+
+# ---- builders with the reference's names (vit.py:323-408); pretrained checkpoints need network -> ignored ------------
+def _build(num_classes, kw, **cfg):
+    kw = {k: v for k, v in kw.items() if k not in ("pretrained", "pretrained_path")}
+    device = kw.pop("device", "cuda")
+    return VisionTransformer(VitConfig(num_classes=num_classes, **cfg), device=device)
+
+
+def vit_tiny_test(num_classes=10, **kw):
+    return _build(num_classes, kw, img_size=8, patch_size=2, embed_dim=128, depth=2, num_heads=2, drop_path_rate=0.2)
+
+
+def vit_small_patch2_32(num_classes=1000, **kw):
+    return _build(num_classes, kw, img_size=32, patch_size=2, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)
+
+

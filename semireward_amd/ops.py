@@ -1,0 +1,145 @@
+"""Torch-tensor front end of the C ABI (include/srhip.h).  Torch is plumbing only: it owns device
+memory and the stream; every op below is a hand-written HIP kernel in libsrhip.so.  No fallbacks."""
+import torch
+
+from . import _lib
+from ._lib import EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32  # noqa: F401
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libsrhip needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.lib(), name)(*args), name)
+
+
+# ---- dense ------------------------------------------------------------------------------------
+def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, row_scale=None, rows_per_sample=0,
+            aux_in=None, aux_out=None, ldaux=0, alpha=1.0, beta=0.0):
+    """C[M,N] (+)= A[M,K] . B[N,K]^T  (bf16 operands; see srhip_gemm_nt)."""
+    _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
+          rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
+
+
+def attn_fwd(qkv, out, lse, B, N, H, scale):
+    _call("srhip_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, H, scale, _s())
+
+
+def attn_bwd(qkv, out, d_out, lse, dqkv, delta_ws, B, N, H, scale):
+    _call("srhip_attn_bwd", _p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), _p(delta_ws), B, N, H, scale, _s())
+
+
+def layernorm_fwd(x, gamma, beta, eps, out, mean, rstd, M, D):
+    _call("srhip_layernorm_fwd", _p(x), _p(gamma), _p(beta), eps, _p(out), _p(mean), _p(rstd), M, D, _s())
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M, D):
+    _call("srhip_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), M, D, _s())
+
+
+def patch_embed_fwd(img, img_index, Wp, bp, cls, pos, x, B, C, HW, ps, D):
+    _call("srhip_patch_embed_fwd", _p(img), _p(img_index), _p(Wp), _p(bp), _p(cls), _p(pos), _p(x), B, C, HW, ps, D, _s())
+
+
+def patch_embed_bwd(dx, img, img_index, dWp, dbp, dcls, dpos, B, C, HW, ps, D):
+    _call("srhip_patch_embed_bwd", _p(dx), _p(img), _p(img_index), _p(dWp), _p(dbp), _p(dcls), _p(dpos), B, C, HW, ps, D, _s())
+
+
+def cls_head_fwd(x, gamma, beta, eps, Wh, bh, feat, logits, xhat, rstd, B, N, D, C):
+    _call("srhip_cls_head_fwd", _p(x), _p(gamma), _p(beta), eps, _p(Wh), _p(bh), _p(feat), _p(logits), _p(xhat), _p(rstd),
+          B, N, D, C, _s())
+
+
+def cls_head_bwd(dlogits, Wh, gamma, feat, xhat, rstd, dx, dWh, dbh, dgamma, dbeta, B, N, D, C):
+    _call("srhip_cls_head_bwd", _p(dlogits), _p(Wh), _p(gamma), _p(feat), _p(xhat), _p(rstd), _p(dx), _p(dWh), _p(dbh),
+          _p(dgamma), _p(dbeta), B, N, D, C, _s())
+
+
+def cast_scale_rows(x, scale, rows_per_sample, out, M, D):
+    _call("srhip_cast_scale_rows", _p(x), _p(scale), rows_per_sample, _p(out), M, D, _s())
+
+
+def transpose_to_bf16(inp, in_is_f32, ld_in, out, ld_out, M, Mp, C, apply_gelu=False, colsum=None):
+    _call("srhip_transpose_to_bf16", _p(inp), int(in_is_f32), ld_in, _p(out), ld_out, M, Mp, C, int(apply_gelu), _p(colsum), _s())
+
+
+def cast_f32_bf16(x, out, n):
+    _call("srhip_cast_f32_bf16", _p(x), _p(out), n, _s())
+
+
+def droppath_fill(out, probs, depth, B, seed):
+    _call("srhip_droppath_fill", _p(out), _p(probs), depth, B, seed, _s())
+
+
+# ---- score filter -----------------------------------------------------------------------------
+def row_max(inp, in_is_probs, probs_out, max_probs, max_idx, B, C):
+    _call("srhip_row_max", _p(inp), int(in_is_probs), _p(probs_out), _p(max_probs), _p(max_idx), B, C, _s())
+
+
+def flexmatch_mask(max_probs, max_idx, idx_ulb, p_cutoff, selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len,
+                   thresh_warmup):
+    _call("srhip_flexmatch_mask", _p(max_probs), _p(max_idx), _p(idx_ulb), p_cutoff, _p(selected_label), _p(hist),
+          _p(classwise_acc), _p(mask), B, C, ulb_dest_len, int(thresh_warmup), _s())
+
+
+def flexmatch_rebuild_hist(selected_label, hist, ulb_dest_len, C):
+    _call("srhip_flexmatch_rebuild_hist", _p(selected_label), _p(hist), ulb_dest_len, C, _s())
+
+
+def fixed_mask(max_probs, p_cutoff, mask, B):
+    _call("srhip_fixed_mask", _p(max_probs), p_cutoff, _p(mask), B, _s())
+
+
+def reward_mask2(reward, mask2, mean_out, groups, B):
+    _call("srhip_reward_mask2", _p(reward), _p(mask2), _p(mean_out), groups, B, _s())
+
+
+def masked_ce(logits, targets, mask, mask2, grad_scale, loss_out, dlogits, B, C):
+    _call("srhip_masked_ce", _p(logits), _p(targets), _p(mask), _p(mask2), grad_scale, _p(loss_out), _p(dlogits), B, C, _s())
+
+
+# ---- rewarder / generator ---------------------------------------------------------------------
+def rewarder_param_count(F, L):
+    return int(_lib.lib().srhip_rewarder_param_count(F, L))
+
+
+def rewarder_ws_floats(G, B):
+    return int(_lib.lib().srhip_rewarder_ws_floats(G, B))
+
+
+def generator_param_count(F):
+    return int(_lib.lib().srhip_generator_param_count(F))
+
+
+def rewarder_fwd(params, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False):
+    _call("srhip_rewarder_fwd", _p(params), _p(feats), _p(labels), _p(reward), _p(ws), G, B, F, L, int(save_for_bwd), _s())
+
+
+def rewarder_bwd(params, feats, labels, target, ws, grads, losses, B, F, L):
+    _call("srhip_rewarder_bwd", _p(params), _p(feats), _p(labels), _p(target), _p(ws), _p(grads), _p(losses), B, F, L, _s())
+
+
+def generator_fwd(params, x, out, label, B, F):
+    _call("srhip_generator_fwd", _p(params), _p(x), _p(out), _p(label), B, F, _s())
+
+
+def sr_target(gen, ref, target, B):
+    _call("srhip_sr_target", _p(gen), _p(ref), _p(target), B, _s())
+
+
+def adam_flat(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    _call("srhip_adam_flat", _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, step, _s())
+
+
+def adamw_flat(p, g, m, v, p_bf16, ema, chunk_table, n_chunks, lr_t, wd_t, lr_factor, step, beta1=0.9, beta2=0.999, eps=1e-8,
+               ema_m=0.0, grad_scale=1.0, zero_grad=True):
+    _call("srhip_adamw_flat", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(ema), _p(chunk_table), n_chunks, _p(lr_t), _p(wd_t),
+          lr_factor, beta1, beta2, eps, step, ema_m, grad_scale, int(zero_grad), _s())

@@ -1,0 +1,99 @@
+"""Backbone optimizer state for the flat parameter block: AdamW with the reference's layer-decay
+param groups and the cosine-with-warmup schedule, executed by ONE fused HIP launch per step.
+
+Mirrors reference semantics (not code):
+  get_optimizer / param_groups_layer_decay   semilearn/core/utils/build.py:193-224, semilearn/nets/utils.py:143-204
+  get_cosine_schedule_with_warmup            semilearn/core/utils/build.py:227-251
+  ParamUpdateHook.after_train_step           semilearn/core/hooks/param_update.py:33-40
+"""
+import math
+import re
+
+import torch
+
+from . import ops
+
+CHUNK = 4096
+
+
+def build_chunk_table(sizes, chunk=CHUNK):
+    """int32 [n_chunks, 4] = (offset, length, tensor id, 0); a chunk never straddles two tensors."""
+    rows, off = [], 0
+    for tid, n in enumerate(sizes):
+        o = 0
+        while o < n:
+            ln = min(chunk, n - o)
+            rows.append((off + o, ln, tid, 0))
+            o += ln
+        off += n
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def vit_layer_id(name, depth):
+    """VisionTransformer.group_matcher (vit.py:311-320) via group_with_matcher(reverse=True)."""
+    if name in ("cls_token", "pos_embed") or name.startswith("patch_embed"):
+        return 0
+    m = re.match(r"^blocks\.(\d+)", name)
+    if m:
+        return int(m.group(1)) + 1
+    if name.startswith("norm"):
+        return depth            # MATCH_PREV_GROUP: shares the last block's id
+    return depth + 1            # head -> layer_max
+
+
+def layer_decay_hparams(names_shapes, depth, lr, weight_decay, layer_decay, no_weight_decay=("pos_embed", "cls_token")):
+    out = []
+    for name, shape in names_shapes:
+        scale = layer_decay ** (depth + 1 - vit_layer_id(name, depth)) if layer_decay != 1.0 else 1.0
+        wd = 0.0 if (len(shape) == 1 or name in no_weight_decay or name.endswith(".bias")) else weight_decay
+        out.append((scale * lr, wd))
+    return out
+
+
+def cosine_with_warmup(step, num_training_steps, num_warmup_steps=0, num_cycles=7.0 / 16.0):
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    t = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, math.cos(math.pi * num_cycles * t))
+
+
+class FusedAdamW:
+    """Optimizer + LambdaLR scheduler of the reference collapsed into one object (step() == optimizer.step();
+    scheduler.step(); model.zero_grad()).  ``state_dict`` keeps torch-compatible keys for checkpoints."""
+
+    def __init__(self, model, lr, weight_decay, layer_decay, num_train_iter, num_warmup_iter, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        dev = model.flat.device
+        ns = model.names_shapes
+        hp = layer_decay_hparams(ns, model.cfg.depth, lr, weight_decay, layer_decay)
+        self.lr_t = torch.tensor([h[0] for h in hp], dtype=torch.float32, device=dev)
+        self.wd_t = torch.tensor([h[1] for h in hp], dtype=torch.float32, device=dev)
+        self.table = build_chunk_table([int(torch.Size(s).numel()) for _, s in ns]).to(dev)
+        self.m = torch.zeros_like(model.flat)
+        self.v = torch.zeros_like(model.flat)
+        self.betas, self.eps = betas, eps
+        self.num_train_iter, self.num_warmup_iter = num_train_iter, num_warmup_iter
+        self.step_count = 0          # optimizer steps taken (bias correction)
+        self.sched_step = 0          # LambdaLR last_epoch
+        self.base_lr = lr
+
+    def lr_factor(self):
+        return cosine_with_warmup(self.sched_step, self.num_train_iter, self.num_warmup_iter)
+
+    def get_last_lr(self):
+        return [self.base_lr * self.lr_factor()]
+
+    def step(self, ema=None, ema_m=0.0, grad_scale=1.0):
+        self.step_count += 1
+        ops.adamw_flat(self.model.flat, self.model.grad, self.m, self.v, self.model.flat_bf16, ema, self.table,
+                       self.table.shape[0], self.lr_t, self.wd_t, self.lr_factor(), self.step_count, self.betas[0],
+                       self.betas[1], self.eps, ema_m=ema_m, grad_scale=grad_scale, zero_grad=True)
+        self.model.refresh_transposed()
+        self.sched_step += 1
+
+    def state_dict(self):
+        return dict(m=self.m.cpu(), v=self.v.cpu(), step=self.step_count, sched_step=self.sched_step)
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.step_count, self.sched_step = int(sd["step"]), int(sd["sched_step"])

@@ -1,0 +1,393 @@
+"""Per-kernel parity of libsrhip (through the C ABI) against fp32 references / the CPU oracle.  Needs a MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hooks_ref as H          # noqa: E402
+from oracle import optim_ref as O          # noqa: E402
+from oracle import semireward_ref as S     # noqa: E402
+from oracle import vit_ref as V            # noqa: E402
+from semireward_amd import ops             # noqa: E402
+from semireward_amd.utils import synth     # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32)).to(DEV)
+
+
+def bf(x):
+    return x.to(torch.bfloat16).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(16, 128, 64), (300, 256, 128), (24 * 257, 1152, 384), (4112, 384, 1536), (384, 1536, 4160), (130, 4, 64)])
+def test_gemm_epilogues(M, N, K):
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.1))
+    bias = rnd(N, seed=3)
+    ref = A.double().cpu() @ B.double().cpu().t()          # transposition-detecting: A, B are asymmetric random
+    refb = ref + bias.double().cpu()
+    # bf16 + bias
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(ops.EPI_BF16, A, B, C, M, N, K, bias=bias)
+    assert relerr(C, refb) < 4e-3
+    # GELU (+ pre-activation save)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(ops.EPI_GELU_BF16, A, B, C, M, N, K, bias=bias, aux_out=pre, ldaux=N)
+    assert relerr(C, gelu(refb)) < 5e-3 and relerr(pre, refb) < 4e-3
+    # residual + per-sample scale
+    rps = 4 if M % 4 == 0 else 1
+    sc = (torch.arange(M // rps, device=DEV) % 3).float() * 0.625
+    X0 = rnd(M, N, seed=4)
+    X = X0.clone()
+    ops.gemm_nt(ops.EPI_RESID_F32, A, B, X, M, N, K, bias=bias, row_scale=sc, rows_per_sample=rps)
+    want = X0.double().cpu() + sc.double().cpu().repeat_interleave(rps)[:, None] * refb
+    assert relerr(X, want) < 1e-5 + 2e-3 * float(refb.norm() / want.norm())
+    # residual, out-of-place source
+    X2 = torch.empty_like(X0)
+    ops.gemm_nt(ops.EPI_RESID_F32, A, B, X2, M, N, K, bias=bias, aux_in=X0, ldaux=N)
+    assert relerr(X2, X0.double().cpu() + refb) < 1e-5 + 2e-3 * float(refb.norm() / (X0.double().cpu() + refb).norm())
+    # dGELU
+    pin = bf(rnd(M, N, seed=5))
+    ops.gemm_nt(ops.EPI_DGELU_BF16, A, B, C, M, N, K, aux_in=pin, ldaux=N)
+    p = pin.double().cpu().requires_grad_(True)
+    gelu(p).sum().backward()
+    assert relerr(C, ref * p.grad) < 5e-3
+    # fp32 accumulate
+    G0 = rnd(M, N, seed=6)
+    G = G0.clone()
+    ops.gemm_nt(ops.EPI_F32, A, B, G, M, N, K, alpha=0.5, beta=1.0)
+    assert relerr(G, G0.double().cpu() + 0.5 * ref) < 1e-5
+    ops.gemm_nt(ops.EPI_F32, A, B, G, M, N, K, alpha=1.0, beta=0.0)
+    assert relerr(G, ref) < 1e-5
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric B: catches a swapped row/col C write that random-norm checks could hide."""
+    K = 128
+    A = torch.zeros(K, K, device=DEV)
+    A[torch.arange(K), torch.arange(K)] = 1
+    Bm = (torch.arange(256 * K, device=DEV).reshape(256, K) % 251).float() / 8
+    C = torch.empty(K, 256, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(ops.EPI_F32, bf(A), bf(Bm), C, K, 256, K)
+    assert torch.equal(C.cpu(), bf(Bm).float().cpu().t())
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(ops.EPI_F32, bf(A), bf(Bm), C, K, 256, 100)      # K % 64 != 0 -> error code, not a crash
+
+
+# ------------------------------------------------------------------------------------------------
+def attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q @ k.transpose(-2, -1)) * scale, dim=-1)
+    return (a @ v).transpose(1, 2).reshape(B * N, H * 64), torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 17, 2), (2, 197, 6), (4, 257, 6), (1, 64, 1), (2, 33, 3)])
+def test_attention_fwd_bwd(B, N, H):
+    D = H * 64
+    qkv = bf(rnd(B * N, 3 * D, seed=7, scale=1.5))
+    out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(qkv, out, lse, B, N, H, 0.125)
+    x = qkv.double().cpu().requires_grad_(True)
+    ro, rl = attn_ref(x, B, N, H, 0.125)
+    assert relerr(out, ro) < 6e-3
+    assert float((lse.double().cpu() - rl).abs().max()) < 2e-3
+    d_out = bf(rnd(B * N, D, seed=8))
+    ro.backward(d_out.double().cpu())
+    dqkv = torch.zeros(B * N, 3 * D, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    ops.attn_bwd(qkv, out, d_out, lse, dqkv, delta, B, N, H, 0.125)
+    g = x.grad
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert relerr(dqkv[:, sl], g[:, sl]) < 1.5e-2, name
+
+
+def test_attention_forced_large_scores():
+    """Spiked key: exercises the max-subtraction path with raw scores >> the rest (guide rule 26)."""
+    B, N, H = 1, 257, 1
+    qkv = bf(rnd(N, 192, seed=9))
+    qkv[5, :64] = 6.0
+    qkv[200, 64:128] = 6.0
+    out = torch.empty(N, 64, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd(qkv, out, None, B, N, H, 0.125)
+    ro, _ = attn_ref(qkv.double().cpu(), B, N, H, 0.125)
+    assert torch.isfinite(out.float()).all() and relerr(out, ro) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,D", [(7, 128), (4112, 384), (1000, 768)])
+def test_layernorm_fwd_bwd(M, D):
+    x, g, b = rnd(M, D, seed=10, scale=2.0) + 0.5, 1 + 0.1 * rnd(D, seed=11), 0.1 * rnd(D, seed=12)
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, g, b, 1e-6, out, mean, rstd, M, D)
+    xc = x.double().cpu().requires_grad_(True)
+    gc, bc = g.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xc, (D,), gc, bc, 1e-6)
+    assert relerr(out, ref) < 3e-3
+    assert float((mean.double().cpu() - xc.detach().mean(-1)).abs().max()) < 1e-5
+    dy = bf(rnd(M, D, seed=13))
+    ref.backward(dy.double().cpu())
+    dx0 = rnd(M, D, seed=14)
+    dx, dg, db = dx0.clone(), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy, x, mean, rstd, g, dx, dg, db, M, D)
+    assert relerr(dx - dx0, xc.grad) < 2e-5
+    assert relerr(dg, gc.grad) < 2e-5 and relerr(db, bc.grad) < 2e-5
+
+
+@pytest.mark.parametrize("cfgd", [V.VIT_TINY_TEST, V.VIT_SMALL_P2_32])
+def test_patch_embed_and_head(cfgd):
+    cfg = V.VitCfg(num_classes=10, **cfgd)
+    D, N, ps, HW = cfg.embed_dim, cfg.num_tokens, cfg.patch_size, cfg.img_size
+    P = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_params(V.param_shapes(cfg), 21).items()}
+    nimg, B = 5, 7
+    img = rnd(nimg, 3, HW, HW, seed=15)
+    idx = torch.tensor([0, 3, 1, 4, 4, 2, 0], dtype=torch.int32, device=DEV)
+    x = torch.empty(B, N, D, device=DEV)
+    ops.patch_embed_fwd(img, idx, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], P["cls_token"], P["pos_embed"], x,
+                        B, 3, HW, ps, D)
+    Pc = {k: v.double().cpu().requires_grad_(True) for k, v in P.items()}
+    sel = img.double().cpu()[idx.cpu().long()]
+    t = V.patchify(sel, ps) @ Pc["patch_embed.proj.weight"].reshape(D, -1).t() + Pc["patch_embed.proj.bias"]
+    t = torch.cat((Pc["cls_token"].expand(B, -1, -1), t), dim=1) + Pc["pos_embed"]
+    assert relerr(x, t) < 1e-6
+    dx = rnd(B, N, D, seed=16)
+    t.backward(dx.double().cpu())
+    dW, dbp = torch.zeros_like(P["patch_embed.proj.weight"]), torch.zeros(D, device=DEV)
+    dcls, dpos = torch.zeros(D, device=DEV), torch.zeros(N, D, device=DEV)
+    ops.patch_embed_bwd(dx, img, idx, dW, dbp, dcls, dpos, B, 3, HW, ps, D)
+    assert relerr(dW, Pc["patch_embed.proj.weight"].grad) < 1e-5 and relerr(dbp, Pc["patch_embed.proj.bias"].grad) < 1e-5
+    assert relerr(dcls, Pc["cls_token"].grad.reshape(-1)) < 1e-5 and relerr(dpos, Pc["pos_embed"].grad[0]) < 1e-5
+    # cls head
+    C = cfg.num_classes
+    feat, logits = torch.empty(B, D, device=DEV), torch.empty(B, C, device=DEV)
+    xhat, rstd = torch.empty(B, D, device=DEV), torch.empty(B, device=DEV)
+    ops.cls_head_fwd(x, P["norm.weight"], P["norm.bias"], 1e-6, P["head.weight"], P["head.bias"], feat, logits, xhat, rstd, B, N, D, C)
+    xc = x.double().cpu().requires_grad_(True)
+    f = torch.nn.functional.layer_norm(xc[:, 0], (D,), Pc["norm.weight"], Pc["norm.bias"], 1e-6)
+    lg = f @ Pc["head.weight"].t() + Pc["head.bias"]
+    assert relerr(feat, f) < 1e-6 and relerr(logits, lg) < 1e-6
+    dl = rnd(B, C, seed=17)
+    lg.backward(dl.double().cpu())
+    dxh = torch.zeros(B, N, D, device=DEV)
+    dWh, dbh = torch.zeros(C, D, device=DEV), torch.zeros(C, device=DEV)
+    dgn, dbn = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.cls_head_bwd(dl, P["head.weight"], P["norm.weight"], feat, xhat, rstd, dxh, dWh, dbh, dgn, dbn, B, N, D, C)
+    assert relerr(dxh, xc.grad) < 2e-5 and relerr(dWh, Pc["head.weight"].grad) < 1e-5 and relerr(dbh, Pc["head.bias"].grad) < 1e-5
+    assert relerr(dgn, Pc["norm.weight"].grad) < 1e-5 and relerr(dbn, Pc["norm.bias"].grad) < 1e-5
+
+
+def test_glue_kernels():
+    M, D, rps = 4112, 384, 257
+    x = rnd(M, D, seed=18)
+    sc = rnd(M // rps, seed=19)
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.cast_scale_rows(x, sc, rps, out, M, D)
+    assert torch.equal(out, (x * sc.repeat_interleave(rps)[:, None]).to(torch.bfloat16))
+    Mp = 4160
+    t = torch.full((D, Mp), 7.0, dtype=torch.bfloat16, device=DEV)
+    cs = torch.zeros(D, device=DEV)
+    ops.transpose_to_bf16(out, False, D, t, Mp, M, Mp, D, colsum=cs)
+    assert torch.equal(t[:, :M], out.t()) and float(t[:, M:].float().abs().max()) == 0.0
+    assert relerr(cs, out.float().sum(0)) < 1e-5
+    ops.transpose_to_bf16(out, False, D, t, Mp, M, Mp, D, apply_gelu=True)
+    assert relerr(t[:, :M], gelu(out.float().double()).t()) < 3e-3
+    w = rnd(384, 1536, seed=20)
+    wt = torch.empty(1536, 384, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_to_bf16(w, True, 1536, wt, 384, 384, 384, 1536)
+    assert torch.equal(wt, w.t().to(torch.bfloat16))
+    flat = rnd(100003, seed=22)
+    fb = torch.empty(100003, dtype=torch.bfloat16, device=DEV)
+    ops.cast_f32_bf16(flat, fb, flat.numel())
+    assert torch.equal(fb, flat.to(torch.bfloat16))
+    probs = torch.tensor(V.drop_path_probs(V.VitCfg(**V.VIT_SMALL_P2_32)), device=DEV)
+    dp = torch.empty(12, 2, 4096, device=DEV)
+    ops.droppath_fill(dp, probs, 12, 4096, 1234)
+    keep = 1 - probs.cpu().numpy()
+    vals = dp.cpu().numpy()
+    assert np.all(vals[0] == 1.0)
+    for l in range(1, 12):
+        nz = vals[l] != 0
+        assert np.allclose(vals[l][nz], 1 / keep[l]) and abs(nz.mean() - keep[l]) < 0.03
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["c10_w", "c100_w", "c10_nw", "c100_b256"])
+def test_flexmatch_score_filter_bit_exact(golden, tag):
+    """Golden probabilities from the reference -> masks / classwise_acc / selected_label must be bit-identical."""
+    g = golden("hooks")
+    C, U, Bu, steps, warm, seed = [int(v) for v in g[f"{tag}/meta"]]
+    sel = torch.full((U,), -1, dtype=torch.int64, device=DEV)
+    hist = torch.zeros(C + 1, dtype=torch.int32, device=DEV)
+    acc = torch.zeros(C, device=DEV)
+    ops.flexmatch_rebuild_hist(sel, hist, U, C)
+    mp, mi, mask, fm = torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV), torch.empty(Bu, device=DEV), torch.empty(Bu, device=DEV)
+    for t in range(steps):
+        probs = torch.from_numpy(g[f"{tag}/probs"][t]).to(DEV)
+        idx = torch.from_numpy(g[f"{tag}/idx"][t]).to(DEV)
+        ops.row_max(probs, True, None, mp, mi, Bu, C)
+        assert np.array_equal(mi.cpu().numpy(), g[f"{tag}/pseudo_label"][t])
+        ops.fixed_mask(mp, 0.95, fm, Bu)
+        assert np.array_equal(fm.cpu().numpy(), g[f"{tag}/fixed_mask"][t])
+        ops.flexmatch_mask(mp, mi, idx, 0.95, sel, hist, acc, mask, Bu, C, U, bool(warm))
+        assert np.array_equal(mask.cpu().numpy(), g[f"{tag}/mask"][t]), (tag, t)
+        assert np.array_equal(acc.cpu().numpy().view(np.uint32), g[f"{tag}/classwise_acc"][t].view(np.uint32)), (tag, t)
+    s = sel.cpu().numpy()
+    nz = np.nonzero(s != -1)[0]
+    assert np.array_equal(nz, g[f"{tag}/sel_idx"]) and np.array_equal(s[nz], g[f"{tag}/sel_val"])
+    h2 = torch.zeros_like(hist)
+    ops.flexmatch_rebuild_hist(sel, h2, U, C)
+    assert torch.equal(hist, h2)                      # incremental histogram == recount
+    # fused-softmax mode on logits: same argmax, max-prob within 2 ulp of the reference softmax
+    lg = torch.from_numpy(g[f"{tag}/logits"][0]).to(DEV)
+    po = torch.empty(Bu, C, device=DEV)
+    ops.row_max(lg, False, po, mp, mi, Bu, C)
+    ref = g[f"{tag}/probs"][0]
+    assert np.array_equal(mi.cpu().numpy(), ref.argmax(-1))
+    np.testing.assert_allclose(mp.cpu().numpy(), ref.max(-1), rtol=3e-7)
+    np.testing.assert_allclose(po.cpu().numpy(), ref, rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["b8_c100", "b64_c10", "b256_c100"])
+def test_masked_ce(golden, tag):
+    g = golden("losses")
+    lg = torch.from_numpy(g[f"{tag}/logits"]).to(DEV)
+    y = torch.from_numpy(g[f"{tag}/y"]).to(DEV)
+    m, m2 = torch.from_numpy(g[f"{tag}/mask"]).to(DEV), torch.from_numpy(g[f"{tag}/mask2"]).to(DEV)
+    B, C = lg.shape
+    loss, dl = torch.empty(1, device=DEV), torch.empty(B, C, device=DEV)
+    ops.masked_ce(lg, y, None, None, 1.0, loss, dl, B, C)
+    assert abs(float(loss) - float(g[f"{tag}/sup"])) < 2e-6
+    np.testing.assert_allclose(dl.cpu().numpy(), g[f"{tag}/sup_grad"], rtol=2e-5, atol=1e-8)
+    ops.masked_ce(lg, y, m, m2, 1.0, loss, dl, B, C)
+    assert abs(float(loss) - float(g[f"{tag}/unsup"])) < 2e-6
+    np.testing.assert_allclose(dl.cpu().numpy(), g[f"{tag}/unsup_grad"], rtol=2e-5, atol=1e-8)
+    ops.masked_ce(lg, y, m, None, 1.0, loss, None, B, C)
+    assert abs(float(loss) - float(g[f"{tag}/unsup_mask1"])) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+def flat_params(d, keys):
+    return torch.cat([torch.from_numpy(np.ascontiguousarray(d[k])).reshape(-1) for k in keys]).to(DEV)
+
+
+def unflat(flat, shapes):
+    out, o = {}, 0
+    for k, s in shapes.items():
+        n = int(np.prod(s))
+        out[k] = flat[o:o + n].reshape(s).cpu()
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("tag", ["f384_b8", "f128_b64", "f768_b16_c200"])
+def test_rewarder_generator(golden, tag):
+    g = golden("rewarder")
+    Fd, C, B, seed = [int(v) for v in g[f"{tag}/meta"]]
+    L = S.label_dim(C)
+    shapes = S.rewarder_shapes(Fd, C)
+    rp_np = synth.synth_params(shapes, seed)
+    gp_np = synth.synth_params(S.generator_shapes(Fd), seed + 100)
+    gp_np["fc_layers.6.bias"] = gp_np["fc_layers.6.bias"] + np.float32(2.6)
+    rp, gp = flat_params(rp_np, S.REWARDER_KEYS), flat_params(gp_np, S.GENERATOR_KEYS)
+    assert rp.numel() == ops.rewarder_param_count(Fd, L) and gp.numel() == ops.generator_param_count(Fd)
+    rng = np.random.Generator(np.random.PCG64(seed + 200))
+    feats = torch.from_numpy(rng.standard_normal((B, Fd)).astype(np.float32)).to(DEV)
+    labels = torch.from_numpy(rng.integers(0, C, size=(B,), dtype=np.int64)).to(DEV)
+    ws = torch.empty(ops.rewarder_ws_floats(1, B), device=DEV)
+    r = torch.empty(B, device=DEV)
+    ops.rewarder_fwd(rp, feats, labels, r, ws, 1, B, Fd, L)
+    np.testing.assert_allclose(r.cpu().numpy(), g[f"{tag}/reward"][:, 0], rtol=1e-5, atol=1e-6)   # stated fp tolerance for rewards
+    # mask2: bit-exact on the REFERENCE's rewards (integer thresholding parity)
+    m2, mean = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    ops.reward_mask2(torch.from_numpy(g[f"{tag}/reward"][:, 0]).to(DEV), m2, mean, 1, B)
+    assert np.array_equal(m2.cpu().numpy(), g[f"{tag}/mask2"])
+    # grouped launch == per-group launches
+    G = 3
+    fe3 = torch.cat([feats, feats.flip(0), feats * 0.5])
+    lb3 = torch.cat([labels, labels.flip(0), labels])
+    ws3 = torch.empty(ops.rewarder_ws_floats(G, B), device=DEV)
+    r3 = torch.empty(G * B, device=DEV)
+    ops.rewarder_fwd(rp, fe3, lb3, r3, ws3, G, B, Fd, L)
+    for gi in range(G):
+        ops.rewarder_fwd(rp, fe3[gi * B:(gi + 1) * B].contiguous(), lb3[gi * B:(gi + 1) * B].contiguous(), r, ws, 1, B, Fd, L)
+        assert torch.equal(r, r3[gi * B:(gi + 1) * B])
+    # generator
+    go, gl = torch.empty(B, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.generator_fwd(gp, feats, go, gl, B, Fd)
+    np.testing.assert_allclose(go.cpu().numpy(), g[f"{tag}/gen_out"][:, 0], rtol=1e-5, atol=2e-6)
+    assert np.array_equal(gl.cpu().numpy(), g[f"{tag}/gen_label"][:, 0])
+    # SR update: target, losses, grads, two Adam steps
+    tgt = torch.empty(B, device=DEV)
+    ops.sr_target(gl, labels, tgt, B)
+    assert np.array_equal(tgt.cpu().numpy(), g[f"{tag}/upd_target"][:, 0])
+    grads, m, v = torch.empty_like(rp), torch.zeros_like(rp), torch.zeros_like(rp)
+    losses = torch.empty(2, device=DEV)
+    for step in (1, 2):
+        ops.rewarder_fwd(rp, feats, gl, r, ws, 1, B, Fd, L, save_for_bwd=True)
+        ops.rewarder_bwd(rp, feats, gl, tgt, ws, grads, losses, B, Fd, L)
+        if step == 1:
+            np.testing.assert_allclose(r.cpu().numpy(), g[f"{tag}/upd_reward"][:, 0], rtol=1e-5, atol=1e-6)
+            assert abs(float(losses[0]) - float(g[f"{tag}/generator_loss"])) < 2e-6
+            assert abs(float(losses[1]) - float(g[f"{tag}/rewarder_loss"])) < 2e-6
+            gd = unflat(grads, shapes)
+            for k in S.REWARDER_KEYS:
+                if k == "cross_attention_fc.bias":
+                    assert float(gd[k].abs().max()) == 0.0           # analytically zero; see test_oracle_golden
+                    continue
+                gs = g.samp(f"{tag}/grad/{k}")
+                a = gd[k].numpy().ravel()[::gs["stride"]]
+                np.testing.assert_allclose(a, gs["sample"], rtol=5e-4, atol=1e-7 + 1e-4 * float(np.abs(gs["sample"]).max()), err_msg=k)
+        ops.adam_flat(rp, grads, m, v, rp.numel(), 5e-4, step)
+        pd = unflat(rp, shapes)
+        for k in S.REWARDER_KEYS:
+            if k == "cross_attention_fc.bias":
+                continue
+            gs = g.samp(f"{tag}/after{step}/{k}")
+            np.testing.assert_allclose(pd[k].numpy().ravel()[::gs["stride"]], gs["sample"], rtol=1e-5, atol=3e-5, err_msg=k)
+
+
+def test_adamw_flat_matches_oracle():
+    cfg = V.VitCfg(num_classes=10, **V.VIT_TINY_TEST)
+    from semireward_amd.optim import build_chunk_table
+    shapes = V.param_shapes(cfg)
+    P = synth.synth_params(shapes, 61)
+    hp = O.vit_param_hparams(shapes, cfg.depth, 5e-4, 5e-4, 0.5)
+    names = [n for n, _ in shapes]
+    flat = torch.cat([torch.from_numpy(P[n]).reshape(-1) for n in names]).to(DEV)
+    sizes = [int(np.prod(s)) for _, s in shapes]
+    table = build_chunk_table(sizes).to(DEV)
+    lr_t = torch.tensor([hp[n][0] for n in names], dtype=torch.float32, device=DEV)
+    wd_t = torch.tensor([hp[n][1] for n in names], dtype=torch.float32, device=DEV)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    pb, ema = torch.empty(flat.numel(), dtype=torch.bfloat16, device=DEV), flat.clone()
+    Pt = {k: torch.from_numpy(v_.copy()) for k, v_ in P.items()}
+    mo = {k: torch.zeros_like(v_) for k, v_ in Pt.items()}
+    vo = {k: torch.zeros_like(v_) for k, v_ in Pt.items()}
+    for step in range(4):
+        gr = synth.synth_params(shapes, 70 + step)
+        gflat = torch.cat([torch.from_numpy(gr[n]).reshape(-1) * 0.1 for n in names]).to(DEV)
+        fac = O.cosine_warmup_factor(step, 10, 2)
+        ops.adamw_flat(flat, gflat, m, v, pb, ema, table, table.shape[0], lr_t, wd_t, fac, step + 1, ema_m=0.9, zero_grad=True)
+        assert float(gflat.abs().max()) == 0.0
+        for k in names:
+            O.adamw_step(Pt[k], torch.from_numpy(gr[k]) * 0.1, mo[k], vo[k], step + 1, hp[k][0] * fac, hp[k][1])
+    want = torch.cat([Pt[n].reshape(-1) for n in names])
+    np.testing.assert_allclose(flat.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-8)
+    assert torch.equal(pb, flat.to(torch.bfloat16))
