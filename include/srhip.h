@@ -97,8 +97,10 @@ int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const
 int srhip_flexmatch_rebuild_hist(const long long* selected_label, int* hist, int ulb_dest_len, int C, void* stream);
 /* FixedThresholdingHook.masking (semilearn/algorithms/hooks/masking.py:42-57). */
 int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream);
-/* mask2 = (reward >= reward.mean()) per independent group of B rows (srflexmatch.py:100-101) (K11). */
-int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, int groups, int B, void* stream);
+/* mask2 = (reward >= reward.mean()) per independent group of B rows (srflexmatch.py:100-101) (K11).
+ * mean_in (optional, [groups]) overrides the local mean: data-parallel global-threshold extension. */
+int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, const float* mean_in, int groups, int B,
+                       void* stream);
 /* ce_loss / consistency_loss forward + analytic backward (semilearn/core/criterions/cross_entropy.py:11-31,
  * consistency.py:38-45): loss = mean_B(nll*mask*mask2); dlogits = grad_scale*(softmax-onehot)*mask*mask2/B. */
 int srhip_masked_ce(const float* logits, const long long* targets, const float* mask, const float* mask2, float grad_scale,

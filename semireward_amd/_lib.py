@@ -7,6 +7,10 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
 
+# torch must be imported BEFORE libsrhip.so is dlopen'ed: torch ships its own libamdhip64; if libsrhip pulled the
+# system copy in first the process would hold two HIP runtimes and our launches would see "no device" (hipError 100).
+import torch  # noqa: F401  (plumbing: device memory + streams)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsrhip.so")
 
@@ -31,7 +35,7 @@ SIGNATURES = {
     "srhip_flexmatch_mask": (I, [P, P, P, F, P, P, P, P, I, I, I, I, P]),
     "srhip_flexmatch_rebuild_hist": (I, [P, P, I, I, P]),
     "srhip_fixed_mask": (I, [P, F, P, I, P]),
-    "srhip_reward_mask2": (I, [P, P, P, I, I, P]),
+    "srhip_reward_mask2": (I, [P, P, P, P, I, I, P]),
     "srhip_masked_ce": (I, [P, P, P, P, F, P, P, I, I, P]),
     "srhip_rewarder_param_count": (L, [I, I]),
     "srhip_rewarder_ws_floats": (L, [I, I]),

@@ -1,0 +1,8 @@
+"""Importing this package registers the SemiReward algorithms under the reference's keys."""
+from ..core.registry import ALGORITHMS  # noqa: F401
+from .srflexmatch import SRFlexMatch  # noqa: F401
+
+
+def get_algorithm(args, net_builder, tb_log=None, logger=None):
+    """semilearn/algorithms/__init__.py:8-18."""
+    return ALGORITHMS[args.algorithm](args=args, net_builder=net_builder, tb_log=tb_log, logger=logger)

@@ -1,0 +1,195 @@
+"""SRFlexMatch (FlexMatch + SemiReward) on the HIP engine -- registered under the reference's key 'srflexmatch'.
+
+Reference: semilearn/algorithms/srflexmatch/srflexmatch.py (train_step :107-217, data_generator :72-104).
+Semantics reproduced exactly: control-flow thresholds on ``it``, K = sr_decay() extra
+backbone passes whose masking calls mutate the FlexMatch state, only the LAST pass's loss survives, per-rank reward
+mean, inert generator, no-op max_reward filter, stage-1 / stage-2 rewarder updates.
+
+What is restructured for MI355X -- results are unchanged because ViT rows are independent (no BatchNorm):
+  * the 1+K passes over the SAME 24 images are ONE batched forward of (1+K)*Bt rows, each (pass, image) row with
+    its own DropPath draw, instead of 1+K sequential launches trains at Bt=24;
+  * only rows whose logits enter the loss carry a backward graph: x_lb of pass 0 (sup loss) and x_ulb_s of the last
+    pass (unsup loss).  The reference back-propagates two full 24-row graphs whose other rows receive exactly zero
+    gradient; pruning them is an algebraic identity, not an approximation;
+  * softmax/argmax of all passes is one launch, the K rewarder scorings are one grouped launch, the FlexMatch
+    state updates stay sequential (they are order dependent) but never leave the device.
+"""
+import torch
+
+from .. import ops
+from ..core.algorithmbase import AlgorithmBase, DeferredScalar
+from ..core.registry import ALGORITHMS
+from .hooks import FlexMatchThresholdingHook, PseudoLabelingHook
+from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
+from .utils import SSL_Argument, str2bool
+
+
+class _Plan:
+    """Row bookkeeping for one (nl, nu, K): which (pass, image) rows need a backward graph."""
+
+    def __init__(self, nl, nu, K, device):
+        Bt = nl + 2 * nu
+        last = K
+        grad = [(0, j) for j in range(nl)] + [(last, j) for j in range(nl + nu, Bt)]
+        gset = set(grad)
+        inf = [(k, j) for k in range(K + 1) for j in range(Bt) if (k, j) not in gset]
+        t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
+        self.grad_cols = t([k * Bt + j for k, j in grad], torch.int64)
+        self.inf_cols = t([k * Bt + j for k, j in inf], torch.int64)
+        self.grad_img = t([j for _, j in grad], torch.int32)
+        self.inf_img = t([j for _, j in inf], torch.int32)
+        self.P, self.Bt = K + 1, Bt
+
+
+@ALGORITHMS.register("srflexmatch")
+class SRFlexMatch(AlgorithmBase):
+    def __init__(self, args, net_builder, tb_log=None, logger=None):
+        super().__init__(args, net_builder, tb_log, logger)
+        self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label, thresh_warmup=args.thresh_warmup)
+        self.N_k = args.N_k
+        # sr_ema != 0 selects EMARewarder in the reference (srflexmatch.py:49-50); its forward is identical and its EMA
+        # dict is never read, so one Rewarder class covers both.
+        self.rewarder = Rewarder(label_dim(self.num_classes), 128, args.feature_dim, device=self.device)
+        self.generator = Generator(args.feature_dim, device=self.device)
+        self.start_timing = args.start_timing
+        self.rewarder_optimizer = FlatAdam(self.rewarder, args.sr_lr)
+        self.generator_optimizer = None       # generator grads are None in the reference -> its Adam step is a no-op (A.1)
+        self.max_reward = torch.full((), -float("inf"), device=self.device)
+        self.dp.broadcast_params(self.model, self.rewarder, self.generator)
+        self._plans = {}
+        self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
+        self.inject_droppath = None            # tests: list of [depth,2,Bt] tensors, one per pass
+        self.trace = None                      # tests: dict filled with per-pass intermediates when not None
+
+    def init(self, T, p_cutoff, hard_label=True, thresh_warmup=True):
+        self.T, self.p_cutoff, self.use_hard_label, self.thresh_warmup = T, p_cutoff, hard_label, thresh_warmup
+
+    def set_hooks(self):
+        self.register_hook(PseudoLabelingHook(), "PseudoLabelingHook")
+        self.register_hook(FlexMatchThresholdingHook(ulb_dest_len=self.args.ulb_dest_len, num_classes=self.num_classes,
+                                                     thresh_warmup=self.args.thresh_warmup, device=self.device), "MaskingHook")
+        super().set_hooks()
+
+    # ---- batched (1+K)-pass forward ------------------------------------------------------------------
+    def _forward_passes(self, imgs, nl, nu, K):
+        key = (nl, nu, K)
+        if key not in self._plans:
+            self._plans[key] = _Plan(nl, nu, K, self.device)
+        pl = self._plans[key]
+        P, Bt, m = pl.P, pl.Bt, self.model
+        C, D = self.num_classes, m.cfg.embed_dim
+        if self.inject_droppath is not None:
+            dp_all = torch.cat([d.to(self.device) for d in self.inject_droppath[:P]], dim=2)       # [depth,2,P*Bt]
+        elif m.training and m.cfg.drop_path_rate > 0:
+            dp_all = m.make_droppath(P * Bt)
+        else:
+            dp_all = None
+        sel = (lambda cols: dp_all.index_select(2, cols).contiguous()) if dp_all is not None else (lambda cols: None)
+        logits = torch.empty(P * Bt, C, dtype=torch.float32, device=self.device)
+        feats = torch.empty(P * Bt, D, dtype=torch.float32, device=self.device)
+        ni = pl.inf_cols.numel()
+        step = self.infer_chunk if self.infer_chunk > 0 else ni
+        for s in range(0, ni, step):
+            cols = pl.inf_cols[s:s + step]
+            lg, ft, _ = m.forward_features(imgs, pl.inf_img[s:s + step].contiguous(), sel(cols), save=False)
+            logits.index_copy_(0, cols, lg)
+            feats.index_copy_(0, cols, ft)
+        lg, ft, ctx = m.forward_features(imgs, pl.grad_img, sel(pl.grad_cols), save=True)
+        logits.index_copy_(0, pl.grad_cols, lg)
+        feats.index_copy_(0, pl.grad_cols, ft)
+        return logits.view(P, Bt, C), feats.view(P, Bt, D), ctx
+
+    def _sr_update(self, feats, gen_labels, ref_labels):
+        """srflexmatch.py:179-193 / :194-208: target, MSE(r,1) + MSE(r,t), both backward() into the rewarder, Adam."""
+        feats = feats.contiguous()
+        target = cosine_target(gen_labels, ref_labels)
+        self.rewarder.train()
+        self.rewarder.score(feats, gen_labels, groups=1, save_for_bwd=True)
+        losses = torch.empty(2, dtype=torch.float32, device=self.device)
+        self.rewarder.backward_mse(feats, gen_labels, target, losses)
+        if self.dp.active:
+            self.dp.all_reduce_flat(self.rewarder.grad).mul_(1.0 / self.world_size)
+        self.rewarder_optimizer.step()
+        if self.trace is not None:
+            self.trace.update(sr_target=target, sr_losses=losses)
+
+    def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
+        assert self.use_cat, "USB-style SemiReward configs use use_cat=True (SURVEY.md Appendix C)"
+        nl, nu, it = y_lb.shape[0], x_ulb_w.shape[0], self.it
+        K = self.sr_decay() if it > self.start_timing else 0                                     # :147, :75
+        imgs = torch.cat((x_lb, x_ulb_w, x_ulb_s)).contiguous()                                  # :113
+        L, Fe, ctx = self._forward_passes(imgs, nl, nu, K)
+        P, C = K + 1, self.num_classes
+        hook = self.hooks_dict["MaskingHook"]
+        # softmax + max/argmax of the weak logits of ALL passes: one launch (compute_prob :135, argmax :142-146)
+        Lw = L[:, nl:nl + nu].reshape(P * nu, C)
+        mp = torch.empty(P * nu, dtype=torch.float32, device=self.device)
+        mi = torch.empty(P * nu, dtype=torch.int64, device=self.device)
+        ops.row_max(Lw, False, None, mp, mi, P * nu, C)
+        # masking is order dependent (it mutates selected_label / classwise_acc): pass 0 first, then the K loop passes
+        masks = [hook.masking_from_max(self, mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], idx_ulb) for k in range(P)]
+        pl0 = mi[:nu]
+        sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132
+        if K > 0:
+            self.rewarder.eval()                                                                  # :74
+            fw = Fe[1:, nl:nl + nu].reshape(K * nu, -1)
+            reward = self.rewarder.score(fw, mi[nu:], groups=K)                                    # :99
+            mask2 = torch.empty_like(reward)
+            mean_in = self.dp.reward_means(reward, K).contiguous() if (self.dp.global_reward_threshold and self.dp.active) else None
+            ops.reward_mask2(reward, mask2, None, K, nu, mean_in=mean_in)                          # :100-101
+            plK, mK, m2K = mi[K * nu:], masks[K], mask2[(K - 1) * nu:]
+            unsup_loss, dl_s = self.consistency_loss(L[K, nl + nu:], plK, "ce", mask=mK, mask2=m2K, grad_scale=self.lambda_u)   # :102
+        else:
+            reward = mask2 = None
+            unsup_loss, dl_s = self.consistency_loss(L[0, nl + nu:], pl0, "ce", mask=masks[0], grad_scale=self.lambda_u)        # :152
+        # ---- backbone backward: only the rows with a non-zero upstream gradient (see module docstring)
+        self.model.backward(ctx, torch.cat((dl_lb, dl_s)))
+        # ---- rewarder / generator training (:154-208)
+        fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
+        if it > 0:
+            if it >= self.start_timing:                                                           # :163
+                r0 = self.rewarder.score(fw0.contiguous(), pl0)                                   # :166
+                self.max_reward = torch.maximum(self.max_reward, r0.mean())                       # :167-170 (filter is a no-op, A.2)
+                if it % self.N_k == 0 and it > self.start_timing:                                 # :173
+                    self.max_reward = torch.full((), -float("inf"), device=self.device)
+                    gen2 = self.generator.forward_with_labels(fw0.contiguous())[1]                # :177-178
+                    self._sr_update(fw0, gen2, pl0)
+            else:
+                gen = self.generator.forward_with_labels(fx.contiguous())[1]                      # :158-159
+                self._sr_update(fx, gen, y_lb)                                                    # :194-208
+        total_loss = sup_loss + self.lambda_u * unsup_loss                                        # :210
+        if self.trace is not None:
+            self.trace.update(K=K, masks=masks, max_probs=mp, pseudo=mi, reward=reward, mask2=mask2, logits=L, feats=Fe)
+        feat_dict = {"x_lb": fx, "x_ulb_w": fw0, "x_ulb_s": Fe[0, nl + nu:]}
+        out_dict = self.process_out_dict(loss=total_loss, feat=feat_dict)
+        log_dict = self.process_log_dict(sup_loss=DeferredScalar(sup_loss), unsup_loss=DeferredScalar(unsup_loss),
+                                         total_loss=DeferredScalar(total_loss), util_ratio=DeferredScalar(masks[0].mean()))
+        return out_dict, log_dict
+
+    def get_save_dict(self):
+        d = super().get_save_dict()
+        d["classwise_acc"] = self.hooks_dict["MaskingHook"].classwise_acc.cpu()
+        d["selected_label"] = self.hooks_dict["MaskingHook"].selected_label.cpu()
+        # n4: the reference forgets the SR state on resume; keep it under extra keys
+        d["sr_rewarder"], d["sr_generator"] = self.rewarder.state_dict(), self.generator.state_dict()
+        d["sr_rewarder_optimizer"], d["sr_max_reward"] = self.rewarder_optimizer.state_dict(), float(self.max_reward)
+        return d
+
+    def load_model(self, load_path):
+        ck = super().load_model(load_path)
+        h = self.hooks_dict["MaskingHook"]
+        h.classwise_acc = ck["classwise_acc"].to(self.device)
+        h.selected_label = ck["selected_label"].to(self.device)
+        if "sr_rewarder" in ck:
+            self.rewarder.load_state_dict(ck["sr_rewarder"]); self.generator.load_state_dict(ck["sr_generator"])
+            self.rewarder_optimizer.load_state_dict(ck["sr_rewarder_optimizer"])
+            self.max_reward = torch.full((), ck["sr_max_reward"], device=self.device)
+        return ck
+
+    @staticmethod
+    def get_argument():
+        return [SSL_Argument("--hard_label", str2bool, True), SSL_Argument("--T", float, 0.5),
+                SSL_Argument("--p_cutoff", float, 0.95), SSL_Argument("--thresh_warmup", str2bool, True),
+                SSL_Argument("--start_timing", int, 20000), SSL_Argument("--feature_dim", int, 384),
+                SSL_Argument("--sr_lr", float, 0.0005), SSL_Argument("--N_k", int, 10),
+                SSL_Argument("--sr_ema", str2bool, True), SSL_Argument("--sr_ema_m", float, 0.999)]

@@ -1,0 +1,240 @@
+"""AlgorithmBase: the reference's plugin surface (semilearn/core/algorithmbase.py:49-606) on the HIP engine.
+
+Kept identical: constructor signature ``(args, net_builder, tb_log=None, logger=None)``, attribute names
+(model, ema_model, optimizer, scheduler, loader_dict, it, epoch, hooks_dict, ce_loss, consistency_loss ...),
+``process_batch`` (signature-driven kwargs filter, :282-306), ``train`` loop and hook dispatch (:346-375,
+:579-593), ``sr_decay`` (:177-183), ``get_save_dict`` / ``load_model`` keys (:459-547).
+Different by design: the backbone backward is fused into ``train_step`` (``out_dict['loss']`` is a
+detached scalar and ``model.grad`` is already populated), the optimizer + scheduler are one fused object, the EMA
+model is an alias when ``ema_m == 0``, and log scalars are fetched lazily (no per-step host sync).
+Datasets / loaders are out of scope (CPU input pipeline): ``train()`` consumes any iterable of (data_lb, data_ulb).
+"""
+import os
+from collections import OrderedDict
+from inspect import signature
+
+import torch
+
+from ..distributed import DataParallel
+from ..optim import FusedAdamW
+from .criterions import CELoss, ConsistencyLoss
+from .hooks import EMAHook, Hook, ParamUpdateHook, get_priority
+
+
+class DeferredScalar:
+    """A device scalar that becomes a python float on first use (float(), format, comparison).  The reference calls
+    .item() four times per step (srflexmatch.py:213-216): four host syncs.  LoggingHook only reads them every
+    num_log_iter steps, so the sync is deferred to that moment."""
+    __slots__ = ("_t", "_v")
+
+    def __init__(self, t):
+        self._t, self._v = t, None
+
+    def __float__(self):
+        if self._v is None:
+            self._v = float(self._t.item())
+            self._t = None
+        return self._v
+
+    def item(self):
+        return float(self)
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __add__(self, o): return float(self) + float(o)
+    __radd__ = __add__
+    def __mul__(self, o): return float(self) * float(o)
+    __rmul__ = __mul__
+    def __lt__(self, o): return float(self) < float(o)
+    def __gt__(self, o): return float(self) > float(o)
+    def __eq__(self, o): return float(self) == float(o)
+    def __hash__(self): return id(self)
+
+
+class AlgorithmBase:
+    def __init__(self, args, net_builder, tb_log=None, logger=None, **kwargs):
+        self.args = args
+        g = lambda k, d=None: getattr(args, k, d)   # noqa: E731  (yaml overlay: any key may or may not exist)
+        self.num_classes = args.num_classes
+        self.ema_m = g("ema_m", 0.0)
+        self.epochs = g("epoch", 1)
+        self.num_train_iter = args.num_train_iter
+        self.num_eval_iter = g("num_eval_iter", 0)
+        self.num_log_iter = g("num_log_iter", 0)
+        self.num_iter_per_epoch = int(self.num_train_iter // max(1, self.epochs))
+        self.lambda_u = g("ulb_loss_ratio", 1.0)
+        self.use_cat = g("use_cat", True)
+        self.use_amp = g("amp", False)       # the HIP engine always runs bf16 operands / fp32 accumulate
+        self.clip_grad = g("clip_grad", 0)
+        self.save_name, self.save_dir = g("save_name", "run"), g("save_dir", "./saved_models")
+        self.resume = g("resume", False)
+        self.algorithm = g("algorithm", None)
+        self.tb_log = tb_log
+        self.print_fn = print if logger is None else logger.info
+        self.gpu = g("gpu", None)
+        self.rank = g("rank", 0)
+        self.distributed = g("distributed", False)
+        self.world_size = g("world_size", 1)
+        self.device = torch.device("cuda", self.gpu if isinstance(self.gpu, int) else torch.cuda.current_device())
+        self.dp = DataParallel(self.world_size, self.rank, global_reward_threshold=g("global_reward_threshold", False))
+        self.it = 0
+        self.epoch = 0
+        self.start_epoch = 0
+        self.best_eval_metric, self.best_it = 0.0, 0
+        self.net_builder = net_builder
+        self.ema = None
+        self.dataset_dict = self.set_dataset()
+        self.loader_dict = self.set_data_loader()
+        self.model = self.set_model()
+        self.ema_model = self.set_ema_model()
+        self.optimizer, self.scheduler = self.set_optimizer()
+        self.ce_loss = CELoss()
+        self.consistency_loss = ConsistencyLoss()
+        self.task_type = "cls"
+        self._hooks = []
+        self.hooks_dict = OrderedDict()
+        self.set_hooks()
+
+    def init(self, **kwargs):
+        raise NotImplementedError
+
+    # ---- construction ---------------------------------------------------------------------------
+    def set_dataset(self):
+        return None          # CPU input pipeline is out of scope; batches come from the caller
+
+    def set_data_loader(self):
+        return None
+
+    def set_model(self):
+        model = self.net_builder(num_classes=self.num_classes, device=self.device)
+        model.refresh_operands()
+        return model
+
+    def set_ema_model(self):
+        if not self.ema_m:
+            return self.model        # ema_m == 0 -> shadow == params after every step (misc.py:152-155): alias, 0 bytes moved
+        ema = self.net_builder(num_classes=self.num_classes, device=self.device)
+        ema.load_state_dict(self.model.state_dict())
+        return ema
+
+    def set_optimizer(self):
+        a = self.args
+        assert getattr(a, "optim", "AdamW") == "AdamW", "the ViT/BERT SemiReward configs use AdamW (SGD: classic_cv row, later)"
+        opt = FusedAdamW(self.model, a.lr, getattr(a, "weight_decay", 0.0), getattr(a, "layer_decay", 1.0),
+                         self.num_train_iter, getattr(a, "num_warmup_iter", 0))
+        return opt, opt      # optimizer and scheduler are one fused object
+
+    def set_hooks(self):
+        self.register_hook(ParamUpdateHook(), None, "HIGHEST")
+        self.register_hook(EMAHook(), None, "HIGH")
+
+    # ---- batch / dict helpers (algorithmbase.py:282-333) -------------------------------------------
+    def process_batch(self, input_args=None, **kwargs):
+        if input_args is None:
+            input_args = list(signature(self.train_step).parameters.keys())
+        out = {}
+        for arg, var in kwargs.items():
+            if arg not in input_args or var is None:
+                continue
+            if isinstance(var, dict):
+                var = {k: v.to(self.device, non_blocking=True) for k, v in var.items()}
+            else:
+                var = var.to(self.device, non_blocking=True)
+            out[arg] = var
+        return out
+
+    def process_out_dict(self, out_dict=None, **kwargs):
+        out_dict = {} if out_dict is None else out_dict
+        out_dict.update(kwargs)
+        return out_dict
+
+    def process_log_dict(self, log_dict=None, prefix="train", **kwargs):
+        log_dict = {} if log_dict is None else log_dict
+        for k, v in kwargs.items():
+            log_dict[prefix + "/" + k] = v
+        return log_dict
+
+    def compute_prob(self, logits):
+        return torch.softmax(logits, dim=-1)     # API parity only; the hot path fuses softmax into srhip_row_max
+
+    def sr_decay(self, max_sampling_time=8):
+        """algorithmbase.py:177-183."""
+        return int(max(max_sampling_time, 1 + (self.num_train_iter / self.it)))
+
+    def train_step(self, *a, **k):
+        raise NotImplementedError
+
+    # ---- outer loop (algorithmbase.py:346-375) -------------------------------------------------------
+    def train(self, batches=None):
+        self.model.train()
+        self.call_hook("before_run")
+        for epoch in range(self.start_epoch, self.epochs):
+            self.epoch = epoch
+            if self.it >= self.num_train_iter:
+                break
+            self.call_hook("before_train_epoch")
+            src = batches if batches is not None else zip(self.loader_dict["train_lb"], self.loader_dict["train_ulb"])
+            for data_lb, data_ulb in src:
+                if self.it >= self.num_train_iter:
+                    break
+                self.call_hook("before_train_step")
+                self.out_dict, self.log_dict = self.train_step(**self.process_batch(**data_lb, **data_ulb))
+                self.call_hook("after_train_step")
+                self.it += 1
+            self.call_hook("after_train_epoch")
+        self.call_hook("after_run")
+
+    # ---- checkpoints (algorithmbase.py:459-547) ----------------------------------------------------------
+    def get_save_dict(self):
+        return {"model": self.model.state_dict(), "ema_model": self.ema_model.state_dict(),
+                "optimizer": self.optimizer.state_dict(), "scheduler": {"last_epoch": self.optimizer.sched_step},
+                "loss_scaler": {}, "it": self.it + 1, "epoch": self.epoch + 1, "best_it": self.best_it,
+                "best_eval_acc": self.best_eval_metric}
+
+    def save_model(self, save_name, save_path):
+        os.makedirs(save_path, exist_ok=True)
+        torch.save(self.get_save_dict(), os.path.join(save_path, save_name))
+
+    def load_model(self, load_path):
+        ck = torch.load(load_path, map_location="cpu")
+        self.model.load_state_dict(ck["model"])
+        if self.ema_model is not self.model:
+            self.ema_model.load_state_dict(ck["ema_model"])
+        self.it, self.start_epoch = ck["it"], ck["epoch"]
+        self.epoch, self.best_it = self.start_epoch, ck["best_it"]
+        self.best_eval_metric = ck.get("best_eval_acc", 0.0)
+        self.optimizer.load_state_dict(ck["optimizer"])
+        return ck
+
+    # ---- hooks (algorithmbase.py:548-599) ---------------------------------------------------------------------
+    def register_hook(self, hook, name=None, priority="NORMAL"):
+        assert isinstance(hook, Hook)
+        hook.priority = get_priority(priority)
+        hook.name = name if name is not None else type(hook).__name__
+        inserted = False
+        for i in range(len(self._hooks) - 1, -1, -1):
+            if hook.priority >= self._hooks[i].priority:
+                self._hooks.insert(i + 1, hook)
+                inserted = True
+                break
+        if not inserted:
+            self._hooks.insert(0, hook)
+        self.hooks_dict = OrderedDict((h.name, h) for h in self._hooks)
+
+    def call_hook(self, fn_name, hook_name=None, *args, **kwargs):
+        if hook_name is not None:
+            return getattr(self.hooks_dict[hook_name], fn_name)(self, *args, **kwargs)
+        for hook in self.hooks_dict.values():
+            if hasattr(hook, fn_name):
+                getattr(hook, fn_name)(self, *args, **kwargs)
+
+    def registered_hook(self, hook_name):
+        return hook_name in self.hooks_dict
+
+    @staticmethod
+    def get_argument():
+        return {}

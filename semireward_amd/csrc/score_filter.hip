@@ -123,11 +123,13 @@ __global__ void fixed_mask_kernel(const float* __restrict__ max_probs, float p_c
 // Mean: fp32, fixed order.  B <= 64: left-to-right (== torch CPU for the reference batch of 8);
 // larger B: per-lane strided partials then a fixed shuffle tree (deterministic).
 __global__ __launch_bounds__(64) void reward_mask2_kernel(const float* __restrict__ reward, float* __restrict__ mask2,
-                                                         float* __restrict__ mean_out, int B) {
+                                                         float* __restrict__ mean_out, const float* __restrict__ mean_in, int B) {
   const float* r = reward + (size_t)blockIdx.x * B;
   const int lane = threadIdx.x;
   float s;
-  if (B <= 64) {
+  if (mean_in) {                      // externally supplied threshold (data-parallel global mean extension)
+    s = mean_in[blockIdx.x] * (float)B;
+  } else if (B <= 64) {
     s = 0.f;
     for (int i = 0; i < B; ++i) s += r[i];
   } else {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void reward_mask2_kernel(const float* __restric
     for (int i = lane; i < B; i += 64) p += r[i];
     s = wave_sum(p);
   }
-  const float mean = s / (float)B;
+  const float mean = mean_in ? mean_in[blockIdx.x] : s / (float)B;
   for (int i = lane; i < B; i += 64) mask2[(size_t)blockIdx.x * B + i] = r[i] >= mean ? 1.0f : 0.0f;
   if (mean_out && lane == 0) mean_out[blockIdx.x] = mean;
 }
@@ -222,9 +224,10 @@ extern "C" int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* m
   return SR_OK;
 }
 
-extern "C" int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, int groups, int B, void* stream) {
+extern "C" int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, const float* mean_in, int groups, int B,
+                                  void* stream) {
   if (groups <= 0 || B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(reward_mask2_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, reward, mask2, mean_out, B);
+  hipLaunchKernelGGL(reward_mask2_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, reward, mask2, mean_out, mean_in, B);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

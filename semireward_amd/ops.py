@@ -98,8 +98,8 @@ def fixed_mask(max_probs, p_cutoff, mask, B):
     _call("srhip_fixed_mask", _p(max_probs), p_cutoff, _p(mask), B, _s())
 
 
-def reward_mask2(reward, mask2, mean_out, groups, B):
-    _call("srhip_reward_mask2", _p(reward), _p(mask2), _p(mean_out), groups, B, _s())
+def reward_mask2(reward, mask2, mean_out, groups, B, mean_in=None):
+    _call("srhip_reward_mask2", _p(reward), _p(mask2), _p(mean_out), _p(mean_in), groups, B, _s())
 
 
 def masked_ce(logits, targets, mask, mask2, grad_scale, loss_out, dlogits, B, C):
