@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""bench.py -- unlabeled images/s of the SemiReward hot path (SRFlexMatch, ViT-S/2, CIFAR-100 shapes) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one reference-semantics training iteration in the steady SR regime (it > start_timing, K = sr_decay() = 8
+extra backbone passes, rewarder update every N_k = 10 steps): SRFlexMatch.train_step (batched (1+K)-pass forward,
+score filter, rewarder scoring, masked losses, hand-written backward) + ParamUpdateHook (gradient all-reduce when
+N > 1, fused AdamW / scheduler / zero_grad).  Inputs are synthetic (seeded N(0,1) images), resident
+in HBM before the timed region; weights are random-init of the reference architecture.
+Workload = BASELINE.json configs[1]: config/SemiReward/usb_cv/flexmatch/flexmatch_cifar100_200_0.yaml
+(per-GPU batch 8 labelled + 8 weak + 8 strong).  ``--bu`` scales the per-GPU batch for the throughput variant.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NS = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, epoch=200, ema_m=0.0, ulb_loss_ratio=1.0,
+          use_cat=True, amp=False, lr=5e-4, weight_decay=5e-4, layer_decay=0.5, num_warmup_iter=5120, optim="AdamW",
+          T=0.5, p_cutoff=0.95, hard_label=True, thresh_warmup=True, ulb_dest_len=50000, N_k=10, start_timing=20000,
+          feature_dim=384, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99)
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (the 5 PF headline is 2:1 sparse)
+START_IT = 30000                          # it >= 25601 -> sr_decay() == 8 (88 % of the reference run)
+
+
+def cpu_baseline(bl, bu):
+    """Reference-semantics step on the host cores, timed on a bounded sample with the CPU oracle (kind = 'port'):
+    one (Bl+2Bu)-image ViT-S/2 pass with autograd graph is timed (fwd) together with the backward of two such graphs
+    and one AdamW sweep; the K=8 step time is (1+K)*t_fwd + t_bwd2 + t_opt, exactly the reference's work per step."""
+    from oracle import hooks_ref as H
+    from oracle import optim_ref as O
+    from oracle import vit_ref as V
+    from semireward_amd.utils import synth
+    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.synth_params(V.param_shapes(cfg), 0).items()}
+    b = synth.synth_batch(0, bl, bu, 32, 100, 50000)
+    x = torch.from_numpy(np.concatenate([b["x_lb"], b["x_ulb_w"], b["x_ulb_s"]]))
+    y = torch.from_numpy(np.concatenate([b["y_lb"], b["y_lb"][:1].repeat(2 * bu)]))
+    dp = torch.from_numpy(synth.synth_droppath(1, V.drop_path_probs(cfg), x.shape[0]))
+    V.vit_forward(P, x[:2], cfg, dp[:, :, :2])                       # warm the allocator / threads
+    t0 = time.perf_counter()
+    o1 = V.vit_forward(P, x, cfg, dp)
+    o2 = V.vit_forward(P, x, cfg, dp)
+    t1 = time.perf_counter()
+    (H.ce_loss_mean(o1["logits"], y) + H.ce_loss_mean(o2["logits"], y)).backward()
+    t2 = time.perf_counter()
+    hp = O.vit_param_hparams(V.param_shapes(cfg), cfg.depth, 5e-4, 5e-4, 0.5)
+    with torch.no_grad():
+        for k, p in P.items():
+            O.adamw_step(p, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1, hp[k][0], hp[k][1])
+    t3 = time.perf_counter()
+    t_fwd, t_bwd2, t_opt = (t1 - t0) / 2, t2 - t1, t3 - t2
+    K = 8
+    t_step = (1 + K) * t_fwd + t_bwd2 + t_opt
+    return {"value": bu / t_step, "unit": "unlabeled images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle ViT-S/2 fp32, Bt=%d: 2 graph forwards (%.2fs each) + backward of both (%.2fs) + AdamW (%.2fs); "
+                      "K=8 step = 9*fwd + bwd + opt = %.1fs" % (x.shape[0], t_fwd, t_bwd2, t_opt, t_step)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bu", type=int, default=8, help="per-GPU unlabeled batch (reference yaml: 8, uratio 1)")
+    ap.add_argument("--bl", type=int, default=0, help="per-GPU labelled batch (default = --bu, uratio 1)")
+    ap.add_argument("--regime", choices=["sr", "pre"], default="sr", help="sr: it > start_timing (K=8); pre: K=0")
+    ap.add_argument("--infer-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+    bl = a.bl or a.bu
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1 and a.gpus == 1, "launch N>1 with torch.distributed.run --nproc-per-node N"
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from semireward_amd import ops
+    from semireward_amd.algorithms import get_algorithm
+    from semireward_amd.nets import vit
+    from semireward_amd.utils import synth
+
+    args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **NS)
+    alg = get_algorithm(args, vit.vit_small_patch2_32)
+    P = synth.synth_params(alg.model.names_shapes, 0)
+    alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
+    alg.model.seed = 1234 + rank
+    b = synth.synth_batch(100 + rank, bl, a.bu, 32, 100, 50000)            # each rank: its own shard of the unlabeled stream
+    batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+    alg.it = START_IT if a.regime == "sr" else 1000
+    alg.optimizer.sched_step = alg.it
+    alg.model.train()
+
+    def step():
+        alg.out_dict, alg.log_dict = alg.train_step(**batch)
+        alg.call_hook("after_train_step")
+        alg.it += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    prof = None if a.no_roofline else ops.enable_gemm_profile()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.disable_gemm_profile()
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    K = alg.sr_decay() if a.regime == "sr" else 0
+    if rank == 0:
+        out = {"metric": "unlabeled images/sec/node (FlexMatch+SR, ViT-S CIFAR-100)", "value": world * a.bu * a.steps / dt,
+               "unit": "unlabeled images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, steady SR regime"
+                                      if a.regime == "sr" else "SRFlexMatch ViT-S/2@32, pre-start_timing regime",
+                          "per_gpu_batch": {"lb": bl, "ulb_w": a.bu, "ulb_s": a.bu}, "K_passes": K,
+                          "forward_image_passes_per_step": (1 + K) * (bl + 2 * a.bu), "backward_images_per_step": bl + a.bu,
+                          "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
+                          "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
+        if prof is not None:
+            fl, ms, n = prof.totals()
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all epilogues)", "bound": "mfma", "achieved": ach,
+                               "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                               "traffic": None, "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1),
+                               "gemm_share_of_step": ms / (1e3 * dt)}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(bl, a.bu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

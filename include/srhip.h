@@ -25,7 +25,7 @@ extern "C" {
  * Replaces nn.Linear forward/backward of the backbone:
  *   qkv / proj   semilearn/nets/vit/vit.py:93-98, :105          (K3, K5)
  *   fc1 / fc2    semilearn/nets/vit/vit.py:69-75                (K6)
- * Requirements: K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc % 4 == 0.
+ * Requirements: K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.
  */
 enum {
   SRHIP_EPI_BF16 = 0,       /* C(bf16) = acc + bias                                              */
@@ -114,14 +114,21 @@ int srhip_masked_ce(const float* logits, const long long* targets, const float* 
 long srhip_rewarder_param_count(int F, int L);
 long srhip_rewarder_ws_floats(int G, int B);
 long srhip_generator_param_count(int F);
-int srhip_rewarder_fwd(const float* params, const float* feats, const long long* labels, float* reward, float* ws, int G,
-                       int B, int F, int L, int save_for_bwd, void* stream);
+/* params_t: transposed copies of the 2-D weights, streamed coalesced by the forward kernels; size
+ * srhip_rewarder_t_floats(F) / srhip_generator_t_floats(F); refresh with *_prepare after every parameter change. */
+long srhip_rewarder_t_floats(int F);
+long srhip_generator_t_floats(int F);
+int srhip_rewarder_prepare(const float* params, float* params_t, int F, int L, void* stream);
+int srhip_generator_prepare(const float* params, float* params_t, int F, void* stream);
+int srhip_rewarder_fwd(const float* params, const float* params_t, const float* feats, const long long* labels, float* reward,
+                       float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream);
 /* Gradient of MSE(r,1) + MSE(r,target) w.r.t. every rewarder parameter (srflexmatch.py:183-190 / :198-205);
  * grads is overwritten; losses[0..1] = (generator_loss, rewarder_loss) when non-NULL. */
 int srhip_rewarder_bwd(const float* params, const float* feats, const long long* labels, const float* target, float* ws,
                        float* grads, float* losses, int B, int F, int L, void* stream);
 /* Generator.forward (semireward.py:21-24) and the .long() cast (srflexmatch.py:158-159). */
-int srhip_generator_fwd(const float* params, const float* x, float* out, long long* label, int B, int F, void* stream);
+int srhip_generator_fwd(const float* params, const float* params_t, const float* x, float* out, long long* label, int B, int F,
+                        void* stream);
 /* (cosine_similarity_n(one_hot, one_hot)+1)/2 (semireward.py:130-139, srflexmatch.py:180-182): 1.0 / 0.5. */
 int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, void* stream);
 /* torch.optim.Adam step on a flat block (srflexmatch.py:54, :192-193). */

@@ -40,9 +40,13 @@ SIGNATURES = {
     "srhip_rewarder_param_count": (L, [I, I]),
     "srhip_rewarder_ws_floats": (L, [I, I]),
     "srhip_generator_param_count": (L, [I]),
-    "srhip_rewarder_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_rewarder_t_floats": (L, [I]),
+    "srhip_generator_t_floats": (L, [I]),
+    "srhip_rewarder_prepare": (I, [P, P, I, I, P]),
+    "srhip_generator_prepare": (I, [P, P, I, P]),
+    "srhip_rewarder_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_rewarder_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
-    "srhip_generator_fwd": (I, [P, P, P, P, I, I, P]),
+    "srhip_generator_fwd": (I, [P, P, P, P, P, I, I, P]),
     "srhip_sr_target": (I, [P, P, P, I, P]),
     "srhip_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P]),
     "srhip_adamw_flat": (I, [P, P, P, P, P, P, P, I, P, P, F, F, F, F, I, F, F, I, P]),

@@ -83,6 +83,16 @@ class Generator(_FlatModule):
         super().__init__(shapes, device, seed)
         self.feature_dim = feature_dim
         assert self.flat.numel() == ops.generator_param_count(feature_dim)
+        self.flat_t = torch.empty(ops.generator_t_floats(feature_dim), dtype=torch.float32, device=self.device)
+        self.prepare()
+
+    def prepare(self):
+        """refresh the transposed weight copies the forward kernel streams (after any parameter change)"""
+        ops.generator_prepare(self.flat, self.flat_t, self.feature_dim)
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.prepare()
 
     def __call__(self, x):
         """Returns the [B,1] fp32 output, like the reference module."""
@@ -92,7 +102,7 @@ class Generator(_FlatModule):
         B = x.shape[0]
         out = torch.empty(B, dtype=torch.float32, device=self.device)
         lab = torch.empty(B, dtype=torch.int64, device=self.device)
-        ops.generator_fwd(self.flat, x.contiguous(), out, lab, B, self.feature_dim)
+        ops.generator_fwd(self.flat, self.flat_t, x.contiguous(), out, lab, B, self.feature_dim)
         return out, lab
 
 
@@ -113,6 +123,16 @@ class Rewarder(_FlatModule):
         assert self.flat.numel() == ops.rewarder_param_count(F, L)
         self.grad = torch.zeros_like(self.flat)
         self._ws = {}
+        self.flat_t = torch.empty(ops.rewarder_t_floats(F), dtype=torch.float32, device=self.device)
+        self.prepare()
+
+    def prepare(self):
+        """refresh the transposed weight copies the forward kernels stream (after any parameter change)"""
+        ops.rewarder_prepare(self.flat, self.flat_t, self.feature_dim, self.label_dim)
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.prepare()
 
     def _workspace(self, G, B):
         key = (G, B)
@@ -125,7 +145,7 @@ class Rewarder(_FlatModule):
         R = features.shape[0]
         B = R // groups
         reward = torch.empty(R, dtype=torch.float32, device=self.device)
-        ops.rewarder_fwd(self.flat, features.contiguous(), label_indices.contiguous(), reward, self._workspace(groups, B),
+        ops.rewarder_fwd(self.flat, self.flat_t, features.contiguous(), label_indices.contiguous(), reward, self._workspace(groups, B),
                          groups, B, self.feature_dim, self.label_dim, save_for_bwd)
         return reward
 
@@ -153,6 +173,7 @@ class FlatAdam:
     def step(self):
         self.steps += 1
         ops.adam_flat(self.module.flat, self.module.grad, self.m, self.v, self.module.flat.numel(), self.lr, self.steps)
+        self.module.prepare()
 
     def state_dict(self):
         return dict(m=self.m.cpu(), v=self.v.cpu(), steps=self.steps)

@@ -6,10 +6,12 @@
 //   SR update block    semilearn/algorithms/srflexmatch/srflexmatch.py:180-208  (two MSE losses, two backward(),
 //                      Adam(lr=sr_lr) -- the generator's step is a no-op: its graph is cut by .long())
 //
-// Everything is fp32 (136 962 parameters, batches of 8..256 rows): latency-bound, so the design is
-// "one wave per row, activations in LDS, weights streamed coalesced from L2, wave-shuffle reductions"
-// and -- the part that matters for the K-pass scoring loop -- ALL independent groups (the K passes of
-// one training step, each with its own softmax over its 2B rows) go through ONE launch.
+// Everything is fp32 (136 962 parameters, batches of 8..256 rows): latency-bound.  Forward design: a tile of
+// 8 rows per workgroup sits transposed in LDS, every thread owns one output column and streams the TRANSPOSED
+// weight matrix coalesced from L2 (8 FMAs per 4-byte load, no cross-lane reduction, loads independent of each
+// other so they pipeline) -- the first version used one wave-reduction per output and was 25x slower because
+// 449 dependent L2 round trips were serialised.  ALL independent groups (the K passes of one training step, each
+// with its own softmax over its 2B rows) go through ONE launch pair.
 // Parameter block: flat fp32 in the reference's named_parameters() order (offsets in RewOff).
 #include "common.h"
 #include "srhip.h"
@@ -53,20 +55,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// y[j] = act( sum_k x[k] * W[j*K + k] + b[j] ), x and y in LDS owned by this wave.  ACT: 0 none, 1 relu
-template <int ACT>
-__device__ __forceinline__ void wave_linear(const float* __restrict__ W, const float* __restrict__ b, const float* x, float* y,
-                                            int J, int K, int lane) {
-  for (int j = 0; j < J; ++j) {
-    const float* w = W + (size_t)j * K;
-    float a = 0.f;
-    for (int k = lane; k < K; k += 64) a += x[k] * w[k];
-    a = wave_sum(a);
-    if (lane == 0) { a += b[j]; y[j] = (ACT == 1) ? fmaxf(a, 0.f) : a; }
-  }
-  wave_lds_sync();
-}
-
 // 128-wide LayerNorm of the two values per lane (j = lane, lane + 64); eps 1e-5 (nn.LayerNorm default)
 __device__ __forceinline__ void wave_ln128(float v0, float v1, const float* g, const float* b, int lane, float& o0, float& o1,
                                            float& xh0, float& xh1, float& rs) {
@@ -78,65 +66,136 @@ __device__ __forceinline__ void wave_ln128(float v0, float v1, const float* g, c
   o1 = xh1 * g[lane + 64] + b[lane + 64];
 }
 
-// Kernel 1: rows 0..B-1 of a group = feature rows, B..2B-1 = label rows.  One wave per row.
-// grid = (ceil(2B/4), G), block 256.
-__global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict__ P, const float* __restrict__ feats,
-                                                       const long long* __restrict__ labels, float* __restrict__ ws,
-                                                       int G, int B, int F, int L, int save) {
-  const RewOff o(F, L);
-  const RewWs w(G, B);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave, grp = blockIdx.y;
-  if (row >= 2 * B) return;
-  float v0, v1;
-  const float *gam, *bet;
-  if (row < B) {
-    const float* x = feats + ((size_t)grp * B + row) * F;
-    float xr[16];                                   // F <= 1024
-#pragma unroll
-    for (int i = 0; i < 16; ++i) xr[i] = (i * 64 + lane < F) ? x[i * 64 + lane] : 0.f;
-    v0 = 0.f; v1 = 0.f;
-    for (int j = 0; j < E; ++j) {
-      const float* wr = P + o.Wf + (size_t)j * F;
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (i * 64 < F) a += (i * 64 + lane < F) ? xr[i] * wr[i * 64 + lane] : 0.f;
-      a = wave_sum(a) + P[o.bf + j];
-      if ((j & 63) == lane) { if (j < 64) v0 = a; else v1 = a; }
-    }
-    gam = P + o.gf; bet = P + o.bef;
-  } else {
-    const long long y = labels[(size_t)grp * B + (row - B)];
-    const float* e = P + o.Emb + (size_t)y * E;
-    v0 = e[lane]; v1 = e[lane + 64];
-    gam = P + o.gl; bet = P + o.bl;
+// ---- transposed-weight block (built by srhip_rewarder_prepare / srhip_generator_prepare) -------------------
+// The forward streams W^T[k][j] so that consecutive threads (outputs j) read consecutive addresses while a
+// tile of 8 input rows sits in LDS: 8 FMAs per 4-byte weight load, no cross-lane reductions at all.
+struct RewTOff {
+  int WfT, W1T, W2T, W3T, total;
+  __host__ __device__ RewTOff(int F) {
+    int o = 0;
+    WfT = o; o += F * E; W1T = o; o += E * 256; W2T = o; o += 256 * E; W3T = o; o += E * 64;
+    total = o;
   }
-  float z0, z1, xh0, xh1, rs;
-  wave_ln128(v0, v1, gam, bet, lane, z0, z1, xh0, xh1, rs);
-  const size_t zr = ((size_t)grp * 2 * B + row);
-  ws[w.z + zr * E + lane] = z0;
-  ws[w.z + zr * E + lane + 64] = z1;
-  const float s = wave_sum(z0 * P[o.wa + lane] + z1 * P[o.wa + lane + 64]) + P[o.ba];
-  if (lane == 0) ws[w.slog + zr] = s;
-  if (save) {
-    ws[w.xhat + zr * E + lane] = xh0;
-    ws[w.xhat + zr * E + lane + 64] = xh1;
-    if (lane == 0) ws[w.rstd + zr] = rs;
+};
+struct GenTOff {
+  int W1T, W2T, W3T, total;
+  __host__ __device__ GenTOff(int F) {
+    int o = 0;
+    W1T = o; o += F * 256; W2T = o; o += 256 * 128; W3T = o; o += 128 * 64;
+    total = o;
+  }
+};
+
+constexpr int RT = 8;   // rows per workgroup tile
+
+// yT[j][r] = act(b[j] + sum_k xT[k][r] * WT[k*J + j]), r < 8.  256 threads; the k-range is split over 256/J
+// thread groups and combined through `scratch` (>= 256*8 floats).  xT / yT: LDS, [*][8] row-tile-transposed.
+template <int J, int ACT>
+__device__ __forceinline__ void tile_linear(const float* __restrict__ WT, const float* __restrict__ b, const float* xT, float* yT,
+                                            float* scratch, int K) {
+  constexpr int NP = 256 / J;
+  const int t = threadIdx.x, j = t % J, part = t / J;
+  const int kc = (K + NP - 1) / NP, k0 = part * kc, k1 = min(K, k0 + kc);
+  float acc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+#pragma unroll 4
+  for (int k = k0; k < k1; ++k) {
+    const float w = WT[(size_t)k * J + j];
+    const float4 xa = *reinterpret_cast<const float4*>(xT + k * RT), xb = *reinterpret_cast<const float4*>(xT + k * RT + 4);
+    acc[0] += w * xa.x; acc[1] += w * xa.y; acc[2] += w * xa.z; acc[3] += w * xa.w;
+    acc[4] += w * xb.x; acc[5] += w * xb.y; acc[6] += w * xb.z; acc[7] += w * xb.w;
+  }
+  if (NP > 1) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RT; ++r) scratch[(part * J + j) * RT + r] = acc[r];
+    __syncthreads();
+    if (part == 0) {
+      for (int q = 1; q < NP; ++q)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] += scratch[(q * J + j) * RT + r];
+    }
+  }
+  if (part == 0) {
+    const float bj = b[j];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const float v = acc[r] + bj;
+      yT[j * RT + r] = (ACT == 1) ? fmaxf(v, 0.f) : v;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void transpose_small_kernel(const float* __restrict__ W, float* __restrict__ WT, int J, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // W [J][K] -> WT [K][J]
+  if (i < J * K) { const int j = i / K, k = i % K; WT[(size_t)k * J + j] = W[i]; }
+}
+
+// Kernel 1: a tile of 8 feature rows AND the matching 8 label rows of one group.
+// feature_fc (F->128) through tile_linear, then one wave per 2 rows for the two LayerNorms and the attention logit.
+// grid = (ceil(B/8), G), block 256, dyn LDS = (F*8 + 128*8 + 256*8) floats.
+__global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                       const float* __restrict__ feats, const long long* __restrict__ labels,
+                                                       float* __restrict__ ws, int G, int B, int F, int L, int save) {
+  const RewOff o(F, L);
+  const RewTOff ot(F);
+  const RewWs w(G, B);
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xT = sm;                  // [F][8]
+  float* hT = xT + F * RT;         // [128][8]
+  float* scratch = hT + E * RT;    // [256*8]
+  const int grp = blockIdx.y, r0 = blockIdx.x * RT;
+  for (int e = threadIdx.x; e < F * RT; e += 256) {
+    const int r = e / F, k = e % F;
+    xT[k * RT + r] = (r0 + r < B) ? feats[((size_t)grp * B + r0 + r) * F + k] : 0.f;
+  }
+  __syncthreads();
+  tile_linear<E, 0>(PT + ot.WfT, P + o.bf, xT, hT, scratch, F);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int q = wave; q < 2 * RT; q += 4) {           // q < 8: feature row q ; q >= 8: label row q - 8
+    const int r = q & (RT - 1), row = r0 + r;
+    if (row >= B) continue;
+    float v0, v1;
+    const float *gam, *bet;
+    if (q < RT) {
+      v0 = hT[lane * RT + r]; v1 = hT[(lane + 64) * RT + r];
+      gam = P + o.gf; bet = P + o.bef;
+    } else {
+      const long long y = labels[(size_t)grp * B + row];
+      const float* e = P + o.Emb + (size_t)y * E;
+      v0 = e[lane]; v1 = e[lane + 64];
+      gam = P + o.gl; bet = P + o.bl;
+    }
+    float z0, z1, xh0, xh1, rs;
+    wave_ln128(v0, v1, gam, bet, lane, z0, z1, xh0, xh1, rs);
+    const size_t zr = (size_t)grp * 2 * B + (q < RT ? row : B + row);
+    ws[w.z + zr * E + lane] = z0;
+    ws[w.z + zr * E + lane + 64] = z1;
+    const float s = wave_sum(z0 * P[o.wa + lane] + z1 * P[o.wa + lane + 64]) + P[o.ba];
+    if (lane == 0) ws[w.slog + zr] = s;
+    if (save) {
+      ws[w.xhat + zr * E + lane] = xh0;
+      ws[w.xhat + zr * E + lane + 64] = xh1;
+      if (lane == 0) ws[w.rstd + zr] = rs;
+    }
   }
 }
 
-// Kernel 2: softmax over the group's 2B logits, context vector, then the per-row MLP/FFN head.
-// grid = (ceil(B/4), G), block 256 (one wave per row).  Every workgroup re-derives the group context
-// (2B x 128 reads) instead of paying a third launch.
-__global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict__ P, float* __restrict__ ws, float* __restrict__ reward,
+// Kernel 2: softmax over the group's 2B logits, context vector, then the MLP/FFN head for a tile of 8 rows.
+// grid = (ceil(B/8), G), block 256.  Every workgroup re-derives the group context (2B x 128 reads) instead of
+// paying a third launch.
+__global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                       float* __restrict__ ws, float* __restrict__ reward,
                                                        int G, int B, int F, int L, int save) {
   const RewOff o(F, L);
+  const RewTOff ot(F);
   const RewWs w(G, B);
   __shared__ float ctx[E];
   __shared__ float red[8];
-  __shared__ float buf[4][E + 256 + E + 64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float uT[E * RT], m1T[256 * RT], m2T[E * RT], f1T[64 * RT], scratch[256 * RT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = blockIdx.y, r0 = blockIdx.x * RT;
   const float* sl = ws + w.slog + (size_t)grp * 2 * B;
   const float* z = ws + w.z + (size_t)grp * 2 * B * E;
   // --- softmax statistics over 2B rows (fixed reduction order)
@@ -157,38 +216,38 @@ __global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict_
     const int j = threadIdx.x & (E - 1), half = threadIdx.x >> 7;
     float a = 0.f;
     for (int i = half; i < 2 * B; i += 2) a += expf(sl[i] - mx) * inv * z[(size_t)i * E + j];
-    if (half == 1) buf[0][j] = a;
+    if (half == 1) scratch[j] = a;
     __syncthreads();
-    if (half == 0) ctx[j] = a + buf[0][j];
+    if (half == 0) ctx[j] = a + scratch[j];
     __syncthreads();
   }
   if (save && blockIdx.x == 0) {
     for (int i = threadIdx.x; i < 2 * B; i += 256) ws[w.alpha + (size_t)grp * 2 * B + i] = expf(sl[i] - mx) * inv;
     if (threadIdx.x < E) ws[w.ctx + (size_t)grp * E + threadIdx.x] = ctx[threadIdx.x];
   }
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= B) return;
-  float* u = buf[wave];
-  float* m1 = u + E;
-  float* m2 = m1 + 256;
-  float* f1 = m2 + E;
-  const float* e = z + (size_t)(B + row) * E;
-  u[lane] = e[lane] + ctx[lane];
-  u[lane + 64] = e[lane + 64] + ctx[lane + 64];
-  wave_lds_sync();
-  wave_linear<1>(P + o.W1, P + o.b1, u, m1, 256, E, lane);
-  wave_linear<0>(P + o.W2, P + o.b2, m1, m2, E, 256, lane);
-  wave_linear<1>(P + o.W3, P + o.b3, m2, f1, 64, E, lane);
-  const float lg = wave_sum(f1[lane] * P[o.w4 + lane]) + P[o.b4];
-  const float r = 1.0f / (1.0f + expf(-lg));
-  const size_t gr = (size_t)grp * B + row;
-  if (lane == 0) reward[gr] = r;
-  if (save) {
-    ws[w.u + gr * E + lane] = u[lane]; ws[w.u + gr * E + lane + 64] = u[lane + 64];
-    for (int j = lane; j < 256; j += 64) ws[w.m1 + gr * 256 + j] = m1[j];
-    ws[w.m2 + gr * E + lane] = m2[lane]; ws[w.m2 + gr * E + lane + 64] = m2[lane + 64];
-    ws[w.f1 + gr * 64 + lane] = f1[lane];
-    if (lane == 0) ws[w.r + gr] = r;
+  // --- u = e + ctx for the tile's rows (label rows live at z[B + row])
+  for (int e = threadIdx.x; e < E * RT; e += 256) {
+    const int r = e / E, k = e % E, row = r0 + r;
+    uT[k * RT + r] = row < B ? z[(size_t)(B + row) * E + k] + ctx[k] : 0.f;
+  }
+  __syncthreads();
+  tile_linear<256, 1>(PT + ot.W1T, P + o.b1, uT, m1T, scratch, E);
+  tile_linear<E, 0>(PT + ot.W2T, P + o.b2, m1T, m2T, scratch, 256);
+  tile_linear<64, 1>(PT + ot.W3T, P + o.b3, m2T, f1T, scratch, E);
+  for (int r = wave; r < RT; r += 4) {
+    const int row = r0 + r;
+    if (row >= B) continue;
+    const float lg = wave_sum(f1T[lane * RT + r] * P[o.w4 + lane]) + P[o.b4];
+    const float rr = 1.0f / (1.0f + expf(-lg));
+    const size_t gr = (size_t)grp * B + row;
+    if (lane == 0) reward[gr] = rr;
+    if (save) {
+      ws[w.u + gr * E + lane] = uT[lane * RT + r]; ws[w.u + gr * E + lane + 64] = uT[(lane + 64) * RT + r];
+      for (int j = lane; j < 256; j += 64) ws[w.m1 + gr * 256 + j] = m1T[j * RT + r];
+      ws[w.m2 + gr * E + lane] = m2T[lane * RT + r]; ws[w.m2 + gr * E + lane + 64] = m2T[(lane + 64) * RT + r];
+      ws[w.f1 + gr * 64 + lane] = f1T[lane * RT + r];
+      if (lane == 0) ws[w.r + gr] = rr;
+    }
   }
 }
 
@@ -319,28 +378,39 @@ __global__ void rew_emb_scatter_kernel(const float* __restrict__ dpre, const lon
 }
 
 // ------------------------------------------------------------------------------------------------
-// Generator: relu(L4(relu(L3(relu(L2(relu(L1 x))))))) -> (float, int64 label).  One wave per row.
-__global__ __launch_bounds__(256) void generator_kernel(const float* __restrict__ P, const float* __restrict__ x, float* __restrict__ out,
+// Generator: relu(L4(relu(L3(relu(L2(relu(L1 x))))))) -> (float, int64 label).  Tile of 8 rows per workgroup.
+// dyn LDS = F*8 floats + the fixed buffers below.
+__global__ __launch_bounds__(256) void generator_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                       const float* __restrict__ x, float* __restrict__ out,
                                                        long long* __restrict__ label, int B, int F) {
-  __shared__ float buf[4][1024 + 256 + 128 + 64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wave;
-  if (row >= B) return;
-  float* x0 = buf[wave];
-  float* h1 = x0 + 1024;
-  float* h2 = h1 + 256;
-  float* h3 = h2 + 128;
-  for (int k = lane; k < F; k += 64) x0[k] = x[(size_t)row * F + k];
-  wave_lds_sync();
+  const GenTOff ot(F);
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* xT = gsm;                         // [F][8]
+  float* h1 = xT + F * RT;                 // [256][8]
+  float* h2 = h1 + 256 * RT;               // [128][8]
+  float* h3 = h2 + 128 * RT;               // [64][8]
+  float* scratch = h3 + 64 * RT;           // [256*8]
+  const int r0 = blockIdx.x * RT;
+  for (int e = threadIdx.x; e < F * RT; e += 256) {
+    const int r = e / F, k = e % F;
+    xT[k * RT + r] = (r0 + r < B) ? x[(size_t)(r0 + r) * F + k] : 0.f;
+  }
+  __syncthreads();
   int off = 0;
-  const float* W1 = P + off; off += 256 * F; const float* b1 = P + off; off += 256;
-  const float* W2 = P + off; off += 128 * 256; const float* b2 = P + off; off += 128;
-  const float* W3 = P + off; off += 64 * 128; const float* b3 = P + off; off += 64;
+  off += 256 * F; const float* b1 = P + off; off += 256;
+  off += 128 * 256; const float* b2 = P + off; off += 128;
+  off += 64 * 128; const float* b3 = P + off; off += 64;
   const float* W4 = P + off; off += 64; const float* b4 = P + off;
-  wave_linear<1>(W1, b1, x0, h1, 256, F, lane);
-  wave_linear<1>(W2, b2, h1, h2, 128, 256, lane);
-  wave_linear<1>(W3, b3, h2, h3, 64, 128, lane);
-  const float v = fmaxf(wave_sum(h3[lane] * W4[lane]) + b4[0], 0.f);
-  if (lane == 0) { out[row] = v; label[row] = (long long)v; }   // .long(): truncation toward zero
+  tile_linear<256, 1>(PT + ot.W1T, b1, xT, h1, scratch, F);
+  tile_linear<128, 1>(PT + ot.W2T, b2, h1, h2, scratch, 256);
+  tile_linear<64, 1>(PT + ot.W3T, b3, h2, h3, scratch, 128);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = wave; r < RT; r += 4) {
+    const int row = r0 + r;
+    if (row >= B) continue;
+    const float v = fmaxf(wave_sum(h3[lane * RT + r] * W4[lane]) + b4[0], 0.f);
+    if (lane == 0) { out[row] = v; label[row] = (long long)v; }   // .long(): truncation toward zero
+  }
 }
 
 // target_b = 1.0 if gen_b == ref_b else 0.5   ( (cos(one_hot, one_hot) + 1) / 2, srflexmatch.py:180-182 )
@@ -366,14 +436,48 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 extern "C" long srhip_rewarder_param_count(int F, int L) { return RewOff(F, L).total; }
 extern "C" long srhip_rewarder_ws_floats(int G, int B) { return (long)RewWs(G, B).total; }
 extern "C" long srhip_generator_param_count(int F) { return 256L * F + 256 + 128 * 256 + 128 + 64 * 128 + 64 + 64 + 1; }
+extern "C" long srhip_rewarder_t_floats(int F) { return RewTOff(F).total; }
+extern "C" long srhip_generator_t_floats(int F) { return GenTOff(F).total; }
 
-extern "C" int srhip_rewarder_fwd(const float* params, const float* feats, const long long* labels, float* reward, float* ws,
-                                  int G, int B, int F, int L, int save_for_bwd, void* stream) {
-  if (G <= 0 || B <= 0 || F <= 0 || F > 1024 || L <= 0 || (save_for_bwd && G != 1)) return SR_EINVAL;
+static void launch_tr(const float* W, float* WT, int J, int K, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_small_kernel, dim3(cdiv((long)J * K, 256)), dim3(256), 0, s, W, WT, J, K);
+}
+
+extern "C" int srhip_rewarder_prepare(const float* params, float* params_t, int F, int L, void* stream) {
+  if (F <= 0 || F > 1024 || L <= 0) return SR_EINVAL;
+  const RewOff o(F, L);
+  const RewTOff ot(F);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rew_embed_kernel, dim3(cdiv(2 * B, 4), G), dim3(256), 0, s, params, feats, labels, ws, G, B, F, L, save_for_bwd);
+  launch_tr(params + o.Wf, params_t + ot.WfT, E, F, s);
+  launch_tr(params + o.W1, params_t + ot.W1T, 256, E, s);
+  launch_tr(params + o.W2, params_t + ot.W2T, E, 256, s);
+  launch_tr(params + o.W3, params_t + ot.W3T, 64, E, s);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rew_score_kernel, dim3(cdiv(B, 4), G), dim3(256), 0, s, params, ws, reward, G, B, F, L, save_for_bwd);
+  return SR_OK;
+}
+
+extern "C" int srhip_generator_prepare(const float* params, float* params_t, int F, void* stream) {
+  if (F <= 0 || F > 1024) return SR_EINVAL;
+  const GenTOff ot(F);
+  hipStream_t s = (hipStream_t)stream;
+  const float* W1 = params;
+  const float* W2 = W1 + 256 * F + 256;
+  const float* W3 = W2 + 128 * 256 + 128;
+  launch_tr(W1, params_t + ot.W1T, 256, F, s);
+  launch_tr(W2, params_t + ot.W2T, 128, 256, s);
+  launch_tr(W3, params_t + ot.W3T, 64, 128, s);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_rewarder_fwd(const float* params, const float* params_t, const float* feats, const long long* labels,
+                                  float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream) {
+  if (G <= 0 || B <= 0 || F <= 0 || F > 1024 || L <= 0 || (save_for_bwd && G != 1) || !params_t) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t sm1 = ((size_t)F * RT + E * RT + 256 * RT) * sizeof(float);
+  hipLaunchKernelGGL(rew_embed_kernel, dim3(cdiv(B, RT), G), dim3(256), sm1, s, params, params_t, feats, labels, ws, G, B, F, L, save_for_bwd);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rew_score_kernel, dim3(cdiv(B, RT), G), dim3(256), 0, s, params, params_t, ws, reward, G, B, F, L, save_for_bwd);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -402,9 +506,11 @@ extern "C" int srhip_rewarder_bwd(const float* params, const float* feats, const
   return SR_OK;
 }
 
-extern "C" int srhip_generator_fwd(const float* params, const float* x, float* out, long long* label, int B, int F, void* stream) {
-  if (B <= 0 || F <= 0 || F > 1024) return SR_EINVAL;
-  hipLaunchKernelGGL(generator_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, params, x, out, label, B, F);
+extern "C" int srhip_generator_fwd(const float* params, const float* params_t, const float* x, float* out, long long* label, int B,
+                                   int F, void* stream) {
+  if (B <= 0 || F <= 0 || F > 1024 || !params_t) return SR_EINVAL;
+  const size_t sm = ((size_t)F * RT + (256 + 128 + 64 + 256) * RT) * sizeof(float);
+  hipLaunchKernelGGL(generator_kernel, dim3(cdiv(B, RT)), dim3(256), sm, (hipStream_t)stream, params, params_t, x, out, label, B, F);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

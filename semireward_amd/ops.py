@@ -21,10 +21,45 @@ def _call(name, *args):
     _lib.check(getattr(_lib.lib(), name)(*args), name)
 
 
+# ---- optional live profiling of the dominant kernel (bench.py roofline object) -------------------
+class _GemmProfile:
+    """HIP events (torch.cuda.Event on the launch stream) around every srhip_gemm_nt launch."""
+
+    def __init__(self):
+        self.recs = []
+
+    def totals(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.recs)
+        return sum(f for _, _, f in self.recs), ms, len(self.recs)
+
+
+_PROFILE = None
+
+
+def enable_gemm_profile():
+    global _PROFILE
+    _PROFILE = _GemmProfile()
+    return _PROFILE
+
+
+def disable_gemm_profile():
+    global _PROFILE
+    _PROFILE = None
+
+
 # ---- dense ------------------------------------------------------------------------------------
 def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, row_scale=None, rows_per_sample=0,
             aux_in=None, aux_out=None, ldaux=0, alpha=1.0, beta=0.0):
     """C[M,N] (+)= A[M,K] . B[N,K]^T  (bf16 operands; see srhip_gemm_nt)."""
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
+              rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
+        e1.record()
+        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K))
+        return
     _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
           rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
 
@@ -119,16 +154,32 @@ def generator_param_count(F):
     return int(_lib.lib().srhip_generator_param_count(F))
 
 
-def rewarder_fwd(params, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False):
-    _call("srhip_rewarder_fwd", _p(params), _p(feats), _p(labels), _p(reward), _p(ws), G, B, F, L, int(save_for_bwd), _s())
+def rewarder_t_floats(F):
+    return int(_lib.lib().srhip_rewarder_t_floats(F))
+
+
+def generator_t_floats(F):
+    return int(_lib.lib().srhip_generator_t_floats(F))
+
+
+def rewarder_prepare(params, params_t, F, L):
+    _call("srhip_rewarder_prepare", _p(params), _p(params_t), F, L, _s())
+
+
+def generator_prepare(params, params_t, F):
+    _call("srhip_generator_prepare", _p(params), _p(params_t), F, _s())
+
+
+def rewarder_fwd(params, params_t, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False):
+    _call("srhip_rewarder_fwd", _p(params), _p(params_t), _p(feats), _p(labels), _p(reward), _p(ws), G, B, F, L, int(save_for_bwd), _s())
 
 
 def rewarder_bwd(params, feats, labels, target, ws, grads, losses, B, F, L):
     _call("srhip_rewarder_bwd", _p(params), _p(feats), _p(labels), _p(target), _p(ws), _p(grads), _p(losses), B, F, L, _s())
 
 
-def generator_fwd(params, x, out, label, B, F):
-    _call("srhip_generator_fwd", _p(params), _p(x), _p(out), _p(label), B, F, _s())
+def generator_fwd(params, params_t, x, out, label, B, F):
+    _call("srhip_generator_fwd", _p(params), _p(params_t), _p(x), _p(out), _p(label), B, F, _s())
 
 
 def sr_target(gen, ref, target, B):

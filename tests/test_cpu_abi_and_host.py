@@ -1,0 +1,107 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/srhip.h declares (no compute calls
+without a GPU), host-side logic (chunk table, layer-decay table, scheduler, pass plan, registry, DeferredScalar)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "srhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(srhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from semireward_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from semireward_amd.build import build
+        build()
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(h, n), n
+    # the Python binding table covers exactly the header
+    assert sorted(_lib.SIGNATURES.keys()) == names
+    lib = _lib.lib()
+    assert lib.srhip_rewarder_param_count(384, 100) == 136962          # == reference Rewarder(100,128,384)
+    assert lib.srhip_generator_param_count(384) == 139777              # == reference Generator(384)
+    assert lib.srhip_rewarder_ws_floats(1, 8) > 0 and lib.srhip_rewarder_t_floats(384) == 128 * 384 + 2 * 256 * 128 + 64 * 128
+
+
+def test_invalid_arguments_return_error_codes_without_gpu():
+    """Argument validation happens before any launch, so it is testable on CPU."""
+    from semireward_amd import _lib
+    lib = _lib.lib()
+    assert lib.srhip_gemm_nt(0, None, 64, None, 64, None, 64, 16, 16, 100, None, None, 0, None, None, 0, 1.0, 0.0, None) == -1
+    assert lib.srhip_attn_fwd(None, None, None, 1, 1000, 6, 0.125, None) == -1
+    assert lib.srhip_layernorm_fwd(None, None, None, 1e-6, None, None, None, 4, 100, None) == -1
+    assert lib.srhip_rewarder_fwd(None, None, None, None, None, None, 2, 8, 384, 100, 1, None) == -1     # save needs G == 1
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from semireward_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsrhip.so")
+    with pytest.raises(RuntimeError, match="only compute path"):
+        _lib.lib()
+
+
+def test_optimizer_host_tables(golden):
+    from oracle import vit_ref as V
+    from semireward_amd.nets import vit
+    from semireward_amd.optim import build_chunk_table, cosine_with_warmup, layer_decay_hparams
+    g = golden("optim")
+    cfg = vit.VitConfig(img_size=32, patch_size=2, embed_dim=384, depth=12, num_heads=6, num_classes=100, drop_path_rate=0.2)
+    ns = vit.param_names_shapes(cfg)
+    assert [(n, tuple(s)) for n, s in ns] == [(n, tuple(s)) for n, s in V.param_shapes(V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32))]
+    assert sum(int(np.prod(s)) for _, s in ns) == 21436900
+    hp = dict(zip([n for n, _ in ns], layer_decay_hparams(ns, 12, 5e-4, 5e-4, 0.5)))
+    for n, lr, wd in zip(g["small/names"], g["small/lr"], g["small/wd"]):          # the reference's 28 param groups
+        assert hp[str(n)][0] == pytest.approx(float(lr), rel=1e-12) and hp[str(n)][1] == float(wd), n
+    for s, f in zip(g["sched/steps"], g["sched/factor"]):
+        assert cosine_with_warmup(int(s), 204800, 5120) == pytest.approx(float(f), rel=1e-12, abs=1e-15)
+    sizes = [int(np.prod(s)) for _, s in ns]
+    t = build_chunk_table(sizes).numpy()
+    assert t[:, 1].sum() == 21436900 and t[:, 1].max() <= 4096 and t[:, 1].min() > 0
+    starts = np.cumsum([0] + sizes)
+    for off, ln, tid, _ in t[::97]:
+        assert starts[tid] <= off and off + ln <= starts[tid + 1]          # a chunk never straddles two tensors
+
+
+def test_pass_plan_and_registry():
+    from semireward_amd.algorithms import ALGORITHMS
+    from semireward_amd.algorithms.srflexmatch import SRFlexMatch, _Plan
+    assert ALGORITHMS["srflexmatch"] is SRFlexMatch
+    names = [a.name for a in SRFlexMatch.get_argument()]
+    assert names == ["--hard_label", "--T", "--p_cutoff", "--thresh_warmup", "--start_timing", "--feature_dim", "--sr_lr",
+                     "--N_k", "--sr_ema", "--sr_ema_m"]                      # srflexmatch.py:233-246
+    for nl, nu, K in [(8, 8, 8), (8, 8, 0), (4, 4, 20), (3, 5, 2)]:
+        p = _Plan(nl, nu, K, "cpu")
+        Bt = nl + 2 * nu
+        allc = torch.cat([p.grad_cols, p.inf_cols]).sort().values
+        assert torch.equal(allc, torch.arange((K + 1) * Bt))                 # every (pass, image) row exactly once
+        assert p.grad_cols.numel() == nl + nu
+        assert p.grad_cols[:nl].tolist() == list(range(nl))                  # pass 0, labelled rows (sup loss)
+        assert p.grad_cols[nl:].tolist() == [K * Bt + j for j in range(nl + nu, Bt)]   # last pass, strong rows
+        assert torch.equal(p.grad_img.long(), p.grad_cols % Bt) and torch.equal(p.inf_img.long(), p.inf_cols % Bt)
+
+
+def test_deferred_scalar_and_sr_decay():
+    from semireward_amd.core.algorithmbase import AlgorithmBase, DeferredScalar
+    d = DeferredScalar(torch.tensor(1.5))
+    assert float(d) == 1.5 and "%.2f" % d == "1.50" and d + 1 == 2.5 and d.item() == 1.5
+
+    class A:
+        num_train_iter = 204800
+    for it, k in [(20001, 11), (20480, 11), (22755, 10), (25600, 9), (25601, 8), (204799, 8)]:
+        A.it = it
+        assert AlgorithmBase.sr_decay(A) == k

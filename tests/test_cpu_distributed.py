@@ -1,0 +1,82 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: flat-gradient all-reduce + 1/world scaling equals the
+single-process gradient of the concatenated batch; rank-stride sharding; packed reward-statistic all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Flat:
+    def __init__(self, n):
+        self.flat = torch.zeros(n)
+        self.grad = torch.zeros(n)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import hooks_ref as H
+    from semireward_amd.distributed import DataParallel, shard_indices
+    dp = DataParallel(world, rank, global_reward_threshold=True)
+    assert dp.active
+    # (1) parameters: rank 0's block wins, like DDP's construction-time broadcast
+    m = _Flat(1000)
+    m.flat += rank + 1
+    dp.broadcast_params(m)
+    assert float(m.flat.min()) == 1.0 and float(m.flat.max()) == 1.0
+    # (2) gradients: per-rank mean-loss gradients, SUM all-reduce, 1/world scale == gradient of the global-batch mean loss
+    rng = np.random.Generator(np.random.PCG64(5))
+    W = torch.from_numpy(rng.standard_normal((10, 32)).astype(np.float32))
+    X = torch.from_numpy(rng.standard_normal((16, 32)).astype(np.float32))
+    Y = torch.from_numpy(rng.integers(0, 10, size=(16,), dtype=np.int64))
+    mine = shard_indices(16, rank, world)
+    assert mine == list(range(rank, 16, world))                       # reference DistributedSampler: perm[rank::world]
+    w = W.clone().requires_grad_(True)
+    H.ce_loss_mean(X[mine] @ w.t(), Y[mine]).backward()
+    m.grad = w.grad.reshape(-1).clone()
+    dp.all_reduce_grads(m)
+    got = m.grad / world
+    w2 = W.clone().requires_grad_(True)
+    H.ce_loss_mean(X @ w2.t(), Y).backward()
+    ok_grad = torch.allclose(got, w2.grad.reshape(-1), rtol=1e-5, atol=1e-7)
+    # (3) global reward threshold extension: packed (sum..., n) all-reduce == mean over the concatenated ranks
+    r_all = torch.from_numpy(rng.random((world, 3, 8)).astype(np.float32))      # [rank, groups, B]
+    means = dp.reward_means(r_all[rank].reshape(-1), 3)
+    ok_mean = torch.allclose(means, r_all.permute(1, 0, 2).reshape(3, -1).mean(1), rtol=1e-6)
+    q.put((rank, bool(ok_grad), bool(ok_mean)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def test_local_mode_is_reference_semantics():
+    from semireward_amd.distributed import DataParallel
+    dp = DataParallel(1, 0)
+    assert not dp.active
+    r = torch.arange(16, dtype=torch.float32)
+    assert torch.equal(dp.reward_means(r, 2), torch.tensor([3.5, 11.5]))     # per-rank local mean (srflexmatch.py:100)

@@ -312,7 +312,10 @@ def test_rewarder_generator(golden, tag):
     labels = torch.from_numpy(rng.integers(0, C, size=(B,), dtype=np.int64)).to(DEV)
     ws = torch.empty(ops.rewarder_ws_floats(1, B), device=DEV)
     r = torch.empty(B, device=DEV)
-    ops.rewarder_fwd(rp, feats, labels, r, ws, 1, B, Fd, L)
+    rpt, gpt = torch.empty(ops.rewarder_t_floats(Fd), device=DEV), torch.empty(ops.generator_t_floats(Fd), device=DEV)
+    ops.rewarder_prepare(rp, rpt, Fd, L)
+    ops.generator_prepare(gp, gpt, Fd)
+    ops.rewarder_fwd(rp, rpt, feats, labels, r, ws, 1, B, Fd, L)
     np.testing.assert_allclose(r.cpu().numpy(), g[f"{tag}/reward"][:, 0], rtol=1e-5, atol=1e-6)   # stated fp tolerance for rewards
     # mask2: bit-exact on the REFERENCE's rewards (integer thresholding parity)
     m2, mean = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
@@ -324,13 +327,13 @@ def test_rewarder_generator(golden, tag):
     lb3 = torch.cat([labels, labels.flip(0), labels])
     ws3 = torch.empty(ops.rewarder_ws_floats(G, B), device=DEV)
     r3 = torch.empty(G * B, device=DEV)
-    ops.rewarder_fwd(rp, fe3, lb3, r3, ws3, G, B, Fd, L)
+    ops.rewarder_fwd(rp, rpt, fe3, lb3, r3, ws3, G, B, Fd, L)
     for gi in range(G):
-        ops.rewarder_fwd(rp, fe3[gi * B:(gi + 1) * B].contiguous(), lb3[gi * B:(gi + 1) * B].contiguous(), r, ws, 1, B, Fd, L)
+        ops.rewarder_fwd(rp, rpt, fe3[gi * B:(gi + 1) * B].contiguous(), lb3[gi * B:(gi + 1) * B].contiguous(), r, ws, 1, B, Fd, L)
         assert torch.equal(r, r3[gi * B:(gi + 1) * B])
     # generator
     go, gl = torch.empty(B, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
-    ops.generator_fwd(gp, feats, go, gl, B, Fd)
+    ops.generator_fwd(gp, gpt, feats, go, gl, B, Fd)
     np.testing.assert_allclose(go.cpu().numpy(), g[f"{tag}/gen_out"][:, 0], rtol=1e-5, atol=2e-6)
     assert np.array_equal(gl.cpu().numpy(), g[f"{tag}/gen_label"][:, 0])
     # SR update: target, losses, grads, two Adam steps
@@ -340,7 +343,8 @@ def test_rewarder_generator(golden, tag):
     grads, m, v = torch.empty_like(rp), torch.zeros_like(rp), torch.zeros_like(rp)
     losses = torch.empty(2, device=DEV)
     for step in (1, 2):
-        ops.rewarder_fwd(rp, feats, gl, r, ws, 1, B, Fd, L, save_for_bwd=True)
+        ops.rewarder_prepare(rp, rpt, Fd, L)
+        ops.rewarder_fwd(rp, rpt, feats, gl, r, ws, 1, B, Fd, L, save_for_bwd=True)
         ops.rewarder_bwd(rp, feats, gl, tgt, ws, grads, losses, B, Fd, L)
         if step == 1:
             np.testing.assert_allclose(r.cpu().numpy(), g[f"{tag}/upd_reward"][:, 0], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage: tools_prof.sh <tag> [bench args]   (runs on the GPU box; writes gpurun_out/<tag>.stats.txt)
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o r -- python $GRAFT_REPO_ROOT/bench.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
+python - <<PY
+import sqlite3,glob
+db=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/$tag/*.db")[0]
+c=sqlite3.connect(db)
+rows=list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+with open("$GRAFT_REPO_ROOT/gpurun_out/$tag.stats.txt","w") as f:
+    for n,cl,t,a,p in rows[:40]:
+        f.write("%-100s %6d %10.0f %9.1f %6.2f\n"%(n[:100],cl,t,a,p))
+    f.write("TOTAL_US %.0f\n"%sum(r[2] for r in rows))
+cols=[r[1] for r in c.execute("pragma table_info(kernels)")]
+with open("$GRAFT_REPO_ROOT/gpurun_out/$tag.dispatch.txt","w") as f:
+    f.write(" ".join(cols)+"\n")
+    q=list(c.execute("select name, grid_x, grid_y, workgroup_x, (end-start) as dur, start from kernels order by start"))
+    q=q[-int(len(q)/7):]
+    for n,gx,gy,wx,d,st in q:
+        f.write("%-60s grid=%7d x %3d wg=%4d dur_us=%9.1f\n"%(n[:60],gx,gy,wx,d/1e3))
+PY
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/$tag
