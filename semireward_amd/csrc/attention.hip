@@ -49,33 +49,53 @@ __device__ __forceinline__ s16x8_t pack8(const float* lo, const float* hi) {
   return __builtin_bit_cast(s16x8_t, r);
 }
 
-// Stage rows [0,N) of a [N][64] bf16 slice (row stride ld elements) into row-major LDS (pitch KPAD),
-// zero-filling rows [N, NP).
-__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, int ld, int N, int NP, int tid, int nthr) {
-  for (int c = tid; c < NP * 8; c += nthr) {
-    const int row = c >> 3, slot = c & 7;
-    uint4 v = {0u, 0u, 0u, 0u};
-    if (row < N) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + slot * 8);
-    *reinterpret_cast<uint4*>(dst + row * KPAD + slot * 8) = v;
+// Staging helpers.  Trip counts are compile-time (NP) and every global load of a helper is issued before the
+// first LDS write, so a workgroup pays ONE memory round trip per operand instead of one per loop iteration
+// (the first version serialised ~18 dependent L2/HBM round trips per workgroup: 60 us of latency for 2 us of MFMA).
+// Stage rows [0,N) of a [N][64] bf16 slice (row stride ld elements) into row-major LDS (pitch KPAD), zero-filling [N,NP).
+template <int NP>
+__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
+  constexpr int IT = (NP * 8 + 255) / 256;
+  u32x4_t v[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * 256, row = c >> 3, slot = c & 7;
+    v[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < NP * 8 && row < N) v[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)row * ld + slot * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * 256, row = c >> 3, slot = c & 7;
+    if (c < NP * 8) *reinterpret_cast<u32x4_t*>(dst + row * KPAD + slot * 8) = v[i];
   }
 }
 
 // Stage the TRANSPOSE of a [N][64] slice into LDS as dst[d][row] (pitch TP), two rows per 32-bit write.
-__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, int ld, int N, int NP, int TP, int tid, int nthr) {
-  const int pairs = NP >> 1;
-  for (int c = tid; c < pairs * 8; c += nthr) {
-    const int pr = c % pairs, slot = c / pairs;
-    const int r0 = 2 * pr, r1 = r0 + 1;
-    uint4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
-    if (r0 < N) a = *reinterpret_cast<const uint4*>(src + (size_t)r0 * ld + slot * 8);
-    if (r1 < N) b = *reinterpret_cast<const uint4*>(src + (size_t)r1 * ld + slot * 8);
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+template <int NP>
+__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
+  constexpr int TP = NP + 8, PAIRS = NP / 2, IT = (PAIRS * 8 + 255) / 256;
+  u32x4_t va[IT], vb[IT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t lo = (aw[j] & 0xffffu) | (bw[j] << 16);
-      const uint32_t hi = (aw[j] >> 16) | (bw[j] & 0xffff0000u);
-      *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j) * TP + r0) = lo;
-      *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j + 1) * TP + r0) = hi;
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * 256, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
+    va[i] = u32x4_t{0u, 0u, 0u, 0u};
+    vb[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < PAIRS * 8) {
+      if (r0 < N) va[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)r0 * ld + slot * 8);
+      if (r0 + 1 < N) vb[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)(r0 + 1) * ld + slot * 8);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * 256, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
+    if (c < PAIRS * 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = (va[i][j] & 0xffffu) | (vb[i][j] << 16);
+        const uint32_t hi = (va[i][j] >> 16) | (vb[i][j] & 0xffff0000u);
+        *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j) * TP + r0) = lo;
+        *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j + 1) * TP + r0) = hi;
+      }
     }
   }
 }
@@ -92,15 +112,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
-  stage_rows(Ks, base + D, ld, N, NP, tid, 256);
-  stage_transposed(Vt, base + 2 * D, ld, N, NP, TP, tid, 256);
-  __syncthreads();
   const float sc2 = scale * LOG2E;
   const int nqt = (N + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int q = qt * 16 + l15, qc = min(q, N - 1);
+  // first query tile's operands are requested before the staging traffic so they arrive under it
+  s16x8_t qn0, qn1;
+  {
+    const int qc = min(wave * 16 + l15, N - 1);
     const bf16_t* qp = base + (size_t)qc * ld + g * 8;
-    const s16x8_t q0 = ld16(qp), q1 = ld16(qp + 32);
+    qn0 = ld16(qp); qn1 = ld16(qp + 32);
+  }
+  stage_rows<NP>(Ks, base + D, ld, N, tid);
+  stage_transposed<NP>(Vt, base + 2 * D, ld, N, tid);
+  __syncthreads();
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + l15;
+    const s16x8_t q0 = qn0, q1 = qn1;
+    if (qt + 4 < nqt) {               // prefetch the next tile's Q fragments (hidden behind this tile's MFMAs)
+      const int qc = min((qt + 4) * 16 + l15, N - 1);
+      const bf16_t* qp = base + (size_t)qc * ld + g * 8;
+      qn0 = ld16(qp); qn1 = ld16(qp + 32);
+    }
     f32x4_t s[NKT];
     float mx = -INFINITY;
 #pragma unroll
@@ -124,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(s[t][r] - mx);
+        const float p = fast_exp2(s[t][r] - mx);
         s[t][r] = p;
         sum += p;
       }
@@ -174,30 +205,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
-  stage_rows(Ks, base + D, ld, N, NP, tid, 256);
-  stage_rows(Vs, base + 2 * D, ld, N, NP, tid, 256);
-  stage_transposed(Kt, base + D, ld, N, NP, TP, tid, 256);
-  __syncthreads();
   const float sc2 = scale * LOG2E;
   const int nqt = (N + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int q = qt * 16 + l15, qc = min(q, N - 1);
+  s16x8_t nq0, nq1, nd0, nd1, no0, no1;
+  float nlse;
+  auto fetch = [&](int qt_) {
+    const int qc = min(qt_ * 16 + l15, N - 1);
     const bf16_t* qp = base + (size_t)qc * ld + g * 8;
-    const s16x8_t q0 = ld16(qp), q1 = ld16(qp + 32);
     const bf16_t* dop = d_out + ((size_t)b * N + qc) * D + h * HD + g * 8;
     const bf16_t* op = o_fwd + ((size_t)b * N + qc) * D + h * HD + g * 8;
-    const s16x8_t do0 = ld16(dop), do1 = ld16(dop + 32);
+    nq0 = ld16(qp); nq1 = ld16(qp + 32);
+    nd0 = ld16(dop); nd1 = ld16(dop + 32);
+    no0 = ld16(op); no1 = ld16(op + 32);
+    nlse = lse[((size_t)b * H + h) * N + qc];
+  };
+  fetch(wave);
+  stage_rows<NP>(Ks, base + D, ld, N, tid);
+  stage_rows<NP>(Vs, base + 2 * D, ld, N, tid);
+  stage_transposed<NP>(Kt, base + D, ld, N, tid);
+  __syncthreads();
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + l15;
+    const s16x8_t q0 = nq0, q1 = nq1, do0 = nd0, do1 = nd1;
     // delta[q]: this lane holds d-slots 8g..8g+7 and 32+8g.. of row q
     float dl = 0.f;
     {
-      const s16x8_t o0 = ld16(op), o1 = ld16(op + 32);
+      const s16x8_t o0 = no0, o1 = no1;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         dl += bf2f((bf16_t)do0[j]) * bf2f((bf16_t)o0[j]) + bf2f((bf16_t)do1[j]) * bf2f((bf16_t)o1[j]);
       dl += __shfl_xor(dl, 16, 64);
       dl += __shfl_xor(dl, 32, 64);
     }
-    const float lse2 = lse[((size_t)b * H + h) * N + qc] * LOG2E;
+    const float lse2 = nlse * LOG2E;
+    if (qt + 4 < nqt) fetch(qt + 4);      // next tile's operands travel under this tile's MFMAs
     if (q < N && g == 0) delta[((size_t)b * H + h) * N + q] = dl;
     f32x4_t dq[4];
 #pragma unroll
@@ -218,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = t * 16 + g * 4 + r;
-          const float p = key < N ? exp2f(s[r] * sc2 - lse2) : 0.f;
+          const float p = key < N ? fast_exp2(s[r] * sc2 - lse2) : 0.f;
           ds[e][r] = p * (dp[r] - dl) * scale;
         }
       }
@@ -257,8 +298,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
-  stage_transposed(Qt, base, ld, N, NP, TP, tid, 256);
-  stage_transposed(dOt, dobase, D, N, NP, TP, tid, 256);
+  stage_transposed<NP>(Qt, base, ld, N, tid);
+  stage_transposed<NP>(dOt, dobase, D, N, tid);
   for (int i = tid; i < NP; i += 256) {
     lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : 0.f;
     dl_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
@@ -274,22 +315,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     f32x4_t dv[4], dk[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    for (int u = 0; u < NKT / 2; ++u) {
-      float pp[2][4], ds[2][4];
+    // (q, dO) row fragments of query-tile pair u come straight from L2; pair u+1 is requested before pair u is used
+    s16x8_t fq[2][2], fd[2][2];
+    auto fetch = [&](int u_) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int qrow = (2 * u + e) * 16 + l15, qc = min(qrow, N - 1);
+        const int qc = min((2 * u_ + e) * 16 + l15, N - 1);
         const bf16_t* qp = base + (size_t)qc * ld + g * 8;
         const bf16_t* dop = dobase + (size_t)qc * D + g * 8;
+        fq[e][0] = ld16(qp); fq[e][1] = ld16(qp + 32);
+        fd[e][0] = ld16(dop); fd[e][1] = ld16(dop + 32);
+      }
+    };
+    fetch(0);
+    for (int u = 0; u < NKT / 2; ++u) {
+      float pp[2][4], ds[2][4];
+      s16x8_t cq[2][2], cd[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { cq[e][0] = fq[e][0]; cq[e][1] = fq[e][1]; cd[e][0] = fd[e][0]; cd[e][1] = fd[e][1]; }
+      if (u + 1 < NKT / 2) fetch(u + 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = mfma16(ld16(qp), k0, s);            // a-operand rows = queries, b-operand cols = keys
-        s = mfma16(ld16(qp + 32), k1, s);
-        dp = mfma16(ld16(dop), v0, dp);
-        dp = mfma16(ld16(dop + 32), v1, dp);
+        s = mfma16(cq[e][0], k0, s);            // a-operand rows = queries, b-operand cols = keys
+        s = mfma16(cq[e][1], k1, s);
+        dp = mfma16(cd[e][0], v0, dp);
+        dp = mfma16(cd[e][1], v1, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = (2 * u + e) * 16 + g * 4 + r;      // result row = query
-          const float p = (qq < N && key < N) ? exp2f(s[r] * sc2 - lse_s[qq]) : 0.f;
+          const float p = (qq < N && key < N) ? fast_exp2(s[r] * sc2 - lse_s[qq]) : 0.f;
           pp[e][r] = p;
           ds[e][r] = p * (dp[r] - dl_s[qq]) * scale;
         }

@@ -22,16 +22,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, on the gfx950 hardware converter (v_cvt_pk_bf16_f32: one instruction per PAIR).
+// (A hand-rolled integer RNE with a NaN test compiled to one divergent exec-mask region per value -- 209 of them in
+// the attention kernel -- and dominated its runtime.)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+
+// raw v_exp_f32 (2^x): arguments on the hot paths are <= 0 (x - rowmax), so the OCML range/denormal fix-up is dead weight
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -44,10 +47,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, branch-free, one v_exp + one v_rcp).  The OCML erff costs ~40
+// instructions with branches: in the fc1 epilogue it took 80 us of a 220 us GEMM.  The GELU outputs are rounded to bf16
+// (2^-9 relative) right after, so 1.5e-7 absolute is invisible; semantics stay nn.GELU() "exact erf" (vit.py:63,72).
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f);
   return cdf + x * pdf;
 }
 

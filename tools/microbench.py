@@ -1,0 +1,48 @@
+"""Micro-benchmarks of single libsrhip kernels on the GPU box (HIP-event timing, median of reps)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from semireward_amd import ops
+
+DEV = "cuda:0"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def attn(N=257, H=6):
+    for B in (7, 43, 86, 128, 200):
+        D = H * 64
+        qkv = torch.randn(B * N, 3 * D, device=DEV).to(torch.bfloat16)
+        out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+        t = timeit(lambda: ops.attn_fwd(qkv, out, None, B, N, H, 0.125))
+        fl = 4.0 * N * N * 64 * B * H
+        print("attn_fwd B=%4d WGs=%5d  %8.1f us  %7.1f TF/s" % (B, B * H, t, fl / t / 1e6), flush=True)
+
+
+def gemm():
+    for (M, N, K, epi, name) in [(51400, 1152, 384, ops.EPI_BF16, "qkv"), (51400, 384, 384, ops.EPI_RESID_F32, "proj"),
+                                 (51400, 1536, 384, ops.EPI_GELU_BF16, "fc1"), (51400, 384, 1536, ops.EPI_RESID_F32, "fc2"),
+                                 (51400, 1536, 384, ops.EPI_BF16, "fc1-nogelu"), (8192, 8192, 8192, ops.EPI_BF16, "big")]:
+        A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        Bm = (torch.randn(N, K, device=DEV) * 0.05).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV)
+        C = torch.zeros(M, N, dtype=torch.float32 if epi == ops.EPI_RESID_F32 else torch.bfloat16, device=DEV)
+        t = timeit(lambda: ops.gemm_nt(epi, A, Bm, C, M, N, K, bias=bias), reps=10)
+        print("gemm %-10s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        globals()[a]()
