@@ -53,31 +53,31 @@ __device__ __forceinline__ s16x8_t pack8(const float* lo, const float* hi) {
 // first LDS write, so a workgroup pays ONE memory round trip per operand instead of one per loop iteration
 // (the first version serialised ~18 dependent L2/HBM round trips per workgroup: 60 us of latency for 2 us of MFMA).
 // Stage rows [0,N) of a [N][64] bf16 slice (row stride ld elements) into row-major LDS (pitch KPAD), zero-filling [N,NP).
-template <int NP>
+template <int NP, int NT = 256>
 __device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
-  constexpr int IT = (NP * 8 + 255) / 256;
+  constexpr int IT = (NP * 8 + NT - 1) / NT;
   u32x4_t v[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * 256, row = c >> 3, slot = c & 7;
+    const int c = tid + i * NT, row = c >> 3, slot = c & 7;
     v[i] = u32x4_t{0u, 0u, 0u, 0u};
     if (c < NP * 8 && row < N) v[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)row * ld + slot * 8);
   }
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * 256, row = c >> 3, slot = c & 7;
+    const int c = tid + i * NT, row = c >> 3, slot = c & 7;
     if (c < NP * 8) *reinterpret_cast<u32x4_t*>(dst + row * KPAD + slot * 8) = v[i];
   }
 }
 
 // Stage the TRANSPOSE of a [N][64] slice into LDS as dst[d][row] (pitch TP), two rows per 32-bit write.
-template <int NP>
+template <int NP, int NT = 256>
 __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
-  constexpr int TP = NP + 8, PAIRS = NP / 2, IT = (PAIRS * 8 + 255) / 256;
+  constexpr int TP = NP + 8, PAIRS = NP / 2, IT = (PAIRS * 8 + NT - 1) / NT;
   u32x4_t va[IT], vb[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * 256, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
+    const int c = tid + i * NT, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
     va[i] = u32x4_t{0u, 0u, 0u, 0u};
     vb[i] = u32x4_t{0u, 0u, 0u, 0u};
     if (c < PAIRS * 8) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src,
   }
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * 256, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
+    const int c = tid + i * NT, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
     if (c < PAIRS * 8) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -101,9 +101,12 @@ __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src,
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward: grid = B*H workgroups of 256 threads.  NKT = number of 16-key tiles (even), NP = 16*NKT.
+// forward: grid = B*H workgroups of 512 threads (8 waves share the head's K / V^T: two workgroups per CU -> 4 waves per
+// SIMD, which is what hides the per-query-tile dependency chain ds_read -> MFMA -> max -> exp -> MFMA).
+// NKT = number of 16-key tiles (even), NP = 16*NKT.
+constexpr int FWD_NT = 512, FWD_NW = FWD_NT / 64;
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                       float* __restrict__ lse, int N, int H, float scale) {
   constexpr int NP = NKT * 16, TP = NP + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -117,21 +120,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   // first query tile's operands are requested before the staging traffic so they arrive under it
   s16x8_t qn0, qn1;
   {
-    const int qc = min(wave * 16 + l15, N - 1);
+    const int qc = min(wave * 16 + l15, N - 1);   // (wave < FWD_NW <= nqt for every supported N >= 113)
     const bf16_t* qp = base + (size_t)qc * ld + g * 8;
     qn0 = ld16(qp); qn1 = ld16(qp + 32);
   }
-  stage_rows<NP>(Ks, base + D, ld, N, tid);
-  stage_transposed<NP>(Vt, base + 2 * D, ld, N, tid);
+  stage_rows<NP, FWD_NT>(Ks, base + D, ld, N, tid);
+  stage_transposed<NP, FWD_NT>(Vt, base + 2 * D, ld, N, tid);
   __syncthreads();
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += FWD_NW) {
     const int q = qt * 16 + l15;
     const s16x8_t q0 = qn0, q1 = qn1;
-    if (qt + 4 < nqt) {               // prefetch the next tile's Q fragments (hidden behind this tile's MFMAs)
-      const int qc = min((qt + 4) * 16 + l15, N - 1);
+    if (qt + FWD_NW < nqt) {          // prefetch the next tile's Q fragments (hidden behind this tile's MFMAs)
+      const int qc = min((qt + FWD_NW) * 16 + l15, N - 1);
       const bf16_t* qp = base + (size_t)qc * ld + g * 8;
       qn0 = ld16(qp); qn1 = ld16(qp + 32);
     }
+    // raw scores stay unscaled in registers; p = 2^(s*c - max*c) is ONE fma + v_exp per element (c = scale*log2e > 0,
+    // so max commutes with the scaling).  Only key tiles that straddle N need the per-element mask (wave-uniform test).
     f32x4_t s[NKT];
     float mx = -INFINITY;
 #pragma unroll
@@ -140,22 +145,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       f32x4_t a = {0.f, 0.f, 0.f, 0.f};
       a = mfma16(ld16(kp), q0, a);
       a = mfma16(ld16(kp + 32), q1, a);
+      if (t * 16 + 16 > N) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + g * 4 + r;
-        a[r] = key < N ? a[r] * sc2 : -INFINITY;
-        mx = fmaxf(mx, a[r]);
+        for (int r = 0; r < 4; ++r) a[r] = (t * 16 + g * 4 + r < N) ? a[r] : -INFINITY;
       }
+      mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
       s[t] = a;
+      // keep hipcc from hoisting all 36 fragment reads (144 VGPRs) to the top of the unrolled loop: that pushed the
+      // kernel to 414 registers = 1 wave/SIMD = 1 workgroup/CU
+      if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nmx = -mx * sc2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = fast_exp2(s[t][r] - mx);
+        const float p = fast_exp2(fmaf(s[t][r], sc2, nmx));
         s[t][r] = p;
         sum += p;
       }
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const bf16_t* vp = Vt + (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
         o[dt] = mfma16(ld8x2(vp, vp + 16), pb, o[dt]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (q < N) {
       const float inv = 1.0f / sum;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         uint2 v = {pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv)};
         *reinterpret_cast<uint2*>(op + dt * 16) = v;
       }
-      if (lse && g == 0) lse[((size_t)b * H + h) * N + q] = (mx + log2f(sum)) * LN2;
+      if (lse && g == 0) lse[((size_t)b * H + h) * N + q] = (mx * sc2 + log2f(sum)) * LN2;
     }
   }
 }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 //   S^T, dP^T (query on l15) per key-tile pair -> P, dS (bf16) -> dQ^T[d][q] += K^T[d][keys] . dS^T[keys][q]
 // delta[q] = rowsum(dO[q] * O[q]) is computed in-kernel from the saved forward output.
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                          const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                          bf16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                          int N, int H, float scale) {
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // walks query-tile pairs:  S[q][key], dP[q][key] with the KEY on l15 ->
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int NP = NKT * 16, TP = NP + 8;
@@ -328,6 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       }
     };
     fetch(0);
+#pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       float pp[2][4], ds[2][4];
       s16x8_t cq[2][2], cd[2][2];
@@ -391,7 +401,7 @@ extern "C" int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int
     const size_t sm = (size_t)NP * KPAD * 2 + (size_t)64 * (NP + 8) * 2;
     auto kern = attn_fwd_kernel<NKT>;
     if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
     SR_CHECK_LAUNCH();
     return SR_OK;
   });

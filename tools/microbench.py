@@ -43,6 +43,15 @@ def gemm():
         print("gemm %-10s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e6), flush=True)
 
 
+def attn200():
+    B, N, H = 200, 257, 6
+    qkv = torch.randn(B * N, 3 * H * 64, device=DEV).to(torch.bfloat16)
+    out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=DEV)
+    for _ in range(5):
+        ops.attn_fwd(qkv, out, None, B, N, H, 0.125)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     for a in sys.argv[1:]:
         globals()[a]()
