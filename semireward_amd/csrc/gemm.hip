@@ -15,6 +15,9 @@
 // counted s_waitcnt vmcnt(8/4/0) -- no register staging, no ds_write pass.  16-B slots are permuted per row
 // (on the source address, as LDS-DMA writes lane-linear) so every ds_read_b128 lane group is conflict-free.
 // Block->tile mapping is XCD-aware (consecutive N-tiles of one A row-panel share an XCD L2).
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "srhip.h"
 
@@ -28,7 +31,7 @@ struct GemmArgs {
   const float* row_scale;
   const bf16_t* aux_in;
   bf16_t* aux_out;
-  int M, N, K, lda, ldb, ldc, ldaux, rows_per_sample, ksplit_tiles;
+  int M, N, K, lda, ldb, ldc, ldaux, rows_per_sample, ksplit_tiles, debug;
   float alpha, beta;
 };
 
@@ -45,6 +48,59 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int N_>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// Epilogue of one lane-quad: v[0..3] = C[m][n..n+3] accumulators (bias not yet added).
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float (&v)[4], float rs, bool atomic_f32) {
+  if (g.debug & 1) {                      // tuning only (SRHIP_DEBUG=1): no epilogue memory traffic
+    if (v[0] == 123456.75f) reinterpret_cast<float*>(g.C)[0] = v[1] + v[2] + v[3];
+    return;
+  }
+  if (g.bias) {
+    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n);
+    v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+  }
+  const size_t off = (size_t)m * g.ldc + n;
+  if (EPI == SRHIP_EPI_BF16) {
+    u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
+  } else if (EPI == SRHIP_EPI_GELU_BF16) {
+    if (g.aux_out) {
+      u32x2_t p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *reinterpret_cast<u32x2_t*>(g.aux_out + (size_t)m * g.ldaux + n) = p;
+    }
+    u32x2_t o = {pack_bf2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]))};
+    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
+  } else if (EPI == SRHIP_EPI_RESID_F32) {
+    // residual source: C itself (in place) or, when the pre-block stream is kept for the backward, aux_in (fp32, ldaux)
+    f32x4_t* cp = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + off);
+    f32x4_t x = g.aux_in ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(g.aux_in) + (size_t)m * g.ldaux + n) : *cp;
+    x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
+    *cp = x;
+  } else if (EPI == SRHIP_EPI_DGELU_BF16) {
+    const u32x2_t p = *reinterpret_cast<const u32x2_t*>(g.aux_in + (size_t)m * g.ldaux + n);
+    const float p0 = bf2f((bf16_t)(p[0] & 0xffff)), p1 = bf2f((bf16_t)(p[0] >> 16));
+    const float p2 = bf2f((bf16_t)(p[1] & 0xffff)), p3 = bf2f((bf16_t)(p[1] >> 16));
+    u32x2_t o = {pack_bf2(v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1)),
+                 pack_bf2(v[2] * gelu_erf_grad(p2), v[3] * gelu_erf_grad(p3))};
+    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
+  } else if (atomic_f32) {  // SRHIP_EPI_F32 with split-K: C += alpha*acc (beta == 1 by contract)
+    float* cp = reinterpret_cast<float*>(g.C) + off;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, g.alpha * v[r]);
+  } else {  // SRHIP_EPI_F32: C = alpha*acc + beta*C
+    f32x4_t* cp = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + off);
+    f32x4_t x = {g.alpha * v[0], g.alpha * v[1], g.alpha * v[2], g.alpha * v[3]};
+    if (g.beta != 0.0f) {
+      const f32x4_t c = *cp;
+      x[0] += g.beta * c[0]; x[1] += g.beta * c[1]; x[2] += g.beta * c[2]; x[3] += g.beta * c[3];
+    }
+    *cp = x;
+  }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
@@ -132,50 +188,135 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       const int n = n0 + wn * 64 + nt * 16 + lg * 4;
       if (n >= g.N) continue;
       float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-      if (g.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-      }
-      const size_t off = (size_t)m * g.ldc + n;
-      if (EPI == SRHIP_EPI_BF16) {
-        uint2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
-      } else if (EPI == SRHIP_EPI_GELU_BF16) {
-        if (g.aux_out) {
-          uint2 p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-          *reinterpret_cast<uint2*>(g.aux_out + (size_t)m * g.ldaux + n) = p;
-        }
-        uint2 o = {pack_bf2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]))};
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
-      } else if (EPI == SRHIP_EPI_RESID_F32) {
-        // residual source: C itself (in place) or, when the pre-block stream is kept for the backward,
-        // a separate fp32 buffer passed as aux_in (leading dimension ldaux)
-        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + off);
-        float4 x = g.aux_in ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux_in) + (size_t)m * g.ldaux + n)
-                            : *cp;
-        x.x += rs * v[0]; x.y += rs * v[1]; x.z += rs * v[2]; x.w += rs * v[3];
-        *cp = x;
-      } else if (EPI == SRHIP_EPI_DGELU_BF16) {
-        const uint2 p = *reinterpret_cast<const uint2*>(g.aux_in + (size_t)m * g.ldaux + n);
-        const float p0 = bf2f((bf16_t)(p.x & 0xffff)), p1 = bf2f((bf16_t)(p.x >> 16));
-        const float p2 = bf2f((bf16_t)(p.y & 0xffff)), p3 = bf2f((bf16_t)(p.y >> 16));
-        uint2 o = {pack_bf2(v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1)),
-                   pack_bf2(v[2] * gelu_erf_grad(p2), v[3] * gelu_erf_grad(p3))};
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
-      } else if (gridDim.y > 1) {  // SRHIP_EPI_F32 with split-K: C += alpha*acc (beta == 1 by contract)
-        float* cp = reinterpret_cast<float*>(g.C) + off;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(cp + r, g.alpha * v[r]);
-      } else {  // SRHIP_EPI_F32: C = alpha*acc + beta*C
-        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + off);
-        float4 x = {g.alpha * v[0], g.alpha * v[1], g.alpha * v[2], g.alpha * v[3]};
-        if (g.beta != 0.0f) {
-          const float4 c = *cp;
-          x.x += g.beta * c.x; x.y += g.beta * c.y; x.z += g.beta * c.z; x.w += g.beta * c.w;
-        }
-        *cp = x;
-      }
+      epi_store<EPI>(g, m, n, v, rs, gridDim.y > 1);
     }
+  }
+}
+
+// =================================================================================================
+// Large-problem kernel: 256 x (128|256) CU-level tile, 8 waves, persistent over tiles.
+//
+// Measured on MI355X (profiles/r01_c_*): a 16 KiB K-step of the 128x128 kernel costs ~0.9 us whatever the staging
+// method, because global->LDS latency is ~2 us under load and a CU can only keep (LDS ring) bytes in flight: ~36 GB/s
+// per CU.  L2 hit rate is 90 % and HBM fetch is the A panel once -- it is a latency x capacity limit, not bandwidth.
+// Throughput is therefore (flop per in-flight byte) x (ring bytes / latency): this kernel doubles the first factor
+// (256x128 -> 85 flop/B, 256x256 -> 128 flop/B vs 64) and gives the ring 120-128 KiB instead of 2 x 48 KiB, and it
+// never drains the pipeline between tiles: a workgroup walks tiles  blockIdx.x, +gridDim.x, ...  with the LDS-DMA
+// prefetch cursor running PDG steps ahead of the MFMA cursor across tile boundaries.
+// Waves: 4 (m) x 2 (n); wave tile 64 x (16*NTW); NTW = 4 -> BN = 128, NTW = 8 -> BN = 256.
+constexpr int GBM = 256;
+
+template <int EPI, int NTW>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
+  constexpr int GBN = 32 * NTW;
+  constexpr int A_EL = GBM * BK, B_EL = GBN * BK, STG = A_EL + B_EL;
+  constexpr int NSTG = (NTW == 4) ? 5 : 4, PDG = NSTG - 1;
+  constexpr int NI = 2 + (NTW == 4 ? 1 : 2);          // LDS-DMA instructions per wave per stage
+  extern __shared__ __attribute__((aligned(16))) bf16_t gsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int ntn = (g.N + GBN - 1) / GBN, ntm = (g.M + GBM - 1) / GBM, ntiles = ntm * ntn;
+  const int nk = g.K / BK;
+  const int first = blockIdx.x;
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
+  const int steps = my_tiles * nk;
+
+  // ---- producer cursor (LDS-DMA); lane -> (row, physical slot) as in the 128x128 kernel
+  int pt = first, pk = 0;
+  const int ra0 = 32 * wave + (lane >> 2), ra1 = ra0 + 16;
+  const int rb0 = (NTW == 4 ? 16 * wave : 32 * wave) + (lane >> 2), rb1 = rb0 + 16;
+  const int sa0 = ((lane & 3) ^ swz(ra0)) * 8, sa1 = ((lane & 3) ^ swz(ra1)) * 8;
+  const int sb0 = ((lane & 3) ^ swz(rb0)) * 8, sb1 = ((lane & 3) ^ swz(rb1)) * 8;
+  const bf16_t *pa0, *pa1, *pb0, *pb1;
+  auto set_tile = [&](int t) {
+    const int m0 = (t / ntn) * GBM, n0 = (t % ntn) * GBN;
+    pa0 = g.A + (size_t)min(m0 + ra0, g.M - 1) * g.lda + sa0;
+    pa1 = g.A + (size_t)min(m0 + ra1, g.M - 1) * g.lda + sa1;
+    pb0 = g.B + (size_t)min(n0 + rb0, g.N - 1) * g.ldb + sb0;
+    pb1 = g.B + (size_t)min(n0 + rb1, g.N - 1) * g.ldb + sb1;
+  };
+  set_tile(pt);
+  auto issue = [&](int stage) {
+    bf16_t* sa = gsm + stage * STG + (32 * wave) * BK;
+    bf16_t* sb = gsm + stage * STG + A_EL + (NTW == 4 ? 16 * wave : 32 * wave) * BK;
+    const int ko = pk * BK;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(pa0 + ko), (lds_void*)sa, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(pa1 + ko), (lds_void*)(sa + 16 * BK), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(pb0 + ko), (lds_void*)sb, 16, 0, 0);
+    if (NTW == 8) __builtin_amdgcn_global_load_lds((gbl_void*)(pb1 + ko), (lds_void*)(sb + 16 * BK), 16, 0, 0);
+    if (++pk == nk) { pk = 0; pt += gridDim.x; if (pt < ntiles) set_tile(pt); }
+  };
+#pragma unroll
+  for (int p = 0; p < PDG; ++p)
+    if (p < steps) issue(p);
+
+  int fo_a[NTW], fo_b[4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) { const int rn = wn * (16 * NTW) + t * 16 + l15; fo_a[t] = A_EL + rn * BK + ((lg ^ swz(rn)) << 3); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const int rm = wm * 64 + t * 16 + l15; fo_b[t] = rm * BK + ((lg ^ swz(rm)) << 3); }
+  f32x4_t acc[NTW][4];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int ct = first, ck = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int rem = steps - 1 - s;        // step s landed once <= min(rem, PDG-1) younger stages (NI ops each) are in flight
+    if (rem >= PDG - 1) wait_vm<(PDG - 1) * NI>();
+    else if (rem == 2) wait_vm<2 * NI>();
+    else if (rem == 1) wait_vm<NI>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + PDG < steps) issue((s + PDG) % NSTG);
+    const bf16_t* st = gsm + (s % NSTG) * STG;
+    s16x8_t fa[NTW], fb[4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) fa[t] = *reinterpret_cast<const s16x8_t*>(st + fo_a[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fb[t] = *reinterpret_cast<const s16x8_t*>(st + fo_b[t]);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]),
+                                                            acc[i][j], 0, 0, 0);
+    if (++ck == nk) {
+      const int m0 = (ct / ntn) * GBM, n0 = (ct % ntn) * GBN;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + l15;
+        float rs = 1.0f;
+        if (EPI == SRHIP_EPI_RESID_F32 && g.row_scale && m < g.M) rs = g.row_scale[m / g.rows_per_sample];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          const int n = n0 + wn * (16 * NTW) + i * 16 + lg * 4;
+          float v[4] = {acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]};
+          acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (m < g.M && n < g.N) epi_store<EPI>(g, m, n, v, rs, false);
+        }
+      }
+      ck = 0;
+      ct += gridDim.x;
+    }
+  }
+}
+
+template <int EPI>
+static void launch_big(const GemmArgs& g, int ntw, int grid, hipStream_t s) {
+  if (ntw == 4) {
+    constexpr size_t sm = (size_t)5 * (GBM + 128) * BK * sizeof(bf16_t);
+    auto kern = gemm_big_kernel<EPI, 4>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, s, g);
+  } else {
+    constexpr size_t sm = (size_t)4 * (GBM + 256) * BK * sizeof(bf16_t);
+    auto kern = gemm_big_kernel<EPI, 8>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, s, g);
   }
 }
 
@@ -193,6 +334,8 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
   g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; g.alpha = alpha; g.beta = beta;
+  static const int dbg = getenv("SRHIP_DEBUG") ? atoi(getenv("SRHIP_DEBUG")) : 0;
+  g.debug = dbg;
   const int grid = cdiv(M, BM) * cdiv(N, BN);
   hipStream_t s = (hipStream_t)stream;
   // split-K: weight-gradient products (small M x N, long K = tokens) would otherwise fill a few dozen of the 256 CUs.
@@ -205,6 +348,28 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
   g.ksplit_tiles = cdiv(nkt, splits);
   splits = cdiv(nkt, g.ksplit_tiles);
   const dim3 grid3(grid, splits);
+  // large problems go to the persistent 256-row kernel (tuning switches: SRHIP_GEMM=tile|big128|big256)
+  static const char* mode = getenv("SRHIP_GEMM");
+  const bool force_tile = mode && mode[0] == 't';
+  // measured (tools/microbench.py, M = 51400): N >= 1024 -> 256x256 persistent kernel wins (fc1 152 -> 144 us, 8192^3
+  // 775 -> 1064 TF); N = 384 products are epilogue/HBM bound and slightly better on the 128x128 kernel (2 WGs/CU).
+  const bool want_big = N >= 1024 || (mode && mode[0] == 'b');
+  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (long)M * N >= 256L * 256 * 128) {
+    int ntw = 8;
+    if (mode && !strcmp(mode, "big128")) ntw = 4;
+    if (mode && !strcmp(mode, "big256")) ntw = 8;
+    const int tiles = cdiv(M, GBM) * cdiv(N, 32 * ntw);
+    const int pgrid = min(tiles, 256);
+    switch (epilogue) {
+      case SRHIP_EPI_BF16: launch_big<SRHIP_EPI_BF16>(g, ntw, pgrid, s); break;
+      case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, ntw, pgrid, s); break;
+      case SRHIP_EPI_RESID_F32: launch_big<SRHIP_EPI_RESID_F32>(g, ntw, pgrid, s); break;
+      case SRHIP_EPI_DGELU_BF16: launch_big<SRHIP_EPI_DGELU_BF16>(g, ntw, pgrid, s); break;
+      default: return SR_EINVAL;
+    }
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  }
   switch (epilogue) {
     case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_BF16>, grid3, dim3(256), 0, s, g); break;
     case SRHIP_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_GELU_BF16>, grid3, dim3(256), 0, s, g); break;

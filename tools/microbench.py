@@ -43,6 +43,17 @@ def gemm():
         print("gemm %-10s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e6), flush=True)
 
 
+def gemm_qkv5():
+    M, N, K = 51400, 1152, 384
+    A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    Bm = (torch.randn(N, K, device=DEV) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV)
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    for _ in range(5):
+        ops.gemm_nt(ops.EPI_BF16, A, Bm, C, M, N, K, bias=bias)
+    torch.cuda.synchronize()
+
+
 def attn200():
     B, N, H = 200, 257, 6
     qkv = torch.randn(B * N, 3 * H * 64, device=DEV).to(torch.bfloat16)
