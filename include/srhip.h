@@ -39,6 +39,17 @@ int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, 
                   const float* bias, const float* row_scale, int rows_per_sample, const void* aux_in, void* aux_out,
                   int ldaux, float alpha, float beta, void* stream);
 
+/* Grouped variant for the fp32 weight-gradient products (dW = dY^T X of every block, reference: autograd of the same
+ * nn.Linear call sites): C_p = alpha * A_p . B_p^T + beta * C_p for n_problems independent products in ONE launch.
+ * desc_dev: DEVICE array; tile_start = running sum of ceil(M/128)*ceil(N/128) over the preceding problems;
+ * total_tiles = that sum over all problems.  Same operand requirements as srhip_gemm_nt (K % 32 == 0 ...). */
+typedef struct srhip_group_desc {
+  const void* A; const void* B; float* C;
+  int M, N, K, lda, ldb, ldc, tile_start, pad0, pad1, pad2;
+} srhip_group_desc;                      /* 64 bytes */
+int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
+                              void* stream);
+
 /* Fused attention, head_dim 64.  qkv bf16 [B*N, 3*H*64] as written by the qkv Linear; out bf16 [B*N, H*64];
  * lse fp32 [B,H,N] (NULL when no backward is needed).  Replaces vit.py:100-104 (K4).  N <= 512. */
 int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);

@@ -102,16 +102,13 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
   }
 }
 
+// One 128x128 output tile, K-tiles [kt0, kt1).  smem: NS * STAGE elements (the kernel's ONE __shared__ object: a second
+// one makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline).
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
-  // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
-  __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, int m0, int n0, int kt0, int kt1, bool atomic_f32) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int ntn = (g.N + BN - 1) / BN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);   // (blockIdx.y = split-K slice)
-  const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
 
   // ---- LDS-DMA staging (global_load_lds, 16 B/lane): a wave-instruction fills 16 rows x 64 B = 1 KiB, lane l lands on
   // row l>>2, physical slot l&3; the swizzle therefore goes on the per-lane SOURCE address (guide rule 21).
@@ -137,9 +134,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // split-K (EPI_F32 only): blockIdx.y owns k-tiles [kt0, kt1); partial sums are combined with fp32 atomics
-  const int nk_all = g.K / BK;
-  const int kt0 = (int)blockIdx.y * g.ksplit_tiles, kt1 = min(nk_all, kt0 + g.ksplit_tiles);
   const int nk = kt1 - kt0;
   if (nk <= 0) return;
   // fragment read offsets (elements) inside a tile: row r, logical slot lg
@@ -188,9 +182,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       const int n = n0 + wn * 64 + nt * 16 + lg * 4;
       if (n >= g.N) continue;
       float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-      epi_store<EPI>(g, m, n, v, rs, gridDim.y > 1);
+      epi_store<EPI>(g, m, n, v, rs, atomic_f32);
     }
   }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
+  const int ntn = (g.N + BN - 1) / BN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  // split-K (EPI_F32 only): blockIdx.y owns k-tiles [kt0, kt1); partial sums are combined with fp32 atomics
+  const int kt0 = (int)blockIdx.y * g.ksplit_tiles, kt1 = min(g.K / BK, kt0 + g.ksplit_tiles);
+  gemm_tile_body<EPI>(g, smem, (wg / ntn) * BM, (wg % ntn) * BN, kt0, kt1, gridDim.y > 1);
+}
+
+// Grouped fp32-accumulating launch: ONE grid over the 128x128 tiles of up to 64 independent products.  Used for the
+// weight gradients dW_l = dY_l^T X_l of all transformer blocks (48 products of 9..36 tiles each for ViT-S): launched one
+// by one they fill 4-14 % of the chip (63 us each, 3 ms per step); grouped they are one 1296-tile launch.
+__global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_group_desc* __restrict__ desc, int n_problems,
+                                                                  float alpha, float beta) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
+  const int tile = blockIdx.x;
+  int p = 0;
+  while (p + 1 < n_problems && tile >= desc[p + 1].tile_start) ++p;
+  const srhip_group_desc d = desc[p];
+  GemmArgs g;
+  g.A = (const bf16_t*)d.A; g.B = (const bf16_t*)d.B; g.C = d.C; g.bias = nullptr; g.row_scale = nullptr;
+  g.aux_in = nullptr; g.aux_out = nullptr;
+  g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldaux = 0; g.rows_per_sample = 1;
+  g.ksplit_tiles = d.K / BK; g.debug = 0; g.alpha = alpha; g.beta = beta;
+  const int local = tile - d.tile_start, ntn = (d.N + BN - 1) / BN;
+  gemm_tile_body<SRHIP_EPI_F32>(g, smem, (local / ntn) * BM, (local % ntn) * BN, 0, d.K / BK, false);
 }
 
 // =================================================================================================
@@ -378,6 +401,14 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
     case SRHIP_EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_F32>, grid3, dim3(256), 0, s, g); break;
     default: return SR_EINVAL;
   }
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
+                                         void* stream) {
+  if (!desc_dev || n_problems <= 0 || n_problems > 4096 || total_tiles <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(gemm_grouped_f32_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_problems, alpha, beta);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -246,6 +246,28 @@ class VisionTransformer:
     __call__ = forward
 
     # ---- backward ---------------------------------------------------------------------------------
+    def _bwd_transposed(self, M, Mp):
+        """Persistent per-layer transposed operand buffers + the grouped-GEMM descriptor table (built once per batch size)."""
+        key = ("bwdT", M)
+        if key in self._ws:
+            return self._ws[key]
+        cfg = self.cfg
+        D, Hd = cfg.embed_dim, cfg.hidden
+        mk = lambda r: torch.zeros(r, Mp, dtype=torch.bfloat16, device=self.device)   # noqa: E731
+        layers, problems = [], []
+        G = lambda n: self.view(n, self.grad)   # noqa: E731
+        for i in range(cfg.depth):
+            b = "blocks.%d." % i
+            t = dict(g2T=mk(D), hT=mk(Hd), dpreT=mk(Hd), ln2T=mk(D), g1T=mk(D), aoT=mk(D), dqkvT=mk(3 * D), ln1T=mk(D))
+            layers.append(t)
+            problems += [(t["g2T"], t["hT"], G(b + "mlp.fc2.weight"), D, Hd, Mp),
+                         (t["dpreT"], t["ln2T"], G(b + "mlp.fc1.weight"), Hd, D, Mp),
+                         (t["g1T"], t["aoT"], G(b + "attn.proj.weight"), D, D, Mp),
+                         (t["dqkvT"], t["ln1T"], G(b + "attn.qkv.weight"), 3 * D, D, Mp)]
+        out = dict(layers=layers, desc=ops.make_group_desc(problems, self.device))
+        self._ws[key] = out
+        return out
+
     def backward(self, ctx, dlogits):
         """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] for a save=True forward."""
         cfg = self.cfg
@@ -260,47 +282,44 @@ class VisionTransformer:
         ops.cls_head_bwd(dlogits, P("head.weight"), P("norm.weight"), ctx.feat, ctx.xhat, ctx.rstd, dx, G("head.weight"),
                          G("head.bias"), G("norm.weight"), G("norm.bias"), B, N, D, C)
         g = self._buf("b_g", (M, D), bf16)
-        gT = self._buf("b_gT", (D, Mp), bf16)
-        aT = self._buf("b_aT", (D, Mp), bf16)
-        hT = self._buf("b_hT", (Hd, Mp), bf16)
         dpre = self._buf("b_dpre", (M, Hd), bf16)
-        dpreT = self._buf("b_dpreT", (Hd, Mp), bf16)
         dln = self._buf("b_dln", (M, D), bf16)
         dao = self._buf("b_dao", (M, D), bf16)
         dqkv = self._buf("b_dqkv", (M, 3 * D), bf16)
-        dqkvT = self._buf("b_dqkvT", (3 * D, Mp), bf16)
         delta = self._buf("b_delta", (B, H, N), f32)
+        # transposed operands of the weight-gradient products are kept per layer so that all 4*depth products
+        # dW = dY^T X run as ONE grouped launch after the layer loop (see srhip_gemm_nt_grouped_f32)
+        T = self._bwd_transposed(M, Mp)
         scale = 64 ** -0.5
         dp = ctx.dp
         for i in reversed(range(cfg.depth)):
             b = "blocks.%d." % i
+            Ti = T["layers"][i]
             s1 = dp[i, 0] if dp is not None else None
             s2 = dp[i, 1] if dp is not None else None
             # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))))
             ops.cast_scale_rows(dx, s2, N, g, M, D)
-            ops.transpose_to_bf16(g, False, D, gT, Mp, M, Mp, D, colsum=G(b + "mlp.fc2.bias"))
-            ops.transpose_to_bf16(ctx.pre[i], False, Hd, hT, Mp, M, Mp, Hd, apply_gelu=True)
-            ops.gemm_nt(ops.EPI_F32, gT, hT, G(b + "mlp.fc2.weight"), D, Hd, Mp, alpha=1.0, beta=1.0)
+            ops.transpose_to_bf16(g, False, D, Ti["g2T"], Mp, M, Mp, D, colsum=G(b + "mlp.fc2.bias"))
+            ops.transpose_to_bf16(ctx.pre[i], False, Hd, Ti["hT"], Mp, M, Mp, Hd, apply_gelu=True)
             ops.gemm_nt(ops.EPI_DGELU_BF16, g, self.wT[b + "mlp.fc2.weight"], dpre, M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
-            ops.transpose_to_bf16(dpre, False, Hd, dpreT, Mp, M, Mp, Hd, colsum=G(b + "mlp.fc1.bias"))
-            ops.transpose_to_bf16(ctx.ln2[i], False, D, aT, Mp, M, Mp, D)
-            ops.gemm_nt(ops.EPI_F32, dpreT, aT, G(b + "mlp.fc1.weight"), Hd, D, Mp, alpha=1.0, beta=1.0)
+            ops.transpose_to_bf16(dpre, False, Hd, Ti["dpreT"], Mp, M, Mp, Hd, colsum=G(b + "mlp.fc1.bias"))
+            ops.transpose_to_bf16(ctx.ln2[i], False, D, Ti["ln2T"], Mp, M, Mp, D)
             ops.gemm_nt(ops.EPI_BF16, dpre, self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
             ops.layernorm_bwd(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
                               G(b + "norm2.bias"), M, D)
             # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
             ops.cast_scale_rows(dx, s1, N, g, M, D)
-            ops.transpose_to_bf16(g, False, D, gT, Mp, M, Mp, D, colsum=G(b + "attn.proj.bias"))
-            ops.transpose_to_bf16(ctx.ao[i], False, D, aT, Mp, M, Mp, D)
-            ops.gemm_nt(ops.EPI_F32, gT, aT, G(b + "attn.proj.weight"), D, D, Mp, alpha=1.0, beta=1.0)
+            ops.transpose_to_bf16(g, False, D, Ti["g1T"], Mp, M, Mp, D, colsum=G(b + "attn.proj.bias"))
+            ops.transpose_to_bf16(ctx.ao[i], False, D, Ti["aoT"], Mp, M, Mp, D)
             ops.gemm_nt(ops.EPI_BF16, g, self.wT[b + "attn.proj.weight"], dao, M, D, D)
             ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], dqkv, delta, B, N, H, scale)
-            ops.transpose_to_bf16(dqkv, False, 3 * D, dqkvT, Mp, M, Mp, 3 * D, colsum=G(b + "attn.qkv.bias"))
-            ops.transpose_to_bf16(ctx.ln1[i], False, D, aT, Mp, M, Mp, D)
-            ops.gemm_nt(ops.EPI_F32, dqkvT, aT, G(b + "attn.qkv.weight"), 3 * D, D, Mp, alpha=1.0, beta=1.0)
+            ops.transpose_to_bf16(dqkv, False, 3 * D, Ti["dqkvT"], Mp, M, Mp, 3 * D, colsum=G(b + "attn.qkv.bias"))
+            ops.transpose_to_bf16(ctx.ln1[i], False, D, Ti["ln1T"], Mp, M, Mp, D)
             ops.gemm_nt(ops.EPI_BF16, dqkv, self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
             ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
                               G(b + "norm1.bias"), M, D)
+        desc, npb, ntiles, flops = T["desc"]
+        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops)
         ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
                             G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
 

@@ -64,6 +64,35 @@ def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, r
           rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
 
 
+GROUP_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
+                    ("ldb", "<i4"), ("ldc", "<i4"), ("tile_start", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"), ("pad2", "<i4")]
+
+
+def make_group_desc(problems, device):
+    """problems: list of (A, B, C, M, N, K) with A bf16 [M,K], B bf16 [N,K], C fp32 [M,N] device tensors (dense rows).
+    Returns (device uint8 tensor holding srhip_group_desc[], n_problems, total_tiles, total flops)."""
+    import numpy as np
+    arr = np.zeros(len(problems), dtype=GROUP_DESC_DTYPE)
+    t = 0
+    for i, (A, B, C, M, N, K) in enumerate(problems):
+        arr[i] = (_p(A), _p(B), _p(C), M, N, K, K, K, N, t, 0, 0, 0)
+        t += ((M + 127) // 128) * ((N + 127) // 128)
+    assert arr.itemsize == 64
+    flops = float(sum(2.0 * M * N * K for _, _, _, M, N, K in problems))
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops
+
+
+def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0):
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
+        e1.record()
+        _PROFILE.recs.append((e0, e1, flops))
+        return
+    _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
+
+
 def attn_fwd(qkv, out, lse, B, N, H, scale):
     _call("srhip_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, H, scale, _s())
 
