@@ -88,6 +88,14 @@ int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const float* gamma
 int srhip_cast_scale_rows(const float* x, const float* scale, int rows_per_sample, void* out, long M, int D, void* stream);
 int srhip_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, void* out, int ld_out, int M, int Mp, int C,
                             int apply_gelu, float* colsum, void* stream);
+/* Batched srhip_transpose_to_bf16 (no column sums): one launch over all 64x64 tiles of n transposes.
+ * tile_start = running sum of ceil(Mp/64) * (C/64) over the preceding entries. */
+typedef struct srhip_transpose_desc {
+  const void* in; void* out;
+  int in_is_f32, ld_in, ld_out, M, Mp, C, apply_gelu, tile_start;
+  long pad;
+} srhip_transpose_desc;                  /* 56 bytes */
+int srhip_transpose_batched(const srhip_transpose_desc* desc_dev, int n, int total_tiles, void* stream);
 int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stream);
 /* timm DropPath (vit.py:148,161): out[depth,2,B] = Bernoulli(1-p_l)/(1-p_l), counter-based RNG. */
 int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream);

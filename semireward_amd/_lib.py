@@ -30,6 +30,7 @@ SIGNATURES = {
     "srhip_cls_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "srhip_cast_scale_rows": (I, [P, P, I, P, L, I, P]),
     "srhip_transpose_to_bf16": (I, [P, I, I, P, I, I, I, I, I, P, P]),
+    "srhip_transpose_batched": (I, [P, I, I, P]),
     "srhip_cast_f32_bf16": (I, [P, P, L, P]),
     "srhip_droppath_fill": (I, [P, P, I, I, c_ulonglong, P]),
     "srhip_row_max": (I, [P, I, P, P, P, I, I, P]),

@@ -299,12 +299,10 @@ __global__ void cast_scale_rows_kernel(const float* __restrict__ x, const float*
 
 // Transpose in [M, C] (bf16 or fp32, row stride ld_in) -> out bf16 [C, Mp] (row stride ld_out), zero-filling
 // columns m in [M, Mp).  Optional exact-erf GELU on the fly, optional column sums (bias gradients, atomic +=).
-// 64 x 64 tile through LDS.  grid = (ceil(Mp/64), C/64).
+// 64 x 64 tile through LDS.
 template <typename TIN, bool GELU>
-__global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
-                                                       int M, int Mp, float* __restrict__ colsum) {
-  __shared__ float tile[64][65];
-  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+__device__ __forceinline__ void transpose_tile(const TIN* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
+                                               int M, int Mp, float* __restrict__ colsum, int m0, int c0, float (*tile)[65]) {
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int r = e >> 6, c = e & 63, m = m0 + r;
     float v = 0.f;
@@ -325,6 +323,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ 
     for (int r = 0; r < 64; ++r) s += tile[r][threadIdx.x];
     atomicAdd(colsum + c0 + threadIdx.x, s);
   }
+}
+
+// grid = (ceil(Mp/64), C/64)
+template <typename TIN, bool GELU>
+__global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
+                                                       int M, int Mp, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  transpose_tile<TIN, GELU>(in, ld_in, out, ld_out, M, Mp, colsum, blockIdx.x * 64, blockIdx.y * 64, tile);
+}
+
+// Batched form: ONE launch over the 64x64 tiles of many independent transposes (the 4*depth weight copies refreshed
+// after every optimizer step, and the 4*depth saved-activation transposes at the start of a backward).
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const srhip_transpose_desc* __restrict__ desc, int n) {
+  __shared__ float tile[64][65];
+  const int t = blockIdx.x;
+  int p = 0;
+  while (p + 1 < n && t >= desc[p + 1].tile_start) ++p;
+  const srhip_transpose_desc d = desc[p];
+  const int local = t - d.tile_start, tm = (d.Mp + 63) / 64;
+  const int m0 = (local % tm) * 64, c0 = (local / tm) * 64;
+  if (d.in_is_f32) transpose_tile<float, false>((const float*)d.in, d.ld_in, (bf16_t*)d.out, d.ld_out, d.M, d.Mp, nullptr, m0, c0, tile);
+  else if (d.apply_gelu) transpose_tile<bf16_t, true>((const bf16_t*)d.in, d.ld_in, (bf16_t*)d.out, d.ld_out, d.M, d.Mp, nullptr, m0, c0, tile);
+  else transpose_tile<bf16_t, false>((const bf16_t*)d.in, d.ld_in, (bf16_t*)d.out, d.ld_out, d.M, d.Mp, nullptr, m0, c0, tile);
 }
 
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, size_t n) {
@@ -463,6 +484,13 @@ extern "C" int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stre
 extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream) {
   if (depth <= 0 || B <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_transpose_batched(const srhip_transpose_desc* desc_dev, int n, int total_tiles, void* stream) {
+  if (!desc_dev || n <= 0 || total_tiles <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -93,6 +93,7 @@ class VisionTransformer:
         self.dp_probs = torch.linspace(0, cfg.drop_path_rate, cfg.depth).to(self.device)    # vit.py:247-249
         self.training = True
         self._ws = {}
+        self._wT_desc = None
         self._rng_calls = 0
         self.seed = 0
 
@@ -127,9 +128,14 @@ class VisionTransformer:
         self.refresh_transposed()
 
     def refresh_transposed(self):
-        for n, t in self.wT.items():
-            r, c = self.offsets[n][1]
-            ops.transpose_to_bf16(self.p(n), True, c, t, r, r, r, c)
+        """W [out,in] fp32 -> W^T [in,out] bf16 for all 4*depth GEMM weights: one batched launch."""
+        if self._wT_desc is None:
+            items = []
+            for n, t in self.wT.items():
+                r, c = self.offsets[n][1]
+                items.append((self.p(n), True, c, t, r, r, r, c, False))
+            self._wT_desc = ops.make_transpose_desc(items, self.device)
+        ops.transpose_batched(*self._wT_desc)
 
     def no_weight_decay(self):
         return {"pos_embed", "cls_token"}
@@ -159,6 +165,27 @@ class VisionTransformer:
         ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, (self.seed << 32) + self._rng_calls)
         return dp
 
+    def _ctx_buffers(self, B):
+        """Activation buffers of a save=True forward.  Persistent per batch size (one live context per size), so the
+        batched-transpose / grouped-GEMM descriptor tables that point into them are built once."""
+        key = ("ctx", B)
+        if key in self._ws:
+            return self._ws[key]
+        cfg = self.cfg
+        D, N, H, Hd = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden
+        M = B * N
+        f32, bf16 = torch.float32, torch.bfloat16
+        mk = lambda shape, dt: [torch.empty(shape, dtype=dt, device=self.device) for _ in range(cfg.depth)]   # noqa: E731
+        ctx = FwdContext()
+        ctx.xs = mk((M, D), f32) + [torch.empty(M, D, dtype=f32, device=self.device)]
+        ctx.xmid, ctx.ln1, ctx.ln2 = mk((M, D), f32), mk((M, D), bf16), mk((M, D), bf16)
+        ctx.qkv, ctx.ao, ctx.pre = mk((M, 3 * D), bf16), mk((M, D), bf16), mk((M, Hd), bf16)
+        ctx.lse, ctx.st1, ctx.st2 = mk((B, H, N), f32), mk((2, M), f32), mk((2, M), f32)
+        ctx.xhat = torch.empty(B, D, dtype=f32, device=self.device)
+        ctx.rstd = torch.empty(B, dtype=f32, device=self.device)
+        self._ws[key] = ctx
+        return ctx
+
     # ---- forward ----------------------------------------------------------------------------------
     def forward_features(self, img, img_index=None, droppath=None, save=False, B=None):
         """img fp32 [n_img, C, H, W]; img_index int32 [B] (optional gather); droppath fp32 [depth,2,B] or None.
@@ -171,18 +198,8 @@ class VisionTransformer:
         tag = "s" if save else "i"
         ctx = None
         if save:
-            ctx = FwdContext()
+            ctx = self._ctx_buffers(B)
             ctx.B, ctx.img, ctx.img_index, ctx.dp = B, img, img_index, droppath
-            ctx.xs = [torch.empty(M, D, dtype=f32, device=self.device) for _ in range(cfg.depth + 1)]
-            ctx.xmid = [torch.empty(M, D, dtype=f32, device=self.device) for _ in range(cfg.depth)]
-            ctx.ln1 = [torch.empty(M, D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
-            ctx.ln2 = [torch.empty(M, D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
-            ctx.qkv = [torch.empty(M, 3 * D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
-            ctx.ao = [torch.empty(M, D, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
-            ctx.pre = [torch.empty(M, Hd, dtype=bf16, device=self.device) for _ in range(cfg.depth)]
-            ctx.lse = [torch.empty(B, H, N, dtype=f32, device=self.device) for _ in range(cfg.depth)]
-            ctx.st1 = [torch.empty(2, M, dtype=f32, device=self.device) for _ in range(cfg.depth)]
-            ctx.st2 = [torch.empty(2, M, dtype=f32, device=self.device) for _ in range(cfg.depth)]
             x = ctx.xs[0]
         else:
             x = self._buf(tag + "x", (M, D), f32)
@@ -228,8 +245,6 @@ class VisionTransformer:
         feat = torch.empty(B, D, dtype=f32, device=self.device)
         logits = torch.empty(B, C, dtype=f32, device=self.device)
         if save:
-            ctx.xhat = torch.empty(B, D, dtype=f32, device=self.device)
-            ctx.rstd = torch.empty(B, dtype=f32, device=self.device)
             ctx.feat = feat
         ops.cls_head_fwd(x, P("norm.weight"), P("norm.bias"), cfg.eps, P("head.weight"), P("head.bias"), feat, logits,
                          ctx.xhat if save else None, ctx.rstd if save else None, B, N, D, C)
@@ -246,25 +261,29 @@ class VisionTransformer:
     __call__ = forward
 
     # ---- backward ---------------------------------------------------------------------------------
-    def _bwd_transposed(self, M, Mp):
-        """Persistent per-layer transposed operand buffers + the grouped-GEMM descriptor table (built once per batch size)."""
+    def _bwd_transposed(self, M, Mp, ctx):
+        """Persistent per-layer transposed operand buffers + the grouped-GEMM / batched-transpose descriptor tables
+        (built once per batch size; ``ctx`` buffers are persistent too)."""
         key = ("bwdT", M)
         if key in self._ws:
             return self._ws[key]
         cfg = self.cfg
         D, Hd = cfg.embed_dim, cfg.hidden
         mk = lambda r: torch.zeros(r, Mp, dtype=torch.bfloat16, device=self.device)   # noqa: E731
-        layers, problems = [], []
+        layers, problems, saved = [], [], []
         G = lambda n: self.view(n, self.grad)   # noqa: E731
         for i in range(cfg.depth):
             b = "blocks.%d." % i
             t = dict(g2T=mk(D), hT=mk(Hd), dpreT=mk(Hd), ln2T=mk(D), g1T=mk(D), aoT=mk(D), dqkvT=mk(3 * D), ln1T=mk(D))
             layers.append(t)
+            saved += [(ctx.pre[i], False, Hd, t["hT"], Mp, M, Mp, Hd, True), (ctx.ln2[i], False, D, t["ln2T"], Mp, M, Mp, D, False),
+                      (ctx.ao[i], False, D, t["aoT"], Mp, M, Mp, D, False), (ctx.ln1[i], False, D, t["ln1T"], Mp, M, Mp, D, False)]
             problems += [(t["g2T"], t["hT"], G(b + "mlp.fc2.weight"), D, Hd, Mp),
                          (t["dpreT"], t["ln2T"], G(b + "mlp.fc1.weight"), Hd, D, Mp),
                          (t["g1T"], t["aoT"], G(b + "attn.proj.weight"), D, D, Mp),
                          (t["dqkvT"], t["ln1T"], G(b + "attn.qkv.weight"), 3 * D, D, Mp)]
-        out = dict(layers=layers, desc=ops.make_group_desc(problems, self.device))
+        out = dict(layers=layers, desc=ops.make_group_desc(problems, self.device),
+                   saved_desc=ops.make_transpose_desc(saved, self.device))
         self._ws[key] = out
         return out
 
@@ -289,7 +308,8 @@ class VisionTransformer:
         delta = self._buf("b_delta", (B, H, N), f32)
         # transposed operands of the weight-gradient products are kept per layer so that all 4*depth products
         # dW = dY^T X run as ONE grouped launch after the layer loop (see srhip_gemm_nt_grouped_f32)
-        T = self._bwd_transposed(M, Mp)
+        T = self._bwd_transposed(M, Mp, ctx)
+        ops.transpose_batched(*T["saved_desc"])      # ln1^T, attn_out^T, ln2^T, gelu(pre)^T of every layer: one launch
         scale = 64 ** -0.5
         dp = ctx.dp
         for i in reversed(range(cfg.depth)):
@@ -300,21 +320,17 @@ class VisionTransformer:
             # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))))
             ops.cast_scale_rows(dx, s2, N, g, M, D)
             ops.transpose_to_bf16(g, False, D, Ti["g2T"], Mp, M, Mp, D, colsum=G(b + "mlp.fc2.bias"))
-            ops.transpose_to_bf16(ctx.pre[i], False, Hd, Ti["hT"], Mp, M, Mp, Hd, apply_gelu=True)
             ops.gemm_nt(ops.EPI_DGELU_BF16, g, self.wT[b + "mlp.fc2.weight"], dpre, M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
             ops.transpose_to_bf16(dpre, False, Hd, Ti["dpreT"], Mp, M, Mp, Hd, colsum=G(b + "mlp.fc1.bias"))
-            ops.transpose_to_bf16(ctx.ln2[i], False, D, Ti["ln2T"], Mp, M, Mp, D)
             ops.gemm_nt(ops.EPI_BF16, dpre, self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
             ops.layernorm_bwd(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
                               G(b + "norm2.bias"), M, D)
             # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
             ops.cast_scale_rows(dx, s1, N, g, M, D)
             ops.transpose_to_bf16(g, False, D, Ti["g1T"], Mp, M, Mp, D, colsum=G(b + "attn.proj.bias"))
-            ops.transpose_to_bf16(ctx.ao[i], False, D, Ti["aoT"], Mp, M, Mp, D)
             ops.gemm_nt(ops.EPI_BF16, g, self.wT[b + "attn.proj.weight"], dao, M, D, D)
             ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], dqkv, delta, B, N, H, scale)
             ops.transpose_to_bf16(dqkv, False, 3 * D, Ti["dqkvT"], Mp, M, Mp, 3 * D, colsum=G(b + "attn.qkv.bias"))
-            ops.transpose_to_bf16(ctx.ln1[i], False, D, Ti["ln1T"], Mp, M, Mp, D)
             ops.gemm_nt(ops.EPI_BF16, dqkv, self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
             ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
                               G(b + "norm1.bias"), M, D)

@@ -135,6 +135,27 @@ def transpose_to_bf16(inp, in_is_f32, ld_in, out, ld_out, M, Mp, C, apply_gelu=F
     _call("srhip_transpose_to_bf16", _p(inp), int(in_is_f32), ld_in, _p(out), ld_out, M, Mp, C, int(apply_gelu), _p(colsum), _s())
 
 
+TRANSPOSE_DESC_DTYPE = [("in", "<u8"), ("out", "<u8"), ("in_is_f32", "<i4"), ("ld_in", "<i4"), ("ld_out", "<i4"), ("M", "<i4"),
+                        ("Mp", "<i4"), ("C", "<i4"), ("apply_gelu", "<i4"), ("tile_start", "<i4"), ("pad", "<i8")]
+
+
+def make_transpose_desc(items, device):
+    """items: list of (inp, in_is_f32, ld_in, out, ld_out, M, Mp, C, apply_gelu).  Returns (desc tensor, n, total_tiles)."""
+    import numpy as np
+    arr = np.zeros(len(items), dtype=TRANSPOSE_DESC_DTYPE)
+    t = 0
+    for i, (inp, f32, ld_in, out, ld_out, M, Mp, C, gelu) in enumerate(items):
+        assert C % 64 == 0 and Mp % 2 == 0 and Mp >= M
+        arr[i] = (_p(inp), _p(out), int(f32), ld_in, ld_out, M, Mp, C, int(gelu), t, 0)
+        t += ((Mp + 63) // 64) * (C // 64)
+    assert arr.itemsize == 56
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(items), t
+
+
+def transpose_batched(desc, n, total_tiles):
+    _call("srhip_transpose_batched", _p(desc), n, total_tiles, _s())
+
+
 def cast_f32_bf16(x, out, n):
     _call("srhip_cast_f32_bf16", _p(x), _p(out), n, _s())
 
