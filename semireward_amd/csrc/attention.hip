@@ -201,8 +201,11 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
 // backward, part 1: dQ.  One workgroup per (image, head); wave walks 16-query tiles.
 //   S^T, dP^T (query on l15) per key-tile pair -> P, dS (bf16) -> dQ^T[d][q] += K^T[d][keys] . dS^T[keys][q]
 // delta[q] = rowsum(dO[q] * O[q]) is computed in-kernel from the saved forward output.
+// grid = (B*H, QS): blockIdx.y takes every QS-th group of BWD_NW query tiles (the backward batch is small -- 16 images --
+// so one workgroup per head would leave 60 % of the CUs idle).
+constexpr int BWD_NT = 512, BWD_NW = BWD_NT / 64;
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+__global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                          const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                          bf16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                          int N, int H, float scale) {
@@ -228,12 +231,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     no0 = ld16(op); no1 = ld16(op + 32);
     nlse = lse[((size_t)b * H + h) * N + qc];
   };
-  fetch(wave);
-  stage_rows<NP>(Ks, base + D, ld, N, tid);
-  stage_rows<NP>(Vs, base + 2 * D, ld, N, tid);
-  stage_transposed<NP>(Kt, base + D, ld, N, tid);
+  const int qstride = BWD_NW * gridDim.y, qfirst = blockIdx.y * BWD_NW + wave;
+  fetch(qfirst);
+  stage_rows<NP, BWD_NT>(Ks, base + D, ld, N, tid);
+  stage_rows<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
+  stage_transposed<NP, BWD_NT>(Kt, base + D, ld, N, tid);
   __syncthreads();
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = qfirst; qt < nqt; qt += qstride) {
     const int q = qt * 16 + l15;
     const s16x8_t q0 = nq0, q1 = nq1, do0 = nd0, do1 = nd1;
     // delta[q]: this lane holds d-slots 8g..8g+7 and 32+8g.. of row q
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       dl += __shfl_xor(dl, 32, 64);
     }
     const float lse2 = nlse * LOG2E;
-    if (qt + 4 < nqt) fetch(qt + 4);      // next tile's operands travel under this tile's MFMAs
+    if (qt + qstride < nqt) fetch(qt + qstride);      // next tile's operands travel under this tile's MFMAs
     if (q < N && g == 0) delta[((size_t)b * H + h) * N + q] = dl;
     f32x4_t dq[4];
 #pragma unroll
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // walks query-tile pairs:  S[q][key], dP[q][key] with the KEY on l15 ->
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
+__global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int NP = NKT * 16, TP = NP + 8;
@@ -307,15 +311,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
-  stage_transposed<NP>(Qt, base, ld, N, tid);
-  stage_transposed<NP>(dOt, dobase, D, N, tid);
-  for (int i = tid; i < NP; i += 256) {
+  stage_transposed<NP, BWD_NT>(Qt, base, ld, N, tid);
+  stage_transposed<NP, BWD_NT>(dOt, dobase, D, N, tid);
+  for (int i = tid; i < NP; i += BWD_NT) {
     lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : 0.f;
     dl_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
   }
   __syncthreads();
   const float sc2 = scale * LOG2E;
-  for (int kt = wave; kt < NKT; kt += 4) {
+  for (int kt = blockIdx.y * BWD_NW + wave; kt < NKT; kt += BWD_NW * gridDim.y) {
     const int key = kt * 16 + l15, kc = min(key, N - 1);
     if (kt * 16 >= N) break;
     const bf16_t* kp = base + D + (size_t)kc * ld + g * 8;
@@ -419,10 +423,14 @@ extern "C" int srhip_attn_bwd(const void* qkv, const void* out, const void* d_ou
     auto k2 = attn_bwd_dkv_kernel<NKT>;
     if (sm1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
     if (sm2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
-    hipLaunchKernelGGL(k1, dim3(B * H), dim3(256), sm1, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
+    // split query / key tiles over extra workgroups until the grid covers the chip (each split re-stages K/V or Q/dO)
+    const int nt16 = (N + 15) / 16;
+    int split = 1;
+    while (B * H * split < 256 && split * BWD_NW < nt16) ++split;
+    hipLaunchKernelGGL(k1, dim3(B * H, split), dim3(BWD_NT), sm1, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale);
     SR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k2, dim3(B * H), dim3(256), sm2, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)d_out, lse,
+    hipLaunchKernelGGL(k2, dim3(B * H, split), dim3(BWD_NT), sm2, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)d_out, lse,
                        (const float*)delta_ws, (bf16_t*)dqkv, N, H, scale);
     SR_CHECK_LAUNCH();
     return SR_OK;
