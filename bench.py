@@ -119,14 +119,24 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    prof = None if a.no_roofline else ops.enable_gemm_profile()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    ops.disable_gemm_profile()
+    # roofline pass: the SAME steps again, in this process, with HIP events around every GEMM launch on the launch
+    # stream.  Kept out of the timed region above because 2 x 145 event records per step cost ~0.9 ms of host time.
+    prof = None
+    if not a.no_roofline and rank == 0:
+        prof = ops.enable_gemm_profile()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        ops.disable_gemm_profile()
+        prof_steps = a.steps
+    if world > 1:
+        dist.barrier()
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,12 +154,21 @@ def main():
                           "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
         if prof is not None:
-            fl, ms, n = prof.totals()
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all epilogues)", "bound": "mfma", "achieved": ach,
-                               "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                               "traffic": None, "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1),
-                               "gemm_share_of_step": ms / (1e3 * dt)}
+            pk = prof.per_kernel()
+            name, (fl, ms, n) = max(pk.items(), key=lambda kv: kv[1][1])          # dominant kernel = most time in the timed region
+            tfl, tms, tn = prof.totals()
+            ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")          # PMC pass of this same command (tools/pmc.sh)
+            if os.path.exists(tf) and a.bu == 8 and a.regime == "sr" and world == 1:
+                traffic = (json.load(open(tf)).get(name) or {}).get("hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "launches": n,
+                               "avg_launch_us": 1e3 * ms / n, "flop_per_launch": fl / n, "ms_per_step_in_kernel": ms / prof_steps,
+                               "measured_over": "%d instrumented steps run right after the timed region (same process, same inputs)" % prof_steps,
+                               "all_gemm_kernels": {"achieved": tfl / (tms * 1e-3) / 1e12, "launches": tn, "ms_per_step": tms / prof_steps},
+                               "note": "K=384 products of a D=384 ViT are HBM/fill bound (DESIGN.md section 6): hbm floor of this "
+                                       "kernel's launches is bytes/8 TB/s, see profiles/"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bl, a.bu)
         print(json.dumps(out), flush=True)

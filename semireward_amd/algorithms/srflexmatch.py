@@ -114,6 +114,10 @@ class SRFlexMatch(AlgorithmBase):
             self.trace.update(sr_target=target, sr_losses=losses)
 
     def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
+        with ops.stream_scope():
+            return self._train_step(x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s)
+
+    def _train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
         assert self.use_cat, "USB-style SemiReward configs use use_cat=True (SURVEY.md Appendix C)"
         nl, nu, it = y_lb.shape[0], x_ulb_w.shape[0], self.it
         K = self.sr_decay() if it > self.start_timing else 0                                     # :147, :75

@@ -43,7 +43,9 @@ class ParamUpdateHook(Hook):
         ema, ema_m = None, 0.0
         if algorithm.ema_model is not None and algorithm.ema_model is not algorithm.model:
             ema, ema_m = algorithm.ema_model.flat, algorithm.ema_m
-        algorithm.optimizer.step(ema=ema, ema_m=ema_m, grad_scale=scale)
+        from .. import ops
+        with ops.stream_scope():
+            algorithm.optimizer.step(ema=ema, ema_m=ema_m, grad_scale=scale)
 
 
 class EMAHook(Hook):
