@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_group_desc* __restrict__ desc, int n_problems,
                                                                   float alpha, float beta) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);      // tiles of one product (shared operands) stay on one XCD's L2
   int p = 0;
   while (p + 1 < n_problems && tile >= desc[p + 1].tile_start) ++p;
   const srhip_group_desc d = desc[p];
@@ -229,46 +229,55 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
 // Waves: 4 (m) x 2 (n); wave tile 64 x (16*NTW); NTW = 4 -> BN = 128, NTW = 8 -> BN = 256.
 constexpr int GBM = 256;
 
-template <int EPI, int NTW>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
-  constexpr int GBN = 32 * NTW;
+// WN = waves along n (2: 8 waves, one workgroup per CU; 1: 4 waves with wave tile 64 x (16*NTW), TWO workgroups per CU whose
+// K-loop and epilogue phases drift apart and overlap).
+template <int EPI, int NTW, int WN>
+__global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
+  constexpr int NWV = 4 * WN;                        // waves per workgroup (4 along m)
+  constexpr int GBN = 16 * NTW * WN;
   constexpr int A_EL = GBM * BK, B_EL = GBN * BK, STG = A_EL + B_EL;
-  constexpr int NSTG = (NTW == 4) ? 5 : 4, PDG = NSTG - 1;
-  constexpr int NI = 2 + (NTW == 4 ? 1 : 2);          // LDS-DMA instructions per wave per stage
+  constexpr int NSTG = (WN == 1) ? 3 : ((NTW == 4) ? 5 : 4), PDG = NSTG - 1;
+  constexpr int AI = 16 / NWV, BI = (GBN / 16) / NWV; // LDS-DMA instructions (16 rows each) per wave for the A / B sub-tile
+  constexpr int NI = AI + BI;
   extern __shared__ __attribute__((aligned(16))) bf16_t gsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, lg = lane >> 4;
   const int ntn = (g.N + GBN - 1) / GBN, ntm = (g.M + GBM - 1) / GBM, ntiles = ntm * ntn;
   const int nk = g.K / BK;
-  const int first = blockIdx.x;
+  // XCD-aware start tile: workgroups b, b+8, b+16.. share an XCD (private L2), so each XCD walks a CONTIGUOUS chunk of the
+  // tile list (tiles of one A row-panel are neighbours).  Without it the 5-6 N-tiles of a panel ran on different XCDs and
+  // the A operand was fetched 6x from HBM/MALL (PMC: 249 MB per qkv launch for a 39.5 MB operand).
+  const int first = xcd_remap(blockIdx.x, gridDim.x);
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
   const int steps = my_tiles * nk;
 
   // ---- producer cursor (LDS-DMA); lane -> (row, physical slot) as in the 128x128 kernel
   int pt = first, pk = 0;
-  const int ra0 = 32 * wave + (lane >> 2), ra1 = ra0 + 16;
-  const int rb0 = (NTW == 4 ? 16 * wave : 32 * wave) + (lane >> 2), rb1 = rb0 + 16;
-  const int sa0 = ((lane & 3) ^ swz(ra0)) * 8, sa1 = ((lane & 3) ^ swz(ra1)) * 8;
-  const int sb0 = ((lane & 3) ^ swz(rb0)) * 8, sb1 = ((lane & 3) ^ swz(rb1)) * 8;
-  const bf16_t *pa0, *pa1, *pb0, *pb1;
+  int ra[AI], rb[BI], sa[AI], sb[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) { ra[i] = (wave * AI + i) * 16 + (lane >> 2); sa[i] = ((lane & 3) ^ swz(ra[i])) * 8; }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) { rb[i] = (wave * BI + i) * 16 + (lane >> 2); sb[i] = ((lane & 3) ^ swz(rb[i])) * 8; }
+  const bf16_t* pa[AI];
+  const bf16_t* pb[BI];
   auto set_tile = [&](int t) {
     const int m0 = (t / ntn) * GBM, n0 = (t % ntn) * GBN;
-    pa0 = g.A + (size_t)min(m0 + ra0, g.M - 1) * g.lda + sa0;
-    pa1 = g.A + (size_t)min(m0 + ra1, g.M - 1) * g.lda + sa1;
-    pb0 = g.B + (size_t)min(n0 + rb0, g.N - 1) * g.ldb + sb0;
-    pb1 = g.B + (size_t)min(n0 + rb1, g.N - 1) * g.ldb + sb1;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) pa[i] = g.A + (size_t)min(m0 + ra[i], g.M - 1) * g.lda + sa[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) pb[i] = g.B + (size_t)min(n0 + rb[i], g.N - 1) * g.ldb + sb[i];
   };
   set_tile(pt);
   auto issue = [&](int stage) {
-    bf16_t* sa = gsm + stage * STG + (32 * wave) * BK;
-    bf16_t* sb = gsm + stage * STG + A_EL + (NTW == 4 ? 16 * wave : 32 * wave) * BK;
+    bf16_t* da = gsm + stage * STG + (wave * AI * 16) * BK;
+    bf16_t* db = gsm + stage * STG + A_EL + (wave * BI * 16) * BK;
     const int ko = pk * BK;
-    __builtin_amdgcn_global_load_lds((gbl_void*)(pa0 + ko), (lds_void*)sa, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(pa1 + ko), (lds_void*)(sa + 16 * BK), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(pb0 + ko), (lds_void*)sb, 16, 0, 0);
-    if (NTW == 8) __builtin_amdgcn_global_load_lds((gbl_void*)(pb1 + ko), (lds_void*)(sb + 16 * BK), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(pa[i] + ko), (lds_void*)(da + i * 16 * BK), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(pb[i] + ko), (lds_void*)(db + i * 16 * BK), 16, 0, 0);
     if (++pk == nk) { pk = 0; pt += gridDim.x; if (pt < ntiles) set_tile(pt); }
   };
 #pragma unroll
@@ -328,19 +337,23 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
   }
 }
 
+template <int EPI, int NTW, int WN>
+static void launch_big_t(const GemmArgs& g, int grid_cap, hipStream_t s) {
+  constexpr int GBN = 16 * NTW * WN;
+  constexpr int NSTG = (WN == 1) ? 3 : ((NTW == 4) ? 5 : 4);
+  constexpr size_t sm = (size_t)NSTG * (GBM + GBN) * BK * sizeof(bf16_t);
+  const int tiles = cdiv(g.M, GBM) * cdiv(g.N, GBN);
+  auto kern = gemm_big_kernel<EPI, NTW, WN>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(kern, dim3(min(tiles, grid_cap)), dim3(256 * WN), sm, s, g);
+}
+
+// variant: 0 = 256x256 / 8 waves / 1 WG per CU, 1 = 256x128 / 8 waves, 2 = 256x128 / 4 waves / 2 WGs per CU
 template <int EPI>
-static void launch_big(const GemmArgs& g, int ntw, int grid, hipStream_t s) {
-  if (ntw == 4) {
-    constexpr size_t sm = (size_t)5 * (GBM + 128) * BK * sizeof(bf16_t);
-    auto kern = gemm_big_kernel<EPI, 4>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, s, g);
-  } else {
-    constexpr size_t sm = (size_t)4 * (GBM + 256) * BK * sizeof(bf16_t);
-    auto kern = gemm_big_kernel<EPI, 8>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, s, g);
-  }
+static void launch_big(const GemmArgs& g, int variant, hipStream_t s) {
+  if (variant == 0) launch_big_t<EPI, 8, 2>(g, 256, s);
+  else if (variant == 1) launch_big_t<EPI, 4, 2>(g, 256, s);
+  else launch_big_t<EPI, 8, 1>(g, 512, s);
 }
 
 }  // namespace
@@ -378,16 +391,14 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
   // 775 -> 1064 TF); N = 384 products are epilogue/HBM bound and slightly better on the 128x128 kernel (2 WGs/CU).
   const bool want_big = N >= 1024 || (mode && mode[0] == 'b');
   if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (long)M * N >= 256L * 256 * 128) {
-    int ntw = 8;
-    if (mode && !strcmp(mode, "big128")) ntw = 4;
-    if (mode && !strcmp(mode, "big256")) ntw = 8;
-    const int tiles = cdiv(M, GBM) * cdiv(N, 32 * ntw);
-    const int pgrid = min(tiles, 256);
+    int variant = 0;
+    if (mode && !strcmp(mode, "big128")) variant = 1;
+    if (mode && !strcmp(mode, "big2wg")) variant = 2;
     switch (epilogue) {
-      case SRHIP_EPI_BF16: launch_big<SRHIP_EPI_BF16>(g, ntw, pgrid, s); break;
-      case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, ntw, pgrid, s); break;
-      case SRHIP_EPI_RESID_F32: launch_big<SRHIP_EPI_RESID_F32>(g, ntw, pgrid, s); break;
-      case SRHIP_EPI_DGELU_BF16: launch_big<SRHIP_EPI_DGELU_BF16>(g, ntw, pgrid, s); break;
+      case SRHIP_EPI_BF16: launch_big<SRHIP_EPI_BF16>(g, variant, s); break;
+      case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, variant, s); break;
+      case SRHIP_EPI_RESID_F32: launch_big<SRHIP_EPI_RESID_F32>(g, variant, s); break;
+      case SRHIP_EPI_DGELU_BF16: launch_big<SRHIP_EPI_DGELU_BF16>(g, variant, s); break;
       default: return SR_EINVAL;
     }
     SR_CHECK_LAUNCH();

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* __restrict__ src,
 }
 
 template <int MODE, int SEG, int IPW, int NS>
-void run(const char* name, int threads, const char* src, size_t src_bytes, int row_stride, float* sink, int wgs_per_cu) {
-  const int nw = threads / 64, steps = 400, grid = 256 * wgs_per_cu;
+void run(const char* name, int threads, const char* src, size_t src_bytes, int row_stride, float* sink, int wgs_per_cu, int cus = 256) {
+  const int nw = threads / 64, steps = 400, grid = cus * wgs_per_cu;
   const size_t lds = (size_t)(MODE == 0 ? NS : 2) * nw * IPW * 1024;
   auto k = fill_kernel<MODE, SEG, IPW, NS>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -77,7 +77,7 @@ void run(const char* name, int threads, const char* src, size_t src_bytes, int r
   float ms; hipEventElapsedTime(&ms, a, b);
   const double bytes = (double)grid * steps * nw * IPW * 1024;
   printf("%-34s thr=%3d wg/cu=%d seg=%4d KiB/wave/step=%d stages=%d lds=%3zuK : %7.1f us  %6.2f TB/s  %5.1f GB/s/CU  %4.1f B/clk/CU\n", name, threads,
-         wgs_per_cu, SEG, IPW, NS, lds / 1024, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / 256, bytes / ms / 1e6 / 256 / 2.4);
+         wgs_per_cu, SEG, IPW, NS, lds / 1024, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / cus, bytes / ms / 1e6 / cus / 2.4);
   if (hipGetLastError() != hipSuccess) printf("  (launch error)\n");
 }
 
@@ -96,6 +96,13 @@ int main() {
   run<0, 128, 8, 3>("dma seg128 8KiB/wave ring3 4w", 256, src, src_bytes, 768, sink, 1);
   run<0, 128, 2, 8>("dma seg128 2KiB/wave ring8 8w", 512, src, src_bytes, 768, sink, 1);
   run<0, 128, 1, 8>("dma seg128 1KiB/wave ring8 8w x2", 512, src, src_bytes, 768, sink, 2);
+  // load sensitivity: same kernel on fewer workgroups (is 45 GB/s/CU a latency x in-flight limit or a shared-bandwidth limit?)
+  run<0, 128, 4, 4>("dma 8w ring4 on  32 WGs", 512, src, src_bytes, 768, sink, 1, 32);
+  run<0, 128, 4, 4>("dma 8w ring4 on  64 WGs", 512, src, src_bytes, 768, sink, 1, 64);
+  run<0, 128, 4, 4>("dma 8w ring4 on 128 WGs", 512, src, src_bytes, 768, sink, 1, 128);
+  run<0, 128, 4, 4>("dma 8w ring4 on 256 WGs", 512, src, src_bytes, 768, sink, 1, 256);
+  run<0, 128, 4, 2>("dma 8w ring2 on  32 WGs", 512, src, src_bytes, 768, sink, 1, 32);
+  run<0, 128, 4, 2>("dma 8w ring2 on 256 WGs", 512, src, src_bytes, 768, sink, 1, 256);
   // register staging
   run<1, 64, 2, 4>("reg seg64  2KiB/wave pd3", 256, src, src_bytes, 768, sink, 2);
   run<1, 128, 2, 4>("reg seg128 2KiB/wave pd3", 256, src, src_bytes, 768, sink, 2);
