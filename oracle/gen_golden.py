@@ -266,23 +266,29 @@ class _PassModel(torch.nn.Module):
 
 
 TRACE = dict(num_train_iter=2000, start_timing=100, N_k=10, ulb_dest_len=256, C=10, Bl=4, Bu=4,
-             its=[0, 1, 99, 100, 101, 110, 300, 301], seed=81, num_warmup_iter=50)
+             its=[0, 1, 99, 100, 101, 110, 300, 301], seed=81, num_warmup_iter=50, p_cutoff=0.95, algorithm="srflexmatch")
+# srfixmatch: a fixed threshold of 0.95 would mask every row of a random-init 10-class model; 0.16 exercises both outcomes
+TRACE_FIX = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=91, p_cutoff=0.16, algorithm="srfixmatch")
 
 
 def build_headless_srflexmatch(model, C, Fd, tr):
-    srf = R.mod("semilearn.algorithms.srflexmatch.srflexmatch")
+    fix = tr["algorithm"] == "srfixmatch"
+    srf = R.mod("semilearn.algorithms.srfixmatch.fixmatch") if fix else R.mod("semilearn.algorithms.srflexmatch.srflexmatch")
     sr = R.mod("semilearn.algorithms.semireward.semireward")
     um = R.mod("semilearn.algorithms.srflexmatch.utils")
     hk = R.mod("semilearn.algorithms.hooks")
     cr = R.mod("semilearn.core.criterions")
     bu = R.mod("semilearn.core.utils.build")
-    alg = object.__new__(srf.SRFlexMatch)
+    alg = object.__new__(srf.SRFixMatch if fix else srf.SRFlexMatch)
     alg.args = types.SimpleNamespace(ulb_dest_len=tr["ulb_dest_len"], thresh_warmup=True)
     alg.num_classes, alg.use_cat, alg.amp_cm, alg.gpu = C, True, contextlib.nullcontext, None
     alg.lambda_u, alg.num_train_iter, alg.it = 1.0, tr["num_train_iter"], 0
     alg.model = model
     alg.ce_loss, alg.consistency_loss = cr.CELoss(), cr.ConsistencyLoss()
-    alg.init(T=0.5, p_cutoff=0.95, hard_label=True, thresh_warmup=True)
+    if fix:
+        alg.init(T=0.5, p_cutoff=tr["p_cutoff"], hard_label=True)
+    else:
+        alg.init(T=0.5, p_cutoff=tr["p_cutoff"], hard_label=True, thresh_warmup=True)
     alg.N_k, alg.start_timing = tr["N_k"], tr["start_timing"]
     alg.rewarder = sr.Rewarder(sr.label_dim(C), 128, Fd)
     alg.generator = sr.Generator(Fd)
@@ -294,14 +300,22 @@ def build_headless_srflexmatch(model, C, Fd, tr):
     from collections import OrderedDict
     alg.hooks_dict = OrderedDict()
     alg.register_hook(hk.PseudoLabelingHook(), "PseudoLabelingHook")
-    alg.register_hook(um.FlexMatchThresholdingHook(ulb_dest_len=tr["ulb_dest_len"], num_classes=C, thresh_warmup=True), "MaskingHook")
+    if fix:
+        alg.register_hook(hk.FixedThresholdingHook(), "MaskingHook")
+    else:
+        alg.register_hook(um.FlexMatchThresholdingHook(ulb_dest_len=tr["ulb_dest_len"], num_classes=C, thresh_warmup=True), "MaskingHook")
     alg.optimizer = bu.get_optimizer(model, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
     alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
     return alg
 
 
-def gen_trace():
-    tr = TRACE
+def gen_trace_fix():
+    gen_trace(TRACE_FIX, "srfixmatch_trace.npz")
+
+
+def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
+    tr = tr or TRACE
+    fix = tr["algorithm"] == "srfixmatch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
     Fd = cfg.embed_dim
@@ -332,11 +346,15 @@ def gen_trace():
 
         def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
             m = _orig(algorithm, *a, **k)
-            _rec["mask"].append(m.numpy().copy()); _rec["acc"].append(mh.classwise_acc.numpy().copy())
+            _rec["mask"].append(m.numpy().copy())
+            _rec["acc"].append(mh.classwise_acc.numpy().copy() if hasattr(mh, "classwise_acc") else np.zeros(1, np.float32))
             return m
         mh.masking = wrapped
         rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
-        o, log = alg.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["idx_ulb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]))
+        if fix:
+            o, log = alg.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]))
+        else:
+            o, log = alg.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["idx_ulb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]))
         mh.masking = orig
         assert alg.model.calls == K + 1, (alg.model.calls, K)
         o["loss"].backward()                      # ParamUpdateHook.after_train_step
@@ -359,13 +377,17 @@ def gen_trace():
             flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
         mr = alg.max_reward
         out[f"{p}/max_reward"] = np.float64(float(mr))
-        sel = mh.selected_label.numpy(); nz = np.nonzero(sel != -1)[0]
-        out[f"{p}/sel_idx"] = nz.astype(np.int64); out[f"{p}/sel_val"] = sel[nz]
+        if not fix:
+            sel = mh.selected_label.numpy(); nz = np.nonzero(sel != -1)[0]
+            out[f"{p}/sel_idx"] = nz.astype(np.int64); out[f"{p}/sel_val"] = sel[nz]
     out["meta/its"] = np.array(tr["its"], dtype=np.int64)
-    np.savez_compressed(os.path.join(OUT, "srflexmatch_trace.npz"), **out)
+    allm = np.concatenate([out[f"it{it}/masks"].ravel() for it in tr["its"]])
+    print(fname, "mask mean", allm.mean())
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
-GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace)
+GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
+            trace_fix=gen_trace_fix)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

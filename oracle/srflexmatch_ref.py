@@ -24,7 +24,10 @@ class SRFlexMatchOracle:
     def __init__(self, cfg, vit_params, rewarder_params, generator_params, *,
                  num_train_iter, start_timing, N_k=10, p_cutoff=0.95, lambda_u=1.0,
                  ulb_dest_len=50000, thresh_warmup=True, sr_lr=5e-4,
-                 lr=5e-4, weight_decay=5e-4, layer_decay=0.5, num_warmup_iter=0):
+                 lr=5e-4, weight_decay=5e-4, layer_decay=0.5, num_warmup_iter=0, algorithm="srflexmatch"):
+        # algorithm: 'srflexmatch' (FlexMatchThresholdingHook, needs idx_ulb) or 'srfixmatch'
+        # (FixedThresholdingHook, semilearn/algorithms/srfixmatch/fixmatch.py:13-225 -- same step otherwise)
+        self.algorithm = algorithm
         self.cfg = cfg
         self.P = {k: v.clone() for k, v in vit_params.items()}
         self.R = {k: v.clone() for k, v in rewarder_params.items()}
@@ -54,6 +57,11 @@ class SRFlexMatchOracle:
         fw, fs = ft[nl:].chunk(2)
         return lg[:nl], lw, ls, ft[:nl], fw, fs
 
+    def _mask(self, probs, idx_ulb):
+        if self.algorithm == "srfixmatch":
+            return H.fixed_threshold_mask(probs.numpy(), self.p_cutoff)                      # masking.py:55-56
+        return self.hook.masking(probs.numpy(), idx_ulb.numpy(), self.p_cutoff)              # srflexmatch/utils.py:38-63
+
     def _sr_update(self, feats, gen_labels, ref_labels):
         target = S.cosine_target(gen_labels, ref_labels, self.cfg.num_classes)
         reward, grads, lg, lr_ = S.rewarder_update_grads(self.R, feats, gen_labels, target)
@@ -71,7 +79,7 @@ class SRFlexMatchOracle:
         lx, lw, ls, fx, fw, fs = self._forward(P, x_lb, x_ulb_w, x_ulb_s, droppath[0])
         sup_loss = H.ce_loss_mean(lx, y_lb)                                       # :132
         probs = H.softmax_probs(lw.detach())                                      # :135
-        mask0 = torch.from_numpy(self.hook.masking(probs.numpy(), idx_ulb.numpy(), self.p_cutoff))  # :141
+        mask0 = torch.from_numpy(self._mask(probs, idx_ulb))                             # :141
         pl0 = torch.from_numpy(H.pseudo_label_hard(probs.numpy()))                # :142
         tr["passes"] = [dict(mask=mask0.clone(), pseudo_label=pl0.clone(),
                              classwise_acc=self.hook.classwise_acc.copy())]
@@ -82,7 +90,7 @@ class SRFlexMatchOracle:
                 _, lwk, lsk, _, fwk, _ = self._forward(P, x_lb, x_ulb_w, x_ulb_s, droppath[k])
                 pk = H.softmax_probs(lwk.detach())
                 plk = torch.from_numpy(H.pseudo_label_hard(pk.numpy()))
-                mk = torch.from_numpy(self.hook.masking(pk.numpy(), idx_ulb.numpy(), self.p_cutoff))
+                mk = torch.from_numpy(self._mask(pk, idx_ulb))
                 reward = S.rewarder_forward(self.R, fwk.detach(), plk)            # :99 (no grad flows, A.10)
                 mask2 = S.reward_mask2(reward)                                    # :100-101
                 unsup_loss = H.consistency_loss(lsk, plk, mk, mask2)              # :102

@@ -1,4 +1,4 @@
-"""SRFlexMatch (FlexMatch + SemiReward) on the HIP engine -- registered under the reference's key 'srflexmatch'.
+"""SRFlexMatch / SRFixMatch (FlexMatch|FixMatch + SemiReward) on the HIP engine -- registered under the reference's keys.
 
 Reference: semilearn/algorithms/srflexmatch/srflexmatch.py (train_step :107-217, data_generator :72-104).
 Semantics reproduced exactly: control-flow thresholds on ``it``, K = sr_decay() extra
@@ -19,7 +19,7 @@ import torch
 from .. import ops
 from ..core.algorithmbase import AlgorithmBase, DeferredScalar
 from ..core.registry import ALGORITHMS
-from .hooks import FlexMatchThresholdingHook, PseudoLabelingHook
+from .hooks import FixedThresholdingHook, FlexMatchThresholdingHook, PseudoLabelingHook
 from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
@@ -41,11 +41,13 @@ class _Plan:
         self.P, self.Bt = K + 1, Bt
 
 
-@ALGORITHMS.register("srflexmatch")
-class SRFlexMatch(AlgorithmBase):
+class SRConsistencyBase(AlgorithmBase):
+    """Shared step of the confidence-threshold SemiReward algorithms (SRFlexMatch, SRFixMatch): the reference classes
+    differ only in their MaskingHook and in whether ``train_step`` receives ``idx_ulb``."""
+
     def __init__(self, args, net_builder, tb_log=None, logger=None):
         super().__init__(args, net_builder, tb_log, logger)
-        self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label, thresh_warmup=args.thresh_warmup)
+        self._init_thresholds(args)
         self.N_k = args.N_k
         # sr_ema != 0 selects EMARewarder in the reference (srflexmatch.py:49-50); its forward is identical and its EMA
         # dict is never read (SURVEY.md A.6), so one Rewarder class covers both.
@@ -61,14 +63,12 @@ class SRFlexMatch(AlgorithmBase):
         self.inject_droppath = None            # tests: list of [depth,2,Bt] tensors, one per pass
         self.trace = None                      # tests: dict filled with per-pass intermediates when not None
 
-    def init(self, T, p_cutoff, hard_label=True, thresh_warmup=True):
-        self.T, self.p_cutoff, self.use_hard_label, self.thresh_warmup = T, p_cutoff, hard_label, thresh_warmup
+    def _init_thresholds(self, args):
+        raise NotImplementedError
 
-    def set_hooks(self):
-        self.register_hook(PseudoLabelingHook(), "PseudoLabelingHook")
-        self.register_hook(FlexMatchThresholdingHook(ulb_dest_len=self.args.ulb_dest_len, num_classes=self.num_classes,
-                                                     thresh_warmup=self.args.thresh_warmup, device=self.device), "MaskingHook")
-        super().set_hooks()
+    def _masks(self, max_probs, max_idx, idx_ulb, P, nu):
+        """Per-pass confidence masks [P lists of nu] given the row-max of every pass's weak logits."""
+        raise NotImplementedError
 
     # ---- batched (1+K)-pass forward ------------------------------------------------------------------
     def _forward_passes(self, imgs, nl, nu, K):
@@ -113,10 +113,6 @@ class SRFlexMatch(AlgorithmBase):
         if self.trace is not None:
             self.trace.update(sr_target=target, sr_losses=losses)
 
-    def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
-        with ops.stream_scope():
-            return self._train_step(x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s)
-
     def _train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
         assert self.use_cat, "USB-style SemiReward configs use use_cat=True (SURVEY.md Appendix C)"
         nl, nu, it = y_lb.shape[0], x_ulb_w.shape[0], self.it
@@ -124,14 +120,12 @@ class SRFlexMatch(AlgorithmBase):
         imgs = torch.cat((x_lb, x_ulb_w, x_ulb_s)).contiguous()                                  # :113
         L, Fe, ctx = self._forward_passes(imgs, nl, nu, K)
         P, C = K + 1, self.num_classes
-        hook = self.hooks_dict["MaskingHook"]
         # softmax + max/argmax of the weak logits of ALL passes: one launch (compute_prob :135, argmax :142-146)
         Lw = L[:, nl:nl + nu].reshape(P * nu, C)
         mp = torch.empty(P * nu, dtype=torch.float32, device=self.device)
         mi = torch.empty(P * nu, dtype=torch.int64, device=self.device)
         ops.row_max(Lw, False, None, mp, mi, P * nu, C)
-        # masking is order dependent (it mutates selected_label / classwise_acc): pass 0 first, then the K loop passes
-        masks = [hook.masking_from_max(self, mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], idx_ulb) for k in range(P)]
+        masks = self._masks(mp, mi, idx_ulb, P, nu)
         pl0 = mi[:nu]
         sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132
         if K > 0:
@@ -170,13 +164,55 @@ class SRFlexMatch(AlgorithmBase):
                                          total_loss=DeferredScalar(total_loss), util_ratio=DeferredScalar(masks[0].mean()))
         return out_dict, log_dict
 
+    def _sr_save(self, d):
+        # n4 (SURVEY.md 8f): the reference forgets the SR state on resume; keep it under extra keys
+        d["sr_rewarder"], d["sr_generator"] = self.rewarder.state_dict(), self.generator.state_dict()
+        d["sr_rewarder_optimizer"], d["sr_max_reward"] = self.rewarder_optimizer.state_dict(), float(self.max_reward)
+        return d
+
+    def _sr_load(self, ck):
+        if "sr_rewarder" in ck:
+            self.rewarder.load_state_dict(ck["sr_rewarder"]); self.generator.load_state_dict(ck["sr_generator"])
+            self.rewarder_optimizer.load_state_dict(ck["sr_rewarder_optimizer"])
+            self.max_reward = torch.full((), ck["sr_max_reward"], device=self.device)
+        return ck
+
+    def get_save_dict(self):
+        return self._sr_save(super().get_save_dict())
+
+    def load_model(self, load_path):
+        return self._sr_load(super().load_model(load_path))
+
+
+@ALGORITHMS.register("srflexmatch")
+class SRFlexMatch(SRConsistencyBase):
+    """semilearn/algorithms/srflexmatch/srflexmatch.py:15-246."""
+
+    def _init_thresholds(self, args):
+        self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label, thresh_warmup=args.thresh_warmup)
+
+    def init(self, T, p_cutoff, hard_label=True, thresh_warmup=True):
+        self.T, self.p_cutoff, self.use_hard_label, self.thresh_warmup = T, p_cutoff, hard_label, thresh_warmup
+
+    def set_hooks(self):
+        self.register_hook(PseudoLabelingHook(), "PseudoLabelingHook")
+        self.register_hook(FlexMatchThresholdingHook(ulb_dest_len=self.args.ulb_dest_len, num_classes=self.num_classes,
+                                                     thresh_warmup=self.args.thresh_warmup, device=self.device), "MaskingHook")
+        super().set_hooks()
+
+    def _masks(self, mp, mi, idx_ulb, P, nu):
+        # order dependent (mutates selected_label / classwise_acc): pass 0 first, then the K loop passes
+        hook = self.hooks_dict["MaskingHook"]
+        return [hook.masking_from_max(self, mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], idx_ulb) for k in range(P)]
+
+    def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
+        with ops.stream_scope():
+            return self._train_step(x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s)
+
     def get_save_dict(self):
         d = super().get_save_dict()
         d["classwise_acc"] = self.hooks_dict["MaskingHook"].classwise_acc.cpu()
         d["selected_label"] = self.hooks_dict["MaskingHook"].selected_label.cpu()
-        # n4 (SURVEY.md 8f): the reference forgets the SR state on resume; keep it under extra keys
-        d["sr_rewarder"], d["sr_generator"] = self.rewarder.state_dict(), self.generator.state_dict()
-        d["sr_rewarder_optimizer"], d["sr_max_reward"] = self.rewarder_optimizer.state_dict(), float(self.max_reward)
         return d
 
     def load_model(self, load_path):
@@ -184,10 +220,6 @@ class SRFlexMatch(AlgorithmBase):
         h = self.hooks_dict["MaskingHook"]
         h.classwise_acc = ck["classwise_acc"].to(self.device)
         h.selected_label = ck["selected_label"].to(self.device)
-        if "sr_rewarder" in ck:
-            self.rewarder.load_state_dict(ck["sr_rewarder"]); self.generator.load_state_dict(ck["sr_generator"])
-            self.rewarder_optimizer.load_state_dict(ck["sr_rewarder_optimizer"])
-            self.max_reward = torch.full((), ck["sr_max_reward"], device=self.device)
         return ck
 
     @staticmethod
@@ -197,3 +229,37 @@ class SRFlexMatch(AlgorithmBase):
                 SSL_Argument("--start_timing", int, 20000), SSL_Argument("--feature_dim", int, 384),
                 SSL_Argument("--sr_lr", float, 0.0005), SSL_Argument("--N_k", int, 10),
                 SSL_Argument("--sr_ema", str2bool, True), SSL_Argument("--sr_ema_m", float, 0.999)]
+
+
+@ALGORITHMS.register("srfixmatch")
+class SRFixMatch(SRConsistencyBase):
+    """semilearn/algorithms/srfixmatch/fixmatch.py:13-225: FixMatch + SemiReward.  Same step as SRFlexMatch with the
+    stateless FixedThresholdingHook (masking.py:42-57) -> the masks of all passes come from ONE launch."""
+
+    def _init_thresholds(self, args):
+        self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label)
+
+    def init(self, T, p_cutoff, hard_label=True):
+        self.T, self.p_cutoff, self.use_hard_label = T, p_cutoff, hard_label
+
+    def set_hooks(self):
+        self.register_hook(PseudoLabelingHook(), "PseudoLabelingHook")
+        self.register_hook(FixedThresholdingHook(), "MaskingHook")
+        super().set_hooks()
+
+    def _masks(self, mp, mi, idx_ulb, P, nu):
+        m = torch.empty_like(mp)
+        ops.fixed_mask(mp, float(self.p_cutoff), m, P * nu)
+        return [m[k * nu:(k + 1) * nu] for k in range(P)]
+
+    def train_step(self, x_lb, y_lb, x_ulb_w, x_ulb_s):
+        with ops.stream_scope():
+            return self._train_step(x_lb, y_lb, None, x_ulb_w, x_ulb_s)
+
+    @staticmethod
+    def get_argument():
+        return [SSL_Argument("--hard_label", str2bool, True), SSL_Argument("--T", float, 0.5),
+                SSL_Argument("--p_cutoff", float, 0.95), SSL_Argument("--start_timing", int, 20000),
+                SSL_Argument("--feature_dim", int, 384), SSL_Argument("--sr_lr", float, 0.0005),
+                SSL_Argument("--N_k", int, 10), SSL_Argument("--sr_ema", str2bool, True),
+                SSL_Argument("--sr_ema_m", float, 0.999)]

@@ -79,8 +79,12 @@ def test_optimizer_host_tables(golden):
 
 def test_pass_plan_and_registry():
     from semireward_amd.algorithms import ALGORITHMS
-    from semireward_amd.algorithms.srflexmatch import SRFlexMatch, _Plan
-    assert ALGORITHMS["srflexmatch"] is SRFlexMatch
+    from inspect import signature
+    from semireward_amd.algorithms.srflexmatch import SRFixMatch, SRFlexMatch, _Plan
+    assert ALGORITHMS["srflexmatch"] is SRFlexMatch and ALGORITHMS["srfixmatch"] is SRFixMatch
+    # train_step signatures ARE the batch schema (algorithmbase.py:287-306)
+    assert list(signature(SRFlexMatch.train_step).parameters)[1:] == ["x_lb", "y_lb", "idx_ulb", "x_ulb_w", "x_ulb_s"]
+    assert list(signature(SRFixMatch.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w", "x_ulb_s"]
     names = [a.name for a in SRFlexMatch.get_argument()]
     assert names == ["--hard_label", "--T", "--p_cutoff", "--thresh_warmup", "--start_timing", "--feature_dim", "--sr_lr",
                      "--N_k", "--sr_ema", "--sr_ema_m"]                      # srflexmatch.py:233-246

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import semireward_ref as S        # noqa: E402
 from oracle import vit_ref as V               # noqa: E402
-from oracle.gen_golden import TRACE           # noqa: E402
+from oracle.gen_golden import TRACE, TRACE_FIX   # noqa: E402
 from semireward_amd.algorithms import get_algorithm   # noqa: E402
 from semireward_amd.nets import vit           # noqa: E402
 from semireward_amd.utils import synth        # noqa: E402
@@ -32,12 +32,13 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def test_srflexmatch_trace(golden):
-    g = golden("srflexmatch_trace")
-    tr = TRACE
+@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX)])
+def test_sr_train_step_trace(golden, name, tr):
+    g = golden(name)
+    fix = tr["algorithm"] == "srfixmatch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
-    alg = get_algorithm(make_args(), vit.vit_tiny_test)
+    alg = get_algorithm(make_args(algorithm=tr["algorithm"], p_cutoff=tr["p_cutoff"]), vit.vit_tiny_test)
     T = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
     alg.model.load_state_dict(T(synth.synth_params(V.param_shapes(cfg), seed)))
     alg.rewarder.load_state_dict(T(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), seed + 1)))
@@ -53,7 +54,7 @@ def test_srflexmatch_trace(golden):
                                for k in range(K + 1)]
         alg.trace = {}
         before = alg.rewarder.flat.clone()
-        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))   # idx_ulb dropped for srfixmatch
         alg.out_dict, alg.log_dict = out, log
         assert alg.optimizer.lr_factor() == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
         alg.call_hook("after_train_step")
@@ -71,7 +72,7 @@ def test_srflexmatch_trace(golden):
         assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
         mr = float(g[f"{p}/max_reward"])
         assert (np.isinf(mr) and np.isinf(float(alg.max_reward))) or float(alg.max_reward) == pytest.approx(mr, rel=1e-2), p
-        if masks.shape == want.shape and (masks == want).all():
+        if not fix and masks.shape == want.shape and (masks == want).all():
             sel = alg.hooks_dict["MaskingHook"].selected_label.cpu().numpy()
             nz = np.nonzero(sel != -1)[0]
             assert np.array_equal(nz, g[f"{p}/sel_idx"]) and np.array_equal(sel[nz], g[f"{p}/sel_val"]), p
