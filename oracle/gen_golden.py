@@ -309,6 +309,105 @@ def build_headless_srflexmatch(model, C, Fd, tr):
     return alg
 
 
+TRACE_PL = dict(TRACE, its=[0, 1, 99, 100, 101, 110, 900], seed=95, p_cutoff=0.16, algorithm="srpseudolabel", unsup_warm_up=0.4)
+
+
+class _PassModelPL(torch.nn.Module):
+    """SRPseudoLabel calls model(x_lb) then model(x_ulb_w) in pass 0 and model(x_ulb_w) in every later pass."""
+
+    def __init__(self, model, dps):
+        super().__init__()
+        self.model, self.dps, self.calls = model, dps, 0
+
+    def forward(self, x):
+        inject_droppath(self.model, self.dps[self.calls])
+        self.calls += 1
+        return self.model(x)
+
+
+def gen_trace_pl():
+    tr = TRACE_PL
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+    Fd = cfg.embed_dim
+    srp = R.mod("semilearn.algorithms.srpseudolabel.srpseudolabel")
+    sr = R.mod("semilearn.algorithms.semireward.semireward")
+    hk = R.mod("semilearn.algorithms.hooks")
+    cr = R.mod("semilearn.core.criterions")
+    bu = R.mod("semilearn.core.utils.build")
+    misc = R.mod("semilearn.core.utils.misc")
+    model = build_ref_vit(V.VIT_TINY_TEST, C, synth.synth_params(V.param_shapes(cfg), seed))
+    model.train()
+    alg = object.__new__(srp.SRPseudoLabel)
+    alg.args = types.SimpleNamespace()
+    alg.num_classes, alg.amp_cm, alg.gpu, alg.task_type = C, contextlib.nullcontext, None, "cls"
+    alg.lambda_u, alg.num_train_iter, alg.it = 1.0, tr["num_train_iter"], 0
+    alg.bn_controller = misc.Bn_Controller()
+    alg.ce_loss, alg.consistency_loss = cr.CELoss(), cr.ConsistencyLoss()
+    alg.init(p_cutoff=tr["p_cutoff"], unsup_warm_up=tr["unsup_warm_up"])
+    alg.N_k, alg.start_timing = tr["N_k"], tr["start_timing"]
+    alg.rewarder, alg.generator = sr.Rewarder(sr.label_dim(C), 128, Fd), sr.Generator(Fd)
+    load_module_params(alg.rewarder, synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1))
+    load_module_params(alg.generator, synth.synth_params(S.generator_shapes(Fd), seed + 2))
+    alg.rewarder_optimizer = torch.optim.Adam(alg.rewarder.parameters(), lr=5e-4)
+    alg.generator_optimizer = torch.optim.Adam(alg.generator.parameters(), lr=5e-4)
+    alg.criterion = torch.nn.MSELoss()
+    alg.max_reward = -float("inf")
+    alg._hooks = []
+    from collections import OrderedDict
+    alg.hooks_dict = OrderedDict()
+    alg.register_hook(hk.PseudoLabelingHook(), "PseudoLabelingHook")
+    alg.register_hook(hk.FixedThresholdingHook(), "MaskingHook")
+    alg.optimizer = bu.get_optimizer(model, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+    alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
+    out, prev_it = {}, -1
+    for n, it in enumerate(tr["its"]):
+        for _ in range(it - prev_it - 1):
+            alg.scheduler.step()
+        prev_it = it
+        alg.it = it
+        K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        dps = [synth.synth_droppath(seed + 1000 * (n + 1), V.drop_path_probs(cfg), Bl)] + \
+              [synth.synth_droppath(seed + 1000 * (n + 1) + 1 + k, V.drop_path_probs(cfg), Bu) for k in range(K + 1)]
+        alg.model = _PassModelPL(model, dps)
+        rec = []
+        mh = alg.hooks_dict["MaskingHook"]
+        orig = mh.masking
+
+        def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
+            m = _orig(algorithm, *a, **k)
+            _rec.append(m.numpy().copy())
+            return m
+        mh.masking = wrapped
+        rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
+        o, log = alg.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["x_ulb_w"]))
+        mh.masking = orig
+        assert alg.model.calls == K + 2, (alg.model.calls, K)
+        o["loss"].backward()
+        p = f"it{it}"
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/grad/{nme}", samp(prm.grad.numpy(), 64), out)
+        out[f"{p}/lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / 5e-4)
+        alg.optimizer.step(); alg.scheduler.step(); model.zero_grad()
+        for k_, v in log.items():
+            out[f"{p}/log/{k_.split('/')[-1]}"] = np.float64(v)
+        out[f"{p}/K"] = np.int64(K)
+        out[f"{p}/masks"] = np.stack(rec)
+        for k_ in ("x_lb", "x_ulb_w"):
+            out[f"{p}/feat/{k_}"] = o["feat"][k_].detach().numpy()
+        out[f"{p}/rewarder_updated"] = np.int64(any(not torch.equal(rbefore[k_], v.detach()) for k_, v in alg.rewarder.named_parameters()))
+        for k_, v in alg.rewarder.named_parameters():
+            flat(f"{p}/rewarder/{k_}", samp(v.detach().numpy(), 64), out)
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
+        out[f"{p}/max_reward"] = np.float64(float(alg.max_reward))
+    out["meta/its"] = np.array(tr["its"], dtype=np.int64)
+    allm = np.concatenate([out[f"it{it}/masks"].ravel() for it in tr["its"]])
+    print("srpseudolabel_trace.npz mask mean", allm.mean())
+    np.savez_compressed(os.path.join(OUT, "srpseudolabel_trace.npz"), **out)
+
+
 def gen_trace_fix():
     gen_trace(TRACE_FIX, "srfixmatch_trace.npz")
 
@@ -387,7 +486,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
-            trace_fix=gen_trace_fix)
+            trace_fix=gen_trace_fix, trace_pl=gen_trace_pl)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -1,6 +1,7 @@
 """Importing this package registers the SemiReward algorithms under the reference's keys."""
 from ..core.registry import ALGORITHMS  # noqa: F401
 from .srflexmatch import SRFixMatch, SRFlexMatch  # noqa: F401
+from .srpseudolabel import SRPseudoLabel  # noqa: F401
 
 
 def get_algorithm(args, net_builder, tb_log=None, logger=None):

@@ -25,20 +25,28 @@ from .utils import SSL_Argument, str2bool
 
 
 class _Plan:
-    """Row bookkeeping for one (nl, nu, K): which (pass, image) rows need a backward graph."""
+    """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
+    rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
 
-    def __init__(self, nl, nu, K, device):
-        Bt = nl + 2 * nu
-        last = K
-        grad = [(0, j) for j in range(nl)] + [(last, j) for j in range(nl + nu, Bt)]
-        gset = set(grad)
-        inf = [(k, j) for k in range(K + 1) for j in range(Bt) if (k, j) not in gset]
+    def __init__(self, cols_img, grad_cols, device):
+        gset = set(grad_cols)
+        inf_cols = [c for c in range(len(cols_img)) if c not in gset]
         t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
-        self.grad_cols = t([k * Bt + j for k, j in grad], torch.int64)
-        self.inf_cols = t([k * Bt + j for k, j in inf], torch.int64)
-        self.grad_img = t([j for _, j in grad], torch.int32)
-        self.inf_img = t([j for _, j in inf], torch.int32)
-        self.P, self.Bt = K + 1, Bt
+        self.grad_cols, self.inf_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64)
+        self.grad_img = t([cols_img[c] for c in grad_cols], torch.int32)
+        self.inf_img = t([cols_img[c] for c in inf_cols], torch.int32)
+        self.ncols = len(cols_img)
+
+    @classmethod
+    def cat_passes(cls, nl, nu, K, device):
+        """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
+        labelled rows of pass 0 and the strong rows of the last pass."""
+        Bt = nl + 2 * nu
+        cols_img = [j for _ in range(K + 1) for j in range(Bt)]
+        grad = list(range(nl)) + [K * Bt + j for j in range(nl + nu, Bt)]
+        p = cls(cols_img, grad, device)
+        p.P, p.Bt = K + 1, Bt
+        return p
 
 
 class SRConsistencyBase(AlgorithmBase):
@@ -70,25 +78,23 @@ class SRConsistencyBase(AlgorithmBase):
         """Per-pass confidence masks [P lists of nu] given the row-max of every pass's weak logits."""
         raise NotImplementedError
 
-    # ---- batched (1+K)-pass forward ------------------------------------------------------------------
-    def _forward_passes(self, imgs, nl, nu, K):
-        key = (nl, nu, K)
-        if key not in self._plans:
-            self._plans[key] = _Plan(nl, nu, K, self.device)
-        pl = self._plans[key]
-        P, Bt, m = pl.P, pl.Bt, self.model
+    # ---- batched multi-pass forward -----------------------------------------------------------------
+    def _forward_plan(self, imgs, pl, droppath_cols=None):
+        """Runs every column of the plan through the backbone (inference rows in one or more no-save launches-trains, grad
+        rows with activations kept).  Returns (logits [ncols,C], feats [ncols,D], ctx)."""
+        m = self.model
         C, D = self.num_classes, m.cfg.embed_dim
-        if self.inject_droppath is not None:
-            dp_all = torch.cat([d.to(self.device) for d in self.inject_droppath[:P]], dim=2)       # [depth,2,P*Bt]
+        if droppath_cols is not None:
+            dp_all = droppath_cols.to(self.device)                                                   # [depth,2,ncols]
         elif m.training and m.cfg.drop_path_rate > 0:
-            dp_all = m.make_droppath(P * Bt)
+            dp_all = m.make_droppath(pl.ncols)
         else:
             dp_all = None
         sel = (lambda cols: dp_all.index_select(2, cols).contiguous()) if dp_all is not None else (lambda cols: None)
-        logits = torch.empty(P * Bt, C, dtype=torch.float32, device=self.device)
-        feats = torch.empty(P * Bt, D, dtype=torch.float32, device=self.device)
+        logits = torch.empty(pl.ncols, C, dtype=torch.float32, device=self.device)
+        feats = torch.empty(pl.ncols, D, dtype=torch.float32, device=self.device)
         ni = pl.inf_cols.numel()
-        step = self.infer_chunk if self.infer_chunk > 0 else ni
+        step = self.infer_chunk if self.infer_chunk > 0 else max(ni, 1)
         for s in range(0, ni, step):
             cols = pl.inf_cols[s:s + step]
             lg, ft, _ = m.forward_features(imgs, pl.inf_img[s:s + step].contiguous(), sel(cols), save=False)
@@ -97,7 +103,16 @@ class SRConsistencyBase(AlgorithmBase):
         lg, ft, ctx = m.forward_features(imgs, pl.grad_img, sel(pl.grad_cols), save=True)
         logits.index_copy_(0, pl.grad_cols, lg)
         feats.index_copy_(0, pl.grad_cols, ft)
-        return logits.view(P, Bt, C), feats.view(P, Bt, D), ctx
+        return logits, feats, ctx
+
+    def _forward_passes(self, imgs, nl, nu, K):
+        key = (nl, nu, K)
+        if key not in self._plans:
+            self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device)
+        pl = self._plans[key]
+        dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
+        logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
+        return logits.view(pl.P, pl.Bt, -1), feats.view(pl.P, pl.Bt, -1), ctx
 
     def _sr_update(self, feats, gen_labels, ref_labels):
         """srflexmatch.py:179-193 / :194-208: target, MSE(r,1) + MSE(r,t), both backward() into the rewarder, Adam."""

@@ -88,8 +88,11 @@ def test_pass_plan_and_registry():
     names = [a.name for a in SRFlexMatch.get_argument()]
     assert names == ["--hard_label", "--T", "--p_cutoff", "--thresh_warmup", "--start_timing", "--feature_dim", "--sr_lr",
                      "--N_k", "--sr_ema", "--sr_ema_m"]                      # srflexmatch.py:233-246
+    from semireward_amd.algorithms.srpseudolabel import SRPseudoLabel
+    assert ALGORITHMS["srpseudolabel"] is SRPseudoLabel
+    assert list(signature(SRPseudoLabel.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w"]
     for nl, nu, K in [(8, 8, 8), (8, 8, 0), (4, 4, 20), (3, 5, 2)]:
-        p = _Plan(nl, nu, K, "cpu")
+        p = _Plan.cat_passes(nl, nu, K, "cpu")
         Bt = nl + 2 * nu
         allc = torch.cat([p.grad_cols, p.inf_cols]).sort().values
         assert torch.equal(allc, torch.arange((K + 1) * Bt))                 # every (pass, image) row exactly once

@@ -108,3 +108,49 @@ def test_train_loop_and_checkpoint(tmp_path):
     assert torch.equal(alg2.model.flat, alg.model.flat) and torch.equal(alg2.rewarder.flat, alg.rewarder.flat)
     h1, h2 = alg.hooks_dict["MaskingHook"], alg2.hooks_dict["MaskingHook"]
     assert torch.equal(h1.selected_label, h2.selected_label) and torch.equal(h1.hist, h2.hist)
+
+
+def test_srpseudolabel_trace(golden):
+    from oracle.gen_golden import TRACE_PL as tr
+    g = golden("srpseudolabel_trace")
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+    alg = get_algorithm(make_args(algorithm="srpseudolabel", p_cutoff=tr["p_cutoff"], unsup_warm_up=tr["unsup_warm_up"]), vit.vit_tiny_test)
+    T = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
+    alg.model.load_state_dict(T(synth.synth_params(V.param_shapes(cfg), seed)))
+    alg.rewarder.load_state_dict(T(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), seed + 1)))
+    alg.generator.load_state_dict(T(synth.synth_params(S.generator_shapes(cfg.embed_dim), seed + 2)))
+    flips = total = 0
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        alg.it = it
+        alg.optimizer.sched_step = it
+        K = int(g[f"{p}/K"])
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        dpl = torch.from_numpy(synth.synth_droppath(seed + 1000 * (n + 1), V.drop_path_probs(cfg), Bl))
+        dpu = [torch.from_numpy(synth.synth_droppath(seed + 1000 * (n + 1) + 1 + k, V.drop_path_probs(cfg), Bu)) for k in range(K + 1)]
+        alg.inject_droppath = [(dpl, dpu[0])] + dpu[1:]
+        alg.trace = {}
+        before = alg.rewarder.flat.clone()
+        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))   # idx_ulb / x_ulb_s dropped
+        alg.out_dict, alg.log_dict = out, log
+        alg.call_hook("after_train_step")
+        assert alg.trace["K"] == K
+        masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
+        bad = masks != g[f"{p}/masks"]
+        flips += int(bad.sum())
+        total += bad.size
+        # a flipped row must sit ON the threshold: |max_prob - p_cutoff| within the bf16-backbone noise of the probabilities
+        mpv = alg.trace["max_probs"].cpu().numpy().reshape(masks.shape)
+        assert np.all(np.abs(mpv[bad] - tr["p_cutoff"]) < 6e-3), (p, mpv[bad])
+        if bad.any():
+            continue          # a flipped mask changes this step's loss by construction; later steps are still checked
+        for k_ in ("sup_loss", "unsup_loss", "total_loss"):
+            assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
+        ftol = 2e-2 + 1.5e-2 * sum(1 for j in tr["its"][:n] if j >= tr["num_warmup_iter"])
+        for k_ in ("x_lb", "x_ulb_w"):
+            assert rel(out["feat"][k_].cpu(), g[f"{p}/feat/{k_}"]) < ftol, (p, k_)
+        assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+    # the fixture puts the cut-off (0.16) in the bulk of a random-init model's max-prob distribution, so a few rows sit on
+    # it; identical masks on identical probabilities are covered bit-exactly by test_gpu_kernels (golden probs)
+    assert flips <= 0.03 * total, (flips, total)

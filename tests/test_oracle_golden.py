@@ -204,3 +204,40 @@ def test_sr_decay_schedule():
     assert H.sr_decay(N, 20001) == 11 and H.sr_decay(N, 20480) == 11
     assert H.sr_decay(N, 22755) == 10 and H.sr_decay(N, 25600) == 9
     assert H.sr_decay(N, 25601) == 8 and H.sr_decay(N, 204799) == 8
+
+
+def test_srpseudolabel_trace(golden):
+    """SRPseudoLabel (srpseudolabel.py:59-201) against the reference trace: separate lb / ulb forwards, logits-fed fixed
+    threshold, self-training loss on the weak view, unsup warm-up factor."""
+    from oracle.gen_golden import TRACE_PL as tr
+    from oracle.srpseudolabel_ref import SRPseudoLabelOracle
+    g = golden("srpseudolabel_trace")
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+    Fd = cfg.embed_dim
+    orc = SRPseudoLabelOracle(
+        cfg, TP(synth.synth_params(V.param_shapes(cfg), seed)), TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
+        TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)), num_train_iter=tr["num_train_iter"],
+        start_timing=tr["start_timing"], N_k=tr["N_k"], ulb_dest_len=tr["ulb_dest_len"], num_warmup_iter=tr["num_warmup_iter"],
+        p_cutoff=tr["p_cutoff"], unsup_warm_up=tr["unsup_warm_up"])
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        orc.it = it
+        K = int(g[f"{p}/K"])
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        dpl = T(synth.synth_droppath(seed + 1000 * (n + 1), V.drop_path_probs(cfg), Bl))
+        dpu = [T(synth.synth_droppath(seed + 1000 * (n + 1) + 1 + k, V.drop_path_probs(cfg), Bu)) for k in range(K + 1)]
+        t = orc.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["x_ulb_w"]), [(dpl, dpu[0])] + dpu[1:])
+        assert t["K"] == K
+        assert np.array_equal(np.stack([q["mask"].numpy() for q in t["passes"]]), g[f"{p}/masks"]), p
+        for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+            assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=2e-5, abs=2e-6), (p, k_)
+        assert int("sr_stage" in t) == int(g[f"{p}/rewarder_updated"]), p
+        for nme, _ in V.param_shapes(cfg):
+            check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 2e-3, 2e-6, f"{p} grad {nme}")
+            check_samp(orc.P[nme].numpy(), g.samp(f"{p}/param/{nme}"), 1e-4, 2e-6, f"{p} param {nme}",
+                       exclude=k_bias_rows(cfg) if nme.endswith("attn.qkv.bias") else None)
+        for k_ in NOISE_FREE_KEYS:
+            check_samp(orc.R[k_].numpy(), g.samp(f"{p}/rewarder/{k_}"), 1e-4, 3e-5, f"{p} rewarder {k_}")
+    allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
+    assert 0.05 < allm.mean() < 0.95
