@@ -116,6 +116,19 @@ int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const
 int srhip_flexmatch_rebuild_hist(const long long* selected_label, int* hist, int ulb_dest_len, int C, void* stream);
 /* FixedThresholdingHook.masking (semilearn/algorithms/hooks/masking.py:42-57). */
 int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream);
+/* FreeMatchThresholdingHook (semilearn/algorithms/freematch/utils.py:24-66), split so that data-parallel ranks can all-reduce
+ * the sufficient statistics instead of all-gathering probabilities:
+ *   stats : colsum[c] = sum_i probs[i,c], hist[c] = #{i : argmax_i = c} of the LOCAL batch;
+ *   update: time_p / p_model / label_hist EMA from the GLOBAL statistics (maxp_all [n_all] = gathered max-probs, colsum, hist),
+ *           then mask[i] = max_probs[i] >= time_p * p_model[idx_i] / max(p_model) for the local rows.  n_all <= 1024. */
+int srhip_freematch_stats(const float* probs, const long long* max_idx, float* colsum, float* hist, int B, int C, void* stream);
+int srhip_freematch_update(const float* maxp_all, int n_all, const float* colsum, const float* hist, const float* max_probs,
+                           const long long* max_idx, float* time_p, float* p_model, float* label_hist, float* mask, int B, int C,
+                           float momentum, float one_minus_momentum, int use_quantile, int clip_thresh, void* stream);
+/* entropy_loss (semilearn/algorithms/srfreematch/srfreematch.py:16-44) forward + analytic backward on the masked rows of the strong
+ * logits; loss = 0 and no gradient when the mask is empty (:216-219).  ws: B*C floats.  accumulate != 0: dlogits += . */
+int srhip_freematch_entropy(const float* logits, const float* mask, const float* p_model, const float* label_hist, float grad_scale,
+                            float* loss_out, float* dlogits, float* ws, int B, int C, int accumulate, void* stream);
 /* mask2 = (reward >= reward.mean()) per independent group of B rows (srflexmatch.py:100-101) (K11).
  * mean_in (optional, [groups]) overrides the local mean: data-parallel global-threshold extension. */
 int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, const float* mean_in, int groups, int B,

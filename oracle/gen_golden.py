@@ -273,19 +273,25 @@ TRACE_FIX = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=91, p_cutoff=0.16, a
 
 def build_headless_srflexmatch(model, C, Fd, tr):
     fix = tr["algorithm"] == "srfixmatch"
+    free = tr["algorithm"] == "srfreematch"
     srf = R.mod("semilearn.algorithms.srfixmatch.fixmatch") if fix else R.mod("semilearn.algorithms.srflexmatch.srflexmatch")
+    if free:
+        srf = R.mod("semilearn.algorithms.srfreematch.srfreematch")
     sr = R.mod("semilearn.algorithms.semireward.semireward")
     um = R.mod("semilearn.algorithms.srflexmatch.utils")
     hk = R.mod("semilearn.algorithms.hooks")
     cr = R.mod("semilearn.core.criterions")
     bu = R.mod("semilearn.core.utils.build")
-    alg = object.__new__(srf.SRFixMatch if fix else srf.SRFlexMatch)
+    alg = object.__new__(srf.SRFreeMatch if free else (srf.SRFixMatch if fix else srf.SRFlexMatch))
     alg.args = types.SimpleNamespace(ulb_dest_len=tr["ulb_dest_len"], thresh_warmup=True)
     alg.num_classes, alg.use_cat, alg.amp_cm, alg.gpu = C, True, contextlib.nullcontext, None
     alg.lambda_u, alg.num_train_iter, alg.it = 1.0, tr["num_train_iter"], 0
     alg.model = model
     alg.ce_loss, alg.consistency_loss = cr.CELoss(), cr.ConsistencyLoss()
-    if fix:
+    if free:
+        alg.init(T=0.5, hard_label=True, ema_p=tr["ema_p"], use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"])
+        alg.lambda_e, alg.distributed, alg.world_size = tr["ent_loss_ratio"], False, 1
+    elif fix:
         alg.init(T=0.5, p_cutoff=tr["p_cutoff"], hard_label=True)
     else:
         alg.init(T=0.5, p_cutoff=tr["p_cutoff"], hard_label=True, thresh_warmup=True)
@@ -300,7 +306,10 @@ def build_headless_srflexmatch(model, C, Fd, tr):
     from collections import OrderedDict
     alg.hooks_dict = OrderedDict()
     alg.register_hook(hk.PseudoLabelingHook(), "PseudoLabelingHook")
-    if fix:
+    if free:
+        fmu = R.mod("semilearn.algorithms.freematch.utils")
+        alg.register_hook(fmu.FreeMatchThresholdingHook(num_classes=C, momentum=tr["ema_p"]), "MaskingHook")
+    elif fix:
         alg.register_hook(hk.FixedThresholdingHook(), "MaskingHook")
     else:
         alg.register_hook(um.FlexMatchThresholdingHook(ulb_dest_len=tr["ulb_dest_len"], num_classes=C, thresh_warmup=True), "MaskingHook")
@@ -408,13 +417,55 @@ def gen_trace_pl():
     np.savez_compressed(os.path.join(OUT, "srpseudolabel_trace.npz"), **out)
 
 
+TRACE_FREE = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=97, algorithm="srfreematch", ema_p=0.9, use_quantile=True,
+                  clip_thresh=False, ent_loss_ratio=0.05)     # ema_p 0.9 / lambda_e 0.05: make the EMA state and the fairness term visible in 6 steps
+
+
+def gen_trace_free():
+    gen_trace(TRACE_FREE, "srfreematch_trace.npz")
+
+
+def gen_freematch_hook():
+    """FreeMatchThresholdingHook sequences + entropy_loss values/grads straight from the reference."""
+    um = R.mod("semilearn.algorithms.freematch.utils")
+    srf = R.mod("semilearn.algorithms.srfreematch.srfreematch")
+    out = {}
+    for tag, C, Bu, steps, m, uq, clip, seed in [("c10_q", 10, 8, 24, 0.9, True, False, 61), ("c100_mean", 100, 64, 12, 0.999, False, True, 62),
+                                                 ("c100_q", 100, 8, 30, 0.99, True, False, 63)]:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        alg = types.SimpleNamespace(distributed=False, world_size=1, use_quantile=uq, clip_thresh=clip)
+        hook = um.FreeMatchThresholdingHook(num_classes=C, momentum=m)
+        logits = (rng.standard_normal((steps, Bu, C)) * rng.uniform(0.5, 4.0, size=(steps, Bu, 1))).astype(np.float32)
+        ls = (rng.standard_normal((steps, Bu, C)) * 2).astype(np.float32)
+        masks, tps, pms, lhs, ents, entg, probs_all = [], [], [], [], [], [], []
+        for t in range(steps):
+            probs = torch.softmax(T(logits[t]), dim=-1)
+            mk = hook.masking(alg, logits_x_ulb=probs, softmax_x_ulb=False)
+            masks.append(mk.numpy().copy()); tps.append(np.float32(hook.time_p)); pms.append(hook.p_model.numpy().copy())
+            lhs.append(hook.label_hist.numpy().copy()); probs_all.append(probs.numpy())
+            lg = T(ls[t]).requires_grad_(True)
+            if mk.sum() > 0:
+                e, _ = srf.entropy_loss(mk, lg, hook.p_model, hook.label_hist)
+                e.backward()
+                ents.append(np.float32(e.item())); entg.append(lg.grad.numpy().copy())
+            else:
+                ents.append(np.float32(0)); entg.append(np.zeros_like(ls[t]))
+        out.update({f"{tag}/probs": np.stack(probs_all), f"{tag}/logits_s": ls, f"{tag}/mask": np.stack(masks), f"{tag}/time_p": np.array(tps),
+                    f"{tag}/p_model": np.stack(pms), f"{tag}/label_hist": np.stack(lhs), f"{tag}/ent": np.array(ents),
+                    f"{tag}/ent_grad": np.stack(entg), f"{tag}/meta": np.array([C, Bu, steps, int(uq), int(clip), seed], dtype=np.int64),
+                    f"{tag}/momentum": np.float64(m)})
+        print(tag, "mask mean", np.stack(masks).mean())
+    np.savez_compressed(os.path.join(OUT, "freematch_hook.npz"), **out)
+
+
 def gen_trace_fix():
     gen_trace(TRACE_FIX, "srfixmatch_trace.npz")
 
 
 def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
     tr = tr or TRACE
-    fix = tr["algorithm"] == "srfixmatch"
+    fix = tr["algorithm"] in ("srfixmatch", "srfreematch")        # no idx_ulb, no selected_label state
+    free = tr["algorithm"] == "srfreematch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
     Fd = cfg.embed_dim
@@ -476,6 +527,9 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
             flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
         mr = alg.max_reward
         out[f"{p}/max_reward"] = np.float64(float(mr))
+        if free:
+            out[f"{p}/time_p"] = np.float32(mh.time_p); out[f"{p}/p_model"] = mh.p_model.numpy().copy()
+            out[f"{p}/label_hist"] = mh.label_hist.numpy().copy()
         if not fix:
             sel = mh.selected_label.numpy(); nz = np.nonzero(sel != -1)[0]
             out[f"{p}/sel_idx"] = nz.astype(np.int64); out[f"{p}/sel_val"] = sel[nz]
@@ -486,7 +540,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
-            trace_fix=gen_trace_fix, trace_pl=gen_trace_pl)
+            trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -97,3 +97,50 @@ def consistency_loss(logits, targets, mask=None, mask2=None):
     if mask2 is not None:
         loss = loss * mask2
     return loss.mean()
+
+
+class FreeMatchState:
+    """freematch/utils.py:10-66 (self-adaptive thresholds).  torch-CPU fp32, same op order as the reference so the
+    EMA state is reproduced bit for bit.  ``masking`` = update(probs) then mask (utils.py:47-65)."""
+
+    def __init__(self, num_classes, momentum=0.999, use_quantile=True, clip_thresh=False):
+        self.num_classes, self.m = num_classes, momentum
+        self.use_quantile, self.clip_thresh = use_quantile, clip_thresh
+        self.p_model = torch.ones(num_classes) / num_classes
+        self.label_hist = torch.ones(num_classes) / num_classes
+        self.time_p = self.p_model.mean()
+
+    def update(self, probs):
+        max_probs, max_idx = torch.max(probs, dim=-1, keepdim=True)
+        if self.use_quantile:
+            self.time_p = self.time_p * self.m + (1 - self.m) * torch.quantile(max_probs, 0.8)     # :30
+        else:
+            self.time_p = self.time_p * self.m + (1 - self.m) * max_probs.mean()                   # :32
+        if self.clip_thresh:
+            self.time_p = torch.clip(self.time_p, 0.0, 0.95)
+        self.p_model = self.p_model * self.m + (1 - self.m) * probs.mean(dim=0)                    # :37
+        hist = torch.bincount(max_idx.reshape(-1), minlength=self.num_classes).to(self.p_model.dtype)
+        self.label_hist = self.label_hist * self.m + (1 - self.m) * (hist / hist.sum())            # :38-39
+
+    def masking(self, probs):
+        probs = torch.as_tensor(probs, dtype=torch.float32)
+        self.update(probs)
+        max_probs, max_idx = probs.max(dim=-1)
+        mod = self.p_model / torch.max(self.p_model, dim=-1)[0]                                    # :63
+        return max_probs.ge(self.time_p * mod[max_idx]).to(max_probs.dtype)                        # :64
+
+
+def freematch_entropy_loss(mask, logits_s, prob_model, label_hist):
+    """srfreematch.py:16-44 (fairness / entropy term).  Returns the loss (0-d tensor, differentiable w.r.t. logits_s)."""
+    sel = mask.bool()
+    ls = logits_s[sel]
+    prob_s = ls.softmax(dim=-1)
+    pred = prob_s.argmax(dim=-1)
+    hist_s = torch.bincount(pred, minlength=ls.shape[1]).to(ls.dtype)
+    hist_s = hist_s / hist_s.sum()
+    inv = lambda v: torch.where(torch.isinf(1 / v), torch.zeros_like(v), 1 / v)   # noqa: E731  replace_inf_to_zero(1 / v)
+    mod_prob_model = prob_model.reshape(1, -1) * inv(label_hist.reshape(1, -1)).detach()
+    mod_prob_model = mod_prob_model / mod_prob_model.sum(dim=-1, keepdim=True)
+    mod_mean = prob_s.mean(dim=0, keepdim=True) * inv(hist_s).detach()
+    mod_mean = mod_mean / mod_mean.sum(dim=-1, keepdim=True)
+    return (mod_prob_model * torch.log(mod_mean + 1e-12)).sum(dim=1).mean()

@@ -37,6 +37,9 @@ SIGNATURES = {
     "srhip_flexmatch_mask": (I, [P, P, P, F, P, P, P, P, I, I, I, I, P]),
     "srhip_flexmatch_rebuild_hist": (I, [P, P, I, I, P]),
     "srhip_fixed_mask": (I, [P, F, P, I, P]),
+    "srhip_freematch_stats": (I, [P, P, P, P, I, I, P]),
+    "srhip_freematch_update": (I, [P, I, P, P, P, P, P, P, P, P, I, I, F, F, I, I, P]),
+    "srhip_freematch_entropy": (I, [P, P, P, P, F, P, P, P, I, I, I, P]),
     "srhip_reward_mask2": (I, [P, P, P, P, I, I, P]),
     "srhip_masked_ce": (I, [P, P, P, P, F, P, P, I, I, P]),
     "srhip_rewarder_param_count": (L, [I, I]),

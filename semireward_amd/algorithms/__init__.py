@@ -1,6 +1,7 @@
 """Importing this package registers the SemiReward algorithms under the reference's keys."""
 from ..core.registry import ALGORITHMS  # noqa: F401
 from .srflexmatch import SRFixMatch, SRFlexMatch  # noqa: F401
+from .srfreematch import SRFreeMatch  # noqa: F401
 from .srpseudolabel import SRPseudoLabel  # noqa: F401
 
 

@@ -76,3 +76,42 @@ class FlexMatchThresholdingHook(MaskingHook):
     def masking(self, algorithm, logits_x_ulb, idx_ulb, softmax_x_ulb=True, *a, **k):
         mp, mi = _row_max(logits_x_ulb, is_probs=not softmax_x_ulb)
         return self.masking_from_max(algorithm, mp, mi, idx_ulb)
+
+
+class FreeMatchThresholdingHook(MaskingHook):
+    """Self-adaptive thresholding of FreeMatch (semilearn/algorithms/freematch/utils.py:10-66): EMA of the global confidence
+    (``time_p``, mean or 0.8-quantile of the max-probs), of the class marginals (``p_model``) and of the predicted-label
+    histogram (``label_hist``); state advances at EVERY masking call.  Same attribute names as the reference so the
+    algorithm's get_save_dict / load_model keep working."""
+
+    def __init__(self, num_classes, momentum=0.999, device="cuda", *a, **k):
+        super().__init__()
+        self.num_classes, self.m = num_classes, momentum
+        self.p_model = torch.ones(num_classes, dtype=torch.float32, device=device) / num_classes
+        self.label_hist = torch.ones(num_classes, dtype=torch.float32, device=device) / num_classes
+        self.time_p = self.p_model.mean().reshape(1)
+        self._colsum = torch.empty(num_classes, dtype=torch.float32, device=device)
+        self._hist = torch.empty(num_classes, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def masking_from_probs(self, algorithm, probs, max_probs, max_idx):
+        B, C = probs.shape
+        ops.freematch_stats(probs, max_idx, self._colsum, self._hist, B, C)
+        maxp_all, n_all = max_probs, B
+        dp = getattr(algorithm, "dp", None)
+        if dp is not None and dp.active:                      # reference: concat_all_gather(probs) (utils.py:25-26)
+            maxp_all, n_all = dp.gather_stats(max_probs, self._colsum, self._hist)
+        mask = torch.empty_like(max_probs)
+        ops.freematch_update(maxp_all, n_all, self._colsum, self._hist, max_probs, max_idx, self.time_p, self.p_model, self.label_hist,
+                             mask, B, C, self.m, bool(algorithm.use_quantile), bool(algorithm.clip_thresh))
+        algorithm.p_model, algorithm.label_hist, algorithm.time_p = self.p_model, self.label_hist, self.time_p   # utils.py:41-43
+        return mask
+
+    @torch.no_grad()
+    def masking(self, algorithm, logits_x_ulb, softmax_x_ulb=True, *a, **k):
+        B, C = logits_x_ulb.shape
+        probs = torch.empty(B, C, dtype=torch.float32, device=logits_x_ulb.device)
+        mp = torch.empty(B, dtype=torch.float32, device=probs.device)
+        mi = torch.empty(B, dtype=torch.int64, device=probs.device)
+        ops.row_max(logits_x_ulb.contiguous(), not softmax_x_ulb, probs, mp, mi, B, C)
+        return self.masking_from_probs(algorithm, probs, mp, mi)

@@ -38,12 +38,13 @@ class _Plan:
         self.ncols = len(cols_img)
 
     @classmethod
-    def cat_passes(cls, nl, nu, K, device):
+    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
         labelled rows of pass 0 and the strong rows of the last pass."""
         Bt = nl + 2 * nu
         cols_img = [j for _ in range(K + 1) for j in range(Bt)]
-        grad = list(range(nl)) + [K * Bt + j for j in range(nl + nu, Bt)]
+        grad = list(range(nl)) + ([j for j in range(nl + nu, Bt)] if extra_pass0_strong else []) + \
+            [K * Bt + j for j in range(nl + nu, Bt)]
         p = cls(cols_img, grad, device)
         p.P, p.Bt = K + 1, Bt
         return p
@@ -74,9 +75,15 @@ class SRConsistencyBase(AlgorithmBase):
     def _init_thresholds(self, args):
         raise NotImplementedError
 
-    def _masks(self, max_probs, max_idx, idx_ulb, P, nu):
+    def _masks(self, max_probs, max_idx, idx_ulb, P, nu, weak_logits):
         """Per-pass confidence masks [P lists of nu] given the row-max of every pass's weak logits."""
         raise NotImplementedError
+
+    def _fairness(self, logits_s0, mask0, dl_into):
+        """Optional extra loss on the pass-0 strong logits (FreeMatch).  Returns a 0-d loss tensor or None; adds its gradient
+        (already scaled) into ``dl_into`` when that is not None, else returns (loss, new dlogits)."""
+        return None, None
+
 
     # ---- batched multi-pass forward -----------------------------------------------------------------
     def _forward_plan(self, imgs, pl, droppath_cols=None):
@@ -105,10 +112,12 @@ class SRConsistencyBase(AlgorithmBase):
         feats.index_copy_(0, pl.grad_cols, ft)
         return logits, feats, ctx
 
+    fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient
+
     def _forward_passes(self, imgs, nl, nu, K):
         key = (nl, nu, K)
         if key not in self._plans:
-            self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device)
+            self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0)
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
@@ -140,7 +149,7 @@ class SRConsistencyBase(AlgorithmBase):
         mp = torch.empty(P * nu, dtype=torch.float32, device=self.device)
         mi = torch.empty(P * nu, dtype=torch.int64, device=self.device)
         ops.row_max(Lw, False, None, mp, mi, P * nu, C)
-        masks = self._masks(mp, mi, idx_ulb, P, nu)
+        masks = self._masks(mp, mi, idx_ulb, P, nu, Lw)
         pl0 = mi[:nu]
         sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132
         if K > 0:
@@ -155,8 +164,15 @@ class SRConsistencyBase(AlgorithmBase):
         else:
             reward = mask2 = None
             unsup_loss, dl_s = self.consistency_loss(L[0, nl + nu:], pl0, "ce", mask=masks[0], grad_scale=self.lambda_u)        # :152
+        # optional fairness term on the pass-0 strong rows (FreeMatch): same rows as dl_s when K == 0, extra grad rows otherwise
+        if K > 0:
+            ent_loss, dl_e = self._fairness(L[0, nl + nu:], masks[0], None)
+            dl_all = (dl_lb, dl_e, dl_s) if dl_e is not None else (dl_lb, dl_s)
+        else:
+            ent_loss, _ = self._fairness(L[0, nl + nu:], masks[0], dl_s)
+            dl_all = (dl_lb, dl_s)
         # ---- backbone backward: only the rows with a non-zero upstream gradient (see module docstring)
-        self.model.backward(ctx, torch.cat((dl_lb, dl_s)))
+        self.model.backward(ctx, torch.cat(dl_all))
         # ---- rewarder / generator training (:154-208)
         fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
         if it > 0:
@@ -171,6 +187,8 @@ class SRConsistencyBase(AlgorithmBase):
                 gen = self.generator.forward_with_labels(fx.contiguous())[1]                      # :158-159
                 self._sr_update(fx, gen, y_lb)                                                    # :194-208
         total_loss = sup_loss + self.lambda_u * unsup_loss                                        # :210
+        if ent_loss is not None:
+            total_loss = total_loss + self.lambda_e * ent_loss                                    # srfreematch.py:220
         if self.trace is not None:
             self.trace.update(K=K, masks=masks, max_probs=mp, pseudo=mi, reward=reward, mask2=mask2, logits=L, feats=Fe)
         feat_dict = {"x_lb": fx, "x_ulb_w": fw0, "x_ulb_s": Fe[0, nl + nu:]}
@@ -215,7 +233,7 @@ class SRFlexMatch(SRConsistencyBase):
                                                      thresh_warmup=self.args.thresh_warmup, device=self.device), "MaskingHook")
         super().set_hooks()
 
-    def _masks(self, mp, mi, idx_ulb, P, nu):
+    def _masks(self, mp, mi, idx_ulb, P, nu, weak_logits=None):
         # order dependent (mutates selected_label / classwise_acc): pass 0 first, then the K loop passes
         hook = self.hooks_dict["MaskingHook"]
         return [hook.masking_from_max(self, mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], idx_ulb) for k in range(P)]
@@ -262,7 +280,7 @@ class SRFixMatch(SRConsistencyBase):
         self.register_hook(FixedThresholdingHook(), "MaskingHook")
         super().set_hooks()
 
-    def _masks(self, mp, mi, idx_ulb, P, nu):
+    def _masks(self, mp, mi, idx_ulb, P, nu, weak_logits=None):
         m = torch.empty_like(mp)
         ops.fixed_mask(mp, float(self.p_cutoff), m, P * nu)
         return [m[k * nu:(k + 1) * nu] for k in range(P)]

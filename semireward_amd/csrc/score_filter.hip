@@ -188,6 +188,189 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FreeMatch self-adaptive thresholding (semilearn/algorithms/freematch/utils.py:24-66) and the fairness ("entropy") loss
+// (semilearn/algorithms/srfreematch/srfreematch.py:16-44).  All arithmetic fp32, op by op in the reference's order
+// (contraction is off in this file) so the EMA state tracks the reference to the last bits.
+
+// column sums of the probabilities and the predicted-class histogram of the LOCAL batch (the data-parallel path all-reduces
+// these sufficient statistics instead of all-gathering probs).  grid = ceil(C/256).
+__global__ void freematch_stats_kernel(const float* __restrict__ probs, const long long* __restrict__ max_idx, float* __restrict__ colsum,
+                                       float* __restrict__ hist, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, h = 0.f;
+  for (int i = 0; i < B; ++i) {
+    s += probs[(size_t)i * C + c];
+    h += (max_idx[i] == c) ? 1.0f : 0.0f;
+  }
+  colsum[c] = s;
+  hist[c] = h;
+}
+
+// ONE workgroup: time_p / p_model / label_hist EMA update from the (global) statistics, then the mask of the LOCAL rows.
+__global__ __launch_bounds__(256) void freematch_update_kernel(const float* __restrict__ maxp_all, int n_all, const float* __restrict__ colsum,
+                                                              const float* __restrict__ hist, const float* __restrict__ max_probs,
+                                                              const long long* __restrict__ max_idx, float* __restrict__ time_p,
+                                                              float* __restrict__ p_model, float* __restrict__ label_hist,
+                                                              float* __restrict__ mask, int B, int C, float m, float one_minus_m,
+                                                              int use_quantile, int clip_thresh) {
+  __shared__ float srt[1024];
+  __shared__ float sh[8];
+  const int tid = threadIdx.x;
+  // --- time_p
+  if (use_quantile) {          // torch.quantile(x, 0.8), 'linear': sort, rank = 0.8f*(n-1), lerp exactly as ATen does
+    for (int i = tid; i < n_all; i += 256) {
+      const float v = maxp_all[i];
+      int r = 0;
+      for (int j = 0; j < n_all; ++j) { const float u = maxp_all[j]; r += (u < v || (u == v && j < i)) ? 1 : 0; }
+      srt[r] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const float rank = 0.8f * (float)(n_all - 1);
+      const float lo = floorf(rank), w = rank - lo;
+      const float a = srt[(int)lo], b = srt[(int)ceilf(rank)], d = b - a;
+      sh[0] = (w < 0.5f) ? a + w * d : b - d * (1.0f - w);
+    }
+  } else if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n_all; ++i) s += maxp_all[i];
+    sh[0] = s / (float)n_all;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float tp = time_p[0] * m + one_minus_m * sh[0];
+    if (clip_thresh) tp = fminf(fmaxf(tp, 0.0f), 0.95f);
+    time_p[0] = tp;
+    sh[1] = tp;
+  }
+  // --- p_model, label_hist
+  float hs = 0.f;
+  for (int c = tid; c < C; c += 256) hs += hist[c];
+  hs = wave_sum(hs);
+  if ((tid & 63) == 0) sh[2 + (tid >> 6)] = hs;
+  __syncthreads();
+  const float hsum = sh[2] + sh[3] + sh[4] + sh[5];
+  float pmax = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float pm = p_model[c] * m + one_minus_m * (colsum[c] / (float)n_all);
+    p_model[c] = pm;
+    label_hist[c] = label_hist[c] * m + one_minus_m * (hist[c] / hsum);
+    pmax = fmaxf(pmax, pm);
+  }
+  pmax = wave_max(pmax);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[2 + (tid >> 6)] = pmax;
+  __syncthreads();
+  pmax = fmaxf(fmaxf(sh[2], sh[3]), fmaxf(sh[4], sh[5]));
+  const float tp = sh[1];
+  __threadfence_block();
+  for (int i = tid; i < B; i += 256) {
+    const float mod = p_model[(int)max_idx[i]] / pmax;
+    mask[i] = max_probs[i] >= tp * mod ? 1.0f : 0.0f;
+  }
+}
+
+// Fairness loss + analytic gradient.  ONE workgroup.  ws: B*C floats (softmax of the strong logits).
+//   S = {i : mask_i = 1};  mean_c = mean_{i in S} p_ic;  hist_c = share of S predicted c;  a_c = 1/hist_c (0 where hist_c = 0)
+//   q = normalise(mean * a);  w = normalise(p_model / label_hist);  loss = sum_c w_c log(q_c + 1e-12)
+//   dlogits_ij (+)= grad_scale * p_ij * (g_j - sum_k p_ik g_k) / |S|,   g_c = a_c * (w_c/(q_c+eps) - sum_k w_k q_k/(q_k+eps)) / Z
+__global__ __launch_bounds__(256) void freematch_entropy_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
+                                                               const float* __restrict__ p_model, const float* __restrict__ label_hist,
+                                                               float grad_scale, float* __restrict__ loss_out, float* __restrict__ dlogits,
+                                                               float* __restrict__ ws, int B, int C, int accumulate) {
+  __shared__ float g[2048];
+  __shared__ int pred[1024];
+  __shared__ float sh[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  auto bsum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+  };
+  for (int row = wave; row < B; row += 4) {
+    const float* r = logits + (size_t)row * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, r[c]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int c = lane; c < C; c += 64) sm += expf(r[c] - mx);
+    const float inv = 1.0f / wave_sum(sm);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float p = expf(r[c] - mx) * inv;
+      ws[(size_t)row * C + c] = p;
+      if (p > bv) { bv = p; bi = c; }
+    }
+    wave_argmax(bv, bi);
+    if (lane == 0) pred[row] = bi;
+  }
+  float ns = 0.f;
+  for (int i = tid; i < B; i += 256) ns += mask[i] != 0.f ? 1.0f : 0.0f;
+  const float nsel = bsum(ns);
+  if (nsel == 0.f) {                          // reference: `if mask.sum() > 0 ... else ent_loss = 0.0` (srfreematch.py:216-219)
+    if (tid == 0) loss_out[0] = 0.f;
+    if (!accumulate)
+      for (int e = tid; e < B * C; e += 256) dlogits[e] = 0.f;
+    return;
+  }
+  float zu = 0.f, zw = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    float mean = 0.f, h = 0.f;
+    for (int i = 0; i < B; ++i)
+      if (mask[i] != 0.f) { mean += ws[(size_t)i * C + c]; h += (pred[i] == c) ? 1.0f : 0.0f; }
+    mean = mean / nsel; h = h / nsel;
+    const float a = h > 0.f ? 1.0f / h : 0.0f;
+    const float lh = label_hist[c];
+    g[c] = mean * a;                                   // u_c (overwritten by g_c below)
+    zu += mean * a;
+    zw += p_model[c] * (lh > 0.f ? 1.0f / lh : 0.0f);
+  }
+  const float Z = bsum(zu), W = bsum(zw);
+  float ls = 0.f, cr = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float lh = label_hist[c];
+    const float w = p_model[c] * (lh > 0.f ? 1.0f / lh : 0.0f) / W;
+    const float q = g[c] / Z;
+    ls += w * logf(q + 1e-12f);
+    cr += w * q / (q + 1e-12f);
+  }
+  const float loss = bsum(ls), cross = bsum(cr);
+  for (int c = tid; c < C; c += 256) {
+    const float lh = label_hist[c];
+    const float w = p_model[c] * (lh > 0.f ? 1.0f / lh : 0.0f) / W;
+    const float u = g[c], q = u / Z;
+    // a_c = u_c / mean_c is not kept: recompute it from the histogram share
+    float h = 0.f;
+    for (int i = 0; i < B; ++i) h += (mask[i] != 0.f && pred[i] == c) ? 1.0f : 0.0f;
+    const float a = h > 0.f ? nsel / h : 0.0f;
+    g[c] = a * (w / (q + 1e-12f) - cross) / Z;
+  }
+  __syncthreads();
+  if (tid == 0) loss_out[0] = loss;
+  for (int row = wave; row < B; row += 4) {
+    float* d = dlogits + (size_t)row * C;
+    if (mask[row] == 0.f) {
+      if (!accumulate) for (int c = lane; c < C; c += 64) d[c] = 0.f;
+      continue;
+    }
+    const float* p = ws + (size_t)row * C;
+    float dot = 0.f;
+    for (int c = lane; c < C; c += 64) dot += p[c] * g[c];
+    dot = wave_sum(dot);
+    const float k = grad_scale / nsel;
+    for (int c = lane; c < C; c += 64) {
+      const float v = k * p[c] * (g[c] - dot);
+      d[c] = accumulate ? d[c] + v : v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B,
@@ -237,6 +420,33 @@ extern "C" int srhip_masked_ce(const float* logits, const long long* targets, co
   if (B <= 0 || C <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(masked_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, mask, mask2, grad_scale,
                      loss_out, dlogits, B, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_freematch_stats(const float* probs, const long long* max_idx, float* colsum, float* hist, int B, int C, void* stream) {
+  if (B <= 0 || C <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(freematch_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, probs, max_idx, colsum, hist, B, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_freematch_update(const float* maxp_all, int n_all, const float* colsum, const float* hist, const float* max_probs,
+                                      const long long* max_idx, float* time_p, float* p_model, float* label_hist, float* mask, int B,
+                                      int C, float momentum, float one_minus_momentum, int use_quantile, int clip_thresh, void* stream) {
+  if (B <= 0 || C <= 0 || n_all <= 0 || n_all > 1024) return SR_EINVAL;
+  hipLaunchKernelGGL(freematch_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, maxp_all, n_all, colsum, hist, max_probs, max_idx,
+                     time_p, p_model, label_hist, mask, B, C, momentum, one_minus_momentum, use_quantile, clip_thresh);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_freematch_entropy(const float* logits, const float* mask, const float* p_model, const float* label_hist,
+                                       float grad_scale, float* loss_out, float* dlogits, float* ws, int B, int C, int accumulate,
+                                       void* stream) {
+  if (B <= 0 || B > 1024 || C <= 0 || C > 2048) return SR_EINVAL;
+  hipLaunchKernelGGL(freematch_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, mask, p_model, label_hist, grad_scale,
+                     loss_out, dlogits, ws, B, C, accumulate);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

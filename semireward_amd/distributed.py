@@ -35,6 +35,17 @@ class DataParallel:
             for m in modules:
                 dist.broadcast(m.flat, src=0)
 
+    def gather_stats(self, max_probs, colsum, hist):
+        """FreeMatch / SoftMatch statistics of the GLOBAL batch: the reference all-gathers [Bu, C] probabilities
+        (algorithms/utils/ops.py:35-45); the sufficient statistics are enough -- column sums and histogram are all-reduced
+        in place, only the Bu max-probs are gathered (needed for the quantile).  Returns (maxp_all, n_all)."""
+        dist.all_reduce(colsum)
+        dist.all_reduce(hist)
+        out = [torch.empty_like(max_probs) for _ in range(self.world_size)]
+        dist.all_gather(out, max_probs.contiguous())
+        allp = torch.cat(out)
+        return allp, allp.numel()
+
     def reward_means(self, reward, groups):
         """Per-group reward mean.  Local (reference, srflexmatch.py:100) unless the global-threshold extension is on,
         in which case (sum, n) is all-reduced: one packed message of groups+1 floats."""

@@ -216,6 +216,21 @@ def fixed_mask(max_probs, p_cutoff, mask, B):
     _call("srhip_fixed_mask", _p(max_probs), p_cutoff, _p(mask), B, _s())
 
 
+def freematch_stats(probs, max_idx, colsum, hist, B, C):
+    _call("srhip_freematch_stats", _p(probs), _p(max_idx), _p(colsum), _p(hist), B, C, _s())
+
+
+def freematch_update(maxp_all, n_all, colsum, hist, max_probs, max_idx, time_p, p_model, label_hist, mask, B, C, m, use_quantile, clip_thresh):
+    import numpy as np
+    _call("srhip_freematch_update", _p(maxp_all), n_all, _p(colsum), _p(hist), _p(max_probs), _p(max_idx), _p(time_p), _p(p_model),
+          _p(label_hist), _p(mask), B, C, float(np.float32(m)), float(np.float32(1 - m)), int(use_quantile), int(clip_thresh), _s())
+
+
+def freematch_entropy(logits, mask, p_model, label_hist, grad_scale, loss_out, dlogits, ws, B, C, accumulate=False):
+    _call("srhip_freematch_entropy", _p(logits), _p(mask), _p(p_model), _p(label_hist), grad_scale, _p(loss_out), _p(dlogits), _p(ws),
+          B, C, int(accumulate), _s())
+
+
 def reward_mask2(reward, mask2, mean_out, groups, B, mean_in=None):
     _call("srhip_reward_mask2", _p(reward), _p(mask2), _p(mean_out), _p(mean_in), groups, B, _s())
 

@@ -88,8 +88,12 @@ def test_pass_plan_and_registry():
     names = [a.name for a in SRFlexMatch.get_argument()]
     assert names == ["--hard_label", "--T", "--p_cutoff", "--thresh_warmup", "--start_timing", "--feature_dim", "--sr_lr",
                      "--N_k", "--sr_ema", "--sr_ema_m"]                      # srflexmatch.py:233-246
+    from semireward_amd.algorithms.srfreematch import SRFreeMatch
     from semireward_amd.algorithms.srpseudolabel import SRPseudoLabel
-    assert ALGORITHMS["srpseudolabel"] is SRPseudoLabel
+    assert ALGORITHMS["srpseudolabel"] is SRPseudoLabel and ALGORITHMS["srfreematch"] is SRFreeMatch
+    assert list(signature(SRFreeMatch.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w", "x_ulb_s"]
+    pf = _Plan.cat_passes(8, 8, 8, "cpu", extra_pass0_strong=True)
+    assert pf.grad_cols.tolist() == list(range(8)) + list(range(16, 24)) + [8 * 24 + j for j in range(16, 24)]
     assert list(signature(SRPseudoLabel.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w"]
     for nl, nu, K in [(8, 8, 8), (8, 8, 0), (4, 4, 20), (3, 5, 2)]:
         p = _Plan.cat_passes(nl, nu, K, "cpu")

@@ -55,7 +55,15 @@ def _worker(rank, world, port, q):
     r_all = torch.from_numpy(rng.random((world, 3, 8)).astype(np.float32))      # [rank, groups, B]
     means = dp.reward_means(r_all[rank].reshape(-1), 3)
     ok_mean = torch.allclose(means, r_all.permute(1, 0, 2).reshape(3, -1).mean(1), rtol=1e-6)
-    q.put((rank, bool(ok_grad), bool(ok_mean)))
+    # (4) FreeMatch statistics: all-reduced column sums / histogram + gathered max-probs == statistics of the concatenated batch
+    pr = torch.softmax(torch.from_numpy(rng.standard_normal((world, 8, 10)).astype(np.float32)), -1)      # [rank, Bu, C]
+    mine_p = pr[rank]
+    colsum, hist = mine_p.sum(0).clone(), torch.bincount(mine_p.argmax(-1), minlength=10).float()
+    allp, n_all = dp.gather_stats(mine_p.max(-1).values.contiguous(), colsum, hist)
+    full = pr.reshape(-1, 10)
+    ok_fm = (n_all == 16 and torch.allclose(colsum, full.sum(0), rtol=1e-6) and torch.equal(hist, torch.bincount(full.argmax(-1), minlength=10).float())
+             and torch.equal(allp, full.max(-1).values))
+    q.put((rank, bool(ok_grad), bool(ok_mean and ok_fm)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -395,3 +395,38 @@ def test_adamw_flat_matches_oracle():
     want = torch.cat([Pt[n].reshape(-1) for n in names])
     np.testing.assert_allclose(flat.cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-8)
     assert torch.equal(pb, flat.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("tag", ["c10_q", "c100_mean", "c100_q"])
+def test_freematch_hook_and_entropy(golden, tag):
+    """FreeMatch thresholds + fairness loss on device against the reference's own sequences (tests/golden/freematch_hook.npz)."""
+    g = golden("freematch_hook")
+    C, Bu, steps, uq, clip, seed = [int(v) for v in g[f"{tag}/meta"]]
+    m = float(g[f"{tag}/momentum"])
+    time_p = torch.full((1,), 1.0 / C, device=DEV)
+    p_model, label_hist = torch.full((C,), 1.0 / C, device=DEV), torch.full((C,), 1.0 / C, device=DEV)
+    colsum, hist = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    mp, mi, mask = torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV), torch.empty(Bu, device=DEV)
+    loss, ws = torch.empty(1, device=DEV), torch.empty(Bu * C, device=DEV)
+    for t in range(steps):
+        probs = torch.from_numpy(g[f"{tag}/probs"][t]).to(DEV)
+        ops.row_max(probs, True, None, mp, mi, Bu, C)
+        ops.freematch_stats(probs, mi, colsum, hist, Bu, C)
+        ops.freematch_update(mp, Bu, colsum, hist, mp, mi, time_p, p_model, label_hist, mask, Bu, C, m, bool(uq), bool(clip))
+        assert np.array_equal(mask.cpu().numpy(), g[f"{tag}/mask"][t]), (tag, t)          # identical masks on identical probabilities
+        assert float(time_p) == pytest.approx(float(g[f"{tag}/time_p"][t]), rel=3e-7)
+        np.testing.assert_allclose(p_model.cpu().numpy(), g[f"{tag}/p_model"][t], rtol=1e-6)
+        np.testing.assert_allclose(label_hist.cpu().numpy(), g[f"{tag}/label_hist"][t], rtol=1e-6)
+        ls = torch.from_numpy(g[f"{tag}/logits_s"][t]).to(DEV)
+        dl = torch.full((Bu, C), 7.0, device=DEV)
+        ops.freematch_entropy(ls, mask, p_model, label_hist, 1.0, loss, dl, ws, Bu, C)
+        assert float(loss) == pytest.approx(float(g[f"{tag}/ent"][t]), rel=2e-5, abs=1e-6)
+        np.testing.assert_allclose(dl.cpu().numpy(), g[f"{tag}/ent_grad"][t], rtol=2e-4, atol=1e-8)
+        d2 = torch.ones(Bu, C, device=DEV)
+        ops.freematch_entropy(ls, mask, p_model, label_hist, 0.5, loss, d2, ws, Bu, C, accumulate=True)
+        np.testing.assert_allclose(d2.cpu().numpy(), 1.0 + 0.5 * g[f"{tag}/ent_grad"][t], rtol=2e-4, atol=1e-7)
+    # empty mask: zero loss, zero / untouched gradient (srfreematch.py:216-219)
+    z = torch.zeros(Bu, device=DEV)
+    dl = torch.full((Bu, C), 7.0, device=DEV)
+    ops.freematch_entropy(ls, z, p_model, label_hist, 1.0, loss, dl, ws, Bu, C)
+    assert float(loss) == 0.0 and float(dl.abs().max()) == 0.0

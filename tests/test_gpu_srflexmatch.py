@@ -32,13 +32,18 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX)])
+from oracle.gen_golden import TRACE_FREE   # noqa: E402
+
+
+@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX), ("srfreematch_trace", TRACE_FREE)])
 def test_sr_train_step_trace(golden, name, tr):
     g = golden(name)
-    fix = tr["algorithm"] == "srfixmatch"
+    fix = tr["algorithm"] in ("srfixmatch", "srfreematch")
+    free = tr["algorithm"] == "srfreematch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
-    alg = get_algorithm(make_args(algorithm=tr["algorithm"], p_cutoff=tr["p_cutoff"]), vit.vit_tiny_test)
+    extra = dict(ema_p=tr["ema_p"], use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"], ent_loss_ratio=tr["ent_loss_ratio"]) if free else {}
+    alg = get_algorithm(make_args(algorithm=tr["algorithm"], p_cutoff=tr["p_cutoff"], **extra), vit.vit_tiny_test)
     T = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
     alg.model.load_state_dict(T(synth.synth_params(V.param_shapes(cfg), seed)))
     alg.rewarder.load_state_dict(T(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), seed + 1)))
@@ -70,6 +75,10 @@ def test_sr_train_step_trace(golden, name, tr):
         for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
             assert rel(out["feat"][k_].cpu(), g[f"{p}/feat/{k_}"]) < ftol, (p, k_)
         assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+        if free:
+            h = alg.hooks_dict["MaskingHook"]
+            assert float(h.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=2e-2)
+            assert rel(h.p_model.cpu(), g[f"{p}/p_model"]) < 2e-2 and rel(h.label_hist.cpu(), g[f"{p}/label_hist"]) < 0.2
         mr = float(g[f"{p}/max_reward"])
         assert (np.isinf(mr) and np.isinf(float(alg.max_reward))) or float(alg.max_reward) == pytest.approx(mr, rel=1e-2), p
         if not fix and masks.shape == want.shape and (masks == want).all():

@@ -241,3 +241,53 @@ def test_srpseudolabel_trace(golden):
             check_samp(orc.R[k_].numpy(), g.samp(f"{p}/rewarder/{k_}"), 1e-4, 3e-5, f"{p} rewarder {k_}")
     allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
     assert 0.05 < allm.mean() < 0.95
+
+
+@pytest.mark.parametrize("tag", ["c10_q", "c100_mean", "c100_q"])
+def test_freematch_hook_and_entropy(golden, tag):
+    """FreeMatchThresholdingHook state (freematch/utils.py:24-66) bit for bit + entropy_loss (srfreematch.py:16-44) value / gradient."""
+    g = golden("freematch_hook")
+    C, Bu, steps, uq, clip, seed = [int(v) for v in g[f"{tag}/meta"]]
+    st = H.FreeMatchState(C, float(g[f"{tag}/momentum"]), bool(uq), bool(clip))
+    for t in range(steps):
+        m = st.masking(T(g[f"{tag}/probs"][t]))
+        assert np.array_equal(m.numpy(), g[f"{tag}/mask"][t]), (tag, t)
+        assert np.float32(st.time_p).view(np.uint32) == g[f"{tag}/time_p"][t].view(np.uint32), (tag, t)
+        assert np.array_equal(st.p_model.numpy().view(np.uint32), g[f"{tag}/p_model"][t].view(np.uint32))
+        assert np.array_equal(st.label_hist.numpy().view(np.uint32), g[f"{tag}/label_hist"][t].view(np.uint32))
+        lg = T(g[f"{tag}/logits_s"][t]).requires_grad_(True)
+        if float(m.sum()) > 0:
+            e = H.freematch_entropy_loss(m, lg, st.p_model, st.label_hist)
+            e.backward()
+            assert float(e.detach()) == pytest.approx(float(g[f"{tag}/ent"][t]), rel=1e-6, abs=1e-7)
+            np.testing.assert_allclose(lg.grad.numpy(), g[f"{tag}/ent_grad"][t], rtol=1e-5, atol=1e-9)
+
+
+def test_srfreematch_trace(golden):
+    from oracle.gen_golden import TRACE_FREE as tr
+    from oracle.srfreematch_ref import SRFreeMatchOracle
+    g = golden("srfreematch_trace")
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+    Fd = cfg.embed_dim
+    orc = SRFreeMatchOracle(
+        cfg, TP(synth.synth_params(V.param_shapes(cfg), seed)), TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
+        TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)), num_train_iter=tr["num_train_iter"],
+        start_timing=tr["start_timing"], N_k=tr["N_k"], ulb_dest_len=tr["ulb_dest_len"], num_warmup_iter=tr["num_warmup_iter"],
+        ema_p=tr["ema_p"], use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"], lambda_e=tr["ent_loss_ratio"])
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        orc.it = it
+        K = int(g[f"{p}/K"])
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        dps = [T(synth.synth_droppath(seed + 1000 * (n + 1) + k, V.drop_path_probs(cfg), Bl + 2 * Bu)) for k in range(K + 1)]
+        t = orc.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]), dps)
+        assert t["K"] == K
+        assert np.array_equal(np.stack([q["mask"].numpy() for q in t["passes"]]), g[f"{p}/masks"]), p
+        for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+            assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=2e-5, abs=2e-6), (p, k_)
+        assert float(orc.fm.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=1e-6)
+        np.testing.assert_allclose(orc.fm.p_model.numpy(), g[f"{p}/p_model"], rtol=1e-6)
+        np.testing.assert_allclose(orc.fm.label_hist.numpy(), g[f"{p}/label_hist"], rtol=1e-6)
+        for nme, _ in V.param_shapes(cfg):
+            check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 2e-3, 2e-6, f"{p} grad {nme}")
