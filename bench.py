@@ -83,11 +83,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1 and a.gpus == 1, "launch N>1 with torch.distributed.run --nproc-per-node N"
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)            # (debug: several ranks on one device with SR_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("SR_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from semireward_amd import ops
     from semireward_amd.algorithms import get_algorithm
@@ -128,7 +134,7 @@ def main():
     # roofline pass: the SAME steps again, in this process, with HIP events around every GEMM launch on the launch
     # stream.  Kept out of the timed region above because 2 x 145 event records per step cost ~0.9 ms of host time.
     prof = None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:                    # every rank runs the pass (the steps contain collectives); rank 0 reports
         prof = ops.enable_gemm_profile()
         for _ in range(a.steps):
             step()
