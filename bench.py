@@ -29,6 +29,7 @@ NS = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, epoch
           T=0.5, p_cutoff=0.95, hard_label=True, thresh_warmup=True, ulb_dest_len=50000, N_k=10, start_timing=20000,
           feature_dim=384, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (the 5 PF headline is 2:1 sparse)
+HBM_PEAK_TBS = 8.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 measured with a float4 copy)
 START_IT = 30000                          # it >= 25601 -> sr_decay() == 8 (88 % of the reference run)
 
 
@@ -161,20 +162,28 @@ def main():
                           "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
         if prof is not None:
             pk = prof.per_kernel()
-            name, (fl, ms, n) = max(pk.items(), key=lambda kv: kv[1][1])          # dominant kernel = most time in the timed region
+            name, (fl, ms, n, nbytes) = max(pk.items(), key=lambda kv: kv[1][1])   # dominant kernel = most time in the pass
             tfl, tms, tn = prof.totals()
-            ach = fl / (ms * 1e-3) / 1e12
+            # which roof bounds this kernel?  arithmetic intensity of its launches vs the ridge of the machine
+            ridge = MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12 / (HBM_PEAK_TBS * 1e12)
+            intensity = fl / nbytes
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")          # PMC pass of this same command (tools/pmc.sh)
             if os.path.exists(tf) and a.bu == 8 and a.regime == "sr" and world == 1:
                 traffic = (json.load(open(tf)).get(name) or {}).get("hbm_bytes_per_launch")
-            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "launches": n,
-                               "avg_launch_us": 1e3 * ms / n, "flop_per_launch": fl / n, "ms_per_step_in_kernel": ms / prof_steps,
-                               "measured_over": "%d instrumented steps run right after the timed region (same process, same inputs)" % prof_steps,
-                               "all_gemm_kernels": {"achieved": tfl / (tms * 1e-3) / 1e12, "launches": tn, "ms_per_step": tms / prof_steps},
-                               "note": "K=384 products of a D=384 ViT are HBM/fill bound (DESIGN.md section 6): hbm floor of this "
-                                       "kernel's launches is bytes/8 TB/s, see profiles/"}
+            if intensity < ridge:
+                ach = nbytes / (ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": ach / (HBM_PEAK_TBS * 1e3)}
+            else:
+                ach = fl / (ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS}
+            roof.update({"kernel": name, "traffic": traffic, "launches": n, "avg_launch_us": 1e3 * ms / n,
+                         "algorithmic_bytes_per_launch": nbytes / n, "flop_per_launch": fl / n, "flop_per_byte": intensity,
+                         "ridge_flop_per_byte": ridge, "tflops": fl / (ms * 1e-3) / 1e12, "ms_per_step_in_kernel": ms / prof_steps,
+                         "measured_over": "%d instrumented steps run right after the timed region (same process, same inputs)" % prof_steps,
+                         "all_gemm_kernels": {"tflops": tfl / (tms * 1e-3) / 1e12, "launches": tn, "ms_per_step": tms / prof_steps}})
+            out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bl, a.bu)
         print(json.dumps(out), flush=True)

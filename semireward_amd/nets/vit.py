@@ -334,8 +334,8 @@ class VisionTransformer:
             ops.gemm_nt(ops.EPI_BF16, dqkv, self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
             ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
                               G(b + "norm1.bias"), M, D)
-        desc, npb, ntiles, flops = T["desc"]
-        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops)
+        desc, npb, ntiles, flops, nbytes = T["desc"]
+        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
                             G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
 

@@ -54,13 +54,29 @@ class _GemmProfile:
             return "gemm_big_kernel<%d, 8>" % epi
         return "gemm_nt_kernel<%d>" % epi
 
+    @staticmethod
+    def gemm_bytes(epi, M, N, K, aux_in, aux_out, beta):
+        """ALGORITHMIC HBM bytes of one product: bf16 operands once + the epilogue's reads/writes of C (and aux)."""
+        b = 2.0 * (M * K + N * K)
+        if epi == EPI_BF16:
+            b += 2.0 * M * N
+        elif epi == EPI_GELU_BF16:
+            b += 2.0 * M * N * (2 if aux_out is not None else 1)
+        elif epi == EPI_RESID_F32:
+            b += 8.0 * M * N                                   # residual read + write, fp32
+        elif epi == EPI_DGELU_BF16:
+            b += 4.0 * M * N                                   # pre-activation read + bf16 write
+        else:
+            b += 4.0 * M * N * (2 if beta != 0.0 else 1)
+        return b
+
     def per_kernel(self):
         torch.cuda.synchronize()
         out = {}
-        for a, b, f, name in self.recs:
-            d = out.setdefault(name, [0.0, 0.0, 0])
-            d[0] += f; d[1] += a.elapsed_time(b); d[2] += 1
-        return out           # name -> [flops, ms, launches]
+        for a, b, f, name, nbytes in self.recs:
+            d = out.setdefault(name, [0.0, 0.0, 0, 0.0])
+            d[0] += f; d[1] += a.elapsed_time(b); d[2] += 1; d[3] += nbytes
+        return out           # name -> [flops, ms, launches, algorithmic bytes]
 
     def totals(self):
         pk = self.per_kernel()
@@ -91,7 +107,8 @@ def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, r
         _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
               rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
         e1.record()
-        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K)))
+        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K),
+                              _GemmProfile.gemm_bytes(epi, M, N, K, aux_in, aux_out, beta)))
         return
     _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
           rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
@@ -112,16 +129,17 @@ def make_group_desc(problems, device):
         t += ((M + 127) // 128) * ((N + 127) // 128)
     assert arr.itemsize == 64
     flops = float(sum(2.0 * M * N * K for _, _, _, M, N, K in problems))
-    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops
+    nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for _, _, _, M, N, K in problems))
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
 
 
-def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0):
+def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
         e1.record()
-        _PROFILE.recs.append((e0, e1, flops, "gemm_grouped_f32_kernel"))
+        _PROFILE.recs.append((e0, e1, flops, "gemm_grouped_f32_kernel", nbytes))
         return
     _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
