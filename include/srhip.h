@@ -65,6 +65,15 @@ int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dgamma, float* dbeta, int M, int D, void* stream);
 
+/* Fused inference MLP half of a transformer block, in place on the fp32 residual stream x [M, D]:
+ *   x += row_scale[m / rows_per_sample] * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) + b2 )
+ * = Block.forward's second residual (vit.py:165) with Mlp.forward (vit.py:69-75), norm2 (vit.py:150) and DropPath
+ * (row_scale, NULL = 1) for rows that need no backward.  W1 bf16 [Hd, D], W2 bf16 [D, Hd], biases / LN affine fp32.
+ * D == 384 (ViT-S width), Hd % 128 == 0, Hd <= 4096.  Same rounding points as layernorm_fwd + gemm_nt(GELU) + gemm_nt(RESID). */
+int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1,
+                    const void* W2, const float* b2, const float* row_scale, int rows_per_sample, int M, int D, int Hd,
+                    void* stream);
+
 /* PatchEmbed conv (kernel = stride = ps) + cls token + pos_embed (vit.py:39-44, :277-280) (K1).
  * img fp32 [*, C, HW, HW]; img_index int32 [B] maps batch row -> image (NULL = identity; lets the K+1 passes of
  * one SemiReward step share one copy of the images); x fp32 [B, N, D], N = (HW/ps)^2 + 1.  C*ps*ps <= 64. */

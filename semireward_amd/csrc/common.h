@@ -57,7 +57,17 @@ __device__ __forceinline__ float erf_as(float x) {
   const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// GELU(x) = x/2 + |x/2| * erf(|x|/sqrt2) with the same 7.1.26 polynomial, constants folded so that the exponential is a bare
+// v_exp_f32 of -(w*w) (w = |x| sqrt(log2 e / 2)): 11 full-rate VALU ops + v_rcp + v_exp.  (The fused MLP kernel evaluates
+// 196608 of these per 128-row tile; at ~28 ops each the VALU time exceeded the MFMA time of the two products.)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float w = fabsf(x) * 0.8493218f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.27273747f, w, 1.0f));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = fmaf(-poly, __builtin_amdgcn_exp2f(-(w * w)), 1.0f);   // erf(|x| / sqrt 2)
+  const float h = 0.5f * x;
+  return fmaf(fabsf(h), r, h);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f);

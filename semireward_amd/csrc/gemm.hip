@@ -136,6 +136,23 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
 
   const int nk = kt1 - kt0;
   if (nk <= 0) return;
+  // RESID: the residual tile (fp32, 64 KiB per workgroup) is requested BEFORE the K loop so that its HBM latency hides under
+  // the MFMA work; the epilogue then only adds and stores.  (The loads are older than every LDS-DMA op, so the counted
+  // vmcnt waits below also cover them.)
+  f32x4_t res[4][4];
+  if (EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 1)) {
+    const float* src = g.aux_in ? reinterpret_cast<const float*>(g.aux_in) : reinterpret_cast<const float*>(g.C);
+    const int lds_ = g.aux_in ? g.ldaux : g.ldc;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = min(m0 + wm * 64 + mt * 16 + l15, g.M - 1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = min(n0 + wn * 64 + nt * 16 + lg * 4, g.N - 4);
+        res[nt][mt] = *reinterpret_cast<const f32x4_t*>(src + (size_t)m * lds_ + n);
+      }
+    }
+  }
   // fragment read offsets (elements) inside a tile: row r, logical slot lg
   int fo_a[4], fo_b[4];
 #pragma unroll
@@ -182,7 +199,17 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
       const int n = n0 + wn * 64 + nt * 16 + lg * 4;
       if (n >= g.N) continue;
       float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-      epi_store<EPI>(g, m, n, v, rs, atomic_f32);
+      if (EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 1)) {
+        f32x4_t x = res[nt][mt];
+        if (g.bias) {
+          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n);
+          v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+        }
+        x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = x;
+      } else {
+        epi_store<EPI>(g, m, n, v, rs, atomic_f32);
+      }
     }
   }
 }
@@ -195,6 +222,93 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // split-K (EPI_F32 only): blockIdx.y owns k-tiles [kt0, kt1); partial sums are combined with fp32 atomics
   const int kt0 = (int)blockIdx.y * g.ksplit_tiles, kt1 = min(g.K / BK, kt0 + g.ksplit_tiles);
   gemm_tile_body<EPI>(g, smem, (wg / ntn) * BM, (wg % ntn) * BN, kt0, kt1, gridDim.y > 1);
+}
+
+// Small-problem kernel: 64x64 output tile, 8-stage LDS-DMA ring (7 K-tiles = 56 KiB in flight per workgroup).
+// The backward of the 16 gradient-carrying images is made of M = 4112-row products: on 128x128 tiles they give 99-400
+// workgroups whose K loop is a chain of ~2 us global->LDS round trips (3 in flight): 15-22 us for 3-7 GFLOP.  Four times as
+// many workgroups with more than twice the bytes in flight each turn that into one latency + a short MFMA tail.
+constexpr int SBM = 64, SNS = 8, SPD = SNS - 1, STILE = SBM * BK, SSTAGE = 2 * STILE;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SNS * SSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int ntn = (g.N + SBM - 1) / SBM;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (wg / ntn) * SBM, n0 = (wg % ntn) * SBM;
+  const int nk = g.K / BK;
+
+  // one A and one B LDS-DMA instruction (16 rows x 64 B) per wave and stage
+  const int r = 16 * wave + (lane >> 2);
+  const int sl = ((lane & 3) ^ swz(r)) * 8;
+  const bf16_t* ga = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + sl;
+  const bf16_t* gb = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + sl;
+  bf16_t* dst = smem + 16 * wave * BK;
+#define SISSUE(kt_, st_)                                                                                               \
+  {                                                                                                                    \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(ga + (size_t)(kt_) * BK), (lds_void*)(dst + (st_) * SSTAGE), 16, 0, 0);          \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gb + (size_t)(kt_) * BK), (lds_void*)(dst + (st_) * SSTAGE + STILE), 16, 0, 0);  \
+  }
+  int fo_a[2], fo_b[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rn = wn * 32 + t * 16 + l15, rm = wm * 32 + t * 16 + l15;
+    fo_a[t] = STILE + rn * BK + ((lg ^ swz(rn)) << 3);
+    fo_b[t] = rm * BK + ((lg ^ swz(rm)) << 3);
+  }
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < SPD; ++p)
+    if (p < nk) SISSUE(p, p)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = nk - 1 - kt;          // tile kt has landed once <= 2*min(rem, SPD-1) younger DMA ops are outstanding
+    switch (min(rem, SPD - 1)) {
+      case 6: WAIT_VM(12); break;
+      case 5: WAIT_VM(10); break;
+      case 4: WAIT_VM(8); break;
+      case 3: WAIT_VM(6); break;
+      case 2: WAIT_VM(4); break;
+      case 1: WAIT_VM(2); break;
+      default: WAIT_VM(0); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + SPD < nk) SISSUE(kt + SPD, (kt + SPD) % SNS)
+    const bf16_t* st = smem + (kt % SNS) * SSTAGE;
+    s16x8_t fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      fa[t] = *reinterpret_cast<const s16x8_t*>(st + fo_a[t]);
+      fb[t] = *reinterpret_cast<const s16x8_t*>(st + fo_b[t]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(bf16x8_t, fa[nt]), __builtin_bit_cast(bf16x8_t, fb[mt]), acc[nt][mt], 0, 0, 0);
+  }
+#undef SISSUE
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + wm * 32 + mt * 16 + l15;
+    if (m >= g.M) continue;
+    float rs = 1.0f;
+    if (EPI == SRHIP_EPI_RESID_F32 && g.row_scale) rs = g.row_scale[m / g.rows_per_sample];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + wn * 32 + nt * 16 + lg * 4;
+      if (n >= g.N) continue;
+      float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+      epi_store<EPI>(g, m, n, v, rs, false);
+    }
+  }
 }
 
 // Grouped fp32-accumulating launch: ONE grid over the 128x128 tiles of up to 64 independent products.  Used for the
@@ -399,6 +513,20 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
       case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, variant, s); break;
       case SRHIP_EPI_RESID_F32: launch_big<SRHIP_EPI_RESID_F32>(g, variant, s); break;
       case SRHIP_EPI_DGELU_BF16: launch_big<SRHIP_EPI_DGELU_BF16>(g, variant, s); break;
+      default: return SR_EINVAL;
+    }
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  }
+  // under-filled launches (less than one round of 2 workgroups per CU on 128x128 tiles) -> 64x64 tiles, deep ring
+  const bool force_small = mode && mode[0] == 's';
+  if ((grid < 512 || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
+    const dim3 gs(cdiv(M, SBM) * cdiv(N, SBM));
+    switch (epilogue) {
+      case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_GELU_BF16>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_RESID_F32: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_RESID_F32>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_DGELU_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_DGELU_BF16>, gs, dim3(256), 0, s, g); break;
       default: return SR_EINVAL;
     }
     SR_CHECK_LAUNCH();

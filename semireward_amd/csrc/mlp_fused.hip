@@ -1,0 +1,343 @@
+// Fused inference MLP half of a transformer block (gfx950):
+//     x <- x + row_scale * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) + b2 )            reference: semilearn/nets/vit/vit.py:165
+// (Block.forward, second residual: x + drop_path2(ls2(mlp(norm2(x))))), Mlp.forward vit.py:69-75.
+//
+// Why: at the reference batch 200 of the 216 images of a step are forwarded WITHOUT a backward (the K weak/strong passes that
+// only feed the rewarder / the masks).  As three launches (LN, fc1+GELU, fc2+residual) the [M, 4D] hidden activation makes a
+// round trip through HBM (2 x 158 MB per layer at M = 51400) and LN re-reads x; fused, HBM sees x in, x out.
+//
+// Structure (one workgroup = 128 rows, 8 waves x 16 rows, ONE workgroup per CU, 254 VGPRs):
+//   * every wave owns 16 rows end to end: it normalises them in registers (bf16 MFMA B-fragments, 48 VGPRs), so neither x
+//     nor the hidden activation ever sits in LDS -- all 128 KiB of the ring hold WEIGHT tiles.
+//   * weights stream through a 16-slot LDS-DMA ring of 8 KiB tiles ([128 rows x 32 k] bf16, buffer_load ... lds); per
+//     64-wide hidden chunk c, 12 stages of 8 MFMAs per wave:
+//       stages 0-5  (GEMM1): W1 rows of hidden pair-group u = j/3 (32 hidden) x k-steps 4(j%3) .. +3
+//       stages 6-11 (GEMM2): W2 rows 128 th .. (th = j%3) x hidden 64 c + 32 u .., u = (j-6)/3
+//     so the accumulators of group u = 0 are complete after stage 2 and its GELU (VALU) has stages 3-5 to hide under; u = 1
+//     is finished by stage 5 and needed by stage 9.
+//   * GEMM1: D1 = mfma(W1 frag, xn frag): lane (m = lane&15, g = lane>>4) receives rows 4g..4g+3 of the A tile.  A-tile row i
+//     of tile P is fed with hidden unit 8 (i>>2) + (i&3), tile Q with 8 (i>>2) + 4 + (i&3) (just the LDS row each lane
+//     reads), so after GELU + bias + bf16 pack the lane holds hidden 8g .. 8g+7 of the group: exactly the B fragment of
+//     k-step u of GEMM2 -- the chained-MFMA trick, the hidden activation never leaves registers.
+//   * software pipeline inside every wave (fragments of stage s+1 requested before the MFMAs of stage s, two fragment sets),
+//     one barrier per GS stages, no branches in the loop body (out-of-range ring refills are buffer-OOB no-ops that keep the
+//     vmcnt arithmetic uniform).
+//   * epilogue: re-read x (fp32), add, store.
+// Rounding points are the ones of the unfused path (xn bf16, GELU output bf16, fp32 accumulation), so the two paths agree to
+// fp32 summation order.
+#include <stdlib.h>
+
+#include <utility>
+
+#include "../../include/srhip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int RT = 128;                   // rows (weights) per ring tile
+constexpr int TILE_EL = RT * BK;          // 4096 bf16 = 8 KiB
+constexpr int NS = 16;                    // ring slots
+constexpr int FBM = 128;                  // x rows per workgroup
+constexpr int CH = 64;                    // hidden units per chunk (acc1 = 4 tiles: 16 VGPRs; 128 would not fit 256 VGPRs)
+
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // as in gemm.hip
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+template <int N_>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) -- the stage index must be a constant expression
+// (s_waitcnt immediates, accumulator indices)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+struct MlpArgs {
+  float* x;
+  const float *gamma, *beta, *b1, *b2, *row_scale;
+  const bf16_t *W1, *W2;
+  float eps;
+  int M, Hd, rows_per_sample;
+};
+
+// DBG (tuning builds only, SRHIP_MLP_DEBUG): 1 = no GELU, 2 = no DMA / no vmcnt waits, 4 = no ds_reads, 8 = no MFMA
+template <int D_, int DBG, int GS>
+__global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
+  constexpr int KS1 = D_ / BK;            // 12 k-steps of GEMM1
+  constexpr int KQ = 4;                   // k-steps per GEMM1 stage
+  constexpr int G1S = 2 * (KS1 / KQ);     // 6 GEMM1 stages per chunk: 2 pair-groups x 3 k-ranges
+  constexpr int TH = D_ / RT;             // 3 output thirds of GEMM2
+  constexpr int NT2 = D_ / 16;            // 24 output tiles per wave
+  constexpr int G2S = (CH / BK) * TH;     // 6 GEMM2 stages per chunk: W2[128 outputs] x 32 hidden
+  constexpr int SPC = G1S + G2S;          // ring stages per hidden chunk (12)
+  constexpr int NG = NS / GS;             // groups in the ring: 1 being read, 1 cooling down, NG - 2 in flight
+  constexpr int PD = (NG - 2) * GS;       // stages in flight after a refill
+  static_assert(KS1 % KQ == 0 && D_ % RT == 0 && SPC % GS == 0 && NS % GS == 0 && NG >= 3, "layout");
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  float* sb1 = reinterpret_cast<float*>(sm + NS * TILE_EL);
+  float* sb2 = sb1 + a.Hd;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA destinations (M0) stay scalar arithmetic
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int nch = a.Hd / CH;
+  for (int i = tid; i < a.Hd; i += 512) sb1[i] = a.b1[i];
+  for (int i = tid; i < D_; i += 512) sb2[i] = a.b2[i];
+
+  // ---- producer: one LDS-DMA instruction (16 LDS rows x 64 B) per wave and stage.  Buffer addressing: (SGPR resource
+  // descriptor) + (32-bit per-lane byte offset) + (uniform byte offset in an SGPR); num_records = the weight's size, so an
+  // offset of 2^31 is out of range: the load moves nothing but still counts in vmcnt.
+  const int pr = 16 * wave + (lane >> 2);                        // LDS row of this lane's 16 B
+  const int psl = ((lane & 3) ^ swz(pr)) * 8;
+  // GEMM1 stage (u, kt): LDS row 32 s + h = W1[64 c + 32 u + h][32 (4 kt + s) ..],  s = k-step inside the stage, h < 32
+  // GEMM2 stage (u, th): LDS row r = W2[128 th + r][64 c + 32 u ..]
+  const int lo1 = ((pr & 31) * D_ + (pr >> 5) * BK + psl) * 2;
+  const int lo2 = (pr * a.Hd + psl) * 2;
+  const int pdst = 16 * wave * BK;
+  const int wbytes = a.Hd * D_ * 2;
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1), 0, wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2), 0, wbytes, 0x00020000);
+  constexpr int OOB = 0x7ffffff0;
+  auto issue = [&](int c, int j, int slot) {                 // stage j of chunk c (j is a compile-time constant at every call)
+    if (DBG & 2) return;
+    lds_void* dst = (lds_void*)(sm + slot * TILE_EL + pdst);
+    const bool valid = c < nch;
+    if (j < G1S) {
+      const int u = j / (KS1 / KQ), kt = j % (KS1 / KQ);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, valid ? lo1 : OOB, ((c * CH + 32 * u) * D_ + kt * KQ * BK) * 2, 0, 0);
+    } else {
+      const int jj = j - G1S, u = jj / TH, th = jj % TH;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, dst, 16, valid ? lo2 : OOB, (th * RT * a.Hd + c * CH + u * BK) * 2, 0, 0);
+    }
+  };
+
+  // ---- consumer fragment offsets (elements) inside a ring tile
+  // GEMM2 (and any plain tile): row l15 of 16-row tile t: + t * 16 * BK
+  const int fo2 = l15 * BK + ((lg ^ swz(l15)) << 3);
+  // GEMM1: A-tile row i = l15 <- hidden 8 (i>>2) + (i&3) (+4 for tile Q) of the 32-row sub-tile of k-step s: + s * 32 * BK
+  const int h1 = 8 * (l15 >> 2) + (l15 & 3);
+  const int fo1p = h1 * BK + ((lg ^ swz(h1)) << 3);
+  const int fo1q = (h1 + 4) * BK + ((lg ^ swz(h1 + 4)) << 3);
+
+  const int ntiles = (a.M + FBM - 1) / FBM;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m = tile * FBM + wave * 16 + l15;
+    const int mc = min(m, a.M - 1);
+    // ---- LayerNorm of the wave's 16 rows, straight into MFMA B-fragments: lane holds x[m][32 s + 8 g .. +7], s = 0..11
+    u32x4_t xn[KS1];
+    {
+      const float* xr = a.x + (size_t)mc * D_ + 8 * lg;
+      f32x4_t v[2 * KS1];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS1; ++k) {
+        v[2 * k] = *reinterpret_cast<const f32x4_t*>(xr + 32 * k);
+        v[2 * k + 1] = *reinterpret_cast<const f32x4_t*>(xr + 32 * k + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 2 * KS1; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mu = s * (1.0f / D_);
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2 * KS1; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mu; q += d * d; }
+      }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rs = rsqrtf(q * (1.0f / D_) + a.eps);
+#pragma unroll
+      for (int k = 0; k < KS1; ++k) {
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(a.gamma + 32 * k + 8 * lg);
+        const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(a.gamma + 32 * k + 8 * lg + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(a.beta + 32 * k + 8 * lg);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(a.beta + 32 * k + 8 * lg + 4);
+        const f32x4_t p = v[2 * k], r = v[2 * k + 1];
+        xn[k] = u32x4_t{pack_bf2((p[0] - mu) * rs * g0[0] + b0[0], (p[1] - mu) * rs * g0[1] + b0[1]),
+                        pack_bf2((p[2] - mu) * rs * g0[2] + b0[2], (p[3] - mu) * rs * g0[3] + b0[3]),
+                        pack_bf2((r[0] - mu) * rs * g1[0] + b1[0], (r[1] - mu) * rs * g1[1] + b1[1]),
+                        pack_bf2((r[2] - mu) * rs * g1[2] + b1[2], (r[3] - mu) * rs * g1[3] + b1[3])};
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting all 48 affine loads (spills)
+      }
+    }
+    __syncthreads();                       // previous tile's ring reads are over (and sb1/sb2 are written)
+#pragma unroll
+    for (int p = 0; p < PD; ++p) issue(p / SPC, p % SPC, p);   // groups 0 .. NG-3
+
+    __builtin_amdgcn_sched_barrier(0);     // the accumulators must not become live (zeroed early) across the LayerNorm above
+    f32x4_t acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc1[4];                       // [2 u + {P, Q}], started at the fc1 bias of the tile's hidden units
+    u32x4_t hf[2];
+    u32x4_t fa0[4], fa1[4];                // A fragments of half-stage h of stage j in fa[h]: 4 fragments = 4 MFMAs
+
+    // Group sync before the first read of group (c * SPC + j) / GS: own DMA parts of the group have landed (counted vmcnt:
+    // the NG - 3 younger groups may still be in flight), barrier (everybody's parts have), then refill the group that was
+    // consumed two syncs ago.
+    auto sync_group = [&](auto jc, int c) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      static_assert(j % GS == 0, "group start");
+      if constexpr ((DBG & 2) == 0) wait_vm<GS*(NG - 3)>();
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < GS; ++i) {
+        const int jn = (j + PD + i) % SPC, cn = c + (j + PD + i) / SPC;
+        issue(cn, jn, (c * SPC + j + PD + i) & (NS - 1));
+      }
+    };
+    // half-stage (j, h): GEMM1: k-steps 2h, 2h+1 of the stage x tiles P, Q; GEMM2: output tiles 4h .. 4h+3 of the third
+    auto read_half = [&](auto jc, auto hc, int c) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value, h = decltype(hc)::value;
+      u32x4_t(&fa)[4] = h ? fa1 : fa0;
+      const bf16_t* st = sm + ((c * SPC + j) & (NS - 1)) * TILE_EL;
+      if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t] = u32x4_t{(unsigned)(c + t), 1u, 2u, (unsigned)j};
+      } else if constexpr (j < G1S) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          fa[2 * s_] = *reinterpret_cast<const u32x4_t*>(st + fo1p + (2 * h + s_) * 32 * BK);
+          fa[2 * s_ + 1] = *reinterpret_cast<const u32x4_t*>(st + fo1q + (2 * h + s_) * 32 * BK);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const u32x4_t*>(st + fo2 + (4 * h + t) * 16 * BK);
+      }
+    };
+    // bias + GELU + bf16 pack, ONE element at a time so that it can be threaded between MFMAs: element e = 4 X + r of
+    // pair-group u is hidden unit 64 c + 32 u + 8 g + e (X = 0: tile P, 1: tile Q; r = accumulator register).
+    float gcarry = 0.f;
+    // accumulator start = fc1 bias: lane (g) holds hidden 64 c + 32 u + 8 g + 4 X + r in register r of tile X
+    auto acc1_start = [&](auto uc, auto xc, int c) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value, X = decltype(xc)::value;
+      acc1[2 * u + X] = *reinterpret_cast<const f32x4_t*>(sb1 + min(c, nch - 1) * CH + 32 * u + 8 * lg + 4 * X);
+    };
+    auto gelu_elem = [&](auto uc, auto ec, int c) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value, e = decltype(ec)::value, X = e >> 2, r = e & 3;
+      const float v = acc1[2 * u + X][r];
+      float gv;
+      if constexpr ((DBG & 1) != 0) gv = v; else gv = gelu_erf(v);
+      if constexpr ((e & 1) == 0) gcarry = gv; else hf[u][e >> 1] = pack_bf2(gcarry, gv);
+      if constexpr (r == 3) acc1_start(uc, std::integral_constant<int, X>{}, c + 1);     // restart for the next chunk
+    };
+    // Which GELU elements ride behind half-stage (j, h): group 0 (complete after stage 2) behind stages 3-5, group 1
+    // (complete after stage 5, needed by stage 9) behind stages 6-8; 2,1,1,2,1,1 elements per half-stage.
+    auto gelu_slot = [&](auto jc, auto hc, auto pc, int c) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value, h = decltype(hc)::value, part = decltype(pc)::value;
+      if constexpr (j >= 3 && j <= 8 && (DBG & 8) == 0) {
+        constexpr int u = (j - 3) / 3, q = 2 * ((j - 3) % 3) + h;           // q = 0..5
+        constexpr int first[7] = {0, 2, 3, 4, 6, 7, 8};
+        constexpr int e0 = first[q], n = first[q + 1] - first[q];
+        if constexpr (part < n) gelu_elem(std::integral_constant<int, u>{}, std::integral_constant<int, e0 + part>{}, c);
+      }
+    };
+    auto mfma_one = [&](auto jc, auto hc, auto tc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value, h = decltype(hc)::value, t = decltype(tc)::value;
+      u32x4_t(&fa)[4] = h ? fa1 : fa0;
+      if constexpr ((DBG & 8) != 0) {
+        asm volatile("" ::"v"(fa[t]));
+        if constexpr (j == G1S - 1) { hf[0] = fa[0]; hf[1] = fa[1]; }
+      } else if constexpr (j < G1S) {
+        constexpr int u = j / (KS1 / KQ), kt = j % (KS1 / KQ);
+        acc1[2 * u + (t & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(bf16x8_t, fa[t]), __builtin_bit_cast(bf16x8_t, xn[kt * KQ + 2 * h + (t >> 1)]), acc1[2 * u + (t & 1)],
+            0, 0, 0);
+      } else {
+        constexpr int u = (j - G1S) / TH, th = (j - G1S) % TH;
+        acc2[th * 8 + 4 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(bf16x8_t, fa[t]), __builtin_bit_cast(bf16x8_t, hf[u]), acc2[th * 8 + 4 * h + t], 0, 0, 0);
+      }
+    };
+    // half-stage (j, h): 4 MFMAs with up to two GELU elements threaded between them (VALU work in the shadow of the matrix
+    // pipe; in one lump it left the pipe idle ~25 % of the time because both waves of a SIMD reach it together)
+    auto mfma_half = [&](auto jc, auto hc, int c) __attribute__((always_inline)) {     // c = chunk the stage belongs to
+      using T0 = std::integral_constant<int, 0>;
+      using T1 = std::integral_constant<int, 1>;
+      using T2 = std::integral_constant<int, 2>;
+      using T3 = std::integral_constant<int, 3>;
+      mfma_one(jc, hc, T0{});
+      mfma_one(jc, hc, T1{});
+      __builtin_amdgcn_sched_barrier(0);
+      gelu_slot(jc, hc, T0{}, c);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_one(jc, hc, T2{});
+      mfma_one(jc, hc, T3{});
+      __builtin_amdgcn_sched_barrier(0);
+      gelu_slot(jc, hc, T1{}, c);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      acc1_start(I0{}, I0{}, 0); acc1_start(I0{}, I1{}, 0); acc1_start(I1{}, I0{}, 0); acc1_start(I1{}, I1{}, 0);
+    }
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    sync_group(H0{}, 0);
+    read_half(H0{}, H0{}, 0);
+    for (int c = 0; c < nch; ++c)
+      static_for<SPC>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int jn = (j + 1) % SPC;
+        const int cn = c + (j + 1) / SPC;
+        read_half(jc, H1{}, c);
+        mfma_half(jc, H0{}, c);
+        if constexpr (jn % GS == 0) sync_group(std::integral_constant<int, jn>{}, cn);
+        read_half(std::integral_constant<int, jn>{}, H0{}, cn);  // (one stage past the end: a stale slot, never multiplied)
+        mfma_half(jc, H1{}, c);
+      });
+    // ---- epilogue: lane holds y[m][16 t + 4 g + r]
+    if (m < a.M) {
+      const float rsc = a.row_scale ? a.row_scale[m / a.rows_per_sample] : 1.0f;
+      float* xr = a.x + (size_t)m * D_ + 4 * lg;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sb2 + 16 * t + 4 * lg);
+        f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
+        xv[0] += rsc * (acc2[t][0] + bb[0]); xv[1] += rsc * (acc2[t][1] + bb[1]);
+        xv[2] += rsc * (acc2[t][2] + bb[2]); xv[3] += rsc * (acc2[t][3] + bb[3]);
+        *reinterpret_cast<f32x4_t*>(xr + 16 * t) = xv;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1,
+                               const void* W2, const float* b2, const float* row_scale, int rows_per_sample, int M, int D, int Hd,
+                               void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return SR_EINVAL;
+  if (D != 384 || Hd < 128 || (Hd % RT) || Hd > 4096) return SR_EINVAL;          // ViT-S width; hidden in 128-wide chunks
+  if (row_scale && rows_per_sample <= 0) return SR_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) return SR_EINVAL;
+  MlpArgs a;
+  a.x = x; a.gamma = ln_gamma; a.beta = ln_beta; a.b1 = b1; a.b2 = b2; a.row_scale = row_scale;
+  a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
+  a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + D) * sizeof(float);
+  void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4>;
+#ifdef SRHIP_TUNING
+  switch (getenv("SRHIP_MLP_DEBUG") ? atoi(getenv("SRHIP_MLP_DEBUG")) : 0) {
+    case 1: kern = mlp_fused_kernel<384, 1, 4>; break;
+    case 2: kern = mlp_fused_kernel<384, 2, 4>; break;
+    case 3: kern = mlp_fused_kernel<384, 3, 4>; break;
+    case 7: kern = mlp_fused_kernel<384, 7, 4>; break;
+    case 11: kern = mlp_fused_kernel<384, 11, 4>; break;
+    case 15: kern = mlp_fused_kernel<384, 15, 4>; break;
+    case 100: kern = mlp_fused_kernel<384, 0, 2>; break;
+    case 101: kern = mlp_fused_kernel<384, 0, 1>; break;
+    default: break;
+  }
+#endif
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int ntiles = cdiv(M, FBM);
+  hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

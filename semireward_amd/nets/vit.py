@@ -15,6 +15,7 @@ Data layout in HBM (B images, N tokens, D channels, M = B*N rows):
   weights                   bf16 [out, in]   (+ transposed bf16 copies for the dX products)
 """
 import math
+import os
 
 import torch
 
@@ -54,6 +55,9 @@ def param_names_shapes(cfg):
                 (b + "mlp.fc2.weight", (D, Hd)), (b + "mlp.fc2.bias", (D,))]
     out += [("norm.weight", (D,)), ("norm.bias", (D,)), ("head.weight", (C, D)), ("head.bias", (C,))]
     return out
+
+
+_FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 
 
 def _round_up(a, b):
@@ -206,7 +210,9 @@ class VisionTransformer:
             ln = self._buf(tag + "ln", (M, D), bf16)
             qkv = self._buf(tag + "qkv", (M, 3 * D), bf16)
             ao = self._buf(tag + "ao", (M, D), bf16)
-        hbuf = self._buf(tag + "h", (M, Hd), bf16)
+        # rows without a backward run LN2 + fc1 + GELU + fc2 + residual as ONE kernel (ViT-S width; SRHIP_FUSED_MLP=0: off)
+        fused_mlp = (not save) and D == 384 and Hd % 128 == 0 and Hd <= 4096 and M >= 1024 and _FUSED_MLP
+        hbuf = None if fused_mlp else self._buf(tag + "h", (M, Hd), bf16)
         wb = self.flat_bf16
         P = self.p
         ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),
@@ -238,10 +244,14 @@ class VisionTransformer:
             else:
                 ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), x, M, D, D, bias=P(b + "attn.proj.bias"),
                             row_scale=s1, rows_per_sample=N)
-                ops.layernorm_fwd(x, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln, None, None, M, D)
-                ops.gemm_nt(ops.EPI_GELU_BF16, ln, P(b + "mlp.fc1.weight", wb), hbuf, M, Hd, D, bias=P(b + "mlp.fc1.bias"))
-                ops.gemm_nt(ops.EPI_RESID_F32, hbuf, P(b + "mlp.fc2.weight", wb), x, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
-                            row_scale=s2, rows_per_sample=N)
+                if fused_mlp:
+                    ops.mlp_fused(x, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb),
+                                  P(b + "mlp.fc1.bias"), P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd)
+                else:
+                    ops.layernorm_fwd(x, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln, None, None, M, D)
+                    ops.gemm_nt(ops.EPI_GELU_BF16, ln, P(b + "mlp.fc1.weight", wb), hbuf, M, Hd, D, bias=P(b + "mlp.fc1.bias"))
+                    ops.gemm_nt(ops.EPI_RESID_F32, hbuf, P(b + "mlp.fc2.weight", wb), x, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
+                                row_scale=s2, rows_per_sample=N)
         feat = torch.empty(B, D, dtype=f32, device=self.device)
         logits = torch.empty(B, C, dtype=f32, device=self.device)
         if save:

@@ -52,6 +52,8 @@ class _GemmProfile:
     def kernel_name(cls, epi, M, N, K):
         if epi != EPI_F32 and N >= 1024 and M >= 1024 and M * N >= 256 * 256 * 128:
             return "gemm_big_kernel<%d, 8>" % epi
+        if epi != EPI_F32 and -(-M // 128) * -(-N // 128) < 512:
+            return "gemm_small_kernel<%d>" % epi
         return "gemm_nt_kernel<%d>" % epi
 
     @staticmethod
@@ -154,6 +156,20 @@ def attn_bwd(qkv, out, d_out, lse, dqkv, delta_ws, B, N, H, scale):
 
 def layernorm_fwd(x, gamma, beta, eps, out, mean, rstd, M, D):
     _call("srhip_layernorm_fwd", _p(x), _p(gamma), _p(beta), eps, _p(out), _p(mean), _p(rstd), M, D, _s())
+
+
+def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M, D, Hd):
+    """x (fp32 [M,D], in place) += row_scale * (fc2(gelu(fc1(LN(x)))) + b2); inference rows only (nothing is saved)."""
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_mlp_fused", _p(x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale), rows_per_sample,
+              M, D, Hd, _s())
+        e1.record()
+        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd, "mlp_fused_kernel<384>", 8.0 * M * D + 4.0 * D * Hd))
+        return
+    _call("srhip_mlp_fused", _p(x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale), rows_per_sample,
+          M, D, Hd, _s())
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M, D):

@@ -77,6 +77,42 @@ def test_gemm_epilogues(M, N, K):
     assert relerr(G, ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,rows_per_sample", [(128, 0), (257 * 3, 257), (1000, 0), (257 * 40 + 5, 257)])
+def test_mlp_fused(M, rows_per_sample):
+    """Fused LN2 + fc1 + GELU + fc2 + residual (srhip_mlp_fused) against (a) the fp32 torch formula of vit.py:165 / 69-75 on
+    the bf16-rounded weights and (b) the three unfused libsrhip launches it replaces (same rounding points)."""
+    D, Hd = 384, 1536
+    x0 = rnd(M, D, seed=1)
+    x0[:, 7] += 3.0                                            # non-zero mean / uneven columns: transposed fragments would show
+    g, b = rnd(D, seed=2, scale=0.2) + 1.0, rnd(D, seed=3, scale=0.1)
+    W1, W2 = bf(rnd(Hd, D, seed=4, scale=0.05)), bf(rnd(D, Hd, seed=5, scale=0.03))
+    b1, b2 = rnd(Hd, seed=6, scale=0.1), rnd(D, seed=7, scale=0.1)
+    rs = None
+    if rows_per_sample:
+        ns = (M + rows_per_sample - 1) // rows_per_sample
+        rs = torch.from_numpy(np.random.Generator(np.random.PCG64(8)).choice([0.0, 1.0 / 0.9], size=ns).astype(np.float32)).to(DEV)
+    # (a) fp32 reference
+    xn = torch.nn.functional.layer_norm(x0, (D,), g, b, 1e-6)
+    y = gelu(xn @ W1.float().T + b1) @ W2.float().T + b2
+    scale = rs.repeat_interleave(rows_per_sample)[:M, None] if rs is not None else 1.0
+    want = x0 + scale * y
+    # (b) unfused HIP path
+    xu = x0.clone()
+    ln = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    h = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_fwd(xu, g, b, 1e-6, ln, None, None, M, D)
+    ops.gemm_nt(ops.EPI_GELU_BF16, ln, W1, h, M, Hd, D, bias=b1)
+    ops.gemm_nt(ops.EPI_RESID_F32, h, W2, xu, M, D, Hd, bias=b2, row_scale=rs, rows_per_sample=rows_per_sample)
+    xf = x0.clone()
+    ops.mlp_fused(xf, g, b, 1e-6, W1, b1, W2, b2, rs, rows_per_sample, M, D, Hd)
+    torch.cuda.synchronize()
+    assert relerr(xf - x0, want - x0) < 6e-3                   # bf16 activations (2^-9) through two products
+    assert relerr(xf - x0, xu - x0) < 1.5e-3                   # same rounding points; LN mean/var summation order differs
+    if rs is not None:                                         # dropped samples are untouched, bit for bit
+        dropped = (rs.repeat_interleave(rows_per_sample)[:M] == 0)
+        assert torch.equal(xf[dropped], x0[dropped])
+
+
 def test_gemm_identity_asymmetric():
     """A = I against an asymmetric B: catches a swapped row/col C write that random-norm checks could hide."""
     K = 128

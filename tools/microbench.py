@@ -43,6 +43,49 @@ def gemm():
         print("gemm %-10s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e6), flush=True)
 
 
+def gemm_small():
+    """The M = 4112-row products of the backward (16 gradient-carrying images)."""
+    for (M, N, K, epi, name) in [(4112, 384, 1152, ops.EPI_BF16, "dqkv->dx"), (4112, 384, 384, ops.EPI_BF16, "dproj->do"),
+                                 (4112, 1536, 384, ops.EPI_DGELU_BF16, "dfc2->dh"), (4112, 384, 1536, ops.EPI_BF16, "dfc1->dx"),
+                                 (4112, 1152, 384, ops.EPI_BF16, "qkv fwd"), (4112, 1536, 384, ops.EPI_GELU_BF16, "fc1 fwd"),
+                                 (4112, 384, 1536, ops.EPI_RESID_F32, "fc2 fwd")]:
+        A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        Bm = (torch.randn(N, K, device=DEV) * 0.05).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV)
+        C = torch.zeros(M, N, dtype=torch.float32 if epi == ops.EPI_RESID_F32 else torch.bfloat16, device=DEV)
+        aux = torch.randn(M, N, device=DEV).to(torch.bfloat16) if epi == ops.EPI_DGELU_BF16 else None
+        t = timeit(lambda: ops.gemm_nt(epi, A, Bm, C, M, N, K, bias=bias, aux_in=aux), reps=20)
+        print("gemm %-10s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e6), flush=True)
+
+
+def mlp():
+    """Fused LN2+fc1+GELU+fc2+residual vs the three unfused launches (inference rows of the reference batch)."""
+    M, D, Hd = 51400, 384, 1536
+    x = torch.randn(M, D, device=DEV)
+    g, b = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
+    W1 = (torch.randn(Hd, D, device=DEV) * 0.05).to(torch.bfloat16)
+    W2 = (torch.randn(D, Hd, device=DEV) * 0.02).to(torch.bfloat16)
+    b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(D, device=DEV) * 0.1
+    ln = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    h = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+
+    def unfused():
+        ops.layernorm_fwd(x, g, b, 1e-6, ln, None, None, M, D)
+        ops.gemm_nt(ops.EPI_GELU_BF16, ln, W1, h, M, Hd, D, bias=b1)
+        ops.gemm_nt(ops.EPI_RESID_F32, h, W2, x, M, D, Hd, bias=b2)
+    t0 = timeit(unfused, reps=10)
+    x.normal_()
+    t1 = timeit(lambda: ops.mlp_fused(x, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd), reps=10)
+    if os.environ.get("SRHIP_TUNING_BUILD"):
+        for dbg in (1, 2, 3, 7, 11, 15, 100, 101):
+            os.environ["SRHIP_MLP_DEBUG"] = str(dbg)
+            t = timeit(lambda: ops.mlp_fused(x, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd), reps=5)
+            print("  debug=%3d (1 no GELU, 2 no DMA, 4 no ds_read, 8 no MFMA; 100: GS=2, 101: GS=1): %8.1f us" % (dbg, t), flush=True)
+        os.environ.pop("SRHIP_MLP_DEBUG")
+    fl = 4.0 * M * D * Hd
+    print("mlp unfused %8.1f us %7.1f TF/s | fused %8.1f us %7.1f TF/s" % (t0, fl / t0 / 1e6, t1, fl / t1 / 1e6), flush=True)
+
+
 def gemm_qkv5():
     M, N, K = 51400, 1152, 384
     A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
