@@ -50,6 +50,18 @@ typedef struct srhip_group_desc {
 int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
                               void* stream);
 
+/* Grouped weight-gradient products from ROW-MAJOR operands (no transposes): for each problem
+ *   C[M,N] = alpha * A^T . B + beta * C,  A bf16 [K, M] (lda), B bf16 [K, N] (ldb), C fp32 [M, N] (ldc);  dbias[M] += colsum(A)
+ * i.e. dW = dY^T X and db = sum_tokens dY of an nn.Linear (autograd of vit.py:69-75, :95-112) with K = tokens.
+ * K is arbitrary (rows past K read as zero); M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, operands 16-byte aligned.
+ * tile_start / total_tiles as in srhip_group_desc.  dbias may be NULL. */
+typedef struct srhip_group_tn_desc {
+  const void* A; const void* B; float* C; float* dbias;
+  int M, N, K, lda, ldb, ldc, tile_start, pad0;
+} srhip_group_tn_desc;                   /* 64 bytes */
+int srhip_gemm_tn_grouped_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
+                              void* stream);
+
 /* Fused attention, head_dim 64.  qkv bf16 [B*N, 3*H*64] as written by the qkv Linear; out bf16 [B*N, H*64];
  * lse fp32 [B,H,N] (NULL when no backward is needed).  Replaces vit.py:100-104 (K4).  N <= 512. */
 int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);

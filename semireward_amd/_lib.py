@@ -20,6 +20,7 @@ P, I, F, L = c_void_p, c_int, c_float, c_long
 SIGNATURES = {
     "srhip_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, P, I, P, P, I, F, F, P]),
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
+    "srhip_gemm_tn_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_attn_fwd": (I, [P, P, P, I, I, I, F, P]),
     "srhip_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, F, P]),
     "srhip_layernorm_fwd": (I, [P, P, P, F, P, P, P, I, I, P]),

@@ -66,7 +66,7 @@ def _round_up(a, b):
 
 class FwdContext:
     """Activations kept by a ``save=True`` forward for the hand-written backward."""
-    __slots__ = ("B", "img", "img_index", "dp", "xs", "xmid", "ln1", "ln2", "qkv", "ao", "lse", "pre", "st1", "st2",
+    __slots__ = ("B", "img", "img_index", "dp", "xs", "xmid", "ln1", "ln2", "qkv", "ao", "lse", "pre", "h", "st1", "st2",
                  "feat", "xhat", "rstd")
 
 
@@ -184,6 +184,7 @@ class VisionTransformer:
         ctx.xs = mk((M, D), f32) + [torch.empty(M, D, dtype=f32, device=self.device)]
         ctx.xmid, ctx.ln1, ctx.ln2 = mk((M, D), f32), mk((M, D), bf16), mk((M, D), bf16)
         ctx.qkv, ctx.ao, ctx.pre = mk((M, 3 * D), bf16), mk((M, D), bf16), mk((M, Hd), bf16)
+        ctx.h = mk((M, Hd), bf16)                # GELU output: the X operand of dW_fc2
         ctx.lse, ctx.st1, ctx.st2 = mk((B, H, N), f32), mk((2, M), f32), mk((2, M), f32)
         ctx.xhat = torch.empty(B, D, dtype=f32, device=self.device)
         ctx.rstd = torch.empty(B, dtype=f32, device=self.device)
@@ -212,7 +213,7 @@ class VisionTransformer:
             ao = self._buf(tag + "ao", (M, D), bf16)
         # rows without a backward run LN2 + fc1 + GELU + fc2 + residual as ONE kernel (ViT-S width; SRHIP_FUSED_MLP=0: off)
         fused_mlp = (not save) and D == 384 and Hd % 128 == 0 and Hd <= 4096 and M >= 1024 and _FUSED_MLP
-        hbuf = None if fused_mlp else self._buf(tag + "h", (M, Hd), bf16)
+        hbuf = None if (fused_mlp or save) else self._buf(tag + "h", (M, Hd), bf16)
         wb = self.flat_bf16
         P = self.p
         ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),
@@ -235,10 +236,10 @@ class VisionTransformer:
                             row_scale=s1, rows_per_sample=N, aux_in=x, ldaux=D)
                 ln2 = ctx.ln2[i]
                 ops.layernorm_fwd(xm, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln2, ctx.st2[i][0], ctx.st2[i][1], M, D)
-                ops.gemm_nt(ops.EPI_GELU_BF16, ln2, P(b + "mlp.fc1.weight", wb), hbuf, M, Hd, D, bias=P(b + "mlp.fc1.bias"),
+                ops.gemm_nt(ops.EPI_GELU_BF16, ln2, P(b + "mlp.fc1.weight", wb), ctx.h[i], M, Hd, D, bias=P(b + "mlp.fc1.bias"),
                             aux_out=ctx.pre[i], ldaux=Hd)
                 xn = ctx.xs[i + 1]
-                ops.gemm_nt(ops.EPI_RESID_F32, hbuf, P(b + "mlp.fc2.weight", wb), xn, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
+                ops.gemm_nt(ops.EPI_RESID_F32, ctx.h[i], P(b + "mlp.fc2.weight", wb), xn, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
                             row_scale=s2, rows_per_sample=N, aux_in=xm, ldaux=D)
                 x = xn
             else:
@@ -271,29 +272,28 @@ class VisionTransformer:
     __call__ = forward
 
     # ---- backward ---------------------------------------------------------------------------------
-    def _bwd_transposed(self, M, Mp, ctx):
-        """Persistent per-layer transposed operand buffers + the grouped-GEMM / batched-transpose descriptor tables
-        (built once per batch size; ``ctx`` buffers are persistent too)."""
-        key = ("bwdT", M)
+    def _bwd_plan(self, M, ctx):
+        """Per-layer output-gradient buffers (the A operands of dW = dY^T X, kept until the ONE grouped launch after the layer
+        loop) + the descriptor table of that launch (built once per batch size; ``ctx`` buffers are persistent too).
+        Operands stay row-major [tokens, features]: srhip_gemm_tn_grouped_f32 gathers the MFMA fragments with LDS transpose
+        reads, and sums the bias gradients on the way (no transposes, no column-sum kernels)."""
+        key = ("bwdplan", M)
         if key in self._ws:
             return self._ws[key]
         cfg = self.cfg
         D, Hd = cfg.embed_dim, cfg.hidden
-        mk = lambda r: torch.zeros(r, Mp, dtype=torch.bfloat16, device=self.device)   # noqa: E731
-        layers, problems, saved = [], [], []
+        mk = lambda c: torch.empty(M, c, dtype=torch.bfloat16, device=self.device)   # noqa: E731
+        layers, problems = [], []
         G = lambda n: self.view(n, self.grad)   # noqa: E731
         for i in range(cfg.depth):
             b = "blocks.%d." % i
-            t = dict(g2T=mk(D), hT=mk(Hd), dpreT=mk(Hd), ln2T=mk(D), g1T=mk(D), aoT=mk(D), dqkvT=mk(3 * D), ln1T=mk(D))
+            t = dict(g2=mk(D), dpre=mk(Hd), g1=mk(D), dqkv=mk(3 * D))
             layers.append(t)
-            saved += [(ctx.pre[i], False, Hd, t["hT"], Mp, M, Mp, Hd, True), (ctx.ln2[i], False, D, t["ln2T"], Mp, M, Mp, D, False),
-                      (ctx.ao[i], False, D, t["aoT"], Mp, M, Mp, D, False), (ctx.ln1[i], False, D, t["ln1T"], Mp, M, Mp, D, False)]
-            problems += [(t["g2T"], t["hT"], G(b + "mlp.fc2.weight"), D, Hd, Mp),
-                         (t["dpreT"], t["ln2T"], G(b + "mlp.fc1.weight"), Hd, D, Mp),
-                         (t["g1T"], t["aoT"], G(b + "attn.proj.weight"), D, D, Mp),
-                         (t["dqkvT"], t["ln1T"], G(b + "attn.qkv.weight"), 3 * D, D, Mp)]
-        out = dict(layers=layers, desc=ops.make_group_desc(problems, self.device),
-                   saved_desc=ops.make_transpose_desc(saved, self.device))
+            problems += [(t["g2"], ctx.h[i], G(b + "mlp.fc2.weight"), G(b + "mlp.fc2.bias"), D, Hd, M),
+                         (t["dpre"], ctx.ln2[i], G(b + "mlp.fc1.weight"), G(b + "mlp.fc1.bias"), Hd, D, M),
+                         (t["g1"], ctx.ao[i], G(b + "attn.proj.weight"), G(b + "attn.proj.bias"), D, D, M),
+                         (t["dqkv"], ctx.ln1[i], G(b + "attn.qkv.weight"), G(b + "attn.qkv.bias"), 3 * D, D, M)]
+        out = dict(layers=layers, desc=ops.make_group_tn_desc(problems, self.device))
         self._ws[key] = out
         return out
 
@@ -303,23 +303,16 @@ class VisionTransformer:
         D, N, H, Hd, C = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes
         B = ctx.B
         M = B * N
-        Mp = _round_up(M, 64)
         f32, bf16 = torch.float32, torch.bfloat16
         P, G, wb = self.p, (lambda n: self.p(n, self.grad)), self.flat_bf16
         dx = self._buf("b_dx", (M, D), f32)
         dx.zero_()
         ops.cls_head_bwd(dlogits, P("head.weight"), P("norm.weight"), ctx.feat, ctx.xhat, ctx.rstd, dx, G("head.weight"),
                          G("head.bias"), G("norm.weight"), G("norm.bias"), B, N, D, C)
-        g = self._buf("b_g", (M, D), bf16)
-        dpre = self._buf("b_dpre", (M, Hd), bf16)
         dln = self._buf("b_dln", (M, D), bf16)
         dao = self._buf("b_dao", (M, D), bf16)
-        dqkv = self._buf("b_dqkv", (M, 3 * D), bf16)
         delta = self._buf("b_delta", (B, H, N), f32)
-        # transposed operands of the weight-gradient products are kept per layer so that all 4*depth products
-        # dW = dY^T X run as ONE grouped launch after the layer loop (see srhip_gemm_nt_grouped_f32)
-        T = self._bwd_transposed(M, Mp, ctx)
-        ops.transpose_batched(*T["saved_desc"])      # ln1^T, attn_out^T, ln2^T, gelu(pre)^T of every layer: one launch
+        T = self._bwd_plan(M, ctx)
         scale = 64 ** -0.5
         dp = ctx.dp
         for i in reversed(range(cfg.depth)):
@@ -328,24 +321,21 @@ class VisionTransformer:
             s1 = dp[i, 0] if dp is not None else None
             s2 = dp[i, 1] if dp is not None else None
             # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))))
-            ops.cast_scale_rows(dx, s2, N, g, M, D)
-            ops.transpose_to_bf16(g, False, D, Ti["g2T"], Mp, M, Mp, D, colsum=G(b + "mlp.fc2.bias"))
-            ops.gemm_nt(ops.EPI_DGELU_BF16, g, self.wT[b + "mlp.fc2.weight"], dpre, M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
-            ops.transpose_to_bf16(dpre, False, Hd, Ti["dpreT"], Mp, M, Mp, Hd, colsum=G(b + "mlp.fc1.bias"))
-            ops.gemm_nt(ops.EPI_BF16, dpre, self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
+            ops.cast_scale_rows(dx, s2, N, Ti["g2"], M, D)
+            ops.gemm_nt(ops.EPI_DGELU_BF16, Ti["g2"], self.wT[b + "mlp.fc2.weight"], Ti["dpre"], M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
+            ops.gemm_nt(ops.EPI_BF16, Ti["dpre"], self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
             ops.layernorm_bwd(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
                               G(b + "norm2.bias"), M, D)
             # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
-            ops.cast_scale_rows(dx, s1, N, g, M, D)
-            ops.transpose_to_bf16(g, False, D, Ti["g1T"], Mp, M, Mp, D, colsum=G(b + "attn.proj.bias"))
-            ops.gemm_nt(ops.EPI_BF16, g, self.wT[b + "attn.proj.weight"], dao, M, D, D)
-            ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], dqkv, delta, B, N, H, scale)
-            ops.transpose_to_bf16(dqkv, False, 3 * D, Ti["dqkvT"], Mp, M, Mp, 3 * D, colsum=G(b + "attn.qkv.bias"))
-            ops.gemm_nt(ops.EPI_BF16, dqkv, self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
+            ops.cast_scale_rows(dx, s1, N, Ti["g1"], M, D)
+            ops.gemm_nt(ops.EPI_BF16, Ti["g1"], self.wT[b + "attn.proj.weight"], dao, M, D, D)
+            ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], Ti["dqkv"], delta, B, N, H, scale)
+            ops.gemm_nt(ops.EPI_BF16, Ti["dqkv"], self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
             ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
                               G(b + "norm1.bias"), M, D)
+        # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
         desc, npb, ntiles, flops, nbytes = T["desc"]
-        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
                             G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
 

@@ -146,6 +146,37 @@ def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flop
     _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
 
+GROUP_TN_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
+                       ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("tile_start", "<i4"), ("pad0", "<i4")]
+
+
+def make_group_tn_desc(problems, device):
+    """problems: list of (A, B, C, dbias, M, N, K) with A bf16 [K,M], B bf16 [K,N] (dense rows), C fp32 [M,N], dbias fp32 [M]
+    or None.  Returns (device uint8 tensor holding srhip_group_tn_desc[], n_problems, total_tiles, flops, algorithmic bytes)."""
+    import numpy as np
+    arr = np.zeros(len(problems), dtype=GROUP_TN_DESC_DTYPE)
+    t = 0
+    for i, (A, B, C, db, M, N, K) in enumerate(problems):
+        arr[i] = (_p(A), _p(B), _p(C), _p(db) or 0, M, N, K, M, N, N, t, 0)
+        t += ((M + 127) // 128) * ((N + 127) // 128)
+    assert arr.itemsize == 64
+    flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
+    nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
+
+
+def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
+    """C_p = alpha * A_p^T . B_p + beta * C_p (+ dbias_p += colsum A_p) for all problems in one launch."""
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_gemm_tn_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
+        e1.record()
+        _PROFILE.recs.append((e0, e1, flops, "gemm_tn_grouped_f32_kernel", nbytes))
+        return
+    _call("srhip_gemm_tn_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
+
+
 def attn_fwd(qkv, out, lse, B, N, H, scale):
     _call("srhip_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, H, scale, _s())
 

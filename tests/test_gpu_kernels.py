@@ -113,6 +113,27 @@ def test_mlp_fused(M, rows_per_sample):
         assert torch.equal(xf[dropped], x0[dropped])
 
 
+def test_gemm_tn_grouped():
+    """dW = dY^T X (+ db = colsum dY) from row-major operands (srhip_gemm_tn_grouped_f32, LDS transpose reads) against fp32
+    torch on the same bf16 operands; ragged K (not a multiple of 32), partial tiles, accumulate into C, several problems."""
+    shapes = [(300, 384, 1536), (64, 128, 128), (1028, 1152, 384), (33, 136, 72), (4112, 384, 384)]     # (K, M, N)
+    problems, refs = [], []
+    for i, (K, M, N) in enumerate(shapes):
+        A, Bm = bf(rnd(K, M, seed=10 + i)), bf(rnd(K, N, seed=20 + i))
+        A[:, 3] += 1.0                                             # asymmetric: a transposed / permuted fragment would show
+        C0, db0 = rnd(M, N, seed=30 + i), rnd(M, seed=40 + i)
+        C, db = C0.clone(), (db0.clone() if i != 1 else None)
+        problems.append((A, Bm, C, db, M, N, K))
+        refs.append((C0 + 0.5 * (A.float().T @ Bm.float()), None if db is None else db0 + A.float().sum(0)))
+    desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV)
+    ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=0.5, beta=1.0)
+    torch.cuda.synchronize()
+    for (A, Bm, C, db, M, N, K), (Cr, dbr) in zip(problems, refs):
+        assert relerr(C, Cr) < 2e-6, (K, M, N, relerr(C, Cr))
+        if db is not None:
+            assert relerr(db, dbr) < 2e-6, (K, M, N)
+
+
 def test_gemm_identity_asymmetric():
     """A = I against an asymmetric B: catches a swapped row/col C write that random-norm checks could hide."""
     K = 128
