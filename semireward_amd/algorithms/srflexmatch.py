@@ -14,6 +14,8 @@ What is restructured for MI355X -- results are unchanged because ViT rows are in
   * softmax/argmax of all passes is one launch, the K rewarder scorings are one grouped launch, the FlexMatch
     state updates stay sequential (they are order dependent) but never leave the device.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -69,6 +71,10 @@ class SRConsistencyBase(AlgorithmBase):
         self.dp.broadcast_params(self.model, self.rewarder, self.generator)
         self._plans = {}
         self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
+        # gradient-row forward on a second HIP stream (SR_OVERLAP_GRAD_ROWS=0 serialises it behind the inference forward)
+        self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", os.environ.get("SR_OVERLAP_GRAD_ROWS", "1") != "0")) \
+            and torch.cuda.is_available()
+        self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
         self.inject_droppath = None            # tests: list of [depth,2,Bt] tensors, one per pass
         self.trace = None                      # tests: dict filled with per-pass intermediates when not None
 
@@ -100,6 +106,16 @@ class SRConsistencyBase(AlgorithmBase):
         sel = (lambda cols: dp_all.index_select(2, cols).contiguous()) if dp_all is not None else (lambda cols: None)
         logits = torch.empty(pl.ncols, C, dtype=torch.float32, device=self.device)
         feats = torch.empty(pl.ncols, D, dtype=torch.float32, device=self.device)
+        # The gradient-carrying rows (16 of 216 images at the reference batch) run on a SECOND HIP stream: their launches are
+        # 100-400 workgroups of latency-bound work (14-28 us each, 1.6 ms per step back to back) that fit beside the tails of
+        # the 200-image inference launches.  Both forwards only read the parameters; they write disjoint workspaces.
+        main = torch.cuda.current_stream()
+        side = self._side_stream if self.overlap_grad_rows else None
+        dp_grad = sel(pl.grad_cols)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side), ops.stream_scope():
+                lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
         ni = pl.inf_cols.numel()
         step = self.infer_chunk if self.infer_chunk > 0 else max(ni, 1)
         for s in range(0, ni, step):
@@ -107,9 +123,14 @@ class SRConsistencyBase(AlgorithmBase):
             lg, ft, _ = m.forward_features(imgs, pl.inf_img[s:s + step].contiguous(), sel(cols), save=False)
             logits.index_copy_(0, cols, lg)
             feats.index_copy_(0, cols, ft)
-        lg, ft, ctx = m.forward_features(imgs, pl.grad_img, sel(pl.grad_cols), save=True)
-        logits.index_copy_(0, pl.grad_cols, lg)
-        feats.index_copy_(0, pl.grad_cols, ft)
+        if side is not None:
+            main.wait_stream(side)
+            lg_g.record_stream(main)
+            ft_g.record_stream(main)
+        else:
+            lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
+        logits.index_copy_(0, pl.grad_cols, lg_g)
+        feats.index_copy_(0, pl.grad_cols, ft_g)
         return logits, feats, ctx
 
     fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient

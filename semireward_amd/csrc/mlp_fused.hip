@@ -23,6 +23,10 @@
 //     one barrier per GS stages, no branches in the loop body (out-of-range ring refills are buffer-OOB no-ops that keep the
 //     vmcnt arithmetic uniform).
 //   * epilogue: re-read x (fp32), add, store.
+// Measured alternatives (tools/microbench.py mlp, M = 51400): 4 waves x 32 rows (one wave per SIMD, every fragment feeding
+// two MFMAs, 512 registers) 357 us vs 248 us for this layout -- a lone wave per SIMD stalls at every s_waitcnt; lockstep
+// stages without the in-wave prefetch 330 us; GELU in one lump per chunk +10 us.  PMC of this kernel: MFMA pipe 19 % busy, LDS
+// array 21 %, VALU 18 %, waves 30 % of their time in s_waitcnt: latency-, not throughput-bound at two waves per SIMD.
 // Rounding points are the ones of the unfused path (xn bf16, GELU output bf16, fp32 accumulation), so the two paths agree to
 // fp32 summation order.
 #include <stdlib.h>
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   }
 }
 
+
 }  // namespace
 
 extern "C" int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1,
@@ -335,8 +340,8 @@ extern "C" int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_
     default: break;
   }
 #endif
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int ntiles = cdiv(M, FBM);
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
   SR_CHECK_LAUNCH();
   return SR_OK;

@@ -52,7 +52,7 @@ class _GemmProfile:
     def kernel_name(cls, epi, M, N, K):
         if epi != EPI_F32 and N >= 1024 and M >= 1024 and M * N >= 256 * 256 * 128:
             return "gemm_big_kernel<%d, 8>" % epi
-        if epi != EPI_F32 and -(-M // 128) * -(-N // 128) < 512:
+        if epi != EPI_F32 and -(-M // 128) * -(-N // 128) < 256:
             return "gemm_small_kernel<%d>" % epi
         return "gemm_nt_kernel<%d>" % epi
 
