@@ -51,7 +51,7 @@ class _GemmProfile:
     @classmethod
     def kernel_name(cls, epi, M, N, K):
         if epi != EPI_F32 and N >= 1024 and M >= 1024 and M * N >= 256 * 256 * 128:
-            return "gemm_big_kernel<%d, 8>" % epi
+            return "gemm_big_kernel<%d, 8, 2>" % epi
         if epi != EPI_F32 and -(-M // 128) * -(-N // 128) < 256:
             return "gemm_small_kernel<%d>" % epi
         return "gemm_nt_kernel<%d>" % epi
@@ -197,7 +197,7 @@ def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M
         _call("srhip_mlp_fused", _p(x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale), rows_per_sample,
               M, D, Hd, _s())
         e1.record()
-        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd, "mlp_fused_kernel<384>", 8.0 * M * D + 4.0 * D * Hd))
+        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd, "mlp_fused_kernel<384, 0, 4>", 8.0 * M * D + 4.0 * D * Hd))
         return
     _call("srhip_mlp_fused", _p(x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale), rows_per_sample,
           M, D, Hd, _s())
