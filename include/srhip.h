@@ -146,6 +146,18 @@ int srhip_freematch_stats(const float* probs, const long long* max_idx, float* c
 int srhip_freematch_update(const float* maxp_all, int n_all, const float* colsum, const float* hist, const float* max_probs,
                            const long long* max_idx, float* time_p, float* p_model, float* label_hist, float* mask, int B, int C,
                            float momentum, float one_minus_momentum, int use_quantile, int clip_thresh, void* stream);
+/* SoftMatch.  Distributed ranks all-reduce the column sums / gather the max-probs (as for FreeMatch) and call these.
+ * distalign: DistAlignEMAHook.dist_align (semilearn/algorithms/hooks/dist_align.py:26-56): p_model <- EMA of colsum_ulb / n_ulb (first call:
+ *   plain mean; *inited is a device flag, 0 before the first call), p_target <- EMA of colsum_lb / n_lb when colsum_lb != NULL
+ *   (p_target_type 'model'); aligned[i,:] = probs[i,:] * (p_target + 1e-6) / (p_model + 1e-6), renormalised; max_probs / max_idx of it.
+ * softmatch_mask: SoftMatchWeightingHook.update + masking (semilearn/algorithms/srsoftmatch/utils.py:32-76, per_class False): mu_var[0..1]
+ *   <- EMA of mean / unbiased variance of maxp_all [n_all] (.item() double arithmetic reproduced), mask[i] = exp(-clamp(p_i - mu, max 0)^2 /
+ *   (2 var / n_sigma^2)). */
+int srhip_distalign(const float* probs, const float* colsum_ulb, int n_ulb, const float* colsum_lb, int n_lb, float* p_model,
+                    float* p_target, int* inited, double momentum, float* aligned, float* max_probs, long long* max_idx, int B, int C,
+                    void* stream);
+int srhip_softmatch_mask(const float* maxp_all, int n_all, const float* max_probs, float* mu_var, double momentum, int n_sigma, float* mask,
+                         int B, void* stream);
 /* entropy_loss (semilearn/algorithms/srfreematch/srfreematch.py:16-44) forward + analytic backward on the masked rows of the strong
  * logits; loss = 0 and no gradient when the mask is empty (:216-219).  ws: B*C floats.  accumulate != 0: dlogits += . */
 int srhip_freematch_entropy(const float* logits, const float* mask, const float* p_model, const float* label_hist, float grad_scale,

@@ -274,15 +274,18 @@ TRACE_FIX = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=91, p_cutoff=0.16, a
 def build_headless_srflexmatch(model, C, Fd, tr):
     fix = tr["algorithm"] == "srfixmatch"
     free = tr["algorithm"] == "srfreematch"
+    soft = tr["algorithm"] == "srsoftmatch"
     srf = R.mod("semilearn.algorithms.srfixmatch.fixmatch") if fix else R.mod("semilearn.algorithms.srflexmatch.srflexmatch")
     if free:
         srf = R.mod("semilearn.algorithms.srfreematch.srfreematch")
+    if soft:
+        srf = R.mod("semilearn.algorithms.srsoftmatch.srsoftmatch")
     sr = R.mod("semilearn.algorithms.semireward.semireward")
     um = R.mod("semilearn.algorithms.srflexmatch.utils")
     hk = R.mod("semilearn.algorithms.hooks")
     cr = R.mod("semilearn.core.criterions")
     bu = R.mod("semilearn.core.utils.build")
-    alg = object.__new__(srf.SRFreeMatch if free else (srf.SRFixMatch if fix else srf.SRFlexMatch))
+    alg = object.__new__(srf.SRSoftMatch if soft else (srf.SRFreeMatch if free else (srf.SRFixMatch if fix else srf.SRFlexMatch)))
     alg.args = types.SimpleNamespace(ulb_dest_len=tr["ulb_dest_len"], thresh_warmup=True)
     alg.num_classes, alg.use_cat, alg.amp_cm, alg.gpu = C, True, contextlib.nullcontext, None
     alg.lambda_u, alg.num_train_iter, alg.it = 1.0, tr["num_train_iter"], 0
@@ -291,6 +294,10 @@ def build_headless_srflexmatch(model, C, Fd, tr):
     if free:
         alg.init(T=0.5, hard_label=True, ema_p=tr["ema_p"], use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"])
         alg.lambda_e, alg.distributed, alg.world_size = tr["ent_loss_ratio"], False, 1
+    elif soft:
+        alg.init(T=0.5, hard_label=True, dist_align=True, dist_uniform=tr["dist_uniform"], ema_p=tr["ema_p"], n_sigma=tr["n_sigma"],
+                 per_class=False)
+        alg.distributed, alg.world_size = False, 1
     elif fix:
         alg.init(T=0.5, p_cutoff=tr["p_cutoff"], hard_label=True)
     else:
@@ -309,6 +316,11 @@ def build_headless_srflexmatch(model, C, Fd, tr):
     if free:
         fmu = R.mod("semilearn.algorithms.freematch.utils")
         alg.register_hook(fmu.FreeMatchThresholdingHook(num_classes=C, momentum=tr["ema_p"]), "MaskingHook")
+    elif soft:
+        smu = R.mod("semilearn.algorithms.srsoftmatch.utils")
+        alg.register_hook(hk.DistAlignEMAHook(num_classes=C, momentum=tr["ema_p"], p_target_type="uniform" if tr["dist_uniform"] else "model"),
+                          "DistAlignHook")
+        alg.register_hook(smu.SoftMatchWeightingHook(num_classes=C, n_sigma=tr["n_sigma"], momentum=tr["ema_p"], per_class=False), "MaskingHook")
     elif fix:
         alg.register_hook(hk.FixedThresholdingHook(), "MaskingHook")
     else:
@@ -425,6 +437,44 @@ def gen_trace_free():
     gen_trace(TRACE_FREE, "srfreematch_trace.npz")
 
 
+# srsoftmatch: ema_p 0.9 makes the Gaussian's EMA mean / variance move visibly in 6 steps; dist_uniform False = p_target follows the
+# labelled batch ('model'), the more general of the two DistAlign modes (uniform is covered by tests/golden/softmatch_hook.npz)
+TRACE_SOFT = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=103, algorithm="srsoftmatch", ema_p=0.9, n_sigma=2, dist_uniform=False)
+
+
+def gen_trace_soft():
+    gen_trace(TRACE_SOFT, "srsoftmatch_trace.npz")
+
+
+def gen_softmatch_hook():
+    """DistAlignEMAHook + SoftMatchWeightingHook sequences straight from the reference (both p_target modes)."""
+    smu = R.mod("semilearn.algorithms.srsoftmatch.utils")
+    hk = R.mod("semilearn.algorithms.hooks")
+    out = {}
+    for tag, C, Bu, Bl, steps, m, ns, ptype, seed in [("c10_uniform", 10, 8, 8, 24, 0.9, 2, "uniform", 71), ("c100_model", 100, 64, 16, 24, 0.9, 2, "model", 72),
+                                                      ("c10_model_s3", 10, 7, 5, 30, 0.8, 3, "model", 73)]:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        alg = types.SimpleNamespace(distributed=False, world_size=1)
+        da = hk.DistAlignEMAHook(num_classes=C, momentum=m, p_target_type=ptype)
+        sm = smu.SoftMatchWeightingHook(num_classes=C, n_sigma=ns, momentum=m, per_class=False)
+        lu = (rng.standard_normal((steps, Bu, C)) * rng.uniform(0.5, 4.0, size=(steps, Bu, 1))).astype(np.float32)
+        ll = (rng.standard_normal((steps, Bl, C)) * 2).astype(np.float32)
+        rec = dict(aligned=[], mask_a=[], mask_p=[], mu=[], var=[], p_model=[], p_target=[])
+        for t in range(steps):
+            pu, plb = torch.softmax(T(lu[t]), dim=-1), torch.softmax(T(ll[t]), dim=-1)
+            al = da.dist_align(alg, probs_x_ulb=pu, probs_x_lb=plb)
+            ma = sm.masking(alg, logits_x_ulb=al, softmax_x_ulb=False)           # pass-0 style call (aligned probabilities)
+            mp_ = sm.masking(alg, logits_x_ulb=pu, softmax_x_ulb=False)          # loop-pass style call (plain probabilities)
+            rec["aligned"].append(al.numpy().copy()); rec["mask_a"].append(ma.numpy().copy()); rec["mask_p"].append(mp_.numpy().copy())
+            rec["mu"].append(np.float32(sm.prob_max_mu_t)); rec["var"].append(np.float32(sm.prob_max_var_t))
+            rec["p_model"].append(da.p_model.numpy().copy()); rec["p_target"].append(da.p_target.numpy().copy())
+        out.update({f"{tag}/logits_ulb": lu, f"{tag}/logits_lb": ll, f"{tag}/momentum": np.float64(m),
+                    f"{tag}/meta": np.array([C, Bu, Bl, steps, ns, int(ptype == "model"), seed], dtype=np.int64)})
+        out.update({f"{tag}/{k}": np.stack(v) for k, v in rec.items()})
+        print(tag, "mask mean", np.stack(rec["mask_a"]).mean(), np.stack(rec["mask_p"]).mean())
+    np.savez_compressed(os.path.join(OUT, "softmatch_hook.npz"), **out)
+
+
 def gen_freematch_hook():
     """FreeMatchThresholdingHook sequences + entropy_loss values/grads straight from the reference."""
     um = R.mod("semilearn.algorithms.freematch.utils")
@@ -464,8 +514,9 @@ def gen_trace_fix():
 
 def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
     tr = tr or TRACE
-    fix = tr["algorithm"] in ("srfixmatch", "srfreematch")        # no idx_ulb, no selected_label state
+    fix = tr["algorithm"] in ("srfixmatch", "srfreematch", "srsoftmatch")        # no idx_ulb, no selected_label state
     free = tr["algorithm"] == "srfreematch"
+    soft = tr["algorithm"] == "srsoftmatch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
     Fd = cfg.embed_dim
@@ -530,6 +581,10 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
         if free:
             out[f"{p}/time_p"] = np.float32(mh.time_p); out[f"{p}/p_model"] = mh.p_model.numpy().copy()
             out[f"{p}/label_hist"] = mh.label_hist.numpy().copy()
+        if soft:
+            dh = alg.hooks_dict["DistAlignHook"]
+            out[f"{p}/mu"] = np.float32(mh.prob_max_mu_t); out[f"{p}/var"] = np.float32(mh.prob_max_var_t)
+            out[f"{p}/p_model"] = dh.p_model.numpy().copy(); out[f"{p}/p_target"] = dh.p_target.numpy().copy()
         if not fix:
             sel = mh.selected_label.numpy(); nz = np.nonzero(sel != -1)[0]
             out[f"{p}/sel_idx"] = nz.astype(np.int64); out[f"{p}/sel_val"] = sel[nz]
@@ -540,7 +595,8 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
-            trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook)
+            trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
+            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

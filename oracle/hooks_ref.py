@@ -8,6 +8,8 @@ shortcuts) because the masks must be bit-exact:
   ce_loss                    semilearn/core/criterions/cross_entropy.py:11-31
   consistency_loss           semilearn/core/criterions/consistency.py:13-45
   sr_decay                   semilearn/core/algorithmbase.py:177-183
+  SoftMatchWeightingHook     semilearn/algorithms/srsoftmatch/utils.py:12-76
+  DistAlignEMAHook           semilearn/algorithms/hooks/dist_align.py:10-71
 """
 import numpy as np
 import torch
@@ -144,3 +146,44 @@ def freematch_entropy_loss(mask, logits_s, prob_model, label_hist):
     mod_mean = prob_s.mean(dim=0, keepdim=True) * inv(hist_s).detach()
     mod_mean = mod_mean / mod_mean.sum(dim=-1, keepdim=True)
     return (mod_prob_model * torch.log(mod_mean + 1e-12)).sum(dim=1).mean()
+
+
+class DistAlignState:
+    """dist_align.py:10-71 (EMA distribution alignment).  torch-CPU fp32, same op order as the reference.
+    p_target_type 'uniform' (SoftMatch default, fixed 1/C) or 'model' (EMA of the labelled-batch marginals)."""
+
+    def __init__(self, num_classes, momentum=0.999, p_target_type="uniform"):
+        assert p_target_type in ("uniform", "model")
+        self.m = momentum
+        self.update_p_target = p_target_type == "model"
+        self.p_target = torch.ones((num_classes,)) / num_classes                                    # :62-66
+        self.p_model = None
+
+    def dist_align(self, probs_x_ulb, probs_x_lb=None):
+        probs_x_ulb = torch.as_tensor(probs_x_ulb, dtype=torch.float32)
+        if self.p_model is None:                                                                    # :49-52
+            self.p_model = torch.mean(probs_x_ulb, dim=0)
+        else:
+            self.p_model = self.p_model * self.m + torch.mean(probs_x_ulb, dim=0) * (1 - self.m)
+        if self.update_p_target:                                                                    # :54-56
+            self.p_target = self.p_target * self.m + torch.mean(torch.as_tensor(probs_x_lb, dtype=torch.float32), dim=0) * (1 - self.m)
+        aligned = probs_x_ulb * (self.p_target + 1e-6) / (self.p_model + 1e-6)                       # :31
+        return aligned / aligned.sum(dim=-1, keepdim=True)                                           # :32
+
+
+class SoftMatchState:
+    """srsoftmatch/utils.py:12-76 with per_class=False (the configs' value): EMA of mean / unbiased variance of the max-probs,
+    truncated-Gaussian sample weight.  ``.item()`` makes the new statistic a python double before it meets the fp32 state."""
+
+    def __init__(self, num_classes, n_sigma=2, momentum=0.999):
+        self.n_sigma, self.m = n_sigma, momentum
+        self.mu = torch.tensor(1.0 / num_classes)                                                   # :24
+        self.var = torch.tensor(1.0)                                                                # :25
+
+    def masking(self, probs):
+        probs = torch.as_tensor(probs, dtype=torch.float32)
+        max_probs, _ = probs.max(dim=-1)
+        mu_b, var_b = torch.mean(max_probs), torch.var(max_probs, unbiased=True)                    # :38-39
+        self.mu = self.m * self.mu + (1 - self.m) * mu_b.item()                                     # :40
+        self.var = self.m * self.var + (1 - self.m) * var_b.item()                                  # :41
+        return torch.exp(-((torch.clamp(max_probs - self.mu, max=0.0) ** 2) / (2 * self.var / (self.n_sigma ** 2))))   # :75

@@ -5,7 +5,7 @@ raises.  Signatures mirror include/srhip.h one to one.
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_long, c_ulonglong, c_void_p
+from ctypes import c_double, c_float, c_int, c_long, c_ulonglong, c_void_p
 
 # torch must be imported BEFORE libsrhip.so is dlopen'ed: torch ships its own libamdhip64; if libsrhip pulled the
 # system copy in first the process would hold two HIP runtimes and our launches would see "no device" (hipError 100).
@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libsrhip.so")
 
 EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_F32 = range(5)
 
-P, I, F, L = c_void_p, c_int, c_float, c_long
+P, I, F, L, Dbl = c_void_p, c_int, c_float, c_long, c_double
 SIGNATURES = {
     "srhip_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, P, I, P, P, I, F, F, P]),
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
@@ -42,6 +42,8 @@ SIGNATURES = {
     "srhip_freematch_stats": (I, [P, P, P, P, I, I, P]),
     "srhip_freematch_update": (I, [P, I, P, P, P, P, P, P, P, P, I, I, F, F, I, I, P]),
     "srhip_freematch_entropy": (I, [P, P, P, P, F, P, P, P, I, I, I, P]),
+    "srhip_distalign": (I, [P, P, I, P, I, P, P, P, Dbl, P, P, P, I, I, P]),
+    "srhip_softmatch_mask": (I, [P, I, P, P, Dbl, I, P, I, P]),
     "srhip_reward_mask2": (I, [P, P, P, P, I, I, P]),
     "srhip_masked_ce": (I, [P, P, P, P, F, P, P, I, I, P]),
     "srhip_rewarder_param_count": (L, [I, I]),

@@ -3,6 +3,7 @@ from ..core.registry import ALGORITHMS  # noqa: F401
 from .srflexmatch import SRFixMatch, SRFlexMatch  # noqa: F401
 from .srfreematch import SRFreeMatch  # noqa: F401
 from .srpseudolabel import SRPseudoLabel  # noqa: F401
+from .srsoftmatch import SRSoftMatch  # noqa: F401
 
 
 def get_algorithm(args, net_builder, tb_log=None, logger=None):

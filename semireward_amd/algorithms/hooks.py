@@ -115,3 +115,86 @@ class FreeMatchThresholdingHook(MaskingHook):
         mi = torch.empty(B, dtype=torch.int64, device=probs.device)
         ops.row_max(logits_x_ulb.contiguous(), not softmax_x_ulb, probs, mp, mi, B, C)
         return self.masking_from_probs(algorithm, probs, mp, mi)
+
+
+class DistAlignEMAHook(Hook):
+    """EMA distribution alignment (semilearn/algorithms/hooks/dist_align.py:10-71), p_target_type 'uniform' or 'model'.  Same
+    attribute names as the reference (``p_model``, ``p_target``) so get_save_dict / load_model keep working; ``p_model`` holds
+    zeros until the first call (the reference keeps None)."""
+
+    def __init__(self, num_classes, momentum=0.999, p_target_type="uniform", p_target=None, device="cuda"):
+        super().__init__()
+        assert p_target_type in ("uniform", "model"), "p_target_type 'gt' (a given prior) is not used by the SemiReward configs"
+        self.num_classes, self.m = num_classes, momentum
+        self.update_p_target = p_target_type == "model"
+        self.p_target = torch.ones(num_classes, dtype=torch.float32, device=device) / num_classes
+        self.p_model = torch.zeros(num_classes, dtype=torch.float32, device=device)
+        self.inited = torch.zeros(1, dtype=torch.int32, device=device)
+        self._cs_u = torch.empty(num_classes, dtype=torch.float32, device=device)
+        self._cs_l = torch.empty(num_classes, dtype=torch.float32, device=device)
+        self._hist = torch.empty(num_classes, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def align(self, algorithm, probs_x_ulb, probs_x_lb=None):
+        """Returns (aligned probabilities [B,C], their row max [B], argmax [B])."""
+        B, C = probs_x_ulb.shape
+        dev = probs_x_ulb.device
+        zi = torch.zeros(max(B, probs_x_lb.shape[0] if probs_x_lb is not None else 0), dtype=torch.int64, device=dev)
+        ops.freematch_stats(probs_x_ulb.contiguous(), zi, self._cs_u, self._hist, B, C)                # column sums of the local rows
+        n_u, n_l, cs_l = B, 0, None
+        if self.update_p_target:
+            assert probs_x_lb is not None
+            n_l = probs_x_lb.shape[0]
+            ops.freematch_stats(probs_x_lb.contiguous(), zi, self._cs_l, self._hist, n_l, C)
+            cs_l = self._cs_l
+        dp = getattr(algorithm, "dp", None)
+        if dp is not None and dp.active:                      # reference: concat_all_gather of both batches (dist_align.py:42-45)
+            dp.all_reduce_flat(self._cs_u)
+            n_u *= dp.world_size
+            if cs_l is not None:
+                dp.all_reduce_flat(cs_l)
+                n_l *= dp.world_size
+        aligned = torch.empty(B, C, dtype=torch.float32, device=dev)
+        mp = torch.empty(B, dtype=torch.float32, device=dev)
+        mi = torch.empty(B, dtype=torch.int64, device=dev)
+        ops.distalign(probs_x_ulb.contiguous(), self._cs_u, n_u, cs_l, n_l, self.p_model, self.p_target, self.inited, self.m, aligned, mp, mi, B, C)
+        return aligned, mp, mi
+
+    @torch.no_grad()
+    def dist_align(self, algorithm, probs_x_ulb, probs_x_lb=None):
+        return self.align(algorithm, probs_x_ulb, probs_x_lb)[0]
+
+
+class SoftMatchWeightingHook(MaskingHook):
+    """SoftMatch truncated-Gaussian sample weighting (semilearn/algorithms/srsoftmatch/utils.py:12-76), per_class False (the configs'
+    value).  The EMA mean / variance advance at EVERY masking call.  ``prob_max_mu_t`` / ``prob_max_var_t`` as in the reference."""
+
+    def __init__(self, num_classes, n_sigma=2, momentum=0.999, per_class=False, device="cuda", *a, **k):
+        super().__init__()
+        assert not per_class, "per_class SoftMatch statistics are not on the SemiReward hot path (configs use per_class False)"
+        self.num_classes, self.n_sigma, self.m = num_classes, n_sigma, momentum
+        self.mu_var = torch.tensor([1.0 / num_classes, 1.0], dtype=torch.float32, device=device)
+
+    @property
+    def prob_max_mu_t(self):
+        return self.mu_var[0]
+
+    @property
+    def prob_max_var_t(self):
+        return self.mu_var[1]
+
+    @torch.no_grad()
+    def masking_from_max(self, algorithm, max_probs):
+        B = max_probs.numel()
+        maxp_all, n_all = max_probs, B
+        dp = getattr(algorithm, "dp", None)
+        if dp is not None and dp.active:                      # reference: concat_all_gather(probs) (utils.py:34-35)
+            maxp_all, n_all = dp.gather_stats(max_probs, None, None)
+        mask = torch.empty_like(max_probs)
+        ops.softmatch_mask(maxp_all.contiguous(), n_all, max_probs.contiguous(), self.mu_var, self.m, self.n_sigma, mask, B)
+        return mask
+
+    @torch.no_grad()
+    def masking(self, algorithm, logits_x_ulb, softmax_x_ulb=True, *a, **k):
+        mp, _ = _row_max(logits_x_ulb, is_probs=not softmax_x_ulb)
+        return self.masking_from_max(algorithm, mp)

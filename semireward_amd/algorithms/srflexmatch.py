@@ -170,6 +170,7 @@ class SRConsistencyBase(AlgorithmBase):
         mp = torch.empty(P * nu, dtype=torch.float32, device=self.device)
         mi = torch.empty(P * nu, dtype=torch.int64, device=self.device)
         ops.row_max(Lw, False, None, mp, mi, P * nu, C)
+        self._lb_logits0 = L[0, :nl]                       # SoftMatch's 'model' alignment target reads the labelled rows of pass 0
         masks = self._masks(mp, mi, idx_ulb, P, nu, Lw)
         pl0 = mi[:nu]
         sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132

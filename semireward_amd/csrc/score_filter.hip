@@ -424,6 +424,92 @@ extern "C" int srhip_masked_ce(const float* logits, const long long* targets, co
   return SR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SoftMatch (a12): DistAlignEMAHook.dist_align (semilearn/algorithms/hooks/dist_align.py:26-56) and
+// SoftMatchWeightingHook.update/masking (semilearn/algorithms/srsoftmatch/utils.py:32-76, per_class = False).
+// ONE workgroup each: B rows of C probabilities (B <= a few hundred per GPU).
+
+// p_model (and p_target when colsum_lb != NULL) EMA from the column sums of the GLOBAL batch, then for the LOCAL rows
+// aligned = probs * (p_target + 1e-6) / (p_model + 1e-6), renormalised, and its row max / argmax.
+__global__ __launch_bounds__(256) void distalign_kernel(const float* __restrict__ probs, const float* __restrict__ colsum_ulb, int n_ulb,
+                                                       const float* __restrict__ colsum_lb, int n_lb, float* __restrict__ p_model,
+                                                       float* __restrict__ p_target, int* __restrict__ inited, float m, float one_minus_m,
+                                                       float* __restrict__ aligned, float* __restrict__ max_probs,
+                                                       long long* __restrict__ max_idx, int B, int C) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool first = (*inited == 0);
+  for (int c = tid; c < C; c += 256) {
+    const float mean_u = colsum_ulb[c] / (float)n_ulb;                                  // torch.mean(probs_x_ulb, dim=0)
+    p_model[c] = first ? mean_u : p_model[c] * m + mean_u * one_minus_m;                // :49-52
+    if (colsum_lb) p_target[c] = p_target[c] * m + (colsum_lb[c] / (float)n_lb) * one_minus_m;   // :54-56
+  }
+  __syncthreads();                            // p_model / p_target of this launch are visible to the whole workgroup (one WG)
+  if (tid == 0) *inited = 1;
+  for (int i = wave; i < B; i += 4) {         // one wave per row
+    const float* pr = probs + (size_t)i * C;
+    float* ar = aligned + (size_t)i * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float a = pr[c] * (p_target[c] + 1e-6f) / (p_model[c] + 1e-6f);             // :31
+      ar[c] = a;
+      s += a;
+    }
+    s = wave_sum(s);
+    float best = -1.0f;
+    int bi = 0;
+    for (int c = lane; c < C; c += 64) {
+      const float a = ar[c] / s;                                                        // :32
+      ar[c] = a;
+      if (a > best) { best = a; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {         // max with first-index tie break (torch.max)
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { max_probs[i] = best; max_idx[i] = bi; }
+  }
+}
+
+// mu / var EMA of the max-probs of the GLOBAL batch (mean, unbiased variance), then the truncated-Gaussian weight of the LOCAL rows.
+// The reference takes the batch statistics through .item(): (1 - m) * stat is a python double product that is rounded to fp32
+// when it meets the fp32 state (utils.py:40-41); m * state is an fp32 product.
+__global__ __launch_bounds__(256) void softmatch_mask_kernel(const float* __restrict__ maxp_all, int n_all, const float* __restrict__ max_probs,
+                                                            float* __restrict__ mu_var, double m, int n_sigma, float* __restrict__ mask, int B) {
+  __shared__ double red[4];
+  __shared__ float st[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  for (int i = tid; i < n_all; i += 256) s += (double)maxp_all[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n_all);      // torch.mean (fp32 result)
+  __syncthreads();
+  double q = 0.0;
+  for (int i = tid; i < n_all; i += 256) { const double d = (double)maxp_all[i] - (double)mean; q += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  if (tid == 0) {
+    const float var = (float)((red[0] + red[1] + red[2] + red[3]) / (double)(n_all - 1));   // torch.var(unbiased=True); n_all = 1 -> nan as torch
+    const float mf = (float)m;
+    st[0] = mf * mu_var[0] + (float)((1.0 - m) * (double)mean);                          // :40
+    st[1] = mf * mu_var[1] + (float)((1.0 - m) * (double)var);                           // :41
+    mu_var[0] = st[0];
+    mu_var[1] = st[1];
+  }
+  __syncthreads();
+  const float mu = st[0], den = (2.0f * st[1]) / (float)(n_sigma * n_sigma);
+  for (int i = tid; i < B; i += 256) {
+    const float d = fminf(max_probs[i] - mu, 0.0f);                                     // torch.clamp(max=0.0)
+    mask[i] = expf(-((d * d) / den));                                                   // :75
+  }
+}
+
 extern "C" int srhip_freematch_stats(const float* probs, const long long* max_idx, float* colsum, float* hist, int B, int C, void* stream) {
   if (B <= 0 || C <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(freematch_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, probs, max_idx, colsum, hist, B, C);
@@ -447,6 +533,26 @@ extern "C" int srhip_freematch_entropy(const float* logits, const float* mask, c
   if (B <= 0 || B > 1024 || C <= 0 || C > 2048) return SR_EINVAL;
   hipLaunchKernelGGL(freematch_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, mask, p_model, label_hist, grad_scale,
                      loss_out, dlogits, ws, B, C, accumulate);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_distalign(const float* probs, const float* colsum_ulb, int n_ulb, const float* colsum_lb, int n_lb, float* p_model,
+                               float* p_target, int* inited, double momentum, float* aligned, float* max_probs, long long* max_idx,
+                               int B, int C, void* stream) {
+  if (!probs || !colsum_ulb || !p_model || !p_target || !inited || !aligned || !max_probs || !max_idx) return SR_EINVAL;
+  if (B <= 0 || C <= 0 || n_ulb <= 0 || (colsum_lb && n_lb <= 0)) return SR_EINVAL;
+  hipLaunchKernelGGL(distalign_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, colsum_ulb, n_ulb, colsum_lb, n_lb, p_model,
+                     p_target, inited, (float)momentum, (float)(1.0 - momentum), aligned, max_probs, max_idx, B, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_softmatch_mask(const float* maxp_all, int n_all, const float* max_probs, float* mu_var, double momentum, int n_sigma,
+                                    float* mask, int B, void* stream) {
+  if (!maxp_all || !max_probs || !mu_var || !mask || n_all <= 0 || B <= 0 || n_sigma <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(softmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, maxp_all, n_all, max_probs, mu_var, momentum, n_sigma,
+                     mask, B);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

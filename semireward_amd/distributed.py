@@ -39,8 +39,10 @@ class DataParallel:
         """FreeMatch / SoftMatch statistics of the GLOBAL batch: the reference all-gathers [Bu, C] probabilities
         (algorithms/utils/ops.py:35-45); the sufficient statistics are enough -- column sums and histogram are all-reduced
         in place, only the Bu max-probs are gathered (needed for the quantile).  Returns (maxp_all, n_all)."""
-        dist.all_reduce(colsum)
-        dist.all_reduce(hist)
+        if colsum is not None:
+            dist.all_reduce(colsum)
+        if hist is not None:
+            dist.all_reduce(hist)
         out = [torch.empty_like(max_probs) for _ in range(self.world_size)]
         dist.all_gather(out, max_probs.contiguous())
         allp = torch.cat(out)

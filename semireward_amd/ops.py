@@ -291,6 +291,15 @@ def freematch_update(maxp_all, n_all, colsum, hist, max_probs, max_idx, time_p, 
           _p(label_hist), _p(mask), B, C, float(np.float32(m)), float(np.float32(1 - m)), int(use_quantile), int(clip_thresh), _s())
 
 
+def distalign(probs, colsum_ulb, n_ulb, colsum_lb, n_lb, p_model, p_target, inited, momentum, aligned, max_probs, max_idx, B, C):
+    _call("srhip_distalign", _p(probs), _p(colsum_ulb), n_ulb, _p(colsum_lb), n_lb, _p(p_model), _p(p_target), _p(inited), float(momentum),
+          _p(aligned), _p(max_probs), _p(max_idx), B, C, _s())
+
+
+def softmatch_mask(maxp_all, n_all, max_probs, mu_var, momentum, n_sigma, mask, B):
+    _call("srhip_softmatch_mask", _p(maxp_all), n_all, _p(max_probs), _p(mu_var), float(momentum), int(n_sigma), _p(mask), B, _s())
+
+
 def freematch_entropy(logits, mask, p_model, label_hist, grad_scale, loss_out, dlogits, ws, B, C, accumulate=False):
     _call("srhip_freematch_entropy", _p(logits), _p(mask), _p(p_model), _p(label_hist), grad_scale, _p(loss_out), _p(dlogits), _p(ws),
           B, C, int(accumulate), _s())

@@ -92,6 +92,12 @@ def test_pass_plan_and_registry():
     from semireward_amd.algorithms.srpseudolabel import SRPseudoLabel
     assert ALGORITHMS["srpseudolabel"] is SRPseudoLabel and ALGORITHMS["srfreematch"] is SRFreeMatch
     assert list(signature(SRFreeMatch.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w", "x_ulb_s"]
+    from semireward_amd.algorithms.srsoftmatch import SRSoftMatch
+    assert ALGORITHMS["srsoftmatch"] is SRSoftMatch                         # all five registry keys of the reference
+    assert list(signature(SRSoftMatch.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w", "x_ulb_s"]
+    assert [a.name for a in SRSoftMatch.get_argument()] == [
+        "--hard_label", "--T", "--dist_align", "--dist_uniform", "--ema_p", "--n_sigma", "--per_class", "--start_timing", "--feature_dim",
+        "--sr_lr", "--N_k", "--sr_ema", "--sr_ema_m"]                        # srsoftmatch.py:243-258
     pf = _Plan.cat_passes(8, 8, 8, "cpu", extra_pass0_strong=True)
     assert pf.grad_cols.tolist() == list(range(8)) + list(range(16, 24)) + [8 * 24 + j for j in range(16, 24)]
     assert list(signature(SRPseudoLabel.train_step).parameters)[1:] == ["x_lb", "y_lb", "x_ulb_w"]

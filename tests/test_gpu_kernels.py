@@ -487,3 +487,45 @@ def test_freematch_hook_and_entropy(golden, tag):
     dl = torch.full((Bu, C), 7.0, device=DEV)
     ops.freematch_entropy(ls, z, p_model, label_hist, 1.0, loss, dl, ws, Bu, C)
     assert float(loss) == 0.0 and float(dl.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["c10_uniform", "c100_model", "c10_model_s3"])
+def test_softmatch_and_distalign(golden, tag):
+    """DistAlign EMA + aligned probabilities and the SoftMatch Gaussian weight on device against the reference's own sequences
+    (tests/golden/softmatch_hook.npz): EMA state to fp32 round-off (reduction order differs), weights to 2e-6."""
+    g = golden("softmatch_hook")
+    C, Bu, Bl, steps, ns, model_t, seed = [int(v) for v in g[f"{tag}/meta"]]
+    m = float(g[f"{tag}/momentum"])
+    p_model, p_target = torch.zeros(C, device=DEV), torch.ones(C, device=DEV) / C
+    inited = torch.zeros(1, dtype=torch.int32, device=DEV)
+    mu_var = torch.tensor([1.0 / C, 1.0], device=DEV)
+    cs_u, cs_l, hist = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    zi = torch.zeros(max(Bu, Bl), dtype=torch.int64, device=DEV)
+    for t in range(steps):
+        lu, ll = torch.from_numpy(g[f"{tag}/logits_ulb"][t]).to(DEV), torch.from_numpy(g[f"{tag}/logits_lb"][t]).to(DEV)
+        pu, plb = torch.empty(Bu, C, device=DEV), torch.empty(Bl, C, device=DEV)
+        mp, mi = torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV)
+        mpl, mil = torch.empty(Bl, device=DEV), torch.empty(Bl, dtype=torch.int64, device=DEV)
+        ops.row_max(lu, False, pu, mp, mi, Bu, C)
+        ops.row_max(ll, False, plb, mpl, mil, Bl, C)
+        ops.freematch_stats(pu, zi, cs_u, hist, Bu, C)
+        ops.freematch_stats(plb, zi, cs_l, hist, Bl, C)
+        al, amp, ami = torch.empty(Bu, C, device=DEV), torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV)
+        ops.distalign(pu, cs_u, Bu, cs_l if model_t else None, Bl, p_model, p_target, inited, m, al, amp, ami, Bu, C)
+        ma, mk = torch.empty(Bu, device=DEV), torch.empty(Bu, device=DEV)
+        ops.softmatch_mask(amp, Bu, amp, mu_var, m, ns, ma, Bu)
+        mu_a = mu_var.clone()
+        ops.softmatch_mask(mp, Bu, mp, mu_var, m, ns, mk, Bu)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p_model.cpu().numpy(), g[f"{tag}/p_model"][t], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(p_target.cpu().numpy(), g[f"{tag}/p_target"][t], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(al.cpu().numpy(), g[f"{tag}/aligned"][t], rtol=5e-6, atol=1e-9)
+        assert torch.equal(amp, al.max(dim=1)[0]) and torch.equal(ami, al.argmax(dim=1))
+        np.testing.assert_allclose(mu_var.cpu().numpy(), [g[f"{tag}/mu"][t], g[f"{tag}/var"][t]], rtol=3e-6)
+        # the weights are steep functions of (p - mu) / sigma: compare with the formula on the device's own state, and with the
+        # reference within the amplification of the 1e-6 state round-off
+        np.testing.assert_allclose(ma.cpu().numpy(), g[f"{tag}/mask_a"][t], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(mk.cpu().numpy(), g[f"{tag}/mask_p"][t], rtol=2e-4, atol=1e-6)
+        d = torch.clamp(amp - mu_a[0], max=0.0)
+        np.testing.assert_allclose(ma.cpu().numpy(), torch.exp(-(d * d) / (2 * mu_a[1] / ns ** 2)).cpu().numpy(), rtol=3e-6, atol=1e-7)
+    assert int(inited) == 1

@@ -32,17 +32,21 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-from oracle.gen_golden import TRACE_FREE   # noqa: E402
+from oracle.gen_golden import TRACE_FREE, TRACE_SOFT   # noqa: E402
 
 
-@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX), ("srfreematch_trace", TRACE_FREE)])
+@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX), ("srfreematch_trace", TRACE_FREE),
+                                     ("srsoftmatch_trace", TRACE_SOFT)])
 def test_sr_train_step_trace(golden, name, tr):
     g = golden(name)
-    fix = tr["algorithm"] in ("srfixmatch", "srfreematch")
+    fix = tr["algorithm"] in ("srfixmatch", "srfreematch", "srsoftmatch")
     free = tr["algorithm"] == "srfreematch"
+    soft = tr["algorithm"] == "srsoftmatch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
     extra = dict(ema_p=tr["ema_p"], use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"], ent_loss_ratio=tr["ent_loss_ratio"]) if free else {}
+    if soft:
+        extra = dict(ema_p=tr["ema_p"], n_sigma=tr["n_sigma"], dist_uniform=tr["dist_uniform"], dist_align=True, per_class=False)
     alg = get_algorithm(make_args(algorithm=tr["algorithm"], p_cutoff=tr["p_cutoff"], **extra), vit.vit_tiny_test)
     T = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
     alg.model.load_state_dict(T(synth.synth_params(V.param_shapes(cfg), seed)))
@@ -66,7 +70,11 @@ def test_sr_train_step_trace(golden, name, tr):
         assert alg.trace["K"] == K
         masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
         want = g[f"{p}/masks"]
-        flips += int((masks != want).sum())
+        if soft:      # the mask is a continuous weight (SoftMatch): compare values; bf16 logits move max-probs by ~1e-2 relative
+            np.testing.assert_allclose(masks, want, rtol=0.0, atol=6e-2)
+            assert float(log["train/util_ratio"]) == pytest.approx(float(g[f"{p}/log/util_ratio"]), abs=4e-2)
+        else:
+            flips += int((masks != want).sum())
         for k_ in ("sup_loss", "unsup_loss", "total_loss"):
             assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
         # AdamW moves every weight by ~lr per step whatever |g| is, so bf16-operand gradient noise turns into a
@@ -75,6 +83,11 @@ def test_sr_train_step_trace(golden, name, tr):
         for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
             assert rel(out["feat"][k_].cpu(), g[f"{p}/feat/{k_}"]) < ftol, (p, k_)
         assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+        if soft:
+            sm, da = alg.hooks_dict["MaskingHook"], alg.hooks_dict["DistAlignHook"]
+            assert float(sm.prob_max_mu_t) == pytest.approx(float(g[f"{p}/mu"]), rel=2e-2)
+            assert float(sm.prob_max_var_t) == pytest.approx(float(g[f"{p}/var"]), rel=5e-2)
+            assert rel(da.p_model.cpu(), g[f"{p}/p_model"]) < 2e-2 and rel(da.p_target.cpu(), g[f"{p}/p_target"]) < 2e-2
         if free:
             h = alg.hooks_dict["MaskingHook"]
             assert float(h.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=2e-2)

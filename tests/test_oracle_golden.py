@@ -291,3 +291,56 @@ def test_srfreematch_trace(golden):
         np.testing.assert_allclose(orc.fm.label_hist.numpy(), g[f"{p}/label_hist"], rtol=1e-6)
         for nme, _ in V.param_shapes(cfg):
             check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 2e-3, 2e-6, f"{p} grad {nme}")
+
+
+@pytest.mark.parametrize("tag", ["c10_uniform", "c100_model", "c10_model_s3"])
+def test_softmatch_and_distalign_hooks(golden, tag):
+    """DistAlignEMAHook (dist_align.py:26-56) and SoftMatchWeightingHook (srsoftmatch/utils.py:32-76) sequences of the reference:
+    EMA state bit for bit, aligned probabilities / weights to fp32 round-off."""
+    g = golden("softmatch_hook")
+    C, Bu, Bl, steps, ns, model_t, seed = [int(v) for v in g[f"{tag}/meta"]]
+    m = float(g[f"{tag}/momentum"])
+    da, sm = H.DistAlignState(C, m, "model" if model_t else "uniform"), H.SoftMatchState(C, ns, m)
+    for t in range(steps):
+        pu, plb = torch.softmax(T(g[f"{tag}/logits_ulb"][t]), dim=-1), torch.softmax(T(g[f"{tag}/logits_lb"][t]), dim=-1)
+        al = da.dist_align(pu, plb)
+        ma = sm.masking(al)
+        mp_ = sm.masking(pu)
+        assert np.array_equal(da.p_model.numpy().view(np.uint32), g[f"{tag}/p_model"][t].view(np.uint32)), (tag, t)
+        assert np.array_equal(da.p_target.numpy().view(np.uint32), g[f"{tag}/p_target"][t].view(np.uint32)), (tag, t)
+        assert np.float32(sm.mu).view(np.uint32) == g[f"{tag}/mu"][t].view(np.uint32), (tag, t)
+        assert np.float32(sm.var).view(np.uint32) == g[f"{tag}/var"][t].view(np.uint32), (tag, t)
+        assert np.array_equal(al.numpy(), g[f"{tag}/aligned"][t]) and np.array_equal(ma.numpy(), g[f"{tag}/mask_a"][t])
+        assert np.array_equal(mp_.numpy(), g[f"{tag}/mask_p"][t])
+    allm = np.concatenate([g[f"{tag}/mask_a"].ravel(), g[f"{tag}/mask_p"].ravel()])
+    assert allm.min() >= 0.0 and allm.max() <= 1.0 and 0.05 < allm.mean() < 0.999 and (allm < 0.9).any()     # the weight is exercised
+
+
+def test_srsoftmatch_trace(golden):
+    from oracle.gen_golden import TRACE_SOFT as tr
+    from oracle.srsoftmatch_ref import SRSoftMatchOracle
+    g = golden("srsoftmatch_trace")
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+    Fd = cfg.embed_dim
+    orc = SRSoftMatchOracle(
+        cfg, TP(synth.synth_params(V.param_shapes(cfg), seed)), TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
+        TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)), num_train_iter=tr["num_train_iter"],
+        start_timing=tr["start_timing"], N_k=tr["N_k"], ulb_dest_len=tr["ulb_dest_len"], num_warmup_iter=tr["num_warmup_iter"],
+        ema_p=tr["ema_p"], n_sigma=tr["n_sigma"], dist_uniform=tr["dist_uniform"])
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        orc.it = it
+        K = int(g[f"{p}/K"])
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        dps = [T(synth.synth_droppath(seed + 1000 * (n + 1) + k, V.drop_path_probs(cfg), Bl + 2 * Bu)) for k in range(K + 1)]
+        t = orc.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]), dps)
+        assert t["K"] == K
+        np.testing.assert_allclose(np.stack([q["mask"].numpy() for q in t["passes"]]), g[f"{p}/masks"], rtol=1e-5, atol=1e-7)
+        for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+            assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=2e-5, abs=2e-6), (p, k_)
+        assert float(orc.sm.mu) == pytest.approx(float(g[f"{p}/mu"]), rel=1e-6) and float(orc.sm.var) == pytest.approx(float(g[f"{p}/var"]), rel=1e-6)
+        np.testing.assert_allclose(orc.da.p_model.numpy(), g[f"{p}/p_model"], rtol=1e-6)
+        np.testing.assert_allclose(orc.da.p_target.numpy(), g[f"{p}/p_target"], rtol=1e-6)
+        for nme, _ in V.param_shapes(cfg):
+            check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 2e-3, 2e-6, f"{p} grad {nme}")
