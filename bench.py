@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--bu", type=int, default=8, help="per-GPU unlabeled batch (reference yaml: 8, uratio 1)")
     ap.add_argument("--bl", type=int, default=0, help="per-GPU labelled batch (default = --bu, uratio 1)")
     ap.add_argument("--regime", choices=["sr", "pre"], default="sr", help="sr: it > start_timing (K=8); pre: K=0")
+    ap.add_argument("--img", type=int, choices=[32, 224], default=32,
+                    help="32: ViT-S/2 on 32x32 (north-star config); 224: ViT-S/16 on 224x224 (vit_small_patch16_224, 197 tokens)")
     ap.add_argument("--infer-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -102,12 +104,12 @@ def main():
     from semireward_amd.utils import synth
 
     args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **NS)
-    alg = get_algorithm(args, vit.vit_small_patch2_32)
+    alg = get_algorithm(args, vit.vit_small_patch2_32 if a.img == 32 else vit.vit_small_patch16_224)
     P = synth.synth_params(alg.model.names_shapes, 0)
     alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
     alg.model.seed = 1234 + rank
-    b = synth.synth_batch(100 + rank, bl, a.bu, 32, 100, 50000)            # each rank: its own shard of the unlabeled stream
+    b = synth.synth_batch(100 + rank, bl, a.bu, a.img, 100, 50000)         # each rank: its own shard of the unlabeled stream
     batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
     alg.it = START_IT if a.regime == "sr" else 1000
     alg.optimizer.sched_step = alg.it
@@ -154,8 +156,9 @@ def main():
                "unit": "unlabeled images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, steady SR regime"
-                                      if a.regime == "sr" else "SRFlexMatch ViT-S/2@32, pre-start_timing regime",
+               "config": {"workload": ("SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, " if a.img == 32 else
+                                       "SRFlexMatch ViT-S/16@224 (vit_small_patch16_224) 224x224x3 batches, 100 classes, ") +
+                                      ("steady SR regime" if a.regime == "sr" else "pre-start_timing regime"),
                           "per_gpu_batch": {"lb": bl, "ulb_w": a.bu, "ulb_s": a.bu}, "K_passes": K,
                           "forward_image_passes_per_step": (1 + K) * (bl + 2 * a.bu), "backward_images_per_step": bl + a.bu,
                           "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
@@ -169,7 +172,7 @@ def main():
             intensity = fl / nbytes
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")          # PMC pass of this same command (tools/pmc.sh)
-            if os.path.exists(tf) and a.bu == 8 and a.regime == "sr" and world == 1:
+            if os.path.exists(tf) and a.bu == 8 and a.regime == "sr" and world == 1 and a.img == 32:
                 traffic = (json.load(open(tf)).get(name) or {}).get("hbm_bytes_per_launch")
             if intensity < ridge:
                 ach = nbytes / (ms * 1e-3) / 1e9
@@ -184,7 +187,7 @@ def main():
                          "measured_over": "%d instrumented steps run right after the timed region (same process, same inputs)" % prof_steps,
                          "all_gemm_kernels": {"tflops": tfl / (tms * 1e-3) / 1e12, "launches": tn, "ms_per_step": tms / prof_steps}})
             out["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.img == 32:
             out["cpu_baseline"] = cpu_baseline(bl, a.bu)
         print(json.dumps(out), flush=True)
     if world > 1:

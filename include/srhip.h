@@ -95,6 +95,17 @@ int srhip_patch_embed_fwd(const float* img, const int* img_index, const float* W
 int srhip_patch_embed_bwd(const float* dx, const float* img, const int* img_index, float* dWp, float* dbp, float* dcls,
                           float* dpos, int B, int C, int HW, int ps, int D, void* stream);
 
+/* Large-patch PatchEmbed (C * ps * ps > 64, e.g. ViT-S/16 at 224 x 224, vit.py:358-371): the conv of vit.py:39-44 as a GEMM.
+ *   patch_im2col : col[b * Np + p][(c,i,j)] = img[img_index[b]][c][py*ps+i][px*ps+j] as bf16 (ps even); then
+ *                  srhip_gemm_nt(EPI_F32): tok[B*Np, D] = col . Wp^T with Wp = patch_embed.proj.weight viewed [D, C*ps*ps];
+ *   patch_assemble: x[b,0,:] = cls + pos[0], x[b,1+p,:] = tok[b*Np+p,:] + bp + pos[1+p]                       (vit.py:277-280)
+ *   patch_grad_operands (backward): dpos += sum_b dx[b,:,:], dcls += sum_b dx[b,0,:], and the patch-token rows of dx as bf16
+ *                  [B*Np, D] -- the A operand of srhip_gemm_tn_grouped_f32 with B = col: dWp += dx_tok^T col, dbp += colsum dx_tok. */
+int srhip_patch_im2col(const float* img, const int* img_index, void* out, int B, int C, int HW, int ps, void* stream);
+int srhip_patch_assemble(const float* tok, const float* bp, const float* cls, const float* pos, float* x, int B, int Np, int D,
+                         void* stream);
+int srhip_patch_grad_operands(const float* dx, void* dx_tok_bf16, float* dpos, float* dcls, int B, int Np, int D, void* stream);
+
 /* Final norm on the cls token, global_pool='token', classifier head (vit.py:282, :296-305) (K7).
  * feat fp32 [B,D], logits fp32 [B,C]; xhat [B,D] / rstd [B] saved for the backward when non-NULL. */
 int srhip_cls_head_fwd(const float* x, const float* gamma, const float* beta, float eps, const float* Wh, const float* bh,

@@ -188,9 +188,9 @@ def inject_droppath(model, dp):
                 assert np.all(dp[i, j] == 1.0), "Identity drop path (p=0) needs scale 1"
 
 
-def gen_vit():
+def gen_vit(cases=None, fname="vit.npz"):
     out = {}
-    for tag, cfgd, C, B, seed in [("tiny", V.VIT_TINY_TEST, 10, 6, 51), ("small_p2_32", V.VIT_SMALL_P2_32, 100, 24, 52)]:
+    for tag, cfgd, C, B, seed in cases or [("tiny", V.VIT_TINY_TEST, 10, 6, 51), ("small_p2_32", V.VIT_SMALL_P2_32, 100, 24, 52)]:
         cfg = V.VitCfg(num_classes=C, **cfgd)
         params = synth.synth_params(V.param_shapes(cfg), seed)
         rng = np.random.Generator(np.random.PCG64(seed + 1))
@@ -212,7 +212,12 @@ def gen_vit():
         for n, p in model.named_parameters():
             flat(f"{tag}/grad/{n}", samp(p.grad.numpy(), 256), out)
         out[f"{tag}/meta"] = np.array([C, B, seed], dtype=np.int64)
-    np.savez_compressed(os.path.join(OUT, "vit.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def gen_vit_p16():
+    """ViT-S/16 at 224x224 (vit.py:358-371 vit_small_patch16_224): 197 tokens, patch embedding with K = 768."""
+    gen_vit([("small_p16_224", V.VIT_SMALL_P16_224, 100, 6, 53)], "vit_p16.npz")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -596,7 +601,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
-            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook)
+            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

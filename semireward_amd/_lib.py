@@ -28,6 +28,9 @@ SIGNATURES = {
     "srhip_mlp_fused": (I, [P, P, P, F, P, P, P, P, P, I, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_patch_im2col": (I, [P, P, P, I, I, I, I, P]),
+    "srhip_patch_assemble": (I, [P, P, P, P, P, I, I, I, P]),
+    "srhip_patch_grad_operands": (I, [P, P, P, P, I, I, I, P]),
     "srhip_cls_head_fwd": (I, [P, P, P, F, P, P, P, P, P, P, I, I, I, I, P]),
     "srhip_cls_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "srhip_cast_scale_rows": (I, [P, P, I, P, L, I, P]),

@@ -377,6 +377,43 @@ __global__ void droppath_fill_kernel(float* __restrict__ out, const float* __res
 }  // namespace
 
 // =============================================================================================
+// ---------------------------------------------------------------------------------------------
+// Large-patch PatchEmbed (C * ps^2 > 64, e.g. ViT-S/16 at 224x224: K = 768): the conv with kernel = stride = ps is a GEMM of
+// the unfolded patches with the [D, C*ps*ps] filter (vit.py:39-44).  im2col -> srhip_gemm_nt -> assemble (+ bias, pos, cls).
+// out[b * Np + p][(c, i, j)] = img[idx[b]][c][py * ps + i][px * ps + j]  (bf16), (c, i, j) minor order == Conv2d weight.flatten(1)
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, const int* __restrict__ img_index,
+                                                          bf16_t* __restrict__ out, int C, int HW, int ps) {
+  const int gw = HW / ps, Np = gw * gw, K = C * ps * ps;
+  const int p = blockIdx.x, b = blockIdx.y, py = p / gw, px = p % gw;
+  const int bi = img_index ? img_index[b] : b;
+  const float* im = img + (size_t)bi * C * HW * HW;
+  bf16_t* o = out + ((size_t)b * Np + p) * K;
+  for (int e = 2 * threadIdx.x; e < K; e += 512) {            // ps is even: the pair (j, j+1) stays inside one image row
+    const int c = e / (ps * ps), i = (e / ps) % ps, j = e % ps;
+    const float2 v = *reinterpret_cast<const float2*>(im + ((size_t)c * HW + py * ps + i) * HW + px * ps + j);
+    *reinterpret_cast<uint32_t*>(o + e) = pack_bf2(v.x, v.y);
+  }
+}
+
+// x[b, 0, :] = cls + pos[0];  x[b, 1 + p, :] = tok[b * Np + p, :] + bias + pos[1 + p]      (vit.py:277-280)
+__global__ void patch_assemble_kernel(const float* __restrict__ tok, const float* __restrict__ bp, const float* __restrict__ cls,
+                                      const float* __restrict__ pos, float* __restrict__ x, int Np, int D) {
+  const int t = blockIdx.x, b = blockIdx.y, N = Np + 1;
+  float* xr = x + ((size_t)b * N + t) * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float v = (t == 0) ? cls[d] : tok[((size_t)b * Np + t - 1) * D + d] + bp[d];
+    xr[d] = v + pos[(size_t)t * D + d];
+  }
+}
+
+// backward operand: the patch-token rows of dx (fp32 [B, N, D], cls row skipped) as bf16 [B * Np, D]
+__global__ void patch_gather_grad_kernel(const float* __restrict__ dx, bf16_t* __restrict__ out, int Np, int D) {
+  const int p = blockIdx.x, b = blockIdx.y;
+  const float* src = dx + ((size_t)b * (Np + 1) + 1 + p) * D;
+  bf16_t* o = out + ((size_t)b * Np + p) * D;
+  for (int d = 2 * threadIdx.x; d < D; d += 2 * blockDim.x) *reinterpret_cast<uint32_t*>(o + d) = pack_bf2(src[d], src[d + 1]);
+}
+
 extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* out,
                                    float* mean, float* rstd, int M, int D, void* stream) {
   if (M <= 0 || (D != 128 && D != 384 && D != 768) || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
@@ -491,6 +528,33 @@ extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, in
 extern "C" int srhip_transpose_batched(const srhip_transpose_desc* desc_dev, int n, int total_tiles, void* stream) {
   if (!desc_dev || n <= 0 || total_tiles <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_patch_im2col(const float* img, const int* img_index, void* out, int B, int C, int HW, int ps, void* stream) {
+  if (!img || !out || B <= 0 || C <= 0 || ps <= 0 || (ps & 1) || HW % ps) return SR_EINVAL;
+  const int gw = HW / ps;
+  hipLaunchKernelGGL(patch_im2col_kernel, dim3(gw * gw, B), dim3(256), 0, (hipStream_t)stream, img, img_index, (bf16_t*)out, C, HW, ps);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_patch_assemble(const float* tok, const float* bp, const float* cls, const float* pos, float* x, int B, int Np,
+                                    int D, void* stream) {
+  if (!tok || !bp || !cls || !pos || !x || B <= 0 || Np <= 0 || D <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(patch_assemble_kernel, dim3(Np + 1, B), dim3(D < 256 ? 64 : 256), 0, (hipStream_t)stream, tok, bp, cls, pos, x, Np, D);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_patch_grad_operands(const float* dx, void* dx_tok_bf16, float* dpos, float* dcls, int B, int Np, int D,
+                                         void* stream) {
+  if (!dx || !dx_tok_bf16 || !dpos || !dcls || B <= 0 || Np <= 0 || D <= 0 || (D & 1) || D > 1024) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(patch_embed_bwd_pos_kernel, dim3(Np + 1), dim3(D), 0, s, dx, dpos, dcls, B, Np + 1, D);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(patch_gather_grad_kernel, dim3(Np, B), dim3(D < 512 ? 64 : 256), 0, s, dx, (bf16_t*)dx_tok_bf16, Np, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -216,8 +216,17 @@ class VisionTransformer:
         hbuf = None if (fused_mlp or save) else self._buf(tag + "h", (M, Hd), bf16)
         wb = self.flat_bf16
         P = self.p
-        ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),
-                            P("pos_embed"), x, B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+        Kp = cfg.in_chans * cfg.patch_size ** 2
+        if Kp <= 64:                                # CIFAR-style 2x2 / 4x4 patches: direct fp32 kernel
+            ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),
+                                P("pos_embed"), x, B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+        else:                                       # ViT-S/16 at 224: unfold (bf16) -> GEMM with the [D, 768] filter -> + bias / pos / cls
+            Np = N - 1
+            col = self._buf(tag + "col", (B * Np, Kp), bf16)
+            tok = self._buf(tag + "tok", (B * Np, D), f32)
+            ops.patch_im2col(img, img_index, col, B, cfg.in_chans, cfg.img_size, cfg.patch_size)
+            ops.gemm_nt(ops.EPI_F32, col, P("patch_embed.proj.weight", wb), tok, B * Np, D, Kp)
+            ops.patch_assemble(tok, P("patch_embed.proj.bias"), P("cls_token"), P("pos_embed"), x, B, Np, D)
         scale = 64 ** -0.5
         for i in range(cfg.depth):
             b = "blocks.%d." % i
@@ -336,8 +345,23 @@ class VisionTransformer:
         # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
         desc, npb, ntiles, flops, nbytes = T["desc"]
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
-        ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
-                            G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+        Kp = cfg.in_chans * cfg.patch_size ** 2
+        if Kp <= 64:
+            ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
+                                G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+        else:                                       # dWp += dx_tok^T col, dbp += colsum dx_tok (TN grouped GEMM, one problem); dpos, dcls
+            Np = N - 1
+            key = ("pebwd", B)
+            if key not in self._ws:
+                col = torch.empty(B * Np, Kp, dtype=bf16, device=self.device)
+                dxt = torch.empty(B * Np, D, dtype=bf16, device=self.device)
+                gw = self.view("patch_embed.proj.weight", self.grad).view(D, Kp)
+                desc = ops.make_group_tn_desc([(dxt, col, gw, self.view("patch_embed.proj.bias", self.grad), D, Kp, B * Np)], self.device)
+                self._ws[key] = (col, dxt, desc)
+            col, dxt, desc = self._ws[key]
+            ops.patch_im2col(ctx.img, ctx.img_index, col, B, cfg.in_chans, cfg.img_size, cfg.patch_size)
+            ops.patch_grad_operands(dx, dxt, G("pos_embed"), G("cls_token"), B, Np, D)
+            ops.gemm_tn_grouped_f32(desc[0], desc[1], desc[2], alpha=1.0, beta=1.0, flops=desc[3], nbytes=desc[4])
 
 
 # ---- builders with the reference's names (vit.py:323-408); pretrained checkpoints need network -> ignored ------------
@@ -349,6 +373,11 @@ def _build(num_classes, kw, **cfg):
 
 def vit_tiny_test(num_classes=10, **kw):
     return _build(num_classes, kw, img_size=8, patch_size=2, embed_dim=128, depth=2, num_heads=2, drop_path_rate=0.2)
+
+
+def vit_small_patch16_224(num_classes=1000, **kw):
+    """vit.py:358-371: ViT-S/16, 197 tokens."""
+    return _build(num_classes, kw, img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)
 
 
 def vit_small_patch2_32(num_classes=1000, **kw):

@@ -215,6 +215,18 @@ def patch_embed_bwd(dx, img, img_index, dWp, dbp, dcls, dpos, B, C, HW, ps, D):
     _call("srhip_patch_embed_bwd", _p(dx), _p(img), _p(img_index), _p(dWp), _p(dbp), _p(dcls), _p(dpos), B, C, HW, ps, D, _s())
 
 
+def patch_im2col(img, img_index, out, B, C, HW, ps):
+    _call("srhip_patch_im2col", _p(img), _p(img_index), _p(out), B, C, HW, ps, _s())
+
+
+def patch_assemble(tok, bp, cls, pos, x, B, Np, D):
+    _call("srhip_patch_assemble", _p(tok), _p(bp), _p(cls), _p(pos), _p(x), B, Np, D, _s())
+
+
+def patch_grad_operands(dx, dx_tok, dpos, dcls, B, Np, D):
+    _call("srhip_patch_grad_operands", _p(dx), _p(dx_tok), _p(dpos), _p(dcls), B, Np, D, _s())
+
+
 def cls_head_fwd(x, gamma, beta, eps, Wh, bh, feat, logits, xhat, rstd, B, N, D, C):
     _call("srhip_cls_head_fwd", _p(x), _p(gamma), _p(beta), eps, _p(Wh), _p(bh), _p(feat), _p(logits), _p(xhat), _p(rstd),
           B, N, D, C, _s())

@@ -25,12 +25,14 @@ def rel(a, b):
 def build(tag):
     if tag == "tiny":
         return vit.vit_tiny_test(num_classes=10, device=DEV), V.VitCfg(num_classes=10, **V.VIT_TINY_TEST)
+    if tag == "small_p16_224":
+        return vit.vit_small_patch16_224(num_classes=100, device=DEV), V.VitCfg(num_classes=100, **V.VIT_SMALL_P16_224)
     return vit.vit_small_patch2_32(num_classes=100, device=DEV), V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "small_p2_32"])
+@pytest.mark.parametrize("tag", ["tiny", "small_p2_32", "small_p16_224"])
 def test_vit_matches_reference_golden(golden, tag):
-    g = golden("vit")
+    g = golden("vit_p16" if tag == "small_p16_224" else "vit")
     C, B, seed = [int(v) for v in g[f"{tag}/meta"]]
     model, cfg = build(tag)
     assert [n for n, _ in model.names_shapes] == [n for n, _ in V.param_shapes(cfg)]
