@@ -15,6 +15,7 @@ from inspect import signature
 
 import torch
 
+from .. import ops
 from ..distributed import DataParallel
 from ..optim import FusedAdamW
 from .criterions import CELoss, ConsistencyLoss
@@ -187,6 +188,63 @@ class AlgorithmBase:
                 self.it += 1
             self.call_hook("after_train_epoch")
         self.call_hook("after_run")
+
+    # ---- evaluation (algorithmbase.py:377-457) ----------------------------------------------------------------
+    @staticmethod
+    def classification_metrics(y_true, y_pred):
+        """accuracy / balanced accuracy / macro precision, recall, F1 with the conventions of the sklearn calls the reference makes
+        (algorithmbase.py:419-423): macro averages over the labels present in y_true or y_pred, 0 for an undefined ratio; balanced
+        accuracy over the classes present in y_true."""
+        import numpy as np
+        y_true, y_pred = np.asarray(y_true, np.int64), np.asarray(y_pred, np.int64)
+        labels = np.union1d(y_true, y_pred)
+        idx = {int(c): i for i, c in enumerate(labels)}
+        cm = np.zeros((labels.size, labels.size), dtype=np.int64)
+        np.add.at(cm, (np.vectorize(idx.get)(y_true), np.vectorize(idx.get)(y_pred)), 1)
+        tp, sup, prd = np.diag(cm).astype(np.float64), cm.sum(1).astype(np.float64), cm.sum(0).astype(np.float64)
+        rec = np.divide(tp, sup, out=np.zeros_like(tp), where=sup > 0)
+        prec = np.divide(tp, prd, out=np.zeros_like(tp), where=prd > 0)
+        f1 = np.divide(2 * prec * rec, prec + rec, out=np.zeros_like(tp), where=(prec + rec) > 0)
+        return {"top-1-acc": float(tp.sum() / max(y_true.size, 1)), "balanced_acc": float(rec[sup > 0].mean()),
+                "precision": float(prec.mean()), "recall": float(rec.mean()), "F1": float(f1.mean())}
+
+    def evaluate(self, eval_dest="eval", out_key="logits", return_logits=False, loader=None):
+        """Inference over ``loader_dict[eval_dest]`` (or ``loader``: an iterable of {'x_lb', 'y_lb'}) with the EMA weights
+        (``ema.apply_shadow`` of the reference == evaluating ``ema_model`` here), same result keys.  The forward runs on the
+        inference kernels of the training path; predictions stay on the device until ONE copy at the end (the reference
+        synchronises three times per batch)."""
+        import numpy as np
+        assert out_key == "logits"
+        net = self.ema_model
+        if net is not self.model:
+            net.refresh_operands()                    # bf16 operand copy of the EMA block
+        loader = loader if loader is not None else self.loader_dict[eval_dest]
+        C = self.num_classes
+        logits_all, y_all = [], []
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
+        total = 0
+        with ops.stream_scope():
+            for data in loader:
+                x = data["x_lb"].to(self.device, non_blocking=True).contiguous()
+                y = data["y_lb"].to(self.device, non_blocking=True).contiguous()
+                B = int(y.shape[0])
+                lg, _, _ = net.forward_features(x, None, None, save=False)
+                w = (y >= 0).to(torch.float32)                               # F.cross_entropy(ignore_index=-1): mean over the kept rows
+                loss = torch.empty(1, dtype=torch.float32, device=self.device)
+                ops.masked_ce(lg, y.clamp_min(0), w, None, 1.0, loss, torch.empty(B, C, dtype=torch.float32, device=self.device), B, C)
+                loss_sum += loss * (B * B / w.sum().clamp_min(1.0))          # masked_ce averages over B rows -> mean over kept, times B
+                logits_all.append(lg)
+                y_all.append(y)
+                total += B
+        logits = torch.cat(logits_all)
+        y_true = torch.cat(y_all).cpu().numpy()
+        y_pred = logits.argmax(dim=-1).cpu().numpy()
+        m = self.classification_metrics(y_true, y_pred)
+        out = {eval_dest + "/loss": float(loss_sum) / max(total, 1)}
+        out.update({eval_dest + "/" + k: v for k, v in m.items()})
+        if return_logits:
+            out[eval_dest + "/logits"] = logits.cpu().numpy()
+        return out
 
     # ---- checkpoints (algorithmbase.py:459-547) ----------------------------------------------------------
     def get_save_dict(self):

@@ -122,3 +122,19 @@ def test_deferred_scalar_and_sr_decay():
     for it, k in [(20001, 11), (20480, 11), (22755, 10), (25600, 9), (25601, 8), (204799, 8)]:
         A.it = it
         assert AlgorithmBase.sr_decay(A) == k
+
+
+def test_classification_metrics_match_sklearn():
+    """evaluate() host metrics (algorithmbase.py:419-423) against the sklearn calls the reference makes."""
+    from sklearn.metrics import accuracy_score, balanced_accuracy_score, f1_score, precision_score, recall_score
+    from semireward_amd.core.algorithmbase import AlgorithmBase
+    rng = np.random.Generator(np.random.PCG64(5))
+    for C, n in [(10, 200), (100, 300), (3, 7)]:
+        yt, yp = rng.integers(0, C, n), rng.integers(0, C, n)
+        yp[: n // 3] = yt[: n // 3]
+        m = AlgorithmBase.classification_metrics(yt, yp)
+        assert m["top-1-acc"] == pytest.approx(accuracy_score(yt, yp))
+        assert m["balanced_acc"] == pytest.approx(balanced_accuracy_score(yt, yp))
+        assert m["precision"] == pytest.approx(precision_score(yt, yp, average="macro", zero_division=0))
+        assert m["recall"] == pytest.approx(recall_score(yt, yp, average="macro", zero_division=0))
+        assert m["F1"] == pytest.approx(f1_score(yt, yp, average="macro", zero_division=0))

@@ -176,3 +176,37 @@ def test_srpseudolabel_trace(golden):
     # the fixture puts the cut-off (0.16) in the bulk of a random-init model's max-prob distribution, so a few rows sit on
     # it; identical masks on identical probabilities are covered bit-exactly by test_gpu_kernels (golden probs)
     assert flips <= 0.03 * total, (flips, total)
+
+
+def test_evaluate_matches_oracle_forward():
+    """AlgorithmBase.evaluate (algorithmbase.py:377-457): eval-mode forward of the EMA weights over a loader, CE loss with
+    ignore_index = -1, sklearn-convention metrics -- against the CPU oracle's forward on the same parameters."""
+    import torch.nn.functional as F
+    cfg = V.VitCfg(num_classes=10, **V.VIT_TINY_TEST)
+    alg = get_algorithm(make_args(num_train_iter=6, start_timing=2, N_k=2, num_warmup_iter=0), vit.vit_tiny_test)
+    P = synth.synth_params(V.param_shapes(cfg), 7)
+    alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    rng = np.random.Generator(np.random.PCG64(11))
+    batches, xs, ys = [], [], []
+    for n in (5, 8, 3):
+        x = rng.standard_normal((n, 3, cfg.img_size, cfg.img_size)).astype(np.float32)
+        y = rng.integers(0, 10, size=(n,), dtype=np.int64)
+        y[0] = -1 if n == 8 else y[0]                                        # one ignored row
+        batches.append({"x_lb": torch.from_numpy(x), "y_lb": torch.from_numpy(y)})
+        xs.append(x); ys.append(y)
+    out = alg.evaluate("eval", loader=batches, return_logits=True)
+    Pt = {k: torch.from_numpy(v) for k, v in P.items()}
+    ref = V.vit_forward(Pt, torch.from_numpy(np.concatenate(xs)), cfg)["logits"]
+    y = torch.from_numpy(np.concatenate(ys))
+    assert rel(out["eval/logits"], ref.numpy()) < 2e-2
+    tot, off = 0.0, 0
+    for b in ys:                                                             # reference: sum_b CE_mean(batch b) * len(b) / N
+        tot += float(F.cross_entropy(ref[off:off + len(b)], y[off:off + len(b)], ignore_index=-1)) * len(b); off += len(b)
+    assert out["eval/loss"] == pytest.approx(tot / off, rel=2e-2)
+    yp = ref.argmax(-1).numpy()
+    if (out["eval/logits"].argmax(-1) == yp).all():
+        from semireward_amd.core.algorithmbase import AlgorithmBase
+        keep = np.ones_like(yp, dtype=bool)
+        m = AlgorithmBase.classification_metrics(np.concatenate(ys), yp)
+        assert out["eval/top-1-acc"] == pytest.approx(m["top-1-acc"]) and out["eval/F1"] == pytest.approx(m["F1"])
+    assert set(out) == {"eval/loss", "eval/top-1-acc", "eval/balanced_acc", "eval/precision", "eval/recall", "eval/F1", "eval/logits"}
