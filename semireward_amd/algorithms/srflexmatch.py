@@ -109,21 +109,28 @@ class SRConsistencyBase(AlgorithmBase):
         # The gradient-carrying rows (16 of 216 images at the reference batch) run on a SECOND HIP stream: their launches are
         # 100-400 workgroups of latency-bound work (14-28 us each, 1.6 ms per step back to back) that fit beside the tails of
         # the 200-image inference launches.  Both forwards only read the parameters; they write disjoint workspaces.
+        # Host order matters: the 200-image inference launches are enqueued FIRST (6 ms of GPU work in ~60 launches), the ~90
+        # small launches of the gradient rows (1.3 ms of host enqueue time) after them on the other stream, gated only by an
+        # event recorded before either -- enqueued the other way round the main stream sat idle while the host was still feeding
+        # the side stream (rocprof timeline: a 1.28 ms hole).
         main = torch.cuda.current_stream()
         side = self._side_stream if self.overlap_grad_rows else None
         dp_grad = sel(pl.grad_cols)
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side), ops.stream_scope():
-                lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
         ni = pl.inf_cols.numel()
         step = self.infer_chunk if self.infer_chunk > 0 else max(ni, 1)
-        for s in range(0, ni, step):
-            cols = pl.inf_cols[s:s + step]
-            lg, ft, _ = m.forward_features(imgs, pl.inf_img[s:s + step].contiguous(), sel(cols), save=False)
+        chunks = [(pl.inf_cols[s:s + step], pl.inf_img[s:s + step].contiguous()) for s in range(0, ni, step)]
+        dps = [sel(cols) for cols, _ in chunks]
+        if side is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)                       # parameters, images, DropPath draws are final here
+        for (cols, imgi), dpi in zip(chunks, dps):
+            lg, ft, _ = m.forward_features(imgs, imgi, dpi, save=False)
             logits.index_copy_(0, cols, lg)
             feats.index_copy_(0, cols, ft)
         if side is not None:
+            side.wait_event(ready)
+            with torch.cuda.stream(side), ops.stream_scope():
+                lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
             main.wait_stream(side)
             lg_g.record_stream(main)
             ft_g.record_stream(main)
