@@ -100,34 +100,102 @@ __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src,
   }
 }
 
+// ---- conflict-free LDS images for the forward kernel (PMC of the first layout: 47 % of the LDS-array cycles were bank conflicts,
+// and the two 8-byte V^T reads of an operand were fused into ds_read2_b64 = 8 cycles instead of 4 for one ds_read_b128) ----
+// K image: [key][64] with 128-B rows; the 16-B chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  A row covers half of the 64
+// banks (even rows 0-31, odd rows 32-63), so the 16 lanes of every ds_read_b128 service group (MI355X_MICROARCH.md, LDS) hit 16
+// distinct (row parity, chunk) pairs -- checked for all four groups and for both halves (chunk g and g + 4) of an operand.
+template <int NP, int NT>
+__device__ __forceinline__ void stage_rows_swz(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
+  constexpr int IT = (NP * 8 + NT - 1) / NT;
+  u32x4_t v[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * NT, row = c >> 3, slot = c & 7;
+    v[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < NP * 8 && row < N) v[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)row * ld + slot * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * NT, row = c >> 3, slot = c & 7;
+    if (c < NP * 8) *reinterpret_cast<u32x4_t*>(dst + row * HD + ((slot ^ ((row >> 1) & 7)) << 3)) = v[i];
+  }
+}
+
+// V^T image: dst[d][pos(key)], pitch TP.  Inside every group of 32 keys the order is permuted so that the 8 k-slots an MFMA lane
+// group g needs (keys 4g..4g+3 of the even 16-key tile, then of the odd one -- exactly the registers P comes out in) are ONE
+// 16-B chunk:  pos = 32 u + 8 ((kk & 15) >> 2) + 4 (kk >> 4) + (kk & 3), kk = key - 32 u;  chunk index ^= PI[(d >> 2) & 3] as in
+// gemm.hip (rows d and d + 4 share banks when TP / 2 is 16 or 48 mod 64).
+constexpr int vt_pitch(int NP) { return ((NP / 2) % 64 == 16 || (NP / 2) % 64 == 48) ? NP : NP + 32; }
+__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+template <int NP, int NT>
+__device__ __forceinline__ void stage_transposed_perm(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
+  constexpr int TP = vt_pitch(NP), PAIRS = NP / 2, IT = (PAIRS * 8 + NT - 1) / NT;
+  u32x4_t va[IT], vb[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * NT, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
+    va[i] = u32x4_t{0u, 0u, 0u, 0u};
+    vb[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < PAIRS * 8) {
+      if (r0 < N) va[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)r0 * ld + slot * 8);
+      if (r0 + 1 < N) vb[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)(r0 + 1) * ld + slot * 8);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * NT, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
+    if (c < PAIRS * 8) {
+      const int kk = r0 & 31, chunk = (kk & 15) >> 2, within = ((kk >> 4) << 2) + (kk & 3);     // r0 even: the pair stays adjacent
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = (va[i][j] & 0xffffu) | (vb[i][j] << 16);
+        const uint32_t hi = (va[i][j] >> 16) | (vb[i][j] & 0xffff0000u);
+        const int d0 = slot * 8 + 2 * j, d1 = d0 + 1;
+        *reinterpret_cast<uint32_t*>(dst + d0 * TP + (r0 & ~31) + ((chunk ^ swz4(d0)) << 3) + within) = lo;
+        *reinterpret_cast<uint32_t*>(dst + d1 * TP + (r0 & ~31) + ((chunk ^ swz4(d1)) << 3) + within) = hi;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: grid = B*H workgroups of 512 threads (8 waves share the head's K / V^T: two workgroups per CU -> 4 waves per
 // SIMD, which is what hides the per-query-tile dependency chain ds_read -> MFMA -> max -> exp -> MFMA).
 // NKT = number of 16-key tiles (even), NP = 16*NKT.
 constexpr int FWD_NT = 512, FWD_NW = FWD_NT / 64;
+// dispatch_nkt instantiates NKT in {2, 8, 14, 18, 32} and picks the smallest >= ceil(N / 32) * 2: key tiles below the previous
+// size are always complete
+constexpr int nkt_lo(int nkt) { return nkt == 32 ? 18 : nkt == 18 ? 14 : nkt == 14 ? 8 : nkt == 8 ? 2 : 0; }
 template <int NKT>
 __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                       float* __restrict__ lse, int N, int H, float scale) {
-  constexpr int NP = NKT * 16, TP = NP + 8;
+  constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][KPAD]
-  bf16_t* Vt = Ks + NP * KPAD;                        // [64][TP]
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][64], chunk-swizzled (stage_rows_swz)
+  bf16_t* Vt = Ks + NP * HD;                          // [64][TP], key-permuted + chunk-swizzled (stage_transposed_perm)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const float sc2 = scale * LOG2E;
   const int nqt = (N + 15) >> 4;
+  const int kc = g ^ ((l15 >> 1) & 7);                // chunk of k-slots 8g.. of this lane's key row; the other half is kc ^ 4
+  const int kof0 = l15 * HD + (kc << 3), kof1 = l15 * HD + ((kc ^ 4) << 3);
+  const int vof = l15 * TP + ((g ^ swz4(l15)) << 3);
+  // N = 257 is 16 full query tiles + ONE row: the wave that owns tile 16 works 3 tiles, the others 2.  Rotating the tile -> wave
+  // map with the workgroup index spreads those third tiles over the SIMDs of a CU (two workgroups are resident per CU).
+  const int wv = (wave + blockIdx.x) & (FWD_NW - 1);
   // first query tile's operands are requested before the staging traffic so they arrive under it
   s16x8_t qn0, qn1;
   {
-    const int qc = min(wave * 16 + l15, N - 1);   // (wave < FWD_NW <= nqt for every supported N >= 113)
+    const int qc = min(wv * 16 + l15, N - 1);     // (wv < FWD_NW <= nqt for every supported N >= 113)
     const bf16_t* qp = base + (size_t)qc * ld + g * 8;
     qn0 = ld16(qp); qn1 = ld16(qp + 32);
   }
-  stage_rows<NP, FWD_NT>(Ks, base + D, ld, N, tid);
-  stage_transposed<NP, FWD_NT>(Vt, base + 2 * D, ld, N, tid);
+  stage_rows_swz<NP, FWD_NT>(Ks, base + D, ld, N, tid);
+  stage_transposed_perm<NP, FWD_NT>(Vt, base + 2 * D, ld, N, tid);
   __syncthreads();
-  for (int qt = wave; qt < nqt; qt += FWD_NW) {
+  for (int qt = wv; qt < nqt; qt += FWD_NW) {
     const int q = qt * 16 + l15;
     const s16x8_t q0 = qn0, q1 = qn1;
     if (qt + FWD_NW < nqt) {          // prefetch the next tile's Q fragments (hidden behind this tile's MFMAs)
@@ -141,11 +209,13 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-      const bf16_t* kp = Ks + (t * 16 + l15) * KPAD + g * 8;
       f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-      a = mfma16(ld16(kp), q0, a);
-      a = mfma16(ld16(kp + 32), q1, a);
-      if (t * 16 + 16 > N) {
+      a = mfma16(ld16(Ks + t * 16 * HD + kof0), q0, a);
+      a = mfma16(ld16(Ks + t * 16 * HD + kof1), q1, a);
+      // Only the key tiles past the previous dispatch size can straddle N (this instantiation serves 16 * nkt_lo < N <= NP): the
+      // others are full by construction.  Testing every tile against the runtime N cost 144 v_cndmask + 94 v_readlane per
+      // query tile (the 72 compare results were spilled from SGPR pairs to VGPR lanes) -- 40 % of the loop's VALU work.
+      if (t >= nkt_lo(NKT) && t * 16 + 16 > N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = (t * 16 + g * 4 + r < N) ? a[r] : -INFINITY;
       }
@@ -179,8 +249,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       const s16x8_t pb = pack8(lo, hi);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t* vp = Vt + (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
-        o[dt] = mfma16(ld8x2(vp, vp + 16), pb, o[dt]);
+        o[dt] = mfma16(ld16(Vt + dt * 16 * TP + 32 * u + vof), pb, o[dt]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -269,11 +338,16 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
         s = mfma16(ld16(kp + 32), q1, s);
         dp = mfma16(ld16(vp), do0, dp);
         dp = mfma16(ld16(vp + 32), do1, dp);
+        if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = t * 16 + g * 4 + r;
-          const float p = key < N ? fast_exp2(s[r] * sc2 - lse2) : 0.f;
-          ds[e][r] = p * (dp[r] - dl) * scale;
+          for (int r = 0; r < 4; ++r) {
+            const int key = t * 16 + g * 4 + r;
+            const float p = key < N ? fast_exp2(s[r] * sc2 - lse2) : 0.f;
+            ds[e][r] = p * (dp[r] - dl) * scale;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[e][r] = fast_exp2(s[r] * sc2 - lse2) * (dp[r] - dl) * scale;
         }
       }
       const s16x8_t dsb = pack8(ds[0], ds[1]);
@@ -314,7 +388,7 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
   stage_transposed<NP, BWD_NT>(Qt, base, ld, N, tid);
   stage_transposed<NP, BWD_NT>(dOt, dobase, D, N, tid);
   for (int i = tid; i < NP; i += BWD_NT) {
-    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : 0.f;
+    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : INFINITY;
     dl_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
   }
   __syncthreads();
@@ -358,7 +432,9 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = (2 * u + e) * 16 + g * 4 + r;      // result row = query
-          const float p = (qq < N && key < N) ? fast_exp2(s[r] * sc2 - lse_s[qq]) : 0.f;
+          // padded queries: lse_s = +inf -> p = 0 exactly.  Padded KEY columns (this lane's key >= N) may hold anything: a column
+          // of P / dS only feeds the dK / dV rows of that key, which are never stored.
+          const float p = fast_exp2(s[r] * sc2 - lse_s[qq]);
           pp[e][r] = p;
           ds[e][r] = p * (dp[r] - dl_s[qq]) * scale;
         }
@@ -402,7 +478,7 @@ extern "C" int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int
   if (B <= 0 || N <= 0 || H <= 0 || N > 512) return SR_EINVAL;
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
-    const size_t sm = (size_t)NP * KPAD * 2 + (size_t)64 * (NP + 8) * 2;
+    const size_t sm = (size_t)NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
     auto kern = attn_fwd_kernel<NKT>;
     if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
