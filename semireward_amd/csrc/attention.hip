@@ -26,7 +26,6 @@
 namespace {
 
 constexpr int HD = 64;        // head dim
-constexpr int KPAD = 72;      // row pitch (elements) of row-major [key][64] LDS tiles
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -36,14 +35,6 @@ __device__ __forceinline__ f32x4_t mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
 
 __device__ __forceinline__ s16x8_t ld16(const bf16_t* p) { return *reinterpret_cast<const s16x8_t*>(p); }
 
-// two 8-byte LDS reads -> one 8 x bf16 operand (k-slots 0-3 from p0, 4-7 from p1)
-__device__ __forceinline__ s16x8_t ld8x2(const bf16_t* p0, const bf16_t* p1) {
-  const uint2 a = *reinterpret_cast<const uint2*>(p0);
-  const uint2 b = *reinterpret_cast<const uint2*>(p1);
-  uint4 r = {a.x, a.y, b.x, b.y};
-  return __builtin_bit_cast(s16x8_t, r);
-}
-
 __device__ __forceinline__ s16x8_t pack8(const float* lo, const float* hi) {
   uint4 r = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
   return __builtin_bit_cast(s16x8_t, r);
@@ -52,55 +43,8 @@ __device__ __forceinline__ s16x8_t pack8(const float* lo, const float* hi) {
 // Staging helpers.  Trip counts are compile-time (NP) and every global load of a helper is issued before the
 // first LDS write, so a workgroup pays ONE memory round trip per operand instead of one per loop iteration
 // (the first version serialised ~18 dependent L2/HBM round trips per workgroup: 60 us of latency for 2 us of MFMA).
-// Stage rows [0,N) of a [N][64] bf16 slice (row stride ld elements) into row-major LDS (pitch KPAD), zero-filling [N,NP).
-template <int NP, int NT = 256>
-__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
-  constexpr int IT = (NP * 8 + NT - 1) / NT;
-  u32x4_t v[IT];
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * NT, row = c >> 3, slot = c & 7;
-    v[i] = u32x4_t{0u, 0u, 0u, 0u};
-    if (c < NP * 8 && row < N) v[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)row * ld + slot * 8);
-  }
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * NT, row = c >> 3, slot = c & 7;
-    if (c < NP * 8) *reinterpret_cast<u32x4_t*>(dst + row * KPAD + slot * 8) = v[i];
-  }
-}
-
-// Stage the TRANSPOSE of a [N][64] slice into LDS as dst[d][row] (pitch TP), two rows per 32-bit write.
-template <int NP, int NT = 256>
-__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, int ld, int N, int tid) {
-  constexpr int TP = NP + 8, PAIRS = NP / 2, IT = (PAIRS * 8 + NT - 1) / NT;
-  u32x4_t va[IT], vb[IT];
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * NT, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
-    va[i] = u32x4_t{0u, 0u, 0u, 0u};
-    vb[i] = u32x4_t{0u, 0u, 0u, 0u};
-    if (c < PAIRS * 8) {
-      if (r0 < N) va[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)r0 * ld + slot * 8);
-      if (r0 + 1 < N) vb[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)(r0 + 1) * ld + slot * 8);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * NT, pr = c % PAIRS, slot = c / PAIRS, r0 = 2 * pr;
-    if (c < PAIRS * 8) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t lo = (va[i][j] & 0xffffu) | (vb[i][j] << 16);
-        const uint32_t hi = (va[i][j] >> 16) | (vb[i][j] & 0xffff0000u);
-        *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j) * TP + r0) = lo;
-        *reinterpret_cast<uint32_t*>(dst + (slot * 8 + 2 * j + 1) * TP + r0) = hi;
-      }
-    }
-  }
-}
-
-// ---- conflict-free LDS images for the forward kernel (PMC of the first layout: 47 % of the LDS-array cycles were bank conflicts,
+// Rows [N, NP) are zero-filled.
+// ---- conflict-free LDS images (PMC of the first layout, [key][72] rows and [d][NP + 8] transposes: 47 % of the LDS-array cycles were bank conflicts,
 // and the two 8-byte V^T reads of an operand were fused into ds_read2_b64 = 8 cycles instead of 4 for one ds_read_b128) ----
 // K image: [key][64] with 128-B rows; the 16-B chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  A row covers half of the 64
 // banks (even rows 0-31, odd rows 32-63), so the 16 lanes of every ds_read_b128 service group (MI355X_MICROARCH.md, LDS) hit 16
@@ -278,12 +222,15 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
                                                          const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                          bf16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                          int N, int H, float scale) {
-  constexpr int NP = NKT * 16, TP = NP + 8;
+  constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][KPAD]
-  bf16_t* Vs = Ks + NP * KPAD;                        // [NP][KPAD]
-  bf16_t* Kt = Vs + NP * KPAD;                        // [64][TP]
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][64]  chunk-swizzled (stage_rows_swz)
+  bf16_t* Vs = Ks + NP * HD;                          // [NP][64]  chunk-swizzled
+  bf16_t* Kt = Vs + NP * HD;                          // [64][TP]  key-permuted + chunk-swizzled (stage_transposed_perm)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int kc_ = g ^ ((l15 >> 1) & 7);
+  const int kof0 = l15 * HD + (kc_ << 3), kof1 = l15 * HD + ((kc_ ^ 4) << 3);
+  const int vof = l15 * TP + ((g ^ swz4(l15)) << 3);
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const float sc2 = scale * LOG2E;
@@ -302,9 +249,9 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
   };
   const int qstride = BWD_NW * gridDim.y, qfirst = blockIdx.y * BWD_NW + wave;
   fetch(qfirst);
-  stage_rows<NP, BWD_NT>(Ks, base + D, ld, N, tid);
-  stage_rows<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
-  stage_transposed<NP, BWD_NT>(Kt, base + D, ld, N, tid);
+  stage_rows_swz<NP, BWD_NT>(Ks, base + D, ld, N, tid);
+  stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
+  stage_transposed_perm<NP, BWD_NT>(Kt, base + D, ld, N, tid);
   __syncthreads();
   for (int qt = qfirst; qt < nqt; qt += qstride) {
     const int q = qt * 16 + l15;
@@ -331,13 +278,11 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int t = 2 * u + e;
-        const bf16_t* kp = Ks + (t * 16 + l15) * KPAD + g * 8;
-        const bf16_t* vp = Vs + (t * 16 + l15) * KPAD + g * 8;
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = mfma16(ld16(kp), q0, s);
-        s = mfma16(ld16(kp + 32), q1, s);
-        dp = mfma16(ld16(vp), do0, dp);
-        dp = mfma16(ld16(vp + 32), do1, dp);
+        s = mfma16(ld16(Ks + t * 16 * HD + kof0), q0, s);
+        s = mfma16(ld16(Ks + t * 16 * HD + kof1), q1, s);
+        dp = mfma16(ld16(Vs + t * 16 * HD + kof0), do0, dp);
+        dp = mfma16(ld16(Vs + t * 16 * HD + kof1), do1, dp);
         if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -353,8 +298,7 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
       const s16x8_t dsb = pack8(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t* ktp = Kt + (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
-        dq[dt] = mfma16(ld8x2(ktp, ktp + 16), dsb, dq[dt]);
+        dq[dt] = mfma16(ld16(Kt + dt * 16 * TP + 32 * u + vof), dsb, dq[dt]);
       }
     }
     if (q < N) {
@@ -375,9 +319,9 @@ template <int NKT>
 __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
-  constexpr int NP = NKT * 16, TP = NP + 8;
+  constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]
+  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]  query-permuted + chunk-swizzled (stage_transposed_perm)
   bf16_t* dOt = Qt + 64 * TP;                         // [64][TP]
   float* lse_s = reinterpret_cast<float*>(dOt + 64 * TP);   // [NP]  (already * log2e)
   float* dl_s = lse_s + NP;                                 // [NP]
@@ -385,8 +329,9 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
-  stage_transposed<NP, BWD_NT>(Qt, base, ld, N, tid);
-  stage_transposed<NP, BWD_NT>(dOt, dobase, D, N, tid);
+  stage_transposed_perm<NP, BWD_NT>(Qt, base, ld, N, tid);
+  stage_transposed_perm<NP, BWD_NT>(dOt, dobase, D, N, tid);
+  const int vof = (threadIdx.x & 15) * TP + (((threadIdx.x >> 4 & 3) ^ swz4(threadIdx.x & 15)) << 3);
   for (int i = tid; i < NP; i += BWD_NT) {
     lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : INFINITY;
     dl_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
@@ -442,9 +387,9 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
       const s16x8_t pb = pack8(pp[0], pp[1]), dsb = pack8(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int off = (dt * 16 + l15) * TP + (2 * u) * 16 + g * 4;
-        dv[dt] = mfma16(ld8x2(dOt + off, dOt + off + 16), pb, dv[dt]);
-        dk[dt] = mfma16(ld8x2(Qt + off, Qt + off + 16), dsb, dk[dt]);
+        const int off = dt * 16 * TP + 32 * u + vof;
+        dv[dt] = mfma16(ld16(dOt + off), pb, dv[dt]);
+        dk[dt] = mfma16(ld16(Qt + off), dsb, dk[dt]);
       }
     }
     if (key < N) {
@@ -492,8 +437,8 @@ extern "C" int srhip_attn_bwd(const void* qkv, const void* out, const void* d_ou
   if (B <= 0 || N <= 0 || H <= 0 || N > 512 || !lse || !delta_ws) return SR_EINVAL;
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
-    const size_t sm1 = (size_t)2 * NP * KPAD * 2 + (size_t)64 * (NP + 8) * 2;
-    const size_t sm2 = (size_t)2 * 64 * (NP + 8) * 2 + (size_t)2 * NP * 4;
+    const size_t sm1 = (size_t)2 * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
+    const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (size_t)2 * NP * 4;
     if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;   // N > 288 backward: not in this round's scope
     auto k1 = attn_bwd_dq_kernel<NKT>;
     auto k2 = attn_bwd_dkv_kernel<NKT>;
