@@ -77,13 +77,18 @@ int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dgamma, float* dbeta, int M, int D, void* stream);
 
-/* Fused inference MLP half of a transformer block, in place on the fp32 residual stream x [M, D]:
- *   x += row_scale[m / rows_per_sample] * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) + b2 )
+/* Fused MLP half of a transformer block on the fp32 residual stream (x -> x_out, both [M, D]; x_out may equal x):
+ *   x_out = x + row_scale[m / rows_per_sample] * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) + b2 )
  * = Block.forward's second residual (vit.py:165) with Mlp.forward (vit.py:69-75), norm2 (vit.py:150) and DropPath
- * (row_scale, NULL = 1) for rows that need no backward.  W1 bf16 [Hd, D], W2 bf16 [D, Hd], biases / LN affine fp32.
+ * (row_scale, NULL = 1).  W1 bf16 [Hd, D], W2 bf16 [D, Hd], biases / LN affine fp32.  The hidden activation stays in registers.
+ * save_rows > 0: the first save_rows rows carry a gradient (they lead a mixed batch); for them the kernel also writes what the
+ * hand-written backward needs -- norm2 output (save_ln2 bf16 [save_rows, D]), fc1 pre-activation and GELU output (save_pre,
+ * save_h bf16 [save_rows, Hd]) and the LayerNorm statistics (save_mean, save_rstd fp32 [save_rows]) -- exactly the values
+ * layernorm_fwd + gemm_nt(GELU, aux_out) would have stored.
  * D == 384 (ViT-S width), Hd % 128 == 0, Hd <= 4096.  Same rounding points as layernorm_fwd + gemm_nt(GELU) + gemm_nt(RESID). */
-int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1,
-                    const void* W2, const float* b2, const float* row_scale, int rows_per_sample, int M, int D, int Hd,
+int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const float* ln_beta, float eps, const void* W1,
+                    const float* b1, const void* W2, const float* b2, const float* row_scale, int rows_per_sample, int save_rows,
+                    void* save_ln2, void* save_pre, void* save_h, float* save_mean, float* save_rstd, int M, int D, int Hd,
                     void* stream);
 
 /* PatchEmbed conv (kernel = stride = ps) + cls token + pos_embed (vit.py:39-44, :277-280) (K1).

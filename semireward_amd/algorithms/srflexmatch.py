@@ -19,6 +19,7 @@ import os
 import torch
 
 from .. import ops
+from ..nets import vit as _vit
 from ..core.algorithmbase import AlgorithmBase, DeferredScalar
 from ..core.registry import ALGORITHMS
 from .hooks import FixedThresholdingHook, FlexMatchThresholdingHook, PseudoLabelingHook
@@ -38,6 +39,7 @@ class _Plan:
         self.grad_img = t([cols_img[c] for c in grad_cols], torch.int32)
         self.inf_img = t([cols_img[c] for c in inf_cols], torch.int32)
         self.ncols = len(cols_img)
+        self.mixed_cols = self.mixed_img = None      # gradient columns first (forward_mixed), built on first use
 
     @classmethod
     def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False):
@@ -106,6 +108,16 @@ class SRConsistencyBase(AlgorithmBase):
         sel = (lambda cols: dp_all.index_select(2, cols).contiguous()) if dp_all is not None else (lambda cols: None)
         logits = torch.empty(pl.ncols, C, dtype=torch.float32, device=self.device)
         feats = torch.empty(pl.ncols, D, dtype=torch.float32, device=self.device)
+        if _vit.MIXED_FWD and m.supports_mixed(pl.ncols):
+            # ONE forward over all (pass, image) columns, gradient columns first: every row takes the big inference launches and the
+            # backward operands of the leading rows are kept by the kernels themselves (nets/vit.py forward_mixed; opt-in, see there).
+            if pl.mixed_cols is None:
+                pl.mixed_cols = torch.cat((pl.grad_cols, pl.inf_cols))
+                pl.mixed_img = torch.cat((pl.grad_img, pl.inf_img)).contiguous()
+            lg, ft, ctx = m.forward_mixed(imgs, pl.mixed_img, sel(pl.mixed_cols), pl.grad_cols.numel())
+            logits.index_copy_(0, pl.mixed_cols, lg)
+            feats.index_copy_(0, pl.mixed_cols, ft)
+            return logits, feats, ctx
         # The gradient-carrying rows (16 of 216 images at the reference batch) run on a SECOND HIP stream: their launches are
         # 100-400 workgroups of latency-bound work (14-28 us each, 1.6 ms per step back to back) that fit beside the tails of
         # the 200-image inference launches.  Both forwards only read the parameters; they write disjoint workspaces.

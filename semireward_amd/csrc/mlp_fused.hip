@@ -60,7 +60,12 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct MlpArgs {
-  float* x;
+  const float* x;          // input residual stream (LayerNorm source and residual term)
+  float* xo;               // output residual stream (== x for the in-place call)
+  // activations kept for the backward of the first ``save_rows`` rows (the gradient-carrying images of a mixed batch), or NULL
+  bf16_t *s_ln2, *s_pre, *s_h;     // [save_rows, D], [save_rows, Hd], [save_rows, Hd]
+  float *s_mean, *s_rstd;          // [save_rows]
+  int save_rows;
   const float *gamma, *beta, *b1, *b2, *row_scale;
   const bf16_t *W1, *W2;
   float eps;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
       const float rs = rsqrtf(q * (1.0f / D_) + a.eps);
+      if (a.save_rows > 0 && m < a.save_rows && lg == 0) { a.s_mean[m] = mu; a.s_rstd[m] = rs; }
 #pragma unroll
       for (int k = 0; k < KS1; ++k) {
         const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(a.gamma + 32 * k + 8 * lg);
@@ -167,6 +173,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
                         pack_bf2((r[2] - mu) * rs * g1[2] + b1[2], (r[3] - mu) * rs * g1[3] + b1[3])};
         if (k & 1) __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting all 48 affine loads (spills)
       }
+    }
+    const bool save_tile = a.save_rows > 0 && tile * FBM + wave * 16 < a.save_rows;      // wave-uniform
+    if (save_tile && m < a.save_rows) {                                                     // norm2 output of the gradient rows
+      bf16_t* lr = a.s_ln2 + (size_t)m * D_ + 8 * lg;
+#pragma unroll
+      for (int k = 0; k < KS1; ++k) *reinterpret_cast<u32x4_t*>(lr + 32 * k) = xn[k];
     }
     __syncthreads();                       // previous tile's ring reads are over (and sb1/sb2 are written)
 #pragma unroll
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     };
     // bias + GELU + bf16 pack, ONE element at a time so that it can be threaded between MFMAs: element e = 4 X + r of
     // pair-group u is hidden unit 64 c + 32 u + 8 g + e (X = 0: tile P, 1: tile Q; r = accumulator register).
-    float gcarry = 0.f;
+    float gcarry = 0.f, pcarry = 0.f;
     // accumulator start = fc1 bias: lane (g) holds hidden 64 c + 32 u + 8 g + 4 X + r in register r of tile X
     auto acc1_start = [&](auto uc, auto xc, int c) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value, X = decltype(xc)::value;
@@ -226,7 +238,16 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       const float v = acc1[2 * u + X][r];
       float gv;
       if constexpr ((DBG & 1) != 0) gv = v; else gv = gelu_erf(v);
-      if constexpr ((e & 1) == 0) gcarry = gv; else hf[u][e >> 1] = pack_bf2(gcarry, gv);
+      if constexpr ((e & 1) == 0) { gcarry = gv; pcarry = v; } else hf[u][e >> 1] = pack_bf2(gcarry, gv);
+      if constexpr ((e & 1) == 1) {
+        // gradient rows: keep the fc1 pre-activation and the GELU output (bf16, as the unfused path saves them); rare (8 % of the
+        // tiles) and conservative for the counted vmcnt waits (extra younger stores can only make a wait longer)
+        if (save_tile && m < a.save_rows) {
+          const size_t o = (size_t)m * a.Hd + c * CH + 32 * u + 8 * lg + (e - 1);
+          *reinterpret_cast<uint32_t*>(a.s_pre + o) = pack_bf2(pcarry, v);
+          *reinterpret_cast<uint32_t*>(a.s_h + o) = hf[u][e >> 1];
+        }
+      }
       if constexpr (r == 3) acc1_start(uc, std::integral_constant<int, X>{}, c + 1);     // restart for the next chunk
     };
     // Which GELU elements ride behind half-stage (j, h): group 0 (complete after stage 2) behind stages 3-5, group 1
@@ -298,14 +319,15 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     // ---- epilogue: lane holds y[m][16 t + 4 g + r]
     if (m < a.M) {
       const float rsc = a.row_scale ? a.row_scale[m / a.rows_per_sample] : 1.0f;
-      float* xr = a.x + (size_t)m * D_ + 4 * lg;
+      const float* xr = a.x + (size_t)m * D_ + 4 * lg;
+      float* xw = a.xo + (size_t)m * D_ + 4 * lg;
 #pragma unroll
       for (int t = 0; t < NT2; ++t) {
         const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sb2 + 16 * t + 4 * lg);
         f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
         xv[0] += rsc * (acc2[t][0] + bb[0]); xv[1] += rsc * (acc2[t][1] + bb[1]);
         xv[2] += rsc * (acc2[t][2] + bb[2]); xv[3] += rsc * (acc2[t][3] + bb[3]);
-        *reinterpret_cast<f32x4_t*>(xr + 16 * t) = xv;
+        *reinterpret_cast<f32x4_t*>(xw + 16 * t) = xv;
       }
     }
   }
@@ -314,15 +336,21 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
 
 }  // namespace
 
-extern "C" int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1,
-                               const void* W2, const float* b2, const float* row_scale, int rows_per_sample, int M, int D, int Hd,
-                               void* stream) {
-  if (!x || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return SR_EINVAL;
+extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const float* ln_beta, float eps, const void* W1,
+                               const float* b1, const void* W2, const float* b2, const float* row_scale, int rows_per_sample,
+                               int save_rows, void* save_ln2, void* save_pre, void* save_h, float* save_mean, float* save_rstd,
+                               int M, int D, int Hd, void* stream) {
+  if (!x || !x_out || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return SR_EINVAL;
   if (D != 384 || Hd < 128 || (Hd % RT) || Hd > 4096) return SR_EINVAL;          // ViT-S width; hidden in 128-wide chunks
   if (row_scale && rows_per_sample <= 0) return SR_EINVAL;
-  if (((uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) return SR_EINVAL;
+  if (save_rows < 0 || save_rows > M || (save_rows > 0 && (!save_ln2 || !save_pre || !save_h || !save_mean || !save_rstd))) return SR_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)x_out | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)save_ln2 |
+       (uintptr_t)save_pre | (uintptr_t)save_h) & 15)
+    return SR_EINVAL;
   MlpArgs a;
-  a.x = x; a.gamma = ln_gamma; a.beta = ln_beta; a.b1 = b1; a.b2 = b2; a.row_scale = row_scale;
+  a.x = x; a.xo = x_out; a.gamma = ln_gamma; a.beta = ln_beta; a.b1 = b1; a.b2 = b2; a.row_scale = row_scale;
+  a.s_ln2 = (bf16_t*)save_ln2; a.s_pre = (bf16_t*)save_pre; a.s_h = (bf16_t*)save_h; a.s_mean = save_mean; a.s_rstd = save_rstd;
+  a.save_rows = save_rows;
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + D) * sizeof(float);
@@ -340,8 +368,8 @@ extern "C" int srhip_mlp_fused(float* x, const float* ln_gamma, const float* ln_
     default: break;
   }
 #endif
-  const int ntiles = cdiv(M, FBM);
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int ntiles = cdiv(M, FBM);
   hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
   SR_CHECK_LAUNCH();
   return SR_OK;

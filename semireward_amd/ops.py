@@ -189,18 +189,21 @@ def layernorm_fwd(x, gamma, beta, eps, out, mean, rstd, M, D):
     _call("srhip_layernorm_fwd", _p(x), _p(gamma), _p(beta), eps, _p(out), _p(mean), _p(rstd), M, D, _s())
 
 
-def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M, D, Hd):
-    """x (fp32 [M,D], in place) += row_scale * (fc2(gelu(fc1(LN(x)))) + b2); inference rows only (nothing is saved)."""
+def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M, D, Hd, x_out=None, save=None):
+    """x_out (default: x, in place; fp32 [M,D]) = x + row_scale * (fc2(gelu(fc1(LN(x)))) + b2), ONE launch.
+    save = (rows, ln2, pre, h, mean, rstd): the first ``rows`` rows also get their backward operands written (see srhip.h)."""
+    rows, ln2, pre, h, mean, rstd = save if save is not None else (0, None, None, None, None, None)
+    args = (_p(x), _p(x_out if x_out is not None else x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale),
+            rows_per_sample, rows, _p(ln2), _p(pre), _p(h), _p(mean), _p(rstd), M, D, Hd)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _call("srhip_mlp_fused", _p(x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale), rows_per_sample,
-              M, D, Hd, _s())
+        _call("srhip_mlp_fused", *args, _s())
         e1.record()
-        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd, "mlp_fused_kernel<384, 0, 4>", 8.0 * M * D + 4.0 * D * Hd))
+        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd, "mlp_fused_kernel<384, 0, 4>",
+                              8.0 * M * D + 4.0 * D * Hd + rows * (2.0 * D + 4.0 * Hd)))
         return
-    _call("srhip_mlp_fused", _p(x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale), rows_per_sample,
-          M, D, Hd, _s())
+    _call("srhip_mlp_fused", *args, _s())
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M, D):

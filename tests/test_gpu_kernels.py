@@ -111,6 +111,23 @@ def test_mlp_fused(M, rows_per_sample):
     if rs is not None:                                         # dropped samples are untouched, bit for bit
         dropped = (rs.repeat_interleave(rows_per_sample)[:M] == 0)
         assert torch.equal(xf[dropped], x0[dropped])
+    # out-of-place call with the backward operands of the leading rows (mixed batch: gradient rows first)
+    R = min(M, 200) if rows_per_sample == 0 else min(M, 2 * rows_per_sample)
+    xo = torch.zeros_like(x0)
+    s_ln2 = torch.zeros(R, D, dtype=torch.bfloat16, device=DEV)
+    s_pre, s_h = torch.zeros(R, Hd, dtype=torch.bfloat16, device=DEV), torch.zeros(R, Hd, dtype=torch.bfloat16, device=DEV)
+    s_mu, s_rs = torch.zeros(R, device=DEV), torch.zeros(R, device=DEV)
+    ops.mlp_fused(x0, g, b, 1e-6, W1, b1, W2, b2, rs, rows_per_sample, M, D, Hd, x_out=xo, save=(R, s_ln2, s_pre, s_h, s_mu, s_rs))
+    pre_u = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    mu_u, rs_u = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x0, g, b, 1e-6, ln, mu_u, rs_u, M, D)
+    ops.gemm_nt(ops.EPI_GELU_BF16, ln, W1, h, M, Hd, D, bias=b1, aux_out=pre_u, ldaux=Hd)
+    torch.cuda.synchronize()
+    assert torch.equal(xo, xf)                                 # same arithmetic, other destination
+    assert relerr(s_ln2.float(), ln[:R].float()) < 1e-3 and relerr(s_pre.float(), pre_u[:R].float()) < 2e-3
+    assert relerr(s_h.float(), h[:R].float()) < 2e-3
+    np.testing.assert_allclose(s_mu.cpu().numpy(), mu_u[:R].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s_rs.cpu().numpy(), rs_u[:R].cpu().numpy(), rtol=1e-5)
 
 
 def test_gemm_tn_grouped():
