@@ -210,3 +210,67 @@ def test_evaluate_matches_oracle_forward():
         m = AlgorithmBase.classification_metrics(np.concatenate(ys), yp)
         assert out["eval/top-1-acc"] == pytest.approx(m["top-1-acc"]) and out["eval/F1"] == pytest.approx(m["F1"])
     assert set(out) == {"eval/loss", "eval/top-1-acc", "eval/balanced_acc", "eval/precision", "eval/recall", "eval/F1", "eval/logits"}
+
+
+def test_full_size_step_properties():
+    """BASELINE.json's north-star configuration at FULL size (ViT-S/2, C = 100, 8/8/8, K = sr_decay() = 8, ulb_dest_len 50 000): the CPU
+    oracle cannot step this in seconds, so parity goes through size-independent properties --
+      * integer work bit-exact: every pass's FlexMatch mask / selected_label / classwise_acc equals the numpy oracle fed with the
+        engine's own max-probs and argmax of that pass (sequential state, 9 passes); reward mask2 == (reward >= per-pass mean);
+      * K = 8 passes, (1 + K) * 24 image rows, finite losses, util_ratio = mean(mask0);
+      * linearity of the hand-written backward: grads(2 * dlogits) == 2 * grads(dlogits) to fp32 round-off (no atomics on bf16);
+      * the step is reproducible: same state + same inputs + same DropPath draws -> same masks and logits."""
+    from oracle import hooks_ref as H
+    NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
+               num_warmup_iter=5120)
+    def make():
+        alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
+        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+        alg.it = 30000
+        alg.optimizer.sched_step = alg.it
+        return alg
+    b = synth.synth_batch(100, 8, 8, 32, 100, 50000)
+    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
+    dps = [torch.from_numpy(synth.synth_droppath(900 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
+    runs = []
+    for _ in range(2):
+        alg = make()
+        alg.inject_droppath = dps
+        alg.trace = {}
+        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+        torch.cuda.synchronize()
+        runs.append((alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}))
+    alg, out, log, tr = runs[0]
+    K, nu, C = tr["K"], 8, 100
+    assert K == 8 and tr["logits"].shape[:2] == (9, 24)
+    # --- integer work against the oracle on the engine's own numbers
+    st = H.FlexMatchState(50000, C, True)
+    mp, mi = tr["max_probs"].cpu().numpy().reshape(9, nu), tr["pseudo"].cpu().numpy().reshape(9, nu)
+    idx = b["idx_ulb"]
+    for k in range(9):
+        probs = np.zeros((nu, C), np.float32)
+        probs[np.arange(nu), mi[k]] = mp[k]                      # masking only looks at (max, argmax) of each row
+        want = st.masking(probs, idx, 0.95)
+        assert np.array_equal(tr["masks"][k].cpu().numpy(), want), k
+    h = alg.hooks_dict["MaskingHook"]
+    assert np.array_equal(h.selected_label.cpu().numpy(), st.selected_label)
+    assert np.array_equal(h.classwise_acc.cpu().numpy().view(np.uint32), st.classwise_acc.view(np.uint32))
+    r = tr["reward"].cpu().numpy().reshape(K, nu)
+    assert np.array_equal(tr["mask2"].cpu().numpy().reshape(K, nu), (r >= r.mean(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32))
+    assert 0.0 <= r.min() and r.max() <= 1.0
+    assert float(log["train/util_ratio"]) == pytest.approx(float(tr["masks"][0].mean()), abs=1e-7)
+    for k_ in ("sup_loss", "unsup_loss", "total_loss"):
+        assert np.isfinite(float(log["train/" + k_]))
+    # --- reproducibility of the forward / filter
+    tr2 = runs[1][3]
+    assert torch.equal(tr["logits"], tr2["logits"]) and all(torch.equal(a, b_) for a, b_ in zip(tr["masks"], tr2["masks"]))
+    # --- linearity of the backward
+    m = alg.model
+    x = torch.from_numpy(np.concatenate([b["x_lb"], b["x_ulb_s"]])).to(DEV)
+    dp = dps[0][:, :, :16].contiguous().to(DEV)
+    lg, _, ctx = m.forward_features(x, None, dp, save=True)
+    dl = torch.from_numpy((np.random.Generator(np.random.PCG64(3)).standard_normal((16, C)) * 1e-2).astype(np.float32)).to(DEV)
+    m.zero_grad(); m.backward(ctx, dl); g1 = m.grad.clone()
+    lg, _, ctx = m.forward_features(x, None, dp, save=True)
+    m.zero_grad(); m.backward(ctx, 2.0 * dl); g2 = m.grad.clone()
+    assert rel(g2.cpu(), (2.0 * g1).cpu().numpy()) < 2e-3        # bf16 rounding of the scaled output gradients is not exactly linear
