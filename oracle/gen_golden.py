@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 from oracle import _ref_import as R  # noqa: E402
 from oracle import semireward_ref as S  # noqa: E402
 from oracle import vit_ref as V  # noqa: E402
+from oracle import wrn_ref as W  # noqa: E402
 from semireward_amd.utils import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -213,6 +214,77 @@ def gen_vit(cases=None, fname="vit.npz"):
             flat(f"{tag}/grad/{n}", samp(p.grad.numpy(), 256), out)
         out[f"{tag}/meta"] = np.array([C, B, seed], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def synth_wrn_params(cfg, seed):
+    """Synthetic WRN parameters: conv / linear weights U(+-1/sqrt(fan_in)), BN gamma 1 +- 0.1, BN beta / biases small."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for n, shp in W.param_shapes(cfg):
+        if ".bn" in n or n.startswith("bn"):
+            out[n] = (1.0 + 0.1 * rng.standard_normal(shp)).astype(np.float32) if n.endswith("weight") else (0.05 * rng.standard_normal(shp)).astype(np.float32)
+        elif len(shp) == 1:
+            out[n] = (0.02 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            b = 1.0 / np.sqrt(int(np.prod(shp[1:])))
+            out[n] = rng.uniform(-b, b, size=shp).astype(np.float32)
+    return out
+
+
+def build_ref_wrn(cfg, params):
+    wm = R.mod("semilearn.nets.wrn.wrn")
+    model = wm.WideResNet(first_stride=cfg.first_stride, num_classes=cfg.num_classes, depth=cfg.depth, widen_factor=cfg.widen)
+    assert [n for n, _ in model.named_parameters()] == [n for n, _ in W.param_shapes(cfg)]
+    load_module_params(model, params)
+    return model
+
+
+def gen_wrn():
+    """WideResNet (wrn.py) forward / backward / BatchNorm running statistics straight from the reference: eval forward, train forward
+    with statistics update, train forward under Bn_Controller.freeze_bn, gradients of a weighted CE."""
+    out = {}
+    bc = R.mod("semilearn.core.utils.misc").Bn_Controller()
+    for tag, cfgd, C, B, HW, seed in [("tiny", W.WRN_TINY_TEST, 10, 6, 8, 61), ("wrn_28_2", W.WRN_28_2, 100, 4, 32, 62)]:
+        cfg = W.WrnCfg(num_classes=C, **cfgd)
+        params = synth_wrn_params(cfg, seed)
+        rng = np.random.Generator(np.random.PCG64(seed + 1))
+        x = rng.standard_normal((B, 3, HW, HW)).astype(np.float32)
+        x2 = rng.standard_normal((B, 3, HW, HW)).astype(np.float32)
+        y = rng.integers(0, C, size=(B,), dtype=np.int64)
+        w = rng.random(B).astype(np.float32)
+        model = build_ref_wrn(cfg, params)
+        # non-trivial running statistics to start from
+        for n, c, _ in W.bn_names(cfg):
+            m = dict(model.named_modules())[n]
+            m.running_mean.copy_(T((0.1 * rng.standard_normal(c)).astype(np.float32)))
+            m.running_var.copy_(T((1.0 + 0.2 * rng.random(c)).astype(np.float32)))
+        for n, c, _ in W.bn_names(cfg):
+            m = dict(model.named_modules())[n]
+            out[f"{tag}/buf0/{n}.running_mean"] = m.running_mean.numpy().copy(); out[f"{tag}/buf0/{n}.running_var"] = m.running_var.numpy().copy()
+        model.eval()
+        with torch.no_grad():
+            o = model(T(x))
+        out[f"{tag}/eval_logits"] = o["logits"].numpy(); out[f"{tag}/eval_feat"] = o["feat"].numpy()
+        model.train()
+        o = model(T(x))                                            # labelled-style forward: statistics move
+        out[f"{tag}/train_logits"] = o["logits"].detach().numpy(); out[f"{tag}/train_feat"] = o["feat"].detach().numpy()
+        for n, c, _ in W.bn_names(cfg):
+            m = dict(model.named_modules())[n]
+            out[f"{tag}/buf1/{n}.running_mean"] = m.running_mean.numpy().copy(); out[f"{tag}/buf1/{n}.running_var"] = m.running_var.numpy().copy()
+        bc.freeze_bn(model)
+        o2 = model(T(x2))                                          # unlabelled-style forward: batch statistics, running stats restored
+        bc.unfreeze_bn(model)
+        out[f"{tag}/frozen_logits"] = o2["logits"].detach().numpy()
+        for n, c, _ in W.bn_names(cfg)[:2]:
+            m = dict(model.named_modules())[n]
+            assert np.array_equal(m.running_mean.numpy(), out[f"{tag}/buf1/{n}.running_mean"])
+        loss = (F.cross_entropy(o["logits"], T(y), reduction="none") * T(w)).mean() + 0.5 * (F.cross_entropy(o2["logits"], T(y), reduction="none") * T(w)).mean()
+        loss.backward()
+        out[f"{tag}/loss"] = np.float32(loss.item())
+        for n, p in model.named_parameters():      # block2/3.layer.0.bn1 feed nothing (wrn.py:46-50: conv1 takes the raw x there): grad None
+            flat(f"{tag}/grad/{n}", samp(p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32), 256), out)
+        out[f"{tag}/meta"] = np.array([C, B, HW, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "wrn.npz"), **out)
 
 
 def gen_vit_p16():
@@ -601,7 +673,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
-            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16)
+            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -344,3 +344,37 @@ def test_srsoftmatch_trace(golden):
         np.testing.assert_allclose(orc.da.p_target.numpy(), g[f"{p}/p_target"], rtol=1e-6)
         for nme, _ in V.param_shapes(cfg):
             check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 2e-3, 2e-6, f"{p} grad {nme}")
+
+
+@pytest.mark.parametrize("tag", ["tiny", "wrn_28_2"])
+def test_wrn_oracle_matches_reference(golden, tag):
+    """oracle/wrn_ref.py against the reference WideResNet (wrn.py): eval / train / frozen-BN forwards, running statistics, gradients."""
+    from oracle import wrn_ref as W
+    from oracle.gen_golden import synth_wrn_params
+    g = golden("wrn")
+    C, B, HW, seed = [int(v) for v in g[f"{tag}/meta"]]
+    cfg = W.WrnCfg(num_classes=C, **(W.WRN_TINY_TEST if tag == "tiny" else W.WRN_28_2))
+    P = {k: T(v).requires_grad_(True) for k, v in synth_wrn_params(cfg, seed).items()}
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    x = T(rng.standard_normal((B, 3, HW, HW)).astype(np.float32)); x2 = T(rng.standard_normal((B, 3, HW, HW)).astype(np.float32))
+    y = T(rng.integers(0, C, size=(B,), dtype=np.int64)); w = T(rng.random(B).astype(np.float32))
+    BUF = {k[len(tag) + 6:]: T(g[k]).clone() for k in g.keys() if k.startswith(f"{tag}/buf0/")}
+    with torch.no_grad():
+        o = W.wrn_forward(P, BUF, x, cfg, train=False)
+    np.testing.assert_allclose(o["logits"].numpy(), g[f"{tag}/eval_logits"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(o["feat"].numpy(), g[f"{tag}/eval_feat"], rtol=2e-4, atol=2e-5)
+    o = W.wrn_forward(P, BUF, x, cfg, train=True, update_stats=True)
+    np.testing.assert_allclose(o["logits"].detach().numpy(), g[f"{tag}/train_logits"], rtol=2e-4, atol=2e-5)
+    for k in BUF:
+        np.testing.assert_allclose(BUF[k].numpy(), g[f"{tag}/buf1/{k}"], rtol=1e-6, atol=1e-7)
+    o2 = W.wrn_forward(P, BUF, x2, cfg, train=True, update_stats=False)
+    np.testing.assert_allclose(o2["logits"].detach().numpy(), g[f"{tag}/frozen_logits"], rtol=2e-4, atol=2e-5)
+    for k in BUF:
+        np.testing.assert_allclose(BUF[k].numpy(), g[f"{tag}/buf1/{k}"], rtol=1e-6, atol=1e-7)          # untouched by the frozen forward
+    ce = torch.nn.functional.cross_entropy
+    loss = (ce(o["logits"], y, reduction="none") * w).mean() + 0.5 * (ce(o2["logits"], y, reduction="none") * w).mean()
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g[f"{tag}/loss"]), rel=1e-5)
+    for n, _ in W.param_shapes(cfg):
+        gr = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
+        check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 2e-3, 1e-6, f"{tag} grad {n}")
