@@ -226,6 +226,40 @@ int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, float
                      const float* lr_t, const float* wd_t, float lr_factor, float beta1, float beta2, float eps, int step,
                      float ema_m, float grad_scale, int zero_grad, void* stream);
 
+/* ---- WideResNet building blocks (classic_cv backbone, semilearn/nets/wrn/wrn.py; BASELINE.json configs[0], parity configuration) ----
+ * Feature maps are NHWC = row-major [rows = B*H*W, C].  conv = im2col (bf16) + srhip_gemm_nt; dW = srhip_gemm_tn_grouped_f32(dY, col);
+ * dX = srhip_gemm_nt(dY, W^T) + col2im.
+ *   nchw_to_nhwc_bf16 : the input batch [B,C,H,W] fp32 -> bf16 [B,H,W,C]
+ *   im2col            : col[(b,yo,xo)][c*k*k + i*k + j] = act[b][yo*s+i-p][xo*s+j-p][c]  (k in {1,3}, p = k/2, zero fill, Kpad % 32 == 0;
+ *                       column order == Conv2d weight.flatten(1), wrn.py:33-43)
+ *   col2im            : the adjoint gather: dact (= | +=) sum of the dcol entries that read each input pixel
+ *   conv_weight_prep  : W fp32 [Cout, K] -> bf16 [Cout, Kpad] and its transpose bf16 [Kpad, Cout];  add_unpad: dW[Cout,K] += dWpad[Cout,Kpad]
+ *   bn_fwd            : nn.BatchNorm2d + LeakyReLU(slope) (wrn.py:32-38, :104-105).  training != 0: statistics of THIS batch (saved in
+ *                       save_mean / save_invstd), running_mean / running_var moved with ``momentum`` (unbiased variance) unless
+ *                       update_running == 0 (Bn_Controller.freeze_bn, core/utils/misc.py:105-129); training == 0: running statistics.
+ *                       Outputs: act_bf16 and/or act_f32 (either may be NULL).  ws: 2*C doubles of scratch.  256 % C == 0.
+ *   bn_bwd            : dx = resid (or 0) + BN'(LeakyReLU'(dact)); dgamma += , dbeta += .
+ *   avgpool_fwd/bwd   : F.adaptive_avg_pool2d(.,1) (wrn.py:121);  fc_fwd/bwd: the classifier Linear (wrn.py:106, :126)
+ *   sgd_flat          : torch.optim.SGD(momentum, nesterov=True) on a flat block (core/utils/build.py:193-224, optim 'SGD'); chunk table =
+ *                       {int64 end, float weight_decay, float pad} per parameter; optional EMA shadow; first_step: buf = d. */
+int srhip_nchw_to_nhwc_bf16(const float* img, void* out, int B, int C, int H, int W, void* stream);
+int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream);
+int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int ksize, int stride, int Kpad, int accumulate, void* stream);
+int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int K, int Kpad, void* stream);
+int srhip_add_unpad(const float* src, float* dst, int Cout, int K, int Kpad, void* stream);
+int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
+                 int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* act_bf16,
+                 float* act_f32, double* ws, int rows, int C, void* stream);
+int srhip_bn_bwd(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
+                 float slope, const float* resid, float* dx, float* dgamma, float* dbeta, double* ws, int rows, int C, void* stream);
+int srhip_avgpool_fwd(const float* act, float* feat, int B, int HW2, int C, void* stream);
+int srhip_avgpool_bwd(const float* dfeat, float* dact, int B, int HW2, int C, void* stream);
+int srhip_fc_fwd(const float* feat, const float* Wc, const float* bc, float* logits, int B, int F, int K, void* stream);
+int srhip_fc_bwd(const float* dlogits, const float* feat, const float* Wc, float* dfeat, float* dWc, float* dbc, int B, int F, int K,
+                 void* stream);
+int srhip_sgd_flat(float* p, float* g, float* buf, float* ema, const void* chunk_table, int nchunks, long long n, float lr, float momentum,
+                   float grad_scale, float ema_m, int first_step, int zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

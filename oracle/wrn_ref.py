@@ -69,19 +69,31 @@ def _bn(x, P, BUF, name, eps, train, update):
     return F.batch_norm(x, rm, rv, P[name + ".weight"], P[name + ".bias"], train, MOMENTUM, eps)
 
 
-def wrn_forward(P, BUF, x, cfg, train=True, update_stats=True):
-    """Returns dict(logits [B,C], feat [B, 64*widen]).  BUF (running statistics) is updated in place when train and update_stats."""
+def _rb(t):
+    """bf16 rounding with a straight-through gradient (models the engine's bf16 GEMM operands)."""
+    return t + (t.to(torch.bfloat16).float() - t).detach()
+
+
+def wrn_forward(P, BUF, x, cfg, train=True, update_stats=True, bf16_operands=False):
+    """Returns dict(logits [B,C], feat [B, 64*widen]).  BUF (running statistics) is updated in place when train and update_stats.
+    bf16_operands: round every convolution's input and filter to bf16 (fp32 accumulation) -- the arithmetic of the HIP engine.  The
+    LeakyReLU kink makes the GRADIENT of a deep ReLU-type net sensitive to which side of zero a pre-activation falls, so a bf16
+    forward is compared with this variant (tight) and with the fp32 reference (loose); see tests/test_gpu_wrn.py."""
     act = lambda t: F.leaky_relu(t, SLOPE)   # noqa: E731
-    out = F.conv2d(x, P["conv1.weight"], P["conv1.bias"], 1, 1)                             # :132
+    if bf16_operands:
+        conv2d = lambda a, w, b, s, p: F.conv2d(_rb(a), _rb(w), b, s, p)   # noqa: E731
+    else:
+        conv2d = F.conv2d
+    out = conv2d(x, P["conv1.weight"], P["conv1.bias"], 1, 1)                               # :132
     for p, cin, cout, stride, abr in blocks(cfg):
         equal = cin == cout
         o = act(_bn(out, P, BUF, p + "bn1", 1e-5, train, update_stats))                     # :46-49
         if not equal and abr:
             out = o                                                                         # x = relu1(bn1(x))  (:47)
-        h = F.conv2d(o if equal else out, P[p + "conv1.weight"], None, stride, 1)           # :50 (note: raw x when not abr)
+        h = conv2d(o if equal else out, P[p + "conv1.weight"], None, stride, 1)             # :50 (note: raw x when not abr)
         h = act(_bn(h, P, BUF, p + "bn2", 1e-5, train, update_stats))
-        h = F.conv2d(h, P[p + "conv2.weight"], None, 1, 1)                                  # :53
-        sc = out if equal else F.conv2d(out, P[p + "convShortcut.weight"], None, stride, 0)
+        h = conv2d(h, P[p + "conv2.weight"], None, 1, 1)                                    # :53
+        sc = out if equal else conv2d(out, P[p + "convShortcut.weight"], None, stride, 0)
         out = sc + h                                                                        # :54
     out = act(_bn(out, P, BUF, "bn1", 1e-3, train, update_stats))                           # :136
     feat = out.mean(dim=(2, 3))                                                             # :121-122

@@ -1,0 +1,347 @@
+// WideResNet (classic_cv backbone, semilearn/nets/wrn/wrn.py) building blocks for gfx950.
+// Activations are NHWC: a feature map is a row-major matrix [rows = B*H*W, C], so BatchNorm is a column statistic, a convolution is
+// im2col (bf16) + srhip_gemm_nt, its weight gradient is srhip_gemm_tn_grouped_f32 on (dY, col) and its input gradient is a GEMM with
+// the transposed filter followed by col2im.  This is the CPU-reference parity configuration (BASELINE.json configs[0]), not the
+// throughput path: kernels are kept simple and HBM-bound.
+#include "../../include/srhip.h"
+#include "common.h"
+
+namespace {
+
+// img fp32 [B, C, H, W] -> bf16 [B, H, W, C]
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int C, int HW2, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // over B*HW2*C
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const size_t p = i / C;                                               // b * HW2 + pixel
+  const size_t b = p / HW2, px = p % HW2;
+  out[i] = f2bf(img[(b * C + c) * HW2 + px]);
+}
+
+// col[(b, yo, xo)][c * k*k + i * k + j] = act[b][yo*s + i - pad][xo*s + j - pad][c]  (0 outside the image, 0 for columns >= C*k*k)
+__global__ void im2col_kernel(const bf16_t* __restrict__ act, bf16_t* __restrict__ col, int H, int W, int C, int ks, int stride,
+                              int Ho, int Wo, int Kpad) {
+  const int row = blockIdx.x;                     // b * Ho * Wo + yo * Wo + xo
+  const int b = row / (Ho * Wo), r = row % (Ho * Wo), yo = r / Wo, xo = r % Wo, pad = ks >> 1, K = C * ks * ks;
+  bf16_t* o = col + (size_t)row * Kpad;
+  for (int e = threadIdx.x; e < Kpad; e += blockDim.x) {
+    bf16_t v = 0;
+    if (e < K) {
+      const int c = e / (ks * ks), i = (e / ks) % ks, j = e % ks;
+      const int y = yo * stride + i - pad, x = xo * stride + j - pad;
+      if (y >= 0 && y < H && x >= 0 && x < W) v = act[(((size_t)b * H + y) * W + x) * C + c];
+    }
+    o[e] = v;
+  }
+}
+
+// dact[b][y][x][c] (=|+=) sum over the (<= k*k) output positions that read this input pixel of dcol[(b,yo,xo)][c*k*k + i*k + j]
+__global__ void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dact, int H, int W, int C, int ks, int stride, int Ho,
+                              int Wo, int Kpad, int accumulate) {
+  const int pix = blockIdx.x;                     // b * H * W + y * W + x
+  const int b = pix / (H * W), r = pix % (H * W), y = r / W, x = r % W, pad = ks >> 1;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < ks; ++i) {
+      const int ty = y + pad - i;
+      if (ty < 0 || ty % stride) continue;
+      const int yo = ty / stride;
+      if (yo >= Ho) continue;
+      for (int j = 0; j < ks; ++j) {
+        const int tx = x + pad - j;
+        if (tx < 0 || tx % stride) continue;
+        const int xo = tx / stride;
+        if (xo >= Wo) continue;
+        s += dcol[(((size_t)b * Ho + yo) * Wo + xo) * Kpad + c * ks * ks + i * ks + j];
+      }
+    }
+    float* d = dact + (size_t)pix * C + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// W fp32 [Cout, K] -> Wb bf16 [Cout, Kpad] (zero padded) and WbT bf16 [Kpad, Cout]
+__global__ void conv_weight_prep_kernel(const float* __restrict__ Wf, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT, int Cout, int K,
+                                        int Kpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * Kpad) return;
+  const int o = i / Kpad, k = i % Kpad;
+  const bf16_t v = k < K ? f2bf(Wf[(size_t)o * K + k]) : (bf16_t)0;
+  Wb[i] = v;
+  WbT[(size_t)k * Cout + o] = v;
+}
+
+// dW (fp32 [Cout, K], +=) <- dWpad [Cout, Kpad]
+__global__ void add_unpad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int K, int Kpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * K) return;
+  dst[i] += src[(size_t)(i / K) * Kpad + i % K];
+}
+
+// ---- BatchNorm over the rows of x fp32 [rows, C] --------------------------------------------------------------------------------
+// partial column sums in double (threads of a workgroup: (256 / C) rows x C channels), combined with fp64 atomics: ws[0..C) = sum,
+// ws[C..2C) = sum of squares (forward) / sum dy', sum dy' * xhat (backward)
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dact, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float slope, double* __restrict__ ws, int rows, int C,
+                                                       int rows_per_block) {
+  const int c = threadIdx.x % C, lane_row = threadIdx.x / C, rpb = 256 / C;
+  if (lane_row >= rpb) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  double s1 = 0.0, s2 = 0.0;
+  float mu = 0.f, is = 0.f, g = 0.f, bt = 0.f;
+  if (BWD) { mu = mean[c]; is = invstd[c]; g = gamma[c]; bt = beta[c]; }
+  for (int r = r0 + lane_row; r < r1; r += rpb) {
+    const float v = x[(size_t)r * C + c];
+    if (!BWD) {
+      s1 += (double)v; s2 += (double)v * (double)v;
+    } else {
+      const float xh = (v - mu) * is, yv = g * xh + bt;
+      const float dy = dact[(size_t)r * C + c] * (yv > 0.f ? 1.0f : slope);
+      s1 += (double)dy; s2 += (double)dy * (double)xh;
+    }
+  }
+  atomicAdd(ws + c, s1);
+  atomicAdd(ws + C + c, s2);
+}
+
+// training forward: statistics of this batch -> (save_mean, save_invstd), optional running update (unbiased variance), activation
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float slope, float momentum, int update_running,
+                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd, int use_running,
+                                                      bf16_t* __restrict__ act, float* __restrict__ act_f32, int rows, int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int c = (int)(i % C);
+  float mu, var;
+  if (use_running) {
+    mu = running_mean[c]; var = running_var[c];
+  } else {
+    const double m = ws[c] / rows, v = ws[C + c] / rows - m * m;
+    mu = (float)m; var = (float)(v > 0.0 ? v : 0.0);
+  }
+  const float is = 1.0f / sqrtf(var + eps);
+  if (!use_running && i < (size_t)C) {            // the first C threads of the grid own one channel each
+    save_mean[c] = mu; save_invstd[c] = is;
+    if (update_running) {
+      const double m = ws[c] / rows, v = ws[C + c] / rows - m * m;
+      const float unb = (float)((v > 0.0 ? v : 0.0) * ((double)rows / (double)(rows > 1 ? rows - 1 : 1)));
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unb;
+    }
+  }
+  const float yv = gamma[c] * ((x[i] - mu) * is) + beta[c];
+  const float a = yv > 0.f ? yv : slope * yv;
+  if (act) act[i] = f2bf(a);
+  if (act_f32) act_f32[i] = a;
+}
+
+// dx = resid + gamma * invstd * (dy' - mean(dy') - xhat * mean(dy' * xhat));  the first C threads add dgamma / dbeta
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dact, const double* __restrict__ ws,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                          const float* __restrict__ resid, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int rows, int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int c = (int)(i % C);
+  const float mu = mean[c], is = invstd[c], g = gamma[c];
+  const float xh = (x[i] - mu) * is, yv = g * xh + beta[c];
+  const float dy = dact[i] * (yv > 0.f ? 1.0f : slope);
+  const float m1 = (float)(ws[c] / rows), m2 = (float)(ws[C + c] / rows);
+  const float v = g * is * (dy - m1 - xh * m2);
+  dx[i] = resid ? resid[i] + v : v;
+  if (i < (size_t)C) { dbeta[c] += (float)ws[c]; dgamma[c] += (float)ws[C + c]; }
+}
+
+// feat[b][c] = mean over the HW2 pixels of act_f32[b][.][c];  backward: dact[b][p][c] = dfeat[b][c] / HW2
+__global__ void avgpool_fwd_kernel(const float* __restrict__ a, float* __restrict__ feat, int HW2, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < HW2; ++p) s += a[((size_t)b * HW2 + p) * C + c];
+    feat[(size_t)b * C + c] = s / HW2;
+  }
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ da, int HW2, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // over B*HW2*C
+  const int c = (int)(i % C);
+  const size_t b = i / ((size_t)HW2 * C);
+  da[i] = dfeat[b * C + c] / HW2;
+}
+
+// classifier: logits[b][k] = feat[b] . Wc[k] + bc[k]
+__global__ void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ logits,
+                              int F, int K) {
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += feat[(size_t)b * F + f] * Wc[(size_t)k * F + f];
+    logits[(size_t)b * K + k] = s + bc[k];
+  }
+}
+// dfeat[b][f] = sum_k dlogits[b][k] Wc[k][f]        (grid = B)
+__global__ void fc_bwd_x_kernel(const float* __restrict__ dl, const float* __restrict__ Wc, float* __restrict__ dfeat, int F, int K) {
+  const int b = blockIdx.x;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += dl[(size_t)b * K + k] * Wc[(size_t)k * F + f];
+    dfeat[(size_t)b * F + f] = s;
+  }
+}
+// dWc[k][f] += sum_b dlogits[b][k] feat[b][f];  dbc[k] += sum_b dlogits[b][k]      (grid = K)
+__global__ void fc_bwd_w_kernel(const float* __restrict__ dl, const float* __restrict__ feat, float* __restrict__ dWc, float* __restrict__ dbc, int B,
+                                int F, int K) {
+  const int k = blockIdx.x;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dl[(size_t)b * K + k] * feat[(size_t)b * F + f];
+    dWc[(size_t)k * F + f] += s;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dl[(size_t)b * K + k];
+    dbc[k] += s;
+  }
+}
+
+// SGD with Nesterov momentum and weight decay on a flat fp32 block; per-chunk weight-decay flag (table of chunk ends).
+struct SgdChunk { long long end; float wd; float pad; };
+__global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, float* __restrict__ ema,
+                                                      const SgdChunk* __restrict__ table, int nchunks, long long n, float lr, float momentum,
+                                                      float grad_scale, float ema_m, int first, int zero_grad) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = nchunks - 1;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (i < table[mid].end) hi = mid; else lo = mid + 1; }
+  const float wd = table[lo].wd;
+  float d = g[i] * grad_scale;
+  const float pv = p[i];
+  if (wd != 0.f) d += wd * pv;
+  const float b = first ? d : momentum * buf[i] + d;
+  buf[i] = b;
+  const float np = pv - lr * (d + momentum * b);
+  p[i] = np;
+  if (ema) ema[i] = ema_m * ema[i] + (1.0f - ema_m) * np;
+  if (zero_grad) g[i] = 0.f;
+}
+
+}  // namespace
+
+#define LAUNCH1D(kern, n, ...) hipLaunchKernelGGL(kern, dim3(cdiv((long)(n), 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" int srhip_nchw_to_nhwc_bf16(const float* img, void* out, int B, int C, int H, int W, void* stream) {
+  if (!img || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return SR_EINVAL;
+  const long n = (long)B * C * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, C, H * W, (size_t)n);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream) {
+  if (!act || !col || B <= 0 || (ksize != 1 && ksize != 3) || stride <= 0 || Kpad < C * ksize * ksize || (Kpad % 32)) return SR_EINVAL;
+  const int pad = ksize >> 1, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  hipLaunchKernelGGL(im2col_kernel, dim3(B * Ho * Wo), dim3(Kpad >= 256 ? 256 : 64), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H,
+                     W, C, ksize, stride, Ho, Wo, Kpad);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int ksize, int stride, int Kpad, int accumulate,
+                            void* stream) {
+  if (!dcol || !dact || B <= 0 || (ksize != 1 && ksize != 3) || stride <= 0 || Kpad < C * ksize * ksize) return SR_EINVAL;
+  const int pad = ksize >> 1, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  hipLaunchKernelGGL(col2im_kernel, dim3(B * H * W), dim3(C >= 128 ? 128 : 64), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho,
+                     Wo, Kpad, accumulate);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int K, int Kpad, void* stream) {
+  if (!Wf || !Wb || !WbT || Cout <= 0 || K <= 0 || Kpad < K) return SR_EINVAL;
+  LAUNCH1D(conv_weight_prep_kernel, (long)Cout * Kpad, Wf, (bf16_t*)Wb, (bf16_t*)WbT, Cout, K, Kpad);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int K, int Kpad, void* stream) {
+  if (!src || !dst || Cout <= 0 || K <= 0 || Kpad < K) return SR_EINVAL;
+  LAUNCH1D(add_unpad_kernel, (long)Cout * K, src, dst, Cout, K, Kpad);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
+                            int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                            void* act_bf16, float* act_f32, double* ws, int rows, int C, void* stream) {
+  if (!x || !gamma || !beta || !running_mean || !running_var || rows <= 0 || C <= 0 || C > 256 || (256 % C)) return SR_EINVAL;
+  if (training && (!save_mean || !save_invstd || !ws)) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (training) {
+    if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), s) != hipSuccess) return SR_ELAUNCH;
+    const int rpb = 1024;
+    hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, ws,
+                       rows, C, rpb);
+    SR_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, ws, gamma, beta, eps, slope, momentum, update_running,
+                     running_mean, running_var, save_mean, save_invstd, !training, (bf16_t*)act_bf16, act_f32, rows, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma,
+                            const float* beta, float slope, const float* resid, float* dx, float* dgamma, float* dbeta, double* ws, int rows,
+                            int C, void* stream) {
+  if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !ws || rows <= 0 || C <= 0 || C > 256 || (256 % C))
+    return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), s) != hipSuccess) return SR_ELAUNCH;
+  const int rpb = 1024;
+  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws, rows,
+                     C, rpb);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, dact, ws, save_mean, save_invstd, gamma, beta,
+                     slope, resid, dx, dgamma, dbeta, rows, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_avgpool_fwd(const float* act, float* feat, int B, int HW2, int C, void* stream) {
+  if (!act || !feat || B <= 0 || HW2 <= 0 || C <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, act, feat, HW2, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_avgpool_bwd(const float* dfeat, float* dact, int B, int HW2, int C, void* stream) {
+  if (!dfeat || !dact || B <= 0 || HW2 <= 0 || C <= 0 || ((long)B * HW2 * C) % 64) return SR_EINVAL;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((long)B * HW2 * C / 64), dim3(64), 0, (hipStream_t)stream, dfeat, dact, HW2, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_fc_fwd(const float* feat, const float* Wc, const float* bc, float* logits, int B, int F, int K, void* stream) {
+  if (!feat || !Wc || !bc || !logits || B <= 0 || F <= 0 || K <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(fc_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, feat, Wc, bc, logits, F, K);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_fc_bwd(const float* dlogits, const float* feat, const float* Wc, float* dfeat, float* dWc, float* dbc, int B, int F, int K,
+                            void* stream) {
+  if (!dlogits || !feat || !Wc || !dfeat || !dWc || !dbc || B <= 0 || F <= 0 || K <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, dlogits, Wc, dfeat, F, K);
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, dlogits, feat, dWc, dbc, B, F, K);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_sgd_flat(float* p, float* g, float* buf, float* ema, const void* chunk_table, int nchunks, long long n, float lr,
+                              float momentum, float grad_scale, float ema_m, int first_step, int zero_grad, void* stream) {
+  if (!p || !g || !buf || !chunk_table || nchunks <= 0 || n <= 0) return SR_EINVAL;
+  LAUNCH1D(sgd_flat_kernel, n, p, g, buf, ema, (const SgdChunk*)chunk_table, nchunks, n, lr, momentum, grad_scale, ema_m, first_step, zero_grad);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

@@ -1,0 +1,299 @@
+"""WideResNet on the HIP kernels (classic_cv backbone: ``wrn_28_2``), reference semilearn/nets/wrn/wrn.py.
+
+This is the CPU-reference PARITY configuration of BASELINE.json (configs[0]: CIFAR-100 WRN-28-2 PseudoLabel + SemiReward), not
+the throughput path.  Feature maps are NHWC = row-major [B*H*W, C]; a convolution is im2col (bf16) + srhip_gemm_nt, its weight
+gradient one problem of the grouped TN GEMM, its input gradient a GEMM with the transposed filter + col2im; BatchNorm + LeakyReLU
+are column-statistic kernels.  Parameter names / order, BatchNorm buffers and state_dict keys are the reference's.
+
+BatchNorm semantics (wrn.py:32-38, core/utils/misc.py:105-129): every forward in training mode normalises with the statistics of
+ITS OWN batch, so -- unlike the ViT engine -- the passes of a step cannot be batched into one launch train; ``update_stats=False``
+is Bn_Controller.freeze_bn ... unfreeze_bn (running statistics untouched).
+"""
+import torch
+
+from .. import ops
+
+MOMENTUM, SLOPE = 0.001, 0.1
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class WrnContext:
+    """Activations of one ``save=True`` forward."""
+    __slots__ = ("B", "H", "W", "stem", "blocks", "final", "feat", "tag")
+
+
+class WideResNet:
+    def __init__(self, num_classes, depth=28, widen_factor=2, first_stride=1, device="cuda", **kw):
+        assert (depth - 4) % 6 == 0
+        self.num_classes, self.depth, self.widen, self.first_stride = num_classes, depth, widen_factor, first_stride
+        self.device = torch.device(device)
+        ch = [16, 16 * widen_factor, 32 * widen_factor, 64 * widen_factor]
+        self.channels, self.num_features = ch, ch[3]
+        n = (depth - 4) // 6
+        self.blocks = []
+        for g, stride in enumerate((first_stride, 2, 2)):
+            for i in range(n):
+                self.blocks.append(("block%d.layer.%d." % (g + 1, i), ch[g] if i == 0 else ch[g + 1], ch[g + 1], stride if i == 0 else 1, g == 0))
+        s = [("conv1.weight", (ch[0], 3, 3, 3)), ("conv1.bias", (ch[0],))]
+        for p, cin, cout, stride, _ in self.blocks:
+            s += [(p + "bn1.weight", (cin,)), (p + "bn1.bias", (cin,)), (p + "conv1.weight", (cout, cin, 3, 3)),
+                  (p + "bn2.weight", (cout,)), (p + "bn2.bias", (cout,)), (p + "conv2.weight", (cout, cout, 3, 3))]
+            if cin != cout:
+                s.append((p + "convShortcut.weight", (cout, cin, 1, 1)))
+        s += [("bn1.weight", (ch[3],)), ("bn1.bias", (ch[3],)), ("classifier.weight", (num_classes, ch[3])), ("classifier.bias", (num_classes,))]
+        self.names_shapes = s
+        self.offsets, o = {}, 0
+        for nme, shp in s:
+            self.offsets[nme] = (o, shp)
+            o += _round_up(int(torch.Size(shp).numel()), 4)          # 16-byte aligned starts (TN GEMM writes dW in place)
+        self.numel = o
+        f32 = torch.float32
+        self.flat = torch.zeros(o, dtype=f32, device=self.device)
+        self.grad = torch.zeros(o, dtype=f32, device=self.device)
+        self.bn = [(p + "bn1", cin, 1e-5) for p, cin, _, _, _ in self.blocks]       # forward order is interleaved; names only matter
+        self.bn = []
+        for p, cin, cout, _, _ in self.blocks:
+            self.bn += [(p + "bn1", cin, 1e-5), (p + "bn2", cout, 1e-5)]
+        self.bn.append(("bn1", ch[3], 1e-3))
+        self.buffers = {}
+        for nme, c, _ in self.bn:
+            self.buffers[nme + ".running_mean"] = torch.zeros(c, dtype=f32, device=self.device)
+            self.buffers[nme + ".running_var"] = torch.ones(c, dtype=f32, device=self.device)
+            self.buffers[nme + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=self.device)
+        self.eps = {nme: e for nme, _, e in self.bn}
+        # bf16 GEMM operands of every convolution: W [Cout, Kpad] and W^T [Kpad, Cout]
+        self.convs = {}
+        for nme, shp in s:
+            if len(shp) == 4:
+                cout, cin, k, _ = shp
+                K = cin * k * k
+                Kp = _round_up(K, 32)
+                self.convs[nme] = dict(cout=cout, cin=cin, k=k, K=K, Kp=Kp,
+                                       Wb=torch.zeros(cout, Kp, dtype=torch.bfloat16, device=self.device),
+                                       WbT=torch.zeros(Kp, cout, dtype=torch.bfloat16, device=self.device))
+        self.ws = torch.zeros(512, dtype=torch.float64, device=self.device)
+        self.training = True
+        self._buf_cache = {}
+
+    # ---- parameter plumbing (same surface as the ViT engine) ------------------------------------------------------------------
+    def p(self, name, buf=None):
+        o, s = self.offsets[name]
+        return (self.flat if buf is None else buf)[o:o + int(torch.Size(s).numel())]
+
+    def view(self, name, buf=None):
+        return self.p(name, buf).view(self.offsets[name][1])
+
+    def named_parameters(self):
+        return [(n, self.view(n)) for n, _ in self.names_shapes]
+
+    def named_grads(self):
+        return [(n, self.view(n, self.grad)) for n, _ in self.names_shapes]
+
+    def state_dict(self):
+        d = {n: self.view(n).detach().clone() for n, _ in self.names_shapes}
+        d.update({k: v.detach().clone() for k, v in self.buffers.items()})
+        return d
+
+    def load_state_dict(self, sd, strict=True):
+        for n, s in self.names_shapes:
+            if n in sd:
+                self.view(n).copy_(torch.as_tensor(sd[n]).to(self.device, torch.float32).reshape(s))
+            elif strict:
+                raise KeyError(n)
+        for k in self.buffers:
+            if k in sd:
+                self.buffers[k].copy_(torch.as_tensor(sd[k]).to(self.device))
+        self.refresh_operands()
+
+    def refresh_operands(self):
+        for n, c in self.convs.items():
+            ops.conv_weight_prep(self.p(n), c["Wb"], c["WbT"], c["cout"], c["K"], c["Kp"])
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def no_weight_decay(self):
+        return [n for n, _ in self.names_shapes if "bn" in n or "bias" in n]            # wrn.py:143-148
+
+    def _buf(self, key, shape, dtype):
+        t = self._buf_cache.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf_cache[key] = t
+        return t
+
+    # ---- forward ----------------------------------------------------------------------------------------------------------------
+    def _conv(self, name, act, B, H, W, stride, out, tag, bias=None, resid=None):
+        """act bf16 NHWC [B,H,W,Cin] -> out fp32 [B*Ho*Wo, Cout] (= resid + conv when resid is given).  Returns (col, Ho, Wo)."""
+        c = self.convs[name]
+        k = c["k"]
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        rows = B * Ho * Wo
+        col = self._buf((tag, name, "col"), (rows, c["Kp"]), torch.bfloat16)
+        ops.im2col(act, col, B, H, W, c["cin"], k, stride, c["Kp"])
+        if resid is None:
+            ops.gemm_nt(ops.EPI_F32, col, c["Wb"], out, rows, c["cout"], c["Kp"], bias=bias)
+        else:
+            ops.gemm_nt(ops.EPI_RESID_F32, col, c["Wb"], out, rows, c["cout"], c["Kp"], bias=bias, aux_in=resid, ldaux=c["cout"])
+        return col, Ho, Wo
+
+    def _bn_act(self, name, x, rows, C, tag, train, update, want_f32=False):
+        """BatchNorm + LeakyReLU(0.1): returns (act bf16 [rows,C], act fp32 or None, (mean, invstd))."""
+        P = self.p
+        act = self._buf((tag, name, "act"), (rows, C), torch.bfloat16)
+        af = self._buf((tag, name, "actf"), (rows, C), torch.float32) if want_f32 else None
+        mean = self._buf((tag, name, "mean"), (C,), torch.float32)
+        invstd = self._buf((tag, name, "invstd"), (C,), torch.float32)
+        ops.bn_fwd(x, P(name + ".weight"), P(name + ".bias"), self.eps[name], SLOPE, MOMENTUM, train, update,
+                   self.buffers[name + ".running_mean"], self.buffers[name + ".running_var"], mean, invstd, act, af, self.ws, rows, C)
+        if train and update:
+            self.buffers[name + ".num_batches_tracked"] += 1
+        return act, af, (mean, invstd)
+
+    def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None):
+        """img fp32 [B,3,H,W] (NCHW as the loaders deliver it).  Returns (logits [B,C], feat [B,F], ctx or None).
+        ``update_stats=False`` = forward under Bn_Controller.freeze_bn.  ``tag`` names the activation buffer set (two saved graphs of
+        a step must not share buffers)."""
+        assert img_index is None and droppath is None, "WideResNet has no DropPath and takes whole batches (BatchNorm couples the rows)"
+        B, _, H, W = img.shape
+        tag = tag or ("s" if save else "i")
+        train = self.training
+        f32 = torch.float32
+        a0 = self._buf((tag, "in"), (B, H, W, 3), torch.bfloat16)
+        ops.nchw_to_nhwc_bf16(img.contiguous(), a0, B, 3, H, W)
+        out = self._buf((tag, "stem.out"), (B * H * W, self.channels[0]), f32)
+        col0, _, _ = self._conv("conv1.weight", a0, B, H, W, 1, out, tag, bias=self.p("conv1.bias"))
+        ctx = None
+        if save:
+            ctx = WrnContext()
+            ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
+        h, w = H, W
+        for p, cin, cout, stride, abr in self.blocks:
+            equal = cin == cout
+            rows_in = B * h * w
+            o, _, st1 = self._bn_act(p + "bn1", out, rows_in, cin, tag, train, update_stats)
+            if equal or abr:
+                conv_in = o
+            else:                                             # wrn.py:50: conv1 takes the RAW x; bn1's output is unused (its statistics still move)
+                conv_in = self._buf((tag, p, "xraw"), (rows_in, cin), torch.bfloat16)
+                ops.cast_f32_bf16(out, conv_in, rows_in * cin)
+            ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+            rows_out = B * ho * wo
+            c1 = self._buf((tag, p, "c1"), (rows_out, cout), f32)
+            col1, _, _ = self._conv(p + "conv1.weight", conv_in, B, h, w, stride, c1, tag)
+            o2, _, st2 = self._bn_act(p + "bn2", c1, rows_out, cout, tag, train, update_stats)
+            y = self._buf((tag, p, "y"), (rows_out, cout), f32)
+            colS = None
+            if equal:
+                sc = out
+            else:
+                sc = self._buf((tag, p, "sc"), (rows_out, cout), f32)
+                colS, _, _ = self._conv(p + "convShortcut.weight", conv_in, B, h, w, stride, sc, tag)
+            col2, _, _ = self._conv(p + "conv2.weight", o2, B, ho, wo, 1, y, tag, resid=sc)
+            if save:
+                ctx.blocks.append(dict(x=out, st1=st1, col1=col1, c1=c1, st2=st2, col2=col2, colS=colS, h=h, w=w, ho=ho, wo=wo))
+            out, h, w = y, ho, wo
+        rows = B * h * w
+        C3 = self.channels[3]
+        _, af, stf = self._bn_act("bn1", out, rows, C3, tag, train, update_stats, want_f32=True)
+        feat = torch.empty(B, C3, dtype=f32, device=self.device)
+        logits = torch.empty(B, self.num_classes, dtype=f32, device=self.device)
+        ops.avgpool_fwd(af, feat, B, h * w, C3)
+        ops.fc_fwd(feat, self.p("classifier.weight"), self.p("classifier.bias"), logits, B, C3, self.num_classes)
+        if save:
+            ctx.final, ctx.feat = dict(x=out, st=stf, h=h, w=w), feat
+        return logits, feat, ctx
+
+    def forward(self, x, only_fc=False, only_feat=False, **kw):
+        assert not only_fc
+        logits, feat, _ = self.forward_features(x.contiguous(), save=False)
+        return feat if only_feat else {"logits": logits, "feat": feat}
+
+    __call__ = forward
+
+    # ---- backward ---------------------------------------------------------------------------------------------------------------
+    def backward(self, ctx, dlogits):
+        """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] for a save=True forward."""
+        B, tag = ctx.B, ctx.tag
+        f32, bf16 = torch.float32, torch.bfloat16
+        P, G = self.p, (lambda n: self.p(n, self.grad))
+        C3, K = self.channels[3], self.num_classes
+        problems, unpad = [], []
+
+        def conv_bwd(name, dy, rows_out, col, need_dx, Hin, Win, stride, din=None, accumulate=False):
+            """dy fp32 [rows_out, Cout] -> dW problem (deferred) and, if need_dx, d(conv input) fp32 [B*Hin*Win, Cin] (into din)."""
+            c = self.convs[name]
+            dyb = self._buf((tag, name, "dyb"), (rows_out, c["cout"]), bf16)
+            ops.cast_f32_bf16(dy, dyb, rows_out * c["cout"])
+            if c["Kp"] == c["K"]:
+                dst = self.view(name, self.grad).view(c["cout"], c["K"])
+            else:
+                dst = self._buf((tag, name, "dwpad"), (c["cout"], c["Kp"]), f32)
+                dst.zero_()
+                unpad.append((dst, name))
+            problems.append((dyb, col, dst, G("conv1.bias") if name == "conv1.weight" else None, c["cout"], c["Kp"], rows_out))
+            if not need_dx:
+                return None
+            dcol = self._buf((tag, name, "dcol"), (rows_out, c["Kp"]), f32)
+            ops.gemm_nt(ops.EPI_F32, dyb, c["WbT"], dcol, rows_out, c["Kp"], c["cout"])
+            if din is None:
+                din = self._buf((tag, name, "din"), (B * Hin * Win, c["cin"]), f32)
+            ops.col2im(dcol, din, B, Hin, Win, c["cin"], c["k"], stride, c["Kp"], accumulate=accumulate)
+            return din
+
+        # classifier, pooling, final BatchNorm
+        fin = ctx.final
+        rows = B * fin["h"] * fin["w"]
+        dfeat = self._buf((tag, "dfeat"), (B, C3), f32)
+        ops.fc_bwd(dlogits.contiguous(), ctx.feat, P("classifier.weight"), dfeat, G("classifier.weight"), G("classifier.bias"), B, C3, K)
+        dact = self._buf((tag, "dactf"), (rows, C3), f32)
+        ops.avgpool_bwd(dfeat, dact, B, fin["h"] * fin["w"], C3)
+        dy = self._buf((tag, "dy.final"), (rows, C3), f32)
+        ops.bn_bwd(dact, fin["x"], fin["st"][0], fin["st"][1], P("bn1.weight"), P("bn1.bias"), SLOPE, None, dy, G("bn1.weight"), G("bn1.bias"),
+                   self.ws, rows, C3)
+        for (p, cin, cout, stride, abr), r in zip(reversed(self.blocks), reversed(ctx.blocks)):
+            equal = cin == cout
+            rows_out, rows_in = B * r["ho"] * r["wo"], B * r["h"] * r["w"]
+            do2 = conv_bwd(p + "conv2.weight", dy, rows_out, r["col2"], True, r["ho"], r["wo"], 1)
+            dc1 = self._buf((tag, p, "dc1"), (rows_out, cout), f32)
+            ops.bn_bwd(do2, r["c1"], r["st2"][0], r["st2"][1], P(p + "bn2.weight"), P(p + "bn2.bias"), SLOPE, None, dc1, G(p + "bn2.weight"),
+                       G(p + "bn2.bias"), self.ws, rows_out, cout)
+            din = conv_bwd(p + "conv1.weight", dc1, rows_out, r["col1"], True, r["h"], r["w"], stride)
+            dx = self._buf((tag, p, "dx"), (rows_in, cin), f32)
+            if equal:
+                ops.bn_bwd(din, r["x"], r["st1"][0], r["st1"][1], P(p + "bn1.weight"), P(p + "bn1.bias"), SLOPE, dy, dx, G(p + "bn1.weight"),
+                           G(p + "bn1.bias"), self.ws, rows_in, cin)
+            else:
+                conv_bwd(p + "convShortcut.weight", dy, rows_out, r["colS"], True, r["h"], r["w"], stride, din=din, accumulate=True)
+                if abr:
+                    ops.bn_bwd(din, r["x"], r["st1"][0], r["st1"][1], P(p + "bn1.weight"), P(p + "bn1.bias"), SLOPE, None, dx,
+                               G(p + "bn1.weight"), G(p + "bn1.bias"), self.ws, rows_in, cin)
+                else:
+                    dx = din                                   # raw-x path; this bn1 feeds nothing (no gradient, as in the reference)
+            dy = dx
+        conv_bwd("conv1.weight", dy, B * ctx.H * ctx.W, ctx.stem["col"], False, ctx.H, ctx.W, 1)
+        desc, npb, ntiles, flops, nbytes = ops.make_group_tn_desc(problems, self.device)
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+        for src, name in unpad:
+            c = self.convs[name]
+            ops.add_unpad(src, self.p(name, self.grad), c["cout"], c["K"], c["Kp"])
+
+
+def wrn_28_2(num_classes=100, **kw):
+    kw = {k: v for k, v in kw.items() if k not in ("pretrained", "pretrained_path")}
+    return WideResNet(num_classes=num_classes, depth=28, widen_factor=2, first_stride=1, **kw)        # wrn.py:151-155
+
+
+def wrn_tiny_test(num_classes=10, **kw):
+    return WideResNet(num_classes=num_classes, depth=10, widen_factor=2, first_stride=1, **kw)

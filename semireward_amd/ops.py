@@ -381,3 +381,56 @@ def adamw_flat(p, g, m, v, p_bf16, ema, chunk_table, n_chunks, lr_t, wd_t, lr_fa
                ema_m=0.0, grad_scale=1.0, zero_grad=True):
     _call("srhip_adamw_flat", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(ema), _p(chunk_table), n_chunks, _p(lr_t), _p(wd_t),
           lr_factor, beta1, beta2, eps, step, ema_m, grad_scale, int(zero_grad), _s())
+
+
+# ---- WideResNet building blocks (classic_cv parity configuration) ---------------------------------------------------------------
+def nchw_to_nhwc_bf16(img, out, B, C, H, W):
+    _call("srhip_nchw_to_nhwc_bf16", _p(img), _p(out), B, C, H, W, _s())
+
+
+def im2col(act, col, B, H, W, C, ksize, stride, Kpad):
+    _call("srhip_im2col", _p(act), _p(col), B, H, W, C, ksize, stride, Kpad, _s())
+
+
+def col2im(dcol, dact, B, H, W, C, ksize, stride, Kpad, accumulate=False):
+    _call("srhip_col2im", _p(dcol), _p(dact), B, H, W, C, ksize, stride, Kpad, int(accumulate), _s())
+
+
+def conv_weight_prep(Wf, Wb, WbT, Cout, K, Kpad):
+    _call("srhip_conv_weight_prep", _p(Wf), _p(Wb), _p(WbT), Cout, K, Kpad, _s())
+
+
+def add_unpad(src, dst, Cout, K, Kpad):
+    _call("srhip_add_unpad", _p(src), _p(dst), Cout, K, Kpad, _s())
+
+
+def bn_fwd(x, gamma, beta, eps, slope, momentum, training, update_running, running_mean, running_var, save_mean, save_invstd, act_bf16,
+           act_f32, ws, rows, C):
+    _call("srhip_bn_fwd", _p(x), _p(gamma), _p(beta), eps, slope, momentum, int(training), int(update_running), _p(running_mean),
+          _p(running_var), _p(save_mean), _p(save_invstd), _p(act_bf16), _p(act_f32), _p(ws), rows, C, _s())
+
+
+def bn_bwd(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, ws, rows, C):
+    _call("srhip_bn_bwd", _p(dact), _p(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta), slope, _p(resid), _p(dx), _p(dgamma),
+          _p(dbeta), _p(ws), rows, C, _s())
+
+
+def avgpool_fwd(act, feat, B, HW2, C):
+    _call("srhip_avgpool_fwd", _p(act), _p(feat), B, HW2, C, _s())
+
+
+def avgpool_bwd(dfeat, dact, B, HW2, C):
+    _call("srhip_avgpool_bwd", _p(dfeat), _p(dact), B, HW2, C, _s())
+
+
+def fc_fwd(feat, Wc, bc, logits, B, F, K):
+    _call("srhip_fc_fwd", _p(feat), _p(Wc), _p(bc), _p(logits), B, F, K, _s())
+
+
+def fc_bwd(dlogits, feat, Wc, dfeat, dWc, dbc, B, F, K):
+    _call("srhip_fc_bwd", _p(dlogits), _p(feat), _p(Wc), _p(dfeat), _p(dWc), _p(dbc), B, F, K, _s())
+
+
+def sgd_flat(p, g, buf, ema, table, nchunks, n, lr, momentum, grad_scale=1.0, ema_m=0.0, first_step=False, zero_grad=True):
+    _call("srhip_sgd_flat", _p(p), _p(g), _p(buf), _p(ema), _p(table), nchunks, n, lr, momentum, grad_scale, ema_m, int(first_step),
+          int(zero_grad), _s())

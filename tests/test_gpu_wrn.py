@@ -1,0 +1,171 @@
+"""WideResNet engine (semireward_amd/nets/wrn.py) on the HIP kernels against vectors produced by the reference WideResNet itself
+(tests/golden/wrn.npz): eval / train / frozen-BN forwards, BatchNorm running statistics, gradients of two graphs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import wrn_ref as W                    # noqa: E402
+from oracle.gen_golden import synth_wrn_params     # noqa: E402
+from semireward_amd import ops                     # noqa: E402
+from semireward_amd.nets import wrn                # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "wrn_28_2"])
+def test_wrn_matches_reference_golden(golden, tag):
+    g = golden("wrn")
+    C, B, HW, seed = [int(v) for v in g[f"{tag}/meta"]]
+    cfg = W.WrnCfg(num_classes=C, **(W.WRN_TINY_TEST if tag == "tiny" else W.WRN_28_2))
+    model = (wrn.wrn_tiny_test if tag == "tiny" else wrn.wrn_28_2)(num_classes=C, device=DEV)
+    assert [n for n, _ in model.names_shapes] == [n for n, _ in W.param_shapes(cfg)]
+    sd = {k: torch.from_numpy(v) for k, v in synth_wrn_params(cfg, seed).items()}
+    sd.update({k[len(tag) + 6:]: torch.from_numpy(g[k]) for k in g.keys() if k.startswith(f"{tag}/buf0/")})
+    model.load_state_dict(sd)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    x = torch.from_numpy(rng.standard_normal((B, 3, HW, HW)).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((B, 3, HW, HW)).astype(np.float32)).to(DEV)
+    y = torch.from_numpy(rng.integers(0, C, size=(B,), dtype=np.int64)).to(DEV)
+    w = torch.from_numpy(rng.random(B).astype(np.float32)).to(DEV)
+    TOL = 2.5e-2                                   # bf16 conv operands through 25 convolutions + BatchNorm, fp32 reference
+    model.eval()
+    lg, ft, _ = model.forward_features(x)
+    assert rel(lg.cpu(), g[f"{tag}/eval_logits"]) < TOL and rel(ft.cpu(), g[f"{tag}/eval_feat"]) < TOL
+    model.train()
+    lg1, ft1, ctx1 = model.forward_features(x, save=True, tag="g0")                       # labelled-style forward: statistics move
+    assert rel(lg1.cpu(), g[f"{tag}/train_logits"]) < TOL and rel(ft1.cpu(), g[f"{tag}/train_feat"]) < TOL
+    for k, v in model.buffers.items():
+        if not k.endswith("num_batches_tracked"):
+            assert rel(v.cpu(), g[f"{tag}/buf1/{k}"]) < 2e-4, k                               # momentum 0.001 keeps them near buf0
+            d_ref = g[f"{tag}/buf1/{k}"] - g[f"{tag}/buf0/{k}"]
+            assert rel(v.cpu().numpy() - g[f"{tag}/buf0/{k}"], d_ref) < 6e-2, k               # the UPDATE itself (batch statistics)
+    snap = {k: v.clone() for k, v in model.buffers.items()}
+    lg2, _, ctx2 = model.forward_features(x2, save=True, update_stats=False, tag="g1")    # Bn_Controller.freeze_bn
+    assert rel(lg2.cpu(), g[f"{tag}/frozen_logits"]) < TOL
+    assert all(torch.equal(v, snap[k]) for k, v in model.buffers.items())
+    # backward of  mean(w * CE(lg1))  +  0.5 * mean(w * CE(lg2))
+    loss1, loss2 = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    dl1, dl2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    ops.masked_ce(lg1, y, w, None, 1.0, loss1, dl1, B, C)
+    ops.masked_ce(lg2, y, w, None, 0.5, loss2, dl2, B, C)
+    assert float(loss1 + 0.5 * loss2) == pytest.approx(float(g[f"{tag}/loss"]), rel=3e-2)
+    model.zero_grad()
+    model.backward(ctx1, dl1)
+    model.backward(ctx2, dl2)
+    torch.cuda.synchronize()
+    worst = []
+    for n, gr in model.named_grads():
+        gs = g.samp(f"{tag}/grad/{n}")
+        a = gr.reshape(-1).cpu().numpy()[::gs["stride"]]
+        if np.abs(gs["sample"]).max() == 0.0:                                                # the two dead bn1's: exactly no gradient
+            assert np.abs(a).max() == 0.0, n
+            continue
+        if n == "conv1.bias":       # a per-channel constant in front of a BatchNorm: analytically zero gradient, round-off in the reference
+            assert np.abs(gs["sample"]).max() < 1e-6 and np.abs(a).max() < 2e-4, (np.abs(a).max(), np.abs(gs["sample"]).max())
+            continue
+        worst.append((rel(a, gs["sample"]), n))
+    worst.sort(reverse=True)
+    # The engine differentiates ITS forward (bf16 convolution operands).  LeakyReLU has a kink: a pre-activation that lands on the other side
+    # of zero than in the fp32 forward (a ~1 % population after a few layers) has a 10x different derivative, so against the fp32 reference
+    # the gradients of a deep ReLU-type net agree only to ~20 % in L2 while every building block is exact (tests below).  The sharp check is
+    # against the oracle evaluated with bf16-rounded convolution operands: same arithmetic, same kinks.
+    assert worst[0][0] < 0.4 and np.median([v for v, _ in worst]) < 0.25, worst[:5]
+    if tag == "tiny":
+        Pt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth_wrn_params(cfg, seed).items()}
+        BUF = {k[len(tag) + 6:]: torch.from_numpy(g[k]).clone() for k in g.keys() if k.startswith(f"{tag}/buf0/")}
+        o1 = W.wrn_forward(Pt, BUF, x.cpu(), cfg, train=True, update_stats=True, bf16_operands=True)
+        o2 = W.wrn_forward(Pt, BUF, x2.cpu(), cfg, train=True, update_stats=False, bf16_operands=True)
+        ce = torch.nn.functional.cross_entropy
+        (((ce(o1["logits"], y.cpu(), reduction="none") * w.cpu()).mean()) + 0.5 * (ce(o2["logits"], y.cpu(), reduction="none") * w.cpu()).mean()).backward()
+        assert rel(lg1.cpu(), o1["logits"].detach().numpy()) < 2e-3 and rel(lg2.cpu(), o2["logits"].detach().numpy()) < 2e-3
+        errs = []
+        for n, gr in model.named_grads():
+            if Pt[n].grad is None or n == "conv1.bias":
+                continue
+            errs.append((rel(gr.cpu(), Pt[n].grad.numpy()), n))
+        errs.sort(reverse=True)
+        assert errs[0][0] < 4e-2 and np.median([v for v, _ in errs]) < 1.5e-2, errs[:5]
+
+
+@pytest.mark.parametrize("B,H,C,Cout,ks,stride", [(3, 8, 32, 64, 3, 1), (2, 8, 32, 64, 3, 2), (2, 8, 16, 32, 1, 2), (4, 4, 128, 128, 3, 1)])
+def test_conv_building_blocks(B, H, C, Cout, ks, stride):
+    """im2col + GEMM forward, GEMM + col2im input gradient, TN weight gradient against F.conv2d autograd (fp32 on the bf16-rounded
+    operands, so the comparison isolates the kernels from bf16 rounding)."""
+    import torch.nn.functional as F
+    rng = np.random.Generator(np.random.PCG64(B * 100 + C))
+    bfr = lambda a: torch.from_numpy(a).to(torch.bfloat16)   # noqa: E731
+    x = bfr(rng.standard_normal((B, H, H, C)).astype(np.float32))                  # NHWC
+    Wt = (rng.standard_normal((Cout, C, ks, ks)) / np.sqrt(C * ks * ks)).astype(np.float32)
+    K, Kp = C * ks * ks, (C * ks * ks + 31) // 32 * 32
+    pad = ks // 2
+    Ho = (H + 2 * pad - ks) // stride + 1
+    rows = B * Ho * Ho
+    xd = x.to(DEV).contiguous()
+    Wb, WbT = torch.zeros(Cout, Kp, dtype=torch.bfloat16, device=DEV), torch.zeros(Kp, Cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv_weight_prep(torch.from_numpy(Wt).to(DEV).reshape(-1), Wb, WbT, Cout, K, Kp)
+    col = torch.empty(rows, Kp, dtype=torch.bfloat16, device=DEV)
+    ops.im2col(xd, col, B, H, H, C, ks, stride, Kp)
+    out = torch.empty(rows, Cout, device=DEV)
+    ops.gemm_nt(ops.EPI_F32, col, Wb, out, rows, Cout, Kp)
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    Wr = Wb[:, :K].float().cpu().reshape(Cout, C, ks, ks).requires_grad_(True)
+    ref = F.conv2d(xr, Wr, None, stride, pad)
+    assert rel(out.cpu().reshape(B, Ho, Ho, Cout), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    dy = bfr(rng.standard_normal((rows, Cout)).astype(np.float32))
+    ref.backward(dy.float().reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2))
+    dyd = dy.to(DEV).contiguous()
+    dcol = torch.empty(rows, Kp, device=DEV)
+    ops.gemm_nt(ops.EPI_F32, dyd, WbT, dcol, rows, Kp, Cout)
+    dx = torch.full((B * H * H, C), 7.0, device=DEV)
+    ops.col2im(dcol, dx, B, H, H, C, ks, stride, Kp, accumulate=False)
+    assert rel(dx.cpu().reshape(B, H, H, C), xr.grad.permute(0, 2, 3, 1).numpy()) < 1e-5
+    dW = torch.zeros(Cout, Kp, device=DEV)
+    desc, npb, nt, _, _ = ops.make_group_tn_desc([(dyd, col, dW, None, Cout, Kp, rows)], DEV)
+    ops.gemm_tn_grouped_f32(desc, npb, nt, alpha=1.0, beta=1.0)
+    assert rel(dW[:, :K].cpu().reshape(Cout, C, ks, ks), Wr.grad.numpy()) < 1e-5
+    assert float(dW[:, K:].abs().max()) == 0.0 if Kp > K else True
+
+
+@pytest.mark.parametrize("rows,C", [(96, 32), (1024, 128), (5000, 16)])
+def test_batchnorm_leakyrelu(rows, C):
+    """srhip_bn_fwd / srhip_bn_bwd against F.batch_norm + leaky_relu autograd: batch statistics, running update (unbiased variance,
+    momentum 0.001), frozen update, eval mode, input gradient with a residual term, dgamma / dbeta."""
+    import torch.nn.functional as F
+    rng = np.random.Generator(np.random.PCG64(rows + C))
+    T = lambda a: torch.from_numpy(a.astype(np.float32))   # noqa: E731
+    x = T(rng.standard_normal((rows, C)) * 1.7 + 0.3)
+    gam, bet = T(1.0 + 0.1 * rng.standard_normal(C)), T(0.1 * rng.standard_normal(C))
+    rm0, rv0 = T(0.1 * rng.standard_normal(C)), T(1.0 + 0.2 * rng.random(C))
+    dact, resid = T(rng.standard_normal((rows, C))), T(rng.standard_normal((rows, C)))
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    y = F.leaky_relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.001, 1e-5), 0.1)
+    y.backward(dact)
+    d = lambda t: t.to(DEV).contiguous()   # noqa: E731
+    xd, gd, bd = d(x), d(gam), d(bet)
+    rmd, rvd = d(rm0), d(rv0)
+    mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    act, af = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV), torch.empty(rows, C, device=DEV)
+    ws = torch.zeros(512, dtype=torch.float64, device=DEV)
+    ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, True, True, rmd, rvd, mean, invstd, act, af, ws, rows, C)
+    assert rel(af.cpu(), y.detach().numpy()) < 2e-6 and rel(act.float().cpu(), y.detach().numpy()) < 4e-3
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-6, atol=1e-7)
+    dx, dg, db = torch.empty(rows, C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_bwd(d(dact), xd, mean, invstd, gd, bd, 0.1, d(resid), dx, dg, db, ws, rows, C)
+    assert rel(dx.cpu(), (xr.grad + resid).numpy()) < 5e-6
+    assert rel(dg.cpu(), gr.grad.numpy()) < 5e-6 and rel(db.cpu(), br.grad.numpy()) < 5e-6
+    # frozen statistics (Bn_Controller) and eval mode
+    rm1, rv1 = rmd.clone(), rvd.clone()
+    ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, True, False, rmd, rvd, mean, invstd, act, af, ws, rows, C)
+    assert torch.equal(rmd, rm1) and torch.equal(rvd, rv1) and rel(af.cpu(), y.detach().numpy()) < 2e-6
+    ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, False, False, rmd, rvd, None, None, act, af, ws, rows, C)
+    ye = F.leaky_relu(F.batch_norm(x, rm, rv, gam, bet, False, 0.001, 1e-5), 0.1)
+    assert rel(af.cpu(), ye.numpy()) < 2e-6
