@@ -423,18 +423,44 @@ class _PassModelPL(torch.nn.Module):
         return self.model(x)
 
 
-def gen_trace_pl():
-    tr = TRACE_PL
+class _CountingModel(torch.nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model, self.calls = model, 0
+
+    def forward(self, x):
+        self.calls += 1
+        return self.model(x)
+
+
+# classic_cv flavour (BASELINE.json configs[0]): WideResNet backbone (depth 10 here), SGD + Nesterov (pseudolabel_cifar100_*.yaml: lr 0.03,
+# momentum 0.9, weight_decay 1e-3), BatchNorm statistics moved by the labelled forward only (Bn_Controller)
+TRACE_PL_WRN = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=107, p_cutoff=0.15, algorithm="srpseudolabel", unsup_warm_up=0.4,
+                    backbone="wrn", lr=0.03, momentum=0.9, weight_decay=1e-3, img=8, num_warmup_iter=0)
+
+
+def gen_trace_pl_wrn():
+    gen_trace_pl(TRACE_PL_WRN, "srpseudolabel_wrn_trace.npz")
+
+
+def gen_trace_pl(tr=None, fname="srpseudolabel_trace.npz"):
+    tr = tr or TRACE_PL
+    wrnb = tr.get("backbone") == "wrn"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
-    cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
-    Fd = cfg.embed_dim
+    if wrnb:
+        wcfg = W.WrnCfg(num_classes=C, **W.WRN_TINY_TEST)
+        Fd = W.channels(wcfg)[3]
+        cfg = types.SimpleNamespace(img_size=tr["img"])
+    else:
+        cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
+        Fd = cfg.embed_dim
     srp = R.mod("semilearn.algorithms.srpseudolabel.srpseudolabel")
     sr = R.mod("semilearn.algorithms.semireward.semireward")
     hk = R.mod("semilearn.algorithms.hooks")
     cr = R.mod("semilearn.core.criterions")
     bu = R.mod("semilearn.core.utils.build")
     misc = R.mod("semilearn.core.utils.misc")
-    model = build_ref_vit(V.VIT_TINY_TEST, C, synth.synth_params(V.param_shapes(cfg), seed))
+    model = build_ref_wrn(wcfg, synth_wrn_params(wcfg, seed)) if wrnb else build_ref_vit(V.VIT_TINY_TEST, C, synth.synth_params(V.param_shapes(cfg), seed))
     model.train()
     alg = object.__new__(srp.SRPseudoLabel)
     alg.args = types.SimpleNamespace()
@@ -456,7 +482,9 @@ def gen_trace_pl():
     alg.hooks_dict = OrderedDict()
     alg.register_hook(hk.PseudoLabelingHook(), "PseudoLabelingHook")
     alg.register_hook(hk.FixedThresholdingHook(), "MaskingHook")
-    alg.optimizer = bu.get_optimizer(model, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+    alg.optimizer = bu.get_optimizer(model, "SGD", tr["lr"], tr["momentum"], tr["weight_decay"], 1.0) if wrnb else \
+        bu.get_optimizer(model, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+    base_lr = tr["lr"] if wrnb else 5e-4
     alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
     out, prev_it = {}, -1
     for n, it in enumerate(tr["its"]):
@@ -466,9 +494,12 @@ def gen_trace_pl():
         alg.it = it
         K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
         b = synth.synth_batch(seed + 10 + n, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
-        dps = [synth.synth_droppath(seed + 1000 * (n + 1), V.drop_path_probs(cfg), Bl)] + \
-              [synth.synth_droppath(seed + 1000 * (n + 1) + 1 + k, V.drop_path_probs(cfg), Bu) for k in range(K + 1)]
-        alg.model = _PassModelPL(model, dps)
+        if wrnb:
+            alg.model = _CountingModel(model)
+        else:
+            dps = [synth.synth_droppath(seed + 1000 * (n + 1), V.drop_path_probs(cfg), Bl)] + \
+                  [synth.synth_droppath(seed + 1000 * (n + 1) + 1 + k, V.drop_path_probs(cfg), Bu) for k in range(K + 1)]
+            alg.model = _PassModelPL(model, dps)
         rec = []
         mh = alg.hooks_dict["MaskingHook"]
         orig = mh.masking
@@ -485,8 +516,8 @@ def gen_trace_pl():
         o["loss"].backward()
         p = f"it{it}"
         for nme, prm in model.named_parameters():
-            flat(f"{p}/grad/{nme}", samp(prm.grad.numpy(), 64), out)
-        out[f"{p}/lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / 5e-4)
+            flat(f"{p}/grad/{nme}", samp(prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32), 64), out)
+        out[f"{p}/lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / base_lr)
         alg.optimizer.step(); alg.scheduler.step(); model.zero_grad()
         for k_, v in log.items():
             out[f"{p}/log/{k_.split('/')[-1]}"] = np.float64(v)
@@ -500,10 +531,14 @@ def gen_trace_pl():
         for nme, prm in model.named_parameters():
             flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
         out[f"{p}/max_reward"] = np.float64(float(alg.max_reward))
+        if wrnb:
+            for nme, c_, _ in W.bn_names(wcfg):
+                m_ = dict(model.named_modules())[nme]
+                out[f"{p}/buf/{nme}.running_mean"] = m_.running_mean.numpy().copy(); out[f"{p}/buf/{nme}.running_var"] = m_.running_var.numpy().copy()
     out["meta/its"] = np.array(tr["its"], dtype=np.int64)
     allm = np.concatenate([out[f"it{it}/masks"].ravel() for it in tr["its"]])
-    print("srpseudolabel_trace.npz mask mean", allm.mean())
-    np.savez_compressed(os.path.join(OUT, "srpseudolabel_trace.npz"), **out)
+    print(fname, "mask mean", allm.mean())
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 TRACE_FREE = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=97, algorithm="srfreematch", ema_p=0.9, use_quantile=True,
@@ -673,7 +708,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
-            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn)
+            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -55,7 +55,21 @@ class SRPseudoLabel(SRConsistencyBase):
         dpc = None
         if self.inject_droppath is not None:        # tests: [ (dp_lb, dp_ulb), dp_ulb(pass 1), ... ]
             dpc = torch.cat([self.inject_droppath[0][0], self.inject_droppath[0][1]] + list(self.inject_droppath[1:P]), dim=2)
-        logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
+        bn_backbone = getattr(self.model, "couples_batch_rows", False)
+        if bn_backbone:
+            # BatchNorm backbone (classic_cv, WRN): every model call of the reference is its own statistics group, so the calls stay
+            # separate launches -- model(x_lb) moves the running statistics (:96), every model(x_ulb_w) runs under Bn_Controller.freeze_bn
+            # (:100-110, :65-76).  Only the labelled forward and the LAST unlabelled forward carry a gradient.
+            lg_lb, ft_lb, ctx_lb = self.model.forward_features(x_lb.contiguous(), save=True, update_stats=True, tag="lb")
+            lws, fws, ctx_u = [], [], None
+            xu = x_ulb_w.contiguous()
+            for k in range(P):
+                lg, ft, cx = self.model.forward_features(xu, save=(k == K), update_stats=False, tag="ulb" if k == K else "ulb_inf")
+                lws.append(lg); fws.append(ft)
+                ctx_u = cx if k == K else ctx_u
+            logits, feats, ctx = torch.cat([lg_lb] + lws), torch.cat([ft_lb] + fws), (ctx_lb, ctx_u)
+        else:
+            logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
         # weak logits of every pass -> softmax max / argmax in one launch (FixedThresholdingHook softmaxes logits, masking.py:48-50)
         Lw = torch.cat([logits[sl] for sl in pl.weak])                                              # [P*nu, C]
         Fw = torch.cat([feats[sl] for sl in pl.weak])
@@ -78,7 +92,11 @@ class SRPseudoLabel(SRConsistencyBase):
         else:
             reward = mask2 = None
             unsup_loss, dl_u = self.consistency_loss(Lw[:nu], pl0, "ce", mask=masks[0], grad_scale=self.lambda_u * warm)   # :130
-        self.model.backward(ctx, torch.cat((dl_lb, dl_u)))
+        if bn_backbone:
+            self.model.backward(ctx[0], dl_lb)
+            self.model.backward(ctx[1], dl_u)
+        else:
+            self.model.backward(ctx, torch.cat((dl_lb, dl_u)))
         fx, fu0 = feats[:nl], feats[nl:nl + nu]
         if it > 0:                                                                                  # :135-191
             if it >= self.start_timing:

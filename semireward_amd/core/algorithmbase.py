@@ -17,7 +17,7 @@ import torch
 
 from .. import ops
 from ..distributed import DataParallel
-from ..optim import FusedAdamW
+from ..optim import FusedAdamW, FusedSGD
 from .criterions import CELoss, ConsistencyLoss
 from .hooks import EMAHook, Hook, ParamUpdateHook, get_priority
 
@@ -120,11 +120,17 @@ class AlgorithmBase:
             return self.model        # ema_m == 0 -> shadow == params after every step (misc.py:152-155): alias, 0 bytes moved
         ema = self.net_builder(num_classes=self.num_classes, device=self.device)
         ema.load_state_dict(self.model.state_dict())
+        if hasattr(ema, "buffers"):          # BatchNorm statistics are not averaged: EMAHook copies the model's (core/hooks/ema.py:20-24)
+            ema.buffers = self.model.buffers
         return ema
 
     def set_optimizer(self):
         a = self.args
-        assert getattr(a, "optim", "AdamW") == "AdamW", "the ViT/BERT SemiReward configs use AdamW (SGD: classic_cv row, later)"
+        if getattr(a, "optim", "AdamW") == "SGD":         # classic_cv configs (WRN): SGD + Nesterov momentum, no layer decay
+            assert getattr(a, "layer_decay", 1.0) == 1.0
+            opt = FusedSGD(self.model, a.lr, getattr(a, "momentum", 0.9), getattr(a, "weight_decay", 0.0), self.num_train_iter,
+                           getattr(a, "num_warmup_iter", 0))
+            return opt, opt
         opt = FusedAdamW(self.model, a.lr, getattr(a, "weight_decay", 0.0), getattr(a, "layer_decay", 1.0),
                          self.num_train_iter, getattr(a, "num_warmup_iter", 0))
         return opt, opt      # optimizer and scheduler are one fused object
@@ -218,6 +224,8 @@ class AlgorithmBase:
         net = self.ema_model
         if net is not self.model:
             net.refresh_operands()                    # bf16 operand copy of the EMA block
+        was_training = getattr(net, "training", True)
+        net.training = False                          # BatchNorm backbones: running statistics (model.eval(), :381)
         loader = loader if loader is not None else self.loader_dict[eval_dest]
         C = self.num_classes
         logits_all, y_all = [], []
@@ -236,6 +244,7 @@ class AlgorithmBase:
                 logits_all.append(lg)
                 y_all.append(y)
                 total += B
+        net.training = was_training
         logits = torch.cat(logits_all)
         y_true = torch.cat(y_all).cpu().numpy()
         y_pred = logits.argmax(dim=-1).cpu().numpy()

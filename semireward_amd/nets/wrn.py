@@ -76,6 +76,7 @@ class WideResNet:
                                        WbT=torch.zeros(Kp, cout, dtype=torch.bfloat16, device=self.device))
         self.ws = torch.zeros(512, dtype=torch.float64, device=self.device)
         self.training = True
+        self.couples_batch_rows = True      # BatchNorm: every forward call is its own statistics group (no cross-pass batching)
         self._buf_cache = {}
 
     # ---- parameter plumbing (same surface as the ViT engine) ------------------------------------------------------------------

@@ -97,3 +97,49 @@ class FusedAdamW:
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.step_count, self.sched_step = int(sd["step"]), int(sd["sched_step"])
+
+
+class FusedSGD:
+    """torch.optim.SGD(momentum, nesterov=True) with the reference's two weight-decay groups (core/utils/build.py:193-224 with
+    layer_decay == 1: nets/utils.py:77-97 -- no decay for 1-D parameters, ``.bias`` and the model's ``no_weight_decay()`` names) and the
+    cosine LambdaLR, as ONE launch per step over the flat block (the classic_cv configs, e.g. WRN-28-2: lr 0.03, momentum 0.9)."""
+
+    def __init__(self, model, lr, momentum, weight_decay, num_train_iter, num_warmup_iter, nesterov=True):
+        assert nesterov, "the reference builds SGD with nesterov=True (build.py:193)"
+        import numpy as np
+        self.model = model
+        dev = model.flat.device
+        ns = model.names_shapes
+        nwd = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
+        ends = [model.offsets[n][0] for n, _ in ns][1:] + [model.numel]          # a parameter's chunk runs to the next one's start
+        tab = np.zeros(len(ns), dtype=[("end", "<i8"), ("wd", "<f4"), ("pad", "<f4")])
+        for i, (n, shp) in enumerate(ns):
+            tab[i] = (ends[i], 0.0 if (len(shp) <= 1 or n.endswith(".bias") or n in nwd) else weight_decay, 0.0)
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        self.nchunks = len(ns)
+        self.buf = torch.zeros_like(model.flat)
+        self.momentum, self.base_lr = momentum, lr
+        self.num_train_iter, self.num_warmup_iter = num_train_iter, num_warmup_iter
+        self.step_count = 0
+        self.sched_step = 0
+
+    def lr_factor(self):
+        return cosine_with_warmup(self.sched_step, self.num_train_iter, self.num_warmup_iter)
+
+    def get_last_lr(self):
+        return [self.base_lr * self.lr_factor()]
+
+    def step(self, ema=None, ema_m=0.0, grad_scale=1.0):
+        ops.sgd_flat(self.model.flat, self.model.grad, self.buf, ema, self.table, self.nchunks, self.model.numel,
+                     self.base_lr * self.lr_factor(), self.momentum, grad_scale=grad_scale, ema_m=ema_m, first_step=self.step_count == 0,
+                     zero_grad=True)
+        self.step_count += 1
+        self.model.refresh_operands()
+        self.sched_step += 1
+
+    def state_dict(self):
+        return dict(momentum_buffer=self.buf.cpu(), step=self.step_count, sched_step=self.sched_step)
+
+    def load_state_dict(self, sd):
+        self.buf.copy_(sd["momentum_buffer"])
+        self.step_count, self.sched_step = int(sd["step"]), int(sd["sched_step"])

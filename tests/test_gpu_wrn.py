@@ -169,3 +169,68 @@ def test_batchnorm_leakyrelu(rows, C):
     ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, False, False, rmd, rvd, None, None, act, af, ws, rows, C)
     ye = F.leaky_relu(F.batch_norm(x, rm, rv, gam, bet, False, 0.001, 1e-5), 0.1)
     assert rel(af.cpu(), ye.numpy()) < 2e-6
+
+
+def test_srpseudolabel_wrn_trace(golden):
+    """BASELINE.json configs[0] (classic_cv: WideResNet + PseudoLabel + SemiReward, SGD) end to end on the HIP engine against a trace of
+    the reference: per-pass masks, losses, features, BatchNorm running statistics (moved by the labelled forward only), rewarder updates,
+    parameters after the fused SGD steps."""
+    import argparse
+    from oracle import semireward_ref as S
+    from oracle.gen_golden import TRACE_PL_WRN as tr
+    from semireward_amd.algorithms import get_algorithm
+    from semireward_amd.utils import synth
+    g = golden("srpseudolabel_wrn_trace")
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    wcfg = W.WrnCfg(num_classes=C, **W.WRN_TINY_TEST)
+    Fd = W.channels(wcfg)[3]
+    args = argparse.Namespace(
+        algorithm="srpseudolabel", num_classes=C, num_train_iter=tr["num_train_iter"], epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=True,
+        amp=False, optim="SGD", lr=tr["lr"], momentum=tr["momentum"], weight_decay=tr["weight_decay"], layer_decay=1.0,
+        num_warmup_iter=tr["num_warmup_iter"], p_cutoff=tr["p_cutoff"], unsup_warm_up=tr["unsup_warm_up"], N_k=tr["N_k"],
+        start_timing=tr["start_timing"], feature_dim=Fd, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1,
+        distributed=False, T=0.5, hard_label=True)
+    alg = get_algorithm(args, wrn.wrn_tiny_test)
+    Tn = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
+    alg.model.load_state_dict(Tn(synth_wrn_params(wcfg, seed)))
+    alg.rewarder.load_state_dict(Tn(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)))
+    alg.generator.load_state_dict(Tn(synth.synth_params(S.generator_shapes(Fd), seed + 2)))
+    flips = total = 0
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        alg.it = it
+        alg.optimizer.sched_step = it
+        K = int(g[f"{p}/K"])
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, tr["img"], C, tr["ulb_dest_len"])
+        alg.trace = {}
+        before = alg.rewarder.flat.clone()
+        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+        alg.out_dict, alg.log_dict = out, log
+        assert alg.optimizer.lr_factor() == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        alg.call_hook("after_train_step")
+        assert alg.trace["K"] == K
+        masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
+        bad = masks != g[f"{p}/masks"]
+        flips += int(bad.sum()); total += bad.size
+        mpv = alg.trace["max_probs"].cpu().numpy().reshape(masks.shape)
+        assert np.all(np.abs(mpv[bad] - tr["p_cutoff"]) < 8e-3), (p, mpv[bad])        # a flipped row sits ON the threshold
+        for k_, v in alg.model.buffers.items():                                         # statistics: labelled forward only, momentum 0.001
+            if not k_.endswith("num_batches_tracked"):
+                # running_mean starts at 0: after a few steps it IS momentum * (bf16-affected batch means of a drifting trajectory, same
+                # growth as the feature tolerance below); running_var starts at 1
+                assert rel(v.cpu(), g[f"{p}/buf/{k_}"]) < (5e-2 + 2e-2 * n if k_.endswith("running_mean") else 1e-3), (p, k_)
+        assert int(alg.model.buffers["bn1.num_batches_tracked"]) == n + 1
+        assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+        if bad.any():
+            continue
+        for k_ in ("sup_loss", "unsup_loss", "total_loss"):
+            assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
+        for k_ in ("x_lb", "x_ulb_w"):
+            assert rel(out["feat"][k_].cpu(), g[f"{p}/feat/{k_}"]) < 5e-2 + 2e-2 * n, (p, k_)
+    assert flips <= 0.05 * total, (flips, total)
+    worst = 0.0
+    for nme, v in alg.model.named_parameters():                                        # 6 SGD steps at lr 0.03 (LeakyReLU-kink gradient noise, see above)
+        gs = g.samp(f"it{tr['its'][-1]}/param/{nme}")
+        a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
+        worst = max(worst, float(np.abs(a - gs["sample"]).max()))
+    assert worst < 3e-2, worst

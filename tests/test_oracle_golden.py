@@ -378,3 +378,37 @@ def test_wrn_oracle_matches_reference(golden, tag):
     for n, _ in W.param_shapes(cfg):
         gr = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
         check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 2e-3, 1e-6, f"{tag} grad {n}")
+
+
+def test_srpseudolabel_wrn_trace(golden):
+    """SRPseudoLabel on the WideResNet backbone with SGD (classic_cv, BASELINE.json configs[0]) against a trace of the reference itself:
+    masks of every pass, losses, BatchNorm running statistics (labelled forward only), gradients, parameters after the SGD steps."""
+    from oracle import wrn_ref as W
+    from oracle.gen_golden import TRACE_PL_WRN as tr, synth_wrn_params
+    from oracle.srpseudolabel_ref import SRPseudoLabelWrnOracle
+    g = golden("srpseudolabel_wrn_trace")
+    C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
+    wcfg = W.WrnCfg(num_classes=C, **W.WRN_TINY_TEST)
+    Fd = W.channels(wcfg)[3]
+    orc = SRPseudoLabelWrnOracle(
+        wcfg, TP(synth_wrn_params(wcfg, seed)), W.init_buffers(wcfg), TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
+        TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)), num_train_iter=tr["num_train_iter"], start_timing=tr["start_timing"],
+        N_k=tr["N_k"], p_cutoff=tr["p_cutoff"], num_warmup_iter=tr["num_warmup_iter"], unsup_warm_up=tr["unsup_warm_up"], lr=tr["lr"],
+        momentum=tr["momentum"], weight_decay=tr["weight_decay"])
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        orc.it = it
+        b = synth.synth_batch(seed + 10 + n, Bl, Bu, tr["img"], C, tr["ulb_dest_len"])
+        t = orc.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["x_ulb_w"]))
+        assert t["K"] == int(g[f"{p}/K"])
+        assert np.array_equal(np.stack([q["mask"].numpy() for q in t["passes"]]), g[f"{p}/masks"]), p
+        for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+            assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=3e-5, abs=3e-6), (p, k_)
+        assert t["lr_factor"] == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9)
+        for k_, v in orc.BUF.items():
+            np.testing.assert_allclose(v.numpy(), g[f"{p}/buf/{k_}"], rtol=2e-6, atol=1e-7, err_msg=f"{p} {k_}")
+        for nme, _ in W.param_shapes(wcfg):
+            check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 3e-3, 3e-6, f"{p} grad {nme}")
+            check_samp(orc.P[nme].numpy(), g.samp(f"{p}/param/{nme}"), 2e-4, 2e-5, f"{p} param {nme}")
+    allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
+    assert 0.05 < allm.mean() < 0.95
