@@ -69,6 +69,8 @@ def install():
     _stub("semilearn.nets", S + "/nets")
     _stub("semilearn.nets.vit", S + "/nets/vit")
     _stub("semilearn.nets.wrn", S + "/nets/wrn")
+    _stub("semilearn.nets.bert", S + "/nets/bert")
+    _stub("semilearn.nets.wave2vecv2", S + "/nets/wave2vecv2")
     _stub("semilearn.algorithms", S + "/algorithms")
     for a in ("srflexmatch", "srfixmatch", "srpseudolabel", "srsoftmatch", "srfreematch",
               "flexmatch", "freematch", "softmatch"):

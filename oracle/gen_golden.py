@@ -22,6 +22,7 @@ from oracle import _ref_import as R  # noqa: E402
 from oracle import semireward_ref as S  # noqa: E402
 from oracle import vit_ref as V  # noqa: E402
 from oracle import wrn_ref as W  # noqa: E402
+from oracle import bert_ref as BR  # noqa: E402
 from semireward_amd.utils import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -285,6 +286,80 @@ def gen_wrn():
             flat(f"{tag}/grad/{n}", samp(p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32), 256), out)
         out[f"{tag}/meta"] = np.array([C, B, HW, seed], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "wrn.npz"), **out)
+
+
+def build_ref_bert(cfg, params):
+    """The reference ClassificationBert around a randomly initialised HF BertModel (``from_pretrained`` needs the network): the module is
+    assembled field by field exactly as bert.py:10-20 does, its forward is the reference's.  attn_implementation='eager' so that the
+    attention-probability dropout is an F.dropout call the generator can feed (same arithmetic as the default sdpa path)."""
+    import torch.nn as nn
+    from transformers import BertConfig, BertModel
+    bm = R.mod("semilearn.nets.bert.bert")
+    hc = BertConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                    intermediate_size=cfg.inter, max_position_embeddings=cfg.max_pos, attn_implementation="eager")
+    model = bm.ClassificationBert.__new__(bm.ClassificationBert)
+    nn.Module.__init__(model)
+    model.bert = BertModel(hc)
+    model.dropout = torch.nn.Dropout(p=0.1, inplace=False)
+    model.num_features = cfg.hidden
+    model.classifier = nn.Sequential(nn.Linear(cfg.hidden, cfg.hidden), nn.GELU(), nn.Linear(cfg.hidden, cfg.num_classes))
+    assert [n for n, _ in model.named_parameters()] == [n for n, _ in BR.param_shapes(cfg)]
+    load_module_params(model, params)
+    return model
+
+
+class InjectedDropout:
+    """Feeds the shared counter-based masks (oracle/bert_ref.keep_mask) to every F.dropout call of one reference forward, in call
+    order: embeddings, (attention probs, attention output, FFN output) per layer, head."""
+
+    def __init__(self, cfg, seed):
+        self.sites = [BR.SITE_EMB] + [4 * i + k for i in range(cfg.layers) for k in (BR.SITE_PROBS, BR.SITE_ATTN_OUT, BR.SITE_FFN_OUT)] + [BR.SITE_HEAD]
+        self.seed, self.p, self.n = seed, cfg.p_drop, 0
+
+    def __enter__(self):
+        self.orig = F.dropout
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            assert training and abs(p - self.p) < 1e-12
+            site = self.sites[self.n]; self.n += 1
+            return x * T(BR.keep_mask(self.seed, site, tuple(x.shape), p).astype(np.float32) / np.float32(1.0 - p))
+        torch.nn.functional.dropout = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.functional.dropout = self.orig
+        assert self.n == len(self.sites), (self.n, len(self.sites))
+
+
+def gen_bert():
+    """ClassificationBert (bert.py) on a random-init HF BertModel (transformers %s): eval forward, train forward with injected dropout,
+    gradients of a weighted CE.  Third-party arithmetic: the reference has no tests at this boundary; these vectors pin it."""
+    import transformers
+    out = {"meta/transformers_version": np.array(transformers.__version__)}
+    for tag, cfgd, C, B, L, seed in [("tiny", BR.BERT_TINY_TEST, 4, 5, 24, 71), ("base", BR.BERT_BASE, 4, 2, 80, 72)]:
+        cfg = BR.BertCfg(num_classes=C, **cfgd)
+        params = BR.synth_params(cfg, seed)
+        ids, mask = BR.synth_tokens(seed + 1, B, L, cfg.vocab)
+        rng = np.random.Generator(np.random.PCG64(seed + 2))
+        y, w = rng.integers(0, C, size=(B,), dtype=np.int64), rng.random(B).astype(np.float32)
+        model = build_ref_bert(cfg, params)
+        x = {"input_ids": T(ids), "attention_mask": T(mask)}
+        model.eval()
+        with torch.no_grad():
+            o = model(x)
+        out[f"{tag}/eval_logits"], out[f"{tag}/eval_feat"] = o["logits"].numpy(), o["feat"].numpy()
+        model.train()
+        dseed = (seed << 32) + 5
+        with InjectedDropout(cfg, dseed):
+            o = model(x)
+            loss = (F.cross_entropy(o["logits"], T(y), reduction="none") * T(w)).mean()
+        loss.backward()
+        out[f"{tag}/train_logits"], out[f"{tag}/train_feat"] = o["logits"].detach().numpy(), o["feat"].detach().numpy()
+        out[f"{tag}/loss"] = np.float32(loss.item())
+        for n, p in model.named_parameters():      # pooler: a parameter of the module that feeds nothing here -> grad None
+            flat(f"{tag}/grad/{n}", samp(p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32), 256), out)
+        out[f"{tag}/meta"] = np.array([C, B, L, seed, dseed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "bert.npz"), **out)
 
 
 def gen_vit_p16():
@@ -708,7 +783,8 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
-            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn)
+            trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
+            bert=gen_bert)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

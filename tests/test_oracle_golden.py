@@ -412,3 +412,33 @@ def test_srpseudolabel_wrn_trace(golden):
             check_samp(orc.P[nme].numpy(), g.samp(f"{p}/param/{nme}"), 2e-4, 2e-5, f"{p} param {nme}")
     allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
     assert 0.05 < allm.mean() < 0.95
+
+
+@pytest.mark.parametrize("tag", ["tiny", "base"])
+def test_bert_oracle_matches_reference(golden, tag):
+    """oracle/bert_ref.py against the reference ClassificationBert on a random-init HF BertModel (third-party arithmetic pinned by these
+    vectors): eval forward, train forward with the shared counter-based dropout masks, gradients of a weighted CE."""
+    from oracle import bert_ref as BR
+    g = golden("bert")
+    C, B, L, seed, dseed = [int(v) for v in g[f"{tag}/meta"]]
+    cfg = BR.BertCfg(num_classes=C, **(BR.BERT_TINY_TEST if tag == "tiny" else BR.BERT_BASE))
+    P = {k: T(v).requires_grad_(True) for k, v in BR.synth_params(cfg, seed).items()}
+    ids, mask = (T(a) for a in BR.synth_tokens(seed + 1, B, L, cfg.vocab))
+    assert int(mask.sum(1).min()) < L and int(mask.sum(1).max()) == L            # ragged batch, longest row fills L
+    rng = np.random.Generator(np.random.PCG64(seed + 2))
+    y, w = T(rng.integers(0, C, size=(B,), dtype=np.int64)), T(rng.random(B).astype(np.float32))
+    with torch.no_grad():
+        o = BR.bert_forward(P, ids, mask, cfg)
+    np.testing.assert_allclose(o["logits"].numpy(), g[f"{tag}/eval_logits"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(o["feat"].numpy(), g[f"{tag}/eval_feat"], rtol=2e-4, atol=2e-5)
+    o = BR.bert_forward(P, ids, mask, cfg, seed=dseed)
+    np.testing.assert_allclose(o["logits"].detach().numpy(), g[f"{tag}/train_logits"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(o["feat"].detach().numpy(), g[f"{tag}/train_feat"], rtol=2e-4, atol=2e-5)
+    loss = (torch.nn.functional.cross_entropy(o["logits"], y, reduction="none") * w).mean()
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g[f"{tag}/loss"]), rel=1e-5)
+    for n, _ in BR.param_shapes(cfg):
+        gr = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
+        check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 2e-3, 1e-6, f"{tag} grad {n}")
+    keep = BR.keep_mask(dseed, 7, (1 << 20,), 0.1)
+    assert abs(keep.mean() - 0.9) < 2e-3                                          # the shared generator is a fair Bernoulli(0.9)
