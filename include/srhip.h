@@ -39,6 +39,13 @@ int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, 
                   const float* bias, const float* row_scale, int rows_per_sample, const void* aux_in, void* aux_out,
                   int ldaux, float alpha, float beta, void* stream);
 
+/* SRHIP_EPI_RESID_F32 with nn.Dropout on the branch: C(f32)[M,N] = resid (f32, ldresid; NULL: C) + dropout(acc + bias) -- the
+ * ``LayerNorm(x + dropout(dense(.)))`` of BertSelfOutput / BertOutput (reached from semilearn/nets/bert/bert.py:34) before the LayerNorm.
+ * Mask element index = m * N + n (ldc == N required), generator as in srhip_attn_masked_fwd. */
+int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                const float* bias, const float* resid, int ldresid, unsigned drop_key, unsigned drop_thresh,
+                                float drop_scale, void* stream);
+
 /* Grouped variant for the fp32 weight-gradient products (dW = dY^T X of every block, reference: autograd of the same
  * nn.Linear call sites): C_p = alpha * A_p . B_p^T + beta * C_p for n_problems independent products in ONE launch.
  * desc_dev: DEVICE array; tile_start = running sum of ceil(M/128)*ceil(N/128) over the preceding problems;
@@ -65,9 +72,21 @@ int srhip_gemm_tn_grouped_f32(const srhip_group_tn_desc* desc_dev, int n_problem
 /* Fused attention, head_dim 64.  qkv bf16 [B*N, 3*H*64] as written by the qkv Linear; out bf16 [B*N, H*64];
  * lse fp32 [B,H,N] (NULL when no backward is needed).  Replaces vit.py:100-104 (K4).  N <= 512. */
 int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);
-/* dqkv bf16 [B*N, 3*H*64]; delta_ws fp32 [B,H,N] scratch.  Autograd backward of vit.py:100-104.  N <= 288. */
+/* dqkv bf16 [B*N, 3*H*64]; delta_ws fp32 [B,H,N] scratch.  Autograd backward of vit.py:100-104.  N <= 512. */
 int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, float* delta_ws,
                    int B, int N, int H, float scale, void* stream);
+
+/* Padding-aware variants for the BERT / Wav2Vec2 encoders (semilearn/nets/bert/bert.py:34 -> transformers BertSelfAttention;
+ * wave2vecv2/wave2vecv2.py:44 -> Wav2Vec2Attention): key_len int32 [B] = number of valid (non-padding) keys of every sequence of a
+ * right-padded batch (NULL: all N), equivalent to the additive -inf attention mask; every query row is computed.  drop_*: train-mode
+ * nn.Dropout on the probabilities from the counter-based generator shared by all dropout sites (element kept iff
+ * fmix32(i * 0x9E3779B1 + drop_key) >= drop_thresh, i = ((b*H + h)*N + q)*N + key; kept values * drop_scale; drop_thresh == 0: none).
+ * N <= 512 forward AND backward (N > 288: V fragments of the dQ pass come from L2 instead of LDS).  B*H*N*N < 2^32. */
+int srhip_attn_masked_fwd(const void* qkv, void* out, float* lse, const int* key_len, int B, int N, int H, float scale,
+                          unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_attn_masked_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, float* delta_ws,
+                          const int* key_len, int B, int N, int H, float scale, unsigned drop_key, unsigned drop_thresh,
+                          float drop_scale, void* stream);
 
 /* nn.LayerNorm over the last dim (vit.py:135,150,268; eps 1e-6 :222) (K2).  x fp32 [M,D] -> out bf16 [M,D];
  * mean/rstd fp32 [M] are written when non-NULL (needed by the backward).  D in {128, 384, 768}. */
@@ -225,6 +244,35 @@ int srhip_adam_flat(float* p, const float* g, float* m, float* v, long n, float 
 int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, float* ema, const int* chunk_table, int n_chunks,
                      const float* lr_t, const float* wd_t, float lr_factor, float beta1, float beta2, float eps, int step,
                      float ema_m, float grad_scale, int zero_grad, void* stream);
+
+/* ---- post-LN transformer encoder glue (BERT / Wav2Vec2 backbones; semilearn/nets/bert/bert.py, wave2vecv2/wave2vecv2.py and the HF modules
+ * they call).  D in {128, 384, 768}; dropout arguments as in srhip_attn_masked_fwd with element index = row * D + column.
+ *   embed_ln_fwd : BertEmbeddings -- x = dropout(LayerNorm(word[ids[seq][p]] + pos[p] + type0)) for row (b, p) of a [B, L] batch; ids int64
+ *                  [*, ld_ids], seq_index int32 [B] picks the row of ids (NULL: identity); x fp32 and bf16 [B*L, D]; mean/rstd [B*L] optional
+ *   embed_ln_bwd : its backward from dy = d/dx: dword[id] += (rows with id == pad_id excluded: nn.Embedding(padding_idx)), dpos[p] +=,
+ *                  dtype0 +=, dgamma +=, dbeta +=  (atomic)
+ *   postln_fwd   : x = LayerNorm(y) as fp32 (next residual) and bf16 (next GEMM operand); x may alias y
+ *   postln_bwd   : dy = d/d(LayerNorm output) -> dx = d/dy fp32 (may alias dy) and dx_bf16 = dropout-masked dx (the gradient of the branch that
+ *                  was added under dropout: operand of its dX / dW products); dgamma +=, dbeta += (atomic)
+ *   meanpool_fwd : feat[b] = mean over ALL L rows of dropout(x[b])  (bert.py:36-37, padding included);  meanpool_bwd: dx = its adjoint
+ *   gelu_f32 / gelu_bwd_f32 : nn.GELU() between the classifier Linears (bert.py:16-20; the Linears are srhip_fc_fwd / srhip_fc_bwd)
+ *   mask_lengths : key_len[b] = sum(attention_mask[b, :]) for the right-padded batches of nlp_collactor.py:63-69 */
+int srhip_embed_ln_fwd(const long long* ids, int ld_ids, const int* seq_index, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* beta, float eps, float* x, void* x_bf16, float* mean, float* rstd, int B, int L, int D,
+                       unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_embed_ln_bwd(const float* dy, const long long* ids, int ld_ids, const int* seq_index, const float* word, const float* pos,
+                       const float* type0, const float* mean, const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype0,
+                       float* dgamma, float* dbeta, int B, int L, int D, int pad_id, unsigned drop_key, unsigned drop_thresh, float drop_scale,
+                       void* stream);
+int srhip_postln_fwd(const float* y, const float* gamma, const float* beta, float eps, float* x, void* x_bf16, float* mean, float* rstd, int M,
+                     int D, void* stream);
+int srhip_postln_bwd(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx, void* dx_bf16,
+                     float* dgamma, float* dbeta, int M, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_meanpool_fwd(const float* x, float* feat, int B, int L, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_meanpool_bwd(const float* dfeat, float* dx, int B, int L, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_gelu_f32(const float* pre, float* out, long n, void* stream);
+int srhip_gelu_bwd_f32(const float* dout, const float* pre, float* dpre, long n, void* stream);
+int srhip_mask_lengths(const long long* mask, int ld, int* key_len, int B, int L, void* stream);
 
 /* ---- WideResNet building blocks (classic_cv backbone, semilearn/nets/wrn/wrn.py; BASELINE.json configs[0], parity configuration) ----
  * Feature maps are NHWC = row-major [rows = B*H*W, C].  conv = im2col (bf16) + srhip_gemm_nt; dW = srhip_gemm_tn_grouped_f32(dY, col);

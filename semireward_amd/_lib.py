@@ -5,7 +5,7 @@ raises.  Signatures mirror include/srhip.h one to one.
 """
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_long, c_ulonglong, c_void_p
+from ctypes import c_double, c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
 
 # torch must be imported BEFORE libsrhip.so is dlopen'ed: torch ships its own libamdhip64; if libsrhip pulled the
 # system copy in first the process would hold two HIP runtimes and our launches would see "no device" (hipError 100).
@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libsrhip.so")
 
 EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, EPI_DGELU_BF16, EPI_F32 = range(5)
 
-P, I, F, L, Dbl = c_void_p, c_int, c_float, c_long, c_double
+P, I, F, L, Dbl, U = c_void_p, c_int, c_float, c_long, c_double, c_uint
 SIGNATURES = {
     "srhip_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, P, I, P, P, I, F, F, P]),
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
@@ -74,6 +74,18 @@ SIGNATURES = {
     "srhip_fc_fwd": (I, [P, P, P, P, I, I, I, P]),
     "srhip_fc_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "srhip_sgd_flat": (I, [P, P, P, P, P, I, L, F, F, F, F, I, I, P]),
+    "srhip_gemm_nt_resid_dropout": (I, [P, I, P, I, P, I, I, I, I, P, P, I, U, U, F, P]),
+    "srhip_attn_masked_fwd": (I, [P, P, P, P, I, I, I, F, U, U, F, P]),
+    "srhip_attn_masked_bwd": (I, [P, P, P, P, P, P, P, I, I, I, F, U, U, F, P]),
+    "srhip_embed_ln_fwd": (I, [P, I, P, P, P, P, P, P, F, P, P, P, P, I, I, I, U, U, F, P]),
+    "srhip_embed_ln_bwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, U, U, F, P]),
+    "srhip_postln_fwd": (I, [P, P, P, F, P, P, P, P, I, I, P]),
+    "srhip_postln_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, U, U, F, P]),
+    "srhip_meanpool_fwd": (I, [P, P, I, I, I, U, U, F, P]),
+    "srhip_meanpool_bwd": (I, [P, P, I, I, I, U, U, F, P]),
+    "srhip_gelu_f32": (I, [P, P, L, P]),
+    "srhip_gelu_bwd_f32": (I, [P, P, P, L, P]),
+    "srhip_mask_lengths": (I, [P, I, P, I, I, P]),
 }
 
 _lib = None

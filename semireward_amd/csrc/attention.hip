@@ -111,9 +111,13 @@ constexpr int FWD_NT = 512, FWD_NW = FWD_NT / 64;
 // dispatch_nkt instantiates NKT in {2, 8, 14, 18, 32} and picks the smallest >= ceil(N / 32) * 2: key tiles below the previous
 // size are always complete
 constexpr int nkt_lo(int nkt) { return nkt == 32 ? 18 : nkt == 18 ? 14 : nkt == 14 ? 8 : nkt == 8 ? 2 : 0; }
-template <int NKT>
+// VAR = true (BERT / Wav2Vec2 encoders): per-sequence key length (right-padded batch: keys >= key_len[b] are masked exactly like the
+// additive -inf mask of the reference, every QUERY row is still computed -- the classifier averages over padded positions too) and
+// train-mode dropout on the probabilities (counter-based, common.h:drop_keep; element index = ((b*H + h)*N + q)*N + key).
+struct AttnVar { const int* key_len; uint32_t drop_key, drop_thresh; float drop_scale; };
+template <int NKT, bool VAR>
 __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                      float* __restrict__ lse, int N, int H, float scale) {
+                                                      float* __restrict__ lse, int N, int H, float scale, AttnVar av) {
   constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][64], chunk-swizzled (stage_rows_swz)
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const float sc2 = scale * LOG2E;
   const int nqt = (N + 15) >> 4;
+  const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
   const int kc = g ^ ((l15 >> 1) & 7);                // chunk of k-slots 8g.. of this lane's key row; the other half is kc ^ 4
   const int kof0 = l15 * HD + (kc << 3), kof1 = l15 * HD + ((kc ^ 4) << 3);
   const int vof = l15 * TP + ((g ^ swz4(l15)) << 3);
@@ -159,7 +164,12 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       // Only the key tiles past the previous dispatch size can straddle N (this instantiation serves 16 * nkt_lo < N <= NP): the
       // others are full by construction.  Testing every tile against the runtime N cost 144 v_cndmask + 94 v_readlane per
       // query tile (the 72 compare results were spilled from SGPR pairs to VGPR lanes) -- 40 % of the loop's VALU work.
-      if (t >= nkt_lo(NKT) && t * 16 + 16 > N) {
+      if (VAR) {
+        if (t * 16 + 16 > klen) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = (t * 16 + g * 4 + r < klen) ? a[r] : -INFINITY;
+        }
+      } else if (t >= nkt_lo(NKT) && t * 16 + 16 > N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = (t * 16 + g * 4 + r < N) ? a[r] : -INFINITY;
       }
@@ -183,6 +193,13 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
+    if (VAR && av.drop_thresh) {                     // nn.Dropout on the normalised probabilities: the row sum is the pre-dropout one
+      const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(g * 4);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = drop_keep(rowbase + t * 16 + r, av.drop_key, av.drop_thresh) ? s[t][r] : 0.f;
+    }
     f32x4_t o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       __builtin_amdgcn_sched_barrier(0);
     }
     if (q < N) {
-      const float inv = 1.0f / sum;
+      const float inv = ((VAR && av.drop_thresh) ? av.drop_scale : 1.0f) / sum;
       bf16_t* op = out + ((size_t)b * N + q) * D + h * HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -217,16 +234,18 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
 // grid = (B*H, QS): blockIdx.y takes every QS-th group of BWD_NW query tiles (the backward batch is small -- 16 images --
 // so one workgroup per head would leave 60 % of the CUs idle).
 constexpr int BWD_NT = 512, BWD_NW = BWD_NT / 64;
-template <int NKT>
+// VG = true (N > 288: K, V and K^T images no longer fit the 160 KB of LDS together): the V row fragments -- plain 16-byte row reads, the
+// A operand of dP = V . dO^T -- come straight from global memory / L2, software-pipelined one key-tile pair ahead.
+template <int NKT, bool VAR, bool VG>
 __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                          const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                          bf16_t* __restrict__ dqkv, float* __restrict__ delta,
-                                                         int N, int H, float scale) {
+                                                         int N, int H, float scale, AttnVar av) {
   constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][64]  chunk-swizzled (stage_rows_swz)
-  bf16_t* Vs = Ks + NP * HD;                          // [NP][64]  chunk-swizzled
-  bf16_t* Kt = Vs + NP * HD;                          // [64][TP]  key-permuted + chunk-swizzled (stage_transposed_perm)
+  bf16_t* Vs = Ks + NP * HD;                          // [NP][64]  chunk-swizzled (absent when VG)
+  bf16_t* Kt = Vs + (VG ? 0 : NP * HD);               // [64][TP]  key-permuted + chunk-swizzled (stage_transposed_perm)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int kc_ = g ^ ((l15 >> 1) & 7);
   const int kof0 = l15 * HD + (kc_ << 3), kof1 = l15 * HD + ((kc_ ^ 4) << 3);
@@ -248,11 +267,20 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
     nlse = lse[((size_t)b * H + h) * N + qc];
   };
   const int qstride = BWD_NW * gridDim.y, qfirst = blockIdx.y * BWD_NW + wave;
+  const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
   fetch(qfirst);
   stage_rows_swz<NP, BWD_NT>(Ks, base + D, ld, N, tid);
-  stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
+  if (!VG) stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
   stage_transposed_perm<NP, BWD_NT>(Kt, base + D, ld, N, tid);
   __syncthreads();
+  s16x8_t vg[2][2];                                   // VG: V fragments of key-tile pair u (rows >= N are clamped: their p is 0)
+  auto vfetch = [&](int u_) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bf16_t* vp = base + 2 * D + (size_t)min((2 * u_ + e) * 16 + l15, N - 1) * ld + g * 8;
+      vg[e][0] = ld16(vp); vg[e][1] = ld16(vp + 32);
+    }
+  };
   for (int qt = qfirst; qt < nqt; qt += qstride) {
     const int q = qt * 16 + l15;
     const s16x8_t q0 = nq0, q1 = nq1, do0 = nd0, do1 = nd1;
@@ -272,18 +300,35 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
     f32x4_t dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (VG) vfetch(0);
+    const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(g * 4);
 #pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       float ds[2][4];
+      s16x8_t cv[2][2];
+      if (VG) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { cv[e][0] = vg[e][0]; cv[e][1] = vg[e][1]; }
+        if (u + 1 < NKT / 2) vfetch(u + 1);
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int t = 2 * u + e;
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
         s = mfma16(ld16(Ks + t * 16 * HD + kof0), q0, s);
         s = mfma16(ld16(Ks + t * 16 * HD + kof1), q1, s);
-        dp = mfma16(ld16(Vs + t * 16 * HD + kof0), do0, dp);
-        dp = mfma16(ld16(Vs + t * 16 * HD + kof1), do1, dp);
-        if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
+        dp = mfma16(VG ? cv[e][0] : ld16(Vs + t * 16 * HD + kof0), do0, dp);
+        dp = mfma16(VG ? cv[e][1] : ld16(Vs + t * 16 * HD + kof1), do1, dp);
+        if (VAR) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = t * 16 + g * 4 + r;
+            const float p = key < klen ? fast_exp2(s[r] * sc2 - lse2) : 0.f;
+            float dpv = dp[r];
+            if (av.drop_thresh) dpv = drop_keep(rowbase + t * 16 + r, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
+            ds[e][r] = p * (dpv - dl) * scale;
+          }
+        } else if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = t * 16 + g * 4 + r;
@@ -315,10 +360,10 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
 // backward, part 2: dK, dV.  One workgroup per (image, head); each wave owns 16-key tiles and
 // walks query-tile pairs:  S[q][key], dP[q][key] with the KEY on l15 ->
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
-template <int NKT>
+template <int NKT, bool VAR>
 __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale, AttnVar av) {
   constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]  query-permuted + chunk-swizzled (stage_transposed_perm)
@@ -338,6 +383,7 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
   }
   __syncthreads();
   const float sc2 = scale * LOG2E;
+  const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
   for (int kt = blockIdx.y * BWD_NW + wave; kt < NKT; kt += BWD_NW * gridDim.y) {
     const int key = kt * 16 + l15, kc = min(key, N - 1);
     if (kt * 16 >= N) break;
@@ -379,9 +425,19 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
           const int qq = (2 * u + e) * 16 + g * 4 + r;      // result row = query
           // padded queries: lse_s = +inf -> p = 0 exactly.  Padded KEY columns (this lane's key >= N) may hold anything: a column
           // of P / dS only feeds the dK / dV rows of that key, which are never stored.
-          const float p = fast_exp2(s[r] * sc2 - lse_s[qq]);
-          pp[e][r] = p;
-          ds[e][r] = p * (dp[r] - dl_s[qq]) * scale;
+          float p = fast_exp2(s[r] * sc2 - lse_s[qq]);
+          float pk = p, dpv = dp[r];
+          if (VAR) {                              // masked keys (rows [klen, N) ARE stored: padded positions have dK = dV = 0)
+            p = key < klen ? p : 0.f;
+            pk = p;
+            if (av.drop_thresh) {
+              const bool keep = drop_keep(((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qq) * (uint32_t)N + (uint32_t)key, av.drop_key, av.drop_thresh);
+              pk = keep ? p * av.drop_scale : 0.f;
+              dpv = keep ? dpv * av.drop_scale : 0.f;
+            }
+          }
+          pp[e][r] = pk;
+          ds[e][r] = p * (dpv - dl_s[qq]) * scale;
         }
       }
       const s16x8_t pb = pack8(pp[0], pp[1]), dsb = pack8(ds[0], ds[1]);
@@ -417,31 +473,32 @@ int dispatch_nkt(int N, F&& f) {
   return SR_EINVAL;
 }
 
-}  // namespace
-
-extern "C" int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
-  if (B <= 0 || N <= 0 || H <= 0 || N > 512) return SR_EINVAL;
+template <bool VAR>
+int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, AttnVar av, void* stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || N > 512 || (long)B * H * N * N >= (1L << 32)) return SR_EINVAL;
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
     const size_t sm = (size_t)NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
-    auto kern = attn_fwd_kernel<NKT>;
+    auto kern = attn_fwd_kernel<NKT, VAR>;
     if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, av);
     SR_CHECK_LAUNCH();
     return SR_OK;
   });
 }
 
-extern "C" int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv,
-                              float* delta_ws, int B, int N, int H, float scale, void* stream) {
-  if (B <= 0 || N <= 0 || H <= 0 || N > 512 || !lse || !delta_ws) return SR_EINVAL;
+template <bool VAR>
+int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, float* delta_ws, int B, int N, int H,
+                    float scale, AttnVar av, void* stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || N > 512 || !lse || !delta_ws || (long)B * H * N * N >= (1L << 32)) return SR_EINVAL;
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
-    const size_t sm1 = (size_t)2 * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
+    constexpr bool VG = NKT > 18;           // K + V + K^T images exceed the LDS: V fragments from L2
+    const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
     const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (size_t)2 * NP * 4;
-    if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;   // N > 288 backward: not in this round's scope
-    auto k1 = attn_bwd_dq_kernel<NKT>;
-    auto k2 = attn_bwd_dkv_kernel<NKT>;
+    if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;
+    auto k1 = attn_bwd_dq_kernel<NKT, VAR, VG>;
+    auto k2 = attn_bwd_dkv_kernel<NKT, VAR>;
     if (sm1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
     if (sm2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
     // split query / key tiles over extra workgroups until the grid covers the chip (each split re-stages K/V or Q/dO)
@@ -449,11 +506,30 @@ extern "C" int srhip_attn_bwd(const void* qkv, const void* out, const void* d_ou
     int split = 1;
     while (B * H * split < 256 && split * BWD_NW < nt16) ++split;
     hipLaunchKernelGGL(k1, dim3(B * H, split), dim3(BWD_NT), sm1, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale);
+                       (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale, av);
     SR_CHECK_LAUNCH();
     hipLaunchKernelGGL(k2, dim3(B * H, split), dim3(BWD_NT), sm2, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)d_out, lse,
-                       (const float*)delta_ws, (bf16_t*)dqkv, N, H, scale);
+                       (const float*)delta_ws, (bf16_t*)dqkv, N, H, scale, av);
     SR_CHECK_LAUNCH();
     return SR_OK;
   });
+}
+
+}  // namespace
+
+extern "C" int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
+  return attn_fwd_launch<false>(qkv, out, lse, B, N, H, scale, AttnVar{nullptr, 0u, 0u, 1.0f}, stream);
+}
+extern "C" int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv,
+                              float* delta_ws, int B, int N, int H, float scale, void* stream) {
+  return attn_bwd_launch<false>(qkv, out, d_out, lse, dqkv, delta_ws, B, N, H, scale, AttnVar{nullptr, 0u, 0u, 1.0f}, stream);
+}
+extern "C" int srhip_attn_masked_fwd(const void* qkv, void* out, float* lse, const int* key_len, int B, int N, int H, float scale,
+                                     unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream) {
+  return attn_fwd_launch<true>(qkv, out, lse, B, N, H, scale, AttnVar{key_len, drop_key, drop_thresh, drop_scale}, stream);
+}
+extern "C" int srhip_attn_masked_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, float* delta_ws,
+                                     const int* key_len, int B, int N, int H, float scale, unsigned drop_key, unsigned drop_thresh,
+                                     float drop_scale, void* stream) {
+  return attn_bwd_launch<true>(qkv, out, d_out, lse, dqkv, delta_ws, B, N, H, scale, AttnVar{key_len, drop_key, drop_thresh, drop_scale}, stream);
 }

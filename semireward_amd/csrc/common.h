@@ -74,6 +74,16 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// Counter-based dropout generator (train-mode nn.Dropout of the BERT / Wav2Vec2 encoders, semilearn/nets/bert/bert.py:15,36 and the HF
+// modules it calls): element with row-major linear index i of a dropout site is KEPT iff fmix32(i * 0x9E3779B1 + key) >= thresh, with
+// thresh = floor(p * 2^32) and key = the 32-bit site key the host derives from (call seed, site id).  Stateless, so the backward
+// regenerates the mask instead of storing it; oracle/bert_ref.py:keep_mask is the same function in numpy.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thresh) { return fmix32(idx * 0x9E3779B1u + key) >= thresh; }
+
 // XCD-aware bijective block remap (blocks b, b+8, b+16.. share an XCD/L2): returns the
 // logical work-group id so that each XCD walks a contiguous chunk of the tile list.
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {

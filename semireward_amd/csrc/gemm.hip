@@ -33,6 +33,8 @@ struct GemmArgs {
   bf16_t* aux_out;
   int M, N, K, lda, ldb, ldc, ldaux, rows_per_sample, ksplit_tiles, debug;
   float alpha, beta;
+  uint32_t drop_key, drop_thresh;      // RESID epilogue: nn.Dropout on (acc + bias) before the residual add (drop_thresh == 0: none)
+  float drop_scale;                    // 1 / (1 - p)
 };
 
 constexpr int BM = 128, BN = 128, BK = 32, NS = 4, PD = NS - 1;
@@ -78,6 +80,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     // residual source: C itself (in place) or, when the pre-block stream is kept for the backward, aux_in (fp32, ldaux)
     f32x4_t* cp = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + off);
     f32x4_t x = g.aux_in ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(g.aux_in) + (size_t)m * g.ldaux + n) : *cp;
+    if (g.drop_thresh) {                 // (uniform) BertSelfOutput / BertOutput: LayerNorm(x + dropout(dense(.)))
+      const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+    }
     x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
     *cp = x;
   } else if (EPI == SRHIP_EPI_DGELU_BF16) {
@@ -205,6 +212,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
           const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n);
           v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
         }
+        if (g.drop_thresh) {
+          const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+        }
         x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
         *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = x;
       } else {
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
   g.A = (const bf16_t*)d.A; g.B = (const bf16_t*)d.B; g.C = d.C; g.bias = nullptr; g.row_scale = nullptr;
   g.aux_in = nullptr; g.aux_out = nullptr;
   g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldaux = 0; g.rows_per_sample = 1;
-  g.ksplit_tiles = d.K / BK; g.debug = 0; g.alpha = alpha; g.beta = beta;
+  g.ksplit_tiles = d.K / BK; g.debug = 0; g.alpha = alpha; g.beta = beta; g.drop_key = 0u; g.drop_thresh = 0u; g.drop_scale = 1.0f;
   const int local = tile - d.tile_start, ntn = (d.N + BN - 1) / BN;
   gemm_tile_body<SRHIP_EPI_F32>(g, smem, (local / ntn) * BM, (local % ntn) * BN, 0, d.K / BK, false);
 }
@@ -472,9 +484,10 @@ static void launch_big(const GemmArgs& g, int variant, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                             int M, int N, int K, const float* bias, const float* row_scale, int rows_per_sample,
-                             const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, void* stream) {
+static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        int M, int N, int K, const float* bias, const float* row_scale, int rows_per_sample,
+                        const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, uint32_t drop_key, uint32_t drop_thresh,
+                        float drop_scale, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4)) return SR_EINVAL;   // BK = 32
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return SR_EINVAL;
   if (epilogue == SRHIP_EPI_DGELU_BF16 && !aux_in) return SR_EINVAL;
@@ -484,6 +497,7 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
   g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; g.alpha = alpha; g.beta = beta;
+  g.drop_key = drop_key; g.drop_thresh = drop_thresh; g.drop_scale = drop_scale;
   static const int dbg = getenv("SRHIP_DEBUG") ? atoi(getenv("SRHIP_DEBUG")) : 0;
   g.debug = dbg;
   const int grid = cdiv(M, BM) * cdiv(N, BN);
@@ -542,6 +556,21 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
   }
   SR_CHECK_LAUNCH();
   return SR_OK;
+}
+
+extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                             int M, int N, int K, const float* bias, const float* row_scale, int rows_per_sample,
+                             const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, void* stream) {
+  return gemm_nt_impl(epilogue, A, lda, B, ldb, C, ldc, M, N, K, bias, row_scale, rows_per_sample, aux_in, aux_out, ldaux, alpha, beta, 0u, 0u,
+                      1.0f, stream);
+}
+
+extern "C" int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                           const float* bias, const float* resid, int ldresid, unsigned drop_key, unsigned drop_thresh,
+                                           float drop_scale, void* stream) {
+  if (ldc != N && drop_thresh) return SR_EINVAL;        // the dropout index is the row-major index of the [M, N] output
+  return gemm_nt_impl(SRHIP_EPI_RESID_F32, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, resid, nullptr, ldresid, 1.0f, 0.0f, drop_key,
+                      drop_thresh, drop_scale, stream);
 }
 
 extern "C" int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,

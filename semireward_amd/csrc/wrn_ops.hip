@@ -172,15 +172,15 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, float* __res
   da[i] = dfeat[b * C + c] / HW2;
 }
 
-// classifier: logits[b][k] = feat[b] . Wc[k] + bc[k]
-__global__ void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ logits,
-                              int F, int K) {
-  const int b = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float s = 0.f;
-    for (int f = 0; f < F; ++f) s += feat[(size_t)b * F + f] * Wc[(size_t)k * F + f];
-    logits[(size_t)b * K + k] = s + bc[k];
-  }
+// classifier: logits[b][k] = feat[b] . Wc[k] + bc[k].  One wave per output, lanes along F (coalesced rows of Wc); grid = (B, ceil(K / 4)).
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                    float* __restrict__ logits, int F, int K) {
+  const int b = blockIdx.x, k = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int f = lane; f < F; f += 64) s += feat[(size_t)b * F + f] * Wc[(size_t)k * F + f];
+  s = wave_sum(s);
+  if (lane == 0) logits[(size_t)b * K + k] = s + bc[k];
 }
 // dfeat[b][f] = sum_k dlogits[b][k] Wc[k][f]        (grid = B)
 __global__ void fc_bwd_x_kernel(const float* __restrict__ dl, const float* __restrict__ Wc, float* __restrict__ dfeat, int F, int K) {
@@ -324,7 +324,7 @@ extern "C" int srhip_avgpool_bwd(const float* dfeat, float* dact, int B, int HW2
 
 extern "C" int srhip_fc_fwd(const float* feat, const float* Wc, const float* bc, float* logits, int B, int F, int K, void* stream) {
   if (!feat || !Wc || !bc || !logits || B <= 0 || F <= 0 || K <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(fc_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, feat, Wc, bc, logits, F, K);
+  hipLaunchKernelGGL(fc_fwd_kernel, dim3(B, cdiv(K, 4)), dim3(256), 0, (hipStream_t)stream, feat, Wc, bc, logits, F, K);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -1,0 +1,402 @@
+"""BERT classification backbone engine on libsrhip: forward / backward over a flat parameter block.
+
+Mirrors the reference's ``semilearn/nets/bert/bert.py`` plugin surface (class ``ClassificationBert``, builders ``bert_base_uncased`` /
+``bert_base_cased``, ``state_dict`` keys = ``bert.`` + the HF BertModel names + ``classifier.0/2``, dict input
+``{'input_ids', 'attention_mask'}``, ``{'logits','feat'}`` result, ``group_matcher`` / ``no_weight_decay``) but not its implementation:
+no nn.Module, no autograd, no ``transformers``.  The encoder the reference obtains from ``transformers.BertModel`` (post-LN layers,
+erf-GELU, LayerNorm eps 1e-12, dropout 0.1 in train mode) is a short list of HIP launches per layer:
+
+    qkv  = x_bf16 . Wqkv^T + b                       srhip_gemm_nt            (q | k | v packed: one product, N = 3D)
+    ctx  = softmax(q k^T / 8 + key mask) v           srhip_attn_masked_fwd    (per-sequence key length, dropout on the probabilities)
+    y1   = x + dropout(ctx . Wo^T + b)               srhip_gemm_nt_resid_dropout
+    x    = LayerNorm(y1)          (fp32 + bf16)      srhip_postln_fwd
+    h    = GELU(x_bf16 . W1^T + b)                   srhip_gemm_nt (GELU epilogue)
+    y2   = x + dropout(h . W2^T + b)                 srhip_gemm_nt_resid_dropout
+    x    = LayerNorm(y2)                             srhip_postln_fwd
+
+and the backward is hand-written (post-LN: the gradient of a LayerNorm input feeds the residual path in fp32 and, dropout-masked, the
+branch's dX / dW products in bf16).  Data layout: B sequences padded to a common L, M = B * L token rows; the residual stream is fp32
+[M, D], GEMM operands bf16; the flat parameter block keeps q/k/v weights (and biases) of a layer adjacent, so the packed [3D, D]
+operand is a VIEW, and a reference checkpoint still maps by name.  ``from_pretrained`` needs the network: weights are random-init
+(HF: normal(0, 0.02), LayerNorm 1/0) or loaded with ``load_state_dict``.
+
+Padding: batches are right-padded (``tokenizer.pad``, nlp_collactor.py:63-69), so the attention mask is a prefix mask and the engine
+carries ``key_len = mask.sum(1)``; every position -- padding included -- is computed and averaged, exactly like bert.py:36-37.
+"""
+import types
+
+import torch
+
+from .. import ops
+
+SITE_EMB, SITE_HEAD = 0x7FFFFFF0, 0x7FFFFFF1
+SITE_PROBS, SITE_ATTN_OUT, SITE_FFN_OUT = 0, 1, 2
+
+
+class BertConfig:
+    def __init__(self, vocab=30522, hidden=768, layers=12, heads=12, inter=3072, max_pos=512, num_classes=2, p_drop=0.1, eps=1e-12,
+                 pad_id=0):
+        self.vocab, self.hidden, self.layers, self.heads, self.inter, self.max_pos = vocab, hidden, layers, heads, inter, max_pos
+        self.num_classes, self.p_drop, self.eps, self.pad_id = num_classes, p_drop, eps, pad_id
+        assert hidden // heads == 64 and hidden in (128, 384, 768), "libsrhip attention is built for head_dim 64"
+        assert inter % 32 == 0 and max_pos <= 512
+    embed_dim = property(lambda self: self.hidden)
+
+
+E = "bert.embeddings."
+
+
+def _layer(i):
+    return "bert.encoder.layer.%d." % i
+
+
+def param_names_shapes(cfg):
+    """Flat-block order: the reference's names; q/k/v weights, then q/k/v biases, adjacent (packed operand views)."""
+    D, I = cfg.hidden, cfg.inter
+    out = [(E + "word_embeddings.weight", (cfg.vocab, D)), (E + "position_embeddings.weight", (cfg.max_pos, D)),
+           (E + "token_type_embeddings.weight", (2, D)), (E + "LayerNorm.weight", (D,)), (E + "LayerNorm.bias", (D,))]
+    for i in range(cfg.layers):
+        p = _layer(i)
+        out += [(p + "attention.self.%s.weight" % n, (D, D)) for n in ("query", "key", "value")]
+        out += [(p + "attention.self.%s.bias" % n, (D,)) for n in ("query", "key", "value")]
+        out += [(p + "attention.output.dense.weight", (D, D)), (p + "attention.output.dense.bias", (D,)),
+                (p + "attention.output.LayerNorm.weight", (D,)), (p + "attention.output.LayerNorm.bias", (D,)),
+                (p + "intermediate.dense.weight", (I, D)), (p + "intermediate.dense.bias", (I,)),
+                (p + "output.dense.weight", (D, I)), (p + "output.dense.bias", (D,)),
+                (p + "output.LayerNorm.weight", (D,)), (p + "output.LayerNorm.bias", (D,))]
+    out += [("bert.pooler.dense.weight", (D, D)), ("bert.pooler.dense.bias", (D,)),
+            ("classifier.0.weight", (D, D)), ("classifier.0.bias", (D,)), ("classifier.2.weight", (cfg.num_classes, D)),
+            ("classifier.2.bias", (cfg.num_classes,))]
+    return out
+
+
+class TokenBatch:
+    """A right-padded token batch on the device: ids int64 [S, L] (contiguous), key_len int32 [S]."""
+    __slots__ = ("ids", "key_len", "S", "L")
+
+    def __init__(self, ids, key_len):
+        self.ids, self.key_len = ids, key_len
+        self.S, self.L = ids.shape
+
+    @classmethod
+    def from_dict(cls, x, device):
+        ids = x["input_ids"].to(device=device, dtype=torch.int64).contiguous()
+        S, L = ids.shape
+        kl = torch.empty(S, dtype=torch.int32, device=device)
+        am = x.get("attention_mask")
+        if am is None:
+            kl.fill_(L)
+        else:
+            ops.mask_lengths(am.to(device=device, dtype=torch.int64).contiguous(), kl, S, L)
+        return cls(ids, kl)
+
+    @classmethod
+    def cat(cls, batches):
+        """Concatenate batches of ONE padded length (the reference's torch.cat of use_cat; differently padded batches stay separate calls)."""
+        assert len({b.L for b in batches}) == 1
+        return cls(torch.cat([b.ids for b in batches]).contiguous(), torch.cat([b.key_len for b in batches]).contiguous())
+
+
+class ClassificationBert:
+    couples_batch_rows = False
+    takes_tokens = True
+
+    def __init__(self, cfg=None, device="cuda", **kw):
+        self.cfg = cfg if cfg is not None else BertConfig(**kw)
+        cfg = self.cfg
+        self.device = torch.device(device)
+        self.num_features = cfg.hidden
+        self.names_shapes = param_names_shapes(cfg)
+        self.offsets, o = {}, 0
+        for n, s in self.names_shapes:
+            self.offsets[n] = (o, s)
+            o += int(torch.Size(s).numel())
+            o = (o + 7) // 8 * 8                     # 16-byte alignment of every tensor in the bf16 copy
+        self.numel = o
+        f32, bf16 = torch.float32, torch.bfloat16
+        self.flat = torch.zeros(o, dtype=f32, device=self.device)
+        self.grad = torch.zeros(o, dtype=f32, device=self.device)
+        self.flat_bf16 = torch.zeros(o, dtype=bf16, device=self.device)
+        D, I = cfg.hidden, cfg.inter
+        self.wT = []                                  # per layer: transposed bf16 operands of the dX products
+        for i in range(cfg.layers):
+            self.wT.append(dict(qkv=torch.zeros(D, 3 * D, dtype=bf16, device=self.device), o=torch.zeros(D, D, dtype=bf16, device=self.device),
+                                w1=torch.zeros(D, I, dtype=bf16, device=self.device), w2=torch.zeros(I, D, dtype=bf16, device=self.device)))
+        self.training = True
+        self._ws, self._wT_desc = {}, None
+        self._rng_calls, self.seed = 0, 0
+        self.inject_seed = None                       # tests: the 64-bit dropout seed of the next forward calls
+
+    # ---- parameter plumbing (same surface as nets/vit.py) --------------------------------------------
+    def p(self, name, buf=None):
+        o, s = self.offsets[name]
+        return (self.flat if buf is None else buf)[o:o + int(torch.Size(s).numel())]
+
+    def view(self, name, buf=None):
+        return self.p(name, buf).view(self.offsets[name][1])
+
+    def packed_qkv(self, i, buf=None):
+        """[3D, D] weight and [3D] bias views over the adjacent q/k/v tensors of layer i."""
+        D = self.cfg.hidden
+        ow = self.offsets[_layer(i) + "attention.self.query.weight"][0]
+        ob = self.offsets[_layer(i) + "attention.self.query.bias"][0]
+        b = self.flat if buf is None else buf
+        return b[ow:ow + 3 * D * D].view(3 * D, D), b[ob:ob + 3 * D]
+
+    def named_parameters(self):
+        return [(n, self.view(n)) for n, _ in self.names_shapes]
+
+    def named_grads(self):
+        return [(n, self.view(n, self.grad)) for n, _ in self.names_shapes]
+
+    def state_dict(self):
+        return {n: self.view(n).detach().clone() for n, _ in self.names_shapes}
+
+    def load_state_dict(self, sd, strict=True):
+        for n, s in self.names_shapes:
+            if n in sd:
+                self.view(n).copy_(torch.as_tensor(sd[n]).to(self.device, torch.float32).reshape(s))
+            elif strict:
+                raise KeyError(n)
+        self.refresh_operands()
+
+    def init_weights(self, seed=0):
+        """HF BertPreTrainedModel._init_weights: normal(0, 0.02) for Linear / Embedding weights ([PAD] row zero), LayerNorm 1 / 0, biases 0;
+        the classifier Linears keep torch's default U(+-1/sqrt(fan_in))."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        sd = {}
+        for n, s in self.names_shapes:
+            if "LayerNorm.weight" in n:
+                sd[n] = torch.ones(s)
+            elif n.startswith("classifier"):
+                bound = 1.0 / (self.cfg.hidden ** 0.5)
+                sd[n] = (torch.rand(s, generator=g) * 2 - 1) * bound
+            elif len(s) == 1:
+                sd[n] = torch.zeros(s)
+            else:
+                sd[n] = torch.randn(s, generator=g) * 0.02
+        sd[E + "word_embeddings.weight"][self.cfg.pad_id].zero_()
+        self.load_state_dict(sd)
+
+    def refresh_operands(self):
+        ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
+        if self._wT_desc is None:
+            items, cfg = [], self.cfg
+            D, I = cfg.hidden, cfg.inter
+            for i in range(cfg.layers):
+                p, t = _layer(i), self.wT[i]
+                items += [(self.packed_qkv(i)[0], True, D, t["qkv"], 3 * D, 3 * D, 3 * D, D, False),
+                          (self.p(p + "attention.output.dense.weight"), True, D, t["o"], D, D, D, D, False),
+                          (self.p(p + "intermediate.dense.weight"), True, D, t["w1"], I, I, I, D, False),
+                          (self.p(p + "output.dense.weight"), True, I, t["w2"], D, D, D, I, False)]
+            self._wT_desc = ops.make_transpose_desc(items, self.device)
+        ops.transpose_batched(*self._wT_desc)
+
+    def no_weight_decay(self):
+        return []
+
+    def group_matcher(self, coarse=False, prefix=""):
+        return dict(stem=r"^{}bert.embeddings".format(prefix), blocks=r"^{}bert.encoder.layer.(\d+)".format(prefix))
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def _buf(self, key, shape, dtype):
+        t = self._ws.get(key)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def next_seed(self):
+        """64-bit dropout seed of one forward call (None in eval mode / p_drop == 0)."""
+        if not self.training or self.cfg.p_drop <= 0.0:
+            return None
+        if self.inject_seed is not None:
+            return self.inject_seed
+        self._rng_calls += 1
+        return ((self.seed & 0xFFFFFFFF) << 32) + self._rng_calls
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def _ctx_buffers(self, B, L, tag):
+        key = ("ctx", B, L, tag)
+        if key in self._ws:
+            return self._ws[key]
+        cfg = self.cfg
+        D, I, H, M = cfg.hidden, cfg.inter, cfg.heads, B * L
+        f32, bf16 = torch.float32, torch.bfloat16
+        mk = lambda shape, dt: [torch.empty(shape, dtype=dt, device=self.device) for _ in range(cfg.layers)]   # noqa: E731
+        c = types.SimpleNamespace()
+        c.xb = mk((M, D), bf16) + [torch.empty(M, D, dtype=bf16, device=self.device)]     # layer inputs (bf16): X operand of dWqkv
+        c.qkv, c.ao, c.lse = mk((M, 3 * D), bf16), mk((M, D), bf16), mk((B, H, L), f32)
+        c.y1, c.st1, c.xbm = mk((M, D), f32), mk((2, M), f32), mk((M, D), bf16)
+        c.pre, c.h, c.y2, c.st2 = mk((M, I), bf16), mk((M, I), bf16), mk((M, D), f32), mk((2, M), f32)
+        c.st0 = torch.empty(2, M, dtype=f32, device=self.device)
+        c.feat = torch.empty(B, D, dtype=f32, device=self.device)
+        c.hpre, c.hact = torch.empty(B, D, dtype=f32, device=self.device), torch.empty(B, D, dtype=f32, device=self.device)
+        self._ws[key] = c
+        return c
+
+    def forward_features(self, tok, seq_index=None, droppath=None, save=False, B=None, seed="auto", tag=""):
+        """tok: TokenBatch; seq_index int32 [B] (optional gather of sequences: lets the K+1 passes of one SemiReward step share one
+        copy of the tokens).  Returns (logits [B, C], feat [B, D], ctx or None).  ``droppath`` is accepted for interface parity
+        with the ViT engine and unused (BERT has no stochastic depth)."""
+        cfg = self.cfg
+        D, I, H, C, L = cfg.hidden, cfg.inter, cfg.heads, cfg.num_classes, tok.L
+        B = int(seq_index.numel()) if seq_index is not None else tok.S
+        M = B * L
+        f32, bf16 = torch.float32, torch.bfloat16
+        seed = self.next_seed() if seed == "auto" else seed
+        dr = (lambda site: ops.Drop(seed, site, cfg.p_drop)) if seed is not None else (lambda site: None)
+        key_len = tok.key_len if seq_index is None else tok.key_len.index_select(0, seq_index.long()).contiguous()
+        P, wb = self.p, self.flat_bf16
+        t = "s" if save else "i"
+        ctx = None
+        x = self._buf(t + "x", (M, D), f32)
+        if save:
+            ctx = self._ctx_buffers(B, L, tag)
+            ctx.B, ctx.L, ctx.tok, ctx.seq_index, ctx.key_len, ctx.seed = B, L, tok, seq_index, key_len, seed
+            xb = ctx.xb[0]
+        else:
+            xb = self._buf(t + "xb", (M, D), bf16)
+            qkv, ao = self._buf(t + "qkv", (M, 3 * D), bf16), self._buf(t + "ao", (M, D), bf16)
+            hbuf = self._buf(t + "h", (M, I), bf16)
+        ops.embed_ln_fwd(tok.ids, seq_index, P(E + "word_embeddings.weight"), P(E + "position_embeddings.weight"),
+                         P(E + "token_type_embeddings.weight"), P(E + "LayerNorm.weight"), P(E + "LayerNorm.bias"), cfg.eps, x, xb,
+                         ctx.st0[0] if save else None, ctx.st0[1] if save else None, B, L, D, dr(SITE_EMB))
+        scale = 64 ** -0.5
+        for i in range(cfg.layers):
+            p = _layer(i)
+            Wqkv, bqkv = self.packed_qkv(i, wb)[0], self.packed_qkv(i)[1]
+            if save:
+                qkv, ao = ctx.qkv[i], ctx.ao[i]
+            ops.gemm_nt(ops.EPI_BF16, xb, Wqkv, qkv, M, 3 * D, D, bias=bqkv)
+            ops.attn_masked_fwd(qkv, ao, ctx.lse[i] if save else None, key_len, B, L, H, scale, dr(4 * i + SITE_PROBS))
+            y1 = ctx.y1[i] if save else x
+            ops.gemm_nt_resid_dropout(ao, P(p + "attention.output.dense.weight", wb), y1, M, D, D, P(p + "attention.output.dense.bias"),
+                                      x if save else None, dr(4 * i + SITE_ATTN_OUT))
+            xbm = ctx.xbm[i] if save else xb
+            ops.postln_fwd(y1, P(p + "attention.output.LayerNorm.weight"), P(p + "attention.output.LayerNorm.bias"), cfg.eps, x, xbm,
+                           ctx.st1[i][0] if save else None, ctx.st1[i][1] if save else None, M, D)
+            h = ctx.h[i] if save else hbuf
+            ops.gemm_nt(ops.EPI_GELU_BF16, xbm, P(p + "intermediate.dense.weight", wb), h, M, I, D, bias=P(p + "intermediate.dense.bias"),
+                        aux_out=ctx.pre[i] if save else None, ldaux=I)
+            y2 = ctx.y2[i] if save else x
+            ops.gemm_nt_resid_dropout(h, P(p + "output.dense.weight", wb), y2, M, D, I, P(p + "output.dense.bias"), x if save else None,
+                                      dr(4 * i + SITE_FFN_OUT))
+            xb = ctx.xb[i + 1] if save else xb
+            ops.postln_fwd(y2, P(p + "output.LayerNorm.weight"), P(p + "output.LayerNorm.bias"), cfg.eps, x, xb,
+                           ctx.st2[i][0] if save else None, ctx.st2[i][1] if save else None, M, D)
+        feat = ctx.feat if save else torch.empty(B, D, dtype=f32, device=self.device)
+        hpre = ctx.hpre if save else torch.empty(B, D, dtype=f32, device=self.device)
+        hact = ctx.hact if save else torch.empty(B, D, dtype=f32, device=self.device)
+        logits = torch.empty(B, C, dtype=f32, device=self.device)
+        ops.meanpool_fwd(x, feat, B, L, D, dr(SITE_HEAD))
+        ops.fc_fwd(feat, P("classifier.0.weight"), P("classifier.0.bias"), hpre, B, D, D)
+        ops.gelu_f32(hpre, hact, B * D)
+        ops.fc_fwd(hact, P("classifier.2.weight"), P("classifier.2.bias"), logits, B, D, C)
+        return logits, (feat.clone() if save else feat), ctx
+
+    def forward(self, x, only_fc=False, only_feat=False, return_embed=False, **kw):
+        """Reference-compatible entry (bert.py:22-48): x = {'input_ids', 'attention_mask'} -> {'logits','feat'}."""
+        assert not only_fc and not return_embed, "only_fc / return_embed (VAT) are not on the SemiReward hot path"
+        tok = x if isinstance(x, TokenBatch) else TokenBatch.from_dict(x, self.device)
+        logits, feat, _ = self.forward_features(tok, None, save=False)
+        return feat if only_feat else {"logits": logits, "feat": feat}
+
+    __call__ = forward
+
+    def extract(self, x):
+        return self.forward(x, only_feat=True)
+
+    # ---- backward -----------------------------------------------------------------------------------------
+    def _bwd_plan(self, M, ctx):
+        """Shared output-gradient buffers (bf16 A operands of dW = dY^T X) + one descriptor table per layer for the grouped
+        weight-gradient launch (row-major operands, bias gradients summed on the way: srhip_gemm_tn_grouped_f32)."""
+        key = ("bwdplan", M, id(ctx))
+        if key in self._ws:
+            return self._ws[key]
+        cfg = self.cfg
+        D, I = cfg.hidden, cfg.inter
+        mk = lambda c: torch.empty(M, c, dtype=torch.bfloat16, device=self.device)   # noqa: E731
+        T = dict(g2=mk(D), dpre=mk(I), g1=mk(D), dqkv=mk(3 * D), dao=mk(D), desc=[])
+        G = lambda n: self.view(n, self.grad)   # noqa: E731
+        for i in range(cfg.layers):
+            p = _layer(i)
+            gw, gb = self.packed_qkv(i, self.grad)
+            T["desc"].append(ops.make_group_tn_desc(
+                [(T["g2"], ctx.h[i], G(p + "output.dense.weight"), G(p + "output.dense.bias"), D, I, M),
+                 (T["dpre"], ctx.xbm[i], G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"), I, D, M),
+                 (T["g1"], ctx.ao[i], G(p + "attention.output.dense.weight"), G(p + "attention.output.dense.bias"), D, D, M),
+                 (T["dqkv"], ctx.xb[i], gw, gb, 3 * D, D, M)], self.device))
+        self._ws[key] = T
+        return T
+
+    def backward(self, ctx, dlogits):
+        """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] of a save=True forward."""
+        cfg = self.cfg
+        D, I, H, C = cfg.hidden, cfg.inter, cfg.heads, cfg.num_classes
+        B, L, seed = ctx.B, ctx.L, ctx.seed
+        M = B * L
+        f32 = torch.float32
+        dr = (lambda site: ops.Drop(seed, site, cfg.p_drop)) if seed is not None else (lambda site: None)
+        P, G = self.p, (lambda n: self.p(n, self.grad))
+        dhact, dhpre = self._buf("b_dhact", (B, D), f32), self._buf("b_dhpre", (B, D), f32)
+        dfeat = self._buf("b_dfeat", (B, D), f32)
+        ops.fc_bwd(dlogits, ctx.hact, P("classifier.2.weight"), dhact, G("classifier.2.weight"), G("classifier.2.bias"), B, D, C)
+        ops.gelu_bwd_f32(dhact, ctx.hpre, dhpre, B * D)
+        ops.fc_bwd(dhpre, ctx.feat, P("classifier.0.weight"), dfeat, G("classifier.0.weight"), G("classifier.0.bias"), B, D, D)
+        dx = self._buf("b_dx", (M, D), f32)
+        ops.meanpool_bwd(dfeat, dx, B, L, D, dr(SITE_HEAD))
+        delta = self._buf("b_delta", (B, H, L), f32)
+        T = self._bwd_plan(M, ctx)
+        scale = 64 ** -0.5
+        for i in reversed(range(cfg.layers)):
+            p, wT = _layer(i), self.wT[i]
+            # ---- FFN: x_out = LN(y2), y2 = x_mid + dropout(W2 gelu(W1 x_mid))
+            ops.postln_bwd(dx, ctx.y2[i], ctx.st2[i][0], ctx.st2[i][1], P(p + "output.LayerNorm.weight"), dx, T["g2"],
+                           G(p + "output.LayerNorm.weight"), G(p + "output.LayerNorm.bias"), M, D, dr(4 * i + SITE_FFN_OUT))
+            ops.gemm_nt(ops.EPI_DGELU_BF16, T["g2"], wT["w2"], T["dpre"], M, I, D, aux_in=ctx.pre[i], ldaux=I)
+            ops.gemm_nt(ops.EPI_RESID_F32, T["dpre"], wT["w1"], dx, M, D, I)
+            # ---- attention: x_mid = LN(y1), y1 = x_in + dropout(Wo attn(qkv(x_in)))
+            ops.postln_bwd(dx, ctx.y1[i], ctx.st1[i][0], ctx.st1[i][1], P(p + "attention.output.LayerNorm.weight"), dx, T["g1"],
+                           G(p + "attention.output.LayerNorm.weight"), G(p + "attention.output.LayerNorm.bias"), M, D,
+                           dr(4 * i + SITE_ATTN_OUT))
+            ops.gemm_nt(ops.EPI_BF16, T["g1"], wT["o"], T["dao"], M, D, D)
+            ops.attn_masked_bwd(ctx.qkv[i], ctx.ao[i], T["dao"], ctx.lse[i], T["dqkv"], delta, ctx.key_len, B, L, H, scale,
+                                dr(4 * i + SITE_PROBS))
+            ops.gemm_nt(ops.EPI_RESID_F32, T["dqkv"], wT["qkv"], dx, M, D, 3 * D)
+            desc, npb, ntiles, flops, nbytes = T["desc"][i]
+            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+        ops.embed_ln_bwd(dx, ctx.tok.ids, ctx.seq_index, P(E + "word_embeddings.weight"), P(E + "position_embeddings.weight"),
+                         P(E + "token_type_embeddings.weight"), ctx.st0[0], ctx.st0[1], P(E + "LayerNorm.weight"),
+                         G(E + "word_embeddings.weight"), G(E + "position_embeddings.weight"), G(E + "token_type_embeddings.weight"),
+                         G(E + "LayerNorm.weight"), G(E + "LayerNorm.bias"), B, L, D, cfg.pad_id, dr(SITE_EMB))
+
+
+# ---- builders with the reference's names (bert.py:62-69); pretrained checkpoints need the network -> random init -------------
+def _build(num_classes, kw, **cfg):
+    kw = {k: v for k, v in kw.items() if k not in ("pretrained", "pretrained_path")}
+    device = kw.pop("device", "cuda")
+    m = ClassificationBert(BertConfig(num_classes=num_classes, **cfg), device=device)
+    m.init_weights(kw.pop("seed", 0))
+    return m
+
+
+def bert_base_uncased(num_classes=2, **kw):
+    return _build(num_classes, kw, vocab=30522)
+
+
+def bert_base_cased(num_classes=2, **kw):
+    return _build(num_classes, kw, vocab=28996)
+
+
+def bert_tiny_test(num_classes=4, **kw):
+    return _build(num_classes, kw, vocab=120, hidden=128, layers=2, heads=2, inter=512, max_pos=64)

@@ -434,3 +434,84 @@ def fc_bwd(dlogits, feat, Wc, dfeat, dWc, dbc, B, F, K):
 def sgd_flat(p, g, buf, ema, table, nchunks, n, lr, momentum, grad_scale=1.0, ema_m=0.0, first_step=False, zero_grad=True):
     _call("srhip_sgd_flat", _p(p), _p(g), _p(buf), _p(ema), _p(table), nchunks, n, lr, momentum, grad_scale, ema_m, int(first_step),
           int(zero_grad), _s())
+
+
+# ---- post-LN encoder (BERT / Wav2Vec2) --------------------------------------------------------------
+class Drop:
+    """One dropout site of one forward call: (key, thresh, scale) of the counter-based generator in csrc/common.h (drop_keep).
+    ``Drop.none`` disables it.  key = fmix32(lo ^ fmix32(hi + 0x9E3779B9 * site)) of the 64-bit call seed."""
+    __slots__ = ("key", "thresh", "scale")
+    none = None
+
+    def __init__(self, seed, site, p):
+        self.key, self.thresh, self.scale = site_key(seed, site), int(p * 4294967296.0), 1.0 / (1.0 - p)
+
+    def args(self):
+        return self.key, self.thresh, self.scale
+
+
+def _fmix32(h):
+    h &= 0xFFFFFFFF
+    h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    return h ^ (h >> 16)
+
+
+def site_key(seed, site):
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    return _fmix32(lo ^ _fmix32((hi + 0x9E3779B9 * (site & 0xFFFFFFFF)) & 0xFFFFFFFF))
+
+
+def _d(drop):
+    return drop.args() if drop is not None else (0, 0, 1.0)
+
+
+def gemm_nt_resid_dropout(A, B, C, M, N, K, bias, resid, drop, lda=None, ldb=None):
+    """C(f32)[M,N] = resid (or C) + dropout(A . B^T + bias)."""
+    _call("srhip_gemm_nt_resid_dropout", _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s())
+
+
+def attn_masked_fwd(qkv, out, lse, key_len, B, N, H, scale, drop=None):
+    _call("srhip_attn_masked_fwd", _p(qkv), _p(out), _p(lse), _p(key_len), B, N, H, scale, *_d(drop), _s())
+
+
+def attn_masked_bwd(qkv, out, d_out, lse, dqkv, delta_ws, key_len, B, N, H, scale, drop=None):
+    _call("srhip_attn_masked_bwd", _p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), _p(delta_ws), _p(key_len), B, N, H, scale, *_d(drop), _s())
+
+
+def embed_ln_fwd(ids, seq_index, word, pos, type0, gamma, beta, eps, x, xb, mean, rstd, B, L, D, drop=None):
+    _call("srhip_embed_ln_fwd", _p(ids), ids.stride(0), _p(seq_index), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), eps, _p(x), _p(xb),
+          _p(mean), _p(rstd), B, L, D, *_d(drop), _s())
+
+
+def embed_ln_bwd(dy, ids, seq_index, word, pos, type0, mean, rstd, gamma, dword, dpos, dtype0, dgamma, dbeta, B, L, D, pad_id, drop=None):
+    _call("srhip_embed_ln_bwd", _p(dy), _p(ids), ids.stride(0), _p(seq_index), _p(word), _p(pos), _p(type0), _p(mean), _p(rstd), _p(gamma),
+          _p(dword), _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), B, L, D, pad_id, *_d(drop), _s())
+
+
+def postln_fwd(y, gamma, beta, eps, x, xb, mean, rstd, M, D):
+    _call("srhip_postln_fwd", _p(y), _p(gamma), _p(beta), eps, _p(x), _p(xb), _p(mean), _p(rstd), M, D, _s())
+
+
+def postln_bwd(dy, y, mean, rstd, gamma, dx, dxb, dgamma, dbeta, M, D, drop=None):
+    _call("srhip_postln_bwd", _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dxb), _p(dgamma), _p(dbeta), M, D, *_d(drop), _s())
+
+
+def meanpool_fwd(x, feat, B, L, D, drop=None):
+    _call("srhip_meanpool_fwd", _p(x), _p(feat), B, L, D, *_d(drop), _s())
+
+
+def meanpool_bwd(dfeat, dx, B, L, D, drop=None):
+    _call("srhip_meanpool_bwd", _p(dfeat), _p(dx), B, L, D, *_d(drop), _s())
+
+
+def gelu_f32(pre, out, n):
+    _call("srhip_gelu_f32", _p(pre), _p(out), n, _s())
+
+
+def gelu_bwd_f32(dout, pre, dpre, n):
+    _call("srhip_gelu_bwd_f32", _p(dout), _p(pre), _p(dpre), n, _s())
+
+
+def mask_lengths(mask, key_len, B, L):
+    _call("srhip_mask_lengths", _p(mask), mask.stride(0), _p(key_len), B, L, _s())

@@ -1,0 +1,207 @@
+"""BERT engine (semireward_amd/nets/bert.py) on the HIP kernels: building blocks against fp64 torch restatements with the SAME dropout
+masks (oracle/bert_ref.keep_mask), the whole backbone against vectors produced by the reference ClassificationBert on a random-init HF
+BertModel (tests/golden/bert.npz): eval forward, train forward with injected dropout, gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bert_ref as BR                  # noqa: E402
+from semireward_amd import ops                     # noqa: E402
+from semireward_amd.nets import bert               # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def keep(seed, site, shape, p):
+    return torch.from_numpy(BR.keep_mask(seed, site, shape, p))
+
+
+def test_site_key_matches_oracle():
+    for seed, site in [(0, 0), ((71 << 32) + 5, 3), (2 ** 64 - 1, BR.SITE_HEAD), (123456789012345, BR.SITE_EMB)]:
+        assert ops.site_key(seed, site) == BR.site_key(seed, site)
+
+
+@pytest.mark.parametrize("B,N,H,p", [(3, 24, 2, 0.0), (2, 80, 12, 0.1), (2, 200, 3, 0.1), (5, 257, 2, 0.1), (2, 512, 2, 0.1), (1, 512, 12, 0.0)])
+def test_attention_masked_dropout_fwd_bwd(B, N, H, p):
+    """softmax(q k^T / 8 + key mask) with dropout on the probabilities, forward and backward, incl. N = 512 (V fragments of the dQ pass
+    from L2) -- against an fp64 restatement that uses the same counter-based keep mask."""
+    D, seed, site = H * 64, (9 << 32) + 77, 6
+    qkv = rnd(B * N, 3 * D, seed=7, scale=1.2).to(torch.bfloat16)
+    rng = np.random.Generator(np.random.PCG64(N))
+    klen = torch.from_numpy(rng.integers(max(1, N // 3), N + 1, size=B).astype(np.int32))
+    klen[0] = N
+    out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    dr = ops.Drop(seed, site, p) if p > 0 else None
+    ops.attn_masked_fwd(qkv, out, lse, klen.to(DEV), B, N, H, 0.125, dr)
+    x = qkv.double().cpu().requires_grad_(True)
+    q, k, v = (x.view(B, N, 3, H, 64)[:, :, j].transpose(1, 2) for j in range(3))
+    neg = torch.where(torch.arange(N)[None] < klen[:, None], 0.0, float("-inf"))[:, None, None, :].double()
+    probs = torch.softmax(q @ k.transpose(-1, -2) * 0.125 + neg, -1)
+    if p > 0:
+        probs = probs * keep(seed, site, (B, H, N, N), p).double() / (1 - p)
+    ro = (probs @ v).transpose(1, 2).reshape(B * N, D)
+    assert rel(out, ro) < 6e-3
+    d_out = rnd(B * N, D, seed=8).to(torch.bfloat16)
+    ro.backward(d_out.double().cpu())
+    dqkv = torch.zeros(B * N, 3 * D, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    ops.attn_masked_bwd(qkv, out, d_out, lse, dqkv, delta, klen.to(DEV), B, N, H, 0.125, dr)
+    g = x.grad
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert rel(dqkv[:, sl], g[:, sl]) < 1.5e-2, name
+    pad = (torch.arange(N)[None] >= klen[:, None]).reshape(-1)                   # padded positions: never attended -> dK = dV = 0 exactly
+    assert float(dqkv[pad.to(DEV)][:, D:].float().abs().max() if pad.any() else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("D,p", [(128, 0.0), (768, 0.1)])
+def test_embed_postln_meanpool(D, p):
+    B, L, V, S, seed = 5, 19, 50, 3, (3 << 32) + 9
+    rng = np.random.Generator(np.random.PCG64(D))
+    ids = torch.from_numpy(rng.integers(0, V, size=(S, L), dtype=np.int64))
+    ids[:, -3:] = 0                                                                    # [PAD] rows
+    idx = torch.tensor([2, 0, 1, 1, 2], dtype=torch.int32)
+    word, pos, typ = rnd(V, D, seed=1), rnd(L + 4, D, seed=2), rnd(2, D, seed=3)
+    gam, bet = 1 + 0.1 * rnd(D, seed=4), 0.1 * rnd(D, seed=5)
+    M = B * L
+    x, xb = torch.empty(M, D, device=DEV), torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    dr = (lambda s: ops.Drop(seed, s, p)) if p > 0 else (lambda s: None)
+    ops.embed_ln_fwd(ids.to(DEV), idx.to(DEV), word, pos, typ, gam, bet, 1e-12, x, xb, mean, rstd, B, L, D, dr(1))
+    c = lambda t: t.double().cpu().requires_grad_(True)   # noqa: E731
+    wc, pc, tc, gc, bc = c(word), c(pos), c(typ), c(gam), c(bet)
+    e = torch.nn.functional.embedding(ids[idx.long()], wc, padding_idx=0) + pc[:L][None] + tc[0]
+    r = torch.nn.functional.layer_norm(e, (D,), gc, bc, 1e-12)
+    if p > 0:
+        r = r * keep(seed, 1, (B, L, D), p).double() / (1 - p)
+    assert rel(x, r.reshape(M, D)) < 2e-6 and rel(xb.float(), r.reshape(M, D)) < 4e-3
+    dy = rnd(M, D, seed=6)
+    r.backward(dy.double().cpu().view(B, L, D))
+    dw, dp_, dt = torch.zeros(V, D, device=DEV), torch.zeros(L + 4, D, device=DEV), torch.zeros(2, D, device=DEV)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.embed_ln_bwd(dy, ids.to(DEV), idx.to(DEV), word, pos, typ, mean, rstd, gam, dw, dp_, dt[0], dg, db, B, L, D, 0, dr(1))
+    assert rel(dw, wc.grad) < 1e-5 and rel(dp_, pc.grad) < 1e-5 and rel(dt, tc.grad) < 1e-5
+    assert rel(dg, gc.grad) < 1e-5 and rel(db, bc.grad) < 1e-5
+    assert float(dw[0].abs().max()) == 0.0
+    # post-LN forward / backward (dropout mask on the bf16 branch gradient only)
+    y = rnd(M, D, seed=7, scale=2.0) + 0.3
+    ops.postln_fwd(y, gam, bet, 1e-12, x, xb, mean, rstd, M, D)
+    yc = c(y); gc, bc = c(gam), c(bet)
+    r = torch.nn.functional.layer_norm(yc, (D,), gc, bc, 1e-12)
+    assert rel(x, r) < 2e-6 and rel(xb.float(), r) < 4e-3
+    r.backward(dy.double().cpu())
+    dx, dxb = torch.empty(M, D, device=DEV), torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    dg.zero_(); db.zero_()
+    ops.postln_bwd(dy, y, mean, rstd, gam, dx, dxb, dg, db, M, D, dr(2))
+    assert rel(dx, yc.grad) < 1e-5 and rel(dg, gc.grad) < 1e-5 and rel(db, bc.grad) < 1e-5
+    masked = yc.grad * (keep(seed, 2, (M, D), p).double() / (1 - p) if p > 0 else 1.0)
+    assert rel(dxb.float(), masked) < 4e-3
+    # in-place variant (dx aliases dy), as the engine calls it
+    dy2 = dy.clone()
+    ops.postln_bwd(dy2, y, mean, rstd, gam, dy2, dxb, dg, db, M, D, dr(2))
+    assert torch.equal(dy2, dx)
+    # mean pool over ALL positions + its adjoint
+    feat = torch.empty(B, D, device=DEV)
+    xin = rnd(M, D, seed=8)
+    ops.meanpool_fwd(xin, feat, B, L, D, dr(3))
+    xc = c(xin)
+    r = (xc.view(B, L, D) * (keep(seed, 3, (B, L, D), p).double() / (1 - p) if p > 0 else 1.0)).mean(1)
+    assert rel(feat, r) < 2e-6
+    df = rnd(B, D, seed=9)
+    r.backward(df.double().cpu())
+    ops.meanpool_bwd(df, dx, B, L, D, dr(3))
+    assert rel(dx, xc.grad) < 2e-6
+    # GELU (exact erf) forward / backward
+    ops.gelu_f32(xin, dx, M * D)
+    xc = c(xin); r = torch.nn.functional.gelu(xc); r.backward(dy.double().cpu())
+    assert rel(dx, r) < 2e-6
+    ops.gelu_bwd_f32(dy, xin, dx, M * D)
+    assert rel(dx, xc.grad) < 2e-6
+    # key lengths
+    am = (torch.arange(L)[None] < torch.tensor([[3], [19], [7]])).long()
+    kl = torch.empty(S, dtype=torch.int32, device=DEV)
+    ops.mask_lengths(am.to(DEV), kl, S, L)
+    assert kl.cpu().tolist() == [3, 19, 7]
+
+
+def test_gemm_resid_dropout():
+    M, N, K, seed = 300, 768, 256, (5 << 32) + 1
+    A, Bm = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2, scale=0.1).to(torch.bfloat16)
+    bias, R = rnd(N, seed=3), rnd(M, N, seed=4)
+    for big in (False, True):
+        Mx = 8192 + 37 if big else M            # 64x64-tile kernel (under-filled grid) and the 128x128 LDS-DMA kernel
+        Ax = A.repeat(Mx // M + 1, 1)[:Mx].contiguous()
+        Rx = R.repeat(Mx // M + 1, 1)[:Mx].contiguous()
+        C = torch.empty(Mx, N, device=DEV)
+        ops.gemm_nt_resid_dropout(Ax, Bm, C, Mx, N, K, bias, Rx, ops.Drop(seed, 4, 0.1))
+        ref = Rx.double().cpu() + (Ax.double().cpu() @ Bm.double().cpu().t() + bias.double().cpu()) * keep(seed, 4, (Mx, N), 0.1).double() / 0.9
+        assert rel(C, ref) < 1e-5
+        C2 = Rx.clone()
+        ops.gemm_nt_resid_dropout(Ax, Bm, C2, Mx, N, K, bias, None, None)                 # in place, no dropout
+        assert rel(C2, Rx.double().cpu() + Ax.double().cpu() @ Bm.double().cpu().t() + bias.double().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["tiny", "base"])
+def test_bert_matches_reference_golden(golden, tag):
+    g = golden("bert")
+    C, B, L, seed, dseed = [int(v) for v in g[f"{tag}/meta"]]
+    cfg = BR.BertCfg(num_classes=C, **(BR.BERT_TINY_TEST if tag == "tiny" else BR.BERT_BASE))
+    model = bert.ClassificationBert(bert.BertConfig(num_classes=C, **(BR.BERT_TINY_TEST if tag == "tiny" else BR.BERT_BASE)), device=DEV)
+    assert sorted(n for n, _ in model.names_shapes) == sorted(n for n, _ in BR.param_shapes(cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in BR.synth_params(cfg, seed).items()})
+    ids, mask = (torch.from_numpy(a) for a in BR.synth_tokens(seed + 1, B, L, cfg.vocab))
+    rng = np.random.Generator(np.random.PCG64(seed + 2))
+    y = torch.from_numpy(rng.integers(0, C, size=(B,), dtype=np.int64)).to(DEV)
+    w = torch.from_numpy(rng.random(B).astype(np.float32)).to(DEV)
+    x = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
+    TOL, TOLF = 4e-2, 2e-2                           # bf16 GEMM / attention operands through up to 12 post-LN layers vs the fp32 reference
+                                                     # (logits: small differences of pooled features through the 2-layer head)
+    model.eval()
+    o = model(x)
+    assert rel(o["logits"], g[f"{tag}/eval_logits"]) < TOL and rel(o["feat"], g[f"{tag}/eval_feat"]) < TOLF
+    model.train()
+    model.inject_seed = dseed
+    tok = bert.TokenBatch.from_dict(x, DEV)
+    lg, ft, ctx = model.forward_features(tok, None, save=True)
+    assert rel(lg, g[f"{tag}/train_logits"]) < TOL and rel(ft, g[f"{tag}/train_feat"]) < TOLF
+    lg_i, ft_i, _ = model.forward_features(tok, None, save=False)                          # the no-save path computes the same thing
+    assert rel(lg_i, lg) < 2e-3 and rel(ft_i, ft) < 2e-3
+    loss, dl = torch.empty(1, device=DEV), torch.empty(B, C, device=DEV)
+    ops.masked_ce(lg, y, w, None, 1.0, loss, dl, B, C)
+    assert float(loss) == pytest.approx(float(g[f"{tag}/loss"]), rel=3e-2)
+    model.zero_grad()
+    model.backward(ctx, dl)
+    worst = {}
+    for n, gr in model.named_grads():
+        gs = g.samp(f"{tag}/grad/{n}")
+        a = gr.reshape(-1).cpu().numpy()[::gs["stride"]]
+        if np.abs(gs["sample"]).max() == 0.0:
+            assert np.abs(a).max() == 0.0, n                                               # pooler, [PAD] row
+            continue
+        if n.endswith("key.bias"):
+            # analytically ZERO (a key bias shifts every score of a query row by the same q . b_k: softmax is invariant); the reference's
+            # own value is fp32 round-off, ours is bf16 round-off -- both must vanish against the query-bias gradient
+            qs = np.abs(g.samp(f"{tag}/grad/{n.replace('key', 'query')}")["sample"]).max()
+            assert np.abs(gs["sample"]).max() < 1e-4 * qs and np.abs(a).max() < 3e-2 * qs, n
+            continue
+        worst[n] = rel(a, gs["sample"])
+    bad = {k: v for k, v in worst.items() if v > 6e-2}
+    assert not bad, bad
+    # gathered sequences (seq_index) = the same rows
+    idx = torch.tensor([B - 1, 0], dtype=torch.int32, device=DEV)
+    model.eval()
+    lg2, _, _ = model.forward_features(tok, idx, save=False)
+    assert rel(lg2, torch.from_numpy(g[f"{tag}/eval_logits"])[[B - 1, 0]]) < TOL
