@@ -254,7 +254,9 @@ int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, float
  *   postln_fwd   : x = LayerNorm(y) as fp32 (next residual) and bf16 (next GEMM operand); x may alias y
  *   postln_bwd   : dy = d/d(LayerNorm output) -> dx = d/dy fp32 (may alias dy) and dx_bf16 = dropout-masked dx (the gradient of the branch that
  *                  was added under dropout: operand of its dX / dW products); dgamma +=, dbeta += (atomic)
- *   meanpool_fwd : feat[b] = mean over ALL L rows of dropout(x[b])  (bert.py:36-37, padding included);  meanpool_bwd: dx = its adjoint
+ *   meanpool_fwd : feat[b] = mean over ALL L rows of dropout(x[b])  (bert.py:36-37, padding included);  meanpool_bwd: dx = its adjoint.
+ *                  seq_len int32 [B] (NULL: L): the padded length of every sequence's OWN batch when differently padded batches (x_lb, x_ulb_w,
+ *                  x_ulb_s of a use_cat=False config) share one launch padded to L -- rows >= seq_len[b] are filler: not averaged, zero gradient
  *   gelu_f32 / gelu_bwd_f32 : nn.GELU() between the classifier Linears (bert.py:16-20; the Linears are srhip_fc_fwd / srhip_fc_bwd)
  *   mask_lengths : key_len[b] = sum(attention_mask[b, :]) for the right-padded batches of nlp_collactor.py:63-69 */
 int srhip_embed_ln_fwd(const long long* ids, int ld_ids, const int* seq_index, const float* word, const float* pos, const float* type0,
@@ -268,8 +270,10 @@ int srhip_postln_fwd(const float* y, const float* gamma, const float* beta, floa
                      int D, void* stream);
 int srhip_postln_bwd(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx, void* dx_bf16,
                      float* dgamma, float* dbeta, int M, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
-int srhip_meanpool_fwd(const float* x, float* feat, int B, int L, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
-int srhip_meanpool_bwd(const float* dfeat, float* dx, int B, int L, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_meanpool_fwd(const float* x, float* feat, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,
+                       float drop_scale, void* stream);
+int srhip_meanpool_bwd(const float* dfeat, float* dx, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,
+                       float drop_scale, void* stream);
 int srhip_gelu_f32(const float* pre, float* out, long n, void* stream);
 int srhip_gelu_bwd_f32(const float* dout, const float* pre, float* dpre, long n, void* stream);
 int srhip_mask_lengths(const long long* mask, int ld, int* key_len, int B, int L, void* stream);

@@ -633,6 +633,107 @@ def gen_trace_soft():
     gen_trace(TRACE_SOFT, "srsoftmatch_trace.npz")
 
 
+# usb_nlp flavour (BASELINE.json configs[3]; config/SemiReward/usb_nlp/softmatch/*.yaml): BERT backbone (2 layers here), dict batches padded
+# to DIFFERENT lengths, use_cat False, AdamW lr 5e-4 (yaml: 5e-5; larger so that 6 steps move the parameters visibly) / wd 5e-4 / layer_decay
+# 0.65, dist_uniform True.  Dropout is switched off (config probabilities 0, module.dropout.p = 0): the reference's torch-RNG masks cannot be
+# reproduced; train-mode dropout arithmetic is pinned separately by bert.npz with injected masks.
+TRACE_SOFT_BERT = dict(num_train_iter=2000, start_timing=100, N_k=10, C=4, Bl=3, Bu=5, its=[0, 1, 99, 100, 101, 110], seed=113,
+                       num_warmup_iter=50, algorithm="srsoftmatch", ema_p=0.5, n_sigma=2, dist_uniform=True, ulb_dest_len=256,
+                       lr=5e-4, weight_decay=5e-4, layer_decay=0.65, L=(20, 24, 17), head_gain=8.0)
+
+
+def trace_bert_params(cfg, seed, head_gain):
+    """bert_ref.synth_params with a louder last classifier layer: the mean-pooled features of a random-init encoder differ little between
+    sequences, and with the stock head every SoftMatch weight would be 1."""
+    bp = BR.synth_params(cfg, seed)
+    bp["classifier.2.weight"] = bp["classifier.2.weight"] * np.float32(head_gain)
+    return bp
+
+
+def synth_token_step(tr, cfg, n):
+    """(x_lb, y_lb, x_ulb_w, x_ulb_s) of trace step n: three right-padded batches of different padded lengths."""
+    seed, (Ll, Lw, Ls) = tr["seed"], tr["L"]
+    lb, w, s_ = (BR.synth_tokens(seed + 10 + 3 * n + j, B, L, cfg.vocab) for j, (B, L) in enumerate(((tr["Bl"], Ll), (tr["Bu"], Lw), (tr["Bu"], Ls))))
+    y = np.random.Generator(np.random.PCG64(seed + 5000 + n)).integers(0, tr["C"], size=(tr["Bl"],), dtype=np.int64)
+    return lb, y, w, s_
+
+
+def gen_trace_soft_bert():
+    tr = TRACE_SOFT_BERT
+    C, seed = tr["C"], tr["seed"]
+    cfg = BR.BertCfg(num_classes=C, p_drop=0.0, **BR.BERT_TINY_TEST)
+    Fd = cfg.hidden
+    bp = trace_bert_params(cfg, seed, tr["head_gain"])
+    rp = synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)
+    gp = synth.synth_params(S.generator_shapes(Fd), seed + 2)
+    model = build_ref_bert(cfg, bp)
+    for m_ in model.modules():
+        if isinstance(m_, torch.nn.Dropout):
+            m_.p = 0.0
+    model.bert.config.attention_probs_dropout_prob = 0.0
+    for lyr in model.bert.encoder.layer:
+        if hasattr(lyr.attention.self, "dropout") and isinstance(lyr.attention.self.dropout, torch.nn.Dropout):
+            lyr.attention.self.dropout.p = 0.0
+        if hasattr(lyr.attention.self, "dropout_prob"):
+            lyr.attention.self.dropout_prob = 0.0
+    model.train()
+    alg = build_headless_srflexmatch(model, C, Fd, tr)
+    alg.use_cat = False
+    bu = R.mod("semilearn.core.utils.build")
+    alg.optimizer = bu.get_optimizer(model, "AdamW", tr["lr"], 0.9, tr["weight_decay"], tr["layer_decay"])
+    alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
+    load_module_params(alg.rewarder, rp)
+    load_module_params(alg.generator, gp)
+    out, prev_it = {}, -1
+    dx = lambda b: {"input_ids": T(b[0]), "attention_mask": T(b[1])}   # noqa: E731
+    for n, it in enumerate(tr["its"]):
+        for _ in range(it - prev_it - 1):
+            alg.scheduler.step()
+        prev_it = it
+        alg.it = it
+        K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
+        lb, y, w, s_ = synth_token_step(tr, cfg, n)
+        cm = _CountingModel(model)
+        alg.model = cm
+        rec = dict(mask=[])
+        mh = alg.hooks_dict["MaskingHook"]
+        orig = mh.masking
+
+        def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
+            m = _orig(algorithm, *a, **k)
+            _rec["mask"].append(m.numpy().copy())
+            return m
+        mh.masking = wrapped
+        rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
+        o, log = alg.train_step(dx(lb), T(y), dx(w), dx(s_))
+        mh.masking = orig
+        assert cm.calls == 3 + 2 * K, (cm.calls, K)          # use_cat False: lb + s + w, then (s, w) per data_generator pass
+        o["loss"].backward()
+        p = f"it{it}"
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/grad/{nme}", samp(prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32), 64), out)
+        out[f"{p}/lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / tr["lr"])      # classifier group: scale 1
+        alg.optimizer.step(); alg.scheduler.step(); model.zero_grad()
+        for k_, v in log.items():
+            out[f"{p}/log/{k_.split('/')[-1]}"] = np.float64(v)
+        out[f"{p}/K"] = np.int64(K)
+        out[f"{p}/masks"] = np.stack(rec["mask"])
+        for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+            out[f"{p}/feat/{k_}"] = o["feat"][k_].detach().numpy()
+        out[f"{p}/rewarder_updated"] = np.int64(any(not torch.equal(rbefore[k_], v.detach()) for k_, v in alg.rewarder.named_parameters()))
+        for k_, v in alg.rewarder.named_parameters():
+            flat(f"{p}/rewarder/{k_}", samp(v.detach().numpy(), 64), out)
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
+        out[f"{p}/max_reward"] = np.float64(float(alg.max_reward))
+        dh = alg.hooks_dict["DistAlignHook"]
+        out[f"{p}/mu"] = np.float32(mh.prob_max_mu_t); out[f"{p}/var"] = np.float32(mh.prob_max_var_t)
+        out[f"{p}/p_model"] = dh.p_model.numpy().copy(); out[f"{p}/p_target"] = dh.p_target.numpy().copy()
+    out["meta/its"] = np.array(tr["its"], dtype=np.int64)
+    print("srsoftmatch_bert_trace.npz mask mean", np.concatenate([out[f"it{it}/masks"].ravel() for it in tr["its"]]).mean())
+    np.savez_compressed(os.path.join(OUT, "srsoftmatch_bert_trace.npz"), **out)
+
+
 def gen_softmatch_hook():
     """DistAlignEMAHook + SoftMatchWeightingHook sequences straight from the reference (both p_target modes)."""
     smu = R.mod("semilearn.algorithms.srsoftmatch.utils")
@@ -784,7 +885,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
-            bert=gen_bert)
+            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

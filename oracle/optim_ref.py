@@ -39,6 +39,26 @@ def vit_param_hparams(names_shapes, depth, lr, weight_decay, layer_decay,
     return out
 
 
+def bert_param_hparams(names_shapes, layers, lr, weight_decay, layer_decay):
+    """ClassificationBert.group_matcher (bert.py:54-56: stem = ^bert.embeddings, blocks = ^bert.encoder.layer.(\\d+)) through
+    group_with_matcher(reverse=True) (nets/utils.py:208-270): embeddings -> 0, encoder layer i -> i + 1, everything unmatched (pooler,
+    classifier) -> layer_max = layers + 1; lr scale layer_decay ** (layer_max - id), no weight decay for 1-D tensors (nets/utils.py:170-176).
+    The pooler feeds nothing on this path: its .grad stays None and torch.optim.AdamW skips it entirely -> (0, 0)."""
+    layer_max = layers + 1
+    out = {}
+    for name, shape in names_shapes:
+        if name.startswith("bert.embeddings"):
+            lid = 0
+        elif name.startswith("bert.encoder.layer."):
+            lid = int(name.split(".")[3]) + 1
+        else:
+            lid = layer_max
+        scale = layer_decay ** (layer_max - lid) if layer_decay != 1.0 else 1.0
+        wd = 0.0 if len(shape) == 1 else weight_decay
+        out[name] = (0.0, 0.0) if name.startswith("bert.pooler") else (scale * lr, wd)
+    return out
+
+
 def cosine_warmup_factor(step, num_training_steps, num_warmup_steps=0, num_cycles=7.0 / 16.0):
     """build.py:237-249.  LambdaLR applies factor(it) at 0-based iteration ``it``."""
     if step < num_warmup_steps:

@@ -39,7 +39,7 @@ class SRFlexMatchOracle:
         self.max_reward = -float("inf")
         self.it = 0
         # optimizer state
-        self.hp = O.vit_param_hparams(V.param_shapes(cfg), cfg.depth, lr, weight_decay, layer_decay)
+        self.hp = self._hparams(cfg, lr, weight_decay, layer_decay)
         self.num_warmup_iter = num_warmup_iter
         self.m = {k: torch.zeros_like(v) for k, v in self.P.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.P.items()}
@@ -49,6 +49,9 @@ class SRFlexMatchOracle:
         self.r_step = 0
 
     # -- helpers -------------------------------------------------------------------
+    def _hparams(self, cfg, lr, weight_decay, layer_decay):
+        return O.vit_param_hparams(V.param_shapes(cfg), cfg.depth, lr, weight_decay, layer_decay)
+
     def _forward(self, P, x_lb, x_ulb_w, x_ulb_s, dp):
         nl = x_lb.shape[0]
         out = V.vit_forward(P, torch.cat((x_lb, x_ulb_w, x_ulb_s)), self.cfg, droppath=dp)

@@ -77,3 +77,29 @@ class SRSoftMatchOracle(SRFlexMatchOracle):
         tr["lr_factor"] = fac
         self.it += 1
         return tr
+
+
+class SRSoftMatchBertOracle(SRSoftMatchOracle):
+    """usb_nlp flavour (BASELINE.json configs[3]; config/SemiReward/usb_nlp/softmatch/*.yaml): ClassificationBert backbone, dict batches
+    ``(ids, mask)`` each padded to its own longest row, ``use_cat: False`` -- train_step forwards x_lb, x_ulb_s and (no_grad) x_ulb_w in
+    separate model calls (srsoftmatch.py:118-128) and data_generator only x_ulb_s and x_ulb_w (:74-80); AdamW with layer_decay through
+    ClassificationBert.group_matcher.  ``seeds``: dropout seed per model call or None (dropout off)."""
+
+    def _hparams(self, cfg, lr, weight_decay, layer_decay):
+        from . import bert_ref as BR
+        return O.bert_param_hparams(BR.param_shapes(cfg), cfg.layers, lr, weight_decay, layer_decay)
+
+    def _forward(self, P, x_lb, x_ulb_w, x_ulb_s, dp):
+        from . import bert_ref as BR
+        lx = fx = None
+        if dp == "pass0":
+            o = BR.bert_forward(P, x_lb[0], x_lb[1], self.cfg)
+            lx, fx = o["logits"], o["feat"]
+        os_ = BR.bert_forward(P, x_ulb_s[0], x_ulb_s[1], self.cfg)
+        with torch.no_grad():
+            ow = BR.bert_forward(P, x_ulb_w[0], x_ulb_w[1], self.cfg)
+        return lx, ow["logits"], os_["logits"], fx, ow["feat"], os_["feat"]
+
+    def train_step(self, x_lb, y_lb, x_ulb_w, x_ulb_s, droppath=None):
+        K = H.sr_decay(self.num_train_iter, self.it) if self.it > self.start_timing else 0
+        return super().train_step(x_lb, y_lb, x_ulb_w, x_ulb_s, ["pass0"] + ["loop"] * K)

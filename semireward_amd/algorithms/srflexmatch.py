@@ -31,8 +31,8 @@ class _Plan:
     """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
     rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
 
-    def __init__(self, cols_img, grad_cols, device):
-        gset = set(grad_cols)
+    def __init__(self, cols_img, grad_cols, device, skip_cols=()):
+        gset = set(grad_cols) | set(skip_cols)
         inf_cols = [c for c in range(len(cols_img)) if c not in gset]
         t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
         self.grad_cols, self.inf_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64)
@@ -42,14 +42,17 @@ class _Plan:
         self.mixed_cols = self.mixed_img = None      # gradient columns first (forward_mixed), built on first use
 
     @classmethod
-    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False):
+    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
-        labelled rows of pass 0 and the strong rows of the last pass."""
+        labelled rows of pass 0 and the strong rows of the last pass.  lb_every_pass=False (use_cat=False, the usb_nlp / usb_audio
+        configs): data_generator forwards only x_ulb_s and x_ulb_w (srflexmatch.py:83-90), so the labelled columns of the passes
+        1..K are never computed (nor read)."""
         Bt = nl + 2 * nu
         cols_img = [j for _ in range(K + 1) for j in range(Bt)]
         grad = list(range(nl)) + ([j for j in range(nl + nu, Bt)] if extra_pass0_strong else []) + \
             [K * Bt + j for j in range(nl + nu, Bt)]
-        p = cls(cols_img, grad, device)
+        skip = [] if lb_every_pass else [k * Bt + j for k in range(1, K + 1) for j in range(nl)]
+        p = cls(cols_img, grad, device, skip)
         p.P, p.Bt = K + 1, Bt
         return p
 
@@ -154,10 +157,19 @@ class SRConsistencyBase(AlgorithmBase):
 
     fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient
 
+    def _tokens(self, x):
+        from ..nets.bert import TokenBatch
+        return x if isinstance(x, TokenBatch) else TokenBatch.from_dict(x, self.device)
+
+    def _token_cat(self, batches):
+        from ..nets.bert import TokenBatch
+        return TokenBatch.cat(batches)
+
     def _forward_passes(self, imgs, nl, nu, K):
-        key = (nl, nu, K)
+        key = (nl, nu, K, bool(self.use_cat))
         if key not in self._plans:
-            self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0)
+            self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
+                                                lb_every_pass=bool(self.use_cat))
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
@@ -178,10 +190,19 @@ class SRConsistencyBase(AlgorithmBase):
             self.trace.update(sr_target=target, sr_losses=losses)
 
     def _train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
-        assert self.use_cat, "USB-style SemiReward configs use use_cat=True (SURVEY.md Appendix C)"
-        nl, nu, it = y_lb.shape[0], x_ulb_w.shape[0], self.it
+        it = self.it
+        if getattr(self.model, "takes_tokens", False):
+            # usb_nlp: x_* are {'input_ids','attention_mask'} dicts, each batch padded to its own longest row (nlp_collactor.py:63-69);
+            # the reference forwards them in separate model calls (use_cat=False, :118-128) -- here they share the batched launches,
+            # filled up to the longest of the three (TokenBatch.cat: identical results, see nets/bert.py)
+            assert not self.use_cat, "token batches of different padded lengths cannot be torch.cat'ed: the usb_nlp configs set use_cat False"
+            tb = [self._tokens(x) for x in (x_lb, x_ulb_w, x_ulb_s)]
+            nl, nu = tb[0].S, tb[1].S
+            imgs = self._token_cat(tb)
+        else:
+            nl, nu = y_lb.shape[0], x_ulb_w.shape[0]
+            imgs = torch.cat((x_lb, x_ulb_w, x_ulb_s)).contiguous()                              # :113
         K = self.sr_decay() if it > self.start_timing else 0                                     # :147, :75
-        imgs = torch.cat((x_lb, x_ulb_w, x_ulb_s)).contiguous()                                  # :113
         L, Fe, ctx = self._forward_passes(imgs, nl, nu, K)
         P, C = K + 1, self.num_classes
         # softmax + max/argmax of the weak logits of ALL passes: one launch (compute_prob :135, argmax :142-146)

@@ -47,10 +47,16 @@ class SRPseudoLabel(SRConsistencyBase):
             return self._step(x_lb, y_lb, x_ulb_w)
 
     def _step(self, x_lb, y_lb, x_ulb_w):
-        nl, nu, it = y_lb.shape[0], x_ulb_w.shape[0], self.it
+        it = self.it
         K = self.sr_decay() if it > self.start_timing else 0                                        # :126, :62
         P, C = K + 1, self.num_classes
-        imgs = torch.cat((x_lb, x_ulb_w)).contiguous()
+        if getattr(self.model, "takes_tokens", False):       # usb_nlp: dict batches, padded separately (see SRConsistencyBase._train_step)
+            tb = [self._tokens(x) for x in (x_lb, x_ulb_w)]
+            nl, nu = tb[0].S, tb[1].S
+            imgs = self._token_cat(tb)
+        else:
+            nl, nu = y_lb.shape[0], x_ulb_w.shape[0]
+            imgs = torch.cat((x_lb, x_ulb_w)).contiguous()
         pl = self._plan(nl, nu, K)
         dpc = None
         if self.inject_droppath is not None:        # tests: [ (dp_lb, dp_ulb), dp_ulb(pass 1), ... ]

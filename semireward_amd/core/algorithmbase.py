@@ -233,7 +233,12 @@ class AlgorithmBase:
         total = 0
         with ops.stream_scope():
             for data in loader:
-                x = data["x_lb"].to(self.device, non_blocking=True).contiguous()
+                x = data["x_lb"]
+                if isinstance(x, dict):                                      # usb_nlp: {'input_ids', 'attention_mask'} (nlp_collactor.py:73)
+                    from ..nets.bert import TokenBatch
+                    x = TokenBatch.from_dict(x, self.device)
+                else:
+                    x = x.to(self.device, non_blocking=True).contiguous()
                 y = data["y_lb"].to(self.device, non_blocking=True).contiguous()
                 B = int(y.shape[0])
                 lg, _, _ = net.forward_features(x, None, None, save=False)

@@ -227,26 +227,32 @@ __global__ __launch_bounds__(256) void postln_bwd_kernel(const float* __restrict
 }
 
 // ---- head: feat[b] = mean over ALL L positions of dropout(x[b])   (bert.py:36-37) -----------------------------------------
-__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ feat, int L, int D, Drop dr) {
+// seq_len (optional): logical padded length of every sequence when batches padded to different lengths share one launch (rows
+// [seq_len[b], L) exist only as filler: excluded from the mean, zero gradient).
+__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ feat, const int* __restrict__ seq_len,
+                                                          int L, int D, Drop dr) {
   __shared__ float part[4][64];
   const int b = blockIdx.x, d = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int Ls = seq_len ? seq_len[b] : L;
   float s = 0.f;
-  for (int p = w; p < L; p += 4) {
+  for (int p = w; p < Ls; p += 4) {
     const size_t i = ((size_t)b * L + p) * D + d;
     const float v = x[i];
     s += (!dr.thresh || drop_keep((uint32_t)i, dr.key, dr.thresh)) ? v : 0.f;
   }
   part[w][threadIdx.x & 63] = s;
   __syncthreads();
-  if (w == 0) feat[(size_t)b * D + d] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * (dr.scale / L);
+  if (w == 0) feat[(size_t)b * D + d] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * (dr.scale / Ls);
 }
-__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx, int L, int D, long n, Drop dr) {
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx, const int* __restrict__ seq_len,
+                                                          int L, int D, long n, Drop dr) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int d = (int)(i % D);
   const long b = i / ((long)L * D);
-  const bool keep = !dr.thresh || drop_keep((uint32_t)i, dr.key, dr.thresh);
-  dx[i] = keep ? dfeat[b * D + d] * (dr.scale / L) : 0.f;
+  const int p = (int)((i / D) % L), Ls = seq_len ? seq_len[b] : L;
+  const bool keep = p < Ls && (!dr.thresh || drop_keep((uint32_t)i, dr.key, dr.thresh));
+  dx[i] = keep ? dfeat[b * D + d] * (dr.scale / Ls) : 0.f;
 }
 
 // nn.GELU() (exact erf) between the two classifier Linears, fp32
@@ -332,20 +338,20 @@ extern "C" int srhip_postln_bwd(const float* dy, const float* y, const float* me
   return SR_OK;
 }
 
-extern "C" int srhip_meanpool_fwd(const float* x, float* feat, int B, int L, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale,
-                                  void* stream) {
+extern "C" int srhip_meanpool_fwd(const float* x, float* feat, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,
+                                  float drop_scale, void* stream) {
   if (!x || !feat || B <= 0 || L <= 0 || D % 64 || (long)B * L * D >= (1L << 32)) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_thresh ? drop_scale : 1.0f};
-  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, D / 64), dim3(256), 0, (hipStream_t)stream, x, feat, L, D, dr);
+  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, D / 64), dim3(256), 0, (hipStream_t)stream, x, feat, seq_len, L, D, dr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
-extern "C" int srhip_meanpool_bwd(const float* dfeat, float* dx, int B, int L, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale,
-                                  void* stream) {
+extern "C" int srhip_meanpool_bwd(const float* dfeat, float* dx, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,
+                                  float drop_scale, void* stream) {
   const long n = (long)B * L * D;
   if (!dfeat || !dx || B <= 0 || L <= 0 || D <= 0 || n >= (1L << 32)) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_thresh ? drop_scale : 1.0f};
-  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, dx, L, D, n, dr);
+  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, dx, seq_len, L, D, n, dr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -41,6 +41,8 @@ class BertConfig:
         assert hidden // heads == 64 and hidden in (128, 384, 768), "libsrhip attention is built for head_dim 64"
         assert inter % 32 == 0 and max_pos <= 512
     embed_dim = property(lambda self: self.hidden)
+    depth = property(lambda self: self.layers)
+    drop_path_rate = 0.0
 
 
 E = "bert.embeddings."
@@ -71,11 +73,13 @@ def param_names_shapes(cfg):
 
 
 class TokenBatch:
-    """A right-padded token batch on the device: ids int64 [S, L] (contiguous), key_len int32 [S]."""
-    __slots__ = ("ids", "key_len", "S", "L")
+    """A right-padded token batch on the device: ids int64 [S, L] (contiguous), key_len int32 [S] = valid tokens per sequence,
+    seq_len int32 [S] or None = the padded length of every sequence's own source batch when batches of different padded lengths were
+    concatenated (rows [seq_len, L) are filler: masked as keys, left out of the mean pool, zero gradient -- results equal separate calls)."""
+    __slots__ = ("ids", "key_len", "seq_len", "S", "L")
 
-    def __init__(self, ids, key_len):
-        self.ids, self.key_len = ids, key_len
+    def __init__(self, ids, key_len, seq_len=None):
+        self.ids, self.key_len, self.seq_len = ids, key_len, seq_len
         self.S, self.L = ids.shape
 
     @classmethod
@@ -92,9 +96,19 @@ class TokenBatch:
 
     @classmethod
     def cat(cls, batches):
-        """Concatenate batches of ONE padded length (the reference's torch.cat of use_cat; differently padded batches stay separate calls)."""
-        assert len({b.L for b in batches}) == 1
-        return cls(torch.cat([b.ids for b in batches]).contiguous(), torch.cat([b.key_len for b in batches]).contiguous())
+        """One batch out of several (x_lb, x_ulb_w, x_ulb_s of one step; the reference forwards them in separate model calls under
+        use_cat=False, each padded to its own longest row).  Shorter batches are filled up to the longest L with [PAD]."""
+        L = max(b.L for b in batches)
+        kl = torch.cat([b.key_len for b in batches]).contiguous()
+        if all(b.L == L and b.seq_len is None for b in batches):
+            return cls(torch.cat([b.ids for b in batches]).contiguous(), kl)
+        ids = torch.zeros(sum(b.S for b in batches), L, dtype=torch.int64, device=kl.device)
+        sl, r = [], 0
+        for b in batches:
+            ids[r:r + b.S, :b.L] = b.ids
+            sl.append(b.seq_len if b.seq_len is not None else torch.full((b.S,), b.L, dtype=torch.int32, device=kl.device))
+            r += b.S
+        return cls(ids, kl, torch.cat(sl).contiguous())
 
 
 class ClassificationBert:
@@ -180,6 +194,9 @@ class ClassificationBert:
 
     def refresh_operands(self):
         ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
         if self._wT_desc is None:
             items, cfg = [], self.cfg
             D, I = cfg.hidden, cfg.inter
@@ -194,6 +211,22 @@ class ClassificationBert:
 
     def no_weight_decay(self):
         return []
+
+    frozen_params = ("bert.pooler.dense.weight", "bert.pooler.dense.bias")    # feed nothing on this path: grad None in the reference
+
+    def layer_ids(self):
+        """group_with_matcher(named_parameters, group_matcher, reverse=True) (nets/utils.py:208-270): embeddings 0, encoder layer i -> i + 1,
+        everything unmatched (pooler, classifier) -> the last id."""
+        L = self.cfg.layers
+        ids = {}
+        for n, _ in self.names_shapes:
+            if n.startswith("bert.embeddings"):
+                ids[n] = 0
+            elif n.startswith("bert.encoder.layer."):
+                ids[n] = int(n.split(".")[3]) + 1
+            else:
+                ids[n] = L + 1
+        return ids, L + 1
 
     def group_matcher(self, coarse=False, prefix=""):
         return dict(stem=r"^{}bert.embeddings".format(prefix), blocks=r"^{}bert.encoder.layer.(\d+)".format(prefix))
@@ -256,13 +289,16 @@ class ClassificationBert:
         seed = self.next_seed() if seed == "auto" else seed
         dr = (lambda site: ops.Drop(seed, site, cfg.p_drop)) if seed is not None else (lambda site: None)
         key_len = tok.key_len if seq_index is None else tok.key_len.index_select(0, seq_index.long()).contiguous()
+        seq_len = None
+        if tok.seq_len is not None:
+            seq_len = tok.seq_len if seq_index is None else tok.seq_len.index_select(0, seq_index.long()).contiguous()
         P, wb = self.p, self.flat_bf16
         t = "s" if save else "i"
         ctx = None
         x = self._buf(t + "x", (M, D), f32)
         if save:
             ctx = self._ctx_buffers(B, L, tag)
-            ctx.B, ctx.L, ctx.tok, ctx.seq_index, ctx.key_len, ctx.seed = B, L, tok, seq_index, key_len, seed
+            ctx.B, ctx.L, ctx.tok, ctx.seq_index, ctx.key_len, ctx.seq_len, ctx.seed = B, L, tok, seq_index, key_len, seq_len, seed
             xb = ctx.xb[0]
         else:
             xb = self._buf(t + "xb", (M, D), bf16)
@@ -298,7 +334,7 @@ class ClassificationBert:
         hpre = ctx.hpre if save else torch.empty(B, D, dtype=f32, device=self.device)
         hact = ctx.hact if save else torch.empty(B, D, dtype=f32, device=self.device)
         logits = torch.empty(B, C, dtype=f32, device=self.device)
-        ops.meanpool_fwd(x, feat, B, L, D, dr(SITE_HEAD))
+        ops.meanpool_fwd(x, feat, B, L, D, dr(SITE_HEAD), seq_len)
         ops.fc_fwd(feat, P("classifier.0.weight"), P("classifier.0.bias"), hpre, B, D, D)
         ops.gelu_f32(hpre, hact, B * D)
         ops.fc_fwd(hact, P("classifier.2.weight"), P("classifier.2.bias"), logits, B, D, C)
@@ -354,7 +390,7 @@ class ClassificationBert:
         ops.gelu_bwd_f32(dhact, ctx.hpre, dhpre, B * D)
         ops.fc_bwd(dhpre, ctx.feat, P("classifier.0.weight"), dfeat, G("classifier.0.weight"), G("classifier.0.bias"), B, D, D)
         dx = self._buf("b_dx", (M, D), f32)
-        ops.meanpool_bwd(dfeat, dx, B, L, D, dr(SITE_HEAD))
+        ops.meanpool_bwd(dfeat, dx, B, L, D, dr(SITE_HEAD), ctx.seq_len)
         delta = self._buf("b_delta", (B, H, L), f32)
         T = self._bwd_plan(M, ctx)
         scale = 64 ** -0.5

@@ -497,12 +497,12 @@ def postln_bwd(dy, y, mean, rstd, gamma, dx, dxb, dgamma, dbeta, M, D, drop=None
     _call("srhip_postln_bwd", _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dxb), _p(dgamma), _p(dbeta), M, D, *_d(drop), _s())
 
 
-def meanpool_fwd(x, feat, B, L, D, drop=None):
-    _call("srhip_meanpool_fwd", _p(x), _p(feat), B, L, D, *_d(drop), _s())
+def meanpool_fwd(x, feat, B, L, D, drop=None, seq_len=None):
+    _call("srhip_meanpool_fwd", _p(x), _p(feat), _p(seq_len), B, L, D, *_d(drop), _s())
 
 
-def meanpool_bwd(dfeat, dx, B, L, D, drop=None):
-    _call("srhip_meanpool_bwd", _p(dfeat), _p(dx), B, L, D, *_d(drop), _s())
+def meanpool_bwd(dfeat, dx, B, L, D, drop=None, seq_len=None):
+    _call("srhip_meanpool_bwd", _p(dfeat), _p(dx), _p(seq_len), B, L, D, *_d(drop), _s())
 
 
 def gelu_f32(pre, out, n):

@@ -16,10 +16,13 @@ from . import ops
 CHUNK = 4096
 
 
-def build_chunk_table(sizes, chunk=CHUNK):
-    """int32 [n_chunks, 4] = (offset, length, tensor id, 0); a chunk never straddles two tensors."""
+def build_chunk_table(sizes, chunk=CHUNK, offsets=None):
+    """int32 [n_chunks, 4] = (offset, length, tensor id, 0); a chunk never straddles two tensors.  ``offsets``: start of every tensor in
+    the flat block (default: densely packed)."""
     rows, off = [], 0
     for tid, n in enumerate(sizes):
+        if offsets is not None:
+            off = offsets[tid]
         o = 0
         while o < n:
             ln = min(chunk, n - o)
@@ -41,12 +44,19 @@ def vit_layer_id(name, depth):
     return depth + 1            # head -> layer_max
 
 
-def layer_decay_hparams(names_shapes, depth, lr, weight_decay, layer_decay, no_weight_decay=("pos_embed", "cls_token")):
+def layer_decay_hparams(names_shapes, depth, lr, weight_decay, layer_decay, no_weight_decay=("pos_embed", "cls_token"), layer_ids=None,
+                        frozen=()):
+    """(lr, weight_decay) per tensor.  ``layer_ids``: (name -> layer id, layer_max) of the model's group_matcher (default: the ViT's);
+    ``frozen``: parameters whose gradient is None in the reference (torch optimizers skip them entirely: no update, no decay)."""
     out = []
     for name, shape in names_shapes:
-        scale = layer_decay ** (depth + 1 - vit_layer_id(name, depth)) if layer_decay != 1.0 else 1.0
+        if layer_ids is not None:
+            lid, lmax = layer_ids[0][name], layer_ids[1]
+        else:
+            lid, lmax = vit_layer_id(name, depth), depth + 1
+        scale = layer_decay ** (lmax - lid) if layer_decay != 1.0 else 1.0
         wd = 0.0 if (len(shape) == 1 or name in no_weight_decay or name.endswith(".bias")) else weight_decay
-        out.append((scale * lr, wd))
+        out.append((0.0, 0.0) if name in frozen else (scale * lr, wd))
     return out
 
 
@@ -65,10 +75,12 @@ class FusedAdamW:
         self.model = model
         dev = model.flat.device
         ns = model.names_shapes
-        hp = layer_decay_hparams(ns, model.cfg.depth, lr, weight_decay, layer_decay)
+        hp = layer_decay_hparams(ns, model.cfg.depth, lr, weight_decay, layer_decay, no_weight_decay=tuple(model.no_weight_decay()),
+                                 layer_ids=model.layer_ids() if hasattr(model, "layer_ids") else None,
+                                 frozen=tuple(getattr(model, "frozen_params", ())))
         self.lr_t = torch.tensor([h[0] for h in hp], dtype=torch.float32, device=dev)
         self.wd_t = torch.tensor([h[1] for h in hp], dtype=torch.float32, device=dev)
-        self.table = build_chunk_table([int(torch.Size(s).numel()) for _, s in ns]).to(dev)
+        self.table = build_chunk_table([int(torch.Size(s).numel()) for _, s in ns], offsets=[model.offsets[n][0] for n, _ in ns]).to(dev)
         self.m = torch.zeros_like(model.flat)
         self.v = torch.zeros_like(model.flat)
         self.betas, self.eps = betas, eps

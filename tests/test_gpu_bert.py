@@ -124,6 +124,17 @@ def test_embed_postln_meanpool(D, p):
     r.backward(df.double().cpu())
     ops.meanpool_bwd(df, dx, B, L, D, dr(3))
     assert rel(dx, xc.grad) < 2e-6
+    # differently padded batches in one launch: rows >= seq_len[b] are filler (not averaged, zero gradient)
+    sl = torch.tensor([L, L - 4, 1, L, 7], dtype=torch.int32)
+    ops.meanpool_fwd(xin, feat, B, L, D, dr(3), sl.to(DEV))
+    xc = c(xin)
+    km = (keep(seed, 3, (B, L, D), p).double() / (1 - p) if p > 0 else torch.ones(B, L, D, dtype=torch.float64))
+    valid = (torch.arange(L)[None] < sl[:, None]).double()[:, :, None]
+    r = (xc.view(B, L, D) * km * valid).sum(1) / sl.double()[:, None]
+    assert rel(feat, r) < 2e-6
+    r.backward(df.double().cpu())
+    ops.meanpool_bwd(df, dx, B, L, D, dr(3), sl.to(DEV))
+    assert rel(dx, xc.grad) < 2e-6 and float(dx.view(B, L, D)[2, 1:].abs().max()) == 0.0
     # GELU (exact erf) forward / backward
     ops.gelu_f32(xin, dx, M * D)
     xc = c(xin); r = torch.nn.functional.gelu(xc); r.backward(dy.double().cpu())
@@ -205,3 +216,67 @@ def test_bert_matches_reference_golden(golden, tag):
     model.eval()
     lg2, _, _ = model.forward_features(tok, idx, save=False)
     assert rel(lg2, torch.from_numpy(g[f"{tag}/eval_logits"])[[B - 1, 0]]) < TOL
+
+
+def test_srsoftmatch_bert_trace(golden):
+    """BASELINE.json configs[3] (usb_nlp: BERT + SoftMatch + SemiReward, use_cat False, three batches of different padded lengths, AdamW
+    with layer decay 0.65) end to end on the HIP engine against a trace of the reference: SoftMatch weights of every pass, losses, features,
+    DistAlign / Gaussian EMA state, rewarder updates, parameters after the fused AdamW steps."""
+    import argparse
+    from oracle import semireward_ref as S
+    from oracle.gen_golden import TRACE_SOFT_BERT as tr, synth_token_step, trace_bert_params
+    from semireward_amd.algorithms import get_algorithm
+    from semireward_amd.utils import synth
+    g = golden("srsoftmatch_bert_trace")
+    C, seed = tr["C"], tr["seed"]
+    cfg = BR.BertCfg(num_classes=C, p_drop=0.0, **BR.BERT_TINY_TEST)
+    Fd = cfg.hidden
+    args = argparse.Namespace(
+        algorithm="srsoftmatch", num_classes=C, num_train_iter=tr["num_train_iter"], epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False,
+        amp=False, optim="AdamW", lr=tr["lr"], weight_decay=tr["weight_decay"], layer_decay=tr["layer_decay"],
+        num_warmup_iter=tr["num_warmup_iter"], T=0.5, hard_label=True, ema_p=tr["ema_p"], n_sigma=tr["n_sigma"], dist_uniform=tr["dist_uniform"],
+        dist_align=True, per_class=False, ulb_dest_len=tr["ulb_dest_len"], N_k=tr["N_k"], start_timing=tr["start_timing"], feature_dim=Fd,
+        sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    builder = lambda num_classes, device: bert.ClassificationBert(   # noqa: E731
+        bert.BertConfig(num_classes=num_classes, p_drop=0.0, **BR.BERT_TINY_TEST), device=device)
+    alg = get_algorithm(args, builder)
+    Tn = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
+    alg.model.load_state_dict(Tn(trace_bert_params(cfg, seed, tr["head_gain"])))
+    alg.rewarder.load_state_dict(Tn(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)))
+    alg.generator.load_state_dict(Tn(synth.synth_params(S.generator_shapes(Fd), seed + 2)))
+    dx = lambda b: {"input_ids": torch.from_numpy(b[0]), "attention_mask": torch.from_numpy(b[1])}   # noqa: E731
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        alg.it = it
+        alg.optimizer.sched_step = it
+        K = int(g[f"{p}/K"])
+        lb, y, w, s_ = synth_token_step(tr, cfg, n)
+        alg.trace = {}
+        before = alg.rewarder.flat.clone()
+        out, log = alg.train_step(**alg.process_batch(x_lb=dx(lb), y_lb=torch.from_numpy(y), x_ulb_w=dx(w), x_ulb_s=dx(s_)))
+        alg.out_dict, alg.log_dict = out, log
+        assert alg.optimizer.lr_factor() == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        alg.call_hook("after_train_step")
+        assert alg.trace["K"] == K
+        ntol = 1.0 + n                                 # AdamW trajectory noise grows with the steps taken (see test_gpu_srflexmatch.py)
+        masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
+        np.testing.assert_allclose(masks, g[f"{p}/masks"], rtol=0.0, atol=6e-2 * ntol)      # continuous SoftMatch weights
+        for k_ in ("sup_loss", "unsup_loss", "total_loss"):
+            assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=5e-2 * ntol, abs=5e-3), (p, k_)
+        for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+            assert rel(out["feat"][k_], g[f"{p}/feat/{k_}"]) < 2e-2 * ntol, (p, k_)
+        assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+        sm, da = alg.hooks_dict["MaskingHook"], alg.hooks_dict["DistAlignHook"]
+        assert float(sm.prob_max_mu_t) == pytest.approx(float(g[f"{p}/mu"]), rel=2e-2 * ntol)
+        assert float(sm.prob_max_var_t) == pytest.approx(float(g[f"{p}/var"]), rel=8e-2 * ntol)
+        assert rel(da.p_model, g[f"{p}/p_model"]) < 2e-2 * ntol
+    worst = 0.0
+    for nme, v in alg.model.named_parameters():
+        if nme.endswith("key.bias"):
+            continue                                   # analytic gradient 0: Adam amplifies round-off (reference) / bf16 noise (here)
+        gs = g.samp(f"it{tr['its'][-1]}/param/{nme}")
+        a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
+        worst = max(worst, float(np.abs(a - gs["sample"]).max()))
+    assert worst < 4e-3, worst                         # <= a handful of lr-sized (5e-4) steps
+    pool = alg.model.view("bert.pooler.dense.weight").cpu().numpy()
+    assert np.array_equal(pool, trace_bert_params(cfg, seed, tr["head_gain"])["bert.pooler.dense.weight"])   # never touched (grad None in the reference)

@@ -442,3 +442,41 @@ def test_bert_oracle_matches_reference(golden, tag):
         check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 2e-3, 1e-6, f"{tag} grad {n}")
     keep = BR.keep_mask(dseed, 7, (1 << 20,), 0.1)
     assert abs(keep.mean() - 0.9) < 2e-3                                          # the shared generator is a fair Bernoulli(0.9)
+
+
+def test_srsoftmatch_bert_trace(golden):
+    """SRSoftMatch on the BERT backbone (usb_nlp, BASELINE.json configs[3]: dict batches of different padded lengths, use_cat False, AdamW
+    with layer decay through ClassificationBert.group_matcher) against a trace of the reference itself."""
+    from oracle import bert_ref as BR
+    from oracle.gen_golden import TRACE_SOFT_BERT as tr, synth_token_step, trace_bert_params
+    from oracle.srsoftmatch_ref import SRSoftMatchBertOracle
+    g = golden("srsoftmatch_bert_trace")
+    C, seed = tr["C"], tr["seed"]
+    cfg = BR.BertCfg(num_classes=C, p_drop=0.0, **BR.BERT_TINY_TEST)
+    Fd = cfg.hidden
+    orc = SRSoftMatchBertOracle(
+        cfg, TP(trace_bert_params(cfg, seed, tr["head_gain"])), TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
+        TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)), num_train_iter=tr["num_train_iter"], start_timing=tr["start_timing"],
+        N_k=tr["N_k"], ulb_dest_len=tr["ulb_dest_len"], num_warmup_iter=tr["num_warmup_iter"], ema_p=tr["ema_p"], n_sigma=tr["n_sigma"],
+        dist_uniform=tr["dist_uniform"], lr=tr["lr"], weight_decay=tr["weight_decay"], layer_decay=tr["layer_decay"])
+    tt = lambda b: (T(b[0]), T(b[1]))   # noqa: E731
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        orc.it = it
+        K = int(g[f"{p}/K"])
+        lb, y, w, s_ = synth_token_step(tr, cfg, n)
+        assert len({lb[0].shape[1], w[0].shape[1], s_[0].shape[1]}) == 3          # three different padded lengths
+        t = orc.train_step(tt(lb), T(y), tt(w), tt(s_))
+        assert t["K"] == K
+        np.testing.assert_allclose(np.stack([q["mask"].numpy() for q in t["passes"]]), g[f"{p}/masks"], rtol=2e-4, atol=1e-6)
+        for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+            assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=5e-5, abs=2e-6), (p, k_)
+        assert float(orc.sm.mu) == pytest.approx(float(g[f"{p}/mu"]), rel=1e-5) and float(orc.sm.var) == pytest.approx(float(g[f"{p}/var"]), rel=1e-4)
+        np.testing.assert_allclose(orc.da.p_model.numpy(), g[f"{p}/p_model"], rtol=1e-5)
+        assert t["lr_factor"] == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        for nme, _ in BR.param_shapes(cfg):
+            check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 3e-3, 2e-6, f"{p} grad {nme}",
+                       exclude=(lambda i: np.ones_like(i, bool)) if nme.endswith("key.bias") else None)     # analytically zero: round-off only
+    for nme, _ in BR.param_shapes(cfg):                                              # after 6 AdamW steps with layer decay 0.65
+        if not nme.endswith("key.bias"):
+            check_samp(orc.P[nme].numpy(), g.samp(f"it{tr['its'][-1]}/param/{nme}"), 2e-3, 3e-5, f"param {nme}")
