@@ -77,6 +77,10 @@ def main():
     ap.add_argument("--regime", choices=["sr", "pre"], default="sr", help="sr: it > start_timing (K=8); pre: K=0")
     ap.add_argument("--img", type=int, choices=[32, 224], default=32,
                     help="32: ViT-S/2 on 32x32 (north-star config); 224: ViT-S/16 on 224x224 (vit_small_patch16_224, 197 tokens)")
+    ap.add_argument("--net", choices=["vit", "bert"], default="vit",
+                    help="vit: the headline workload (BASELINE.json metric); bert: SRSoftMatch + bert_base_uncased on [B, --seq-len] token "
+                         "batches (usb_nlp shapes, BASELINE.json configs[3]) -- reported under its own metric name")
+    ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--infer-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -103,15 +107,32 @@ def main():
     from semireward_amd.nets import vit
     from semireward_amd.utils import synth
 
-    args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **NS)
-    alg = get_algorithm(args, vit.vit_small_patch2_32 if a.img == 32 else vit.vit_small_patch16_224)
-    P = synth.synth_params(alg.model.names_shapes, 0)
-    alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
-    alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
-    alg.model.seed = 1234 + rank
-    b = synth.synth_batch(100 + rank, bl, a.bu, a.img, 100, 50000)         # each rank: its own shard of the unlabeled stream
-    batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
-    alg.it = START_IT if a.regime == "sr" else 1000
+    if a.net == "bert":
+        # config/SemiReward/usb_nlp/softmatch/softmatch_ag_news_40_0.yaml: bert_base_uncased, 4 classes, batch 8 / uratio 1, max_length 512,
+        # use_cat False, AdamW lr 5e-5 wd 5e-4 layer_decay 0.65, dist_align uniform, ema_p 0.999; num_train_iter 102400, start_timing 10000
+        from semireward_amd.nets import bert
+        nlp = dict(NS, algorithm="srsoftmatch", num_classes=4, num_train_iter=102400, start_timing=10000, lr=5e-5, layer_decay=0.65,
+                   use_cat=False, feature_dim=768, dist_align=True, dist_uniform=True, ema_p=0.999, n_sigma=2, per_class=False)
+        args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **nlp)
+        alg = get_algorithm(args, bert.bert_base_uncased)                       # random init (no network for the checkpoint)
+        alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
+        alg.model.seed = 1234 + rank
+        g = torch.Generator().manual_seed(100 + rank)
+        tok = lambda n: {"input_ids": torch.randint(1, 30522, (n, a.seq_len), generator=g),   # noqa: E731
+                         "attention_mask": torch.ones(n, a.seq_len, dtype=torch.int64)}      # full-length rows
+        batch = alg.process_batch(x_lb=tok(bl), y_lb=torch.randint(0, 4, (bl,), generator=g), x_ulb_w=tok(a.bu), x_ulb_s=tok(a.bu))
+        START = 90001                                                           # sr_decay(): max(8, 1 + 102400 / it) = 8
+    else:
+        args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **NS)
+        alg = get_algorithm(args, vit.vit_small_patch2_32 if a.img == 32 else vit.vit_small_patch16_224)
+        P = synth.synth_params(alg.model.names_shapes, 0)
+        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+        alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
+        alg.model.seed = 1234 + rank
+        b = synth.synth_batch(100 + rank, bl, a.bu, a.img, 100, 50000)         # each rank: its own shard of the unlabeled stream
+        batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+        START = START_IT
+    alg.it = START if a.regime == "sr" else 1000
     alg.optimizer.sched_step = alg.it
     alg.model.train()
 
@@ -152,15 +173,19 @@ def main():
         dt = float(t)
     K = alg.sr_decay() if a.regime == "sr" else 0
     if rank == 0:
-        out = {"metric": "unlabeled images/sec/node (FlexMatch+SR, ViT-S CIFAR-100)", "value": world * a.bu * a.steps / dt,
-               "unit": "unlabeled images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        out = {"metric": "unlabeled images/sec/node (FlexMatch+SR, ViT-S CIFAR-100)" if a.net == "vit" else
+               "unlabeled sequences/sec/node (SoftMatch+SR, BERT-base, L=%d)" % a.seq_len, "value": world * a.bu * a.steps / dt,
+               "unit": "unlabeled images/s" if a.net == "vit" else "unlabeled sequences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": ("SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, " if a.img == 32 else
+               "config": {"workload": ("SRSoftMatch bert_base_uncased, [B, %d] token batches, softmatch_ag_news_40_0.yaml shapes, use_cat False, " % a.seq_len
+                                       if a.net == "bert" else
+                                       "SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, " if a.img == 32 else
                                        "SRFlexMatch ViT-S/16@224 (vit_small_patch16_224) 224x224x3 batches, 100 classes, ") +
                                       ("steady SR regime" if a.regime == "sr" else "pre-start_timing regime"),
                           "per_gpu_batch": {"lb": bl, "ulb_w": a.bu, "ulb_s": a.bu}, "K_passes": K,
-                          "forward_image_passes_per_step": (1 + K) * (bl + 2 * a.bu), "backward_images_per_step": bl + a.bu,
+                          "forward_image_passes_per_step": (1 + K) * (bl + 2 * a.bu) - (K * bl if a.net == "bert" else 0),
+                          "backward_images_per_step": bl + a.bu,
                           "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
         if prof is not None:
@@ -172,7 +197,7 @@ def main():
             intensity = fl / nbytes
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")          # PMC pass of this same command (tools/pmc.sh)
-            if os.path.exists(tf) and a.bu == 8 and a.regime == "sr" and world == 1 and a.img == 32:
+            if os.path.exists(tf) and a.bu == 8 and a.regime == "sr" and world == 1 and a.img == 32 and a.net == "vit":
                 traffic = (json.load(open(tf)).get(name) or {}).get("hbm_bytes_per_launch")
             if intensity < ridge:
                 ach = nbytes / (ms * 1e-3) / 1e9
@@ -187,7 +212,7 @@ def main():
                          "measured_over": "%d instrumented steps run right after the timed region (same process, same inputs)" % prof_steps,
                          "all_gemm_kernels": {"tflops": tfl / (tms * 1e-3) / 1e12, "launches": tn, "ms_per_step": tms / prof_steps}})
             out["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline and a.img == 32:
+        if world == 1 and not a.no_cpu_baseline and a.img == 32 and a.net == "vit":
             out["cpu_baseline"] = cpu_baseline(bl, a.bu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -468,6 +468,14 @@ def _d(drop):
 
 def gemm_nt_resid_dropout(A, B, C, M, N, K, bias, resid, drop, lda=None, ldb=None):
     """C(f32)[M,N] = resid (or C) + dropout(A . B^T + bias)."""
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_gemm_nt_resid_dropout", _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s())
+        e1.record()
+        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(EPI_RESID_F32, M, N, K),
+                              _GemmProfile.gemm_bytes(EPI_RESID_F32, M, N, K, resid, None, 0.0)))
+        return
     _call("srhip_gemm_nt_resid_dropout", _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s())
 
 
