@@ -23,6 +23,7 @@ from oracle import semireward_ref as S  # noqa: E402
 from oracle import vit_ref as V  # noqa: E402
 from oracle import wrn_ref as W  # noqa: E402
 from oracle import bert_ref as BR  # noqa: E402
+from oracle import w2v2_ref as WR  # noqa: E402
 from semireward_amd.utils import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -312,16 +313,19 @@ class InjectedDropout:
     """Feeds the shared counter-based masks (oracle/bert_ref.keep_mask) to every F.dropout call of one reference forward, in call
     order: embeddings, (attention probs, attention output, FFN output) per layer, head."""
 
-    def __init__(self, cfg, seed):
-        self.sites = [BR.SITE_EMB] + [4 * i + k for i in range(cfg.layers) for k in (BR.SITE_PROBS, BR.SITE_ATTN_OUT, BR.SITE_FFN_OUT)] + [BR.SITE_HEAD]
-        self.seed, self.p, self.n = seed, cfg.p_drop, 0
+    def __init__(self, cfg, seed, sites=None):
+        self.sites = sites if sites is not None else (
+            [BR.SITE_EMB] + [4 * i + k for i in range(cfg.layers) for k in (BR.SITE_PROBS, BR.SITE_ATTN_OUT, BR.SITE_FFN_OUT)] + [BR.SITE_HEAD])
+        self.seed, self.n = seed, 0
 
     def __enter__(self):
         self.orig = F.dropout
 
         def fake(x, p=0.5, training=True, inplace=False):
-            assert training and abs(p - self.p) < 1e-12
+            assert training
             site = self.sites[self.n]; self.n += 1
+            if p == 0.0:
+                return x
             return x * T(BR.keep_mask(self.seed, site, tuple(x.shape), p).astype(np.float32) / np.float32(1.0 - p))
         torch.nn.functional.dropout = fake
         return self
@@ -360,6 +364,100 @@ def gen_bert():
             flat(f"{tag}/grad/{n}", samp(p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32), 256), out)
         out[f"{tag}/meta"] = np.array([C, B, L, seed, dseed], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "bert.npz"), **out)
+
+
+def build_ref_w2v(cfg, params):
+    """The reference ClassificationWave2Vec around a randomly initialised HF Wav2Vec2Model with the facebook/wav2vec2-base-960h
+    hyper-parameters (``from_pretrained`` needs the network), assembled field by field as wave2vecv2.py:9-21 does; eager attention so that
+    the probability dropout is an F.dropout call."""
+    import torch.nn as nn
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    wm = R.mod("semilearn.nets.wave2vecv2.wave2vecv2")
+    hc = Wav2Vec2Config(hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, intermediate_size=cfg.inter,
+                        conv_dim=tuple(cfg.conv_dim), conv_stride=tuple(cfg.conv_stride), conv_kernel=tuple(cfg.conv_kernel),
+                        num_conv_pos_embeddings=cfg.pos_k, num_conv_pos_embedding_groups=cfg.pos_groups, hidden_dropout=cfg.p_hidden,
+                        activation_dropout=cfg.p_act, attention_dropout=cfg.p_attn, feat_proj_dropout=cfg.p_featproj, layerdrop=cfg.layerdrop,
+                        mask_time_prob=cfg.mask_time_prob, mask_time_length=cfg.mask_time_length, mask_time_min_masks=cfg.mask_time_min_masks,
+                        feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, apply_spec_augment=True,
+                        attn_implementation="eager")
+    model = wm.ClassificationWave2Vec.__new__(wm.ClassificationWave2Vec)
+    nn.Module.__init__(model)
+    model.model = Wav2Vec2Model(hc)
+    model.model.feature_extractor._requires_grad = False
+    model.dropout = torch.nn.Dropout(p=0.1, inplace=False)
+    model.num_features = cfg.hidden
+    model.classifier = nn.Sequential(nn.Linear(cfg.hidden, cfg.hidden), nn.GELU(), nn.Linear(cfg.hidden, cfg.num_classes))
+    assert [n for n, _ in model.named_parameters()] == [n for n, _ in WR.param_shapes(cfg)], \
+        [(a, b) for (a, _), (b, _) in zip(model.named_parameters(), WR.param_shapes(cfg)) if a != b][:3]
+    load_module_params(model, params)
+    return model
+
+
+class InjectedW2vRandomness:
+    """One reference forward with the oracle's random inputs: dropout masks (shared counter-based generator), the SpecAugment mask
+    (replaces transformers' _compute_mask_indices draw) and the LayerDrop decisions (replace the encoder's torch.rand([]) draws)."""
+
+    def __init__(self, cfg, seed, spec_mask, skip):
+        sites = [WR.SITE_FEATPROJ, WR.SITE_EMB]
+        for i in range(cfg.layers):
+            if not skip[i]:
+                sites += [4 * i + WR.SITE_PROBS, 4 * i + WR.SITE_ATTN_OUT, 4 * i + WR.SITE_ACT, 4 * i + WR.SITE_FFN_OUT]
+        self.drop = InjectedDropout(cfg, seed, sites + [WR.SITE_HEAD])
+        self.spec_mask, self.skip, self.layerdrop = spec_mask, list(skip), cfg.layerdrop
+
+    def __enter__(self):
+        import transformers.models.wav2vec2.modeling_wav2vec2 as hm
+        self.hm, self.orig_cm, self.orig_rand = hm, hm._compute_mask_indices, torch.rand
+        hm._compute_mask_indices = lambda shape, *a, **k: self.spec_mask.copy()
+        q = [0.0 if s_ else 1.0 for s_ in self.skip]
+
+        def fake_rand(*a, **k):
+            assert a == ([],) and q
+            return torch.tensor(q.pop(0))
+        torch.rand = fake_rand
+        self.q = q
+        self.drop.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.hm._compute_mask_indices, torch.rand = self.orig_cm, self.orig_rand
+        self.drop.__exit__(*a)
+        assert not self.q
+
+
+def gen_w2v():
+    """ClassificationWave2Vec (wave2vecv2.py) on a random-init HF Wav2Vec2Model (base-960h hyper-parameters): eval forward, train forward
+    with injected dropout / SpecAugment / LayerDrop, gradients of a weighted CE.  Third-party arithmetic: these vectors pin it."""
+    import transformers
+    out = {"meta/transformers_version": np.array(transformers.__version__)}
+    for tag, cfgd, C, B, S, seed, skip in [("tiny", WR.W2V_TINY_TEST, 4, 3, 400, 81, (False, False)), ("tiny_skip", WR.W2V_TINY_TEST, 4, 2, 400, 83, (True, False)),
+                                           ("base", WR.W2V_BASE, 4, 2, 16000, 82, (False,) * 5 + (True,) + (False,) * 6)]:
+        cfg = WR.W2vCfg(num_classes=C, **cfgd)
+        params = WR.synth_params(cfg, seed)
+        rng = np.random.Generator(np.random.PCG64(seed + 1))
+        wave = rng.standard_normal((B, S)).astype(np.float32)
+        y, w = rng.integers(0, C, size=(B,), dtype=np.int64), rng.random(B).astype(np.float32)
+        T_ = WR.frames(cfg, S)[-1]
+        spec = WR.spec_augment_mask(seed + 2, B, T_, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks)
+        model = build_ref_w2v(cfg, params)
+        model.eval()
+        with torch.no_grad():
+            o = model(T(wave))
+        out[f"{tag}/eval_logits"], out[f"{tag}/eval_feat"] = o["logits"].numpy(), o["feat"].numpy()
+        model.train()
+        dseed = (seed << 32) + 5
+        with InjectedW2vRandomness(cfg, dseed, spec, skip):
+            o = model(T(wave))
+            loss = (F.cross_entropy(o["logits"], T(y), reduction="none") * T(w)).mean()
+        loss.backward()
+        out[f"{tag}/train_logits"], out[f"{tag}/train_feat"] = o["logits"].detach().numpy(), o["feat"].detach().numpy()
+        out[f"{tag}/loss"] = np.float32(loss.item())
+        for n, p in model.named_parameters():
+            flat(f"{tag}/grad/{n}", samp(p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32), 256), out)
+        out[f"{tag}/meta"] = np.array([C, B, S, seed, dseed], dtype=np.int64)
+        out[f"{tag}/skip"] = np.array(skip, dtype=np.int64)
+        out[f"{tag}/spec_mask"] = spec
+    np.savez_compressed(os.path.join(OUT, "w2v.npz"), **out)
 
 
 def gen_vit_p16():
@@ -885,7 +983,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
-            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert)
+            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

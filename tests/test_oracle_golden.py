@@ -480,3 +480,34 @@ def test_srsoftmatch_bert_trace(golden):
     for nme, _ in BR.param_shapes(cfg):                                              # after 6 AdamW steps with layer decay 0.65
         if not nme.endswith("key.bias"):
             check_samp(orc.P[nme].numpy(), g.samp(f"it{tr['its'][-1]}/param/{nme}"), 2e-3, 3e-5, f"param {nme}")
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny_skip", "base"])
+def test_w2v_oracle_matches_reference(golden, tag):
+    """oracle/w2v2_ref.py against the reference ClassificationWave2Vec on a random-init HF Wav2Vec2Model (base-960h hyper-parameters):
+    eval forward; train forward with the injected dropout masks, SpecAugment mask and LayerDrop decisions; gradients of a weighted CE."""
+    from oracle import w2v2_ref as WR
+    g = golden("w2v")
+    C, B, S, seed, dseed = [int(v) for v in g[f"{tag}/meta"]]
+    cfg = WR.W2vCfg(num_classes=C, **(WR.W2V_BASE if tag == "base" else WR.W2V_TINY_TEST))
+    P = {k: T(v).requires_grad_(True) for k, v in WR.synth_params(cfg, seed).items()}
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    wave = T(rng.standard_normal((B, S)).astype(np.float32))
+    y, w = T(rng.integers(0, C, size=(B,), dtype=np.int64)), T(rng.random(B).astype(np.float32))
+    spec = WR.spec_augment_mask(seed + 2, B, WR.frames(cfg, S)[-1], cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks)
+    assert np.array_equal(spec, g[f"{tag}/spec_mask"]) and spec.any() and not spec.all()
+    skip = [bool(v) for v in g[f"{tag}/skip"]]
+    with torch.no_grad():
+        o = WR.w2v_forward(P, wave, cfg)
+    np.testing.assert_allclose(o["logits"].numpy(), g[f"{tag}/eval_logits"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(o["feat"].numpy(), g[f"{tag}/eval_feat"], rtol=3e-4, atol=3e-5)
+    o = WR.w2v_forward(P, wave, cfg, seed=dseed, spec_mask=spec, skip=skip)
+    np.testing.assert_allclose(o["logits"].detach().numpy(), g[f"{tag}/train_logits"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(o["feat"].detach().numpy(), g[f"{tag}/train_feat"], rtol=3e-4, atol=3e-5)
+    loss = (torch.nn.functional.cross_entropy(o["logits"], y, reduction="none") * w).mean()
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g[f"{tag}/loss"]), rel=2e-5)
+    for n, _ in WR.param_shapes(cfg):
+        gr = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
+        check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 3e-3, 2e-6, f"{tag} grad {n}",
+                   exclude=(lambda i: np.ones_like(i, bool)) if n.endswith("k_proj.bias") else None)        # analytically zero: round-off only
