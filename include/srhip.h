@@ -277,6 +277,57 @@ int srhip_meanpool_bwd(const float* dfeat, float* dx, const int* seq_len, int B,
 int srhip_gelu_f32(const float* pre, float* out, long n, void* stream);
 int srhip_gelu_bwd_f32(const float* dout, const float* pre, float* dpre, long n, void* stream);
 int srhip_mask_lengths(const long long* mask, int ld, int* key_len, int B, int L, void* stream);
+/* out(bf16)[i] = dropout'(x[i]): the gradient of a branch that sat under nn.Dropout, cast for its dX / dW products (element index i) */
+int srhip_dropout_cast(const float* x, void* out_bf16, long n, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+
+/* gemm_nt with nn.Dropout in the epilogue (generator / index as srhip_attn_masked_fwd, element index m * N + n, ldc == N):
+ *   SRHIP_EPI_GELU_BF16  : C = dropout(GELU(acc + bias)), aux_out = acc + bias        (Wav2Vec2FeedForward.intermediate_dropout)
+ *   SRHIP_EPI_DGELU_BF16 : C = dropout'(acc) * GELU'(aux_in)                           (its adjoint)
+ *   SRHIP_EPI_RESID_F32  : as srhip_gemm_nt_resid_dropout */
+int srhip_gemm_nt_dropout(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                          const void* aux_in, void* aux_out, int ldaux, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+
+/* ---- Wav2Vec2 front end (semilearn/nets/wave2vecv2/wave2vecv2.py:44 -> transformers Wav2Vec2Model: feature encoder, feature projection,
+ * SpecAugment, positional conv embedding).  Activations are channel-last [clip, frame, channel] with a per-layer frame pitch P_l (P_{l-1} =
+ * stride_l * P_l, P_l >= T_l + 1): the conv layers 1.. are srhip_gemm_nt products whose A operand is the previous activation read with
+ * lda = stride * C (overlapping rows) against the tap-major filter; rows >= T_l are filler (finite forward, zero in every gradient).
+ *   w2v_conv0            : layer 0 (1 input channel) + GroupNorm(groups == channels) + GELU.  mode 0: statistics into ws (2 doubles per (clip,
+ *                          channel), zeroed by the caller); 1: out bf16 [B*P0, C]; 2: backward statistics into ws2 from dY (bf16, d/d out),
+ *                          dgamma +=, dbeta +=; 3: dW0 [C, k] +=
+ *   w2v_conv_weight_prep : Conv1d filter fp32 [Cout, Cin, k] -> bf16 Wr [Cout, k*Cin] (tap-major) and WrT [k*Cin, Cout]; wgrad_add: the inverse
+ *                          permutation, dW += dWr
+ *   w2v_col2im_dgelu     : adjoint of the overlapping-row read: dpre_prev = GELU'(pre_prev) * fold(dcol)   (pre_prev NULL: no GELU factor)
+ *   w2v_featln_fwd/bwd   : feature_projection.layer_norm on the bf16 conv output; the backward also applies GELU'(pre) of the last conv layer
+ *   w2v_spec_mask_fwd/bwd: masked frames <- masked_spec_embed; backward: dx (+= add, the positional-conv input gradient with pitch Padd),
+ *                          masked rows -> dembed, filler rows -> 0
+ *   w2v_pos_stage        : group-major zero-padded bf16 copy [groups][rows_total][D/groups] of fp32 rows (frame t lands on row clip*Pp + t +
+ *                          pad_left): operand of the grouped positional conv (srhip_gemm_nt_grouped_f32, lda = D/groups)
+ *   w2v_weightnorm_prep  : weight_norm(dim=2) filter -> bf16 operands Wf [groups][cg][k][cg] and the tap-reversed transpose Wb; norms [k]
+ *   w2v_weightnorm_bwd   : dv +=, dg += from dWf (fp32, Wf layout)
+ *   w2v_pos_finish_fwd   : x0 = dropout(LayerNorm(x + GELU(conv + bias))) fp32 + bf16 (filler rows zero); saves y, mean, rstd
+ *   w2v_pos_finish_bwd   : dx0 -> dy (in place), dconv = dy * GELU'(conv + bias) fp32 [B*P, D]; dgamma +=, dbeta += */
+int srhip_w2v_conv0(int mode, const float* wave, const float* W0, const float* gamma, const float* beta, double* ws, double* ws2, void* out_bf16,
+                    const void* dY, float* dW0, float* dgamma, float* dbeta, int B, int S, int T0, int P0, int C, int k, int stride, float eps,
+                    void* stream);
+int srhip_w2v_conv_weight_prep(const float* W, void* Wr, void* WrT, int Cout, int Cin, int k, void* stream);
+int srhip_w2v_conv_wgrad_add(const float* dWr, float* dW, int Cout, int Cin, int k, void* stream);
+int srhip_w2v_col2im_dgelu(const void* dcol, const void* pre_prev, void* out, int B, int Pl, int Pprev, int C, int k, int stride, void* stream);
+int srhip_w2v_featln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* out, float* mean, float* rstd, int B, int T, int P,
+                         int C, void* stream);
+int srhip_w2v_featln_bwd(const void* dy, const void* x, const void* pre, const float* mean, const float* rstd, const float* gamma, void* dpre,
+                         float* dgamma, float* dbeta, int B, int T, int P, int C, void* stream);
+int srhip_w2v_spec_mask_fwd(float* x, const unsigned char* mask, const float* embed, long M, int D, void* stream);
+int srhip_w2v_spec_mask_bwd(float* dx, const float* add, const unsigned char* mask, float* dembed, int B, int T, int P, int Padd, int D, void* stream);
+int srhip_w2v_pos_stage(const float* src, void* out, int B, int T, int P, int Pp, int D, int groups, int pad_left, long rows_total, void* stream);
+int srhip_w2v_weightnorm_prep(const float* v, const float* g, float* norms, void* Wf, void* Wb, int D, int groups, int k, void* stream);
+int srhip_w2v_weightnorm_bwd(const float* dWf, const float* v, const float* g, const float* norms, float* dv, float* dg, int D, int groups, int k,
+                             void* stream);
+int srhip_w2v_pos_finish_fwd(const float* x, const float* conv, const float* conv_bias, const float* gamma, const float* beta, float eps, float* x0,
+                             void* x0_bf16, float* ysave, float* mean, float* rstd, int B, int T, int P, int Pp, int D, unsigned drop_key,
+                             unsigned drop_thresh, float drop_scale, void* stream);
+int srhip_w2v_pos_finish_bwd(float* dx0, const float* ysave, const float* conv, const float* conv_bias, const float* mean, const float* rstd,
+                             const float* gamma, float* dconv, float* dgamma, float* dbeta, int B, int T, int P, int Pp, int D, unsigned drop_key,
+                             unsigned drop_thresh, float drop_scale, void* stream);
 
 /* ---- WideResNet building blocks (classic_cv backbone, semilearn/nets/wrn/wrn.py; BASELINE.json configs[0], parity configuration) ----
  * Feature maps are NHWC = row-major [rows = B*H*W, C].  conv = im2col (bf16) + srhip_gemm_nt; dW = srhip_gemm_tn_grouped_f32(dY, col);

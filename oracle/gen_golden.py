@@ -313,7 +313,8 @@ class InjectedDropout:
     """Feeds the shared counter-based masks (oracle/bert_ref.keep_mask) to every F.dropout call of one reference forward, in call
     order: embeddings, (attention probs, attention output, FFN output) per layer, head."""
 
-    def __init__(self, cfg, seed, sites=None):
+    def __init__(self, cfg, seed, sites=None, pitch_of=None):
+        self.pitch_of = pitch_of            # Wav2Vec2: masks indexed in the engine's frame-pitched layout (w2v2_ref.pitched_keep)
         self.sites = sites if sites is not None else (
             [BR.SITE_EMB] + [4 * i + k for i in range(cfg.layers) for k in (BR.SITE_PROBS, BR.SITE_ATTN_OUT, BR.SITE_FFN_OUT)] + [BR.SITE_HEAD])
         self.seed, self.n = seed, 0
@@ -326,6 +327,9 @@ class InjectedDropout:
             site = self.sites[self.n]; self.n += 1
             if p == 0.0:
                 return x
+            if self.pitch_of is not None:
+                km = WR.pitched_keep(self.seed, site, tuple(x.shape), p, self.pitch_of(x.shape[-2]))
+                return x * T(np.ascontiguousarray(km).astype(np.float32) / np.float32(1.0 - p))
             return x * T(BR.keep_mask(self.seed, site, tuple(x.shape), p).astype(np.float32) / np.float32(1.0 - p))
         torch.nn.functional.dropout = fake
         return self
@@ -402,7 +406,7 @@ class InjectedW2vRandomness:
         for i in range(cfg.layers):
             if not skip[i]:
                 sites += [4 * i + WR.SITE_PROBS, 4 * i + WR.SITE_ATTN_OUT, 4 * i + WR.SITE_ACT, 4 * i + WR.SITE_FFN_OUT]
-        self.drop = InjectedDropout(cfg, seed, sites + [WR.SITE_HEAD])
+        self.drop = InjectedDropout(cfg, seed, sites + [WR.SITE_HEAD], pitch_of=WR.frame_pitch)
         self.spec_mask, self.skip, self.layerdrop = spec_mask, list(skip), cfg.layerdrop
 
     def __enter__(self):

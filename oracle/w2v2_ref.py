@@ -92,10 +92,25 @@ def spec_augment_mask(seed, B, T, mask_prob, mask_length, min_masks):
     return m
 
 
-def _drop(x, seed, site, p):
+def frame_pitch(T):
+    """Row pitch of the engine's [clip, frame, channel] activations at the encoder: >= T + 1, multiple of 8 (nets/wave2vec.py geometry)."""
+    return (T + 1 + 7) // 8 * 8
+
+
+def pitched_keep(seed, site, shape, p, pitch):
+    """keep mask of a [B, T, X] (or [B, H, T, T]) tensor whose elements are indexed as in the engine's frame-pitched layout [B, pitch, X]
+    ([B, H, pitch, pitch]): the masks are INPUTS of the model, any fixed assignment of generator outputs to elements is as good as another."""
+    if pitch is None:
+        return keep_mask(seed, site, shape, p)
+    if len(shape) == 3:
+        return keep_mask(seed, site, (shape[0], pitch, shape[2]), p)[:, :shape[1]]
+    return keep_mask(seed, site, (shape[0], shape[1], pitch, pitch), p)[:, :, :shape[2], :shape[3]]
+
+
+def _drop(x, seed, site, p, pitch=None):
     if seed is None or p <= 0.0:
         return x
-    return x * torch.from_numpy(keep_mask(seed, site, tuple(x.shape), p).astype(np.float32) / np.float32(1.0 - p))
+    return x * torch.from_numpy(np.ascontiguousarray(pitched_keep(seed, site, tuple(x.shape), p, pitch)).astype(np.float32) / np.float32(1.0 - p))
 
 
 def pos_conv_weight(P):
@@ -105,9 +120,10 @@ def pos_conv_weight(P):
     return g * v / v.norm(dim=(0, 1), keepdim=True)
 
 
-def w2v_forward(P, wave, cfg, seed=None, spec_mask=None, skip=None):
+def w2v_forward(P, wave, cfg, seed=None, spec_mask=None, skip=None, pitched=True):
     """wave fp32 [B, samples].  Eval mode: seed = spec_mask = skip = None.  Train mode: seed = 64-bit dropout seed of the call,
-    spec_mask bool [B, T] (SpecAugment), skip = per-layer LayerDrop flags.  Returns dict(logits, feat, hidden)."""
+    spec_mask bool [B, T] (SpecAugment), skip = per-layer LayerDrop flags; pitched: dropout masks indexed in the engine's frame-pitched
+    layout (pitched_keep).  Returns dict(logits, feat, hidden)."""
     D, H = cfg.hidden, cfg.heads
     x = wave[:, None]
     for i, s in enumerate(cfg.conv_stride):
@@ -118,9 +134,10 @@ def w2v_forward(P, wave, cfg, seed=None, spec_mask=None, skip=None):
         x = F.gelu(x)
     x = x.transpose(1, 2)                                                                         # [B, T, conv_dim]
     B, T, _ = x.shape
+    pt = frame_pitch(T) if pitched else None
     x = F.layer_norm(x, (x.shape[-1],), P["model.feature_projection.layer_norm.weight"], P["model.feature_projection.layer_norm.bias"], LN_EPS)
     x = F.linear(x, P["model.feature_projection.projection.weight"], P["model.feature_projection.projection.bias"])
-    x = _drop(x, seed, SITE_FEATPROJ, cfg.p_featproj)
+    x = _drop(x, seed, SITE_FEATPROJ, cfg.p_featproj, pt)
     if spec_mask is not None:
         x = torch.where(torch.as_tensor(spec_mask)[:, :, None], P["model.masked_spec_embed"], x)
     pc = F.conv1d(x.transpose(1, 2), pos_conv_weight(P), P["model.encoder.pos_conv_embed.conv.bias"], padding=cfg.pos_k // 2,
@@ -129,7 +146,7 @@ def w2v_forward(P, wave, cfg, seed=None, spec_mask=None, skip=None):
         pc = pc[:, :, :-1]
     x = x + F.gelu(pc).transpose(1, 2)
     x = F.layer_norm(x, (D,), P["model.encoder.layer_norm.weight"], P["model.encoder.layer_norm.bias"], LN_EPS)
-    x = _drop(x, seed, SITE_EMB, cfg.p_hidden)
+    x = _drop(x, seed, SITE_EMB, cfg.p_hidden, pt)
     for i in range(cfg.layers):
         if skip is not None and skip[i]:
             continue
@@ -137,14 +154,14 @@ def w2v_forward(P, wave, cfg, seed=None, spec_mask=None, skip=None):
         lin = lambda t, n: F.linear(t, P[q_ + n + ".weight"], P[q_ + n + ".bias"])   # noqa: E731
         heads = lambda t: t.view(B, T, H, D // H).transpose(1, 2)   # noqa: E731
         q, k, v = heads(lin(x, "attention.q_proj")), heads(lin(x, "attention.k_proj")), heads(lin(x, "attention.v_proj"))
-        probs = _drop(torch.softmax(q @ k.transpose(-1, -2) * (D // H) ** -0.5, dim=-1), seed, 4 * i + SITE_PROBS, cfg.p_attn)
+        probs = _drop(torch.softmax(q @ k.transpose(-1, -2) * (D // H) ** -0.5, dim=-1), seed, 4 * i + SITE_PROBS, cfg.p_attn, pt)
         ctx = (probs @ v).transpose(1, 2).reshape(B, T, D)
-        x = F.layer_norm(x + _drop(lin(ctx, "attention.out_proj"), seed, 4 * i + SITE_ATTN_OUT, cfg.p_hidden), (D,),
+        x = F.layer_norm(x + _drop(lin(ctx, "attention.out_proj"), seed, 4 * i + SITE_ATTN_OUT, cfg.p_hidden, pt), (D,),
                          P[q_ + "layer_norm.weight"], P[q_ + "layer_norm.bias"], LN_EPS)
-        h = _drop(F.gelu(lin(x, "feed_forward.intermediate_dense")), seed, 4 * i + SITE_ACT, cfg.p_act)
-        x = F.layer_norm(x + _drop(lin(h, "feed_forward.output_dense"), seed, 4 * i + SITE_FFN_OUT, cfg.p_hidden), (D,),
+        h = _drop(F.gelu(lin(x, "feed_forward.intermediate_dense")), seed, 4 * i + SITE_ACT, cfg.p_act, pt)
+        x = F.layer_norm(x + _drop(lin(h, "feed_forward.output_dense"), seed, 4 * i + SITE_FFN_OUT, cfg.p_hidden, pt), (D,),
                          P[q_ + "final_layer_norm.weight"], P[q_ + "final_layer_norm.bias"], LN_EPS)
-    feat = _drop(x, seed, SITE_HEAD, cfg.p_head).mean(1)                                          # wave2vecv2.py:47-48
+    feat = _drop(x, seed, SITE_HEAD, cfg.p_head, pt).mean(1)                                          # wave2vecv2.py:47-48
     hcls = F.gelu(F.linear(feat, P["classifier.0.weight"], P["classifier.0.bias"]))
     logits = F.linear(hcls, P["classifier.2.weight"], P["classifier.2.bias"])
     return dict(logits=logits, feat=feat, hidden=x)

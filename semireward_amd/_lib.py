@@ -86,6 +86,21 @@ SIGNATURES = {
     "srhip_gelu_f32": (I, [P, P, L, P]),
     "srhip_gelu_bwd_f32": (I, [P, P, P, L, P]),
     "srhip_mask_lengths": (I, [P, I, P, I, I, P]),
+    "srhip_dropout_cast": (I, [P, P, L, U, U, F, P]),
+    "srhip_gemm_nt_dropout": (I, [I, P, I, P, I, P, I, I, I, I, P, P, P, I, U, U, F, P]),
+    "srhip_w2v_conv0": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "srhip_w2v_conv_weight_prep": (I, [P, P, P, I, I, I, P]),
+    "srhip_w2v_conv_wgrad_add": (I, [P, P, I, I, I, P]),
+    "srhip_w2v_col2im_dgelu": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "srhip_w2v_featln_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, P]),
+    "srhip_w2v_featln_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "srhip_w2v_spec_mask_fwd": (I, [P, P, P, L, I, P]),
+    "srhip_w2v_spec_mask_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "srhip_w2v_pos_stage": (I, [P, P, I, I, I, I, I, I, I, L, P]),
+    "srhip_w2v_weightnorm_prep": (I, [P, P, P, P, P, I, I, I, P]),
+    "srhip_w2v_weightnorm_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "srhip_w2v_pos_finish_fwd": (I, [P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, U, U, F, P]),
+    "srhip_w2v_pos_finish_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, U, U, F, P]),
 }
 
 _lib = None

@@ -268,6 +268,14 @@ __global__ __launch_bounds__(256) void gelu_bwd_f32_kernel(const float* __restri
   }
 }
 
+// bf16 cast of a gradient with the adjoint of a dropout site folded in (element index = linear index)
+__global__ __launch_bounds__(256) void dropout_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n, Drop dr) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= n) return;
+  const float2 v = drop2(*reinterpret_cast<const float2*>(x + i), (uint32_t)i, dr);
+  *reinterpret_cast<uint32_t*>(out + i) = pack_bf2(v.x, v.y);
+}
+
 // key lengths of a right-padded batch: klen[b] = sum(attention_mask[b, :])   (nlp_collactor.py:63-69 pads on the right)
 __global__ __launch_bounds__(64) void mask_len_kernel(const long long* __restrict__ mask, int ld, int* __restrict__ klen, int L) {
   float s = 0.f;
@@ -365,6 +373,14 @@ extern "C" int srhip_gelu_f32(const float* pre, float* out, long n, void* stream
 extern "C" int srhip_gelu_bwd_f32(const float* dout, const float* pre, float* dpre, long n, void* stream) {
   if (!dout || !pre || !dpre || n <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, pre, dpre, n);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_dropout_cast(const float* x, void* out_bf16, long n, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream) {
+  if (!x || !out_bf16 || n <= 0 || (n & 1) || n >= (1L << 32)) return SR_EINVAL;
+  const Drop dr{drop_key, drop_thresh, drop_scale};
+  hipLaunchKernelGGL(dropout_cast_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out_bf16, n, dr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -74,7 +74,13 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
       u32x2_t p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
       *reinterpret_cast<u32x2_t*>(g.aux_out + (size_t)m * g.ldaux + n) = p;
     }
-    u32x2_t o = {pack_bf2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]))};
+    float h[4] = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+    if (g.drop_thresh) {                 // (uniform) Wav2Vec2FeedForward.intermediate_dropout: dropout(GELU(dense(x))); aux_out keeps the pre-activation
+      const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? h[r] * g.drop_scale : 0.f;
+    }
+    u32x2_t o = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
     *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
   } else if (EPI == SRHIP_EPI_RESID_F32) {
     // residual source: C itself (in place) or, when the pre-block stream is kept for the backward, aux_in (fp32, ldaux)
@@ -91,6 +97,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     const u32x2_t p = *reinterpret_cast<const u32x2_t*>(g.aux_in + (size_t)m * g.ldaux + n);
     const float p0 = bf2f((bf16_t)(p[0] & 0xffff)), p1 = bf2f((bf16_t)(p[0] >> 16));
     const float p2 = bf2f((bf16_t)(p[1] & 0xffff)), p3 = bf2f((bf16_t)(p[1] >> 16));
+    if (g.drop_thresh) {                 // adjoint of the dropout that followed the GELU
+      const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+    }
     u32x2_t o = {pack_bf2(v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1)),
                  pack_bf2(v[2] * gelu_erf_grad(p2), v[3] * gelu_erf_grad(p3))};
     *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
@@ -563,6 +574,15 @@ extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B
                              const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, void* stream) {
   return gemm_nt_impl(epilogue, A, lda, B, ldb, C, ldc, M, N, K, bias, row_scale, rows_per_sample, aux_in, aux_out, ldaux, alpha, beta, 0u, 0u,
                       1.0f, stream);
+}
+
+extern "C" int srhip_gemm_nt_dropout(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                     const float* bias, const void* aux_in, void* aux_out, int ldaux, unsigned drop_key, unsigned drop_thresh,
+                                     float drop_scale, void* stream) {
+  if (epilogue != SRHIP_EPI_GELU_BF16 && epilogue != SRHIP_EPI_DGELU_BF16 && epilogue != SRHIP_EPI_RESID_F32) return SR_EINVAL;
+  if (ldc != N && drop_thresh) return SR_EINVAL;
+  return gemm_nt_impl(epilogue, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, aux_in, aux_out, ldaux, 1.0f, 0.0f, drop_key, drop_thresh,
+                      drop_scale, stream);
 }
 
 extern "C" int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,

@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_f32_kernel(const srhip
   // ---- LDS-DMA: a wave instruction fills 4 rows x 256 B; lane l -> row (l >> 4), physical chunk p = l & 15 <- source chunk
   // (p - 2 row) & 15.  Rows >= K and bytes past the operand are buffer-out-of-range: they read as zero, which is exactly the
   // padding the reduction needs.  Wave w stages rows 8w .. 8w+7 of both tiles (2 + 2 instructions per stage).
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.A), 0, d.K * d.lda * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.B), 0, d.K * d.ldb * 2, 0x00020000);
+  // (ld < row width = overlapping rows, the unfolded operand of a strided Conv1d read in place: the extent is then (K-1)*ld + width; the
+  // rows >= K of such an operand are real memory, finite by the caller's contract, and meet the zero rows of the other operand)
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.A), 0, max(d.K * d.lda, (d.K - 1) * d.lda + d.M) * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.B), 0, max(d.K * d.ldb, (d.K - 1) * d.ldb + d.N) * 2, 0x00020000);
   int va[2], vb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {

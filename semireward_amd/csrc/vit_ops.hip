@@ -430,10 +430,11 @@ __global__ void patch_gather_grad_kernel(const float* __restrict__ dx, bf16_t* _
 
 extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* out,
                                    float* mean, float* rstd, int M, int D, void* stream) {
-  if (M <= 0 || (D != 128 && D != 384 && D != 768) || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
+  if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768) || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(M, 4)), block(256);
   if (D == 128) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  else if (D == 512) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
   else if (D == 384) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
   else hipLaunchKernelGGL(ln_fwd_kernel<6>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
   SR_CHECK_LAUNCH();
@@ -442,10 +443,11 @@ extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const flo
 
 extern "C" int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                    float* dx, float* dgamma, float* dbeta, int M, int D, void* stream) {
-  if (M <= 0 || (D != 128 && D != 384 && D != 768)) return SR_EINVAL;
+  if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(M, 32)), block(256);
   if (D == 128) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
+  else if (D == 512) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
   else if (D == 384) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
   else hipLaunchKernelGGL(ln_bwd_kernel<6>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
   SR_CHECK_LAUNCH();

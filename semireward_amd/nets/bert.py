@@ -28,9 +28,9 @@ import types
 import torch
 
 from .. import ops
+from .encoder import PostLNEncoderMixin
 
 SITE_EMB, SITE_HEAD = 0x7FFFFFF0, 0x7FFFFFF1
-SITE_PROBS, SITE_ATTN_OUT, SITE_FFN_OUT = 0, 1, 2
 
 
 class BertConfig:
@@ -111,7 +111,7 @@ class TokenBatch:
         return cls(ids, kl, torch.cat(sl).contiguous())
 
 
-class ClassificationBert:
+class ClassificationBert(PostLNEncoderMixin):
     couples_batch_rows = False
     takes_tokens = True
 
@@ -131,11 +131,8 @@ class ClassificationBert:
         self.flat = torch.zeros(o, dtype=f32, device=self.device)
         self.grad = torch.zeros(o, dtype=f32, device=self.device)
         self.flat_bf16 = torch.zeros(o, dtype=bf16, device=self.device)
-        D, I = cfg.hidden, cfg.inter
-        self.wT = []                                  # per layer: transposed bf16 operands of the dX products
-        for i in range(cfg.layers):
-            self.wT.append(dict(qkv=torch.zeros(D, 3 * D, dtype=bf16, device=self.device), o=torch.zeros(D, D, dtype=bf16, device=self.device),
-                                w1=torch.zeros(D, I, dtype=bf16, device=self.device), w2=torch.zeros(I, D, dtype=bf16, device=self.device)))
+        self.enc_alloc_wT()                           # per layer: transposed bf16 operands of the dX products
+        self.enc_p = dict(attn=cfg.p_drop, hidden=cfg.p_drop, act=0.0)
         self.training = True
         self._ws, self._wT_desc = {}, None
         self._rng_calls, self.seed = 0, 0
@@ -149,13 +146,14 @@ class ClassificationBert:
     def view(self, name, buf=None):
         return self.p(name, buf).view(self.offsets[name][1])
 
-    def packed_qkv(self, i, buf=None):
-        """[3D, D] weight and [3D] bias views over the adjacent q/k/v tensors of layer i."""
-        D = self.cfg.hidden
-        ow = self.offsets[_layer(i) + "attention.self.query.weight"][0]
-        ob = self.offsets[_layer(i) + "attention.self.query.bias"][0]
-        b = self.flat if buf is None else buf
-        return b[ow:ow + 3 * D * D].view(3 * D, D), b[ob:ob + 3 * D]
+    def enc_names(self, i):
+        p = _layer(i)
+        return dict(q_w=p + "attention.self.query.weight", q_b=p + "attention.self.query.bias",
+                    o_w=p + "attention.output.dense.weight", o_b=p + "attention.output.dense.bias",
+                    ln1_w=p + "attention.output.LayerNorm.weight", ln1_b=p + "attention.output.LayerNorm.bias",
+                    w1=p + "intermediate.dense.weight", b1=p + "intermediate.dense.bias",
+                    w2=p + "output.dense.weight", b2=p + "output.dense.bias",
+                    ln2_w=p + "output.LayerNorm.weight", ln2_b=p + "output.LayerNorm.bias")
 
     def named_parameters(self):
         return [(n, self.view(n)) for n, _ in self.names_shapes]
@@ -198,15 +196,7 @@ class ClassificationBert:
 
     def refresh_transposed(self):
         if self._wT_desc is None:
-            items, cfg = [], self.cfg
-            D, I = cfg.hidden, cfg.inter
-            for i in range(cfg.layers):
-                p, t = _layer(i), self.wT[i]
-                items += [(self.packed_qkv(i)[0], True, D, t["qkv"], 3 * D, 3 * D, 3 * D, D, False),
-                          (self.p(p + "attention.output.dense.weight"), True, D, t["o"], D, D, D, D, False),
-                          (self.p(p + "intermediate.dense.weight"), True, D, t["w1"], I, I, I, D, False),
-                          (self.p(p + "output.dense.weight"), True, I, t["w2"], D, D, D, I, False)]
-            self._wT_desc = ops.make_transpose_desc(items, self.device)
+            self._wT_desc = ops.make_transpose_desc(self.enc_transpose_items(), self.device)
         ops.transpose_batched(*self._wT_desc)
 
     def no_weight_decay(self):
@@ -262,18 +252,10 @@ class ClassificationBert:
         key = ("ctx", B, L, tag)
         if key in self._ws:
             return self._ws[key]
-        cfg = self.cfg
-        D, I, H, M = cfg.hidden, cfg.inter, cfg.heads, B * L
-        f32, bf16 = torch.float32, torch.bfloat16
-        mk = lambda shape, dt: [torch.empty(shape, dtype=dt, device=self.device) for _ in range(cfg.layers)]   # noqa: E731
         c = types.SimpleNamespace()
-        c.xb = mk((M, D), bf16) + [torch.empty(M, D, dtype=bf16, device=self.device)]     # layer inputs (bf16): X operand of dWqkv
-        c.qkv, c.ao, c.lse = mk((M, 3 * D), bf16), mk((M, D), bf16), mk((B, H, L), f32)
-        c.y1, c.st1, c.xbm = mk((M, D), f32), mk((2, M), f32), mk((M, D), bf16)
-        c.pre, c.h, c.y2, c.st2 = mk((M, I), bf16), mk((M, I), bf16), mk((M, D), f32), mk((2, M), f32)
-        c.st0 = torch.empty(2, M, dtype=f32, device=self.device)
-        c.feat = torch.empty(B, D, dtype=f32, device=self.device)
-        c.hpre, c.hact = torch.empty(B, D, dtype=f32, device=self.device), torch.empty(B, D, dtype=f32, device=self.device)
+        self.enc_alloc_ctx(c, B, L)
+        self.head_alloc_ctx(c, B)
+        c.st0 = torch.empty(2, B * L, dtype=torch.float32, device=self.device)
         self._ws[key] = c
         return c
 
@@ -287,13 +269,13 @@ class ClassificationBert:
         M = B * L
         f32, bf16 = torch.float32, torch.bfloat16
         seed = self.next_seed() if seed == "auto" else seed
-        dr = (lambda site: ops.Drop(seed, site, cfg.p_drop)) if seed is not None else (lambda site: None)
         key_len = tok.key_len if seq_index is None else tok.key_len.index_select(0, seq_index.long()).contiguous()
         seq_len = None
         if tok.seq_len is not None:
             seq_len = tok.seq_len if seq_index is None else tok.seq_len.index_select(0, seq_index.long()).contiguous()
-        P, wb = self.p, self.flat_bf16
+        P = self.p
         t = "s" if save else "i"
+        dr = (lambda site, p=cfg.p_drop: ops.Drop(seed, site, p) if p > 0 else None) if seed is not None else (lambda site, p=0.0: None)
         ctx = None
         x = self._buf(t + "x", (M, D), f32)
         if save:
@@ -302,43 +284,12 @@ class ClassificationBert:
             xb = ctx.xb[0]
         else:
             xb = self._buf(t + "xb", (M, D), bf16)
-            qkv, ao = self._buf(t + "qkv", (M, 3 * D), bf16), self._buf(t + "ao", (M, D), bf16)
-            hbuf = self._buf(t + "h", (M, I), bf16)
         ops.embed_ln_fwd(tok.ids, seq_index, P(E + "word_embeddings.weight"), P(E + "position_embeddings.weight"),
                          P(E + "token_type_embeddings.weight"), P(E + "LayerNorm.weight"), P(E + "LayerNorm.bias"), cfg.eps, x, xb,
                          ctx.st0[0] if save else None, ctx.st0[1] if save else None, B, L, D, dr(SITE_EMB))
-        scale = 64 ** -0.5
-        for i in range(cfg.layers):
-            p = _layer(i)
-            Wqkv, bqkv = self.packed_qkv(i, wb)[0], self.packed_qkv(i)[1]
-            if save:
-                qkv, ao = ctx.qkv[i], ctx.ao[i]
-            ops.gemm_nt(ops.EPI_BF16, xb, Wqkv, qkv, M, 3 * D, D, bias=bqkv)
-            ops.attn_masked_fwd(qkv, ao, ctx.lse[i] if save else None, key_len, B, L, H, scale, dr(4 * i + SITE_PROBS))
-            y1 = ctx.y1[i] if save else x
-            ops.gemm_nt_resid_dropout(ao, P(p + "attention.output.dense.weight", wb), y1, M, D, D, P(p + "attention.output.dense.bias"),
-                                      x if save else None, dr(4 * i + SITE_ATTN_OUT))
-            xbm = ctx.xbm[i] if save else xb
-            ops.postln_fwd(y1, P(p + "attention.output.LayerNorm.weight"), P(p + "attention.output.LayerNorm.bias"), cfg.eps, x, xbm,
-                           ctx.st1[i][0] if save else None, ctx.st1[i][1] if save else None, M, D)
-            h = ctx.h[i] if save else hbuf
-            ops.gemm_nt(ops.EPI_GELU_BF16, xbm, P(p + "intermediate.dense.weight", wb), h, M, I, D, bias=P(p + "intermediate.dense.bias"),
-                        aux_out=ctx.pre[i] if save else None, ldaux=I)
-            y2 = ctx.y2[i] if save else x
-            ops.gemm_nt_resid_dropout(h, P(p + "output.dense.weight", wb), y2, M, D, I, P(p + "output.dense.bias"), x if save else None,
-                                      dr(4 * i + SITE_FFN_OUT))
-            xb = ctx.xb[i + 1] if save else xb
-            ops.postln_fwd(y2, P(p + "output.LayerNorm.weight"), P(p + "output.LayerNorm.bias"), cfg.eps, x, xb,
-                           ctx.st2[i][0] if save else None, ctx.st2[i][1] if save else None, M, D)
-        feat = ctx.feat if save else torch.empty(B, D, dtype=f32, device=self.device)
-        hpre = ctx.hpre if save else torch.empty(B, D, dtype=f32, device=self.device)
-        hact = ctx.hact if save else torch.empty(B, D, dtype=f32, device=self.device)
-        logits = torch.empty(B, C, dtype=f32, device=self.device)
-        ops.meanpool_fwd(x, feat, B, L, D, dr(SITE_HEAD), seq_len)
-        ops.fc_fwd(feat, P("classifier.0.weight"), P("classifier.0.bias"), hpre, B, D, D)
-        ops.gelu_f32(hpre, hact, B * D)
-        ops.fc_fwd(hact, P("classifier.2.weight"), P("classifier.2.bias"), logits, B, D, C)
-        return logits, (feat.clone() if save else feat), ctx
+        self.enc_forward(x, xb, ctx, save, B, L, key_len, dr, tag=t)
+        logits, feat = self.head_forward(x, B, L, dr(SITE_HEAD), seq_len, ctx)
+        return logits, feat, ctx
 
     def forward(self, x, only_fc=False, only_feat=False, return_embed=False, **kw):
         """Reference-compatible entry (bert.py:22-48): x = {'input_ids', 'attention_mask'} -> {'logits','feat'}."""
@@ -353,64 +304,17 @@ class ClassificationBert:
         return self.forward(x, only_feat=True)
 
     # ---- backward -----------------------------------------------------------------------------------------
-    def _bwd_plan(self, M, ctx):
-        """Shared output-gradient buffers (bf16 A operands of dW = dY^T X) + one descriptor table per layer for the grouped
-        weight-gradient launch (row-major operands, bias gradients summed on the way: srhip_gemm_tn_grouped_f32)."""
-        key = ("bwdplan", M, id(ctx))
-        if key in self._ws:
-            return self._ws[key]
-        cfg = self.cfg
-        D, I = cfg.hidden, cfg.inter
-        mk = lambda c: torch.empty(M, c, dtype=torch.bfloat16, device=self.device)   # noqa: E731
-        T = dict(g2=mk(D), dpre=mk(I), g1=mk(D), dqkv=mk(3 * D), dao=mk(D), desc=[])
-        G = lambda n: self.view(n, self.grad)   # noqa: E731
-        for i in range(cfg.layers):
-            p = _layer(i)
-            gw, gb = self.packed_qkv(i, self.grad)
-            T["desc"].append(ops.make_group_tn_desc(
-                [(T["g2"], ctx.h[i], G(p + "output.dense.weight"), G(p + "output.dense.bias"), D, I, M),
-                 (T["dpre"], ctx.xbm[i], G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"), I, D, M),
-                 (T["g1"], ctx.ao[i], G(p + "attention.output.dense.weight"), G(p + "attention.output.dense.bias"), D, D, M),
-                 (T["dqkv"], ctx.xb[i], gw, gb, 3 * D, D, M)], self.device))
-        self._ws[key] = T
-        return T
-
     def backward(self, ctx, dlogits):
         """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] of a save=True forward."""
         cfg = self.cfg
-        D, I, H, C = cfg.hidden, cfg.inter, cfg.heads, cfg.num_classes
+        D = cfg.hidden
         B, L, seed = ctx.B, ctx.L, ctx.seed
         M = B * L
-        f32 = torch.float32
-        dr = (lambda site: ops.Drop(seed, site, cfg.p_drop)) if seed is not None else (lambda site: None)
+        dr = (lambda site, p=cfg.p_drop: ops.Drop(seed, site, p) if p > 0 else None) if seed is not None else (lambda site, p=0.0: None)
         P, G = self.p, (lambda n: self.p(n, self.grad))
-        dhact, dhpre = self._buf("b_dhact", (B, D), f32), self._buf("b_dhpre", (B, D), f32)
-        dfeat = self._buf("b_dfeat", (B, D), f32)
-        ops.fc_bwd(dlogits, ctx.hact, P("classifier.2.weight"), dhact, G("classifier.2.weight"), G("classifier.2.bias"), B, D, C)
-        ops.gelu_bwd_f32(dhact, ctx.hpre, dhpre, B * D)
-        ops.fc_bwd(dhpre, ctx.feat, P("classifier.0.weight"), dfeat, G("classifier.0.weight"), G("classifier.0.bias"), B, D, D)
-        dx = self._buf("b_dx", (M, D), f32)
-        ops.meanpool_bwd(dfeat, dx, B, L, D, dr(SITE_HEAD), ctx.seq_len)
-        delta = self._buf("b_delta", (B, H, L), f32)
-        T = self._bwd_plan(M, ctx)
-        scale = 64 ** -0.5
-        for i in reversed(range(cfg.layers)):
-            p, wT = _layer(i), self.wT[i]
-            # ---- FFN: x_out = LN(y2), y2 = x_mid + dropout(W2 gelu(W1 x_mid))
-            ops.postln_bwd(dx, ctx.y2[i], ctx.st2[i][0], ctx.st2[i][1], P(p + "output.LayerNorm.weight"), dx, T["g2"],
-                           G(p + "output.LayerNorm.weight"), G(p + "output.LayerNorm.bias"), M, D, dr(4 * i + SITE_FFN_OUT))
-            ops.gemm_nt(ops.EPI_DGELU_BF16, T["g2"], wT["w2"], T["dpre"], M, I, D, aux_in=ctx.pre[i], ldaux=I)
-            ops.gemm_nt(ops.EPI_RESID_F32, T["dpre"], wT["w1"], dx, M, D, I)
-            # ---- attention: x_mid = LN(y1), y1 = x_in + dropout(Wo attn(qkv(x_in)))
-            ops.postln_bwd(dx, ctx.y1[i], ctx.st1[i][0], ctx.st1[i][1], P(p + "attention.output.LayerNorm.weight"), dx, T["g1"],
-                           G(p + "attention.output.LayerNorm.weight"), G(p + "attention.output.LayerNorm.bias"), M, D,
-                           dr(4 * i + SITE_ATTN_OUT))
-            ops.gemm_nt(ops.EPI_BF16, T["g1"], wT["o"], T["dao"], M, D, D)
-            ops.attn_masked_bwd(ctx.qkv[i], ctx.ao[i], T["dao"], ctx.lse[i], T["dqkv"], delta, ctx.key_len, B, L, H, scale,
-                                dr(4 * i + SITE_PROBS))
-            ops.gemm_nt(ops.EPI_RESID_F32, T["dqkv"], wT["qkv"], dx, M, D, 3 * D)
-            desc, npb, ntiles, flops, nbytes = T["desc"][i]
-            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+        dx = self._buf("b_dx", (M, D), torch.float32)
+        self.head_backward(ctx, dlogits, dx, B, L, dr(SITE_HEAD), ctx.seq_len)
+        self.enc_backward(dx, ctx, B, L, ctx.key_len, dr)
         ops.embed_ln_bwd(dx, ctx.tok.ids, ctx.seq_index, P(E + "word_embeddings.weight"), P(E + "position_embeddings.weight"),
                          P(E + "token_type_embeddings.weight"), ctx.st0[0], ctx.st0[1], P(E + "LayerNorm.weight"),
                          G(E + "word_embeddings.weight"), G(E + "position_embeddings.weight"), G(E + "token_type_embeddings.weight"),

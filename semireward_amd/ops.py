@@ -521,5 +521,108 @@ def gelu_bwd_f32(dout, pre, dpre, n):
     _call("srhip_gelu_bwd_f32", _p(dout), _p(pre), _p(dpre), n, _s())
 
 
+def dropout_cast(x, out, n, drop=None):
+    _call("srhip_dropout_cast", _p(x), _p(out), n, *_d(drop), _s())
+
+
 def mask_lengths(mask, key_len, B, L):
     _call("srhip_mask_lengths", _p(mask), mask.stride(0), _p(key_len), B, L, _s())
+
+
+def gemm_nt_dropout(epi, A, B, C, M, N, K, drop, *, lda=None, ldb=None, bias=None, aux_in=None, aux_out=None, ldaux=0):
+    """gemm_nt with dropout in the GELU / DGELU / RESID epilogue (ldc == N)."""
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_gemm_nt_dropout", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(aux_in), _p(aux_out), ldaux, *_d(drop), _s())
+        e1.record()
+        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K), _GemmProfile.gemm_bytes(epi, M, N, K, aux_in, aux_out, 0.0)))
+        return
+    _call("srhip_gemm_nt_dropout", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(aux_in), _p(aux_out), ldaux, *_d(drop), _s())
+
+
+# ---- Wav2Vec2 front end ---------------------------------------------------------------------------------
+def _pa(t, off_elems=0):
+    """device pointer of a (possibly offset) view into a contiguous buffer"""
+    return t.data_ptr() + off_elems * t.element_size()
+
+
+def w2v_conv0(mode, wave, W0, gamma, beta, ws, ws2, out, dY, dW0, dgamma, dbeta, B, S, T0, P0, C, k, stride, eps=1e-5):
+    _call("srhip_w2v_conv0", mode, _p(wave), _p(W0), _p(gamma), _p(beta), _p(ws), _p(ws2), _p(out), _p(dY), _p(dW0), _p(dgamma), _p(dbeta),
+          B, S, T0, P0, C, k, stride, eps, _s())
+
+
+def w2v_conv_weight_prep(W, Wr, WrT, Cout, Cin, k):
+    _call("srhip_w2v_conv_weight_prep", _p(W), _p(Wr), _p(WrT), Cout, Cin, k, _s())
+
+
+def w2v_conv_wgrad_add(dWr, dW, Cout, Cin, k):
+    _call("srhip_w2v_conv_wgrad_add", _p(dWr), _p(dW), Cout, Cin, k, _s())
+
+
+def w2v_col2im_dgelu(dcol, pre_prev, out, B, Pl, Pprev, C, k, stride):
+    _call("srhip_w2v_col2im_dgelu", _p(dcol), _p(pre_prev), _p(out), B, Pl, Pprev, C, k, stride, _s())
+
+
+def w2v_featln_fwd(x, gamma, beta, eps, out, mean, rstd, B, T, P, C):
+    _call("srhip_w2v_featln_fwd", _p(x), _p(gamma), _p(beta), eps, _p(out), _p(mean), _p(rstd), B, T, P, C, _s())
+
+
+def w2v_featln_bwd(dy, x, pre, mean, rstd, gamma, dpre, dgamma, dbeta, B, T, P, C):
+    _call("srhip_w2v_featln_bwd", _p(dy), _p(x), _p(pre), _p(mean), _p(rstd), _p(gamma), _p(dpre), _p(dgamma), _p(dbeta), B, T, P, C, _s())
+
+
+def w2v_spec_mask_fwd(x, mask, embed, M, D):
+    _call("srhip_w2v_spec_mask_fwd", _p(x), _p(mask), _p(embed), M, D, _s())
+
+
+def w2v_spec_mask_bwd(dx, add, mask, dembed, B, T, P, Padd, D):
+    _call("srhip_w2v_spec_mask_bwd", _p(dx), _p(add), _p(mask), _p(dembed), B, T, P, Padd, D, _s())
+
+
+def w2v_pos_stage(src, out, B, T, P, Pp, D, groups, pad_left, rows_total):
+    _call("srhip_w2v_pos_stage", _p(src), _p(out), B, T, P, Pp, D, groups, pad_left, rows_total, _s())
+
+
+def w2v_weightnorm_prep(v, g, norms, Wf, Wb, D, groups, k):
+    _call("srhip_w2v_weightnorm_prep", _p(v), _p(g), _p(norms), _p(Wf), _p(Wb), D, groups, k, _s())
+
+
+def w2v_weightnorm_bwd(dWf, v, g, norms, dv, dg, D, groups, k):
+    _call("srhip_w2v_weightnorm_bwd", _p(dWf), _p(v), _p(g), _p(norms), _p(dv), _p(dg), D, groups, k, _s())
+
+
+def w2v_pos_finish_fwd(x, conv, cbias, gamma, beta, eps, x0, x0b, ysave, mean, rstd, B, T, P, Pp, D, drop=None):
+    _call("srhip_w2v_pos_finish_fwd", _p(x), _p(conv), _p(cbias), _p(gamma), _p(beta), eps, _p(x0), _p(x0b), _p(ysave), _p(mean), _p(rstd),
+          B, T, P, Pp, D, *_d(drop), _s())
+
+
+def w2v_pos_finish_bwd(dx0, ysave, conv, cbias, mean, rstd, gamma, dconv, dgamma, dbeta, B, T, P, Pp, D, drop=None):
+    _call("srhip_w2v_pos_finish_bwd", _p(dx0), _p(ysave), _p(conv), _p(cbias), _p(mean), _p(rstd), _p(gamma), _p(dconv), _p(dgamma), _p(dbeta),
+          B, T, P, Pp, D, *_d(drop), _s())
+
+
+def make_group_desc_ld(problems, device):
+    """srhip_group_desc table with explicit leading dimensions / raw pointers: problems = list of (A_ptr, lda, B_ptr, ldb, C_ptr, ldc, M, N, K)."""
+    import numpy as np
+    arr = np.zeros(len(problems), dtype=GROUP_DESC_DTYPE)
+    t = 0
+    for i, (A, lda, B, ldb, C, ldc, M, N, K) in enumerate(problems):
+        arr[i] = (A, B, C, M, N, K, lda, ldb, ldc, t, 0, 0, 0)
+        t += ((M + 127) // 128) * ((N + 127) // 128)
+    flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
+    nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
+
+
+def make_group_tn_desc_ld(problems, device):
+    """srhip_group_tn_desc table with explicit pointers / leading dimensions: (A_ptr, lda, B_ptr, ldb, C_ptr, ldc, dbias_ptr, M, N, K)."""
+    import numpy as np
+    arr = np.zeros(len(problems), dtype=GROUP_TN_DESC_DTYPE)
+    t = 0
+    for i, (A, lda, B, ldb, C, ldc, db, M, N, K) in enumerate(problems):
+        arr[i] = (A, B, C, db or 0, M, N, K, lda, ldb, ldc, t, 0)
+        t += ((M + 127) // 128) * ((N + 127) // 128)
+    flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
+    nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
