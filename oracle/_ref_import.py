@@ -71,6 +71,7 @@ def install():
     _stub("semilearn.nets.wrn", S + "/nets/wrn")
     _stub("semilearn.nets.bert", S + "/nets/bert")
     _stub("semilearn.nets.wave2vecv2", S + "/nets/wave2vecv2")
+    _stub("semilearn.nets.hubert", S + "/nets/hubert")
     _stub("semilearn.algorithms", S + "/algorithms")
     for a in ("srflexmatch", "srfixmatch", "srpseudolabel", "srsoftmatch", "srfreematch",
               "flexmatch", "freematch", "softmatch"):

@@ -370,6 +370,33 @@ def gen_bert():
     np.savez_compressed(os.path.join(OUT, "bert.npz"), **out)
 
 
+def build_ref_hubert(cfg, params):
+    """The reference ClassificationHubert (semilearn/nets/hubert/hubert.py, the backbone of every config/SemiReward/usb_audio yaml) around a
+    randomly initialised HF HubertModel with the facebook/hubert-base-ls960 hyper-parameters -- the same architecture and parameter names as
+    Wav2Vec2 (HubertModel is a re-export of the wav2vec2 blocks)."""
+    import torch.nn as nn
+    from transformers import HubertConfig, HubertModel
+    hm = R.mod("semilearn.nets.hubert.hubert")
+    hc = HubertConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, intermediate_size=cfg.inter,
+                      conv_dim=tuple(cfg.conv_dim), conv_stride=tuple(cfg.conv_stride), conv_kernel=tuple(cfg.conv_kernel),
+                      num_conv_pos_embeddings=cfg.pos_k, num_conv_pos_embedding_groups=cfg.pos_groups, hidden_dropout=cfg.p_hidden,
+                      activation_dropout=cfg.p_act, attention_dropout=cfg.p_attn, feat_proj_dropout=cfg.p_featproj, layerdrop=cfg.layerdrop,
+                      mask_time_prob=cfg.mask_time_prob, mask_time_length=cfg.mask_time_length, mask_time_min_masks=cfg.mask_time_min_masks,
+                      feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, apply_spec_augment=True, feat_proj_layer_norm=True,
+                      attn_implementation="eager")
+    model = hm.ClassificationHubert.__new__(hm.ClassificationHubert)
+    nn.Module.__init__(model)
+    model.model = HubertModel(hc)
+    model.model.feature_extractor._requires_grad = False
+    model.dropout = torch.nn.Dropout(p=0.1, inplace=False)
+    model.num_features = cfg.hidden
+    model.classifier = nn.Sequential(nn.Linear(cfg.hidden, cfg.hidden), nn.GELU(), nn.Linear(cfg.hidden, cfg.num_classes))
+    assert [n for n, _ in model.named_parameters()] == [n for n, _ in WR.param_shapes(cfg)], \
+        [(a, b) for (a, _), (b, _) in zip(model.named_parameters(), WR.param_shapes(cfg)) if a != b][:3]
+    load_module_params(model, params)
+    return model
+
+
 def build_ref_w2v(cfg, params):
     """The reference ClassificationWave2Vec around a randomly initialised HF Wav2Vec2Model with the facebook/wav2vec2-base-960h
     hyper-parameters (``from_pretrained`` needs the network), assembled field by field as wave2vecv2.py:9-21 does; eager attention so that
@@ -401,7 +428,8 @@ class InjectedW2vRandomness:
     """One reference forward with the oracle's random inputs: dropout masks (shared counter-based generator), the SpecAugment mask
     (replaces transformers' _compute_mask_indices draw) and the LayerDrop decisions (replace the encoder's torch.rand([]) draws)."""
 
-    def __init__(self, cfg, seed, spec_mask, skip):
+    def __init__(self, cfg, seed, spec_mask, skip, module="wav2vec2"):
+        self.module = module
         sites = [WR.SITE_FEATPROJ, WR.SITE_EMB]
         for i in range(cfg.layers):
             if not skip[i]:
@@ -410,7 +438,8 @@ class InjectedW2vRandomness:
         self.spec_mask, self.skip, self.layerdrop = spec_mask, list(skip), cfg.layerdrop
 
     def __enter__(self):
-        import transformers.models.wav2vec2.modeling_wav2vec2 as hm
+        import importlib
+        hm = importlib.import_module("transformers.models.%s.modeling_%s" % (self.module, self.module))
         self.hm, self.orig_cm, self.orig_rand = hm, hm._compute_mask_indices, torch.rand
         hm._compute_mask_indices = lambda shape, *a, **k: self.spec_mask.copy()
         q = [0.0 if s_ else 1.0 for s_ in self.skip]
@@ -435,7 +464,8 @@ def gen_w2v():
     import transformers
     out = {"meta/transformers_version": np.array(transformers.__version__)}
     for tag, cfgd, C, B, S, seed, skip in [("tiny", WR.W2V_TINY_TEST, 4, 3, 400, 81, (False, False)), ("tiny_skip", WR.W2V_TINY_TEST, 4, 2, 400, 83, (True, False)),
-                                           ("base", WR.W2V_BASE, 4, 2, 16000, 82, (False,) * 5 + (True,) + (False,) * 6)]:
+                                           ("base", WR.W2V_BASE, 4, 2, 16000, 82, (False,) * 5 + (True,) + (False,) * 6),
+                                           ("hubert_tiny", WR.W2V_TINY_TEST, 4, 3, 400, 84, (False, True))]:
         cfg = WR.W2vCfg(num_classes=C, **cfgd)
         params = WR.synth_params(cfg, seed)
         rng = np.random.Generator(np.random.PCG64(seed + 1))
@@ -443,14 +473,15 @@ def gen_w2v():
         y, w = rng.integers(0, C, size=(B,), dtype=np.int64), rng.random(B).astype(np.float32)
         T_ = WR.frames(cfg, S)[-1]
         spec = WR.spec_augment_mask(seed + 2, B, T_, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks)
-        model = build_ref_w2v(cfg, params)
+        hub = tag.startswith("hubert")
+        model = (build_ref_hubert if hub else build_ref_w2v)(cfg, params)
         model.eval()
         with torch.no_grad():
             o = model(T(wave))
         out[f"{tag}/eval_logits"], out[f"{tag}/eval_feat"] = o["logits"].numpy(), o["feat"].numpy()
         model.train()
         dseed = (seed << 32) + 5
-        with InjectedW2vRandomness(cfg, dseed, spec, skip):
+        with InjectedW2vRandomness(cfg, dseed, spec, skip, "hubert" if hub else "wav2vec2"):
             o = model(T(wave))
             loss = (F.cross_entropy(o["logits"], T(y), reduction="none") * T(w)).mean()
         loss.backward()

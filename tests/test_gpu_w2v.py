@@ -25,13 +25,15 @@ def test_spec_augment_mask_matches_oracle():
         assert np.array_equal(a, WR.spec_augment_mask(seed, B, T, 0.05, 10, 2)) and a.sum(1).min() >= 10
 
 
-@pytest.mark.parametrize("tag", ["tiny", "tiny_skip", "base"])
+@pytest.mark.parametrize("tag", ["tiny", "tiny_skip", "base", "hubert_tiny"])
 def test_w2v_matches_reference_golden(golden, tag):
     g = golden("w2v")
     C, B, S, seed, dseed = [int(v) for v in g[f"{tag}/meta"]]
     cfgd = WR.W2V_BASE if tag == "base" else WR.W2V_TINY_TEST
     cfg = WR.W2vCfg(num_classes=C, **cfgd)
-    model = wave2vec.ClassificationWave2Vec(wave2vec.W2vConfig(num_classes=C, **cfgd), device=DEV)
+    from semireward_amd.nets import hubert
+    cls = hubert.ClassificationHubert if tag.startswith("hubert") else wave2vec.ClassificationWave2Vec      # same engine, same parameter names
+    model = cls(wave2vec.W2vConfig(num_classes=C, **cfgd), device=DEV)
     assert sorted(n for n, _ in model.names_shapes) == sorted(n for n, _ in WR.param_shapes(cfg))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in WR.synth_params(cfg, seed).items()})
     rng = np.random.Generator(np.random.PCG64(seed + 1))

@@ -482,7 +482,7 @@ def test_srsoftmatch_bert_trace(golden):
             check_samp(orc.P[nme].numpy(), g.samp(f"it{tr['its'][-1]}/param/{nme}"), 2e-3, 3e-5, f"param {nme}")
 
 
-@pytest.mark.parametrize("tag", ["tiny", "tiny_skip", "base"])
+@pytest.mark.parametrize("tag", ["tiny", "tiny_skip", "base", "hubert_tiny"])
 def test_w2v_oracle_matches_reference(golden, tag):
     """oracle/w2v2_ref.py against the reference ClassificationWave2Vec on a random-init HF Wav2Vec2Model (base-960h hyper-parameters):
     eval forward; train forward with the injected dropout masks, SpecAugment mask and LayerDrop decisions; gradients of a weighted CE."""
