@@ -867,6 +867,92 @@ def gen_trace_soft_bert():
     np.savez_compressed(os.path.join(OUT, "srsoftmatch_bert_trace.npz"), **out)
 
 
+# usb_audio flavour (BASELINE.json configs[4]: Wave2Vec + FreeMatch + SemiReward; config/SemiReward/usb_audio/*.yaml shapes): raw-waveform
+# batches, use_cat False, AdamW lr 5e-4 (yaml: 5e-5) / wd 5e-4 / layer_decay 0.75.  Train-mode randomness is switched off (all dropout
+# probabilities, LayerDrop and SpecAugment 0): the reference's RNG draws cannot be reproduced; their arithmetic is pinned by w2v.npz.
+TRACE_FREE_W2V = dict(num_train_iter=2000, start_timing=100, N_k=10, C=4, Bl=3, Bu=5, its=[0, 1, 99, 100, 101, 110], seed=127,
+                      num_warmup_iter=50, algorithm="srfreematch", ema_p=0.9, use_quantile=True, clip_thresh=False, ent_loss_ratio=0.05,
+                      ulb_dest_len=256, lr=5e-4, weight_decay=5e-4, layer_decay=0.75, samples=400, head_gain=8.0, p_cutoff=0.95)
+W2V_QUIET = dict(p_hidden=0.0, p_act=0.0, p_attn=0.0, p_featproj=0.0, p_head=0.0, layerdrop=0.0, mask_time_prob=0.0)
+
+
+def trace_w2v_params(cfg, seed, head_gain):
+    bp = WR.synth_params(cfg, seed)
+    bp["classifier.2.weight"] = bp["classifier.2.weight"] * np.float32(head_gain)
+    return bp
+
+
+def synth_wave_step(tr, n):
+    rng = np.random.Generator(np.random.PCG64(tr["seed"] + 10 + n))
+    mk = lambda b: rng.standard_normal((b, tr["samples"])).astype(np.float32)   # noqa: E731
+    return mk(tr["Bl"]), rng.integers(0, tr["C"], size=(tr["Bl"],), dtype=np.int64), mk(tr["Bu"]), mk(tr["Bu"])
+
+
+def gen_trace_free_w2v():
+    tr = TRACE_FREE_W2V
+    C, seed = tr["C"], tr["seed"]
+    cfg = WR.W2vCfg(num_classes=C, **WR.W2V_TINY_TEST, **W2V_QUIET)
+    Fd = cfg.hidden
+    bp = trace_w2v_params(cfg, seed, tr["head_gain"])
+    rp = synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)
+    gp = synth.synth_params(S.generator_shapes(Fd), seed + 2)
+    model = build_ref_w2v(cfg._replace(mask_time_prob=0.05), bp)     # (HF only creates masked_spec_embed when the probability is > 0)
+    model.dropout.p = 0.0
+    model.model.config.apply_spec_augment = False
+    model.train()
+    alg = build_headless_srflexmatch(model, C, Fd, tr)
+    alg.use_cat = False
+    bu = R.mod("semilearn.core.utils.build")
+    alg.optimizer = bu.get_optimizer(model, "AdamW", tr["lr"], 0.9, tr["weight_decay"], tr["layer_decay"])
+    alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
+    load_module_params(alg.rewarder, rp)
+    load_module_params(alg.generator, gp)
+    out, prev_it = {}, -1
+    for n, it in enumerate(tr["its"]):
+        for _ in range(it - prev_it - 1):
+            alg.scheduler.step()
+        prev_it = it
+        alg.it = it
+        K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
+        xl, y, xw, xs = synth_wave_step(tr, n)
+        cm = _CountingModel(model)
+        alg.model = cm
+        rec = dict(mask=[])
+        mh = alg.hooks_dict["MaskingHook"]
+        orig = mh.masking
+
+        def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
+            m = _orig(algorithm, *a, **k)
+            _rec["mask"].append(m.numpy().copy())
+            return m
+        mh.masking = wrapped
+        rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
+        o, log = alg.train_step(T(xl), T(y), T(xw), T(xs))
+        mh.masking = orig
+        assert cm.calls == 3 + 2 * K, (cm.calls, K)
+        o["loss"].backward()
+        p = f"it{it}"
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/grad/{nme}", samp(prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32), 64), out)
+        out[f"{p}/lr_factor"] = np.float64(max(alg.scheduler.get_last_lr()) / tr["lr"])      # the groups of the last layer id have scale 1
+        alg.optimizer.step(); alg.scheduler.step(); model.zero_grad()
+        for k_, v in log.items():
+            out[f"{p}/log/{k_.split('/')[-1]}"] = np.float64(v)
+        out[f"{p}/K"] = np.int64(K)
+        out[f"{p}/masks"] = np.stack(rec["mask"])
+        for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+            out[f"{p}/feat/{k_}"] = o["feat"][k_].detach().numpy()
+        out[f"{p}/rewarder_updated"] = np.int64(any(not torch.equal(rbefore[k_], v.detach()) for k_, v in alg.rewarder.named_parameters()))
+        for nme, prm in model.named_parameters():
+            flat(f"{p}/param/{nme}", samp(prm.detach().numpy(), 64), out)
+        out[f"{p}/max_reward"] = np.float64(float(alg.max_reward))
+        out[f"{p}/time_p"] = np.float32(mh.time_p); out[f"{p}/p_model"] = mh.p_model.numpy().copy()
+        out[f"{p}/label_hist"] = mh.label_hist.numpy().copy()
+    out["meta/its"] = np.array(tr["its"], dtype=np.int64)
+    print("srfreematch_w2v_trace.npz mask mean", np.concatenate([out[f"it{it}/masks"].ravel() for it in tr["its"]]).mean())
+    np.savez_compressed(os.path.join(OUT, "srfreematch_w2v_trace.npz"), **out)
+
+
 def gen_softmatch_hook():
     """DistAlignEMAHook + SoftMatchWeightingHook sequences straight from the reference (both p_target modes)."""
     smu = R.mod("semilearn.algorithms.srsoftmatch.utils")
@@ -1018,7 +1104,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
-            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v)
+            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -59,6 +59,25 @@ def bert_param_hparams(names_shapes, layers, lr, weight_decay, layer_decay):
     return out
 
 
+def w2v_param_hparams(names_shapes, layers, lr, weight_decay, layer_decay, hubert=False):
+    """ClassificationWave2Vec.group_matcher (wave2vecv2.py:51-53: stem = feature_projection | feature_extractor, blocks = encoder.layers.(\\d+));
+    ClassificationHubert's (hubert.py:52-54) also puts encoder.pos_conv_embed into the stem.  Unmatched names (masked_spec_embed, encoder
+    layer_norm, classifier, [pos_conv_embed]) -> layer_max = layers + 1."""
+    layer_max = layers + 1
+    out = {}
+    for name, shape in names_shapes:
+        if name.startswith("model.feature_projection") or name.startswith("model.feature_extractor") or \
+                (hubert and name.startswith("model.encoder.pos_conv_embed")):
+            lid = 0
+        elif name.startswith("model.encoder.layers."):
+            lid = int(name.split(".")[3]) + 1
+        else:
+            lid = layer_max
+        scale = layer_decay ** (layer_max - lid) if layer_decay != 1.0 else 1.0
+        out[name] = (scale * lr, 0.0 if len(shape) == 1 else weight_decay)
+    return out
+
+
 def cosine_warmup_factor(step, num_training_steps, num_warmup_steps=0, num_cycles=7.0 / 16.0):
     """build.py:237-249.  LambdaLR applies factor(it) at 0-based iteration ``it``."""
     if step < num_warmup_steps:

@@ -76,3 +76,29 @@ class SRFreeMatchOracle(SRFlexMatchOracle):
         tr["lr_factor"] = fac
         self.it += 1
         return tr
+
+
+class SRFreeMatchW2vOracle(SRFreeMatchOracle):
+    """usb_audio flavour (BASELINE.json configs[4]): Wav2Vec2 / HuBERT backbone on raw waveforms, ``use_cat: False`` -- train_step forwards x_lb,
+    x_ulb_s and (no_grad) x_ulb_w in separate model calls (srfreematch.py:128-137), data_generator only x_ulb_s and x_ulb_w (:87-94); AdamW with
+    layer decay through the backbone's group_matcher.  Train-mode randomness off (dropout / LayerDrop / SpecAugment probabilities 0)."""
+    hubert = False
+
+    def _hparams(self, cfg, lr, weight_decay, layer_decay):
+        from . import w2v2_ref as WR
+        return O.w2v_param_hparams(WR.param_shapes(cfg), cfg.layers, lr, weight_decay, layer_decay, hubert=self.hubert)
+
+    def _forward(self, P, x_lb, x_ulb_w, x_ulb_s, dp):
+        from . import w2v2_ref as WR
+        lx = fx = None
+        if dp == "pass0":
+            o = WR.w2v_forward(P, x_lb, self.cfg)
+            lx, fx = o["logits"], o["feat"]
+        os_ = WR.w2v_forward(P, x_ulb_s, self.cfg)
+        with torch.no_grad():
+            ow = WR.w2v_forward(P, x_ulb_w, self.cfg)
+        return lx, ow["logits"], os_["logits"], fx, ow["feat"], os_["feat"]
+
+    def train_step(self, x_lb, y_lb, x_ulb_w, x_ulb_s, droppath=None):
+        K = H.sr_decay(self.num_train_iter, self.it) if self.it > self.start_timing else 0
+        return super().train_step(x_lb, y_lb, x_ulb_w, x_ulb_s, ["pass0"] + ["loop"] * K)

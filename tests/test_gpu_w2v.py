@@ -74,3 +74,69 @@ def test_w2v_matches_reference_golden(golden, tag):
     model.eval()
     lg2, _, _ = model.forward_features(wave, idx, save=False)
     assert rel(lg2, torch.from_numpy(g[f"{tag}/eval_logits"])[[B - 1, 0]]) < TOL
+
+
+def test_srfreematch_w2v_trace(golden):
+    """BASELINE.json configs[4] (usb_audio: Wave2Vec + FreeMatch + SemiReward, raw waveforms, use_cat False, AdamW with layer decay 0.75) end to end
+    on the HIP engine against a trace of the reference: masks of every pass, losses, features, FreeMatch EMA state, rewarder updates, parameters
+    after the fused AdamW steps."""
+    import argparse
+    from oracle import semireward_ref as S
+    from oracle.gen_golden import TRACE_FREE_W2V as tr, W2V_QUIET, synth_wave_step, trace_w2v_params
+    from semireward_amd.algorithms import get_algorithm
+    from semireward_amd.utils import synth
+    g = golden("srfreematch_w2v_trace")
+    C, seed = tr["C"], tr["seed"]
+    cfg = WR.W2vCfg(num_classes=C, **WR.W2V_TINY_TEST, **W2V_QUIET)
+    Fd = cfg.hidden
+    args = argparse.Namespace(
+        algorithm="srfreematch", num_classes=C, num_train_iter=tr["num_train_iter"], epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False,
+        amp=False, optim="AdamW", lr=tr["lr"], weight_decay=tr["weight_decay"], layer_decay=tr["layer_decay"],
+        num_warmup_iter=tr["num_warmup_iter"], T=0.5, hard_label=True, ema_p=tr["ema_p"], use_quantile=tr["use_quantile"],
+        clip_thresh=tr["clip_thresh"], ent_loss_ratio=tr["ent_loss_ratio"], p_cutoff=tr["p_cutoff"], ulb_dest_len=tr["ulb_dest_len"], N_k=tr["N_k"],
+        start_timing=tr["start_timing"], feature_dim=Fd, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    builder = lambda num_classes, device: wave2vec.ClassificationWave2Vec(   # noqa: E731
+        wave2vec.W2vConfig(num_classes=num_classes, **WR.W2V_TINY_TEST, **W2V_QUIET), device=device)
+    alg = get_algorithm(args, builder)
+    Tn = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
+    alg.model.load_state_dict(Tn(trace_w2v_params(cfg, seed, tr["head_gain"])))
+    alg.rewarder.load_state_dict(Tn(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)))
+    alg.generator.load_state_dict(Tn(synth.synth_params(S.generator_shapes(Fd), seed + 2)))
+    flips = total = 0
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        alg.it = it
+        alg.optimizer.sched_step = it
+        K = int(g[f"{p}/K"])
+        xl, y, xw, xs = synth_wave_step(tr, n)
+        alg.trace = {}
+        before = alg.rewarder.flat.clone()
+        out, log = alg.train_step(**alg.process_batch(x_lb=torch.from_numpy(xl), y_lb=torch.from_numpy(y), x_ulb_w=torch.from_numpy(xw),
+                                                      x_ulb_s=torch.from_numpy(xs)))
+        alg.out_dict, alg.log_dict = out, log
+        assert alg.optimizer.lr_factor() == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        alg.call_hook("after_train_step")
+        assert alg.trace["K"] == K
+        ntol = 1.0 + n
+        masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
+        bad = masks != g[f"{p}/masks"]
+        flips += int(bad.sum()); total += bad.size
+        assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+        h = alg.hooks_dict["MaskingHook"]
+        assert float(h.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=2e-2 * ntol)
+        assert rel(h.p_model, g[f"{p}/p_model"]) < 2e-2 * ntol
+        for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+            assert rel(out["feat"][k_], g[f"{p}/feat/{k_}"]) < 2.5e-2 * ntol, (p, k_)
+        if bad.any():
+            continue                                   # a row ON the (self-adaptive) threshold flipped: the losses of this step differ by that row
+        for k_ in ("sup_loss", "unsup_loss", "total_loss"):
+            assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=5e-2 * ntol, abs=5e-3), (p, k_)
+    assert flips <= 0.04 * total, (flips, total)
+    worst = 0.0
+    for nme, v in alg.model.named_parameters():
+        if nme.endswith("k_proj.bias"):
+            continue
+        gs = g.samp(f"it{tr['its'][-1]}/param/{nme}")
+        a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
+        worst = max(worst, float(np.abs(a - gs["sample"]).max()))
+    assert worst < 4e-3, worst

@@ -511,3 +511,40 @@ def test_w2v_oracle_matches_reference(golden, tag):
         gr = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
         check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 3e-3, 2e-6, f"{tag} grad {n}",
                    exclude=(lambda i: np.ones_like(i, bool)) if n.endswith("k_proj.bias") else None)        # analytically zero: round-off only
+
+
+def test_srfreematch_w2v_trace(golden):
+    """SRFreeMatch on the Wav2Vec2 backbone (usb_audio, BASELINE.json configs[4]: raw waveforms, use_cat False, AdamW with layer decay through
+    ClassificationWave2Vec.group_matcher) against a trace of the reference itself."""
+    from oracle import w2v2_ref as WR
+    from oracle.gen_golden import TRACE_FREE_W2V as tr, W2V_QUIET, synth_wave_step, trace_w2v_params
+    from oracle.srfreematch_ref import SRFreeMatchW2vOracle
+    g = golden("srfreematch_w2v_trace")
+    C, seed = tr["C"], tr["seed"]
+    cfg = WR.W2vCfg(num_classes=C, **WR.W2V_TINY_TEST, **W2V_QUIET)
+    Fd = cfg.hidden
+    orc = SRFreeMatchW2vOracle(
+        cfg, TP(trace_w2v_params(cfg, seed, tr["head_gain"])), TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
+        TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)), num_train_iter=tr["num_train_iter"], start_timing=tr["start_timing"],
+        N_k=tr["N_k"], ulb_dest_len=tr["ulb_dest_len"], num_warmup_iter=tr["num_warmup_iter"], ema_p=tr["ema_p"],
+        use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"], lambda_e=tr["ent_loss_ratio"], lr=tr["lr"],
+        weight_decay=tr["weight_decay"], layer_decay=tr["layer_decay"])
+    for n, it in enumerate(tr["its"]):
+        p = f"it{it}"
+        orc.it = it
+        K = int(g[f"{p}/K"])
+        xl, y, xw, xs = synth_wave_step(tr, n)
+        t = orc.train_step(T(xl), T(y), T(xw), T(xs))
+        assert t["K"] == K
+        assert np.array_equal(np.stack([q["mask"].numpy() for q in t["passes"]]), g[f"{p}/masks"]), p
+        for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+            assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=1e-4, abs=5e-6), (p, k_)
+        assert float(orc.fm.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=1e-5)
+        np.testing.assert_allclose(orc.fm.p_model.numpy(), g[f"{p}/p_model"], rtol=1e-5)
+        assert t["lr_factor"] == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        for nme, _ in WR.param_shapes(cfg):
+            check_samp(t["grads"][nme].numpy(), g.samp(f"{p}/grad/{nme}"), 5e-3, 3e-6, f"{p} grad {nme}",
+                       exclude=(lambda i: np.ones_like(i, bool)) if nme.endswith("k_proj.bias") else None)
+    for nme, _ in WR.param_shapes(cfg):
+        if not nme.endswith("k_proj.bias"):
+            check_samp(orc.P[nme].numpy(), g.samp(f"it{tr['its'][-1]}/param/{nme}"), 2e-3, 5e-5, f"param {nme}")
