@@ -77,9 +77,11 @@ def main():
     ap.add_argument("--regime", choices=["sr", "pre"], default="sr", help="sr: it > start_timing (K=8); pre: K=0")
     ap.add_argument("--img", type=int, choices=[32, 224], default=32,
                     help="32: ViT-S/2 on 32x32 (north-star config); 224: ViT-S/16 on 224x224 (vit_small_patch16_224, 197 tokens)")
-    ap.add_argument("--net", choices=["vit", "bert"], default="vit",
+    ap.add_argument("--net", choices=["vit", "bert", "hubert"], default="vit",
                     help="vit: the headline workload (BASELINE.json metric); bert: SRSoftMatch + bert_base_uncased on [B, --seq-len] token "
-                         "batches (usb_nlp shapes, BASELINE.json configs[3]) -- reported under its own metric name")
+                         "batches (usb_nlp shapes, BASELINE.json configs[3]); hubert: SRSoftMatch + hubert_base (the Wav2Vec2 architecture) on "
+                         "[B, --samples] waveforms (usb_audio shapes, configs[4]) -- both reported under their own metric names")
+    ap.add_argument("--samples", type=int, default=64000, help="waveform length (usb_audio: 4 s at 16 kHz)")
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--infer-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,6 +124,20 @@ def main():
                          "attention_mask": torch.ones(n, a.seq_len, dtype=torch.int64)}      # full-length rows
         batch = alg.process_batch(x_lb=tok(bl), y_lb=torch.randint(0, 4, (bl,), generator=g), x_ulb_w=tok(a.bu), x_ulb_s=tok(a.bu))
         START = 90001                                                           # sr_decay(): max(8, 1 + 102400 / it) = 8
+    elif a.net == "hubert":
+        # config/SemiReward/usb_audio/softmatch/softmatch_urbansound8k_100_0.yaml: hubert_base, 10 classes, batch 8 / uratio 1, 4 s at 16 kHz,
+        # use_cat False, AdamW lr 5e-5 wd 5e-4 layer_decay 0.75
+        from semireward_amd.nets import hubert
+        au = dict(NS, algorithm="srsoftmatch", num_classes=10, num_train_iter=102400, start_timing=10000, lr=5e-5, layer_decay=0.75,
+                  use_cat=False, feature_dim=768, dist_align=True, dist_uniform=True, ema_p=0.999, n_sigma=2, per_class=False)
+        args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **au)
+        alg = get_algorithm(args, hubert.hubert_base)
+        alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
+        alg.model.seed = 1234 + rank
+        g = torch.Generator().manual_seed(100 + rank)
+        wv = lambda n: torch.randn(n, a.samples, generator=g)   # noqa: E731
+        batch = alg.process_batch(x_lb=wv(bl), y_lb=torch.randint(0, 10, (bl,), generator=g), x_ulb_w=wv(a.bu), x_ulb_s=wv(a.bu))
+        START = 90001
     else:
         args = argparse.Namespace(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk, **NS)
         alg = get_algorithm(args, vit.vit_small_patch2_32 if a.img == 32 else vit.vit_small_patch16_224)
@@ -174,17 +190,20 @@ def main():
     K = alg.sr_decay() if a.regime == "sr" else 0
     if rank == 0:
         out = {"metric": "unlabeled images/sec/node (FlexMatch+SR, ViT-S CIFAR-100)" if a.net == "vit" else
-               "unlabeled sequences/sec/node (SoftMatch+SR, BERT-base, L=%d)" % a.seq_len, "value": world * a.bu * a.steps / dt,
-               "unit": "unlabeled images/s" if a.net == "vit" else "unlabeled sequences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "unlabeled sequences/sec/node (SoftMatch+SR, BERT-base, L=%d)" % a.seq_len if a.net == "bert" else
+               "unlabeled clips/sec/node (SoftMatch+SR, HuBERT-base, %d samples)" % a.samples, "value": world * a.bu * a.steps / dt,
+               "unit": {"vit": "unlabeled images/s", "bert": "unlabeled sequences/s", "hubert": "unlabeled clips/s"}[a.net], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
                "config": {"workload": ("SRSoftMatch bert_base_uncased, [B, %d] token batches, softmatch_ag_news_40_0.yaml shapes, use_cat False, " % a.seq_len
                                        if a.net == "bert" else
+                                       "SRSoftMatch hubert_base, [B, %d] waveforms, softmatch_urbansound8k_100_0.yaml shapes, use_cat False, " % a.samples
+                                       if a.net == "hubert" else
                                        "SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, " if a.img == 32 else
                                        "SRFlexMatch ViT-S/16@224 (vit_small_patch16_224) 224x224x3 batches, 100 classes, ") +
                                       ("steady SR regime" if a.regime == "sr" else "pre-start_timing regime"),
                           "per_gpu_batch": {"lb": bl, "ulb_w": a.bu, "ulb_s": a.bu}, "K_passes": K,
-                          "forward_image_passes_per_step": (1 + K) * (bl + 2 * a.bu) - (K * bl if a.net == "bert" else 0),
+                          "forward_image_passes_per_step": (1 + K) * (bl + 2 * a.bu) - (K * bl if a.net != "vit" else 0),
                           "backward_images_per_step": bl + a.bu,
                           "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
