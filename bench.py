@@ -188,6 +188,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     K = alg.sr_decay() if a.regime == "sr" else 0
+    if rank == 0 and os.environ.get("SR_PHASES", "0") != "0":
+        print("phases (ms since step start: gpu, host):", {k: (round(v[0], 2), round(v[1], 2)) for k, v in alg.phase_report().items()}, file=sys.stderr)
     if rank == 0:
         out = {"metric": "unlabeled images/sec/node (FlexMatch+SR, ViT-S CIFAR-100)" if a.net == "vit" else
                "unlabeled sequences/sec/node (SoftMatch+SR, BERT-base, L=%d)" % a.seq_len if a.net == "bert" else

@@ -26,23 +26,32 @@ from .hooks import FixedThresholdingHook, FlexMatchThresholdingHook, PseudoLabel
 from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
+_PHASES = os.environ.get("SR_PHASES", "0") != "0"
+
 
 class _Plan:
     """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
     rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
 
-    def __init__(self, cols_img, grad_cols, device, skip_cols=()):
+    def __init__(self, cols_img, grad_cols, device, skip_cols=(), read_cols=None):
+        """read_cols: the inference columns whose logits / features the step actually READS (weak rows of every pass).  The others are
+        computed because the reference computes them (the strong and labelled rows of the passes whose loss is thrown away) -- same
+        launches, but nothing waits for them: they run on the second stream behind the gradient rows (``rest``)."""
         gset = set(grad_cols) | set(skip_cols)
-        inf_cols = [c for c in range(len(cols_img)) if c not in gset]
+        inf_all = [c for c in range(len(cols_img)) if c not in gset]
+        rset = set(inf_all) if read_cols is None else set(read_cols)
+        inf_cols = [c for c in inf_all if c in rset]
+        rest_cols = [c for c in inf_all if c not in rset]
         t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
-        self.grad_cols, self.inf_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64)
+        self.grad_cols, self.inf_cols, self.rest_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64), t(rest_cols, torch.int64)
         self.grad_img = t([cols_img[c] for c in grad_cols], torch.int32)
         self.inf_img = t([cols_img[c] for c in inf_cols], torch.int32)
+        self.rest_img = t([cols_img[c] for c in rest_cols], torch.int32)
         self.ncols = len(cols_img)
         self.mixed_cols = self.mixed_img = None      # gradient columns first (forward_mixed), built on first use
 
     @classmethod
-    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True):
+    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
         labelled rows of pass 0 and the strong rows of the last pass.  lb_every_pass=False (use_cat=False, the usb_nlp / usb_audio
         configs): data_generator forwards only x_ulb_s and x_ulb_w (srflexmatch.py:83-90), so the labelled columns of the passes
@@ -52,7 +61,8 @@ class _Plan:
         grad = list(range(nl)) + ([j for j in range(nl + nu, Bt)] if extra_pass0_strong else []) + \
             [K * Bt + j for j in range(nl + nu, Bt)]
         skip = [] if lb_every_pass else [k * Bt + j for k in range(1, K + 1) for j in range(nl)]
-        p = cls(cols_img, grad, device, skip)
+        read = [k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)] if defer_unread else None      # the weak rows
+        p = cls(cols_img, grad, device, skip, read)
         p.P, p.Bt = K + 1, Bt
         return p
 
@@ -80,6 +90,10 @@ class SRConsistencyBase(AlgorithmBase):
         self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", os.environ.get("SR_OVERLAP_GRAD_ROWS", "1") != "0")) \
             and torch.cuda.is_available()
         self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
+        # rows nothing downstream reads (see _Plan) go behind the gradient rows on the second stream; the step end waits for them
+        self.defer_unread_rows = self.overlap_grad_rows and os.environ.get("SR_DEFER_UNREAD_ROWS", "1") != "0"
+        self._rest_done = None
+        self._phases = []
         self.inject_droppath = None            # tests: list of [depth,2,Bt] tensors, one per pass
         self.trace = None                      # tests: dict filled with per-pass intermediates when not None
 
@@ -131,10 +145,13 @@ class SRConsistencyBase(AlgorithmBase):
         main = torch.cuda.current_stream()
         side = self._side_stream if self.overlap_grad_rows else None
         dp_grad = sel(pl.grad_cols)
-        ni = pl.inf_cols.numel()
+        ni, nr = pl.inf_cols.numel(), pl.rest_cols.numel()
         step = self.infer_chunk if self.infer_chunk > 0 else max(ni, 1)
         chunks = [(pl.inf_cols[s:s + step], pl.inf_img[s:s + step].contiguous()) for s in range(0, ni, step)]
+        if side is None and nr:
+            chunks.append((pl.rest_cols, pl.rest_img))
         dps = [sel(cols) for cols, _ in chunks]
+        dp_rest = sel(pl.rest_cols) if (side is not None and nr) else None
         if side is not None:
             ready = torch.cuda.Event()
             ready.record(main)                       # parameters, images, DropPath draws are final here
@@ -144,9 +161,26 @@ class SRConsistencyBase(AlgorithmBase):
             feats.index_copy_(0, cols, ft)
         if side is not None:
             side.wait_event(ready)
+            # tensors allocated on the main stream that the second stream keeps reading after this function returns: tell the caching
+            # allocator (a freed DropPath table was handed to the next main-stream allocation while the deferred rows still read it)
+            for t_ in (logits, feats, dp_grad, dp_rest, imgs, getattr(imgs, "ids", None), getattr(imgs, "key_len", None),
+                       getattr(imgs, "seq_len", None)):
+                if torch.is_tensor(t_):
+                    t_.record_stream(side)
             with torch.cuda.stream(side), ops.stream_scope():
                 lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
-            main.wait_stream(side)
+                grad_done = torch.cuda.Event()
+                grad_done.record(side)
+                if nr:
+                    # Rows whose outputs nothing reads before the step ends (strong / labelled rows of the passes whose loss the
+                    # reference discards): 60 % of the forward work, off the critical path.  The masks, losses and the latency-bound
+                    # backward of the 16 gradient images (small launches that leave most CUs idle) run on the main stream meanwhile.
+                    lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest, save=False, buftag="r")
+                    logits.index_copy_(0, pl.rest_cols, lg_r)
+                    feats.index_copy_(0, pl.rest_cols, ft_r)
+                    self._rest_done = torch.cuda.Event()
+                    self._rest_done.record(side)
+            main.wait_event(grad_done)
             lg_g.record_stream(main)
             ft_g.record_stream(main)
         else:
@@ -154,6 +188,42 @@ class SRConsistencyBase(AlgorithmBase):
         logits.index_copy_(0, pl.grad_cols, lg_g)
         feats.index_copy_(0, pl.grad_cols, ft_g)
         return logits, feats, ctx
+
+    def _step_scope(self):
+        # (tried and measured on MI355X, both without gain: running the step on a high-priority stream -- the hardware offers two levels and
+        # a small launch still waits for a 100-us workgroup of the other stream to retire -- and confining the second stream to a CU subset
+        # with hipExtStreamCreateWithCUMask, which slows the full-chip launches by more than it speeds the small ones up)
+        return ops.stream_scope()
+
+    def _phase_mark(self, name):
+        """Tuning aid (SR_PHASES=1): GPU timestamps (events on the step's stream) + host timestamps of the phases of train_step."""
+        import time
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._phases.append((name, e, time.perf_counter()))
+
+    def phase_report(self):
+        torch.cuda.synchronize()
+        rows, out = self._phases, {}
+        i = 0
+        while i < len(rows):
+            if rows[i][0] == "start":
+                j = i + 1
+                while j < len(rows) and rows[j][0] != "start":
+                    n = rows[j][0]
+                    g, h = out.setdefault(n, ([], []))
+                    g.append(rows[i][1].elapsed_time(rows[j][1])); h.append(1e3 * (rows[j][2] - rows[i][2]))
+                    j += 1
+                i = j
+            else:
+                i += 1
+        return {k: (sum(g[-10:]) / len(g[-10:]), sum(h[-10:]) / len(h[-10:])) for k, (g, h) in out.items()}
+
+    def _join_deferred(self):
+        """The step is complete (and the parameters may change) only when the deferred rows are done."""
+        if self._rest_done is not None:
+            torch.cuda.current_stream().wait_event(self._rest_done)
+            self._rest_done = None
 
     fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient
 
@@ -169,7 +239,7 @@ class SRConsistencyBase(AlgorithmBase):
         key = (nl, nu, K, bool(self.use_cat))
         if key not in self._plans:
             self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
-                                                lb_every_pass=bool(self.use_cat))
+                                                lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows)
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
@@ -203,7 +273,10 @@ class SRConsistencyBase(AlgorithmBase):
             nl, nu = y_lb.shape[0], x_ulb_w.shape[0]
             imgs = torch.cat((x_lb, x_ulb_w, x_ulb_s)).contiguous()                              # :113
         K = self.sr_decay() if it > self.start_timing else 0                                     # :147, :75
+        ph = self._phase_mark if _PHASES else (lambda name: None)
+        ph("start")
         L, Fe, ctx = self._forward_passes(imgs, nl, nu, K)
+        ph("forward_joined")
         P, C = K + 1, self.num_classes
         # softmax + max/argmax of the weak logits of ALL passes: one launch (compute_prob :135, argmax :142-146)
         Lw = L[:, nl:nl + nu].reshape(P * nu, C)
@@ -234,7 +307,9 @@ class SRConsistencyBase(AlgorithmBase):
             ent_loss, _ = self._fairness(L[0, nl + nu:], masks[0], dl_s)
             dl_all = (dl_lb, dl_s)
         # ---- backbone backward: only the rows with a non-zero upstream gradient (see module docstring)
+        ph("losses")
         self.model.backward(ctx, torch.cat(dl_all))
+        ph("backward")
         # ---- rewarder / generator training (:154-208)
         fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
         if it > 0:
@@ -253,6 +328,9 @@ class SRConsistencyBase(AlgorithmBase):
             total_loss = total_loss + self.lambda_e * ent_loss                                    # srfreematch.py:220
         if self.trace is not None:
             self.trace.update(K=K, masks=masks, max_probs=mp, pseudo=mi, reward=reward, mask2=mask2, logits=L, feats=Fe)
+        ph("sr_update")
+        self._join_deferred()
+        ph("deferred_joined")
         feat_dict = {"x_lb": fx, "x_ulb_w": fw0, "x_ulb_s": Fe[0, nl + nu:]}
         out_dict = self.process_out_dict(loss=total_loss, feat=feat_dict)
         log_dict = self.process_log_dict(sup_loss=DeferredScalar(sup_loss), unsup_loss=DeferredScalar(unsup_loss),
@@ -301,7 +379,7 @@ class SRFlexMatch(SRConsistencyBase):
         return [hook.masking_from_max(self, mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], idx_ulb) for k in range(P)]
 
     def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
-        with ops.stream_scope():
+        with self._step_scope():
             return self._train_step(x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s)
 
     def get_save_dict(self):
@@ -348,7 +426,7 @@ class SRFixMatch(SRConsistencyBase):
         return [m[k * nu:(k + 1) * nu] for k in range(P)]
 
     def train_step(self, x_lb, y_lb, x_ulb_w, x_ulb_s):
-        with ops.stream_scope():
+        with self._step_scope():
             return self._train_step(x_lb, y_lb, None, x_ulb_w, x_ulb_s)
 
     @staticmethod

@@ -51,7 +51,7 @@ class SRFreeMatch(SRConsistencyBase):
         return loss[0], dl
 
     def train_step(self, x_lb, y_lb, x_ulb_w, x_ulb_s):
-        with ops.stream_scope():
+        with self._step_scope():
             return self._train_step(x_lb, y_lb, None, x_ulb_w, x_ulb_s)
 
     def get_save_dict(self):

@@ -49,3 +49,4 @@ extern "C" int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
+

@@ -259,7 +259,7 @@ class ClassificationBert(PostLNEncoderMixin):
         self._ws[key] = c
         return c
 
-    def forward_features(self, tok, seq_index=None, droppath=None, save=False, B=None, seed="auto", tag=""):
+    def forward_features(self, tok, seq_index=None, droppath=None, save=False, B=None, seed="auto", tag="", buftag=""):
         """tok: TokenBatch; seq_index int32 [B] (optional gather of sequences: lets the K+1 passes of one SemiReward step share one
         copy of the tokens).  Returns (logits [B, C], feat [B, D], ctx or None).  ``droppath`` is accepted for interface parity
         with the ViT engine and unused (BERT has no stochastic depth)."""
@@ -274,7 +274,7 @@ class ClassificationBert(PostLNEncoderMixin):
         if tok.seq_len is not None:
             seq_len = tok.seq_len if seq_index is None else tok.seq_len.index_select(0, seq_index.long()).contiguous()
         P = self.p
-        t = "s" if save else "i"
+        t = ("s" if save else "i") + buftag
         dr = (lambda site, p=cfg.p_drop: ops.Drop(seed, site, p) if p > 0 else None) if seed is not None else (lambda site, p=0.0: None)
         ctx = None
         x = self._buf(t + "x", (M, D), f32)

@@ -196,7 +196,7 @@ class VisionTransformer:
         return ctx
 
     # ---- forward ----------------------------------------------------------------------------------
-    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None):
+    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None, buftag=""):
         """img fp32 [n_img, C, H, W]; img_index int32 [B] (optional gather); droppath fp32 [depth,2,B] or None.
         Returns (logits [B,C], feat [B,D], ctx or None)."""
         cfg = self.cfg
@@ -204,7 +204,7 @@ class VisionTransformer:
         B = int(img_index.numel()) if img_index is not None else (B or img.shape[0])
         M = B * N
         f32, bf16 = torch.float32, torch.bfloat16
-        tag = "s" if save else "i"
+        tag = ("s" if save else "i") + buftag        # buftag: a second inference launch train on another stream needs its own workspaces
         ctx = None
         if save:
             ctx = self._ctx_buffers(B)

@@ -318,7 +318,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         return c
 
     # ---- forward ---------------------------------------------------------------------------------------------------
-    def forward_features(self, wave, clip_index=None, droppath=None, save=False, B=None, tag=""):
+    def forward_features(self, wave, clip_index=None, droppath=None, save=False, B=None, tag="", buftag=""):
         """wave fp32 [n, samples]; clip_index int32 [B] (optional gather: the K+1 passes of one SemiReward step share one copy of the
         clips).  Returns (logits [B, C], feat [B, D], ctx or None)."""
         cfg = self.cfg
@@ -327,7 +327,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
             wave = wave.index_select(0, clip_index.long())
         wave = wave.contiguous()
         B, S = wave.shape
-        t = ("s" + tag) if save else "i"
+        t = ("s" + tag) if save else ("i" + buftag)
         f = self._front_buffers(B, S, t, save)
         T, P, Pp = f.T, f.P, f.Pp
         Tn, Pn = T[-1], P[-1]

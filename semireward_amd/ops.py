@@ -626,3 +626,4 @@ def make_group_tn_desc_ld(problems, device):
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
+
