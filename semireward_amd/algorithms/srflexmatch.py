@@ -33,7 +33,7 @@ class _Plan:
     """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
     rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
 
-    def __init__(self, cols_img, grad_cols, device, skip_cols=(), read_cols=None):
+    def __init__(self, cols_img, grad_cols, device, skip_cols=(), read_cols=None, rows_per_col=None):
         """read_cols: the inference columns whose logits / features the step actually READS (weak rows of every pass).  The others are
         computed because the reference computes them (the strong and labelled rows of the passes whose loss is thrown away) -- same
         launches, but nothing waits for them: they run on the second stream behind the gradient rows (``rest``)."""
@@ -42,6 +42,14 @@ class _Plan:
         rset = set(inf_all) if read_cols is None else set(read_cols)
         inf_cols = [c for c in inf_all if c in rset]
         rest_cols = [c for c in inf_all if c not in rset]
+        if rest_cols and rows_per_col:
+            # tile quantisation of the deferred launch: its row-streaming kernels own a CU per 128-row tile (fused MLP: 147 KB of LDS), so
+            # 128 images x 257 tokens = 257 tiles would be TWO rounds on 256 CUs, the second one a single tile.  A few columns more in the
+            # launch that is read anyway bring it back to whole rounds.
+            over = (-(-len(rest_cols) * rows_per_col // 128)) % 256
+            if 0 < over <= 8:
+                nmove = min(-(-over * 128 // rows_per_col), len(rest_cols) - 1)
+                inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
         t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
         self.grad_cols, self.inf_cols, self.rest_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64), t(rest_cols, torch.int64)
         self.grad_img = t([cols_img[c] for c in grad_cols], torch.int32)
@@ -51,7 +59,7 @@ class _Plan:
         self.mixed_cols = self.mixed_img = None      # gradient columns first (forward_mixed), built on first use
 
     @classmethod
-    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False):
+    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False, rows_per_col=None):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
         labelled rows of pass 0 and the strong rows of the last pass.  lb_every_pass=False (use_cat=False, the usb_nlp / usb_audio
         configs): data_generator forwards only x_ulb_s and x_ulb_w (srflexmatch.py:83-90), so the labelled columns of the passes
@@ -62,7 +70,7 @@ class _Plan:
             [K * Bt + j for j in range(nl + nu, Bt)]
         skip = [] if lb_every_pass else [k * Bt + j for k in range(1, K + 1) for j in range(nl)]
         read = [k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)] if defer_unread else None      # the weak rows
-        p = cls(cols_img, grad, device, skip, read)
+        p = cls(cols_img, grad, device, skip, read, rows_per_col)
         p.P, p.Bt = K + 1, Bt
         return p
 
@@ -239,7 +247,8 @@ class SRConsistencyBase(AlgorithmBase):
         key = (nl, nu, K, bool(self.use_cat))
         if key not in self._plans:
             self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
-                                                lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows)
+                                                lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows,
+                                                rows_per_col=getattr(self.model.cfg, "num_tokens", None))
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
