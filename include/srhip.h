@@ -95,6 +95,10 @@ int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 /* dx (fp32) += LN'(dy bf16); dgamma/dbeta (fp32) += column sums (atomic). */
 int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dgamma, float* dbeta, int M, int D, void* stream);
+/* ... and also out_bf16[m, :] = bf16(row_scale[m / rows_per_sample] * dx[m, :]) of the UPDATED dx: the DropPath-scaled output gradient of the
+ * next branch (vit.py:164-165 backward), i.e. srhip_layernorm_bwd + srhip_cast_scale_rows in one launch.  row_scale NULL = 1. */
+int srhip_layernorm_bwd_cast(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                             float* dbeta, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D, void* stream);
 
 /* Fused MLP half of a transformer block on the fp32 residual stream (x -> x_out, both [M, D]; x_out may equal x):
  *   x_out = x + row_scale[m / rows_per_sample] * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) + b2 )

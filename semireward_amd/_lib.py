@@ -25,6 +25,7 @@ SIGNATURES = {
     "srhip_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, F, P]),
     "srhip_layernorm_fwd": (I, [P, P, P, F, P, P, P, I, I, P]),
     "srhip_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P]),
+    "srhip_layernorm_bwd_cast": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "srhip_mlp_fused": (I, [P, P, P, P, F, P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),

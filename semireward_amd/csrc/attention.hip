@@ -237,7 +237,7 @@ constexpr int BWD_NT = 512, BWD_NW = BWD_NT / 64;
 // VG = true (N > 288: K, V and K^T images no longer fit the 160 KB of LDS together): the V row fragments -- plain 16-byte row reads, the
 // A operand of dP = V . dO^T -- come straight from global memory / L2, software-pipelined one key-tile pair ahead.
 template <int NKT, bool VAR, bool VG>
-__global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+__device__ __forceinline__ void attn_bwd_dq_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                          const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                          bf16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                          int N, int H, float scale, AttnVar av) {
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dq_kernel(const bf16_t* __
 // walks query-tile pairs:  S[q][key], dP[q][key] with the KEY on l15 ->
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
 template <int NKT, bool VAR>
-__global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale, AttnVar av) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+                                                  const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
+                                                  bf16_t* __restrict__ dqkv, int N, int H, float scale, AttnVar av) {
   constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]  query-permuted + chunk-swizzled (stage_transposed_perm)
@@ -377,9 +377,23 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
   stage_transposed_perm<NP, BWD_NT>(Qt, base, ld, N, tid);
   stage_transposed_perm<NP, BWD_NT>(dOt, dobase, D, N, tid);
   const int vof = (threadIdx.x & 15) * TP + (((threadIdx.x >> 4 & 3) ^ swz4(threadIdx.x & 15)) << 3);
+  // delta[q] = rowsum(dO[q] * O[q]) is recomputed here (64 MACs per query from rows that are L2-hot) instead of read from the dQ pass: the
+  // two passes then have no dependency and share ONE launch (blockIdx.z picks the role) -- one launch less per layer on a latency-bound
+  // chain, and twice the workgroups for a backward batch that does not fill the chip.
   for (int i = tid; i < NP; i += BWD_NT) {
     lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : INFINITY;
-    dl_s[i] = i < N ? delta[((size_t)b * H + h) * N + i] : 0.f;
+    float dl = 0.f;
+    if (i < N) {
+      const bf16_t* dop = dobase + (size_t)i * D;
+      const bf16_t* op = o_fwd + ((size_t)b * N + i) * D + h * HD;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const s16x8_t a = ld16(dop + c * 8), o8 = ld16(op + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)a[j]) * bf2f((bf16_t)o8[j]);
+      }
+    }
+    dl_s[i] = dl;
   }
   __syncthreads();
   const float sc2 = scale * LOG2E;
@@ -462,6 +476,14 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_dkv_kernel(const bf16_t* _
   }
 }
 
+template <int NKT, bool VAR, bool VG>
+__global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+                                                      const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
+                                                      bf16_t* __restrict__ dqkv, float* __restrict__ delta, int N, int H, float scale, AttnVar av) {
+  if (blockIdx.z == 0) attn_bwd_dq_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
+  else attn_bwd_dkv_body<NKT, VAR>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
+}
+
 template <typename F>
 int dispatch_nkt(int N, F&& f) {
   const int nkt = 2 * ((N + 31) / 32);
@@ -497,19 +519,15 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
     const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
     const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (size_t)2 * NP * 4;
     if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;
-    auto k1 = attn_bwd_dq_kernel<NKT, VAR, VG>;
-    auto k2 = attn_bwd_dkv_kernel<NKT, VAR>;
-    if (sm1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
-    if (sm2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+    auto kern = attn_bwd_kernel<NKT, VAR, VG>;
+    const size_t sm = sm1 > sm2 ? sm1 : sm2;
+    if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     // split query / key tiles over extra workgroups until the grid covers the chip (each split re-stages K/V or Q/dO)
     const int nt16 = (N + 15) / 16;
     int split = 1;
-    while (B * H * split < 256 && split * BWD_NW < nt16) ++split;
-    hipLaunchKernelGGL(k1, dim3(B * H, split), dim3(BWD_NT), sm1, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
+    while (B * H * split * 2 < 256 && split * BWD_NW < nt16) ++split;
+    hipLaunchKernelGGL(kern, dim3(B * H, split, 2), dim3(BWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale, av);
-    SR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k2, dim3(B * H, split), dim3(BWD_NT), sm2, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)d_out, lse,
-                       (const float*)delta_ws, (bf16_t*)dqkv, N, H, scale, av);
     SR_CHECK_LAUNCH();
     return SR_OK;
   });

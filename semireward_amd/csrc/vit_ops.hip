@@ -48,7 +48,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, float* __restrict__ dx,
-                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                    bf16_t* __restrict__ out_bf16, const float* __restrict__ row_scale, int rows_per_sample) {
   constexpr int D = NV * 128;
   __shared__ float red[2][4][D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -86,6 +87,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       o.x += rs * (gy[i].x - c1 - xh[i].x * c2);
       o.y += rs * (gy[i].y - c1 - xh[i].y * c2);
       dxr[i * 64 + lane] = o;
+      // the updated gradient of the residual stream, DropPath-scaled and cast: the dY operand of the next branch's products
+      // (was a separate cast_scale_rows launch after every LayerNorm backward: 24 latency-bound launches per step)
+      if (out_bf16) {
+        const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.0f;
+        reinterpret_cast<uint32_t*>(out_bf16 + (size_t)row * D)[i * 64 + lane] = pack_bf2(o.x * sc, o.y * sc);
+      }
     }
   }
 #pragma unroll
@@ -441,17 +448,28 @@ extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const flo
   return SR_OK;
 }
 
-extern "C" int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                   float* dx, float* dgamma, float* dbeta, int M, int D, void* stream) {
-  if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768)) return SR_EINVAL;
+static int layernorm_bwd_impl(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                              float* dbeta, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D, void* stream) {
+  if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768) || (row_scale && rows_per_sample <= 0)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(M, 32)), block(256);
-  if (D == 128) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
-  else if (D == 512) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
-  else if (D == 384) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
-  else hipLaunchKernelGGL(ln_bwd_kernel<6>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M);
+  const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
+#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M, (bf16_t*)out_bf16, \
+                                   row_scale, rps)
+  if (D == 128) LNB(1); else if (D == 512) LNB(4); else if (D == 384) LNB(3); else LNB(6);
+#undef LNB
   SR_CHECK_LAUNCH();
   return SR_OK;
+}
+extern "C" int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                   float* dx, float* dgamma, float* dbeta, int M, int D, void* stream) {
+  return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, nullptr, nullptr, 0, M, D, stream);
+}
+extern "C" int srhip_layernorm_bwd_cast(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                        float* dgamma, float* dbeta, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D,
+                                        void* stream) {
+  if (!out_bf16) return SR_EINVAL;
+  return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, out_bf16, row_scale, rows_per_sample, M, D, stream);
 }
 
 extern "C" int srhip_patch_embed_fwd(const float* img, const int* img_index, const float* Wp, const float* bp, const float* cls,

@@ -423,24 +423,26 @@ class VisionTransformer:
         T = self._bwd_plan(M, ctx)
         scale = 64 ** -0.5
         dp = ctx.dp
+        ops.cast_scale_rows(dx, dp[cfg.depth - 1, 1] if dp is not None else None, N, T["layers"][cfg.depth - 1]["g2"], M, D)
         for i in reversed(range(cfg.depth)):
             b = "blocks.%d." % i
             Ti = T["layers"][i]
             s1 = dp[i, 0] if dp is not None else None
-            s2 = dp[i, 1] if dp is not None else None
-            # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))))
-            ops.cast_scale_rows(dx, s2, N, Ti["g2"], M, D)
+            # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))));  g2 = bf16(s2 * dx) came from the previous LayerNorm backward
             ops.gemm_nt(ops.EPI_DGELU_BF16, Ti["g2"], self.wT[b + "mlp.fc2.weight"], Ti["dpre"], M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
             ops.gemm_nt(ops.EPI_BF16, Ti["dpre"], self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
-            ops.layernorm_bwd(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
-                              G(b + "norm2.bias"), M, D)
+            ops.layernorm_bwd_cast(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
+                                   G(b + "norm2.bias"), Ti["g1"], s1, N, M, D)
             # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
-            ops.cast_scale_rows(dx, s1, N, Ti["g1"], M, D)
             ops.gemm_nt(ops.EPI_BF16, Ti["g1"], self.wT[b + "attn.proj.weight"], dao, M, D, D)
             ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], Ti["dqkv"], delta, B, N, H, scale)
             ops.gemm_nt(ops.EPI_BF16, Ti["dqkv"], self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
-            ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
-                              G(b + "norm1.bias"), M, D)
+            if i > 0:
+                ops.layernorm_bwd_cast(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
+                                       G(b + "norm1.bias"), T["layers"][i - 1]["g2"], dp[i - 1, 1] if dp is not None else None, N, M, D)
+            else:
+                ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
+                                  G(b + "norm1.bias"), M, D)
         # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
         desc, npb, ntiles, flops, nbytes = T["desc"]
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)

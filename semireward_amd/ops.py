@@ -189,6 +189,11 @@ def layernorm_fwd(x, gamma, beta, eps, out, mean, rstd, M, D):
     _call("srhip_layernorm_fwd", _p(x), _p(gamma), _p(beta), eps, _p(out), _p(mean), _p(rstd), M, D, _s())
 
 
+def layernorm_bwd_cast(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, out_bf16, row_scale, rows_per_sample, M, D):
+    _call("srhip_layernorm_bwd_cast", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(out_bf16), _p(row_scale),
+          rows_per_sample, M, D, _s())
+
+
 def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M, D, Hd, x_out=None, save=None):
     """x_out (default: x, in place; fp32 [M,D]) = x + row_scale * (fc2(gelu(fc1(LN(x)))) + b2), ONE launch.
     save = (rows, ln2, pre, h, mean, rstd): the first ``rows`` rows also get their backward operands written (see srhip.h)."""
