@@ -953,6 +953,62 @@ def gen_trace_free_w2v():
     np.savez_compressed(os.path.join(OUT, "srfreematch_w2v_trace.npz"), **out)
 
 
+def synth_image(seed, H, W, kind):
+    """Seeded uint8 HWC test images: noise, low-contrast texture, gradient + noise (exercise the histogram ops differently)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if kind == 0:
+        return rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    if kind == 1:
+        return np.clip(rng.integers(40, 200, size=(1, 1, 3)) + rng.integers(-30, 30, size=(H, W, 3)), 0, 255).astype(np.uint8)
+    return np.clip(np.linspace(0, 255, W)[None, :, None] * np.ones((H, 1, 3)) + rng.integers(-20, 20, size=(H, W, 3)), 0, 255).astype(np.uint8)
+
+
+def gen_augment():
+    """The reference's own RandAugment functions (randaugment.py, Pillow underneath) on seeded uint8 images: every op at random magnitudes,
+    Cutout with given uniform draws, and whole RandAugment(3, .) chains with the op picks / magnitudes / cutout draws recorded."""
+    import importlib.util
+    from PIL import Image
+    import PIL
+    from oracle import augment_ref as A
+    spec = importlib.util.spec_from_file_location("ref_randaugment", os.path.join(R.REF, "semilearn/datasets/augmentation/randaugment.py"))
+    ra = importlib.util.module_from_spec(spec); spec.loader.exec_module(ra)
+    fns = {n: getattr(ra, n) for n in A.OPS}
+    assert [f.__name__ for f, _, _ in ra.augment_list()] == A.OPS and [(lo, hi) for _, lo, hi in ra.augment_list()] == A.RANGES
+    out = {"meta/pillow_version": np.array(PIL.__version__)}
+    rng = np.random.Generator(np.random.PCG64(2024))
+    sizes = [(32, 32), (96, 96), (24, 40)]
+    recs = []
+    for oi, name in enumerate(A.OPS):
+        lo, hi = A.RANGES[oi]
+        for t in range(4):
+            H, W = sizes[t % 3]
+            seed, kind = 5000 + 10 * oi + t, (oi + t) % 3
+            v = lo + (hi - lo) * float(rng.random())
+            res = np.array(fns[name](Image.fromarray(synth_image(seed, H, W, kind)), v))
+            k = f"op/{oi}/{t}"
+            out[k + "/out"], out[k + "/meta"], out[k + "/v"] = res, np.array([seed, H, W, kind], dtype=np.int64), np.float64(v)
+    orig_uniform = np.random.uniform
+    for t in range(6):
+        H, W = sizes[t % 3]
+        seed = 6000 + t
+        ops = rng.integers(0, len(A.OPS), size=3)
+        vals = [A.RANGES[o][0] + (A.RANGES[o][1] - A.RANGES[o][0]) * float(rng.random()) for o in ops]
+        cut_v, ux, uy = 0.5 * float(rng.random()), float(rng.uniform(0, W)), float(rng.uniform(0, H))
+        img = Image.fromarray(synth_image(seed, H, W, t % 3))
+        for o, v in zip(ops, vals):
+            img = fns[A.OPS[o]](img, v)
+        it = iter([ux, uy])
+        np.random.uniform = lambda w: next(it)
+        try:
+            img = ra.Cutout(img, cut_v)
+        finally:
+            np.random.uniform = orig_uniform
+        k = f"chain/{t}"
+        out[k + "/out"], out[k + "/meta"] = np.array(img), np.array([seed, H, W, t % 3], dtype=np.int64)
+        out[k + "/ops"], out[k + "/vals"], out[k + "/cut"] = ops.astype(np.int64), np.array(vals, dtype=np.float64), np.array([cut_v, ux, uy], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+
+
 def gen_softmatch_hook():
     """DistAlignEMAHook + SoftMatchWeightingHook sequences straight from the reference (both p_target modes)."""
     smu = R.mod("semilearn.algorithms.srsoftmatch.utils")
@@ -1104,7 +1160,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
-            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v)
+            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

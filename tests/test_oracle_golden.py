@@ -548,3 +548,22 @@ def test_srfreematch_w2v_trace(golden):
     for nme, _ in WR.param_shapes(cfg):
         if not nme.endswith("k_proj.bias"):
             check_samp(orc.P[nme].numpy(), g.samp(f"it{tr['its'][-1]}/param/{nme}"), 2e-3, 5e-5, f"param {nme}")
+
+
+def test_augment_oracle_matches_reference(golden):
+    """oracle/augment_ref.py against the reference's RandAugment functions (Pillow underneath): every op, Cutout, whole chains -- bit for bit."""
+    from oracle import augment_ref as A
+    from oracle.gen_golden import synth_image
+    g = golden("augment")
+    for oi, name in enumerate(A.OPS):
+        for t in range(4):
+            seed, H, W, kind = [int(v) for v in g[f"op/{oi}/{t}/meta"]]
+            got = A.apply_op(oi, synth_image(seed, H, W, kind), float(g[f"op/{oi}/{t}/v"]))
+            assert np.array_equal(got, g[f"op/{oi}/{t}/out"]), (name, t)
+    for t in range(6):
+        seed, H, W, kind = [int(v) for v in g[f"chain/{t}/meta"]]
+        x = synth_image(seed, H, W, kind)
+        for o, v in zip(g[f"chain/{t}/ops"], g[f"chain/{t}/vals"]):
+            x = A.apply_op(int(o), x, float(v))
+        cv, ux, uy = [float(v) for v in g[f"chain/{t}/cut"]]
+        assert np.array_equal(A.cutout(x, cv, ux, uy), g[f"chain/{t}/out"]), t
