@@ -333,6 +333,19 @@ int srhip_w2v_pos_finish_bwd(float* dx0, const float* ysave, const float* conv, 
                              const float* gamma, float* dconv, float* dgamma, float* dbeta, int B, int T, int P, int Pp, int D, unsigned drop_key,
                              unsigned drop_thresh, float drop_scale, void* stream);
 
+/* ---- device-side augmentation: semilearn/datasets/cv_datasets/cifar.py:34-49 transform_weak / transform_strong and
+ * semilearn/datasets/augmentation/randaugment.py:16-196, one launch per batch.  src uint8 [n_src, H0, W0, 3]; per output image b a parameter
+ * block ip[b*64..] (int32) / dp[b*32..] (float64):
+ *   ip[0..2] crop offset (row, column) in the reflect-padded image and flip flag; ip[3] number of RandAugment ops (<= 4);
+ *   ip[4..7] Cutout rectangle x0, y0, x1, y1, both ends inclusive (x0 < 0: none); ip[8] source image index;
+ *   op k at ip[16 + 12k]: [0] op id in augment_list() order, [1] 1 = pure translation (float64 walk: dp xo, yo, step x, step y at [1..4]),
+ *   [2..7] the 16.16 fixed-point coefficients a0, a1, a2', a3, a4, a5' of Pillow's nearest-neighbour affine walk, [8] Posterize mask;
+ *   dp[8k] the magnitude.
+ * scratch: 2 * S * S * 3 bytes per image.  out fp32 [B, 3, S, S] = (x / 255 - mean) / std; out_u8 (optional) uint8 [B, S, S, 3] before that.
+ * mean3 / std3: HOST pointers to 3 floats.  Bit-exact with Pillow (12.2.0) for every op. */
+int srhip_augment(const unsigned char* src, int n_src, int H0, int W0, int B, int S, int pad, const int* ip, const double* dp,
+                  unsigned char* scratch, float* out, unsigned char* out_u8, const float* mean3, const float* std3, void* stream);
+
 /* ---- WideResNet building blocks (classic_cv backbone, semilearn/nets/wrn/wrn.py; BASELINE.json configs[0], parity configuration) ----
  * Feature maps are NHWC = row-major [rows = B*H*W, C].  conv = im2col (bf16) + srhip_gemm_nt; dW = srhip_gemm_tn_grouped_f32(dY, col);
  * dX = srhip_gemm_nt(dY, W^T) + col2im.

@@ -88,6 +88,7 @@ SIGNATURES = {
     "srhip_gelu_bwd_f32": (I, [P, P, P, L, P]),
     "srhip_mask_lengths": (I, [P, I, P, I, I, P]),
     "srhip_dropout_cast": (I, [P, P, L, U, U, F, P]),
+    "srhip_augment": (I, [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P]),
     "srhip_gemm_nt_dropout": (I, [I, P, I, P, I, P, I, I, I, I, P, P, P, I, U, U, F, P]),
     "srhip_w2v_conv0": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "srhip_w2v_conv_weight_prep": (I, [P, P, P, I, I, I, P]),
