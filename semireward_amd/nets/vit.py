@@ -130,6 +130,23 @@ class VisionTransformer:
                 raise KeyError(n)
         self.refresh_operands()
 
+    def init_weights(self, seed=0):
+        """The reference VisionTransformer has no init function: torch defaults -- nn.Linear / Conv2d kaiming_uniform(a = sqrt 5) =
+        U(+-1/sqrt(fan_in)) for weight and bias, LayerNorm 1 / 0, cls_token and pos_embed zeros (vit.py:241-244)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        sd, fan = {}, {}
+        for n, s_ in self.names_shapes:
+            if n in ("cls_token", "pos_embed"):
+                sd[n] = torch.zeros(s_)
+            elif "norm" in n.split(".")[-2]:
+                sd[n] = torch.ones(s_) if n.endswith("weight") else torch.zeros(s_)
+            else:
+                if n.endswith("weight"):
+                    fan[n[:-7]] = int(torch.Size(s_[1:]).numel())
+                bound = 1.0 / (fan[n.rsplit(".", 1)[0]] ** 0.5)
+                sd[n] = (torch.rand(s_, generator=g) * 2 - 1) * bound
+        self.load_state_dict(sd)
+
     def refresh_operands(self):
         """bf16 operand copy of the whole block + transposed GEMM weights (after any parameter change)."""
         ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
@@ -469,7 +486,9 @@ class VisionTransformer:
 def _build(num_classes, kw, **cfg):
     kw = {k: v for k, v in kw.items() if k not in ("pretrained", "pretrained_path")}
     device = kw.pop("device", "cuda")
-    return VisionTransformer(VitConfig(num_classes=num_classes, **cfg), device=device)
+    m = VisionTransformer(VitConfig(num_classes=num_classes, **cfg), device=device)
+    m.init_weights(kw.pop("seed", 0))
+    return m
 
 
 def vit_tiny_test(num_classes=10, **kw):

@@ -109,6 +109,25 @@ class WideResNet:
                 self.buffers[k].copy_(torch.as_tensor(sd[k]).to(self.device))
         self.refresh_operands()
 
+    def init_weights(self, seed=0):
+        """wrn.py:108-117: Conv2d kaiming_normal(fan_out, leaky_relu: gain sqrt(2 / (1 + 0.01^2))), BatchNorm 1 / 0, Linear xavier_normal
+        with zero bias; conv1.bias keeps torch's default U(+-1/sqrt(fan_in))."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        sd = {}
+        for n, s_ in self.names_shapes:
+            if len(s_) == 4:
+                fan_out = s_[0] * s_[2] * s_[3]
+                sd[n] = torch.randn(s_, generator=g) * ((2.0 / (1.0 + 0.01 ** 2)) ** 0.5 / fan_out ** 0.5)
+            elif len(s_) == 2:
+                sd[n] = torch.randn(s_, generator=g) * (2.0 / (s_[0] + s_[1])) ** 0.5
+            elif ".bn" in n or n.startswith("bn"):
+                sd[n] = torch.ones(s_) if n.endswith("weight") else torch.zeros(s_)
+            elif n == "conv1.bias":
+                sd[n] = (torch.rand(s_, generator=g) * 2 - 1) / 27 ** 0.5
+            else:
+                sd[n] = torch.zeros(s_)
+        self.load_state_dict(sd, strict=False)
+
     def refresh_operands(self):
         for n, c in self.convs.items():
             ops.conv_weight_prep(self.p(n), c["Wb"], c["WbT"], c["cout"], c["K"], c["Kp"])
@@ -293,8 +312,12 @@ class WideResNet:
 
 def wrn_28_2(num_classes=100, **kw):
     kw = {k: v for k, v in kw.items() if k not in ("pretrained", "pretrained_path")}
-    return WideResNet(num_classes=num_classes, depth=28, widen_factor=2, first_stride=1, **kw)        # wrn.py:151-155
+    m = WideResNet(num_classes=num_classes, depth=28, widen_factor=2, first_stride=1, **kw)           # wrn.py:151-155
+    m.init_weights()
+    return m
 
 
 def wrn_tiny_test(num_classes=10, **kw):
-    return WideResNet(num_classes=num_classes, depth=10, widen_factor=2, first_stride=1, **kw)
+    m = WideResNet(num_classes=num_classes, depth=10, widen_factor=2, first_stride=1, **kw)
+    m.init_weights()
+    return m
