@@ -34,6 +34,9 @@ class DataParallel:
         if self.active:
             for m in modules:
                 dist.broadcast(m.flat, src=0)
+                for fn in ("refresh_operands", "prepare"):            # derived copies (bf16 / transposed operands) follow the parameters
+                    if hasattr(m, fn):
+                        getattr(m, fn)()
 
     def gather_stats(self, max_probs, colsum, hist):
         """FreeMatch / SoftMatch statistics of the GLOBAL batch: the reference all-gathers [Bu, C] probabilities
