@@ -299,7 +299,8 @@ int srhip_gemm_nt_dropout(int epilogue, const void* A, int lda, const void* B, i
  *                          channel), zeroed by the caller); 1: out bf16 [B*P0, C]; 2: backward statistics into ws2 from dY (bf16, d/d out),
  *                          dgamma +=, dbeta +=; 3: dW0 [C, k] +=
  *   w2v_conv_weight_prep : Conv1d filter fp32 [Cout, Cin, k] -> bf16 Wr [Cout, k*Cin] (tap-major) and WrT [k*Cin, Cout]; wgrad_add: the inverse
- *                          permutation, dW += dWr
+ *                          permutation, dW += sum of the n_part partial products dWr [n_part, Cout, k*Cin] (the weight-gradient product is
+ *                          split over the frames to fill the chip)
  *   w2v_col2im_dgelu     : adjoint of the overlapping-row read: dpre_prev = GELU'(pre_prev) * fold(dcol)   (pre_prev NULL: no GELU factor)
  *   w2v_featln_fwd/bwd   : feature_projection.layer_norm on the bf16 conv output; the backward also applies GELU'(pre) of the last conv layer
  *   w2v_spec_mask_fwd/bwd: masked frames <- masked_spec_embed; backward: dx (+= add, the positional-conv input gradient with pitch Padd),
@@ -314,7 +315,7 @@ int srhip_w2v_conv0(int mode, const float* wave, const float* W0, const float* g
                     const void* dY, float* dW0, float* dgamma, float* dbeta, int B, int S, int T0, int P0, int C, int k, int stride, float eps,
                     void* stream);
 int srhip_w2v_conv_weight_prep(const float* W, void* Wr, void* WrT, int Cout, int Cin, int k, void* stream);
-int srhip_w2v_conv_wgrad_add(const float* dWr, float* dW, int Cout, int Cin, int k, void* stream);
+int srhip_w2v_conv_wgrad_add(const float* dWr, float* dW, int Cout, int Cin, int k, int n_part, void* stream);
 int srhip_w2v_col2im_dgelu(const void* dcol, const void* pre_prev, void* out, int B, int Pl, int Pprev, int C, int k, int stride, void* stream);
 int srhip_w2v_featln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* out, float* mean, float* rstd, int B, int T, int P,
                          int C, void* stream);

@@ -92,7 +92,7 @@ SIGNATURES = {
     "srhip_gemm_nt_dropout": (I, [I, P, I, P, I, P, I, I, I, I, P, P, P, I, U, U, F, P]),
     "srhip_w2v_conv0": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "srhip_w2v_conv_weight_prep": (I, [P, P, P, I, I, I, P]),
-    "srhip_w2v_conv_wgrad_add": (I, [P, P, I, I, I, P]),
+    "srhip_w2v_conv_wgrad_add": (I, [P, P, I, I, I, I, P]),
     "srhip_w2v_col2im_dgelu": (I, [P, P, P, I, I, I, I, I, I, P]),
     "srhip_w2v_featln_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, P]),
     "srhip_w2v_featln_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -107,11 +107,17 @@ __global__ __launch_bounds__(256) void conv_w_prep_kernel(const float* __restric
   Wr[(size_t)co * k * Cin + (size_t)j * Cin + ci] = v;
   WrT[((size_t)j * Cin + ci) * Cout + co] = v;
 }
-__global__ __launch_bounds__(256) void conv_wgrad_add_kernel(const float* __restrict__ dWr, float* __restrict__ dW, int Cout, int Cin, int k) {
+// n_part partial products (split over the token dimension: a 512 x 1536 weight gradient is 48 tiles, far too few for 256 CUs when the
+// reduction runs over 100 000 frames) are summed on the way
+__global__ __launch_bounds__(256) void conv_wgrad_add_kernel(const float* __restrict__ dWr, float* __restrict__ dW, int Cout, int Cin, int k,
+                                                            int n_part) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)Cout * Cin * k;
   if (i >= n) return;
   const int j = (int)(i % k), ci = (int)((i / k) % Cin), co = (int)(i / ((long)k * Cin));
-  dW[i] += dWr[(size_t)co * k * Cin + (size_t)j * Cin + ci];
+  const size_t src = (size_t)co * k * Cin + (size_t)j * Cin + ci;
+  float a = 0.f;
+  for (int s = 0; s < n_part; ++s) a += dWr[(size_t)s * n + src];
+  dW[i] += a;
 }
 
 // adjoint of the overlapping-row read of a stride-s k-tap conv + (optionally) the GELU of the layer below:
@@ -477,9 +483,9 @@ extern "C" int srhip_w2v_conv_weight_prep(const float* W, void* Wr, void* WrT, i
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
-extern "C" int srhip_w2v_conv_wgrad_add(const float* dWr, float* dW, int Cout, int Cin, int k, void* stream) {
-  if (!dWr || !dW || Cout <= 0 || Cin <= 0 || k <= 0) return SR_EINVAL;
-  W2V_LAUNCH1D(conv_wgrad_add_kernel, (long)Cout * Cin * k, dWr, dW, Cout, Cin, k);
+extern "C" int srhip_w2v_conv_wgrad_add(const float* dWr, float* dW, int Cout, int Cin, int k, int n_part, void* stream) {
+  if (!dWr || !dW || Cout <= 0 || Cin <= 0 || k <= 0 || n_part <= 0) return SR_EINVAL;
+  W2V_LAUNCH1D(conv_wgrad_add_kernel, (long)Cout * Cin * k, dWr, dW, Cout, Cin, k, n_part);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

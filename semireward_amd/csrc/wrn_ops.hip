@@ -182,14 +182,13 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ f
   s = wave_sum(s);
   if (lane == 0) logits[(size_t)b * K + k] = s + bc[k];
 }
-// dfeat[b][f] = sum_k dlogits[b][k] Wc[k][f]        (grid = B)
+// dfeat[b][f] = sum_k dlogits[b][k] Wc[k][f]        (grid = (B, ceil(F / 128)): one column per thread, rows of Wc read coalesced)
 __global__ void fc_bwd_x_kernel(const float* __restrict__ dl, const float* __restrict__ Wc, float* __restrict__ dfeat, int F, int K) {
-  const int b = blockIdx.x;
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) s += dl[(size_t)b * K + k] * Wc[(size_t)k * F + f];
-    dfeat[(size_t)b * F + f] = s;
-  }
+  const int b = blockIdx.x, f = blockIdx.y * 128 + threadIdx.x;
+  if (f >= F) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += dl[(size_t)b * K + k] * Wc[(size_t)k * F + f];
+  dfeat[(size_t)b * F + f] = s;
 }
 // dWc[k][f] += sum_b dlogits[b][k] feat[b][f];  dbc[k] += sum_b dlogits[b][k]      (grid = K)
 __global__ void fc_bwd_w_kernel(const float* __restrict__ dl, const float* __restrict__ feat, float* __restrict__ dWc, float* __restrict__ dbc, int B,
@@ -331,7 +330,7 @@ extern "C" int srhip_fc_fwd(const float* feat, const float* Wc, const float* bc,
 extern "C" int srhip_fc_bwd(const float* dlogits, const float* feat, const float* Wc, float* dfeat, float* dWc, float* dbc, int B, int F, int K,
                             void* stream) {
   if (!dlogits || !feat || !Wc || !dfeat || !dWc || !dbc || B <= 0 || F <= 0 || K <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, dlogits, Wc, dfeat, F, K);
+  hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(B, cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, dlogits, Wc, dfeat, F, K);
   SR_CHECK_LAUNCH();
   hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, dlogits, feat, dWc, dbc, B, F, K);
   SR_CHECK_LAUNCH();

@@ -425,10 +425,19 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         t.dpre = [None] + [torch.zeros(B * P[l] + 16, C, dtype=bf16, device=dev) for l in range(1, nl)]
         t.dY0 = torch.zeros(B * P[0] + 16, C, dtype=bf16, device=dev)
         t.dcol = [None] + [torch.empty(B * P[l], cfg.conv_kernel[l] * C, dtype=bf16, device=dev) for l in range(1, nl)]
-        t.dWr = [None] + [torch.empty(C, cfg.conv_kernel[l] * C, dtype=f32, device=dev) for l in range(1, nl)]
-        t.conv_dw = [None] + [ops.make_group_tn_desc_ld(
-            [(ops._pa(t.dpre[l]), C, ops._pa(f.act[l - 1]), cfg.conv_stride[l] * C, ops._pa(t.dWr[l]), cfg.conv_kernel[l] * C, 0,
-              C, cfg.conv_kernel[l] * C, B * P[l])], dev) for l in range(1, nl)]
+        # weight gradients of the conv layers 1..: ONE grouped launch, the reduction over the frames split into chunks of CH rows (a
+        # 512 x 1536 product is 48 tiles; at 100 000 frames it would run on 48 CUs for a millisecond) -> partial products, summed by wgrad_add
+        CH = 12800
+        t.dW_parts = [0] + [-(-(B * P[l]) // CH) for l in range(1, nl)]
+        t.dWr = [None] + [torch.empty(t.dW_parts[l], C, cfg.conv_kernel[l] * C, dtype=f32, device=dev) for l in range(1, nl)]
+        probs = []
+        for l in range(1, nl):
+            kk, ss, R = cfg.conv_kernel[l], cfg.conv_stride[l], B * P[l]
+            for c_ in range(t.dW_parts[l]):
+                r0 = c_ * CH
+                probs.append((ops._pa(t.dpre[l], r0 * C), C, ops._pa(f.act[l - 1], r0 * ss * C), ss * C, ops._pa(t.dWr[l], c_ * C * kk * C), kk * C, 0,
+                              C, kk * C, min(CH, R - r0)))
+        t.conv_dw = ops.make_group_tn_desc_ld(probs, dev)
         t.ws2 = torch.zeros(B, C, 2, dtype=torch.float64, device=dev)
         self._ws[key] = t
         return t
@@ -468,11 +477,12 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         # ---- conv layers n-1 .. 1: dW from the overlapping-row operand, dX through the transposed filter + fold
         for l in range(nl - 1, 0, -1):
             kk, ss = cfg.conv_kernel[l], cfg.conv_stride[l]
-            desc, npb, ntiles, flops, nbytes = t.conv_dw[l]
-            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes)
-            ops.w2v_conv_wgrad_add(t.dWr[l], G(FE + "%d.conv.weight" % l), C, C, kk)
             ops.gemm_nt(ops.EPI_BF16, t.dpre[l], self.conv_w[l][1], t.dcol[l], B * P[l], kk * C, C)
             ops.w2v_col2im_dgelu(t.dcol[l], f.pre[l - 1] if l > 1 else None, t.dpre[l - 1] if l > 1 else t.dY0, B, P[l], P[l - 1], C, kk, ss)
+        desc, npb, ntiles, flops, nbytes = t.conv_dw
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes)
+        for l in range(1, nl):
+            ops.w2v_conv_wgrad_add(t.dWr[l], G(FE + "%d.conv.weight" % l), C, C, cfg.conv_kernel[l], t.dW_parts[l])
         # ---- conv layer 0 + GroupNorm
         t.ws2.zero_()
         k0, s0 = cfg.conv_kernel[0], cfg.conv_stride[0]

@@ -561,8 +561,8 @@ def w2v_conv_weight_prep(W, Wr, WrT, Cout, Cin, k):
     _call("srhip_w2v_conv_weight_prep", _p(W), _p(Wr), _p(WrT), Cout, Cin, k, _s())
 
 
-def w2v_conv_wgrad_add(dWr, dW, Cout, Cin, k):
-    _call("srhip_w2v_conv_wgrad_add", _p(dWr), _p(dW), Cout, Cin, k, _s())
+def w2v_conv_wgrad_add(dWr, dW, Cout, Cin, k, n_part=1):
+    _call("srhip_w2v_conv_wgrad_add", _p(dWr), _p(dW), Cout, Cin, k, n_part, _s())
 
 
 def w2v_col2im_dgelu(dcol, pre_prev, out, B, Pl, Pprev, C, k, stride):
