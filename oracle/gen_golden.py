@@ -500,6 +500,11 @@ def gen_vit_p16():
     gen_vit([("small_p16_224", V.VIT_SMALL_P16_224, 100, 6, 53)], "vit_p16.npz")
 
 
+def gen_vit_b16_96():
+    """ViT-B/16 at 96x96 (vit.py:374-390 vit_base_patch16_96, the backbone of 8 config/SemiReward/usb_cv yamls): 37 tokens, D = 768."""
+    gen_vit([("base_p16_96", V.VIT_BASE_P16_96, 10, 5, 54)], "vit_b16_96.npz")
+
+
 # ------------------------------------------------------------------------------------------------
 def gen_optim():
     bu = R.mod("semilearn.core.utils.build")
@@ -1160,7 +1165,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
 GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
-            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment)
+            bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment, vit_b16_96=gen_vit_b16_96)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -35,6 +35,7 @@ class VitCfg:
 VIT_SMALL_P2_32 = dict(img_size=32, patch_size=2, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)
 VIT_SMALL_P16_224 = dict(img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)   # vit.py:358-371
 VIT_SMALL_P16_224 = dict(img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)
+VIT_BASE_P16_96 = dict(img_size=96, patch_size=16, embed_dim=768, depth=12, num_heads=12, drop_path_rate=0.2)      # vit.py:374-390
 VIT_TINY_TEST = dict(img_size=8, patch_size=2, embed_dim=128, depth=2, num_heads=2, drop_path_rate=0.2)
 
 

@@ -500,6 +500,11 @@ def vit_small_patch16_224(num_classes=1000, **kw):
     return _build(num_classes, kw, img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)
 
 
+def vit_base_patch16_96(num_classes=1000, **kw):
+    """vit.py:374-390: ViT-B/16 on 96x96 images, 37 tokens (the stl10 / eurosat-style usb_cv configs)."""
+    return _build(num_classes, kw, img_size=96, patch_size=16, embed_dim=768, depth=12, num_heads=12, drop_path_rate=0.2)
+
+
 def vit_small_patch2_32(num_classes=1000, **kw):
     return _build(num_classes, kw, img_size=32, patch_size=2, embed_dim=384, depth=12, num_heads=6, drop_path_rate=0.2)
 

@@ -27,12 +27,14 @@ def build(tag):
         return vit.vit_tiny_test(num_classes=10, device=DEV), V.VitCfg(num_classes=10, **V.VIT_TINY_TEST)
     if tag == "small_p16_224":
         return vit.vit_small_patch16_224(num_classes=100, device=DEV), V.VitCfg(num_classes=100, **V.VIT_SMALL_P16_224)
+    if tag == "base_p16_96":
+        return vit.vit_base_patch16_96(num_classes=10, device=DEV), V.VitCfg(num_classes=10, **V.VIT_BASE_P16_96)
     return vit.vit_small_patch2_32(num_classes=100, device=DEV), V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "small_p2_32", "small_p16_224"])
+@pytest.mark.parametrize("tag", ["tiny", "small_p2_32", "small_p16_224", "base_p16_96"])
 def test_vit_matches_reference_golden(golden, tag):
-    g = golden("vit_p16" if tag == "small_p16_224" else "vit")
+    g = golden({"small_p16_224": "vit_p16", "base_p16_96": "vit_b16_96"}.get(tag, "vit"))
     C, B, seed = [int(v) for v in g[f"{tag}/meta"]]
     model, cfg = build(tag)
     assert [n for n, _ in model.names_shapes] == [n for n, _ in V.param_shapes(cfg)]
@@ -49,7 +51,7 @@ def test_vit_matches_reference_golden(golden, tag):
     # train mode, injected DropPath, save + no-save paths agree bit for bit
     lg2, ft2, ctx = model.forward_features(x, None, dp, save=True)
     lg3, ft3, _ = model.forward_features(x, None, dp, save=False)
-    if tag == "tiny":
+    if tag in ("tiny", "base_p16_96"):           # no fused-MLP path at these widths: the same kernels, the same bits
         assert torch.equal(lg2, lg3) and torch.equal(ft2, ft3)
     else:   # ViT-S width: rows without a backward take the fused LN2+MLP kernel (same rounding points, other fp32 sum order)
         assert rel(lg3.cpu(), lg2.cpu().numpy()) < 4e-3 and rel(ft3.cpu(), ft2.cpu().numpy()) < 4e-3

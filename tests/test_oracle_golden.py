@@ -91,9 +91,9 @@ def test_losses(golden, tag):
     np.testing.assert_allclose(l2.grad.numpy(), g[f"{tag}/unsup_grad"], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("tag,cfgd", [("tiny", V.VIT_TINY_TEST), ("small_p2_32", V.VIT_SMALL_P2_32)])
+@pytest.mark.parametrize("tag,cfgd", [("tiny", V.VIT_TINY_TEST), ("small_p2_32", V.VIT_SMALL_P2_32), ("base_p16_96", V.VIT_BASE_P16_96)])
 def test_vit_forward_backward(golden, tag, cfgd):
-    g = golden("vit")
+    g = golden("vit_b16_96" if tag == "base_p16_96" else "vit")
     C, B, seed = [int(v) for v in g[f"{tag}/meta"]]
     cfg = V.VitCfg(num_classes=C, **cfgd)
     P = TP(synth.synth_params(V.param_shapes(cfg), seed))
