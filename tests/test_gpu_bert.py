@@ -280,3 +280,69 @@ def test_srsoftmatch_bert_trace(golden):
     assert worst < 4e-3, worst                         # <= a handful of lr-sized (5e-4) steps
     pool = alg.model.view("bert.pooler.dense.weight").cpu().numpy()
     assert np.array_equal(pool, trace_bert_params(cfg, seed, tr["head_gain"])["bert.pooler.dense.weight"])   # never touched (grad None in the reference)
+
+
+def test_full_size_step_properties_bert():
+    """BASELINE.json configs[3] at FULL size (bert-base, 8/8/8 sequences of 512 tokens, K = sr_decay() = 8, train-mode dropout on): the CPU
+    oracle cannot step this in seconds, so parity goes through size-independent properties --
+      * the SoftMatch weights of all 9 passes equal the oracle's SoftMatchState fed with the engine's own max-probs of each pass (sequential
+        EMA state), the reward mask2 == (reward >= per-pass mean), util_ratio = mean(mask0);
+      * K = 8 passes, 8 + 9 * 16 sequence forwards, labelled rows only in pass 0 (use_cat False), finite losses;
+      * the step is reproducible: same state + same inputs + same dropout seeds -> identical logits (deferred rows included);
+      * the pooler never moves."""
+    import argparse
+    from oracle import hooks_ref as H
+    from semireward_amd.algorithms import get_algorithm
+    C, L, nl, nu = 4, 512, 8, 8
+    args = dict(algorithm="srsoftmatch", num_classes=C, num_train_iter=102400, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False, amp=False,
+                optim="AdamW", lr=5e-5, weight_decay=5e-4, layer_decay=0.65, num_warmup_iter=5120, T=0.5, hard_label=True, ema_p=0.999, n_sigma=2,
+                dist_uniform=True, dist_align=True, per_class=False, ulb_dest_len=50000, N_k=10, start_timing=10000, feature_dim=768, sr_lr=5e-4,
+                sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    g = torch.Generator().manual_seed(5)
+    def tok(n, full):
+        lens = torch.full((n,), L) if full else torch.randint(L // 2, L + 1, (n,), generator=g)
+        lens[0] = L
+        mask = (torch.arange(L)[None] < lens[:, None]).long()
+        return {"input_ids": torch.randint(1, 30522, (n, L), generator=g) * mask, "attention_mask": mask}
+    batch = dict(x_lb=tok(nl, True), y_lb=torch.randint(0, C, (nl,), generator=g), x_ulb_w=tok(nu, False), x_ulb_s=tok(nu, False))
+    runs = []
+    for _ in range(2):
+        alg = get_algorithm(argparse.Namespace(**args), bert.bert_base_uncased)
+        alg.model.view("classifier.2.weight").mul_(8.0); alg.model.refresh_operands()          # spread the max-probs (random-init head is flat)
+        alg.it = 90001
+        alg.optimizer.sched_step = alg.it
+        alg.model.seed, alg.model._rng_calls = 77, 0
+        alg.trace = {}
+        pool0 = alg.model.view("bert.pooler.dense.weight").clone()
+        out, log = alg.train_step(**alg.process_batch(**batch))
+        alg.out_dict, alg.log_dict = out, log
+        alg.call_hook("after_train_step")
+        torch.cuda.synchronize()
+        runs.append((alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}, pool0))
+    alg, out, log, tr, pool0 = runs[0]
+    K = tr["K"]
+    assert K == 8 and tr["logits"].shape[:2] == (9, 24)
+    st = H.SoftMatchState(C, 2, 0.999)
+    da = H.DistAlignState(C, 0.999, "uniform")
+    mp = tr["max_probs"].cpu().numpy().reshape(9, nu)
+    Lw = tr["logits"][:, nl:nl + nu].float().cpu()
+    for k in range(9):
+        probs = torch.softmax(Lw[k], -1)
+        if k == 0:                                                  # pass 0 weights the distribution-aligned probabilities
+            probs = da.dist_align(probs, None)
+        want = st.masking(probs).numpy()
+        np.testing.assert_allclose(tr["masks"][k].cpu().numpy(), want, rtol=0, atol=2e-4)
+    r = tr["reward"].cpu().numpy().reshape(K, nu)
+    rm = r.mean(axis=1, keepdims=True, dtype=np.float32)
+    far = np.abs(r - rm) > 1e-6           # rows with one pseudo label share one reward (the feature enters only through the batch context, A.4):
+    m2 = tr["mask2"].cpu().numpy().reshape(K, nu)                          # exact ties with the mean are decided by the summation order
+    assert np.array_equal(m2[far], (r >= rm).astype(np.float32)[far]) and set(np.unique(m2)) <= {0.0, 1.0}
+    assert float(log["train/util_ratio"]) == pytest.approx(float(tr["masks"][0].mean()), abs=1e-6)
+    assert all(np.isfinite(float(log["train/" + k_])) for k_ in ("sup_loss", "unsup_loss", "total_loss"))
+    assert abs(mp.mean() - 0.5) < 0.45 and mp.std() > 1e-3          # the scoring saw non-degenerate probabilities
+    tr2 = runs[1][3]
+    assert torch.equal(tr["logits"][:, nl:], tr2["logits"][:, nl:]) and torch.equal(tr["logits"][0], tr2["logits"][0])
+    assert torch.equal(alg.model.view("bert.pooler.dense.weight"), pool0)
+    # ... and the AdamW step lands on the same parameters up to the fp32 atomics of the gradient column sums (order-dependent round-off that Adam
+    # turns into at most a sign flip of one lr-sized step for gradients at the noise floor)
+    assert float((alg.model.flat - runs[1][0].model.flat).abs().max()) <= 2.1 * 5e-5

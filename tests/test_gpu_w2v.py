@@ -140,3 +140,53 @@ def test_srfreematch_w2v_trace(golden):
         a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
         worst = max(worst, float(np.abs(a - gs["sample"]).max()))
     assert worst < 4e-3, worst
+
+
+def test_full_size_step_properties_hubert():
+    """BASELINE.json configs[4] at FULL size (hubert-base, 8/8/8 clips of 64000 samples -> 199 frames, K = 8, train-mode dropout / SpecAugment /
+    LayerDrop on): size-independent properties -- SoftMatch weights of all 9 passes equal the oracle's SoftMatchState fed with the engine's own
+    max-probs, mask2 == (reward >= per-pass mean) away from ties, finite losses, and the step is reproducible (same seeds -> same logits)."""
+    import argparse
+    from oracle import hooks_ref as H
+    from semireward_amd.algorithms import get_algorithm
+    from semireward_amd.nets import hubert
+    C, S, nl, nu = 10, 64000, 8, 8
+    args = dict(algorithm="srsoftmatch", num_classes=C, num_train_iter=102400, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False, amp=False,
+                optim="AdamW", lr=5e-5, weight_decay=5e-4, layer_decay=0.75, num_warmup_iter=5120, T=0.5, hard_label=True, ema_p=0.999, n_sigma=2,
+                dist_uniform=True, dist_align=True, per_class=False, ulb_dest_len=50000, N_k=10, start_timing=10000, feature_dim=768, sr_lr=5e-4,
+                sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    g = torch.Generator().manual_seed(6)
+    batch = dict(x_lb=torch.randn(nl, S, generator=g), y_lb=torch.randint(0, C, (nl,), generator=g), x_ulb_w=torch.randn(nu, S, generator=g),
+                 x_ulb_s=torch.randn(nu, S, generator=g))
+    runs = []
+    for _ in range(2):
+        alg = get_algorithm(argparse.Namespace(**args), hubert.hubert_base)
+        alg.model.view("classifier.2.weight").mul_(8.0); alg.model.refresh_operands()
+        alg.it = 90001
+        alg.optimizer.sched_step = alg.it
+        alg.model.seed, alg.model._rng_calls = 78, 0
+        alg.trace = {}
+        out, log = alg.train_step(**alg.process_batch(**batch))
+        alg.out_dict, alg.log_dict = out, log
+        alg.call_hook("after_train_step")
+        torch.cuda.synchronize()
+        runs.append((alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}))
+    alg, out, log, tr = runs[0]
+    K = tr["K"]
+    assert K == 8 and tr["logits"].shape[:2] == (9, 24)
+    st, da = H.SoftMatchState(C, 2, 0.999), H.DistAlignState(C, 0.999, "uniform")
+    Lw = tr["logits"][:, nl:nl + nu].float().cpu()
+    for k in range(9):
+        probs = torch.softmax(Lw[k], -1)
+        if k == 0:
+            probs = da.dist_align(probs, None)
+        np.testing.assert_allclose(tr["masks"][k].cpu().numpy(), st.masking(probs).numpy(), rtol=0, atol=2e-4)
+    r = tr["reward"].cpu().numpy().reshape(K, nu)
+    rm = r.mean(axis=1, keepdims=True, dtype=np.float32)
+    far = np.abs(r - rm) > 1e-6
+    m2 = tr["mask2"].cpu().numpy().reshape(K, nu)
+    assert np.array_equal(m2[far], (r >= rm).astype(np.float32)[far]) and set(np.unique(m2)) <= {0.0, 1.0}
+    assert all(np.isfinite(float(log["train/" + k_])) for k_ in ("sup_loss", "unsup_loss", "total_loss"))
+    tr2 = runs[1][3]
+    assert torch.equal(tr["logits"][:, nl:], tr2["logits"][:, nl:]) and torch.equal(tr["logits"][0], tr2["logits"][0])
+    assert float((alg.model.flat - runs[1][0].model.flat).abs().max()) <= 2.1 * 5e-5
