@@ -15,7 +15,7 @@ class ClassificationHubert(ClassificationWave2Vec):
                     blocks=r"^{}model.encoder.layers.(\d+)".format(prefix))
 
     def layer_ids(self):
-        ids, lmax = super().layer_ids()
+        ids, lmax = ClassificationWave2Vec.layer_ids(self)
         for n in ids:
             if n.startswith(M_ + "encoder.pos_conv_embed"):
                 ids[n] = 0

@@ -138,3 +138,67 @@ def test_classification_metrics_match_sklearn():
         assert m["precision"] == pytest.approx(precision_score(yt, yp, average="macro", zero_division=0))
         assert m["recall"] == pytest.approx(recall_score(yt, yp, average="macro", zero_division=0))
         assert m["F1"] == pytest.approx(f1_score(yt, yp, average="macro", zero_division=0))
+
+
+def test_plan_defers_only_unread_rows():
+    """Row bookkeeping of one step: gradient rows, rows that are read (weak rows of every pass), rows nothing reads (deferred to the second
+    stream), rows never computed (labelled rows of passes >= 1 under use_cat False); the deferred launch is sized to whole rounds of row tiles."""
+    from semireward_amd.algorithms.srflexmatch import _Plan
+    nl, nu, K = 8, 8, 8
+    Bt = nl + 2 * nu
+    p = _Plan.cat_passes(nl, nu, K, "cpu", defer_unread=True, rows_per_col=257)
+    grad, read, rest = set(p.grad_cols.tolist()), set(p.inf_cols.tolist()), set(p.rest_cols.tolist())
+    assert grad == set(range(nl)) | {K * Bt + j for j in range(nl + nu, Bt)}
+    assert grad | read | rest == set(range((K + 1) * Bt)) and not (grad & read) and not (read & rest) and not (grad & rest)
+    weak = {k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)}
+    assert weak <= read and len(read - weak) == 1                 # 128 x 257 rows = 257 tiles -> one column moves so that 255 tiles remain
+    assert -(-len(rest) * 257 // 128) <= 256
+    q = _Plan.cat_passes(nl, nu, K, "cpu", lb_every_pass=False, defer_unread=True)
+    done = set(q.grad_cols.tolist()) | set(q.inf_cols.tolist()) | set(q.rest_cols.tolist())
+    assert done == set(range((K + 1) * Bt)) - {k * Bt + j for k in range(1, K + 1) for j in range(nl)}          # use_cat False: no x_lb after pass 0
+    r = _Plan.cat_passes(nl, nu, K, "cpu")                          # no deferral: every inference column is "read"
+    assert r.rest_cols.numel() == 0 and r.inf_cols.numel() == (K + 1) * Bt - 2 * nl
+
+
+def test_host_side_random_inputs_match_oracle():
+    """Host logic shared with the oracle by construction, not by import: dropout site keys, SpecAugment spans, optimizer groups of the BERT /
+    Wav2Vec2 / HuBERT matchers, Pillow's Python-layer affine coefficients."""
+    from oracle import augment_ref as A
+    from oracle import bert_ref as BR
+    from oracle import optim_ref as O
+    from oracle import w2v2_ref as WR
+    from semireward_amd import ops
+    from semireward_amd.data import augment as GA
+    from semireward_amd.nets import bert, hubert, wave2vec
+    from semireward_amd.optim import layer_decay_hparams
+    for seed, site in [(0, 0), ((71 << 32) + 5, 3), (2 ** 64 - 1, BR.SITE_HEAD)]:
+        assert ops.site_key(seed, site) == BR.site_key(seed, site)
+    for seed, B, T_ in [(5, 3, 19), (6, 4, 199)]:
+        assert np.array_equal(wave2vec.spec_augment_mask(np.random.Generator(np.random.PCG64(seed)), B, T_, 0.05, 10, 2),
+                              WR.spec_augment_mask(seed, B, T_, 0.05, 10, 2))
+    # optimizer groups (no device memory is touched: only the name tables)
+    cfg = BR.BertCfg(num_classes=4, **BR.BERT_TINY_TEST)
+    names = bert.param_names_shapes(bert.BertConfig(num_classes=4, **BR.BERT_TINY_TEST))
+    assert sorted(n for n, _ in names) == sorted(n for n, _ in BR.param_shapes(cfg))
+    fake = type("M", (), {"names_shapes": names, "cfg": bert.BertConfig(num_classes=4, **BR.BERT_TINY_TEST)})()
+    ids = bert.ClassificationBert.layer_ids(fake)
+    hp = dict(zip([n for n, _ in names], layer_decay_hparams(names, 2, 5e-4, 5e-4, 0.65, no_weight_decay=(), layer_ids=ids,
+                                                              frozen=bert.ClassificationBert.frozen_params)))
+    want = O.bert_param_hparams(BR.param_shapes(cfg), cfg.layers, 5e-4, 5e-4, 0.65)
+    assert all(hp[n] == pytest.approx(want[n], rel=1e-12) for n in want)
+    wcfg = WR.W2vCfg(num_classes=4, **WR.W2V_TINY_TEST)
+    wnames = wave2vec.param_names_shapes(wave2vec.W2vConfig(num_classes=4, **WR.W2V_TINY_TEST))
+    fake = type("M", (), {"names_shapes": wnames, "cfg": wave2vec.W2vConfig(num_classes=4, **WR.W2V_TINY_TEST)})()
+    for cls, hub in ((wave2vec.ClassificationWave2Vec, False), (hubert.ClassificationHubert, True)):
+        ids = cls.layer_ids(fake)
+        hp = dict(zip([n for n, _ in wnames], layer_decay_hparams(wnames, 2, 5e-4, 5e-4, 0.75, no_weight_decay=(), layer_ids=ids)))
+        want = O.w2v_param_hparams(WR.param_shapes(wcfg), wcfg.layers, 5e-4, 5e-4, 0.75, hubert=hub)
+        assert all(hp[n] == pytest.approx(want[n], rel=1e-12) for n in want), cls
+    # Pillow's Python-layer math for the geometric ops: fixed-point coefficients / float64 walk origins
+    assert GA.OPS == A.OPS and GA.RANGES == A.RANGES
+    for S in (32, 96):
+        for op, v in ((7, 17.3), (7, -29.9), (9, 0.21), (10, -0.13), (12, 0.27), (13, -0.3)):
+            a = GA._affine_matrix(op, v, S)
+            want = A.rotate_matrix(v, S, S) if A.OPS[op] == "Rotate" else {"ShearX": (1, v, 0, 0, 1, 0), "ShearY": (1, 0, 0, v, 1, 0),
+                                                                          "TranslateX": (1, 0, v * S, 0, 1, 0), "TranslateY": (1, 0, 0, 0, 1, v * S)}[A.OPS[op]]
+            assert list(a) == list(want)
