@@ -528,8 +528,13 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   const bool force_tile = mode && mode[0] == 't';
   // measured (tools/microbench.py, M = 51400): N >= 1024 -> 256x256 persistent kernel wins (fc1 152 -> 144 us, 8192^3
   // 775 -> 1064 TF); N = 384 products are epilogue/HBM bound and slightly better on the 128x128 kernel (2 WGs/CU).
+  // The persistent kernel runs 256 workgroups over 256x256 tiles: below ~3 full rounds of tiles its round quantisation costs more than the
+  // larger tile saves (the split launches of a training step: 32 639 x 1152 = 640 tiles = 2.5 -> 3 rounds; on the 128x128 kernel 2313 tiles
+  // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
+  static const double big_min_rounds = getenv("SRHIP_BIG_MIN_ROUNDS") ? atof(getenv("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
   const bool want_big = N >= 1024 || (mode && mode[0] == 'b');
-  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (long)M * N >= 256L * 256 * 128) {
+  const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
+  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= big_min_rounds || (mode && mode[0] == 'b'))) {
     int variant = 0;
     if (mode && !strcmp(mode, "big128")) variant = 1;
     if (mode && !strcmp(mode, "big2wg")) variant = 2;
