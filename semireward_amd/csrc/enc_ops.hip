@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void postln_fwd_kernel(const float* __restrict
 
 // ---- post-LN backward: dy = d/d(LayerNorm output) -> dx = d/d(y) in fp32 (the residual path) and, masked by the dropout that sat on
 // the branch (y = x_prev + dropout(branch)), in bf16 (operand of the branch's dX and dW products) ------------------------------
-template <int NV>
+template <int NV, int RPW>
 __global__ __launch_bounds__(256) void postln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, float* __restrict__ dx, bf16_t* __restrict__ dxb,
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void postln_bwd_kernel(const float* __restrict
     ag[i] = ab[i] = make_float2(0.f, 0.f);
     g[i] = reinterpret_cast<const float2*>(gamma)[i * 64 + lane];
   }
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = blockIdx.x * 32 + wave * 8 + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = blockIdx.x * (4 * RPW) + wave * RPW + rr;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
     const float2* yr = reinterpret_cast<const float2*>(y + (size_t)row * D);
@@ -338,8 +338,14 @@ extern "C" int srhip_postln_bwd(const float* dy, const float* y, const float* me
   if (!dy || !y || !mean || !rstd || !dx || !dx_bf16 || !dgamma || !dbeta || M <= 0) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
   hipStream_t s = (hipStream_t)stream;
-#define CALL(NV) hipLaunchKernelGGL(postln_bwd_kernel<NV>, dim3(cdiv(M, 32)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16, dgamma, \
-                                    dbeta, M, dr)
+  const bool small = M < 16384;       // few rows: 8 instead of 32 per workgroup (see ln_bwd_kernel)
+#define CALL(NV)                                                                                                                                    \
+  do {                                                                                                                                              \
+    if (small) hipLaunchKernelGGL((postln_bwd_kernel<NV, 2>), dim3(cdiv(M, 8)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16,     \
+                                  dgamma, dbeta, M, dr);                                                                                            \
+    else hipLaunchKernelGGL((postln_bwd_kernel<NV, 8>), dim3(cdiv(M, 32)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16, dgamma, \
+                            dbeta, M, dr);                                                                                                          \
+  } while (0)
   DISPATCH_NV(D, CALL)
 #undef CALL
   SR_CHECK_LAUNCH();
