@@ -532,7 +532,8 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   // larger tile saves (the split launches of a training step: 32 639 x 1152 = 640 tiles = 2.5 -> 3 rounds; on the 128x128 kernel 2313 tiles
   // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
   static const double big_min_rounds = getenv("SRHIP_BIG_MIN_ROUNDS") ? atof(getenv("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
-  const bool want_big = N >= 1024 || (mode && mode[0] == 'b');
+  // (N = 512 conv layers of the Wav2Vec2 feature encoder, K = 1024 / 1536 over 10^5..10^6 frames: +5 % clips/s on the persistent kernel)
+  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (mode && mode[0] == 'b');
   const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
   if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= big_min_rounds || (mode && mode[0] == 'b'))) {
     int variant = 0;

@@ -50,7 +50,7 @@ class _GemmProfile:
 
     @classmethod
     def kernel_name(cls, epi, M, N, K):
-        if epi != EPI_F32 and N >= 1024 and M >= 1024 and (-(-M // 256)) * (-(-N // 256)) >= 3 * 256:
+        if epi != EPI_F32 and (N >= 1024 or (N >= 512 and K >= 1024 and M >= 65536)) and M >= 1024 and (-(-M // 256)) * (-(-N // 256)) >= 3 * 256:
             return "gemm_big_kernel<%d, 8, 2>" % epi
         if epi != EPI_F32 and -(-M // 128) * -(-N // 128) < 256:
             return "gemm_small_kernel<%d>" % epi
