@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
       for (int j = 0; j < K0MAX; ++j) if (j < k) v = fmaf(w[j], seg[tt * s + j], v);
       if (MODE == 0) { acc0 += v; acc1 += v * v; }
       if (MODE == 1) {
-        const float y = t < T0 ? gelu_exact((v - mean) * rstd * g + be) : 0.f;
+        const float y = t < T0 ? gelu_erf((v - mean) * rstd * g + be) : 0.f;      // A-S erf of common.h (|err| < 1.5e-7, output is bf16): erff tripled this pass
         out[((size_t)b * P0 + t) * C + c] = f2bf(y);
       }
       if (MODE >= 2) {
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ 
 
 // group-major zero-padded staging copy for the grouped positional conv: out[g][clip * Pp + u][cg] = src[clip, u - pad_left, g*cg + c]
 // (0 outside [0, T)); src fp32 with frame pitch P (forward: hidden states) or Psrc rows of a gradient buffer.
-__global__ __launch_bounds__(256) void pos_stage_kernel(const float* __restrict__ src, bf16_t* __restrict__ out, int T, int P, int Pp, int D, int cg,
-                                                       int pad_left, long rows_total, long n) {
+__global__ __launch_bounds__(256) void pos_stage_kernel(const float* __restrict__ src, bf16_t* __restrict__ out, int B, int T, int P, int Pp, int D,
+                                                       int cg, int pad_left, long rows_total, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = (int)(i % cg);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void pos_stage_kernel(const float* __restrict_
   const long clip = r / Pp;
   const int t = (int)(r % Pp) - pad_left;
   float v = 0.f;
-  if (t >= 0 && t < T) v = src[((size_t)clip * P + t) * D + g * cg + c];
+  if (clip < B && t >= 0 && t < T) v = src[((size_t)clip * P + t) * D + g * cg + c];      // (rows past the last clip are slack: zeros)
   out[i] = f2bf(v);
 }
 
@@ -514,7 +514,7 @@ extern "C" int srhip_w2v_pos_stage(const float* src, void* out, int B, int T, in
                                    void* stream) {
   if (!src || !out || B <= 0 || D % groups || rows_total < (long)B * Pp) return SR_EINVAL;
   const long n = rows_total * D;
-  W2V_LAUNCH1D(pos_stage_kernel, n, src, (bf16_t*)out, T, P, Pp, D, D / groups, pad_left, rows_total, n);
+  W2V_LAUNCH1D(pos_stage_kernel, n, src, (bf16_t*)out, B, T, P, Pp, D, D / groups, pad_left, rows_total, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
