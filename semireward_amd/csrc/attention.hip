@@ -195,10 +195,11 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
     sum += __shfl_xor(sum, 32, 64);
     if (VAR && av.drop_thresh) {                     // nn.Dropout on the normalised probabilities: the row sum is the pre-dropout one
       const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(g * 4);
+      const uint32_t h0 = rowbase * 0x9E3779B1u + av.drop_key;
 #pragma unroll
       for (int t = 0; t < NKT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[t][r] = drop_keep(rowbase + t * 16 + r, av.drop_key, av.drop_thresh) ? s[t][r] : 0.f;
+        for (int r = 0; r < 4; ++r) s[t][r] = drop_keep_h0(h0, (uint32_t)(t * 16 + r), av.drop_thresh) ? s[t][r] : 0.f;
     }
     f32x4_t o[4];
 #pragma unroll
