@@ -18,6 +18,7 @@
 // score tile (4 consecutive keys) are directly k-slots of the next MFMA's b-operand.
 // qkv layout: [B*N, 3*D] row-major (q | k | v, head-major inside each third) exactly as the
 // qkv Linear writes it (vit.py:93-98) -- no permute kernel.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -525,8 +526,12 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
     if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     // split query / key tiles over extra workgroups until the grid covers the chip (each split re-stages K/V or Q/dO)
     const int nt16 = (N + 15) / 16;
+    // (measured at the reference batch, 96 (image, head) pairs x 2 roles: no split 1087 img/s, split 2 1072, split 3 1065 while the deferred
+    // rows share the chip -- every split re-stages K / V / Q / dO; alone on the chip (K = 0 regime) split 3 wins by 1 %)
     int split = 1;
-    while (B * H * split * 2 < 256 && split * BWD_NW < nt16) ++split;
+    while (B * H * split * 2 < 128 && split * BWD_NW < nt16) ++split;
+    static const char* force = getenv("SRHIP_ATTN_BWD_SPLIT");
+    if (force && atoi(force) > 0) split = atoi(force);
     hipLaunchKernelGGL(kern, dim3(B * H, split, 2), dim3(BWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale, av);
     SR_CHECK_LAUNCH();
