@@ -101,6 +101,7 @@ class SRConsistencyBase(AlgorithmBase):
         # rows nothing downstream reads (see _Plan) go behind the gradient rows on the second stream; the step end waits for them
         self.defer_unread_rows = self.overlap_grad_rows and os.environ.get("SR_DEFER_UNREAD_ROWS", "1") != "0"
         self._rest_done = None
+        self._grad_pending = None
         self._phases = []
         self.inject_droppath = None            # tests: list of [depth,2,Bt] tensors, one per pass
         self.trace = None                      # tests: dict filled with per-pass intermediates when not None
@@ -188,14 +189,26 @@ class SRConsistencyBase(AlgorithmBase):
                     feats.index_copy_(0, pl.rest_cols, ft_r)
                     self._rest_done = torch.cuda.Event()
                     self._rest_done.record(side)
-            main.wait_event(grad_done)
-            lg_g.record_stream(main)
-            ft_g.record_stream(main)
-        else:
-            lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
+            # The gradient rows are joined LATER (_join_grad): masks, pseudo labels and reward scores only read the weak rows of the launch
+            # above, so that chain (~0.3 ms of tiny sequential launches) runs while the second stream still works on the gradient rows.
+            self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, pl.grad_cols)
+            return logits, feats, ctx
+        lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
         logits.index_copy_(0, pl.grad_cols, lg_g)
         feats.index_copy_(0, pl.grad_cols, ft_g)
         return logits, feats, ctx
+
+    def _join_grad(self):
+        """Logits / features of the gradient rows become visible on the step's stream."""
+        if self._grad_pending is not None:
+            grad_done, lg_g, ft_g, logits, feats, cols = self._grad_pending
+            self._grad_pending = None
+            main = torch.cuda.current_stream()
+            main.wait_event(grad_done)
+            lg_g.record_stream(main)
+            ft_g.record_stream(main)
+            logits.index_copy_(0, cols, lg_g)
+            feats.index_copy_(0, cols, ft_g)
 
     def _step_scope(self):
         # (tried and measured on MI355X, both without gain: running the step on a high-priority stream -- the hardware offers two levels and
@@ -234,6 +247,7 @@ class SRConsistencyBase(AlgorithmBase):
             self._rest_done = None
 
     fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient
+    masks_read_labelled_rows = False      # SoftMatch with the 'model' alignment target: the masks need the labelled logits of pass 0
 
     def _tokens(self, x):
         from ..nets.bert import TokenBatch
@@ -293,9 +307,10 @@ class SRConsistencyBase(AlgorithmBase):
         mi = torch.empty(P * nu, dtype=torch.int64, device=self.device)
         ops.row_max(Lw, False, None, mp, mi, P * nu, C)
         self._lb_logits0 = L[0, :nl]                       # SoftMatch's 'model' alignment target reads the labelled rows of pass 0
+        if self.masks_read_labelled_rows:
+            self._join_grad()
         masks = self._masks(mp, mi, idx_ulb, P, nu, Lw)
         pl0 = mi[:nu]
-        sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132
         if K > 0:
             self.rewarder.eval()                                                                  # :74
             fw = Fe[1:, nl:nl + nu].reshape(K * nu, -1)
@@ -303,6 +318,9 @@ class SRConsistencyBase(AlgorithmBase):
             mask2 = torch.empty_like(reward)
             mean_in = self.dp.reward_means(reward, K).contiguous() if (self.dp.global_reward_threshold and self.dp.active) else None
             ops.reward_mask2(reward, mask2, None, K, nu, mean_in=mean_in)                          # :100-101
+        self._join_grad()                                  # from here on the labelled / strong rows of the loss are read
+        sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132
+        if K > 0:
             plK, mK, m2K = mi[K * nu:], masks[K], mask2[(K - 1) * nu:]
             unsup_loss, dl_s = self.consistency_loss(L[K, nl + nu:], plK, "ce", mask=mK, mask2=m2K, grad_scale=self.lambda_u)   # :102
         else:

@@ -76,6 +76,7 @@ class SRPseudoLabel(SRConsistencyBase):
             logits, feats, ctx = torch.cat([lg_lb] + lws), torch.cat([ft_lb] + fws), (ctx_lb, ctx_u)
         else:
             logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
+            self._join_grad()
         # weak logits of every pass -> softmax max / argmax in one launch (FixedThresholdingHook softmaxes logits, masking.py:48-50)
         Lw = torch.cat([logits[sl] for sl in pl.weak])                                              # [P*nu, C]
         Fw = torch.cat([feats[sl] for sl in pl.weak])

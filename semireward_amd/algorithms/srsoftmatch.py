@@ -34,6 +34,10 @@ class SRSoftMatch(SRConsistencyBase):
                                                   per_class=self.args.per_class, device=self.device), "MaskingHook")
         super().set_hooks()
 
+    @property
+    def masks_read_labelled_rows(self):
+        return bool(self.hooks_dict["DistAlignHook"].update_p_target)
+
     def _masks(self, mp, mi, idx_ulb, P, nu, weak_logits=None):
         C = self.num_classes
         da, sm = self.hooks_dict["DistAlignHook"], self.hooks_dict["MaskingHook"]
