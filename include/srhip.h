@@ -99,6 +99,15 @@ int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const
  * next branch (vit.py:164-165 backward), i.e. srhip_layernorm_bwd + srhip_cast_scale_rows in one launch.  row_scale NULL = 1. */
 int srhip_layernorm_bwd_cast(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
                              float* dbeta, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D, void* stream);
+/* The same with the column sums spread over n_rep partial copies, part fp32 [n_rep][2][D] (copy = workgroup % n_rep; [.][0] dgamma, [.][1]
+ * dbeta): the 2 * D words of one LayerNorm are otherwise hit by every workgroup of the launch, and same-address device-scope atomics
+ * serialise (measured: 11 of 19 us at M = 4112).  out_bf16 may be NULL.  srhip_ln_grad_reduce adds the copies of n_ln LayerNorms
+ * (part [n_ln][n_rep][2][D]) to their dgamma / dbeta (torch.autograd's accumulation into .grad of vit.py:135,150) and clears them:
+ * one launch per step, after the last LayerNorm backward. */
+int srhip_layernorm_bwd_part(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* part,
+                             int n_rep, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D, void* stream);
+typedef struct srhip_ln_reduce_desc { float* dgamma; float* dbeta; } srhip_ln_reduce_desc;   /* 16 bytes */
+int srhip_ln_grad_reduce(const srhip_ln_reduce_desc* desc_dev, float* part, int n_ln, int n_rep, int D, void* stream);
 
 /* Fused MLP half of a transformer block on the fp32 residual stream (x -> x_out, both [M, D]; x_out may equal x):
  *   x_out = x + row_scale[m / rows_per_sample] * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) + b2 )

@@ -26,6 +26,8 @@ SIGNATURES = {
     "srhip_layernorm_fwd": (I, [P, P, P, F, P, P, P, I, I, P]),
     "srhip_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P]),
     "srhip_layernorm_bwd_cast": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "srhip_layernorm_bwd_part": (I, [P, P, P, P, P, P, P, I, P, P, I, I, I, P]),
+    "srhip_ln_grad_reduce": (I, [P, P, I, I, I, P]),
     "srhip_mlp_fused": (I, [P, P, P, P, F, P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, float* __restrict__ dx,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                    bf16_t* __restrict__ out_bf16, const float* __restrict__ row_scale, int rows_per_sample) {
+                                                    bf16_t* __restrict__ out_bf16, const float* __restrict__ row_scale, int rows_per_sample,
+                                                    float* __restrict__ part, int n_rep) {
   constexpr int D = NV * 128;
   __shared__ float red[2][4][D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
+  // 514 workgroups adding into the same 2 * D words serialise at the memory side (device-scope atomics of 8 XCDs: 11 of the 19 us of a
+  // 4112-row launch): with replicas, workgroup w adds into copy w % n_rep of [n_rep][2][D]; srhip_ln_grad_reduce folds them once per step.
+  if (n_rep > 0) { dgamma = part + (size_t)(blockIdx.x % n_rep) * 2 * D; dbeta = dgamma + D; }
+  if (!dgamma) return;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 2;
@@ -450,18 +455,20 @@ extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const flo
 }
 
 static int layernorm_bwd_impl(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
-                              float* dbeta, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D, void* stream) {
+                              float* dbeta, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D, void* stream,
+                              float* part = nullptr, int n_rep = 0) {
   if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768) || (row_scale && rows_per_sample <= 0)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const bool small = M < 16384;
+  static const int rpw_env = getenv("SRHIP_LNB_RPW") ? atoi(getenv("SRHIP_LNB_RPW")) : 0;
+  const bool small = rpw_env ? rpw_env == 2 : M < 16384;
   dim3 grid(cdiv(M, small ? 8 : 32)), block(256);
   const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
 #define LNB(NV)                                                                                                                                   \
   do {                                                                                                                                            \
     if (small) hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M,        \
-                                  (bf16_t*)out_bf16, row_scale, rps);                                                                             \
+                                  (bf16_t*)out_bf16, row_scale, rps, part, n_rep);                                                                             \
     else hipLaunchKernelGGL((ln_bwd_kernel<NV, 8>), grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M,              \
-                            (bf16_t*)out_bf16, row_scale, rps);                                                                                   \
+                            (bf16_t*)out_bf16, row_scale, rps, part, n_rep);                                                                                   \
   } while (0)
   if (D == 128) LNB(1); else if (D == 512) LNB(4); else if (D == 384) LNB(3); else LNB(6);
 #undef LNB
@@ -477,6 +484,33 @@ extern "C" int srhip_layernorm_bwd_cast(const void* dy, const float* x, const fl
                                         void* stream) {
   if (!out_bf16) return SR_EINVAL;
   return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, out_bf16, row_scale, rows_per_sample, M, D, stream);
+}
+extern "C" int srhip_layernorm_bwd_part(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                        float* part, int n_rep, void* out_bf16, const float* row_scale, int rows_per_sample, int M, int D,
+                                        void* stream) {
+  if (!part || n_rep <= 0) return SR_EINVAL;
+  return layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, nullptr, nullptr, out_bf16, row_scale, rows_per_sample, M, D, stream, part, n_rep);
+}
+
+namespace {
+// dgamma / dbeta of n_ln LayerNorms += the sum of their n_rep partial copies ([n_ln][n_rep][2][D]); the copies are cleared for the next step.
+__global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const srhip_ln_reduce_desc* __restrict__ desc, float* __restrict__ part, int n_rep,
+                                                            int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * D) return;
+  float* p = part + (size_t)blockIdx.y * n_rep * 2 * D + c;
+  float acc = 0.f;
+  for (int r = 0; r < n_rep; ++r) { acc += p[(size_t)r * 2 * D]; p[(size_t)r * 2 * D] = 0.f; }
+  const srhip_ln_reduce_desc d = desc[blockIdx.y];
+  float* dst = c < D ? d.dgamma + c : d.dbeta + (c - D);
+  *dst += acc;
+}
+}  // namespace
+extern "C" int srhip_ln_grad_reduce(const srhip_ln_reduce_desc* desc_dev, float* part, int n_ln, int n_rep, int D, void* stream) {
+  if (!desc_dev || !part || n_ln <= 0 || n_rep <= 0 || D <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3(cdiv(2 * D, 256), n_ln), dim3(256), 0, (hipStream_t)stream, desc_dev, part, n_rep, D);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
 }
 
 extern "C" int srhip_patch_embed_fwd(const float* img, const int* img_index, const float* Wp, const float* bp, const float* cls,

@@ -58,6 +58,7 @@ def param_names_shapes(cfg):
     return out
 
 
+LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.layernorm_bwd_part)
 _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 # gradient + inference images in ONE forward (forward_mixed).  Opt-in: at the reference batch the 16 extra images push the qkv GEMM
 # from 4 to 5 rounds of 256x256 tiles (89 -> 106 us) and the two-stream schedule hides the small launches anyway: 8.52 vs 8.10 ms/step.
@@ -419,6 +420,11 @@ class VisionTransformer:
                          (t["g1"], ctx.ao[i], G(b + "attn.proj.weight"), G(b + "attn.proj.bias"), D, D, M),
                          (t["dqkv"], ctx.ln1[i], G(b + "attn.qkv.weight"), G(b + "attn.qkv.bias"), 3 * D, D, M)]
         out = dict(layers=layers, desc=ops.make_group_tn_desc(problems, self.device))
+        # LayerNorm affine gradients: LN_REP partial copies per LayerNorm (same-address atomics of ~500 workgroups serialise), folded into
+        # the gradient block by ONE launch after the layer loop.  Order: norm1, norm2 of block 0, 1, ...
+        out["ln_part"] = torch.zeros(2 * cfg.depth, LN_REP, 2, D, dtype=torch.float32, device=self.device)
+        out["ln_desc"] = ops.make_ln_reduce_desc([(G("blocks.%d.norm%d.weight" % (i, j)), G("blocks.%d.norm%d.bias" % (i, j)))
+                                                  for i in range(cfg.depth) for j in (1, 2)], self.device)
         self._ws[key] = out
         return out
 
@@ -440,6 +446,7 @@ class VisionTransformer:
         T = self._bwd_plan(M, ctx)
         scale = 64 ** -0.5
         dp = ctx.dp
+        lnp = T["ln_part"]
         ops.cast_scale_rows(dx, dp[cfg.depth - 1, 1] if dp is not None else None, N, T["layers"][cfg.depth - 1]["g2"], M, D)
         for i in reversed(range(cfg.depth)):
             b = "blocks.%d." % i
@@ -448,18 +455,15 @@ class VisionTransformer:
             # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))));  g2 = bf16(s2 * dx) came from the previous LayerNorm backward
             ops.gemm_nt(ops.EPI_DGELU_BF16, Ti["g2"], self.wT[b + "mlp.fc2.weight"], Ti["dpre"], M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
             ops.gemm_nt(ops.EPI_BF16, Ti["dpre"], self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
-            ops.layernorm_bwd_cast(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, G(b + "norm2.weight"),
-                                   G(b + "norm2.bias"), Ti["g1"], s1, N, M, D)
+            ops.layernorm_bwd_part(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, lnp[2 * i + 1], LN_REP,
+                                   Ti["g1"], s1, N, M, D)
             # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
             ops.gemm_nt(ops.EPI_BF16, Ti["g1"], self.wT[b + "attn.proj.weight"], dao, M, D, D)
             ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], Ti["dqkv"], delta, B, N, H, scale)
             ops.gemm_nt(ops.EPI_BF16, Ti["dqkv"], self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
-            if i > 0:
-                ops.layernorm_bwd_cast(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
-                                       G(b + "norm1.bias"), T["layers"][i - 1]["g2"], dp[i - 1, 1] if dp is not None else None, N, M, D)
-            else:
-                ops.layernorm_bwd(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, G(b + "norm1.weight"),
-                                  G(b + "norm1.bias"), M, D)
+            ops.layernorm_bwd_part(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, lnp[2 * i], LN_REP,
+                                   T["layers"][i - 1]["g2"] if i > 0 else None, dp[i - 1, 1] if dp is not None and i > 0 else None, N, M, D)
+        ops.ln_grad_reduce(T["ln_desc"], lnp, 2 * cfg.depth, LN_REP, D)
         # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
         desc, npb, ntiles, flops, nbytes = T["desc"]
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)

@@ -194,6 +194,23 @@ def layernorm_bwd_cast(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, out_bf16, ro
           rows_per_sample, M, D, _s())
 
 
+def layernorm_bwd_part(dy, x, mean, rstd, gamma, dx, part, n_rep, out_bf16, row_scale, rows_per_sample, M, D):
+    """layernorm_bwd(_cast) with dgamma / dbeta added into copy (workgroup % n_rep) of part fp32 [n_rep, 2, D]; see ln_grad_reduce."""
+    _call("srhip_layernorm_bwd_part", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(part), n_rep, _p(out_bf16), _p(row_scale),
+          rows_per_sample, M, D, _s())
+
+
+def make_ln_reduce_desc(pairs, device):
+    """pairs: list of (dgamma, dbeta) fp32 views of the gradient block, in the order of the partial copies."""
+    import numpy as np
+    arr = np.array([[_p(g), _p(b)] for g, b in pairs], dtype=np.uint64)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+def ln_grad_reduce(desc, part, n_ln, n_rep, D):
+    _call("srhip_ln_grad_reduce", _p(desc), _p(part), n_ln, n_rep, D, _s())
+
+
 def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M, D, Hd, x_out=None, save=None):
     """x_out (default: x, in place; fp32 [M,D]) = x + row_scale * (fc2(gelu(fc1(LN(x)))) + b2), ONE launch.
     save = (rows, ln2, pre, h, mean, rstd): the first ``rows`` rows also get their backward operands written (see srhip.h)."""
