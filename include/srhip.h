@@ -283,6 +283,10 @@ int srhip_postln_fwd(const float* y, const float* gamma, const float* beta, floa
                      int D, void* stream);
 int srhip_postln_bwd(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx, void* dx_bf16,
                      float* dgamma, float* dbeta, int M, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
+/* postln_bwd with dgamma / dbeta spread over n_rep partial copies part fp32 [n_rep][2][D] (see srhip_layernorm_bwd_part; folded by
+ * srhip_ln_grad_reduce after the last layer). */
+int srhip_postln_bwd_part(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx, void* dx_bf16,
+                          float* part, int n_rep, int M, int D, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
 int srhip_meanpool_fwd(const float* x, float* feat, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,
                        float drop_scale, void* stream);
 int srhip_meanpool_bwd(const float* dfeat, float* dx, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "srhip_embed_ln_bwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, U, U, F, P]),
     "srhip_postln_fwd": (I, [P, P, P, F, P, P, P, P, I, I, P]),
     "srhip_postln_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, U, U, F, P]),
+    "srhip_postln_bwd_part": (I, [P, P, P, P, P, P, P, P, I, I, I, U, U, F, P]),
     "srhip_meanpool_fwd": (I, [P, P, P, I, I, I, U, U, F, P]),
     "srhip_meanpool_bwd": (I, [P, P, P, I, I, I, U, U, F, P]),
     "srhip_gelu_f32": (I, [P, P, L, P]),

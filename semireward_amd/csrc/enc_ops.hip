@@ -173,7 +173,8 @@ template <int NV, int RPW>
 __global__ __launch_bounds__(256) void postln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, float* __restrict__ dx, bf16_t* __restrict__ dxb,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int M, Drop dr) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int M, Drop dr,
+                                                        float* __restrict__ part, int n_rep) {
   constexpr int D = NV * 128;
   __shared__ float red[2][4][D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void postln_bwd_kernel(const float* __restrict
     red[1][wave][c] = ab[i].x; red[1][wave][c + 1] = ab[i].y;
   }
   __syncthreads();
+  if (n_rep > 0) { dgamma = part + (size_t)(blockIdx.x % n_rep) * 2 * D; dbeta = dgamma + D; }     // partial copies: see ln_bwd_kernel (vit_ops.hip)
   for (int c = threadIdx.x; c < D; c += 256) {
     atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
     atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
@@ -332,24 +334,36 @@ extern "C" int srhip_postln_fwd(const float* y, const float* gamma, const float*
   return SR_OK;
 }
 
-extern "C" int srhip_postln_bwd(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx,
-                                void* dx_bf16, float* dgamma, float* dbeta, int M, int D, unsigned drop_key, unsigned drop_thresh,
-                                float drop_scale, void* stream) {
-  if (!dy || !y || !mean || !rstd || !dx || !dx_bf16 || !dgamma || !dbeta || M <= 0) return SR_EINVAL;
+static int postln_bwd_impl(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx,
+                           void* dx_bf16, float* dgamma, float* dbeta, float* part, int n_rep, int M, int D, unsigned drop_key,
+                           unsigned drop_thresh, float drop_scale, void* stream) {
+  if (!dy || !y || !mean || !rstd || !dx || !dx_bf16 || M <= 0) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
   hipStream_t s = (hipStream_t)stream;
   const bool small = M < 16384;       // few rows: 8 instead of 32 per workgroup (see ln_bwd_kernel)
 #define CALL(NV)                                                                                                                                    \
   do {                                                                                                                                              \
     if (small) hipLaunchKernelGGL((postln_bwd_kernel<NV, 2>), dim3(cdiv(M, 8)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16,     \
-                                  dgamma, dbeta, M, dr);                                                                                            \
+                                  dgamma, dbeta, M, dr, part, n_rep);                                                                               \
     else hipLaunchKernelGGL((postln_bwd_kernel<NV, 8>), dim3(cdiv(M, 32)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16, dgamma, \
-                            dbeta, M, dr);                                                                                                          \
+                            dbeta, M, dr, part, n_rep);                                                                                             \
   } while (0)
   DISPATCH_NV(D, CALL)
 #undef CALL
   SR_CHECK_LAUNCH();
   return SR_OK;
+}
+extern "C" int srhip_postln_bwd(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                void* dx_bf16, float* dgamma, float* dbeta, int M, int D, unsigned drop_key, unsigned drop_thresh,
+                                float drop_scale, void* stream) {
+  if (!dgamma || !dbeta) return SR_EINVAL;
+  return postln_bwd_impl(dy, y, mean, rstd, gamma, dx, dx_bf16, dgamma, dbeta, nullptr, 0, M, D, drop_key, drop_thresh, drop_scale, stream);
+}
+extern "C" int srhip_postln_bwd_part(const float* dy, const float* y, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                     void* dx_bf16, float* part, int n_rep, int M, int D, unsigned drop_key, unsigned drop_thresh,
+                                     float drop_scale, void* stream) {
+  if (!part || n_rep <= 0) return SR_EINVAL;
+  return postln_bwd_impl(dy, y, mean, rstd, gamma, dx, dx_bf16, nullptr, nullptr, part, n_rep, M, D, drop_key, drop_thresh, drop_scale, stream);
 }
 
 extern "C" int srhip_meanpool_fwd(const float* x, float* feat, const int* seq_len, int B, int L, int D, unsigned drop_key, unsigned drop_thresh,

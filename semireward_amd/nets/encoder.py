@@ -20,6 +20,7 @@ import torch
 from .. import ops
 
 SITE_PROBS, SITE_ATTN_OUT, SITE_FFN_OUT, SITE_ACT = 0, 1, 2, 3
+LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.postln_bwd_part)
 
 
 class PostLNEncoderMixin:
@@ -114,6 +115,10 @@ class PostLNEncoderMixin:
             T["desc"].append(ops.make_group_tn_desc(
                 [(T["g2"], ctx.h[i], G(nm["w2"]), G(nm["b2"]), D, I, M), (T["dpre"], ctx.xbm[i], G(nm["w1"]), G(nm["b1"]), I, D, M),
                  (T["g1"], ctx.ao[i], G(nm["o_w"]), G(nm["o_b"]), D, D, M), (T["dqkv"], ctx.xb[i], gw, gb, 3 * D, D, M)], self.device))
+        # LayerNorm affine gradients go through LN_REP partial copies per LayerNorm (ops.layernorm_bwd_part), folded after the layer loop
+        T["ln_part"] = torch.zeros(2 * cfg.layers, LN_REP, 2, D, dtype=torch.float32, device=self.device)
+        T["ln_desc"] = ops.make_ln_reduce_desc([(G(self.enc_names(i)[k + "_w"]), G(self.enc_names(i)[k + "_b"]))
+                                                for i in range(cfg.layers) for k in ("ln1", "ln2")], self.device)
         self._ws[key] = T
         return T
 
@@ -131,8 +136,8 @@ class PostLNEncoderMixin:
                 continue
             nm, wT = self.enc_names(i), self.wT[i]
             # ---- FFN: x_out = LN(y2), y2 = x_mid + dropout(W2 [dropout] gelu(W1 x_mid))
-            ops.postln_bwd(dx, ctx.y2[i], ctx.st2[i][0], ctx.st2[i][1], P(nm["ln2_w"]), dx, T["g2"], G(nm["ln2_w"]), G(nm["ln2_b"]), M, D,
-                           dr(4 * i + SITE_FFN_OUT, pr["hidden"]))
+            ops.postln_bwd_part(dx, ctx.y2[i], ctx.st2[i][0], ctx.st2[i][1], P(nm["ln2_w"]), dx, T["g2"], T["ln_part"][2 * i + 1], LN_REP, M, D,
+                                dr(4 * i + SITE_FFN_OUT, pr["hidden"]))
             da = dr(4 * i + SITE_ACT, pr["act"])
             if da is None:
                 ops.gemm_nt(ops.EPI_DGELU_BF16, T["g2"], wT["w2"], T["dpre"], M, I, D, aux_in=ctx.pre[i], ldaux=I)
@@ -140,14 +145,15 @@ class PostLNEncoderMixin:
                 ops.gemm_nt_dropout(ops.EPI_DGELU_BF16, T["g2"], wT["w2"], T["dpre"], M, I, D, da, aux_in=ctx.pre[i], ldaux=I)
             ops.gemm_nt(ops.EPI_RESID_F32, T["dpre"], wT["w1"], dx, M, D, I)
             # ---- attention: x_mid = LN(y1), y1 = x_in + dropout(Wo attn(qkv(x_in)))
-            ops.postln_bwd(dx, ctx.y1[i], ctx.st1[i][0], ctx.st1[i][1], P(nm["ln1_w"]), dx, T["g1"], G(nm["ln1_w"]), G(nm["ln1_b"]), M, D,
-                           dr(4 * i + SITE_ATTN_OUT, pr["hidden"]))
+            ops.postln_bwd_part(dx, ctx.y1[i], ctx.st1[i][0], ctx.st1[i][1], P(nm["ln1_w"]), dx, T["g1"], T["ln_part"][2 * i], LN_REP, M, D,
+                                dr(4 * i + SITE_ATTN_OUT, pr["hidden"]))
             ops.gemm_nt(ops.EPI_BF16, T["g1"], wT["o"], T["dao"], M, D, D)
             ops.attn_masked_bwd(ctx.qkv[i], ctx.ao[i], T["dao"], ctx.lse[i], T["dqkv"], delta, key_len, B, L, H, scale,
                                 dr(4 * i + SITE_PROBS, pr["attn"]))
             ops.gemm_nt(ops.EPI_RESID_F32, T["dqkv"], wT["qkv"], dx, M, D, 3 * D)
             desc, npb, ntiles, flops, nbytes = T["desc"][i]
             ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+        ops.ln_grad_reduce(T["ln_desc"], T["ln_part"], 2 * cfg.layers, LN_REP, D)
 
     # ---- mean-pool + 2-layer classifier head (bert.py:16-20,36-37 / wave2vecv2.py:17-21,46-48) ---------------------------
     def head_forward(self, x, B, L, drop, seq_len, c=None):

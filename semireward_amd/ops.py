@@ -523,6 +523,10 @@ def postln_fwd(y, gamma, beta, eps, x, xb, mean, rstd, M, D):
     _call("srhip_postln_fwd", _p(y), _p(gamma), _p(beta), eps, _p(x), _p(xb), _p(mean), _p(rstd), M, D, _s())
 
 
+def postln_bwd_part(dy, y, mean, rstd, gamma, dx, dxb, part, n_rep, M, D, drop=None):
+    _call("srhip_postln_bwd_part", _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dxb), _p(part), n_rep, M, D, *_d(drop), _s())
+
+
 def postln_bwd(dy, y, mean, rstd, gamma, dx, dxb, dgamma, dbeta, M, D, drop=None):
     _call("srhip_postln_bwd", _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dxb), _p(dgamma), _p(dbeta), M, D, *_d(drop), _s())
 
