@@ -551,7 +551,8 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   }
   // under-filled launches (less than one round of 2 workgroups per CU on 128x128 tiles) -> 64x64 tiles, deep ring
   const bool force_small = mode && mode[0] == 's';
-  if ((grid < 256 || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
+  static const int small_max_grid = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : 256;
+  if ((grid < small_max_grid || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
     const dim3 gs(cdiv(M, SBM) * cdiv(N, SBM));
     switch (epilogue) {
       case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;
