@@ -59,7 +59,8 @@ class _Plan:
         self.mixed_cols = self.mixed_img = None      # gradient columns first (forward_mixed), built on first use
 
     @classmethod
-    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False, rows_per_col=None):
+    def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False, rows_per_col=None,
+                   elide_unread=False):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
         labelled rows of pass 0 and the strong rows of the last pass.  lb_every_pass=False (use_cat=False, the usb_nlp / usb_audio
         configs): data_generator forwards only x_ulb_s and x_ulb_w (srflexmatch.py:83-90), so the labelled columns of the passes
@@ -69,6 +70,12 @@ class _Plan:
         grad = list(range(nl)) + ([j for j in range(nl + nu, Bt)] if extra_pass0_strong else []) + \
             [K * Bt + j for j in range(nl + nu, Bt)]
         skip = [] if lb_every_pass else [k * Bt + j for k in range(1, K + 1) for j in range(nl)]
+        if elide_unread:
+            # OPT-IN extension (not the reference's work): the rows of the passes 1..K whose outputs nothing reads -- labelled rows, and the
+            # strong rows of all but the last pass -- are not computed at all.  Rows are independent in the LayerNorm backbones (no batch
+            # statistics), so every number the step produces is unchanged; pass 0 stays complete (its features are returned in feat_dict).
+            skip = sorted(set(skip) | {k * Bt + j for k in range(1, K + 1) for j in range(nl)} |
+                          {k * Bt + j for k in range(1, K) for j in range(nl + nu, Bt)})
         read = [k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)] if defer_unread else None      # the weak rows
         p = cls(cols_img, grad, device, skip, read, rows_per_col)
         p.P, p.Bt = K + 1, Bt
@@ -100,6 +107,8 @@ class SRConsistencyBase(AlgorithmBase):
         self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
         # rows nothing downstream reads (see _Plan) go behind the gradient rows on the second stream; the step end waits for them
         self.defer_unread_rows = self.overlap_grad_rows and os.environ.get("SR_DEFER_UNREAD_ROWS", "1") != "0"
+        # opt-in: do not compute the rows nothing reads (see _Plan.cat_passes); never on by default -- the reference computes them
+        self.elide_unread_rows = bool(getattr(args, "elide_unread_rows", os.environ.get("SR_ELIDE_UNREAD_ROWS", "0") != "0"))
         self._rest_done = None
         self._grad_pending = None
         self._phases = []
@@ -258,11 +267,14 @@ class SRConsistencyBase(AlgorithmBase):
         return TokenBatch.cat(batches)
 
     def _forward_passes(self, imgs, nl, nu, K):
-        key = (nl, nu, K, bool(self.use_cat))
+        key = (nl, nu, K, bool(self.use_cat), self.elide_unread_rows)
         if key not in self._plans:
+            if self.elide_unread_rows and not getattr(self.model, "rows_independent", False):
+                raise ValueError("elide_unread_rows needs a backbone without batch statistics (ViT / BERT / Wav2Vec2 engines)")
             self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
                                                 lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows,
-                                                rows_per_col=getattr(self.model.cfg, "num_tokens", None))
+                                                rows_per_col=getattr(self.model.cfg, "num_tokens", None),
+                                                elide_unread=self.elide_unread_rows)
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)

@@ -114,6 +114,7 @@ class TokenBatch:
 class ClassificationBert(PostLNEncoderMixin):
     couples_batch_rows = False
     takes_tokens = True
+    rows_independent = True       # LayerNorm only, counter-based dropout indexed per row
 
     def __init__(self, cfg=None, device="cuda", **kw):
         self.cfg = cfg if cfg is not None else BertConfig(**kw)

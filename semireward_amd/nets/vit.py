@@ -77,6 +77,7 @@ class FwdContext:
 
 class VisionTransformer:
     GEMM_WEIGHTS = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+    rows_independent = True       # LayerNorm only: a row's outputs do not depend on which other rows share the launch
 
     def __init__(self, cfg=None, device="cuda", **kw):
         self.cfg = cfg if cfg is not None else VitConfig(**kw)

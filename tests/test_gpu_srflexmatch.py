@@ -274,3 +274,47 @@ def test_full_size_step_properties():
     lg, _, ctx = m.forward_features(x, None, dp, save=True)
     m.zero_grad(); m.backward(ctx, 2.0 * dl); g2 = m.grad.clone()
     assert rel(g2.cpu(), (2.0 * g1).cpu().numpy()) < 2e-3        # bf16 rounding of the scaled output gradients is not exactly linear
+
+
+def test_elide_unread_rows_changes_no_result():
+    """Opt-in ``elide_unread_rows`` (never the default): the (pass, image) rows nothing reads are not computed.  Rows are independent in the
+    ViT engine, so every mask, every logit that IS read, the losses and the updated parameters must equal those of the full step."""
+    NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
+               num_warmup_iter=5120)
+    b = synth.synth_batch(101, 8, 8, 32, 100, 50000)
+    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
+    dps = [torch.from_numpy(synth.synth_droppath(700 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
+    res = []
+    for elide in (False, True):
+        alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
+        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+        alg.it = 30000
+        alg.optimizer.sched_step = alg.it
+        alg.elide_unread_rows = elide
+        alg.inject_droppath = dps
+        alg.trace = {}
+        p_init = alg.model.flat.clone()
+        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+        alg.call_hook("after_train_step")
+        torch.cuda.synchronize()
+        res.append((alg, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}, alg.model.flat.clone()))
+    (a0, l0, t0, p0), (a1, l1, t1, p1) = res
+    K, nl, nu = t0["K"], 8, 8
+    assert K == 8 and t1["K"] == 8
+    plan = a1._plans[(nl, nu, K, True, True)]
+    assert plan.inf_cols.numel() + plan.rest_cols.numel() + plan.grad_cols.numel() == 216 - K * nl - (K - 1) * nu
+    assert all(torch.equal(x, y) for x, y in zip(t0["masks"], t1["masks"]))
+    assert torch.equal(t0["pseudo"], t1["pseudo"]) and torch.equal(t0["max_probs"], t1["max_probs"])
+    assert torch.equal(t0["reward"], t1["reward"]) and torch.equal(t0["mask2"], t1["mask2"])
+    L0, L1 = t0["logits"], t1["logits"]
+    assert torch.equal(L0[:, nl:nl + nu], L1[:, nl:nl + nu])                 # weak rows of every pass
+    assert torch.equal(L0[0], L1[0]) and torch.equal(L0[K, nl + nu:], L1[K, nl + nu:])     # pass 0 complete; strong rows of the last pass
+    assert torch.equal(t0["feats"][0], t1["feats"][0])
+    for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
+        assert float(l0["train/" + k_]) == float(l1["train/" + k_]), k_
+    # fp32 atomics in the weight-gradient sums are unordered: a first-moment-free AdamW step is ~lr * sign(g), so a gradient within round-off
+    # of zero may flip -- at most twice the largest update of the step
+    assert float((p0 - p1).abs().max()) <= 2.1 * float((p0 - p_init).abs().max())
+    assert float((p0 - p1).abs().mean()) <= 1e-3 * float((p0 - p_init).abs().mean())
+    h0, h1 = a0.hooks_dict["MaskingHook"], a1.hooks_dict["MaskingHook"]
+    assert torch.equal(h0.selected_label, h1.selected_label) and torch.equal(h0.classwise_acc, h1.classwise_acc)
