@@ -236,6 +236,12 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
 // grid = (B*H, QS): blockIdx.y takes every QS-th group of BWD_NW query tiles (the backward batch is small -- 16 images --
 // so one workgroup per head would leave 60 % of the CUs idle).
 constexpr int BWD_NT = 512, BWD_NW = BWD_NT / 64;
+#ifdef SRHIP_TUNING
+__device__ long long srhip_attn_dbg[4 * 8192];
+#define DBG_T(i) do { if (threadIdx.x == 0) srhip_attn_dbg[4 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) + (i)] = wall_clock64(); } while (0)
+#else
+#define DBG_T(i) do { } while (0)
+#endif
 // VG = true (N > 288: K, V and K^T images no longer fit the 160 KB of LDS together): the V row fragments -- plain 16-byte row reads, the
 // A operand of dP = V . dO^T -- come straight from global memory / L2, software-pipelined one key-tile pair ahead.
 template <int NKT, bool VAR, bool VG>
@@ -275,6 +281,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t* __restrict__ qkv,
   if (!VG) stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
   stage_transposed_perm<NP, BWD_NT>(Kt, base + D, ld, N, tid);
   __syncthreads();
+  DBG_T(1);
   s16x8_t vg[2][2];                                   // VG: V fragments of key-tile pair u (rows >= N are clamped: their p is 0)
   auto vfetch = [&](int u_) {
 #pragma unroll
@@ -362,7 +369,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t* __restrict__ qkv,
 // backward, part 2: dK, dV.  One workgroup per (image, head); each wave owns 16-key tiles and
 // walks query-tile pairs:  S[q][key], dP[q][key] with the KEY on l15 ->
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]      dK^T[d][key] += Q^T[d][q] . dS[q][key]
-template <int NKT, bool VAR>
+// QG = true (N > 288: the four images no longer fit the LDS): the (q, dO) ROW fragments come from L2 instead, two query-tile pairs in flight.
+template <int NKT, bool VAR, bool QG>
 __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                   const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                   bf16_t* __restrict__ dqkv, int N, int H, float scale, AttnVar av) {
@@ -370,14 +378,25 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]  query-permuted + chunk-swizzled (stage_transposed_perm)
   bf16_t* dOt = Qt + 64 * TP;                         // [64][TP]
-  float* lse_s = reinterpret_cast<float*>(dOt + 64 * TP);   // [NP]  (already * log2e)
-  float* dl_s = lse_s + NP;                                 // [NP]
+  bf16_t* Qs = dOt + 64 * TP;                         // [NP][64]  chunk-swizzled rows (stage_rows_swz): the a-operands of S and dP
+  bf16_t* dOs = Qs + (QG ? 0 : NP * HD);              // [NP][64]  (both absent when QG)
+  float* lse_s = reinterpret_cast<float*>(dOs + (QG ? 0 : NP * HD));   // [NP]  (already * log2e)
+  float* dl_s = lse_s + NP;                                            // [NP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
   stage_transposed_perm<NP, BWD_NT>(Qt, base, ld, N, tid);
   stage_transposed_perm<NP, BWD_NT>(dOt, dobase, D, N, tid);
+  if (!QG) {
+    // Every wave walks ALL query tiles for its key tile: read from L2 that is 8 waves x 8 KB per step through the 64 B/clk vector-memory
+    // path of the CU (measured with wall-clock stamps: the loop of this pass took 38 us against 13 us for the dQ pass, which reads its
+    // fragments from LDS).  Rows >= N are zero.
+    stage_rows_swz<NP, BWD_NT>(Qs, base, ld, N, tid);
+    stage_rows_swz<NP, BWD_NT>(dOs, dobase, D, N, tid);
+  }
+  const int kc_ = g ^ ((l15 >> 1) & 7);
+  const int kof0 = l15 * HD + (kc_ << 3), kof1 = l15 * HD + ((kc_ ^ 4) << 3);
   const int vof = (threadIdx.x & 15) * TP + (((threadIdx.x >> 4 & 3) ^ swz4(threadIdx.x & 15)) << 3);
   // delta[q] = rowsum(dO[q] * O[q]) is recomputed here (64 MACs per query from rows that are L2-hot) instead of read from the dQ pass: the
   // two passes then have no dependency and share ONE launch (blockIdx.z picks the role) -- one launch less per layer on a latency-bound
@@ -398,6 +417,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
     dl_s[i] = dl;
   }
   __syncthreads();
+  DBG_T(1);
   const float sc2 = scale * LOG2E;
   const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
   for (int kt = blockIdx.y * BWD_NW + wave; kt < NKT; kt += BWD_NW * gridDim.y) {
@@ -409,9 +429,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
     f32x4_t dv[4], dk[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    // (q, dO) row fragments of query-tile pair u come straight from L2; pair u+1 is requested before pair u is used
-    s16x8_t fq[2][2], fd[2][2];
-    auto fetch = [&](int u_) {
+    // (q, dO) row fragments of query-tile pair u come straight from L2 (~1 us away when the chip is busy, an iteration is ~0.3 us):
+    // TWO pairs are in flight -- buffers A (even u) and B (odd u) -- so a pair is requested two iterations before it is used
+    // (one pair ahead: 51.6 us for the 16 gradient images, the loop sat on vmcnt every iteration).
+    s16x8_t fqa[2][2], fda[2][2], fqb[2][2], fdb[2][2];
+    auto fetch = [&](s16x8_t (&fq)[2][2], s16x8_t (&fd)[2][2], int u_) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int qc = min((2 * u_ + e) * 16 + l15, N - 1);
@@ -421,14 +443,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
         fd[e][0] = ld16(dop); fd[e][1] = ld16(dop + 32);
       }
     };
-    fetch(0);
-#pragma unroll 1
-    for (int u = 0; u < NKT / 2; ++u) {
+    auto body = [&](const s16x8_t (&cq)[2][2], const s16x8_t (&cd)[2][2], int u) {
       float pp[2][4], ds[2][4];
-      s16x8_t cq[2][2], cd[2][2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { cq[e][0] = fq[e][0]; cq[e][1] = fq[e][1]; cd[e][0] = fd[e][0]; cd[e][1] = fd[e][1]; }
-      if (u + 1 < NKT / 2) fetch(u + 1);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -463,6 +479,37 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
         dv[dt] = mfma16(ld16(dOt + off), pb, dv[dt]);
         dk[dt] = mfma16(ld16(Qt + off), dsb, dk[dt]);
       }
+    };
+    constexpr int NU = NKT / 2;
+    if (!QG) {
+#pragma unroll 1
+      for (int u = 0; u < NU; ++u) {
+        s16x8_t cq[2][2], cd[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ro = (2 * u + e) * 16 * HD;
+          cq[e][0] = ld16(Qs + ro + kof0); cq[e][1] = ld16(Qs + ro + kof1);
+          cd[e][0] = ld16(dOs + ro + kof0); cd[e][1] = ld16(dOs + ro + kof1);
+        }
+        body(cq, cd, u);
+      }
+    } else {
+      fetch(fqa, fda, 0);
+      if (NU > 1) fetch(fqb, fdb, 1);
+#pragma unroll 1
+      for (int u = 0; u < NU; u += 2) {
+        s16x8_t cq[2][2], cd[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { cq[e][0] = fqa[e][0]; cq[e][1] = fqa[e][1]; cd[e][0] = fda[e][0]; cd[e][1] = fda[e][1]; }
+        if (u + 2 < NU) fetch(fqa, fda, u + 2);
+        body(cq, cd, u);
+        if (u + 1 < NU) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { cq[e][0] = fqb[e][0]; cq[e][1] = fqb[e][1]; cd[e][0] = fdb[e][0]; cd[e][1] = fdb[e][1]; }
+          if (u + 3 < NU) fetch(fqb, fdb, u + 3);
+          body(cq, cd, u + 1);
+        }
+      }
     }
     if (key < N) {
       bf16_t* dkp = dqkv + ((size_t)b * N + key) * ld + D + h * HD + g * 4;
@@ -482,8 +529,11 @@ template <int NKT, bool VAR, bool VG>
 __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                       const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                       bf16_t* __restrict__ dqkv, float* __restrict__ delta, int N, int H, float scale, AttnVar av) {
+  DBG_T(0);
   if (blockIdx.z == 0) attn_bwd_dq_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
-  else attn_bwd_dkv_body<NKT, VAR>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
+  else attn_bwd_dkv_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
+  __syncthreads();
+  DBG_T(2);
 }
 
 template <typename F>
@@ -519,7 +569,7 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
     constexpr bool VG = NKT > 18;           // K + V + K^T images exceed the LDS: V fragments from L2
     const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
-    const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (size_t)2 * NP * 4;
+    const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (VG ? 0 : (size_t)2 * NP * HD * 2) + (size_t)2 * NP * 4;
     if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;
     auto kern = attn_bwd_kernel<NKT, VAR, VG>;
     const size_t sm = sm1 > sm2 ? sm1 : sm2;
@@ -541,6 +591,11 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
 
 }  // namespace
 
+#ifdef SRHIP_TUNING
+extern "C" int srhip_attn_debug(long long* out_host, int n) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(srhip_attn_dbg), (size_t)n * sizeof(long long)) == hipSuccess ? SR_OK : SR_EINVAL;
+}
+#endif
 extern "C" int srhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
   return attn_fwd_launch<false>(qkv, out, lse, B, N, H, scale, AttnVar{nullptr, 0u, 0u, 1.0f}, stream);
 }

@@ -106,6 +106,21 @@ def attn200():
     torch.cuda.synchronize()
 
 
+def attn_bwd(N=257, H=6):
+    """Attention backward of the gradient rows (16 images) and of a full launch."""
+    for B in (16, 43, 200):
+        D = H * 64
+        qkv = torch.randn(B * N, 3 * D, device=DEV).to(torch.bfloat16)
+        out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B, H, N, device=DEV)
+        ops.attn_fwd(qkv, out, lse, B, N, H, 0.125)
+        dout = torch.randn(B * N, D, device=DEV).to(torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, N, device=DEV)
+        t = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, dqkv, delta, B, N, H, 0.125), reps=50)
+        print("attn_bwd B=%4d  %8.1f us  %7.1f TF/s" % (B, t, 10.0 * N * N * 64 * B * H / t / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     for a in sys.argv[1:]:
         globals()[a]()
