@@ -108,6 +108,12 @@ __device__ __forceinline__ void stage_transposed_perm(bf16_t* dst, const bf16_t*
 // forward: grid = B*H workgroups of 512 threads (8 waves share the head's K / V^T: two workgroups per CU -> 4 waves per
 // SIMD, which is what hides the per-query-tile dependency chain ds_read -> MFMA -> max -> exp -> MFMA).
 // NKT = number of 16-key tiles (even), NP = 16*NKT.
+#ifdef SRHIP_TUNING
+__device__ long long srhip_attn_dbg[4 * 8192];
+#define DBG_T(i) do { if (threadIdx.x == 0) srhip_attn_dbg[4 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) + (i)] = wall_clock64(); } while (0)
+#else
+#define DBG_T(i) do { } while (0)
+#endif
 constexpr int FWD_NT = 512, FWD_NW = FWD_NT / 64;
 // dispatch_nkt instantiates NKT in {2, 8, 14, 18, 32} and picks the smallest >= ceil(N / 32) * 2: key tiles below the previous
 // size are always complete
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
   const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
   const float sc2 = scale * LOG2E;
   const int nqt = (N + 15) >> 4;
+  DBG_T(0);
   const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
   const int kc = g ^ ((l15 >> 1) & 7);                // chunk of k-slots 8g.. of this lane's key row; the other half is kc ^ 4
   const int kof0 = l15 * HD + (kc << 3), kof1 = l15 * HD + ((kc ^ 4) << 3);
@@ -145,6 +152,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
   stage_rows_swz<NP, FWD_NT>(Ks, base + D, ld, N, tid);
   stage_transposed_perm<NP, FWD_NT>(Vt, base + 2 * D, ld, N, tid);
   __syncthreads();
+  DBG_T(1);
   for (int qt = wv; qt < nqt; qt += FWD_NW) {
     const int q = qt * 16 + l15;
     const s16x8_t q0 = qn0, q1 = qn1;
@@ -227,6 +235,10 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       if (lse && g == 0) lse[((size_t)b * H + h) * N + q] = (mx * sc2 + log2f(sum)) * LN2;
     }
   }
+#ifdef SRHIP_TUNING
+  __syncthreads();
+  DBG_T(2);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,12 +248,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
 // grid = (B*H, QS): blockIdx.y takes every QS-th group of BWD_NW query tiles (the backward batch is small -- 16 images --
 // so one workgroup per head would leave 60 % of the CUs idle).
 constexpr int BWD_NT = 512, BWD_NW = BWD_NT / 64;
-#ifdef SRHIP_TUNING
-__device__ long long srhip_attn_dbg[4 * 8192];
-#define DBG_T(i) do { if (threadIdx.x == 0) srhip_attn_dbg[4 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) + (i)] = wall_clock64(); } while (0)
-#else
-#define DBG_T(i) do { } while (0)
-#endif
+
 // VG = true (N > 288: K, V and K^T images no longer fit the 160 KB of LDS together): the V row fragments -- plain 16-byte row reads, the
 // A operand of dP = V . dO^T -- come straight from global memory / L2, software-pipelined one key-tile pair ahead.
 template <int NKT, bool VAR, bool VG>

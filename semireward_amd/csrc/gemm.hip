@@ -120,6 +120,12 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
   }
 }
 
+#ifdef SRHIP_TUNING
+__device__ long long srhip_gemm_dbg[4 * 8192];
+#define GDBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) srhip_gemm_dbg[4 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define GDBG_T(i) do { } while (0)
+#endif
 // One 128x128 output tile, K-tiles [kt0, kt1).  smem: NS * STAGE elements (the kernel's ONE __shared__ object: a second
 // one makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline).
 template <int EPI>
@@ -204,6 +210,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
             __builtin_bit_cast(bf16x8_t, fa[nt]), __builtin_bit_cast(bf16x8_t, fb[mt]), acc[nt][mt], 0, 0, 0);
   }
 #undef ISSUE
+  GDBG_T(1);
 
   // ---- epilogue: lane holds C[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + r
 #pragma unroll
@@ -244,7 +251,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   // split-K (EPI_F32 only): blockIdx.y owns k-tiles [kt0, kt1); partial sums are combined with fp32 atomics
   const int kt0 = (int)blockIdx.y * g.ksplit_tiles, kt1 = min(g.K / BK, kt0 + g.ksplit_tiles);
+  GDBG_T(0);
   gemm_tile_body<EPI>(g, smem, (wg / ntn) * BM, (wg % ntn) * BN, kt0, kt1, gridDim.y > 1);
+  __syncthreads();
+  GDBG_T(2);
 }
 
 // Small-problem kernel: 64x64 output tile, 8-stage LDS-DMA ring (7 K-tiles = 56 KiB in flight per workgroup).
@@ -576,6 +586,11 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   return SR_OK;
 }
 
+#ifdef SRHIP_TUNING
+extern "C" int srhip_gemm_debug(long long* out_host, int n) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(srhip_gemm_dbg), (size_t)n * sizeof(long long)) == hipSuccess ? SR_OK : SR_EINVAL;
+}
+#endif
 extern "C" int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                              int M, int N, int K, const float* bias, const float* row_scale, int rows_per_sample,
                              const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, void* stream) {
