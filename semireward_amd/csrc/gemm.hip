@@ -32,6 +32,7 @@ struct GemmArgs {
   const bf16_t* aux_in;
   bf16_t* aux_out;
   int M, N, K, lda, ldb, ldc, ldaux, rows_per_sample, ksplit_tiles, debug;
+  int wide_store;                      // EPI_BF16: 16-byte stores after a lane-group exchange (N % 64 == 0, ldc % 8 == 0)
   float alpha, beta;
   uint32_t drop_key, drop_thresh;      // RESID epilogue: nn.Dropout on (acc + bias) before the residual add (drop_thresh == 0: none)
   float drop_scale;                    // 1 / (1 - p)
@@ -118,6 +119,52 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     }
     *cp = x;
   }
+}
+
+// The bf16 epilogues as a value: the packed output quad C[m][n..n+3] of one lane (bias, GELU / GELU', dropout applied; the GELU
+// pre-activation copy is stored on the way).  m is a valid row (callers clamp it for lanes past M; such lanes only take part in the exchange).
+template <int EPI>
+__device__ __forceinline__ u32x2_t epi_quad_bf16(const GemmArgs& g, int m, int n, float (&v)[4], bool row_ok) {
+  if (g.bias) {
+    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n);
+    v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+  }
+  if (EPI == SRHIP_EPI_GELU_BF16) {
+    if (g.aux_out && row_ok) {
+      u32x2_t p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *reinterpret_cast<u32x2_t*>(g.aux_out + (size_t)m * g.ldaux + n) = p;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+  } else if (EPI == SRHIP_EPI_DGELU_BF16) {
+    const u32x2_t p = *reinterpret_cast<const u32x2_t*>(g.aux_in + (size_t)m * g.ldaux + n);
+    const float pv[4] = {bf2f((bf16_t)(p[0] & 0xffff)), bf2f((bf16_t)(p[0] >> 16)), bf2f((bf16_t)(p[1] & 0xffff)), bf2f((bf16_t)(p[1] >> 16))};
+    if (g.drop_thresh) {
+      const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pv[r]);
+  }
+  if (EPI == SRHIP_EPI_GELU_BF16 && g.drop_thresh) {
+    const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+  }
+  return u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+
+// Widened bf16 stores.  A lane's quad is 8 bytes, so the plain epilogue issues one store of 16 rows x 32 B per 16x16 tile, and the stamps of
+// the tuning build put 5 us of a 12-us 128x128 tile there -- store ISSUE, not bandwidth.  v_permlane16_swap trades the quads of two
+// neighbouring 16-column tiles (a, b) between lane groups 1 <-> 0 and 3 <-> 2: afterwards groups 0 / 2 hold columns 0-7 / 8-15 of tile a and
+// groups 1 / 3 the same of tile b -- ONE 16-byte store per lane and tile pair (lane semantics probed on hardware).  Every lane executes the
+// exchange (it is wave-wide); only the store is predicated on the row.  nb = first column of tile a.
+__device__ __forceinline__ void store_quad_pair(bf16_t* C, int ldc, int m, bool row_ok, int nb, int lg, u32x2_t qa, u32x2_t qb) {
+  const auto rx = __builtin_amdgcn_permlane16_swap(qa[0], qb[0], false, false);
+  const auto ry = __builtin_amdgcn_permlane16_swap(qa[1], qb[1], false, false);
+  const int col = nb + (lg & 1) * 16 + (lg >> 1) * 8;
+  if (row_ok) *reinterpret_cast<u32x4_t*>(C + (size_t)m * ldc + col) = u32x4_t{rx[0], ry[0], rx[1], ry[1]};
 }
 
 #ifdef SRHIP_TUNING
@@ -213,6 +260,25 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
   GDBG_T(1);
 
   // ---- epilogue: lane holds C[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + r
+  if ((EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16) && g.wide_store) {
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int mr = m0 + wm * 64 + mt * 16 + l15, m = min(mr, g.M - 1);
+#pragma unroll
+      for (int np = 0; np < 2; ++np) {
+        u32x2_t q[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int nt = 2 * np + e;
+          float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+          q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * 64 + nt * 16 + lg * 4, v, mr < g.M);
+        }
+        store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + wn * 64 + np * 32, lg, q[0], q[1]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + l15;
@@ -328,6 +394,21 @@ __global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g) {
             __builtin_bit_cast(bf16x8_t, fa[nt]), __builtin_bit_cast(bf16x8_t, fb[mt]), acc[nt][mt], 0, 0, 0);
   }
 #undef SISSUE
+  if ((EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16) && g.wide_store) {
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int mr = m0 + wm * 32 + mt * 16 + l15, m = min(mr, g.M - 1);
+      u32x2_t q[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float v[4] = {acc[e][mt][0], acc[e][mt][1], acc[e][mt][2], acc[e][mt][3]};
+        q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * 32 + e * 16 + lg * 4, v, mr < g.M);
+      }
+      store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + wn * 32, lg, q[0], q[1]);
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int m = m0 + wm * 32 + mt * 16 + l15;
@@ -465,6 +546,26 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
                                                             acc[i][j], 0, 0, 0);
     if (++ck == nk) {
       const int m0 = (ct / ntn) * GBM, n0 = (ct % ntn) * GBN;
+      if ((EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16) && g.wide_store &&
+          n0 + GBN <= g.N) {                      // (wave-uniform: full column tiles only; the ragged last one takes the plain path)
+        bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int mr = m0 + wm * 64 + mt * 16 + l15, m = min(mr, g.M - 1);
+#pragma unroll
+          for (int np = 0; np < NTW / 2; ++np) {
+            u32x2_t q[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int i = 2 * np + e;
+              float v[4] = {acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]};
+              acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+              q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * (16 * NTW) + i * 16 + lg * 4, v, mr < g.M);
+            }
+            store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + wn * (16 * NTW) + np * 32, lg, q[0], q[1]);
+          }
+        }
+      } else {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm * 64 + mt * 16 + l15;
@@ -477,6 +578,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
           acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           if (m < g.M && n < g.N) epi_store<EPI>(g, m, n, v, rs, false);
         }
+      }
       }
       ck = 0;
       ct += gridDim.x;
@@ -521,6 +623,10 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   g.drop_key = drop_key; g.drop_thresh = drop_thresh; g.drop_scale = drop_scale;
   static const int dbg = getenv("SRHIP_DEBUG") ? atoi(getenv("SRHIP_DEBUG")) : 0;
   g.debug = dbg;
+  static const bool no_wide = getenv("SRHIP_NO_WIDE_STORE") != nullptr;
+  // (N % 128 == 0: no ragged column tile in the 128- and 64-column kernels; the persistent kernel checks its own last tile)
+  g.wide_store = (epilogue == SRHIP_EPI_BF16 || epilogue == SRHIP_EPI_GELU_BF16 || epilogue == SRHIP_EPI_DGELU_BF16) && !no_wide && !(dbg & 1) &&
+                 (N % 128) == 0 && (ldc % 8) == 0 && (epilogue != SRHIP_EPI_GELU_BF16 || !aux_out || (ldaux % 4) == 0);
   const int grid = cdiv(M, BM) * cdiv(N, BN);
   hipStream_t s = (hipStream_t)stream;
   // split-K: weight-gradient products (small M x N, long K = tokens) would otherwise fill a few dozen of the 256 CUs.
