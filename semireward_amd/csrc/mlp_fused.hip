@@ -73,6 +73,12 @@ struct MlpArgs {
 };
 
 // DBG (tuning builds only, SRHIP_MLP_DEBUG): 1 = no GELU, 2 = no DMA / no vmcnt waits, 4 = no ds_reads, 8 = no MFMA
+#ifdef SRHIP_TUNING
+__device__ long long srhip_mlp_dbg[4 * 1024];
+#define MDBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) srhip_mlp_dbg[4 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define MDBG_T(i) do { } while (0)
+#endif
 template <int D_, int DBG, int GS>
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   constexpr int KS1 = D_ / BK;            // 12 k-steps of GEMM1
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m = tile * FBM + wave * 16 + l15;
     const int mc = min(m, a.M - 1);
+    MDBG_T(0);
     // ---- LayerNorm of the wave's 16 rows, straight into MFMA B-fragments: lane holds x[m][32 s + 8 g .. +7], s = 0..11
     u32x4_t xn[KS1];
     {
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       for (int k = 0; k < KS1; ++k) *reinterpret_cast<u32x4_t*>(lr + 32 * k) = xn[k];
     }
     __syncthreads();                       // previous tile's ring reads are over (and sb1/sb2 are written)
+    MDBG_T(1);
 #pragma unroll
     for (int p = 0; p < PD; ++p) issue(p / SPC, p % SPC, p);   // groups 0 .. NG-3
 
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
         read_half(std::integral_constant<int, jn>{}, H0{}, cn);  // (one stage past the end: a stale slot, never multiplied)
         mfma_half(jc, H1{}, c);
       });
+    MDBG_T(2);
     // ---- epilogue: lane holds y[m][16 t + 4 g + r]
     if (m < a.M) {
       const float rsc = a.row_scale ? a.row_scale[m / a.rows_per_sample] : 1.0f;
@@ -330,12 +339,22 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
         *reinterpret_cast<f32x4_t*>(xw + 16 * t) = xv;
       }
     }
+#ifdef SRHIP_TUNING
+    __builtin_amdgcn_s_waitcnt(0);          // stores issued AND acknowledged
+    __syncthreads();
+    MDBG_T(3);
+#endif
   }
 }
 
 
 }  // namespace
 
+#ifdef SRHIP_TUNING
+extern "C" int srhip_mlp_debug(long long* out_host, int n) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(srhip_mlp_dbg), (size_t)n * sizeof(long long)) == hipSuccess ? SR_OK : SR_EINVAL;
+}
+#endif
 extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const float* ln_beta, float eps, const void* W1,
                                const float* b1, const void* W2, const float* b2, const float* row_scale, int rows_per_sample,
                                int save_rows, void* save_ln2, void* save_pre, void* save_h, float* save_mean, float* save_rstd,
