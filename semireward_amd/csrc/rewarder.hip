@@ -99,12 +99,20 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ WT, const 
   float acc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-#pragma unroll 4
-  for (int k = k0; k < k1; ++k) {
-    const float w = WT[(size_t)k * J + j];
-    const float4 xa = *reinterpret_cast<const float4*>(xT + k * RT), xb = *reinterpret_cast<const float4*>(xT + k * RT + 4);
-    acc[0] += w * xa.x; acc[1] += w * xa.y; acc[2] += w * xa.z; acc[3] += w * xa.w;
-    acc[4] += w * xb.x; acc[5] += w * xb.y; acc[6] += w * xb.z; acc[7] += w * xb.w;
+  // 16 weight loads in flight per thread: the k loop is a chain of L2 round trips (~0.7 us each) -- with 4 per trip the three layers of the
+  // score kernel took 72 trips = 51 us for 64 rows; same summation order, so the results do not change.
+  constexpr int CH = 16;
+  for (int kb = k0; kb < k1; kb += CH) {
+    float w[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) w[c] = (kb + c < k1) ? WT[(size_t)(kb + c) * J + j] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = min(kb + c, k1 - 1);           // (past the end: weight 0 on a valid LDS row)
+      const float4 xa = *reinterpret_cast<const float4*>(xT + k * RT), xb = *reinterpret_cast<const float4*>(xT + k * RT + 4);
+      acc[0] += w[c] * xa.x; acc[1] += w[c] * xa.y; acc[2] += w[c] * xa.z; acc[3] += w[c] * xa.w;
+      acc[4] += w[c] * xb.x; acc[5] += w[c] * xb.y; acc[6] += w[c] * xb.z; acc[7] += w[c] * xb.w;
+    }
   }
   if (NP > 1) {
     __syncthreads();
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict_
   {
     const int j = threadIdx.x & (E - 1), half = threadIdx.x >> 7;
     float a = 0.f;
+#pragma unroll 8
     for (int i = half; i < 2 * B; i += 2) a += expf(sl[i] - mx) * inv * z[(size_t)i * E + j];
     if (half == 1) scratch[j] = a;
     __syncthreads();
