@@ -121,6 +121,24 @@ def attn_bwd(N=257, H=6):
         print("attn_bwd B=%4d  %8.1f us  %7.1f TF/s" % (B, t, 10.0 * N * N * 64 * B * H / t / 1e6), flush=True)
 
 
+def attn_bert(N=512, H=12):
+    """BERT-base attention (padding mask + probability dropout), forward and backward, 8 and 40 sequences."""
+    for B in (8, 40):
+        D = H * 64
+        qkv = torch.randn(B * N, 3 * D, device=DEV).to(torch.bfloat16)
+        out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B, H, N, device=DEV)
+        kl = torch.full((B,), N, dtype=torch.int32, device=DEV)
+        dr = ops.Drop(1234, 0, 0.1)
+        t = timeit(lambda: ops.attn_masked_fwd(qkv, out, lse, kl, B, N, H, 0.125, dr), reps=30)
+        print("attn_masked_fwd B=%3d  %8.1f us  %7.1f TF/s" % (B, t, 4.0 * N * N * 64 * B * H / t / 1e6), flush=True)
+        dout = torch.randn(B * N, D, device=DEV).to(torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, N, device=DEV)
+        t = timeit(lambda: ops.attn_masked_bwd(qkv, out, dout, lse, dqkv, delta, kl, B, N, H, 0.125, dr), reps=30)
+        print("attn_masked_bwd B=%3d  %8.1f us  %7.1f TF/s" % (B, t, 10.0 * N * N * 64 * B * H / t / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     for a in sys.argv[1:]:
         globals()[a]()
