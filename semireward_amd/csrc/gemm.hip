@@ -38,7 +38,7 @@ struct GemmArgs {
   float drop_scale;                    // 1 / (1 - p)
 };
 
-constexpr int BM = 128, BN = 128, BK = 32, NS = 4, PD = NS - 1;
+constexpr int BM = 128, BN = 128, BK = 32, NS = 3, PD = NS - 1;
 constexpr int TILE = BM * BK;            // elements of one operand tile of one stage
 constexpr int STAGE = 2 * TILE;          // A tile then B tile
 
@@ -239,7 +239,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most min(rem, PD-1) younger tiles (4 DMA ops each) are still outstanding
     const int rem = nk - 1 - kt;
-    if (rem >= 2) WAIT_VM(8); else if (rem == 1) WAIT_VM(4); else WAIT_VM(0);
+    if (PD >= 3 && rem >= 2) WAIT_VM(8); else if (PD >= 2 && rem >= 1) WAIT_VM(4); else WAIT_VM(0);
     __builtin_amdgcn_s_barrier();       // every wave's share of tile kt is in LDS; stage (kt-1)%NS is no longer read
     if (kt + PD < nk) { ISSUE(kt0 + kt + PD, (kt + PD) % NS) }
     const bf16_t* st = smem + (kt % NS) * STAGE;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
   const int ntn = (g.N + BN - 1) / BN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
