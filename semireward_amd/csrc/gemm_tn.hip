@@ -24,7 +24,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE = BK * BM;            // 4096 bf16 = 8 KiB: [32 tokens][128 features]
 constexpr int STAGE = 2 * TILE;          // A tile then B tile
-constexpr int NS = 4, PD = NS - 1;
+constexpr int NS = 3, PD = NS - 1;
 
 typedef __attribute__((address_space(3))) void lds_void;
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -36,7 +36,7 @@ __device__ __forceinline__ u32x2_t ds_read_tr16(const bf16_t* p) {
   return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_f32_kernel(const srhip_group_tn_desc* __restrict__ desc, int n_problems,
+__global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip_group_tn_desc* __restrict__ desc, int n_problems,
                                                                      float alpha, float beta) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_f32_kernel(const srhip
     if (q < nk) { ISSUE(q, q) }
   for (int kt = 0; kt < nk; ++kt) {
     const int rem = nk - 1 - kt;
-    if (rem >= 2) WAIT_VM(8); else if (rem == 1) WAIT_VM(4); else WAIT_VM(0);
+    if (PD >= 3 && rem >= 2) WAIT_VM(8); else if (PD >= 2 && rem >= 1) WAIT_VM(4); else WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     if (kt + PD < nk) { ISSUE(kt + PD, (kt + PD) % NS) }
     const bf16_t* st = smem + (kt % NS) * STAGE;
