@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmArgs g) {
 // The backward of the 16 gradient-carrying images is made of M = 4112-row products: on 128x128 tiles they give 99-400
 // workgroups whose K loop is a chain of ~2 us global->LDS round trips (3 in flight): 15-22 us for 3-7 GFLOP.  Four times as
 // many workgroups with more than twice the bytes in flight each turn that into one latency + a short MFMA tail.
-constexpr int SBM = 64, SNS = 8, SPD = SNS - 1, STILE = SBM * BK, SSTAGE = 2 * STILE;
+constexpr int SBM = 64, SNS = 5, SPD = SNS - 1, STILE = SBM * BK, SSTAGE = 2 * STILE;
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_small_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void gemm_small_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[SNS * SSTAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
