@@ -131,6 +131,11 @@ int srhip_patch_embed_fwd(const float* img, const int* img_index, const float* W
 /* all outputs are accumulated (+=). */
 int srhip_patch_embed_bwd(const float* dx, const float* img, const int* img_index, float* dWp, float* dbp, float* dcls,
                           float* dpos, int B, int C, int HW, int ps, int D, void* stream);
+/* The same without atomics on the filter: per-(token chunk, image) partial sums in ws (srhip_patch_embed_bwd_ws_floats(...) floats), folded
+ * by a second launch in a fixed order (deterministic; the one-launch form ends every workgroup in D * (K + 1) same-address atomics). */
+long srhip_patch_embed_bwd_ws_floats(int B, int C, int HW, int ps, int D);
+int srhip_patch_embed_bwd_ws(const float* dx, const float* img, const int* img_index, float* dWp, float* dbp, float* dcls,
+                             float* dpos, float* ws, int B, int C, int HW, int ps, int D, void* stream);
 
 /* Large-patch PatchEmbed (C * ps * ps > 64, e.g. ViT-S/16 at 224 x 224, vit.py:358-371): the conv of vit.py:39-44 as a GEMM.
  *   patch_im2col : col[b * Np + p][(c,i,j)] = img[img_index[b]][c][py*ps+i][px*ps+j] as bf16 (ps even); then

@@ -31,6 +31,8 @@ SIGNATURES = {
     "srhip_mlp_fused": (I, [P, P, P, P, F, P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_patch_embed_bwd_ws_floats": (L, [I, I, I, I, I]),
+    "srhip_patch_embed_bwd_ws": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_im2col": (I, [P, P, P, I, I, I, I, P]),
     "srhip_patch_assemble": (I, [P, P, P, P, P, I, I, I, P]),
     "srhip_patch_grad_operands": (I, [P, P, P, P, I, I, I, P]),

@@ -470,8 +470,9 @@ class VisionTransformer:
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         Kp = cfg.in_chans * cfg.patch_size ** 2
         if Kp <= 64:
-            ops.patch_embed_bwd(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
-                                G("pos_embed"), B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
+            ws = self._buf("b_pe_ws", (ops.patch_embed_bwd_ws_floats(B, cfg.in_chans, cfg.img_size, cfg.patch_size, D),), f32)
+            ops.patch_embed_bwd_ws(dx, ctx.img, ctx.img_index, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), G("cls_token"),
+                                   G("pos_embed"), ws, B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
         else:                                       # dWp += dx_tok^T col, dbp += colsum dx_tok (TN grouped GEMM, one problem); dpos, dcls
             Np = N - 1
             key = ("pebwd", B)

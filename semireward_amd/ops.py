@@ -240,6 +240,15 @@ def patch_embed_bwd(dx, img, img_index, dWp, dbp, dcls, dpos, B, C, HW, ps, D):
     _call("srhip_patch_embed_bwd", _p(dx), _p(img), _p(img_index), _p(dWp), _p(dbp), _p(dcls), _p(dpos), B, C, HW, ps, D, _s())
 
 
+def patch_embed_bwd_ws_floats(B, C, HW, ps, D):
+    return int(_lib.lib().srhip_patch_embed_bwd_ws_floats(B, C, HW, ps, D))
+
+
+def patch_embed_bwd_ws(dx, img, img_index, dWp, dbp, dcls, dpos, ws, B, C, HW, ps, D):
+    """patch_embed_bwd through per-workgroup partial sums in ``ws`` (fp32, patch_embed_bwd_ws_floats elements): no atomics, fixed order."""
+    _call("srhip_patch_embed_bwd_ws", _p(dx), _p(img), _p(img_index), _p(dWp), _p(dbp), _p(dcls), _p(dpos), _p(ws), B, C, HW, ps, D, _s())
+
+
 def patch_im2col(img, img_index, out, B, C, HW, ps):
     _call("srhip_patch_im2col", _p(img), _p(img_index), _p(out), B, C, HW, ps, _s())
 
