@@ -187,6 +187,11 @@ int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max
 int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
                          long long* selected_label, int* hist, float* classwise_acc, float* mask, int B, int C,
                          int ulb_dest_len, int thresh_warmup, void* stream);
+/* n_pass consecutive masking calls on the same idx_ulb (the data_generator passes of one step, srflexmatch.py:75-104) in one launch, in
+ * order: max_probs / max_idx / mask are [n_pass, B]; identical to n_pass srhip_flexmatch_mask calls. */
+int srhip_flexmatch_mask_passes(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
+                                long long* selected_label, int* hist, float* classwise_acc, float* mask, int n_pass, int B, int C,
+                                int ulb_dest_len, int thresh_warmup, void* stream);
 int srhip_flexmatch_rebuild_hist(const long long* selected_label, int* hist, int ulb_dest_len, int C, void* stream);
 /* FixedThresholdingHook.masking (semilearn/algorithms/hooks/masking.py:42-57). */
 int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "srhip_droppath_fill": (I, [P, P, I, I, c_ulonglong, P]),
     "srhip_row_max": (I, [P, I, P, P, P, I, I, P]),
     "srhip_flexmatch_mask": (I, [P, P, P, F, P, P, P, P, I, I, I, I, P]),
+    "srhip_flexmatch_mask_passes": (I, [P, P, P, F, P, P, P, P, I, I, I, I, I, P]),
     "srhip_flexmatch_rebuild_hist": (I, [P, P, I, I, P]),
     "srhip_fixed_mask": (I, [P, F, P, I, P]),
     "srhip_freematch_stats": (I, [P, P, P, P, I, I, P]),

@@ -73,6 +73,16 @@ class FlexMatchThresholdingHook(MaskingHook):
         return mask
 
     @torch.no_grad()
+    def masking_passes(self, algorithm, max_probs, max_idx, idx_ulb, n_pass):
+        """The masking calls of the n_pass data_generator passes of one step (same idx_ulb, pass order) in one launch: [n_pass * nu] in,
+        list of n_pass masks out; state ends where n_pass ``masking_from_max`` calls would leave it."""
+        mask = torch.empty_like(max_probs)
+        nu = max_probs.numel() // n_pass
+        ops.flexmatch_mask_passes(max_probs, max_idx, idx_ulb.contiguous(), float(algorithm.p_cutoff), self._sel, self.hist,
+                                  self.classwise_acc, mask, n_pass, nu, self.num_classes, self.ulb_dest_len, self.thresh_warmup)
+        return [mask[k * nu:(k + 1) * nu] for k in range(n_pass)]
+
+    @torch.no_grad()
     def masking(self, algorithm, logits_x_ulb, idx_ulb, softmax_x_ulb=True, *a, **k):
         mp, mi = _row_max(logits_x_ulb, is_probs=not softmax_x_ulb)
         return self.masking_from_max(algorithm, mp, mi, idx_ulb)

@@ -415,7 +415,7 @@ class SRFlexMatch(SRConsistencyBase):
     def _masks(self, mp, mi, idx_ulb, P, nu, weak_logits=None):
         # order dependent (mutates selected_label / classwise_acc): pass 0 first, then the K loop passes
         hook = self.hooks_dict["MaskingHook"]
-        return [hook.masking_from_max(self, mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], idx_ulb) for k in range(P)]
+        return hook.masking_passes(self, mp, mi, idx_ulb, P)        # one launch, the passes in order inside it
 
     def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
         with self._step_scope():

@@ -63,46 +63,55 @@ __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ 
 //   mask[i]   = max_p[i] >= p_cutoff * (acc[idx] / (2 - acc[idx]))          (utils.py:53, BEFORE the update)
 //   select[i] = max_p[i] >= p_cutoff ; selected_label[idx_ulb[i]] = max_idx[i]   (utils.py:56-60)
 //   hist bookkeeping, then classwise_acc update                                (utils.py:24-35)
+// n_pass > 1: the passes of one SemiReward step (srflexmatch.py:75-104 calls masking once per data_generator pass, on the SAME idx_ulb) in
+// ONE launch, in order -- pass p reads the state pass p-1 left.  State written by one pass is re-read through device-scope loads.
 __global__ __launch_bounds__(256) void flexmatch_mask_kernel(const float* __restrict__ max_probs, const long long* __restrict__ max_idx,
                                                             const long long* __restrict__ idx_ulb, float p_cutoff,
                                                             long long* __restrict__ selected_label, int* __restrict__ hist,
                                                             float* __restrict__ classwise_acc, float* __restrict__ mask,
-                                                            int B, int C, int ulb_dest_len, int thresh_warmup) {
+                                                            int B, int C, int ulb_dest_len, int thresh_warmup, int n_pass) {
   __shared__ int smax[2];
-  for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    const float mp = max_probs[i];
-    const int cls = (int)max_idx[i];
-    const float acc = classwise_acc[cls];
-    const float den = 2.0f - acc;
-    const float rat = acc / den;
-    const float thr = p_cutoff * rat;
-    mask[i] = mp >= thr ? 1.0f : 0.0f;
-    if (mp >= p_cutoff) {
-      const long long j = idx_ulb[i];
-      const long long old = selected_label[j];
-      if (old != cls) {
-        selected_label[j] = cls;
-        atomicSub(hist + (old < 0 ? C : (int)old), 1);
-        atomicAdd(hist + cls, 1);
+  for (int p = 0; p < n_pass; ++p) {
+    const float* mpp = max_probs + (size_t)p * B;
+    const long long* mip = max_idx + (size_t)p * B;
+    float* mk = mask + (size_t)p * B;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      const float mp = mpp[i];
+      const int cls = (int)mip[i];
+      const float acc = __hip_atomic_load(classwise_acc + cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float den = 2.0f - acc;
+      const float rat = acc / den;
+      const float thr = p_cutoff * rat;
+      mk[i] = mp >= thr ? 1.0f : 0.0f;
+      if (mp >= p_cutoff) {
+        const long long j = idx_ulb[i];
+        const long long old = __hip_atomic_load(selected_label + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old != cls) {
+          __hip_atomic_store(selected_label + j, (long long)cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicSub(hist + (old < 0 ? C : (int)old), 1);
+          atomicAdd(hist + cls, 1);
+        }
       }
     }
-  }
-  if (threadIdx.x < 2) smax[threadIdx.x] = 0;
-  __threadfence_block();
-  __syncthreads();
-  int m = 0;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) m = max(m, __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  atomicMax(&smax[0], m);
-  __syncthreads();
-  if (threadIdx.x == 0) smax[1] = max(smax[0], __hip_atomic_load(hist + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  __syncthreads();
-  const int max_all = smax[1];
-  if (max_all < ulb_dest_len) {
-    const int den = thresh_warmup ? max_all : smax[0];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      const int cnt = __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      classwise_acc[c] = (float)((double)cnt / (double)den);
+    if (threadIdx.x < 2) smax[threadIdx.x] = 0;
+    __threadfence();
+    __syncthreads();
+    int m = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) m = max(m, __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    atomicMax(&smax[0], m);
+    __syncthreads();
+    if (threadIdx.x == 0) smax[1] = max(smax[0], __hip_atomic_load(hist + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const int max_all = smax[1];
+    if (max_all < ulb_dest_len) {
+      const int den = thresh_warmup ? max_all : smax[0];
+      for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int cnt = __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(classwise_acc + c, (float)((double)cnt / (double)den), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+    __threadfence();
+    __syncthreads();                  // the next pass reads classwise_acc / selected_label / hist; smax is reset after this point
   }
 }
 
@@ -386,7 +395,16 @@ extern "C" int srhip_flexmatch_mask(const float* max_probs, const long long* max
                                     int ulb_dest_len, int thresh_warmup, void* stream) {
   if (B <= 0 || C <= 0 || ulb_dest_len <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
-                     selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup);
+                     selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, 1);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_flexmatch_mask_passes(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
+                                           long long* selected_label, int* hist, float* classwise_acc, float* mask, int n_pass, int B, int C,
+                                           int ulb_dest_len, int thresh_warmup, void* stream) {
+  if (n_pass <= 0 || B <= 0 || C <= 0 || ulb_dest_len <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
+                     selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

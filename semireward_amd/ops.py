@@ -319,6 +319,13 @@ def flexmatch_mask(max_probs, max_idx, idx_ulb, p_cutoff, selected_label, hist, 
           _p(classwise_acc), _p(mask), B, C, ulb_dest_len, int(thresh_warmup), _s())
 
 
+def flexmatch_mask_passes(max_probs, max_idx, idx_ulb, p_cutoff, selected_label, hist, classwise_acc, mask, n_pass, B, C, ulb_dest_len,
+                          thresh_warmup):
+    """n_pass masking calls in pass order in one launch; max_probs / max_idx / mask are [n_pass * B]."""
+    _call("srhip_flexmatch_mask_passes", _p(max_probs), _p(max_idx), _p(idx_ulb), p_cutoff, _p(selected_label), _p(hist),
+          _p(classwise_acc), _p(mask), n_pass, B, C, ulb_dest_len, int(thresh_warmup), _s())
+
+
 def flexmatch_rebuild_hist(selected_label, hist, ulb_dest_len, C):
     _call("srhip_flexmatch_rebuild_hist", _p(selected_label), _p(hist), ulb_dest_len, C, _s())
 

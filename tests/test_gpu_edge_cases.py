@@ -161,3 +161,28 @@ def test_masked_ce_empty_full_and_extreme(B, C):
     tg = tl.clone().requires_grad_(True)
     H.consistency_loss(tg, ty, m).backward()
     np.testing.assert_allclose(d[B - 1], 0.5 * tg.grad.numpy()[B - 1], rtol=2e-5, atol=1e-8)
+
+
+def test_flexmatch_passes_in_one_launch_equal_sequential_calls():
+    """srhip_flexmatch_mask_passes == the same passes as separate srhip_flexmatch_mask launches (masks and state bit-identical), and both
+    equal the oracle; the passes share idx_ulb and later passes re-select indices the earlier ones selected."""
+    C, U, nu, P = 10, 64, 8, 9
+    g = np.random.Generator(np.random.PCG64(21))
+    idx = g.permutation(U)[:nu].astype(np.int64)
+    probs = [g.dirichlet(np.full(C, 0.03), size=nu).astype(F32) for _ in range(P)]
+    for warm in (True, False):
+        state = H.FlexMatchState(U, C, warm)
+        want = [state.masking(pr, idx, 0.95) for pr in probs]
+        mp = _dev(np.concatenate([pr.max(-1) for pr in probs]))
+        mi = _dev(np.concatenate([pr.argmax(-1) for pr in probs]).astype(np.int64))
+        sel, hist, acc = _flex_engine(C, U, warm)
+        mask = torch.empty(P * nu, device=DEV)
+        ops.flexmatch_mask_passes(mp, mi, _dev(idx), 0.95, sel, hist, acc, mask, P, nu, C, U, warm)
+        assert np.array_equal(mask.cpu().numpy().reshape(P, nu), np.stack(want))
+        assert np.array_equal(sel.cpu().numpy(), state.selected_label)
+        assert np.array_equal(acc.cpu().numpy().view(np.uint32), state.classwise_acc.view(np.uint32))
+        sel2, hist2, acc2 = _flex_engine(C, U, warm)
+        m2 = torch.empty(P * nu, device=DEV)
+        for k in range(P):
+            ops.flexmatch_mask(mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], _dev(idx), 0.95, sel2, hist2, acc2, m2[k * nu:(k + 1) * nu], nu, C, U, warm)
+        assert torch.equal(mask, m2) and torch.equal(sel, sel2) and torch.equal(acc, acc2) and torch.equal(hist, hist2)
