@@ -1,16 +1,31 @@
 """Torch-tensor front end of the C ABI (include/srhip.h).  Torch is plumbing only: it owns device
 memory and the stream; every op below is a hand-written HIP kernel in libsrhip.so.  No fallbacks."""
+import os
+
 import torch
 
 from . import _lib
 from ._lib import EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32  # noqa: F401
 
 
-def _p(t):
+# Argument checks cost 0.3 us per pointer x ~4500 pointers per training step = 1.3 ms of host time, which is what bounds the step once the GPU
+# side drops below ~5 ms (bench.py --elide-unread-rows).  The engine only passes tensors it allocated itself; SRHIP_CHECK_ARGS=1 (set by
+# tests/conftest.py, so every test run validates every call) turns the contiguity / device asserts back on.
+_CHECK_ARGS = os.environ.get("SRHIP_CHECK_ARGS", "0") != "0"
+
+
+def _p_checked(t):
     if t is None:
         return None
     assert t.is_cuda and t.is_contiguous(), "libsrhip needs contiguous device tensors"
     return t.data_ptr()
+
+
+def _p_fast(t):
+    return None if t is None else t.data_ptr()
+
+
+_p = _p_checked if _CHECK_ARGS else _p_fast
 
 
 _STREAM = None
@@ -35,8 +50,16 @@ class stream_scope:
         _STREAM = self.prev
 
 
+_FN = {}
+
+
 def _call(name, *args):
-    _lib.check(getattr(_lib.lib(), name)(*args), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        _lib.check(rc, name)
 
 
 # ---- optional live profiling of the dominant kernel (bench.py roofline object) -------------------
