@@ -94,12 +94,15 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   float* sb1 = reinterpret_cast<float*>(sm + NS * TILE_EL);
   float* sb2 = sb1 + a.Hd;
+  float* sgam = sb2 + D_;                 // LayerNorm affine, read per k-step in the prologue: 48 16-byte reads per lane that came from
+  float* sbet = sgam + D_;                // L1 / L2 in groups of 8 behind a scheduling barrier = six exposed round trips per tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA destinations (M0) stay scalar arithmetic
   const int l15 = lane & 15, lg = lane >> 4;
   const int nch = a.Hd / CH;
   for (int i = tid; i < a.Hd; i += 512) sb1[i] = a.b1[i];
-  for (int i = tid; i < D_; i += 512) sb2[i] = a.b2[i];
+  for (int i = tid; i < D_; i += 512) { sb2[i] = a.b2[i]; sgam[i] = a.gamma[i]; sbet[i] = a.beta[i]; }
+  __syncthreads();
 
   // ---- producer: one LDS-DMA instruction (16 LDS rows x 64 B) per wave and stage.  Buffer addressing: (SGPR resource
   // descriptor) + (32-bit per-lane byte offset) + (uniform byte offset in an SGPR); num_records = the weight's size, so an
@@ -169,10 +172,10 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       if (a.save_rows > 0 && m < a.save_rows && lg == 0) { a.s_mean[m] = mu; a.s_rstd[m] = rs; }
 #pragma unroll
       for (int k = 0; k < KS1; ++k) {
-        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(a.gamma + 32 * k + 8 * lg);
-        const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(a.gamma + 32 * k + 8 * lg + 4);
-        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(a.beta + 32 * k + 8 * lg);
-        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(a.beta + 32 * k + 8 * lg + 4);
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(sgam + 32 * k + 8 * lg);
+        const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(sgam + 32 * k + 8 * lg + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sbet + 32 * k + 8 * lg);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sbet + 32 * k + 8 * lg + 4);
         const f32x4_t p = v[2 * k], r = v[2 * k + 1];
         xn[k] = u32x4_t{pack_bf2((p[0] - mu) * rs * g0[0] + b0[0], (p[1] - mu) * rs * g0[1] + b0[1]),
                         pack_bf2((p[2] - mu) * rs * g0[2] + b0[2], (p[3] - mu) * rs * g0[3] + b0[3]),
@@ -372,7 +375,7 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
   a.save_rows = save_rows;
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + D) * sizeof(float);
+  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 3 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4>;
 #ifdef SRHIP_TUNING
   switch (getenv("SRHIP_MLP_DEBUG") ? atoi(getenv("SRHIP_MLP_DEBUG")) : 0) {
