@@ -5,6 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = "prepare" ]; then
+  if git diff --quiet && git diff --cached --quiet; then echo "working tree equals HEAD: nothing to compare"; exit 1; fi
   git stash -q && python -c "import semireward_amd.build as b; b.build()" > /dev/null && cp semireward_amd/libsrhip.so semireward_amd/libsrhip_A.so
   git stash pop -q && python -c "import semireward_amd.build as b; b.build()" > /dev/null && cp semireward_amd/libsrhip.so semireward_amd/libsrhip_B.so
   echo "prepared A (HEAD) and B (working tree); remove semireward_amd/libsrhip_[AB].so afterwards"
