@@ -124,9 +124,9 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
 // The bf16 epilogues as a value: the packed output quad C[m][n..n+3] of one lane (bias, GELU / GELU', dropout applied; the GELU
 // pre-activation copy is stored on the way).  m is a valid row (callers clamp it for lanes past M; such lanes only take part in the exchange).
 template <int EPI>
-__device__ __forceinline__ u32x2_t epi_quad_bf16(const GemmArgs& g, int m, int n, float (&v)[4], bool row_ok) {
+__device__ __forceinline__ u32x2_t epi_quad_bf16(const GemmArgs& g, int m, int n, float (&v)[4], bool row_ok, const f32x4_t* bpre = nullptr) {
   if (g.bias) {
-    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n);
+    const f32x4_t b4 = bpre ? *bpre : *reinterpret_cast<const f32x4_t*>(g.bias + n);
     v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
   }
   if (EPI == SRHIP_EPI_GELU_BF16) {
@@ -207,6 +207,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
 
   const int nk = kt1 - kt0;
   if (nk <= 0) return;
+  // bias quads of the wave's four column tiles (they depend on n only): requested before the K loop instead of 16 times in the epilogue
+  f32x4_t bq[4];
+  constexpr bool BF16_OUT = EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16;
+  if (BF16_OUT && g.wide_store && g.bias) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bq[nt] = *reinterpret_cast<const f32x4_t*>(g.bias + n0 + wn * 64 + nt * 16 + lg * 4);
+  }
   // RESID: the residual tile (fp32, 64 KiB per workgroup) is requested BEFORE the K loop so that its HBM latency hides under
   // the MFMA work; the epilogue then only adds and stores.  (The loads are older than every LDS-DMA op, so the counted
   // vmcnt waits below also cover them.)  SRHIP_DEBUG=2 (tuning) loads it in the epilogue instead: measured 1196 vs 1208 img/s with three
@@ -273,7 +280,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
         for (int e = 0; e < 2; ++e) {
           const int nt = 2 * np + e;
           float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-          q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * 64 + nt * 16 + lg * 4, v, mr < g.M);
+          q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * 64 + nt * 16 + lg * 4, v, mr < g.M, &bq[nt]);
         }
         store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + wn * 64 + np * 32, lg, q[0], q[1]);
       }
