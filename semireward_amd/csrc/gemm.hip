@@ -287,6 +287,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
     }
     return;
   }
+  if (EPI == SRHIP_EPI_RESID_F32 && g.bias) {      // (the fragment registers of the K loop are free by now: no higher register peak)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bq[nt] = *reinterpret_cast<const f32x4_t*>(g.bias + min(n0 + wn * 64 + nt * 16 + lg * 4, g.N - 4));
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + l15;
@@ -301,7 +305,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
       if (EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 3)) {
         f32x4_t x = res[nt][mt];
         if (g.bias) {
-          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n);
+          const f32x4_t b4 = bq[nt];
           v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
         }
         if (g.drop_thresh) {
