@@ -561,6 +561,11 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
       if ((EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16) && g.wide_store &&
           n0 + GBN <= g.N) {                      // (wave-uniform: full column tiles only; the ragged last one takes the plain path)
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+        f32x4_t bq[NTW];                             // bias quads: once per column tile, not once per (row tile, column tile)
+        if (g.bias) {
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) bq[i] = *reinterpret_cast<const f32x4_t*>(g.bias + n0 + wn * (16 * NTW) + i * 16 + lg * 4);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int mr = m0 + wm * 64 + mt * 16 + l15, m = min(mr, g.M - 1);
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
               const int i = 2 * np + e;
               float v[4] = {acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]};
               acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-              q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * (16 * NTW) + i * 16 + lg * 4, v, mr < g.M);
+              q[e] = epi_quad_bf16<EPI>(g, m, n0 + wn * (16 * NTW) + i * 16 + lg * 4, v, mr < g.M, &bq[i]);
             }
             store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + wn * (16 * NTW) + np * 32, lg, q[0], q[1]);
           }
