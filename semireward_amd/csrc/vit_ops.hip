@@ -16,31 +16,46 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward: x fp32 [M, D] -> out bf16 [M, D]; D = 128 * NV.  One wave per row.
+// Two rows per wave, all loads of both rows (and the affine) requested before the first reduction: a wave that handles one row is a chain of
+// exposed round trips (row, then gamma / beta) and the launch is bounded by wave turnover.  Lane -> column map and reduction order per row
+// are unchanged (bit-identical results).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float eps, bf16_t* __restrict__ out,
                                                     float* __restrict__ mean, float* __restrict__ rstd, int M) {
-  constexpr int D = NV * 128;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * D);
-  float2 v[NV];
-  float s = 0.f;
+  constexpr int D = NV * 128, RW = 2;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW, lane = threadIdx.x & 63;
+  if (row0 >= M) return;
+  float2 v[RW][NV], g[NV], b[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { v[i] = xr[i * 64 + lane]; s += v[i].x + v[i].y; }
-  const float mu = wave_sum(s) * (1.0f / D);
-  float q = 0.f;
+  for (int r = 0; r < RW; ++r) {
+    const float2* xr = reinterpret_cast<const float2*>(x + (size_t)min(row0 + r, M - 1) * D);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { const float a = v[i].x - mu, b = v[i].y - mu; q += a * a + b * b; }
-  const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-  uint32_t* orow = reinterpret_cast<uint32_t*>(out + (size_t)row * D);
+    for (int i = 0; i < NV; ++i) v[r][i] = xr[i * 64 + lane];
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const float2 g = reinterpret_cast<const float2*>(gamma)[i * 64 + lane];
-    const float2 b = reinterpret_cast<const float2*>(beta)[i * 64 + lane];
-    orow[i * 64 + lane] = pack_bf2((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y);
+    g[i] = reinterpret_cast<const float2*>(gamma)[i * 64 + lane];
+    b[i] = reinterpret_cast<const float2*>(beta)[i * 64 + lane];
   }
-  if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[r][i].x + v[r][i].y;
+    const float mu = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const float a = v[r][i].x - mu, c = v[r][i].y - mu; q += a * a + c * c; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    uint32_t* orow = reinterpret_cast<uint32_t*>(out + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      orow[i * 64 + lane] = pack_bf2((v[r][i].x - mu) * rs * g[i].x + b[i].x, (v[r][i].y - mu) * rs * g[i].y + b[i].y);
+    if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
 }
 
 // LayerNorm backward: dx (fp32, +=) and dgamma/dbeta (fp32, atomic +=).  4 * RPW rows per workgroup: 32 for the large launches (fewer
@@ -524,7 +539,7 @@ extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const flo
                                    float* mean, float* rstd, int M, int D, void* stream) {
   if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768) || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(cdiv(M, 4)), block(256);
+  dim3 grid(cdiv(M, 8)), block(256);
   if (D == 128) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
   else if (D == 512) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
   else if (D == 384) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
