@@ -138,33 +138,49 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
 }
 
 // ---- post-LN forward: x = LayerNorm(y) in fp32 (residual stream of the next sub-layer) and bf16 (its GEMM operand) ------------
+// (two rows per wave, every load requested before the first reduction: see ln_fwd_kernel in vit_ops.hip; x may alias y -- a wave reads
+// both of its rows before it writes either)
 template <int NV>
 __global__ __launch_bounds__(256) void postln_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float* __restrict__ x,
                                                         bf16_t* __restrict__ xb, float* __restrict__ mean, float* __restrict__ rstd, int M) {
-  constexpr int D = NV * 128;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float2* yr = reinterpret_cast<const float2*>(y + (size_t)row * D);
-  float2 v[NV];
-  float s = 0.f;
+  constexpr int D = NV * 128, RW = 2;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW, lane = threadIdx.x & 63;
+  if (row0 >= M) return;
+  float2 v[RW][NV], g[NV], c[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { v[i] = yr[i * 64 + lane]; s += v[i].x + v[i].y; }
-  const float mu = wave_sum(s) * (1.0f / D);
-  float q = 0.f;
+  for (int r = 0; r < RW; ++r) {
+    const float2* yr = reinterpret_cast<const float2*>(y + (size_t)min(row0 + r, M - 1) * D);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { const float a = v[i].x - mu, c = v[i].y - mu; q += a * a + c * c; }
-  const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-  float2* xr = reinterpret_cast<float2*>(x + (size_t)row * D);
-  uint32_t* br = reinterpret_cast<uint32_t*>(xb + (size_t)row * D);
+    for (int i = 0; i < NV; ++i) v[r][i] = yr[i * 64 + lane];
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const float2 g = reinterpret_cast<const float2*>(gamma)[i * 64 + lane], c = reinterpret_cast<const float2*>(beta)[i * 64 + lane];
-    const float2 o = make_float2((v[i].x - mu) * rs * g.x + c.x, (v[i].y - mu) * rs * g.y + c.y);
-    xr[i * 64 + lane] = o;
-    br[i * 64 + lane] = pack_bf2(o.x, o.y);
+    g[i] = reinterpret_cast<const float2*>(gamma)[i * 64 + lane];
+    c[i] = reinterpret_cast<const float2*>(beta)[i * 64 + lane];
   }
-  if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[r][i].x + v[r][i].y;
+    const float mu = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const float a = v[r][i].x - mu, e = v[r][i].y - mu; q += a * a + e * e; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    float2* xr = reinterpret_cast<float2*>(x + (size_t)row * D);
+    uint32_t* br = reinterpret_cast<uint32_t*>(xb + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float2 o = make_float2((v[r][i].x - mu) * rs * g[i].x + c[i].x, (v[r][i].y - mu) * rs * g[i].y + c[i].y);
+      xr[i * 64 + lane] = o;
+      br[i * 64 + lane] = pack_bf2(o.x, o.y);
+    }
+    if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
 }
 
 // ---- post-LN backward: dy = d/d(LayerNorm output) -> dx = d/d(y) in fp32 (the residual path) and, masked by the dropout that sat on
@@ -327,7 +343,7 @@ extern "C" int srhip_postln_fwd(const float* y, const float* gamma, const float*
                                 float* rstd, int M, int D, void* stream) {
   if (!y || !x || !x_bf16 || M <= 0 || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-#define CALL(NV) hipLaunchKernelGGL(postln_fwd_kernel<NV>, dim3(cdiv(M, 4)), dim3(256), 0, s, y, gamma, beta, eps, x, (bf16_t*)x_bf16, mean, rstd, M)
+#define CALL(NV) hipLaunchKernelGGL(postln_fwd_kernel<NV>, dim3(cdiv(M, 8)), dim3(256), 0, s, y, gamma, beta, eps, x, (bf16_t*)x_bf16, mean, rstd, M)
   DISPATCH_NV(D, CALL)
 #undef CALL
   SR_CHECK_LAUNCH();
