@@ -330,32 +330,52 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const float* __restri
   float* sh = f + D;
   const int b = blockIdx.x;
   const float* xr = x + (size_t)b * N * D;     // token 0 of image b
+  // the cls row stays in registers (D <= 1024: at most 4 values per thread): ONE global round trip instead of three dependent passes
+  float xv[4], gv[4], bv[4];
   float s = 0.f;
-  for (int d = threadIdx.x; d < D; d += 256) s += xr[d];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = threadIdx.x + 256 * i;
+    xv[i] = d < D ? xr[d] : 0.f;
+    gv[i] = d < D ? gamma[d] : 0.f;
+    bv[i] = d < D ? beta[d] : 0.f;
+    s += xv[i];
+  }
   const float mu = block_sum(s, sh) / D;
   float q = 0.f;
-  for (int d = threadIdx.x; d < D; d += 256) { const float a = xr[d] - mu; q += a * a; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const float a = (threadIdx.x + 256 * i < D) ? xv[i] - mu : 0.f; q += a * a; }
   const float rs = rsqrtf(block_sum(q, sh) / D + eps);
   // grid.y workgroups share an image: each normalises the cls row itself (384 floats) and takes every grid.y-th group of 4 classes
   // (one image per workgroup left 25 serial wave reductions per wave on 200 of 256 CUs: 63 us for 15 MFLOP)
   const bool first = blockIdx.y == 0;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    const float xh = (xr[d] - mu) * rs, v = xh * gamma[d] + beta[d];
-    f[d] = v;
-    if (first) {
-      feat[(size_t)b * D + d] = v;
-      if (xhat) xhat[(size_t)b * D + d] = xh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = threadIdx.x + 256 * i;
+    if (d < D) {
+      const float xh = (xv[i] - mu) * rs, v = xh * gv[i] + bv[i];
+      f[d] = v;
+      if (first) {
+        feat[(size_t)b * D + d] = v;
+        if (xhat) xhat[(size_t)b * D + d] = xh;
+      }
     }
   }
   if (first && rstd && threadIdx.x == 0) rstd[b] = rs;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int c = blockIdx.y * 4 + wave; c < C; c += 4 * gridDim.y) {
+  // two classes per iteration: the weight rows of the second travel while the first is reduced
+  for (int c = blockIdx.y * 4 + wave; c < C; c += 8 * gridDim.y) {
+    const int c2 = c + 4 * gridDim.y;
     const float* w = Wh + (size_t)c * D;
-    float a = 0.f;
-    for (int d = lane; d < D; d += 64) a += f[d] * w[d];
-    a = wave_sum(a);
-    if (lane == 0) logits[(size_t)b * C + c] = a + bh[c];
+    const float* w2 = Wh + (size_t)min(c2, C - 1) * D;
+    float a = 0.f, a2 = 0.f;
+    for (int d = lane; d < D; d += 64) { const float fv = f[d]; a += fv * w[d]; a2 += fv * w2[d]; }
+    a = wave_sum(a); a2 = wave_sum(a2);
+    if (lane == 0) {
+      logits[(size_t)b * C + c] = a + bh[c];
+      if (c2 < C) logits[(size_t)b * C + c2] = a2 + bh[c2];
+    }
   }
 }
 
