@@ -99,6 +99,11 @@ class SRConsistencyBase(AlgorithmBase):
         self.generator_optimizer = None       # generator grads are None in the reference -> its Adam step is a no-op (A.1)
         self.max_reward = torch.full((), -float("inf"), device=self.device)
         self.dp.broadcast_params(self.model, self.rewarder, self.generator)
+        # Opt-in (SR_OVERLAP_ALLREDUCE=1; data parallel + ViT engine): gradient slices are all-reduced under the backward.  The logic is verified
+        # with two gloo ranks on one GPU (tests/test_gpu_dp_overlap.py); it stays off by default until it has been timed on RCCL over xGMI --
+        # this round only had single-GPU boxes, and the proven path is the single all-reduce after the backward.
+        if os.environ.get("SR_OVERLAP_ALLREDUCE", "0") != "0":
+            self.dp.install_overlap(self.model)
         self._plans = {}
         self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
         # gradient-row forward on a second HIP stream (SR_OVERLAP_GRAD_ROWS=0 serialises it behind the inference forward)

@@ -20,9 +20,48 @@ class DataParallel:
     def active(self):
         return self.world_size > 1 and dist.is_available() and dist.is_initialized()
 
+    # ---- all-reduce under the backward ------------------------------------------------------------------------------------------------
+    # The engines finish their weight gradients in layer groups, last layers first, and report every finished contiguous range of the flat
+    # gradient block; each range is all-reduced on a communication stream while the backward of the earlier layers continues (xGMI ring time
+    # of the 86 MB block is otherwise serial with the step).  all_reduce_grads then reduces what was not reported and joins the stream.
+    def install_overlap(self, model):
+        if not (self.active and torch.cuda.is_available() and hasattr(model, "grad_ready_cb")):
+            return False
+        self._comm = torch.cuda.Stream(device=model.grad.device)
+        self._done, self._model = [], model
+        model.grad_ready_cb = self._reduce_range
+        return True
+
+    def _reduce_range(self, lo, hi):
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)                                   # every gradient of [lo, hi) is final on the compute stream here
+        self._comm.wait_event(ready)
+        with torch.cuda.stream(self._comm):
+            dist.all_reduce(self._model.grad[lo:hi], op=dist.ReduceOp.SUM)
+        self._done.append((lo, hi))
+
     def all_reduce_grads(self, model):
-        if self.active:
+        if not self.active:
+            return
+        done = sorted(getattr(self, "_done", ())) if getattr(self, "_model", None) is model else []
+        if not done:
             dist.all_reduce(model.grad, op=dist.ReduceOp.SUM)
+            return
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._comm.wait_event(ready)
+        with torch.cuda.stream(self._comm):
+            pos = 0
+            for lo, hi in done + [(model.grad.numel(), model.grad.numel())]:
+                if lo > pos:
+                    dist.all_reduce(model.grad[pos:lo], op=dist.ReduceOp.SUM)
+                pos = max(pos, hi)
+            fin = torch.cuda.Event()
+            fin.record(self._comm)
+        main.wait_event(fin)
+        self._done = []
 
     def all_reduce_flat(self, t):
         if self.active:

@@ -58,6 +58,7 @@ def param_names_shapes(cfg):
     return out
 
 
+DW_GROUPS = 3              # layer groups of the weight-gradient launch when a grad_ready_cb is installed (data parallel)
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.layernorm_bwd_part)
 _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 # gradient + inference images in ONE forward (forward_mixed).  Opt-in: at the reference batch the 16 extra images push the qkv GEMM
@@ -84,6 +85,7 @@ class VisionTransformer:
         cfg = self.cfg
         self.device = torch.device(device)
         self.names_shapes = param_names_shapes(cfg)
+        self.grad_ready_cb = None          # callable(lo, hi) or None: see backward() / distributed.DataParallel.install_overlap
         self.offsets, o = {}, 0
         for n, s in self.names_shapes:
             self.offsets[n] = (o, s)
@@ -426,6 +428,21 @@ class VisionTransformer:
         out["ln_part"] = torch.zeros(2 * cfg.depth, LN_REP, 2, D, dtype=torch.float32, device=self.device)
         out["ln_desc"] = ops.make_ln_reduce_desc([(G("blocks.%d.norm%d.weight" % (i, j)), G("blocks.%d.norm%d.bias" % (i, j)))
                                                   for i in range(cfg.depth) for j in (1, 2)], self.device)
+        # Data parallel: the same launches cut into DW_GROUPS layer groups (last layers first), so that the all-reduce of a group's slice of the
+        # flat gradient block can travel under the backward of the earlier layers (grad_ready_cb, see distributed.py).
+        ng = max(1, min(DW_GROUPS, cfg.depth))
+        per = -(-cfg.depth // ng)
+        groups = []
+        for hi_l in range(cfg.depth, 0, -per):
+            lo_l = max(0, hi_l - per)
+            names = [n for n, _ in self.names_shapes if n.startswith("blocks.") and lo_l <= int(n.split(".")[1]) < hi_l]
+            lo = min(self.offsets[n][0] for n in names)
+            hi = max(self.offsets[n][0] + int(torch.Size(self.offsets[n][1]).numel()) for n in names)
+            assert sum(int(torch.Size(self.offsets[n][1]).numel()) for n in names) == hi - lo, "block parameters are contiguous in the flat block"
+            groups.append(dict(lo_layer=lo_l, hi_layer=hi_l, flat=(lo, hi), desc=ops.make_group_tn_desc(problems[4 * lo_l:4 * hi_l], self.device),
+                               ln_desc=ops.make_ln_reduce_desc([(G("blocks.%d.norm%d.weight" % (i, j)), G("blocks.%d.norm%d.bias" % (i, j)))
+                                                                for i in range(lo_l, hi_l) for j in (1, 2)], self.device)))
+        out["groups"] = groups
         self._ws[key] = out
         return out
 
@@ -448,6 +465,8 @@ class VisionTransformer:
         scale = 64 ** -0.5
         dp = ctx.dp
         lnp = T["ln_part"]
+        cb = self.grad_ready_cb            # data parallel only: called with the flat-block range of every finished layer group
+        gdone = {g["lo_layer"]: g for g in T["groups"]} if cb is not None else {}
         ops.cast_scale_rows(dx, dp[cfg.depth - 1, 1] if dp is not None else None, N, T["layers"][cfg.depth - 1]["g2"], M, D)
         for i in reversed(range(cfg.depth)):
             b = "blocks.%d." % i
@@ -464,10 +483,17 @@ class VisionTransformer:
             ops.gemm_nt(ops.EPI_BF16, Ti["dqkv"], self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
             ops.layernorm_bwd_part(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, lnp[2 * i], LN_REP,
                                    T["layers"][i - 1]["g2"] if i > 0 else None, dp[i - 1, 1] if dp is not None and i > 0 else None, N, M, D)
-        ops.ln_grad_reduce(T["ln_desc"], lnp, 2 * cfg.depth, LN_REP, D)
-        # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
-        desc, npb, ntiles, flops, nbytes = T["desc"]
-        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+            g = gdone.get(i)
+            if g is not None:               # layers [i, g.hi_layer) are finished: their weight / bias / LayerNorm gradients, then the hand-over
+                desc, npb, ntiles, flops, nbytes = g["desc"]
+                ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+                ops.ln_grad_reduce(g["ln_desc"], lnp[2 * g["lo_layer"]:2 * g["hi_layer"]], 2 * (g["hi_layer"] - g["lo_layer"]), LN_REP, D)
+                cb(*g["flat"])
+        if cb is None:
+            ops.ln_grad_reduce(T["ln_desc"], lnp, 2 * cfg.depth, LN_REP, D)
+            # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
+            desc, npb, ntiles, flops, nbytes = T["desc"]
+            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         Kp = cfg.in_chans * cfg.patch_size ** 2
         if Kp <= 64:
             ws = self._buf("b_pe_ws", (ops.patch_embed_bwd_ws_floats(B, cfg.in_chans, cfg.img_size, cfg.patch_size, D),), f32)
