@@ -154,9 +154,30 @@ class SRConsistencyBase(AlgorithmBase):
             if pl.mixed_cols is None:
                 pl.mixed_cols = torch.cat((pl.grad_cols, pl.inf_cols))
                 pl.mixed_img = torch.cat((pl.grad_img, pl.inf_img)).contiguous()
-            lg, ft, ctx = m.forward_mixed(imgs, pl.mixed_img, sel(pl.mixed_cols), pl.grad_cols.numel())
+            nr_ = pl.rest_cols.numel()
+            side_ = self._side_stream if (self.overlap_grad_rows and nr_) else None
+            dp_mixed, dp_rest_ = sel(pl.mixed_cols), (sel(pl.rest_cols) if nr_ else None)
+            if side_ is not None:                     # the unread rows: second stream, from the start of the step (see below)
+                ready_ = torch.cuda.Event()
+                ready_.record(torch.cuda.current_stream())
+            lg, ft, ctx = m.forward_mixed(imgs, pl.mixed_img, dp_mixed, pl.grad_cols.numel())
             logits.index_copy_(0, pl.mixed_cols, lg)
             feats.index_copy_(0, pl.mixed_cols, ft)
+            if nr_ and side_ is None:
+                lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest_, save=False, buftag="r")
+                logits.index_copy_(0, pl.rest_cols, lg_r)
+                feats.index_copy_(0, pl.rest_cols, ft_r)
+            elif nr_:
+                side_.wait_event(ready_)
+                for t_ in (logits, feats, dp_rest_, imgs):
+                    if torch.is_tensor(t_):
+                        t_.record_stream(side_)
+                with torch.cuda.stream(side_), ops.stream_scope():
+                    lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest_, save=False, buftag="r")
+                    logits.index_copy_(0, pl.rest_cols, lg_r)
+                    feats.index_copy_(0, pl.rest_cols, ft_r)
+                    self._rest_done = torch.cuda.Event()
+                    self._rest_done.record(side_)
             return logits, feats, ctx
         # The gradient-carrying rows (16 of 216 images at the reference batch) run on a SECOND HIP stream: their launches are
         # 100-400 workgroups of latency-bound work (14-28 us each, 1.6 ms per step back to back) that fit beside the tails of
