@@ -318,3 +318,36 @@ def test_elide_unread_rows_changes_no_result():
     assert float((p0 - p1).abs().mean()) <= 1e-3 * float((p0 - p_init).abs().mean())
     h0, h1 = a0.hooks_dict["MaskingHook"], a1.hooks_dict["MaskingHook"]
     assert torch.equal(h0.selected_label, h1.selected_label) and torch.equal(h0.classwise_acc, h1.classwise_acc)
+
+
+def test_mixed_forward_computes_every_row(monkeypatch):
+    """Opt-in ``SRHIP_MIXED_FWD`` (gradient rows inside the inference launches): every (pass, image) row must still be computed -- the rows
+    nothing reads included (they were once dropped by accident) -- and the inference rows must equal those of the default schedule."""
+    NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
+               num_warmup_iter=5120)
+    b = synth.synth_batch(103, 8, 8, 32, 100, 50000)
+    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
+    dps = [torch.from_numpy(synth.synth_droppath(500 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
+    traces = []
+    for mixed in (False, True):
+        monkeypatch.setattr(vit, "MIXED_FWD", mixed)
+        alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
+        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+        alg.it = 30000
+        alg.optimizer.sched_step = alg.it
+        alg.inject_droppath = dps
+        alg.trace = {}
+        alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+        torch.cuda.synchronize()
+        assert (not mixed) or alg.model.supports_mixed(216)
+        traces.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()})
+    t0, t1 = traces
+    K, nl, nu = t0["K"], 8, 8
+    L0, L1 = t0["logits"], t1["logits"]
+    assert torch.isfinite(L1).all() and L1.shape == L0.shape == (K + 1, 24, 100)
+    grad_rows = torch.zeros(K + 1, 24, dtype=torch.bool)
+    grad_rows[0, :nl] = True
+    grad_rows[K, nl + nu:] = True
+    assert torch.equal(L0[~grad_rows], L1[~grad_rows])               # 200 inference rows (read AND unread): same kernels, same bits
+    assert float((L0[grad_rows] - L1[grad_rows]).abs().max()) < 5e-2      # gradient rows: fused vs unfused MLP launches, bf16 round-off
+    assert all(torch.equal(a, c) for a, c in zip(t0["masks"], t1["masks"]))
