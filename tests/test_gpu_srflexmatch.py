@@ -351,3 +351,12 @@ def test_mixed_forward_computes_every_row(monkeypatch):
     assert torch.equal(L0[~grad_rows], L1[~grad_rows])               # 200 inference rows (read AND unread): same kernels, same bits
     assert float((L0[grad_rows] - L1[grad_rows]).abs().max()) < 5e-2      # gradient rows: fused vs unfused MLP launches, bf16 round-off
     assert all(torch.equal(a, c) for a, c in zip(t0["masks"], t1["masks"]))
+    # ... and the unread rows hold what a direct forward of those (pass, image) columns gives: strong rows of pass 3, labelled rows of pass 5
+    pb = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+    imgs = torch.cat((pb["x_lb"], pb["x_ulb_w"], pb["x_ulb_s"])).contiguous()
+    for k, rows in ((3, list(range(nl + nu, 24))), (5, list(range(nl)))):
+        idx = torch.tensor(rows, dtype=torch.int32, device=DEV)
+        dpk = dps[k][:, :, rows].contiguous().to(DEV)
+        lg, _, _ = alg.model.forward_features(imgs, idx, dpk, save=False)
+        torch.cuda.synchronize()
+        assert torch.equal(lg.cpu(), L0[k, rows].cpu()), k
