@@ -192,6 +192,9 @@ int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const
 int srhip_flexmatch_mask_passes(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
                                 long long* selected_label, int* hist, float* classwise_acc, float* mask, int n_pass, int B, int C,
                                 int ulb_dest_len, int thresh_warmup, void* stream);
+/* bit 0: an idx_ulb entry outside [0, ulb_dest_len) reached srhip_flexmatch_mask[_passes] since the last reset (the reference raises
+ * IndexError from the index_put at srflexmatch/utils.py:59; here the entry is skipped).  SYNCHRONISES the stream. */
+int srhip_index_error(int* bits_out, int reset, void* stream);
 int srhip_flexmatch_rebuild_hist(const long long* selected_label, int* hist, int ulb_dest_len, int C, void* stream);
 /* FixedThresholdingHook.masking (semilearn/algorithms/hooks/masking.py:42-57). */
 int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream);
@@ -253,7 +256,13 @@ int srhip_rewarder_bwd(const float* params, const float* feats, const long long*
 int srhip_generator_fwd(const float* params, const float* params_t, const float* x, float* out, long long* label, int B, int F,
                         void* stream);
 /* (cosine_similarity_n(one_hot, one_hot)+1)/2 (semireward.py:130-139, srflexmatch.py:180-182): 1.0 / 0.5. */
-int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, void* stream);
+int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, int num_classes, void* stream);
+/* Label-range errors of the launches above since the last reset.  The reference raises from nn.Embedding / F.one_hot when a (generated or
+ * pseudo) label is outside [0, label_dim) (semireward.py:57, srflexmatch.py:180-181); the kernels stay memory safe (row 0 is read, the
+ * gradient scatter is skipped), set a bit in a device word and the host raises when it reads it here (SYNCHRONISES the stream):
+ * bit 0 embedding lookup, bit 1 embedding-gradient scatter, bit 2 generator output NaN / not representable as int64, bit 3 a label outside
+ * [0, num_classes) in srhip_sr_target (F.one_hot; num_classes <= 0 disables that check). */
+int srhip_label_error(int* bits_out, int reset, void* stream);
 /* torch.optim.Adam step on a flat block (srflexmatch.py:54, :192-193). */
 int srhip_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                     int step, void* stream);
@@ -263,10 +272,17 @@ int srhip_adam_flat(float* p, const float* g, float* m, float* v, long n, float 
  * param groups of semilearn/core/utils/build.py:193-224 + semilearn/nets/utils.py:143-204, fused with the bf16
  * operand refresh, EMA.update (semilearn/core/utils/misc.py:152-155) and model.zero_grad().
  * chunk_table int32 [n_chunks][4] = (offset, length, tensor id, 0); lr_t / wd_t fp32 per tensor;
- * grad_scale multiplies g first (1/world_size after a data-parallel SUM all-reduce). */
+ * grad_scale multiplies g first (1/world_size after a data-parallel SUM all-reduce); clip_coef (device, 1 float, may be NULL) multiplies
+ * it once more: the clip_grad_norm_ coefficient of this step.  ema (may be NULL) <- (1 - ema_m) * p_new + ema_m * ema, op for op as
+ * semilearn/core/utils/misc.py:152-155 (ema_m is a double because the reference forms 1 - decay in double before rounding). */
 int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, float* ema, const int* chunk_table, int n_chunks,
                      const float* lr_t, const float* wd_t, float lr_factor, float beta1, float beta2, float eps, int step,
-                     float ema_m, float grad_scale, int zero_grad, void* stream);
+                     double ema_m, float grad_scale, const float* clip_coef, int zero_grad, void* stream);
+/* torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad) of ParamUpdateHook (semilearn/core/hooks/param_update.py:34-35) on the flat
+ * gradient block: coef_out[0] = min(1, max_norm / (|| pre_scale * g ||_2 + 1e-6)), coef_out[1] = that norm; ws = srhip_clip_grad_ws_floats()
+ * floats.  The gradients are NOT rewritten: the optimizer launch takes coef_out as ``clip_coef``. */
+int srhip_clip_grad_ws_floats(void);
+int srhip_clip_grad_coef(const float* g, long long n, float pre_scale, float max_norm, float* ws, float* coef_out, void* stream);
 
 /* ---- post-LN transformer encoder glue (BERT / Wav2Vec2 backbones; semilearn/nets/bert/bert.py, wave2vecv2/wave2vecv2.py and the HF modules
  * they call).  D in {128, 384, 768}; dropout arguments as in srhip_attn_masked_fwd with element index = row * D + column.
@@ -402,7 +418,7 @@ int srhip_fc_fwd(const float* feat, const float* Wc, const float* bc, float* log
 int srhip_fc_bwd(const float* dlogits, const float* feat, const float* Wc, float* dfeat, float* dWc, float* dbc, int B, int F, int K,
                  void* stream);
 int srhip_sgd_flat(float* p, float* g, float* buf, float* ema, const void* chunk_table, int nchunks, long long n, float lr, float momentum,
-                   float grad_scale, float ema_m, int first_step, int zero_grad, void* stream);
+                   float grad_scale, const float* clip_coef, double ema_m, int first_step, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

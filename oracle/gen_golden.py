@@ -542,6 +542,164 @@ def gen_optim():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_ema():
+    """Row n1 and param_update.py:34-35: the reference's own EMA class (core/utils/misc.py:132-165) driven exactly as
+    EMAHook.after_train_step does (core/hooks/ema.py:20-24), 3 optimizer steps at ema_m 0.999 with seeded gradients, on
+      * the tiny ViT with the layer-decay AdamW of get_optimizer (+ the torch optimizer state_dict of that run, and one more run with
+        clip_grad_norm_(parameters, 0.05) before every step), and
+      * the tiny WideResNet with SGD-Nesterov, whose ema_model also receives the model's BatchNorm buffers.
+    Stored: strided samples + sums of the model and ema_model parameters after every step."""
+    import copy
+    bu = R.mod("semilearn.core.utils.build")
+    misc = R.mod("semilearn.core.utils.misc")
+    out = {}
+    EMA_M = 0.999
+
+    def hook_step(ema, model, ema_model):                      # ema.py:20-24, verbatim order
+        ema.update()
+        ema_model.load_state_dict(model.state_dict())
+        ema_model.load_state_dict(ema.shadow, strict=False)
+
+    # ---- tiny ViT, AdamW, with and without clipping
+    cfgt = V.VitCfg(num_classes=10, **V.VIT_TINY_TEST)
+    shapes = V.param_shapes(cfgt)
+    for tag, clip in (("vit", 0.0), ("vit_clip", 0.05)):
+        mt = build_ref_vit(V.VIT_TINY_TEST, 10, synth.synth_params(shapes, 61))
+        em = copy.deepcopy(mt)
+        ot = bu.get_optimizer(mt, "AdamW", 5e-4, 0.9, 5e-4, 0.5)
+        st = bu.get_cosine_schedule_with_warmup(ot, 10, num_warmup_steps=2)
+        ema = misc.EMA(mt, EMA_M)
+        ema.register()
+        st.step()                                              # leave lr factor 0 (warmup step 0) behind: parameters must move
+        for step in range(3):
+            g = synth.synth_params(shapes, 170 + step)
+            for n, p in mt.named_parameters():
+                p.grad = T(g[n]) * 0.1
+            if clip > 0:
+                tn = torch.nn.utils.clip_grad_norm_(mt.parameters(), clip)
+                out[f"{tag}/total_norm{step}"] = np.float32(float(tn))
+            ot.step(); st.step(); mt.zero_grad()
+            hook_step(ema, mt, em)
+            for n, p in mt.named_parameters():
+                flat(f"{tag}/model{step}/{n}", samp(p.detach().numpy(), 384), out)
+            for n, p in em.named_parameters():
+                flat(f"{tag}/ema{step}/{n}", samp(p.detach().numpy(), 384), out)
+        if tag == "vit":                                       # torch layout of the optimizer state (reference checkpoints, algorithmbase.py:466)
+            sd = ot.state_dict()
+            id2name = {id(p): n for n, p in mt.named_parameters()}
+            names = [id2name[id(p)] for gr in ot.param_groups for p in gr["params"]]
+            out["vit/opt/names_by_index"] = np.array(names)
+            out["vit/opt/group_sizes"] = np.array([len(gr["params"]) for gr in sd["param_groups"]], dtype=np.int64)
+            out["vit/opt/state_keys"] = np.array(sorted(sd["state"][0].keys()))
+            out["vit/opt/step"] = np.float32(float(sd["state"][0]["step"]))
+            out["vit/opt/sched_last_epoch"] = np.int64(st.state_dict()["last_epoch"])
+
+    # ---- tiny WideResNet, SGD-Nesterov, BatchNorm buffers copied into the ema_model
+    cfgw = W.WrnCfg(num_classes=10, **W.WRN_TINY_TEST)
+    paramsw = synth_wrn_params(cfgw, 63)
+    mw = build_ref_wrn(cfgw, paramsw)
+    ew = copy.deepcopy(mw)
+    ow = bu.get_optimizer(mw, "SGD", 0.03, 0.9, 5e-4, 1.0)
+    sw = bu.get_cosine_schedule_with_warmup(ow, 10, num_warmup_steps=0)
+    emaw = misc.EMA(mw, EMA_M)
+    emaw.register()
+    rng = np.random.Generator(np.random.PCG64(64))
+    for step in range(3):
+        gw = synth.synth_params(W.param_shapes(cfgw), 270 + step)          # the test regenerates these from the seed
+        for n, p in mw.named_parameters():
+            p.grad = T(gw[n]) * 0.05
+        for n, c, _ in W.bn_names(cfgw):                       # the labelled forward of a real step moves these; here: seeded values
+            m = dict(mw.named_modules())[n]
+            m.running_mean.copy_(T((0.1 * rng.standard_normal(c)).astype(np.float32)))
+            m.running_var.copy_(T((1.0 + 0.2 * rng.random(c)).astype(np.float32)))
+            m.num_batches_tracked += 1
+            out[f"wrn/buf{step}/{n}.running_mean"] = m.running_mean.numpy().copy()
+            out[f"wrn/buf{step}/{n}.running_var"] = m.running_var.numpy().copy()
+        ow.step(); sw.step(); mw.zero_grad()
+        hook_step(emaw, mw, ew)
+        for n, p in mw.named_parameters():
+            flat(f"wrn/model{step}/{n}", samp(p.detach().numpy(), 384), out)
+        for n, p in ew.named_parameters():
+            flat(f"wrn/ema{step}/{n}", samp(p.detach().numpy(), 384), out)
+        for n, b in ew.named_buffers():
+            out[f"wrn/emabuf{step}/{n}"] = b.numpy().copy()
+    out["meta/ema_m"] = np.float64(EMA_M)
+    np.savez_compressed(os.path.join(OUT, "ema.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_sr_configs():
+    """The yaml contract ("the build must run these yaml unchanged"): for every config/SemiReward/**.yaml the argument
+    namespace the reference's own ``get_config()`` (train.py:29-269) produces for ``python train.py --c <yaml>`` -- argparse defaults, the
+    algorithm's ``get_argument()`` list (train.py:248-254) and ``over_write_args_from_file`` (core/utils/misc.py:18-27), in the reference's
+    three-pass order.  get_config is executed from the reference's source with name2alg / name2imbalg restricted to the five SR classes
+    (imported headless); ruamel.yaml is absent here, PyYAML's Loader (the loader ruamel's ``yaml.Loader`` is compatible with) parses the
+    files.  Stored as data: tests/golden/sr_configs.json = {yaml path relative to config/SemiReward: {key: value}} plus the reference's
+    get_argument() lists; no yaml text."""
+    import ast
+    import glob
+    import json
+    import yaml as pyyaml
+    misc = R.mod("semilearn.core.utils.misc")
+
+    class Loader12(pyyaml.Loader):              # ruamel.yaml resolves YAML 1.2 scalars: ``lr: 5e-05`` is a float there, a str in PyYAML
+        pass
+    import re
+    Loader12.add_implicit_resolver("tag:yaml.org,2002:float", re.compile(r"^[-+]?[0-9][0-9_]*[eE][-+]?[0-9]+$"), list("-+0123456789"))
+    misc.yaml = types.SimpleNamespace(load=pyyaml.load, Loader=Loader12)
+    algs = {"srflexmatch": ("srflexmatch.srflexmatch", "SRFlexMatch"), "srfixmatch": ("srfixmatch.fixmatch", None),
+            "srpseudolabel": ("srpseudolabel.srpseudolabel", "SRPseudoLabel"), "srsoftmatch": ("srsoftmatch.srsoftmatch", "SRSoftMatch"),
+            "srfreematch": ("srfreematch.srfreematch", "SRFreeMatch")}
+    name2alg = {}
+    for k, (m, cls) in algs.items():
+        mod_ = R.mod("semilearn.algorithms." + m)
+        if cls is None:
+            cls = [n for n in dir(mod_) if n.lower() in ("srfixmatch", "fixmatch") and isinstance(getattr(mod_, n), type)][0]
+        name2alg[k] = getattr(mod_, cls)
+    src = open(os.path.join(R.REF, "train.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_config"][0]
+    ns = {"argparse": argparse, "over_write_args_from_file": misc.over_write_args_from_file, "name2alg": name2alg, "name2imbalg": {}}
+    autils = types.ModuleType("semilearn.algorithms.utils")
+    au = R.mod("semilearn.algorithms.utils.misc")
+    autils.str2bool, autils.SSL_Argument = au.str2bool, au.SSL_Argument
+    sys.modules["semilearn.algorithms.utils"] = autils
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "train.py:get_config", "exec"), ns)
+    base = os.path.join(R.REF, "config", "SemiReward")
+    out = {"configs": {}, "get_argument": {}}
+    argv0 = sys.argv
+    try:
+        for y in sorted(glob.glob(os.path.join(base, "**", "*.yaml"), recursive=True)):
+            sys.argv = ["train.py", "--c", y]
+            a = ns["get_config"]()
+            d = dict(vars(a))
+            d["c"] = os.path.relpath(y, base)
+            out["configs"][os.path.relpath(y, base)] = d
+    finally:
+        sys.argv = argv0
+    for k, cls in name2alg.items():
+        out["get_argument"][k] = [[x.name, getattr(x.type, "__name__", str(x.type)), x.default] for x in cls.get_argument()]
+    # the parser's own defaults (train.py:36-225): get_config on a yaml that only names the algorithm, minus that algorithm's arguments
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as tf:
+        tf.write("algorithm: srfixmatch\n")
+    try:
+        sys.argv = ["train.py", "--c", tf.name]
+        d0 = dict(vars(ns["get_config"]()))
+    finally:
+        sys.argv = argv0
+        os.unlink(tf.name)
+    own = {x.name.lstrip("-") for x in name2alg["srfixmatch"].get_argument()} | {"c", "algorithm"}
+    out["parser_defaults"] = {k: v for k, v in d0.items() if k not in own}
+    out["meta"] = {"yaml_loader": "PyYAML %s Loader + the YAML 1.2 exponent-float resolver of ruamel.yaml (absent in the build container), which the "
+                                  "reference uses: misc.py:7,25" % pyyaml.__version__,
+                   "n_configs": len(out["configs"])}
+    with open(os.path.join(OUT, "sr_configs.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("sr_configs.json", len(out["configs"]), "configs")
+
+
+# ------------------------------------------------------------------------------------------------
 class _PassModel(torch.nn.Module):
     """Wraps the reference ViT so every forward uses the next injected DropPath mask set."""
 
@@ -649,7 +807,8 @@ class _CountingModel(torch.nn.Module):
 # classic_cv flavour (BASELINE.json configs[0]): WideResNet backbone (depth 10 here), SGD + Nesterov (pseudolabel_cifar100_*.yaml: lr 0.03,
 # momentum 0.9, weight_decay 1e-3), BatchNorm statistics moved by the labelled forward only (Bn_Controller)
 TRACE_PL_WRN = dict(TRACE, its=[0, 1, 99, 100, 101, 110], seed=107, p_cutoff=0.15, algorithm="srpseudolabel", unsup_warm_up=0.4,
-                    backbone="wrn", lr=0.03, momentum=0.9, weight_decay=1e-3, img=8, num_warmup_iter=0)
+                    backbone="wrn", lr=0.03, momentum=0.9, weight_decay=1e-3, img=8, num_warmup_iter=0,
+                    ema_m=0.999)          # classic_cv yamls: ema_m 0.999 (pseudolabel_cifar100_400_0.yaml:20)
 
 
 def gen_trace_pl_wrn():
@@ -700,6 +859,12 @@ def gen_trace_pl(tr=None, fname="srpseudolabel_trace.npz"):
     base_lr = tr["lr"] if wrnb else 5e-4
     alg.scheduler = bu.get_cosine_schedule_with_warmup(alg.optimizer, tr["num_train_iter"], num_warmup_steps=tr["num_warmup_iter"])
     out, prev_it = {}, -1
+    ema = ema_model = None
+    if tr.get("ema_m"):                     # EMAHook (core/hooks/ema.py:14-24): shadow registered before the run, updated after every step
+        import copy
+        ema = misc.EMA(model, tr["ema_m"])
+        ema.register()
+        ema_model = copy.deepcopy(model)
     for n, it in enumerate(tr["its"]):
         for _ in range(it - prev_it - 1):
             alg.scheduler.step()
@@ -732,6 +897,15 @@ def gen_trace_pl(tr=None, fname="srpseudolabel_trace.npz"):
             flat(f"{p}/grad/{nme}", samp(prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32), 64), out)
         out[f"{p}/lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / base_lr)
         alg.optimizer.step(); alg.scheduler.step(); model.zero_grad()
+        if ema is not None:
+            ema.update()
+            ema_model.load_state_dict(model.state_dict())
+            ema_model.load_state_dict(ema.shadow, strict=False)
+            for nme, prm in ema_model.named_parameters():
+                flat(f"{p}/ema/{nme}", samp(prm.detach().numpy(), 64), out)
+            for nme, bf in ema_model.named_buffers():
+                if not nme.endswith("num_batches_tracked"):
+                    out[f"{p}/emabuf/{nme}"] = bf.numpy().copy()
         for k_, v in log.items():
             out[f"{p}/log/{k_.split('/')[-1]}"] = np.float64(v)
         out[f"{p}/K"] = np.int64(K)
@@ -838,12 +1012,18 @@ def gen_trace_soft_bert():
         orig = mh.masking
 
         def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
+            _rec.setdefault("probs", []).append((k["logits_x_ulb"] if "logits_x_ulb" in k else a[0]).detach().numpy().copy())
             m = _orig(algorithm, *a, **k)
             _rec["mask"].append(m.numpy().copy())
             return m
         mh.masking = wrapped
+        p = f"it{it}"
+        # state of the weighting hook BEFORE the step and the probabilities every masking call received (pass 0: after DistAlign): the GPU
+        # test replays the hook kernels on exactly these inputs and must reproduce the masks of all passes
+        out[f"{p}/pre/mu"] = np.float32(mh.prob_max_mu_t); out[f"{p}/pre/var"] = np.float32(mh.prob_max_var_t)
         rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
         o, log = alg.train_step(dx(lb), T(y), dx(w), dx(s_))
+        out[f"{p}/mask_probs"] = np.stack(rec["probs"])
         mh.masking = orig
         assert cm.calls == 3 + 2 * K, (cm.calls, K)          # use_cat False: lb + s + w, then (s, w) per data_generator pass
         o["loss"].backward()
@@ -927,12 +1107,18 @@ def gen_trace_free_w2v():
         orig = mh.masking
 
         def wrapped(algorithm, *a, _orig=orig, _rec=rec, **k):
+            _rec.setdefault("probs", []).append((k["logits_x_ulb"] if "logits_x_ulb" in k else a[0]).detach().numpy().copy())
             m = _orig(algorithm, *a, **k)
             _rec["mask"].append(m.numpy().copy())
             return m
         mh.masking = wrapped
+        p = f"it{it}"
+        # FreeMatch state BEFORE the step + the probabilities of every masking call: replayed through the hook kernels by the GPU test
+        out[f"{p}/pre/time_p"] = np.float32(mh.time_p); out[f"{p}/pre/p_model"] = mh.p_model.numpy().copy()
+        out[f"{p}/pre/label_hist"] = mh.label_hist.numpy().copy()
         rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
         o, log = alg.train_step(T(xl), T(y), T(xw), T(xs))
+        out[f"{p}/mask_probs"] = np.stack(rec["probs"])
         mh.masking = orig
         assert cm.calls == 3 + 2 * K, (cm.calls, K)
         o["loss"].backward()
@@ -1162,7 +1348,7 @@ def gen_trace(tr=None, fname="srflexmatch_trace.npz"):
     np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
-GENS = dict(rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
+GENS = dict(sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
             bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment, vit_b16_96=gen_vit_b16_96)

@@ -65,9 +65,13 @@ SIGNATURES = {
     "srhip_rewarder_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_rewarder_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "srhip_generator_fwd": (I, [P, P, P, P, P, I, I, P]),
-    "srhip_sr_target": (I, [P, P, P, I, P]),
+    "srhip_sr_target": (I, [P, P, P, I, I, P]),
+    "srhip_label_error": (I, [P, I, P]),
+    "srhip_index_error": (I, [P, I, P]),
     "srhip_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P]),
-    "srhip_adamw_flat": (I, [P, P, P, P, P, P, P, I, P, P, F, F, F, F, I, F, F, I, P]),
+    "srhip_adamw_flat": (I, [P, P, P, P, P, P, P, I, P, P, F, F, F, F, I, Dbl, F, P, I, P]),
+    "srhip_clip_grad_ws_floats": (I, []),
+    "srhip_clip_grad_coef": (I, [P, L, F, F, P, P, P]),
     "srhip_nchw_to_nhwc_bf16": (I, [P, P, I, I, I, I, P]),
     "srhip_im2col": (I, [P, P, I, I, I, I, I, I, I, P]),
     "srhip_col2im": (I, [P, P, I, I, I, I, I, I, I, I, P]),
@@ -79,7 +83,7 @@ SIGNATURES = {
     "srhip_avgpool_bwd": (I, [P, P, I, I, I, P]),
     "srhip_fc_fwd": (I, [P, P, P, P, I, I, I, P]),
     "srhip_fc_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
-    "srhip_sgd_flat": (I, [P, P, P, P, P, I, L, F, F, F, F, I, I, P]),
+    "srhip_sgd_flat": (I, [P, P, P, P, P, I, L, F, F, F, P, Dbl, I, I, P]),
     "srhip_gemm_nt_resid_dropout": (I, [P, I, P, I, P, I, I, I, I, P, P, I, U, U, F, P]),
     "srhip_attn_masked_fwd": (I, [P, P, P, P, I, I, I, F, U, U, F, P]),
     "srhip_attn_masked_bwd": (I, [P, P, P, P, P, P, P, I, I, I, F, U, U, F, P]),

@@ -182,9 +182,10 @@ class FlatAdam:
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.steps = int(sd["steps"])
 
 
-def cosine_target(gen_labels, ref_labels):
-    """(cosine_similarity_n(one_hot(gen), one_hot(ref)) + 1)/2 == 1.0 / 0.5 (semireward.py:130-139, srflexmatch.py:180-182)."""
+def cosine_target(gen_labels, ref_labels, num_classes=0):
+    """(cosine_similarity_n(one_hot(gen), one_hot(ref)) + 1)/2 == 1.0 / 0.5 (semireward.py:130-139, srflexmatch.py:180-182).  With
+    num_classes > 0 a label outside [0, num_classes) -- where F.one_hot raises -- sets the label-error flag (ops.check_label_errors)."""
     B = gen_labels.numel()
     t = torch.empty(B, dtype=torch.float32, device=gen_labels.device)
-    ops.sr_target(gen_labels.contiguous(), ref_labels.contiguous(), t, B)
+    ops.sr_target(gen_labels.contiguous(), ref_labels.contiguous(), t, B, num_classes)
     return t

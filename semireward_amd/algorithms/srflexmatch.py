@@ -309,7 +309,7 @@ class SRConsistencyBase(AlgorithmBase):
     def _sr_update(self, feats, gen_labels, ref_labels):
         """srflexmatch.py:179-193 / :194-208: target, MSE(r,1) + MSE(r,t), both backward() into the rewarder, Adam."""
         feats = feats.contiguous()
-        target = cosine_target(gen_labels, ref_labels)
+        target = cosine_target(gen_labels, ref_labels, self.num_classes)
         self.rewarder.train()
         self.rewarder.score(feats, gen_labels, groups=1, save_for_bwd=True)
         losses = torch.empty(2, dtype=torch.float32, device=self.device)
@@ -317,6 +317,8 @@ class SRConsistencyBase(AlgorithmBase):
         if self.dp.active:
             self.dp.all_reduce_flat(self.rewarder.grad).mul_(1.0 / self.world_size)
         self.rewarder_optimizer.step()
+        if ops._CHECK_ARGS:                 # test suite: surface an out-of-range label at the update itself (production: AlgorithmBase.train
+            ops.check_label_errors()        # checks at epoch boundaries and before a checkpoint -- the check synchronises)
         if self.trace is not None:
             self.trace.update(sr_target=target, sr_losses=losses)
 
@@ -326,7 +328,9 @@ class SRConsistencyBase(AlgorithmBase):
             # usb_nlp: x_* are {'input_ids','attention_mask'} dicts, each batch padded to its own longest row (nlp_collactor.py:63-69);
             # the reference forwards them in separate model calls (use_cat=False, :118-128) -- here they share the batched launches,
             # filled up to the longest of the three (TokenBatch.cat: identical results, see nets/bert.py)
-            assert not self.use_cat, "token batches of different padded lengths cannot be torch.cat'ed: the usb_nlp configs set use_cat False"
+            if self.use_cat:
+                raise ValueError("use_cat: True with token batches: batches of different padded lengths cannot be torch.cat'ed "
+                                 "(the reference fails in torch.cat, srsoftmatch.py:118); the usb_nlp / usb_audio configs set use_cat False")
             tb = [self._tokens(x) for x in (x_lb, x_ulb_w, x_ulb_s)]
             nl, nu = tb[0].S, tb[1].S
             imgs = self._token_cat(tb)

@@ -19,7 +19,7 @@ from .. import ops
 from ..distributed import DataParallel
 from ..optim import FusedAdamW, FusedSGD
 from .criterions import CELoss, ConsistencyLoss
-from .hooks import EMAHook, Hook, ParamUpdateHook, get_priority
+from .hooks import EMAHook, Hook, ParamUpdateHook, TimerHook, get_priority
 
 
 class DeferredScalar:
@@ -69,8 +69,13 @@ class AlgorithmBase:
         self.num_iter_per_epoch = int(self.num_train_iter // max(1, self.epochs))
         self.lambda_u = g("ulb_loss_ratio", 1.0)
         self.use_cat = g("use_cat", True)
-        self.use_amp = g("amp", False)       # the HIP engine always runs bf16 operands / fp32 accumulate
-        self.clip_grad = g("clip_grad", 0)
+        self.use_amp = g("amp", False)
+        if self.use_amp:
+            # the reference's amp is fp16 autocast + GradScaler (algorithmbase.py:103-104, param_update.py:27-32); this engine has one
+            # numeric mode (bf16 operands, fp32 accumulate / residual / optimizer) and no loss scaler: refuse rather than ignore the key
+            raise NotImplementedError("amp: True is not supported by the HIP engine (bf16 operands / fp32 accumulation is always on; "
+                                      "set amp: False as every config/SemiReward yaml does)")
+        self.clip_grad = float(g("clip_grad", 0) or 0)      # > 0: clip_grad_norm_ folded into the optimizer launch (optim._clip_coef)
         self.save_name, self.save_dir = g("save_name", "run"), g("save_dir", "./saved_models")
         self.resume = g("resume", False)
         self.algorithm = g("algorithm", None)
@@ -138,6 +143,7 @@ class AlgorithmBase:
     def set_hooks(self):
         self.register_hook(ParamUpdateHook(), None, "HIGHEST")
         self.register_hook(EMAHook(), None, "HIGH")
+        self.register_hook(TimerHook(), None, "LOWEST")           # algorithmbase.py:564: train/prefetch_time, train/run_time, lr
 
     # ---- batch / dict helpers (algorithmbase.py:282-333) -------------------------------------------
     def process_batch(self, input_args=None, **kwargs):
@@ -193,6 +199,7 @@ class AlgorithmBase:
                 self.call_hook("after_train_step")
                 self.it += 1
             self.call_hook("after_train_epoch")
+            ops.check_label_errors()        # IndexError of nn.Embedding / F.one_hot in the reference; the device flag is read where the host may wait
         self.call_hook("after_run")
 
     # ---- evaluation (algorithmbase.py:377-457) ----------------------------------------------------------------
@@ -268,6 +275,7 @@ class AlgorithmBase:
                 "best_eval_acc": self.best_eval_metric}
 
     def save_model(self, save_name, save_path):
+        ops.check_label_errors()
         os.makedirs(save_path, exist_ok=True)
         torch.save(self.get_save_dict(), os.path.join(save_path, save_name))
 
@@ -279,7 +287,10 @@ class AlgorithmBase:
         self.it, self.start_epoch = ck["it"], ck["epoch"]
         self.epoch, self.best_it = self.start_epoch, ck["best_it"]
         self.best_eval_metric = ck.get("best_eval_acc", 0.0)
-        self.optimizer.load_state_dict(ck["optimizer"])
+        self.optimizer.load_state_dict(ck["optimizer"])             # engine layout, or torch.optim layout of a reference checkpoint
+        sch = ck.get("scheduler") or {}
+        if "last_epoch" in sch:                                     # LambdaLR.state_dict() (algorithmbase.py:468)
+            self.optimizer.sched_step = int(sch["last_epoch"])
         return ck
 
     # ---- hooks (algorithmbase.py:548-599) ---------------------------------------------------------------------

@@ -141,6 +141,13 @@ __global__ void transpose_small_kernel(const float* __restrict__ W, float* __res
   if (i < J * K) { const int j = i / K, k = i % K; WT[(size_t)k * J + j] = W[i]; }
 }
 
+// Label range errors (nn.Embedding / F.one_hot raise in the reference for an index outside [0, label_dim), semireward.py:57, srflexmatch.py:
+// 180-181).  A kernel cannot raise: it records the event in this word and stays memory safe (embedding row 0 is read, the scatter is skipped);
+// the host fetches the word with srhip_label_error() at its next synchronisation point and raises there.
+// bit 0: embedding lookup out of range, bit 1: embedding-gradient scatter out of range, bit 2: generator output not representable (NaN / >= 2^63),
+// bit 3: one_hot class out of range in the SR target
+__device__ int srhip_label_err;
+
 // Kernel 1: a tile of 8 feature rows AND the matching 8 label rows of one group.
 // feature_fc (F->128) through tile_linear, then one wave per 2 rows for the two LayerNorms and the attention logit.
 // grid = (ceil(B/8), G), block 256, dyn LDS = (F*8 + 128*8 + 256*8) floats.
@@ -171,7 +178,8 @@ __global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict_
       v0 = hT[lane * RT + r]; v1 = hT[(lane + 64) * RT + r];
       gam = P + o.gf; bet = P + o.bef;
     } else {
-      const long long y = labels[(size_t)grp * B + row];
+      long long y = labels[(size_t)grp * B + row];
+      if (y < 0 || y >= L) { if (lane == 0) atomicOr(&srhip_label_err, 1); y = 0; }
       const float* e = P + o.Emb + (size_t)y * E;
       v0 = e[lane]; v1 = e[lane + 64];
       gam = P + o.gl; bet = P + o.bl;
@@ -381,9 +389,11 @@ __global__ void small_dw_kernel(const float* __restrict__ dY, int ldy, const flo
 }
 
 // Step D: label-embedding gradient, dEmb[y_b] += d(e_pre)_b  (duplicates -> atomics).  grid = B, block = 128
-__global__ void rew_emb_scatter_kernel(const float* __restrict__ dpre, const long long* __restrict__ labels, float* __restrict__ dEmb) {
+__global__ void rew_emb_scatter_kernel(const float* __restrict__ dpre, const long long* __restrict__ labels, float* __restrict__ dEmb, int L) {
   const int b = blockIdx.x;
-  atomicAdd(dEmb + (size_t)labels[b] * E + threadIdx.x, dpre[(size_t)b * E + threadIdx.x]);
+  const long long y = labels[b];
+  if (y < 0 || y >= L) { if (threadIdx.x == 0) atomicOr(&srhip_label_err, 2); return; }
+  atomicAdd(dEmb + (size_t)y * E + threadIdx.x, dpre[(size_t)b * E + threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,15 +427,27 @@ __global__ __launch_bounds__(256) void generator_kernel(const float* __restrict_
   for (int r = wave; r < RT; r += 4) {
     const int row = r0 + r;
     if (row >= B) continue;
-    const float v = fmaxf(wave_sum(h3[lane * RT + r] * W4[lane]) + b4[0], 0.f);
-    if (lane == 0) { out[row] = v; label[row] = (long long)v; }   // .long(): truncation toward zero
+    const float pre = wave_sum(h3[lane * RT + r] * W4[lane]) + b4[0];
+    const float v = pre != pre ? pre : fmaxf(pre, 0.f);            // torch.relu propagates NaN (fmaxf would return 0)
+    if (lane == 0) {
+      out[row] = v;
+      // .long(): truncation toward zero; NaN / out-of-range conversions are undefined in C and garbage in torch -> -1 + error flag (the
+      // reference then fails in F.one_hot / nn.Embedding)
+      const bool ok = v < 9.2e18f;                                 // false for NaN and +inf too; v >= 0 after the ReLU
+      if (!ok) atomicOr(&srhip_label_err, 4);
+      label[row] = ok ? (long long)v : -1;
+    }
   }
 }
 
 // target_b = 1.0 if gen_b == ref_b else 0.5   ( (cos(one_hot, one_hot) + 1) / 2, srflexmatch.py:180-182 )
-__global__ void sr_target_kernel(const long long* __restrict__ gen, const long long* __restrict__ ref, float* __restrict__ target, int B) {
+__global__ void sr_target_kernel(const long long* __restrict__ gen, const long long* __restrict__ ref, float* __restrict__ target, int B,
+                                 int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) target[i] = gen[i] == ref[i] ? 1.0f : 0.5f;
+  if (i >= B) return;
+  const long long a = gen[i], b = ref[i];
+  if (C > 0 && (a < 0 || a >= C || b < 0 || b >= C)) atomicOr(&srhip_label_err, 8);      // F.one_hot(., num_classes) raises
+  target[i] = a == b ? 1.0f : 0.5f;
 }
 
 // torch.optim.Adam, flat fp32 block (betas 0.9/0.999, eps 1e-8, no weight decay)
@@ -510,7 +532,7 @@ extern "C" int srhip_rewarder_bwd(const float* params, const float* feats, const
   hipLaunchKernelGGL(small_dw_kernel, dim3(256), dim3(128), 0, s, ws + w.dm1, 256, ws + w.u, E, grads + o.W1, grads + o.b1, B, E);
   // feature_fc: d(pre) of the B feature rows sits in dz rows [0,B); label rows [B,2B) feed the embedding
   hipLaunchKernelGGL(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dz, E, feats, F, grads + o.Wf, grads + o.bf, B, F);
-  hipLaunchKernelGGL(rew_emb_scatter_kernel, dim3(B), dim3(E), 0, s, ws + w.dz + (size_t)B * E, labels, grads + o.Emb);
+  hipLaunchKernelGGL(rew_emb_scatter_kernel, dim3(B), dim3(E), 0, s, ws + w.dz + (size_t)B * E, labels, grads + o.Emb, L);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -524,9 +546,22 @@ extern "C" int srhip_generator_fwd(const float* params, const float* params_t, c
   return SR_OK;
 }
 
-extern "C" int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, void* stream) {
+extern "C" int srhip_label_error(int* bits_out, int reset, void* stream) {
+  if (!bits_out) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyFromSymbolAsync(bits_out, HIP_SYMBOL(srhip_label_err), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return SR_ELAUNCH;
+  if (hipStreamSynchronize(s) != hipSuccess) return SR_ELAUNCH;
+  if (reset && *bits_out) {
+    const int z = 0;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(srhip_label_err), &z, sizeof(int), 0, hipMemcpyHostToDevice, s) != hipSuccess) return SR_ELAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return SR_ELAUNCH;
+  }
+  return SR_OK;
+}
+
+extern "C" int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, int num_classes, void* stream) {
   if (B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(sr_target_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, gen, ref, target, B);
+  hipLaunchKernelGGL(sr_target_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, gen, ref, target, B, num_classes);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -16,6 +16,8 @@
 // scatter itself (old label -> new label), which is bit-identical to a recount.
 // Bit-exactness: the threshold p_cutoff * (acc / (2 - acc)) is evaluated op by op
 // in fp32 with contraction disabled; classwise_acc = (float)((double)cnt / (double)max).
+#include <stdlib.h>
+
 #include "common.h"
 #include "srhip.h"
 
@@ -59,12 +61,106 @@ __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ 
   if (lane == 0) { max_probs[row] = bv; max_idx[row] = bi; }
 }
 
+// Index errors: an idx_ulb entry outside [0, ulb_dest_len) raises IndexError in the reference (utils.py:59 index_put); here the entry is
+// skipped (no out-of-bounds write) and bit 0 of this word is set; the host reads it with srhip_index_error() and raises.
+__device__ int srhip_index_err;
+
 // FlexMatch masking + state update.  ONE workgroup (the step is sequential by definition).
 //   mask[i]   = max_p[i] >= p_cutoff * (acc[idx] / (2 - acc[idx]))          (utils.py:53, BEFORE the update)
 //   select[i] = max_p[i] >= p_cutoff ; selected_label[idx_ulb[i]] = max_idx[i]   (utils.py:56-60)
 //   hist bookkeeping, then classwise_acc update                                (utils.py:24-35)
 // n_pass > 1: the passes of one SemiReward step (srflexmatch.py:75-104 calls masking once per data_generator pass, on the SAME idx_ulb) in
-// ONE launch, in order -- pass p reads the state pass p-1 left.  State written by one pass is re-read through device-scope loads.
+// ONE launch, in order -- pass p reads the state pass p-1 left.
+//
+// The whole state a launch touches lives in LDS between the passes: hist[C+1], classwise_acc[C] and the B entries selected_label[idx_ulb[i]]
+// (the passes share idx_ulb).  Global memory is read once at the start (two dependent round trips: idx_ulb -> selected_label) and written
+// once at the end; a pass is three workgroup barriers.  (The first version kept the state in global memory behind device-scope atomics
+// and two __threadfence() per pass: 9 us per pass, 81 us for the 9 passes of a step that move 7 KB.)
+// Duplicate indices inside one batch (the sampler's concatenated permutations can meet): all copies share one LDS slot (rep = first copy) and
+// of the copies selected in a pass the LAST one writes, which is what the reference's CPU index_put does; hist then stays equal to a recount.
+__global__ __launch_bounds__(256) void flexmatch_mask_lds_kernel(const float* __restrict__ max_probs, const long long* __restrict__ max_idx,
+                                                                const long long* __restrict__ idx_ulb, float p_cutoff,
+                                                                long long* __restrict__ selected_label, int* __restrict__ hist,
+                                                                float* __restrict__ classwise_acc, float* __restrict__ mask,
+                                                                int B, int C, int ulb_dest_len, int thresh_warmup, int n_pass) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fm_raw[];
+  int* s_hist = reinterpret_cast<int*>(fm_raw);              // [C + 1]
+  float* s_acc = reinterpret_cast<float*>(s_hist + C + 1);   // [C]
+  int* s_j = reinterpret_cast<int*>(s_acc + C);              // [B] idx_ulb (or -1: out of range)
+  int* s_rep = s_j + B;                                      // [B] first i' with the same index
+  int* s_next = s_rep + B;                                   // [B] next i' > i with the same index, or -1
+  int* s_sel = s_next + B;                                   // [B] current selected_label of the index (valid at rep)
+  int* s_sel0 = s_sel + B;                                   // [B] its value at launch start
+  int* s_flag = s_sel0 + B;                                  // [B] select of the running pass
+  __shared__ int smax[2];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int c = tid; c <= C; c += nt) s_hist[c] = hist[c];
+  for (int c = tid; c < C; c += nt) s_acc[c] = classwise_acc[c];
+  for (int i = tid; i < B; i += nt) {
+    long long j = idx_ulb ? idx_ulb[i] : -1;
+    if (j < 0 || j >= ulb_dest_len) { atomicOr(&srhip_index_err, 1); j = -1; }
+    s_j[i] = (int)j;
+    const int v = j >= 0 ? (int)selected_label[j] : -1;
+    s_sel[i] = v; s_sel0[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < B; i += nt) {
+    const int j = s_j[i];
+    int rep = i, nx = -1;
+    if (j >= 0) {
+      for (int k = 0; k < i; ++k) if (s_j[k] == j) { rep = k; break; }
+      for (int k = i + 1; k < B; ++k) if (s_j[k] == j) { nx = k; break; }
+    }
+    s_rep[i] = rep; s_next[i] = nx;
+  }
+  __syncthreads();
+  for (int p = 0; p < n_pass; ++p) {
+    const float* mpp = max_probs + (size_t)p * B;
+    const long long* mip = max_idx + (size_t)p * B;
+    float* mk = mask + (size_t)p * B;
+    for (int i = tid; i < B; i += nt) {
+      const float mp = mpp[i];
+      const int cls = (int)mip[i];
+      const float acc = s_acc[cls];
+      const float den = 2.0f - acc;
+      const float rat = acc / den;
+      const float thr = p_cutoff * rat;
+      mk[i] = mp >= thr ? 1.0f : 0.0f;
+      s_flag[i] = (mp >= p_cutoff && s_j[i] >= 0) ? 1 : 0;
+    }
+    if (tid < 2) smax[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < B; i += nt) {
+      if (!s_flag[i]) continue;
+      bool last = true;
+      for (int k = s_next[i]; k >= 0; k = s_next[k]) if (s_flag[k]) { last = false; break; }
+      if (!last) continue;
+      const int cls = (int)mip[i], r = s_rep[i], old = s_sel[r];
+      if (old != cls) {
+        s_sel[r] = cls;
+        atomicSub(&s_hist[old < 0 || old >= C ? C : old], 1);
+        atomicAdd(&s_hist[cls], 1);
+      }
+    }
+    __syncthreads();
+    int m = 0;
+    for (int c = tid; c < C; c += nt) m = max(m, s_hist[c]);
+    if (m > 0) atomicMax(&smax[0], m);
+    __syncthreads();
+    const int max_cls = smax[0], max_all = max(max_cls, s_hist[C]);
+    if (max_all < ulb_dest_len) {
+      const int den = thresh_warmup ? max_all : max_cls;
+      for (int c = tid; c < C; c += nt) s_acc[c] = (float)((double)s_hist[c] / (double)den);
+    }
+    __syncthreads();                  // the next pass reads s_acc / s_sel / s_hist; smax is reset after this point
+  }
+  for (int c = tid; c <= C; c += nt) hist[c] = s_hist[c];
+  for (int c = tid; c < C; c += nt) classwise_acc[c] = s_acc[c];
+  for (int i = tid; i < B; i += nt)
+    if (s_j[i] >= 0 && s_rep[i] == i && s_sel[i] != s_sel0[i]) selected_label[s_j[i]] = (long long)s_sel[i];
+}
+
+// General path (state too large for LDS: C > 8192 or B > 4096): state in global memory behind device-scope atomics, two fences per pass.
 __global__ __launch_bounds__(256) void flexmatch_mask_kernel(const float* __restrict__ max_probs, const long long* __restrict__ max_idx,
                                                             const long long* __restrict__ idx_ulb, float p_cutoff,
                                                             long long* __restrict__ selected_label, int* __restrict__ hist,
@@ -85,10 +181,11 @@ __global__ __launch_bounds__(256) void flexmatch_mask_kernel(const float* __rest
       mk[i] = mp >= thr ? 1.0f : 0.0f;
       if (mp >= p_cutoff) {
         const long long j = idx_ulb[i];
-        const long long old = __hip_atomic_load(selected_label + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j < 0 || j >= ulb_dest_len) { atomicOr(&srhip_index_err, 1); continue; }
+        // exchange, not load + store: two rows with the same index both see the true previous label, so hist stays a recount
+        const long long old = (long long)atomicExch(reinterpret_cast<unsigned long long*>(selected_label + j), (unsigned long long)(long long)cls);
         if (old != cls) {
-          __hip_atomic_store(selected_label + j, (long long)cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicSub(hist + (old < 0 ? C : (int)old), 1);
+          atomicSub(hist + (old < 0 || old >= C ? C : (int)old), 1);
           atomicAdd(hist + cls, 1);
         }
       }
@@ -393,19 +490,35 @@ extern "C" int srhip_row_max(const float* in, int in_is_probs, float* probs_out,
 extern "C" int srhip_flexmatch_mask(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
                                     long long* selected_label, int* hist, float* classwise_acc, float* mask, int B, int C,
                                     int ulb_dest_len, int thresh_warmup, void* stream) {
-  if (B <= 0 || C <= 0 || ulb_dest_len <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
-                     selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, 1);
-  SR_CHECK_LAUNCH();
-  return SR_OK;
+  return srhip_flexmatch_mask_passes(max_probs, max_idx, idx_ulb, p_cutoff, selected_label, hist, classwise_acc, mask, 1, B, C, ulb_dest_len,
+                                     thresh_warmup, stream);
 }
 extern "C" int srhip_flexmatch_mask_passes(const float* max_probs, const long long* max_idx, const long long* idx_ulb, float p_cutoff,
                                            long long* selected_label, int* hist, float* classwise_acc, float* mask, int n_pass, int B, int C,
                                            int ulb_dest_len, int thresh_warmup, void* stream) {
-  if (n_pass <= 0 || B <= 0 || C <= 0 || ulb_dest_len <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
-                     selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
+  if (n_pass <= 0 || B <= 0 || C <= 0 || ulb_dest_len <= 0 || !idx_ulb) return SR_EINVAL;
+  if (C <= 8192 && B <= 4096 && !getenv("SRHIP_FLEXMATCH_GENERAL")) {
+    const size_t smem = (size_t)(2 * C + 1) * 4 + (size_t)B * 6 * 4;
+    (void)hipFuncSetAttribute((const void*)flexmatch_mask_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(flexmatch_mask_lds_kernel, dim3(1), dim3(256), smem, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
+                       selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
+  } else {
+    hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
+                       selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
+  }
   SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_index_error(int* bits_out, int reset, void* stream) {
+  if (!bits_out) return SR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyFromSymbolAsync(bits_out, HIP_SYMBOL(srhip_index_err), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return SR_ELAUNCH;
+  if (hipStreamSynchronize(s) != hipSuccess) return SR_ELAUNCH;
+  if (reset && *bits_out) {
+    const int z = 0;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(srhip_index_err), &z, sizeof(int), 0, hipMemcpyHostToDevice, s) != hipSuccess) return SR_ELAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return SR_ELAUNCH;
+  }
   return SR_OK;
 }
 

@@ -210,20 +210,21 @@ __global__ void fc_bwd_w_kernel(const float* __restrict__ dl, const float* __res
 struct SgdChunk { long long end; float wd; float pad; };
 __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, float* __restrict__ ema,
                                                       const SgdChunk* __restrict__ table, int nchunks, long long n, float lr, float momentum,
-                                                      float grad_scale, float ema_m, int first, int zero_grad) {
+                                                      float grad_scale, const float* __restrict__ clip_coef, float ema_m, float ema_1m, int first,
+                                                      int zero_grad) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   int lo = 0, hi = nchunks - 1;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (i < table[mid].end) hi = mid; else lo = mid + 1; }
   const float wd = table[lo].wd;
-  float d = g[i] * grad_scale;
+  float d = g[i] * (clip_coef ? grad_scale * clip_coef[0] : grad_scale);
   const float pv = p[i];
   if (wd != 0.f) d += wd * pv;
   const float b = first ? d : momentum * buf[i] + d;
   buf[i] = b;
   const float np = pv - lr * (d + momentum * b);
   p[i] = np;
-  if (ema) ema[i] = ema_m * ema[i] + (1.0f - ema_m) * np;
+  if (ema) ema[i] = __fadd_rn(__fmul_rn(ema_1m, np), __fmul_rn(ema_m, ema[i]));      // misc.py:154, op for op
   if (zero_grad) g[i] = 0.f;
 }
 
@@ -338,9 +339,11 @@ extern "C" int srhip_fc_bwd(const float* dlogits, const float* feat, const float
 }
 
 extern "C" int srhip_sgd_flat(float* p, float* g, float* buf, float* ema, const void* chunk_table, int nchunks, long long n, float lr,
-                              float momentum, float grad_scale, float ema_m, int first_step, int zero_grad, void* stream) {
+                              float momentum, float grad_scale, const float* clip_coef, double ema_m, int first_step, int zero_grad,
+                              void* stream) {
   if (!p || !g || !buf || !chunk_table || nchunks <= 0 || n <= 0) return SR_EINVAL;
-  LAUNCH1D(sgd_flat_kernel, n, p, g, buf, ema, (const SgdChunk*)chunk_table, nchunks, n, lr, momentum, grad_scale, ema_m, first_step, zero_grad);
+  LAUNCH1D(sgd_flat_kernel, n, p, g, buf, ema, (const SgdChunk*)chunk_table, nchunks, n, lr, momentum, grad_scale, clip_coef, (float)ema_m,
+           (float)(1.0 - ema_m), first_step, zero_grad);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

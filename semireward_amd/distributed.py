@@ -15,6 +15,7 @@ class DataParallel:
     def __init__(self, world_size=1, rank=0, global_reward_threshold=False):
         self.world_size, self.rank = world_size, rank
         self.global_reward_threshold = global_reward_threshold
+        self.comm_events = None      # bench.py: list that receives a HIP-event pair around the gradient all-reduce of every step
 
     @property
     def active(self):
@@ -44,6 +45,16 @@ class DataParallel:
     def all_reduce_grads(self, model):
         if not self.active:
             return
+        if self.comm_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._all_reduce_grads(model)
+            e1.record()
+            self.comm_events.append((e0, e1))
+            return
+        self._all_reduce_grads(model)
+
+    def _all_reduce_grads(self, model):
         done = sorted(getattr(self, "_done", ())) if getattr(self, "_model", None) is model else []
         if not done:
             dist.all_reduce(model.grad, op=dist.ReduceOp.SUM)

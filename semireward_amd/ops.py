@@ -430,8 +430,28 @@ def generator_fwd(params, params_t, x, out, label, B, F):
     _call("srhip_generator_fwd", _p(params), _p(params_t), _p(x), _p(out), _p(label), B, F, _s())
 
 
-def sr_target(gen, ref, target, B):
-    _call("srhip_sr_target", _p(gen), _p(ref), _p(target), B, _s())
+def sr_target(gen, ref, target, B, num_classes=0):
+    _call("srhip_sr_target", _p(gen), _p(ref), _p(target), B, num_classes, _s())
+
+
+_LABEL_ERR = ("a label outside [0, label_dim) reached the rewarder's nn.Embedding (semireward.py:57)",
+              "a label outside [0, label_dim) reached the embedding gradient (semireward.py:57)",
+              "the generator output is NaN or not representable as int64 (srflexmatch.py:158-159)",
+              "a label outside [0, num_classes) reached F.one_hot of the SR target (srflexmatch.py:180-181, :195-196)")
+
+
+def check_label_errors(reset=True):
+    """Raises IndexError if a rewarder / generator launch since the last check saw an out-of-range label -- the error the reference raises
+    from nn.Embedding / F.one_hot at the call itself.  Synchronises the current stream: call it where the host waits anyway."""
+    import ctypes
+    bits, ibits = ctypes.c_int(0), ctypes.c_int(0)
+    _call("srhip_label_error", ctypes.addressof(bits), int(reset), _s())
+    _call("srhip_index_error", ctypes.addressof(ibits), int(reset), _s())
+    msgs = [m for i, m in enumerate(_LABEL_ERR) if bits.value >> i & 1]
+    if ibits.value:
+        msgs.append("an idx_ulb entry outside [0, ulb_dest_len) reached FlexMatchThresholdingHook.update (srflexmatch/utils.py:59)")
+    if msgs:
+        raise IndexError("libsrhip: " + "; ".join(msgs))
 
 
 def adam_flat(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -439,9 +459,19 @@ def adam_flat(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 def adamw_flat(p, g, m, v, p_bf16, ema, chunk_table, n_chunks, lr_t, wd_t, lr_factor, step, beta1=0.9, beta2=0.999, eps=1e-8,
-               ema_m=0.0, grad_scale=1.0, zero_grad=True):
+               ema_m=0.0, grad_scale=1.0, zero_grad=True, clip_coef=None):
     _call("srhip_adamw_flat", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(ema), _p(chunk_table), n_chunks, _p(lr_t), _p(wd_t),
-          lr_factor, beta1, beta2, eps, step, ema_m, grad_scale, int(zero_grad), _s())
+          lr_factor, beta1, beta2, eps, step, float(ema_m), grad_scale, _p(clip_coef), int(zero_grad), _s())
+
+
+def clip_grad_coef(g, n, pre_scale, max_norm, ws, coef_out):
+    """coef_out[0] = min(1, max_norm / (||pre_scale * g|| + 1e-6)), coef_out[1] = the norm (clip_grad_norm_, param_update.py:34-35)."""
+    _call("srhip_clip_grad_coef", _p(g), n, pre_scale, max_norm, _p(ws), _p(coef_out), _s())
+
+
+def clip_grad_ws_floats():
+    from ._lib import lib
+    return int(lib().srhip_clip_grad_ws_floats())
 
 
 # ---- WideResNet building blocks (classic_cv parity configuration) ---------------------------------------------------------------
@@ -492,9 +522,9 @@ def fc_bwd(dlogits, feat, Wc, dfeat, dWc, dbc, B, F, K):
     _call("srhip_fc_bwd", _p(dlogits), _p(feat), _p(Wc), _p(dfeat), _p(dWc), _p(dbc), B, F, K, _s())
 
 
-def sgd_flat(p, g, buf, ema, table, nchunks, n, lr, momentum, grad_scale=1.0, ema_m=0.0, first_step=False, zero_grad=True):
-    _call("srhip_sgd_flat", _p(p), _p(g), _p(buf), _p(ema), _p(table), nchunks, n, lr, momentum, grad_scale, ema_m, int(first_step),
-          int(zero_grad), _s())
+def sgd_flat(p, g, buf, ema, table, nchunks, n, lr, momentum, grad_scale=1.0, ema_m=0.0, first_step=False, zero_grad=True, clip_coef=None):
+    _call("srhip_sgd_flat", _p(p), _p(g), _p(buf), _p(ema), _p(table), nchunks, n, lr, momentum, grad_scale, _p(clip_coef), float(ema_m),
+          int(first_step), int(zero_grad), _s())
 
 
 # ---- post-LN encoder (BERT / Wav2Vec2) --------------------------------------------------------------

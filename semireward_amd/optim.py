@@ -60,6 +60,25 @@ def layer_decay_hparams(names_shapes, depth, lr, weight_decay, layer_decay, no_w
     return out
 
 
+def torch_group_order(model, layer_decay):
+    """Parameter names per torch param group, in the order the reference's get_optimizer creates the groups (build.py:193-224): with layer
+    decay one group per (layer id, no_decay | decay) in order of first appearance while walking named_parameters() (nets/utils.py:172-201,
+    no_decay = 1-D or in no_weight_decay()); without it [no_decay, decay] (nets/utils.py:77-97, no_decay also for ``.bias``)."""
+    nwd = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
+    if layer_decay == 1.0:
+        nd = [n for n, s in model.names_shapes if len(s) <= 1 or n.endswith(".bias") or n in nwd]
+        return [nd, [n for n, _ in model.names_shapes if n not in set(nd)]]
+    ids = model.layer_ids()[0] if hasattr(model, "layer_ids") else {n: vit_layer_id(n, model.cfg.depth) for n, _ in model.names_shapes}
+    groups, key_of = [], {}
+    for n, shp in model.names_shapes:
+        k = (ids[n], len(shp) == 1 or n in nwd)
+        if k not in key_of:
+            key_of[k] = len(groups)
+            groups.append([])
+        groups[key_of[k]].append(n)
+    return groups
+
+
 def cosine_with_warmup(step, num_training_steps, num_warmup_steps=0, num_cycles=7.0 / 16.0):
     if step < num_warmup_steps:
         return float(step) / float(max(1, num_warmup_steps))
@@ -67,9 +86,25 @@ def cosine_with_warmup(step, num_training_steps, num_warmup_steps=0, num_cycles=
     return max(0.0, math.cos(math.pi * num_cycles * t))
 
 
+def _clip_coef(opt, grad_scale, clip_grad):
+    """clip_grad_norm_(model.parameters(), clip_grad) of the reference's ParamUpdateHook (param_update.py:34-35) without rewriting the
+    gradients: the global norm of the (already all-reduced, 1/world-scaled) flat gradient block is reduced on the device and the resulting
+    coefficient min(1, clip / (norm + 1e-6)) is folded into the optimizer launch.  ``opt.last_grad_norm`` keeps [coef, norm] on the device."""
+    if not clip_grad or clip_grad <= 0:
+        return None
+    if getattr(opt, "_clip_ws", None) is None:
+        dev = opt.model.grad.device
+        opt._clip_ws = torch.empty(ops.clip_grad_ws_floats(), dtype=torch.float32, device=dev)
+        opt.last_grad_norm = torch.zeros(2, dtype=torch.float32, device=dev)
+    ops.clip_grad_coef(opt.model.grad, opt.model.grad.numel(), float(grad_scale), float(clip_grad), opt._clip_ws, opt.last_grad_norm)
+    return opt.last_grad_norm
+
+
 class FusedAdamW:
     """Optimizer + LambdaLR scheduler of the reference collapsed into one object (step() == optimizer.step();
-    scheduler.step(); model.zero_grad()).  ``state_dict`` keeps torch-compatible keys for checkpoints."""
+    scheduler.step(); model.zero_grad()).  ``state_dict`` is ENGINE-SPECIFIC (flat ``m`` / ``v`` blocks in named_parameters() order +
+    step counters), not torch.optim's per-parameter ``state`` / ``param_groups`` layout; ``load_state_dict`` also accepts that torch layout
+    (a checkpoint written by the reference, algorithmbase.py:459-475) and converts it."""
 
     def __init__(self, model, lr, weight_decay, layer_decay, num_train_iter, num_warmup_iter, betas=(0.9, 0.999), eps=1e-8):
         self.model = model
@@ -88,6 +123,7 @@ class FusedAdamW:
         self.step_count = 0          # optimizer steps taken (bias correction)
         self.sched_step = 0          # LambdaLR last_epoch
         self.base_lr = lr
+        self.layer_decay = layer_decay
 
     def lr_factor(self):
         return cosine_with_warmup(self.sched_step, self.num_train_iter, self.num_warmup_iter)
@@ -95,11 +131,12 @@ class FusedAdamW:
     def get_last_lr(self):
         return [self.base_lr * self.lr_factor()]
 
-    def step(self, ema=None, ema_m=0.0, grad_scale=1.0):
+    def step(self, ema=None, ema_m=0.0, grad_scale=1.0, clip_grad=0.0):
         self.step_count += 1
+        coef = _clip_coef(self, grad_scale, clip_grad)
         ops.adamw_flat(self.model.flat, self.model.grad, self.m, self.v, self.model.flat_bf16, ema, self.table,
                        self.table.shape[0], self.lr_t, self.wd_t, self.lr_factor(), self.step_count, self.betas[0],
-                       self.betas[1], self.eps, ema_m=ema_m, grad_scale=grad_scale, zero_grad=True)
+                       self.betas[1], self.eps, ema_m=ema_m, grad_scale=grad_scale, zero_grad=True, clip_coef=coef)
         self.model.refresh_transposed()
         self.sched_step += 1
 
@@ -107,8 +144,31 @@ class FusedAdamW:
         return dict(m=self.m.cpu(), v=self.v.cpu(), step=self.step_count, sched_step=self.sched_step)
 
     def load_state_dict(self, sd):
+        if "state" in sd and "param_groups" in sd:                 # torch.optim.AdamW.state_dict() of a reference checkpoint
+            return self._load_torch_state(sd)
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.step_count, self.sched_step = int(sd["step"]), int(sd["sched_step"])
+
+    def _load_torch_state(self, sd):
+        """torch layout: param_groups[i]['params'] = running indices, state[idx] = {step, exp_avg, exp_avg_sq}.  The reference builds its
+        groups with param_groups_layer_decay (nets/utils.py:143-204): group order = first appearance of (layer id, decay / no_decay) while
+        walking named_parameters(), so the running index -> parameter name map is rebuilt the same way."""
+        order = torch_group_order(self.model, self.layer_decay)
+        idx_of = {}
+        for g, names in zip(sd["param_groups"], order):
+            assert len(g["params"]) == len(names), "optimizer state does not match this model's parameter groups"
+            for i, n in zip(g["params"], names):
+                idx_of[n] = i
+        step = 0
+        for n, _ in self.model.names_shapes:
+            st = sd["state"].get(idx_of[n])
+            if st is None:
+                continue                                           # frozen parameter: no state in torch either
+            o, ln = self.model.offsets[n][0], int(st["exp_avg"].numel())
+            self.m[o:o + ln].copy_(st["exp_avg"].reshape(-1)); self.v[o:o + ln].copy_(st["exp_avg_sq"].reshape(-1))
+            step = max(step, int(st["step"]))
+        self.step_count = step
+        return self
 
 
 class FusedSGD:
@@ -141,10 +201,11 @@ class FusedSGD:
     def get_last_lr(self):
         return [self.base_lr * self.lr_factor()]
 
-    def step(self, ema=None, ema_m=0.0, grad_scale=1.0):
+    def step(self, ema=None, ema_m=0.0, grad_scale=1.0, clip_grad=0.0):
+        coef = _clip_coef(self, grad_scale, clip_grad)
         ops.sgd_flat(self.model.flat, self.model.grad, self.buf, ema, self.table, self.nchunks, self.model.numel,
                      self.base_lr * self.lr_factor(), self.momentum, grad_scale=grad_scale, ema_m=ema_m, first_step=self.step_count == 0,
-                     zero_grad=True)
+                     zero_grad=True, clip_coef=coef)
         self.step_count += 1
         self.model.refresh_operands()
         self.sched_step += 1

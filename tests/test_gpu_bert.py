@@ -346,3 +346,30 @@ def test_full_size_step_properties_bert():
     # ... and the AdamW step lands on the same parameters up to the fp32 atomics of the gradient column sums (order-dependent round-off that Adam
     # turns into at most a sign flip of one lr-sized step for gradients at the noise floor)
     assert float((alg.model.flat - runs[1][0].model.flat).abs().max()) <= 2.1 * 5e-5
+
+
+def test_softmatch_weights_on_the_reference_probabilities_have_zero_deviation(golden):
+    """Oracle-fed companion of the trace test: the SoftMatch weighting kernels on EXACTLY the probabilities every masking call of the
+    reference received (srsoftmatch_bert_trace.npz it*/mask_probs; pass 0 after DistAlign) from the reference's own EMA state before the
+    step (it*/pre/*) reproduce the reference's sample weights of all passes -- the backbone's bf16 arithmetic is out of the picture, so
+    nothing may move: the binary part (weight == 1.0 above the mean) with 0 flips, the Gaussian tail to fp32 round-off."""
+    import types
+    from oracle.gen_golden import TRACE_SOFT_BERT as tr
+    from semireward_amd.algorithms.hooks import SoftMatchWeightingHook
+    g = golden("srsoftmatch_bert_trace")
+    stub = types.SimpleNamespace(dp=None)
+    total = 0
+    for it in tr["its"]:
+        p = f"it{it}"
+        probs, want = g[f"{p}/mask_probs"], g[f"{p}/masks"]
+        assert probs.shape[0] == want.shape[0] == int(g[f"{p}/K"]) + 1
+        h = SoftMatchWeightingHook(tr["C"], n_sigma=tr["n_sigma"], momentum=tr["ema_p"], device=DEV)
+        h.mu_var.copy_(torch.tensor([float(g[f"{p}/pre/mu"]), float(g[f"{p}/pre/var"])]))
+        for k in range(probs.shape[0]):
+            m = h.masking(stub, torch.from_numpy(probs[k]).to(DEV), softmax_x_ulb=False).cpu().numpy()
+            assert np.array_equal(m == 1.0, want[k] == 1.0), (p, k)                     # which rows get the full weight: 0 flips
+            np.testing.assert_allclose(m, want[k], rtol=2e-5, atol=1e-7, err_msg=f"{p} pass {k}")
+            total += m.size
+        assert float(h.prob_max_mu_t) == pytest.approx(float(g[f"{p}/mu"]), rel=1e-6)
+        assert float(h.prob_max_var_t) == pytest.approx(float(g[f"{p}/var"]), rel=1e-5)
+    assert total > 300

@@ -186,3 +186,73 @@ def test_flexmatch_passes_in_one_launch_equal_sequential_calls():
         for k in range(P):
             ops.flexmatch_mask(mp[k * nu:(k + 1) * nu], mi[k * nu:(k + 1) * nu], _dev(idx), 0.95, sel2, hist2, acc2, m2[k * nu:(k + 1) * nu], nu, C, U, warm)
         assert torch.equal(mask, m2) and torch.equal(sel, sel2) and torch.equal(acc, acc2) and torch.equal(hist, hist2)
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_flexmatch_duplicate_indices_and_multi_pass_state(general, monkeypatch):
+    """idx_ulb with the SAME index several times in one batch (the sampler's concatenated permutations can meet): selected_label takes the
+    LAST selected copy (the reference's CPU index_put) and the incremental histogram stays equal to the reference's recount -- over several
+    calls and inside one multi-pass launch; both kernel variants (state in LDS / general path with atomicExch)."""
+    if general:
+        monkeypatch.setenv("SRHIP_FLEXMATCH_GENERAL", "1")
+    C, U, Bu, P = 7, 40, 24, 5
+    rng = np.random.Generator(np.random.PCG64(31))
+    state, (sel, hist, acc) = H.FlexMatchState(U, C, True), _flex_engine(C, U, True)
+    for call in range(4):
+        idx = rng.integers(0, 12, size=Bu).astype(np.int64)              # 24 draws from 12 indices: many duplicates
+        probs = np.stack([_probs_with_max([(int(rng.integers(C)), float(rng.choice([0.5, 0.94, 0.96, 0.99]))) for _ in range(Bu)], C)
+                          for _ in range(P)])
+        mp, mi = torch.empty(P * Bu, device=DEV), torch.empty(P * Bu, dtype=torch.int64, device=DEV)
+        ops.row_max(_dev(probs.reshape(P * Bu, C)), True, None, mp, mi, P * Bu, C)
+        mask = torch.empty(P * Bu, device=DEV)
+        ops.flexmatch_mask_passes(mp, mi, _dev(idx), 0.95, sel, hist, acc, mask, P, Bu, C, U, True)
+        if not general:            # last-wins needs the ordered LDS kernel; the atomic path keeps hist == recount for any winner
+            want = np.stack([state.masking(probs[p], idx, 0.95) for p in range(P)])
+            assert np.array_equal(mask.cpu().numpy().reshape(P, Bu), want), call
+            assert np.array_equal(sel.cpu().numpy(), state.selected_label)
+            assert np.array_equal(acc.cpu().numpy().view(np.uint32), state.classwise_acc.view(np.uint32))
+        s = sel.cpu().numpy()
+        recount = np.bincount(np.where(s < 0, C, s), minlength=C + 1)
+        assert np.array_equal(hist.cpu().numpy(), recount), (call, hist.cpu().numpy(), recount)
+    ops.check_label_errors()
+
+
+def test_out_of_range_indices_and_labels_raise_like_the_reference():
+    """nn.Embedding / F.one_hot / index_put raise in the reference for an index outside its table; the kernels stay memory safe, set a device
+    flag and ops.check_label_errors() raises IndexError at the next host check."""
+    from semireward_amd.algorithms.semireward import Generator, Rewarder, cosine_target
+    C, U, Bu = 5, 16, 4
+    ops.check_label_errors()
+    # FlexMatch: idx_ulb beyond the selected_label table
+    sel, hist, acc = _flex_engine(C, U, True)
+    probs = _probs_with_max([(1, 0.99)] * Bu, C)
+    mp, mi = torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV)
+    ops.row_max(_dev(probs), True, None, mp, mi, Bu, C)
+    mask = torch.empty(Bu, device=DEV)
+    guard = torch.full((U + 64,), -1, dtype=torch.int64, device=DEV)
+    ops.flexmatch_mask(mp, mi, _dev(np.array([0, U, 3, -2], dtype=np.int64)), 0.95, guard[:U], hist, acc, mask, Bu, C, U, True)
+    assert int((guard[U:] != -1).sum()) == 0 and int((guard[:U] == 1).sum()) == 2      # nothing written past the table; the 2 valid rows landed
+    with pytest.raises(IndexError, match="idx_ulb"):
+        ops.check_label_errors()
+    ops.check_label_errors()                                                           # reset by the failed check
+    # Rewarder: label >= label_dim
+    rew = Rewarder(100, 128, 32, device=DEV)
+    feats = torch.randn(Bu, 32, device=DEV)
+    r = rew.score(feats, torch.tensor([0, 99, 100, 7], dtype=torch.int64, device=DEV))
+    assert bool(torch.isfinite(r).all())
+    with pytest.raises(IndexError, match="Embedding"):
+        ops.check_label_errors()
+    # Generator: huge features -> output far above any class (still finite): label stored, one_hot of the SR target refuses it
+    gen = Generator(32, device=DEV)
+    gen.flat.abs_(); gen.prepare()
+    _, lab = gen.forward_with_labels(torch.full((Bu, 32), 10.0, device=DEV))
+    assert int(lab.min()) > 1000
+    cosine_target(lab, torch.zeros(Bu, dtype=torch.int64, device=DEV), C)
+    with pytest.raises(IndexError, match="one_hot"):
+        ops.check_label_errors()
+    # ... and a NaN feature: .long() of NaN is garbage in torch; here label -1 + flag
+    _, lab = gen.forward_with_labels(torch.full((Bu, 32), float("nan"), device=DEV))
+    assert int(lab.max()) == -1
+    with pytest.raises(IndexError, match="NaN"):
+        ops.check_label_errors()
+    ops.check_label_errors()

@@ -193,3 +193,93 @@ def test_full_size_step_properties_hubert():
     tr2 = runs[1][3]
     assert torch.equal(tr["logits"][:, nl:], tr2["logits"][:, nl:]) and torch.equal(tr["logits"][0], tr2["logits"][0])
     assert float((alg.model.flat - runs[1][0].model.flat).abs().max()) <= 2.1 * 5e-5
+
+
+def test_freematch_masks_on_the_reference_probabilities_have_zero_flips(golden):
+    """Oracle-fed companion of the trace test: the FreeMatch threshold kernels on EXACTLY the probabilities every masking call of the
+    reference received (srfreematch_w2v_trace.npz it*/mask_probs) from the reference's own EMA state before the step (it*/pre/*) give the
+    reference's masks of all passes with ZERO flips, and leave the EMA state where the reference's hook ends the step."""
+    import types
+    from oracle.gen_golden import TRACE_FREE_W2V as tr
+    from semireward_amd.algorithms.hooks import FreeMatchThresholdingHook
+    g = golden("srfreematch_w2v_trace")
+    stub = types.SimpleNamespace(dp=None, use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"])
+    total = 0
+    for it in tr["its"]:
+        p = f"it{it}"
+        probs, want = g[f"{p}/mask_probs"], g[f"{p}/masks"]
+        assert probs.shape[0] == want.shape[0] == int(g[f"{p}/K"]) + 1
+        h = FreeMatchThresholdingHook(tr["C"], momentum=tr["ema_p"], device=DEV)
+        h.time_p.copy_(torch.tensor([float(g[f"{p}/pre/time_p"])])); h.p_model.copy_(torch.from_numpy(g[f"{p}/pre/p_model"]))
+        h.label_hist.copy_(torch.from_numpy(g[f"{p}/pre/label_hist"]))
+        for k in range(probs.shape[0]):
+            m = h.masking(stub, torch.from_numpy(probs[k]).to(DEV), softmax_x_ulb=False).cpu().numpy()
+            assert np.array_equal(m, want[k]), (p, k, m, want[k])
+            total += m.size
+        assert float(h.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=2e-6)
+        np.testing.assert_allclose(h.p_model.cpu().numpy(), g[f"{p}/p_model"], rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(h.label_hist.cpu().numpy(), g[f"{p}/label_hist"], rtol=2e-6, atol=1e-8)
+    assert total > 300
+
+
+def test_full_size_step_properties_wave2vec_freematch():
+    """BASELINE.json configs[4] EXACTLY: wave2vecv2_base + SRFreeMatch at full size (8/8/8 clips of 64000 samples -> 199 frames, K = 8, train
+    mode: dropout / SpecAugment / LayerDrop on).  Size-independent properties: the FreeMatch masks of all 9 passes, time_p and p_model equal
+    the oracle's FreeMatchState fed with the engine's own probabilities (rows ON a threshold excepted), mask2 == (reward >= per-pass mean)
+    away from ties, the fairness loss and every other loss finite, the fairness rows (pass-0 strong) carry a gradient, and the step is
+    reproducible (same seeds -> same logits)."""
+    import argparse
+    from oracle import hooks_ref as H
+    from semireward_amd.algorithms import get_algorithm
+    C, S, nl, nu = 10, 64000, 8, 8
+    args = dict(algorithm="srfreematch", num_classes=C, num_train_iter=102400, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False, amp=False,
+                optim="AdamW", lr=5e-5, weight_decay=5e-4, layer_decay=0.75, num_warmup_iter=5120, T=0.5, hard_label=True, ema_p=0.999,
+                use_quantile=False, clip_thresh=False, ent_loss_ratio=0.001, p_cutoff=0.95, thresh_warmup=True, ulb_dest_len=50000, N_k=10,
+                start_timing=10000, feature_dim=768, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    g = torch.Generator().manual_seed(16)
+    batch = dict(x_lb=torch.randn(nl, S, generator=g), y_lb=torch.randint(0, C, (nl,), generator=g), x_ulb_w=torch.randn(nu, S, generator=g),
+                 x_ulb_s=torch.randn(nu, S, generator=g))
+    runs = []
+    for _ in range(2):
+        alg = get_algorithm(argparse.Namespace(**args), wave2vec.wave2vecv2_base)
+        assert type(alg.model).__name__ == "ClassificationWave2Vec"
+        alg.model.view("classifier.2.weight").mul_(8.0); alg.model.refresh_operands()
+        alg.it = 90001
+        alg.optimizer.sched_step = alg.it
+        alg.model.seed, alg.model._rng_calls = 79, 0
+        alg.trace = {}
+        out, log = alg.train_step(**alg.process_batch(**batch))
+        alg.out_dict, alg.log_dict = out, log
+        gnorm = float(alg.model.grad.norm())
+        alg.call_hook("after_train_step")
+        torch.cuda.synchronize()
+        runs.append((alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}, gnorm))
+    alg, out, log, tr, gnorm = runs[0]
+    K = tr["K"]
+    assert K == 8 and tr["logits"].shape[:2] == (9, 24)
+    st = H.FreeMatchState(C, 0.999, use_quantile=False, clip_thresh=False)
+    Lw = tr["logits"][:, nl:nl + nu].float().cpu()
+    flips = 0
+    for k in range(9):
+        probs = torch.softmax(Lw[k], -1)
+        want = st.masking(probs).numpy()
+        got = tr["masks"][k].cpu().numpy()
+        mod = st.p_model / st.p_model.max()
+        mp, mi = probs.max(dim=-1)
+        far = (mp - st.time_p * mod[mi]).abs().numpy() > 1e-5            # a row within float round-off of its threshold may fall either way
+        assert np.array_equal(got[far], want[far]), k
+        flips += int((got != want).sum())
+    assert flips <= 1
+    h = alg.hooks_dict["MaskingHook"]
+    assert float(h.time_p) == pytest.approx(float(st.time_p), rel=1e-5)
+    np.testing.assert_allclose(h.p_model.cpu().numpy(), st.p_model.numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(h.label_hist.cpu().numpy(), st.label_hist.numpy(), rtol=1e-5, atol=1e-8)
+    r = tr["reward"].cpu().numpy().reshape(K, nu)
+    rm = r.mean(axis=1, keepdims=True, dtype=np.float32)
+    far = np.abs(r - rm) > 1e-6
+    m2 = tr["mask2"].cpu().numpy().reshape(K, nu)
+    assert np.array_equal(m2[far], (r >= rm).astype(np.float32)[far]) and set(np.unique(m2)) <= {0.0, 1.0}
+    assert all(np.isfinite(float(log["train/" + k_])) for k_ in ("sup_loss", "unsup_loss", "total_loss")) and np.isfinite(gnorm) and gnorm > 0
+    tr2 = runs[1][3]
+    assert torch.equal(tr["logits"][:, nl:], tr2["logits"][:, nl:]) and torch.equal(tr["logits"][0], tr2["logits"][0])
+    assert float((alg.model.flat - runs[1][0].model.flat).abs().max()) <= 2.1 * 5e-5

@@ -185,7 +185,7 @@ def test_srpseudolabel_wrn_trace(golden):
     wcfg = W.WrnCfg(num_classes=C, **W.WRN_TINY_TEST)
     Fd = W.channels(wcfg)[3]
     args = argparse.Namespace(
-        algorithm="srpseudolabel", num_classes=C, num_train_iter=tr["num_train_iter"], epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=True,
+        algorithm="srpseudolabel", num_classes=C, num_train_iter=tr["num_train_iter"], epoch=1, ema_m=tr["ema_m"], ulb_loss_ratio=1.0, use_cat=True,
         amp=False, optim="SGD", lr=tr["lr"], momentum=tr["momentum"], weight_decay=tr["weight_decay"], layer_decay=1.0,
         num_warmup_iter=tr["num_warmup_iter"], p_cutoff=tr["p_cutoff"], unsup_warm_up=tr["unsup_warm_up"], N_k=tr["N_k"],
         start_timing=tr["start_timing"], feature_dim=Fd, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1,
@@ -193,6 +193,8 @@ def test_srpseudolabel_wrn_trace(golden):
     alg = get_algorithm(args, wrn.wrn_tiny_test)
     Tn = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
     alg.model.load_state_dict(Tn(synth_wrn_params(wcfg, seed)))
+    assert alg.ema_m == 0.999 and alg.ema_model is not alg.model       # classic_cv yamls run ema_m 0.999 (pseudolabel_cifar100_400_0.yaml:20)
+    alg.ema_model.load_state_dict(Tn(synth_wrn_params(wcfg, seed)))    # EMA.register(): shadow starts at the parameters (misc.py:146-148)
     alg.rewarder.load_state_dict(Tn(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)))
     alg.generator.load_state_dict(Tn(synth.synth_params(S.generator_shapes(Fd), seed + 2)))
     flips = total = 0
@@ -234,3 +236,15 @@ def test_srpseudolabel_wrn_trace(golden):
         a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
         worst = max(worst, float(np.abs(a - gs["sample"]).max()))
     assert worst < 3e-2, worst
+    # EMA shadow of the run (ema_m 0.999, updated inside the fused SGD launch) against the reference's EMA / EMAHook sequence: the shadow is
+    # 0.999^6 of the initial parameters + 0.1 % slices of a trajectory that agrees to `worst`, and its BatchNorm buffers are the model's
+    last = f"it{tr['its'][-1]}"
+    for nme, v in alg.ema_model.named_parameters():
+        gs = g.samp(f"{last}/ema/{nme}")
+        a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
+        assert float(np.abs(a - gs["sample"]).max()) < 1e-5 + 6e-3 * worst, nme
+        m_ = alg.model.view(nme).reshape(-1).cpu().numpy()[::gs["stride"]]
+        assert float(np.abs(a - m_).max()) > 0.0 or float(np.abs(m_).max()) == 0.0, nme       # a shadow, not a copy of the model
+    for k_ in g.keys(f"{last}/emabuf/"):
+        name = k_.split("/", 2)[2]
+        assert torch.equal(alg.ema_model.buffers[name], alg.model.buffers[name]), name
