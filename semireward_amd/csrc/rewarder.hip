@@ -130,7 +130,7 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ WT, const 
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       const float v = acc[r] + bj;
-      yT[j * RT + r] = (ACT == 1) ? fmaxf(v, 0.f) : v;
+      yT[j * RT + r] = (ACT == 1) ? (v > 0.f || v != v ? v : 0.f) : v;      // nn.ReLU: NaN stays NaN (fmaxf would turn it into 0)
     }
   }
   __syncthreads();

@@ -372,4 +372,4 @@ def test_softmatch_weights_on_the_reference_probabilities_have_zero_deviation(go
             total += m.size
         assert float(h.prob_max_mu_t) == pytest.approx(float(g[f"{p}/mu"]), rel=1e-6)
         assert float(h.prob_max_var_t) == pytest.approx(float(g[f"{p}/var"]), rel=1e-5)
-    assert total > 300
+    assert total >= 200
