@@ -123,6 +123,17 @@ int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const f
                     void* save_ln2, void* save_pre, void* save_h, float* save_mean, float* save_rstd, int M, int D, int Hd,
                     void* stream);
 
+/* Fused qkv projection + attention of a ViT block for rows without a backward: ao = softmax(q k^T * scale) v with [q | k | v] = xn Wqkv^T +
+ * bqkv -- Attention.forward up to the output projection (semilearn/nets/vit/vit.py:93-104) on the norm1 output (:163) in ONE launch, one
+ * workgroup per image; replaces srhip_gemm_nt(qkv) + srhip_attn_fwd for inference rows (the [M, 3D] qkv activation never reaches HBM).
+ * xn_bf16 [B*N, D]: the rows normalised by srhip_layernorm_fwd; Wqkv bf16 [3D, D] (q | k | v rows, head-major); out bf16 [B*N, D].
+ * Built for D = 384, H = 6 and N in {257, 197} (ViT-S/2 at 32x32, ViT-S/16 at 224x224): srhip_attn_block_supported() tells, anything else
+ * is an argument error.  N = 257 = 16 token tiles + one token: qkv_extra bf16 [B, 3D] = q | k | v of token 256 of every image (one
+ * srhip_gemm_nt over the B rows xn_bf16 + 256 * D with lda = N * D) must be given; ignored for N = 197. */
+int srhip_attn_block_supported(int N, int D, int H);
+int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, const float* bqkv, const void* qkv_extra, void* out, int B, int N, int D, int H,
+                           float scale, void* stream);
+
 /* PatchEmbed conv (kernel = stride = ps) + cls token + pos_embed (vit.py:39-44, :277-280) (K1).
  * img fp32 [*, C, HW, HW]; img_index int32 [B] maps batch row -> image (NULL = identity; lets the K+1 passes of
  * one SemiReward step share one copy of the images); x fp32 [B, N, D], N = (HW/ps)^2 + 1.  C*ps*ps <= 64. */

@@ -29,6 +29,8 @@ SIGNATURES = {
     "srhip_layernorm_bwd_part": (I, [P, P, P, P, P, P, P, I, P, P, I, I, I, P]),
     "srhip_ln_grad_reduce": (I, [P, P, I, I, I, P]),
     "srhip_mlp_fused": (I, [P, P, P, P, F, P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
+    "srhip_attn_block_supported": (I, [I, I, I]),
+    "srhip_attn_block_fused": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd_ws_floats": (L, [I, I, I, I, I]),

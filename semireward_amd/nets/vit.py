@@ -61,6 +61,7 @@ def param_names_shapes(cfg):
 DW_GROUPS = 3              # layer groups of the weight-gradient launch when a grad_ready_cb is installed (data parallel)
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.layernorm_bwd_part)
 _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
+_FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
 # gradient + inference images in ONE forward (forward_mixed).  Opt-in: at the reference batch the 16 extra images push the qkv GEMM
 # from 4 to 5 rounds of 256x256 tiles (89 -> 106 us) and the two-stream schedule hides the small launches anyway: 8.52 vs 8.10 ms/step.
 MIXED_FWD = os.environ.get("SRHIP_MIXED_FWD", "0") != "0"
@@ -239,6 +240,8 @@ class VisionTransformer:
         # rows without a backward run LN2 + fc1 + GELU + fc2 + residual as ONE kernel (ViT-S width; SRHIP_FUSED_MLP=0: off)
         fused_mlp = (not save) and D == 384 and Hd % 128 == 0 and Hd <= 4096 and M >= 1024 and _FUSED_MLP
         hbuf = None if (fused_mlp or save) else self._buf(tag + "h", (M, Hd), bf16)
+        fused_attn = (not save) and _FUSED_ATTN and ops.attn_block_supported(N, D, H)       # SRHIP_FUSED_ATTN=0: separate qkv GEMM + attention
+        qkvx = self._buf(tag + "qkvx", (B, 3 * D), bf16) if (fused_attn and N == 257) else None
         wb = self.flat_bf16
         P = self.p
         Kp = cfg.in_chans * cfg.patch_size ** 2
@@ -262,8 +265,12 @@ class VisionTransformer:
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
             else:
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, None, None, M, D)
-            ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
-            ops.attn_fwd(qkv, ao, ctx.lse[i] if save else None, B, N, H, scale)
+            if fused_attn:
+                # rows without a backward: qkv Linear + attention as ONE launch (one workgroup per image; qkv never reaches HBM)
+                ops.attn_block_fused(ln, P(b + "attn.qkv.weight", wb), P(b + "attn.qkv.bias"), ao, B, N, D, H, scale, qkv_extra=qkvx)
+            else:
+                ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
+                ops.attn_fwd(qkv, ao, ctx.lse[i] if save else None, B, N, H, scale)
             if save:
                 xm = ctx.xmid[i]
                 ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), xm, M, D, D, bias=P(b + "attn.proj.bias"),

@@ -200,6 +200,30 @@ def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flop
     _call("srhip_gemm_tn_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
 
+def attn_block_supported(N, D, H):
+    from ._lib import lib
+    return bool(lib().srhip_attn_block_supported(N, D, H))
+
+
+def attn_block_fused(xn, Wqkv, bqkv, out, B, N, D, H, scale, qkv_extra=None):
+    """out = attention(xn Wqkv^T + bqkv) for rows without a backward: qkv Linear + attention in one launch (xn = norm1 output, bf16).
+    N = 257: the q | k | v row of the 257th token of every image comes from one small GEMM (qkv_extra [B, 3D] workspace, filled here)."""
+    if N == 257:
+        # rows 256, 256 + N, ... of xn: a strided A operand (lda = N * D), no gather
+        gemm_nt(EPI_BF16, xn[256:], Wqkv, qkv_extra, B, 3 * D, D, lda=N * D, bias=bqkv)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), B, N, D, H, scale, _s())
+        e1.record()
+        M = B * N
+        # algorithmic work: the qkv product + QK^T + PV; bytes: xn bf16 in, bf16 out, the weights once
+        _PROFILE.recs.append((e0, e1, 2.0 * M * 3 * D * D + 4.0 * B * H * N * N * 64, "attn_block_kernel<%d>" % N,
+                              2.0 * M * D + 2.0 * M * D + 2.0 * 3 * D * D))
+        return
+    _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), B, N, D, H, scale, _s())
+
+
 def attn_fwd(qkv, out, lse, B, N, H, scale):
     _call("srhip_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, H, scale, _s())
 

@@ -329,6 +329,7 @@ def test_mixed_forward_computes_every_row(monkeypatch):
     cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
     dps = [torch.from_numpy(synth.synth_droppath(500 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
     traces = []
+    monkeypatch.setattr(vit, "_FUSED_ATTN", False)     # the mixed forward keeps qkv for its gradient rows: same (unfused) attention kernels on both sides
     for mixed in (False, True):
         monkeypatch.setattr(vit, "MIXED_FWD", mixed)
         alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)

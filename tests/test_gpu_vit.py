@@ -54,7 +54,7 @@ def test_vit_matches_reference_golden(golden, tag):
     if tag in ("tiny", "base_p16_96"):           # no fused-MLP path at these widths: the same kernels, the same bits
         assert torch.equal(lg2, lg3) and torch.equal(ft2, ft3)
     else:   # ViT-S width: rows without a backward take the fused LN2+MLP kernel (same rounding points, other fp32 sum order)
-        assert rel(lg3.cpu(), lg2.cpu().numpy()) < 4e-3 and rel(ft3.cpu(), ft2.cpu().numpy()) < 4e-3
+        assert rel(lg3.cpu(), lg2.cpu().numpy()) < 6e-3 and rel(ft3.cpu(), ft2.cpu().numpy()) < 6e-3   # (inference rows: fused qkv + attention kernel)
     assert rel(lg2.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft2.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
     # gather path: rows permuted through img_index give permuted outputs
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
@@ -111,9 +111,12 @@ def test_vit_backward_matches_oracle_fp32_on_bf16_weights():
             assert rel(gr.cpu().numpy(), ref) < 4e-2, (n, rel(gr.cpu().numpy(), ref))
 
 
-def test_forward_mixed_matches_separate_forwards():
+def test_forward_mixed_matches_separate_forwards(monkeypatch):
     """forward_mixed (gradient images first, one launch train, backward operands kept by the inference kernels) against the two
-    separate forwards it replaces: same logits / features for every image, and the same backbone gradients."""
+    separate forwards it replaces: same logits / features for every image, and the same backbone gradients.  (The mixed forward keeps
+    qkv for its gradient rows, so it runs the separate qkv GEMM + attention kernels: compared here against the same kernels.)"""
+    from semireward_amd.nets import vit as _v
+    monkeypatch.setattr(_v, "_FUSED_ATTN", False)
     torch.manual_seed(0)
     model, cfg = build("small_p2_32")
     assert model.supports_mixed(24)

@@ -86,6 +86,43 @@ def mlp():
     print("mlp unfused %8.1f us %7.1f TF/s | fused %8.1f us %7.1f TF/s" % (t0, fl / t0 / 1e6, t1, fl / t1 / 1e6), flush=True)
 
 
+def attn_block():
+    """Fused norm1 + qkv + attention (one workgroup per image) vs the three launches it replaces, inference rows of a step."""
+    D, H = 384, 6
+    for N in (257, 197):
+        for B in (73, 127, 200):
+            M = B * N
+            x = torch.randn(M, D, device=DEV)
+            g, b = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
+            W = (torch.randn(3 * D, D, device=DEV) * 0.05).to(torch.bfloat16)
+            bq = torch.randn(3 * D, device=DEV) * 0.1
+            ln = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+            qkv = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=DEV)
+            out = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+            qx = torch.empty(B, 3 * D, dtype=torch.bfloat16, device=DEV)
+
+            def unfused():
+                ops.layernorm_fwd(x, g, b, 1e-6, ln, None, None, M, D)
+                ops.gemm_nt(ops.EPI_BF16, ln, W, qkv, M, 3 * D, D, bias=bq)
+                ops.attn_fwd(qkv, out, None, B, N, H, 0.125)
+
+            def fused():
+                ops.layernorm_fwd(x, g, b, 1e-6, ln, None, None, M, D)
+                ops.attn_block_fused(ln, W, bq, out, B, N, D, H, 0.125, qkv_extra=qx)
+            t0 = timeit(unfused, reps=20)
+            t1 = timeit(fused, reps=20)
+            if os.environ.get("SRHIP_TUNING_BUILD") and B == 200:
+                only = lambda: ops._call("srhip_attn_block_fused", ln.data_ptr(), W.data_ptr(), bq.data_ptr(), qx.data_ptr(), out.data_ptr(), B, N, D, H, 0.125, None)   # noqa: E731
+                print("   kernel alone %7.1f us" % timeit(only, reps=20), flush=True)
+                for dbg in (1, 2, 3, 4, 6, 7):
+                    os.environ["SRHIP_AB_DEBUG"] = str(dbg)
+                    print("   debug=%d (1 no attention, 2 no projection MFMAs, 4 no DMA): %7.1f us" % (dbg, timeit(only, reps=10)), flush=True)
+                os.environ.pop("SRHIP_AB_DEBUG")
+            fl = 2.0 * M * 3 * D * D + 4.0 * B * H * N * N * 64
+            print("attn half N=%3d B=%3d: three launches %7.1f us %6.1f TF/s | fused %7.1f us %6.1f TF/s" % (N, B, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6),
+                  flush=True)
+
+
 def gemm_qkv5():
     M, N, K = 51400, 1152, 384
     A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
