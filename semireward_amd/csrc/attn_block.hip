@@ -128,6 +128,9 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
   const int img = blockIdx.x;
+  // heads of this workgroup: the grid is (images, head groups) -- a launch of few images gives every image to 2 or 3 workgroups (each
+  // re-reads the image's normalised rows: 197 KB from L2) so that its latency is that of 3 or 2 heads instead of 6
+  const int hpw = NH / gridDim.y, hbeg = blockIdx.y * hpw, hend = hbeg + hpw;
   const size_t row0 = (size_t)img * N;
 
   // ---- ring producer: LDS row rho = 8 wave + (lane >> 3), chunk position pc = lane & 7 holds source chunk pc ^ ((rho >> 1) & 7) of
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
   auto issue = [&](auto rc, int h) __attribute__((always_inline)) {
     constexpr int r0 = decltype(rc)::value, r = r0 % SPH, m = r / SPM, kc = r % SPM;      // m: 0 K, 1 V, 2 Q
     const int hh = h + r0 / SPH;
-    const bool valid = hh < NH;
+    const bool valid = hh < hend;
     constexpr int brow = m == 0 ? DM : m == 1 ? 2 * DM : 0;
     lds_void* dst = (lds_void*)(ring + (r0 % NS >= 0 ? ((hh * SPH + r) & (NS - 1)) : 0) * ST_EL + wave * 8 * SK);
     if constexpr ((DBG & 4) != 0) return;
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
                                              valid ? ((brow + hh * HD) * DM + kc * SK) * 2 : 0, 0, 0);
   };
   // the first groups travel while the prologue normalises the tokens
-  issue(std::integral_constant<int, 0>{}, 0); issue(std::integral_constant<int, 1>{}, 0);
-  issue(std::integral_constant<int, 2>{}, 0); issue(std::integral_constant<int, 3>{}, 0);
+  issue(std::integral_constant<int, 0>{}, hbeg); issue(std::integral_constant<int, 1>{}, hbeg);
+  issue(std::integral_constant<int, 2>{}, hbeg); issue(std::integral_constant<int, 3>{}, hbeg);
   static_assert((NG - 2) * GS == 4, "prologue issues the first two groups");
 
   for (int i = tid; i < 3 * DM; i += 512) sbias[i] = a.bqkv[i];
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
   using C2 = std::integral_constant<int, 2>;
 
 #pragma unroll 1
-  for (int h = 0; h < NH; ++h) {
+  for (int h = hbeg; h < hend; ++h) {
     // =============== projections of this head: K, V, Q (6 stages each) ===============
     project(C0{}, h);
     project(C1{}, h);
@@ -386,7 +389,11 @@ int launch(const AbArgs& a, hipStream_t s) {
   const size_t smem = (size_t)(NS * ST_EL + NP * HD + HD * TP + 3 * DM) * sizeof(bf16_t) + (size_t)(3 * DM) * sizeof(float);
   auto kern = attn_block_kernel<N, DBG>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(512), smem, s, a);
+  // head groups per image: as many (1, 2, 3 or 6) as keep the launch within one workgroup per CU (SRHIP_AB_SPLIT overrides)
+  int split = 1;
+  for (int c : {2, 3, 6}) if (a.B * c <= 256) split = c;
+  if (const char* e = getenv("SRHIP_AB_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 3 || v == 6) split = v; }
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(512), smem, s, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
