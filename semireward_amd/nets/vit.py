@@ -62,6 +62,9 @@ DW_GROUPS = 3              # layer groups of the weight-gradient launch when a g
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.layernorm_bwd_part)
 _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 _FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
+# the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
+# pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
+_FUSED_MLP_MIN_ROWS = int(os.environ.get("SRHIP_FUSED_MLP_MIN_ROWS", "16384"))
 # gradient + inference images in ONE forward (forward_mixed).  Opt-in: at the reference batch the 16 extra images push the qkv GEMM
 # from 4 to 5 rounds of 256x256 tiles (89 -> 106 us) and the two-stream schedule hides the small launches anyway: 8.52 vs 8.10 ms/step.
 MIXED_FWD = os.environ.get("SRHIP_MIXED_FWD", "0") != "0"
@@ -238,7 +241,7 @@ class VisionTransformer:
             qkv = self._buf(tag + "qkv", (M, 3 * D), bf16)
             ao = self._buf(tag + "ao", (M, D), bf16)
         # rows without a backward run LN2 + fc1 + GELU + fc2 + residual as ONE kernel (ViT-S width; SRHIP_FUSED_MLP=0: off)
-        fused_mlp = (not save) and D == 384 and Hd % 128 == 0 and Hd <= 4096 and M >= 1024 and _FUSED_MLP
+        fused_mlp = (not save) and D == 384 and Hd % 128 == 0 and Hd <= 4096 and M >= _FUSED_MLP_MIN_ROWS and _FUSED_MLP
         hbuf = None if (fused_mlp or save) else self._buf(tag + "h", (M, Hd), bf16)
         fused_attn = (not save) and _FUSED_ATTN and ops.attn_block_supported(N, D, H)       # SRHIP_FUSED_ATTN=0: separate qkv GEMM + attention
         qkvx = self._buf(tag + "qkvx", (B, 3 * D), bf16) if (fused_attn and N == 257) else None
