@@ -79,8 +79,19 @@ def patchify(x, p):
     return x.reshape(B, gh * gw, C * p * p)
 
 
-def vit_forward(P, x, cfg, droppath=None, return_tokens=False):
-    """Returns dict(logits [B,C], feat [B,D]).  droppath: None or [depth,2,B] scales."""
+def vit_forward(P, x, cfg, droppath=None, return_tokens=False, aten_ops=False):
+    """Returns dict(logits [B,C], feat [B,D]).  droppath: None or [depth,2,B] scales.
+    aten_ops: LayerNorm / GELU through the ATen kernels the reference's nn.LayerNorm / nn.GELU modules call (vit.py:63, :222) instead of the
+    op-by-op restatement above -- same values to fp32 round-off, but one fused CPU kernel each instead of 5-6 elementwise passes with their
+    autograd temporaries: the restatement ran 3.5x slower than the reference on the same cores (tools/ref_cpu_step.py), which would have
+    made bench.py's cpu_baseline slow by construction.  bench.py times aten_ops=True."""
+    if aten_ops:
+        import torch.nn.functional as F
+        ln = lambda t_, w, b_: F.layer_norm(t_, (t_.shape[-1],), w, b_, 1e-6)   # noqa: E731
+        gelu, lin = F.gelu, F.linear
+    else:
+        ln, gelu = _ln, _gelu
+        lin = lambda t_, w, b_: t_ @ w.t() + b_                                  # noqa: E731
     B = x.shape[0]
     D, nh = cfg.embed_dim, cfg.num_heads
     hd = D // nh
@@ -90,23 +101,23 @@ def vit_forward(P, x, cfg, droppath=None, return_tokens=False):
     N = t.shape[1]
     for i in range(cfg.depth):
         b = f"blocks.{i}."
-        h = _ln(t, P[b + "norm1.weight"], P[b + "norm1.bias"])
-        qkv = (h @ P[b + "attn.qkv.weight"].t() + P[b + "attn.qkv.bias"]) \
+        h = ln(t, P[b + "norm1.weight"], P[b + "norm1.bias"])
+        qkv = lin(h, P[b + "attn.qkv.weight"], P[b + "attn.qkv.bias"]) \
             .reshape(B, N, 3, nh, hd).permute(2, 0, 3, 1, 4)            # :93-98
         q, k, v = qkv[0], qkv[1], qkv[2]
         a = torch.softmax((q @ k.transpose(-2, -1)) * (hd ** -0.5), dim=-1)   # :100-101
         o = (a @ v).transpose(1, 2).reshape(B, N, D)                    # :104
-        o = o @ P[b + "attn.proj.weight"].t() + P[b + "attn.proj.bias"]
+        o = lin(o, P[b + "attn.proj.weight"], P[b + "attn.proj.bias"])
         if droppath is not None:
             o = o * droppath[i, 0].view(B, 1, 1)
         t = t + o                                                        # :164
-        h = _ln(t, P[b + "norm2.weight"], P[b + "norm2.bias"])
-        h = _gelu(h @ P[b + "mlp.fc1.weight"].t() + P[b + "mlp.fc1.bias"])
-        h = h @ P[b + "mlp.fc2.weight"].t() + P[b + "mlp.fc2.bias"]
+        h = ln(t, P[b + "norm2.weight"], P[b + "norm2.bias"])
+        h = gelu(lin(h, P[b + "mlp.fc1.weight"], P[b + "mlp.fc1.bias"]))
+        h = lin(h, P[b + "mlp.fc2.weight"], P[b + "mlp.fc2.bias"])
         if droppath is not None:
             h = h * droppath[i, 1].view(B, 1, 1)
         t = t + h                                                        # :165
-    t = _ln(t, P["norm.weight"], P["norm.bias"])                         # :282
+    t = ln(t, P["norm.weight"], P["norm.bias"])                          # :282
     feat = t[:, 0]                                                       # :299 global_pool='token'
     logits = feat @ P["head.weight"].t() + P["head.bias"]                # :304
     out = {"logits": logits, "feat": feat}
