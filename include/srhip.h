@@ -122,6 +122,13 @@ int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const f
                     const float* b1, const void* W2, const float* b2, const float* row_scale, int rows_per_sample, int save_rows,
                     void* save_ln2, void* save_pre, void* save_h, float* save_mean, float* save_rstd, int M, int D, int Hd,
                     void* stream);
+/* The same with the attention output projection and the first residual of the block in front (rows without a backward):
+ *   x1 = x + row_scale1 * (ao Wp^T + bp);  x_out = x1 + row_scale2 * (fc2(GELU(fc1(LayerNorm(x1)))) + b2)
+ * -- vit.py:105-106 (proj) + :163 (drop_path1, residual) + :165 in ONE launch; replaces srhip_gemm_nt(EPI_RESID_F32) + srhip_mlp_fused.
+ * ao bf16 [M, D] (attention output, heads concatenated), Wp bf16 [D, D]; x_out may alias x. */
+int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
+                         const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
+                         const float* b2, const float* row_scale2, int rows_per_sample, int M, int D, int Hd, void* stream);
 
 /* Fused qkv projection + attention of a ViT block for rows without a backward: ao = softmax(q k^T * scale) v with [q | k | v] = xn Wqkv^T +
  * bqkv -- Attention.forward up to the output projection (semilearn/nets/vit/vit.py:93-104) on the norm1 output (:163) in ONE launch, one

@@ -50,6 +50,10 @@ class _Plan:
             if 0 < over <= 8:
                 nmove = min(-(-over * 128 // rows_per_col), len(rest_cols) - 1)
                 inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
+        if rest_cols and rows_per_col and len(rest_cols) * rows_per_col < 16384:
+            # a deferred launch below the size from which the fused row-streaming kernels are used (nets/vit.py _FUSED_MLP_MIN_ROWS) would
+            # run different kernels than the same rows do inside a large launch: it rides in the launch that is read (elide mode: 8 images)
+            inf_cols, rest_cols = sorted(inf_cols + rest_cols), []
         t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
         self.grad_cols, self.inf_cols, self.rest_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64), t(rest_cols, torch.int64)
         self.grad_img = t([cols_img[c] for c in grad_cols], torch.int32)

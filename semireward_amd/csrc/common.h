@@ -47,6 +47,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// all-reduce over the four 16-lane rows of a wave with the gfx950 row-swap instructions (instead of two ds_bpermute round trips):
+// permlane16_swap(a, b) = {a.r0 b.r0 a.r2 b.r2, a.r1 b.r1 a.r3 b.r3} (tools/pl_probe.hip), permlane32_swap(a, b) = {a.lo b.lo, a.hi b.hi}
+__device__ __forceinline__ float rows_sum4(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned v = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, branch-free, one v_exp + one v_rcp).  The OCML erff costs ~40
 // instructions with branches: in the fc1 epilogue it took 80 us of a 220 us GEMM.  The GELU outputs are rounded to bf16
 // (2^-9 relative) right after, so 1.5e-7 absolute is invisible; semantics stay nn.GELU() "exact erf" (vit.py:63,72).

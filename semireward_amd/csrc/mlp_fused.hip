@@ -68,6 +68,10 @@ struct MlpArgs {
   int save_rows;
   const float *gamma, *beta, *b1, *b2, *row_scale;
   const bf16_t *W1, *W2;
+  // PROJ variant (rows without a backward): the attention output projection + first residual of the block run in this launch too,
+  //   x <- x + row_scale1 * (ao Wp^T + bp)      (vit.py:163 after Attention.forward :105-106), then the MLP half on the result
+  const bf16_t *ao, *Wp;   // [M, D] attention output (heads concatenated), [D, D]
+  const float *bp, *row_scale1;
   float eps;
   int M, Hd, rows_per_sample;
 };
@@ -79,7 +83,7 @@ __device__ long long srhip_mlp_dbg[4 * 1024];
 #else
 #define MDBG_T(i) do { } while (0)
 #endif
-template <int D_, int DBG, int GS>
+template <int D_, int DBG, int GS, bool PROJ = false>
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   constexpr int KS1 = D_ / BK;            // 12 k-steps of GEMM1
   constexpr int KQ = 4;                   // k-steps per GEMM1 stage
@@ -96,12 +100,14 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   float* sb2 = sb1 + a.Hd;
   float* sgam = sb2 + D_;                 // LayerNorm affine, read per k-step in the prologue: 48 16-byte reads per lane that came from
   float* sbet = sgam + D_;                // L1 / L2 in groups of 8 behind a scheduling barrier = six exposed round trips per tile
+  float* sbp = sbet + D_;                 // PROJ: bias of the attention projection
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA destinations (M0) stay scalar arithmetic
   const int l15 = lane & 15, lg = lane >> 4;
   const int nch = a.Hd / CH;
   for (int i = tid; i < a.Hd; i += 512) sb1[i] = a.b1[i];
   for (int i = tid; i < D_; i += 512) { sb2[i] = a.b2[i]; sgam[i] = a.gamma[i]; sbet[i] = a.beta[i]; }
+  if constexpr (PROJ) for (int i = tid; i < D_; i += 512) sbp[i] = a.bp[i];
   __syncthreads();
 
   // ---- producer: one LDS-DMA instruction (16 LDS rows x 64 B) per wave and stage.  Buffer addressing: (SGPR resource
@@ -118,10 +124,22 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1), 0, wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2), 0, wbytes, 0x00020000);
   constexpr int OOB = 0x7ffffff0;
-  auto issue = [&](int c, int j, int slot) {                 // stage j of chunk c (j is a compile-time constant at every call)
+  // PROJ: the ring sequence starts with VOFF = 3 "virtual chunks" of SPC stages that carry the projection weight Wp: stage j of virtual
+  // chunk v is the LDS tile  r -> Wp[128 v + r][32 j ..]  (the shape of a GEMM2 stage with row pitch D); chunk indices below are virtual
+  // (MLP chunk c = virtual chunk c + VOFF) so that slot arithmetic and the look-ahead of the refills run straight through the seam
+  constexpr int VOFF = PROJ ? TH : 0;
+  const int nchv = nch + VOFF;
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(PROJ ? a.Wp : a.W2), 0, D_ * D_ * 2, 0x00020000);
+  const int lop = (pr * D_ + psl) * 2;
+  auto issue = [&](int cv, int j, int slot) {                // stage j of virtual chunk cv (j is a compile-time constant at every call)
     if (DBG & 2) return;
     lds_void* dst = (lds_void*)(sm + slot * TILE_EL + pdst);
-    const bool valid = c < nch;
+    const bool valid = cv < nchv;
+    if (PROJ && cv < VOFF) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, dst, 16, lop, (cv * RT * D_ + j * BK) * 2, 0, 0);
+      return;
+    }
+    const int c = cv - VOFF;
     if (j < G1S) {
       const int u = j / (KS1 / KQ), kt = j % (KS1 / KQ);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, valid ? lo1 : OOB, ((c * CH + 32 * u) * D_ + kt * KQ * BK) * 2, 0, 0);
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     MDBG_T(0);
     // ---- LayerNorm of the wave's 16 rows, straight into MFMA B-fragments: lane holds x[m][32 s + 8 g .. +7], s = 0..11
     u32x4_t xn[KS1];
-    {
+    if constexpr (!PROJ) {
       const float* xr = a.x + (size_t)mc * D_ + 8 * lg;
       f32x4_t v[2 * KS1];
       float s = 0.f;
@@ -184,11 +202,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
         if (k & 1) __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting all 48 affine loads (spills)
       }
     }
-    const bool save_tile = a.save_rows > 0 && tile * FBM + wave * 16 < a.save_rows;      // wave-uniform
+    const bool save_tile = !PROJ && a.save_rows > 0 && tile * FBM + wave * 16 < a.save_rows;      // wave-uniform
     if (save_tile && m < a.save_rows) {                                                     // norm2 output of the gradient rows
       bf16_t* lr = a.s_ln2 + (size_t)m * D_ + 8 * lg;
 #pragma unroll
       for (int k = 0; k < KS1; ++k) *reinterpret_cast<u32x4_t*>(lr + 32 * k) = xn[k];
+    }
+    // PROJ: the attention output rows of the wave as MFMA B-fragments (lane holds ao[m][32 s + 8 g .. + 7])
+    u32x4_t aof[PROJ ? KS1 : 1];
+    if constexpr (PROJ) {
+      const bf16_t* ar = a.ao + (size_t)mc * D_ + 8 * lg;
+#pragma unroll
+      for (int k = 0; k < KS1; ++k) aof[k] = *reinterpret_cast<const u32x4_t*>(ar + 32 * k);
     }
     __syncthreads();                       // previous tile's ring reads are over (and sb1/sb2 are written)
     MDBG_T(1);
@@ -242,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     // accumulator start = fc1 bias: lane (g) holds hidden 64 c + 32 u + 8 g + 4 X + r in register r of tile X
     auto acc1_start = [&](auto uc, auto xc, int c) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value, X = decltype(xc)::value;
-      acc1[2 * u + X] = *reinterpret_cast<const f32x4_t*>(sb1 + min(c, nch - 1) * CH + 32 * u + 8 * lg + 4 * X);
+      acc1[2 * u + X] = *reinterpret_cast<const f32x4_t*>(sb1 + min(c - VOFF, nch - 1) * CH + 32 * u + 8 * lg + 4 * X);
     };
     auto gelu_elem = [&](auto uc, auto ec, int c) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value, e = decltype(ec)::value, X = e >> 2, r = e & 3;
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
         // gradient rows: keep the fc1 pre-activation and the GELU output (bf16, as the unfused path saves them); rare (8 % of the
         // tiles) and conservative for the counted vmcnt waits (extra younger stores can only make a wait longer)
         if (save_tile && m < a.save_rows) {
-          const size_t o = (size_t)m * a.Hd + c * CH + 32 * u + 8 * lg + (e - 1);
+          const size_t o = (size_t)m * a.Hd + (c - VOFF) * CH + 32 * u + 8 * lg + (e - 1);
           *reinterpret_cast<uint32_t*>(a.s_pre + o) = pack_bf2(pcarry, v);
           *reinterpret_cast<uint32_t*>(a.s_h + o) = hf[u][e >> 1];
         }
@@ -307,16 +332,111 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       gelu_slot(jc, hc, T1{}, c);
       __builtin_amdgcn_sched_barrier(0);
     };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    if constexpr (PROJ) {
+      // ---- attention output projection: VOFF virtual chunks of SPC stages, stage (v, j) = Wp rows 128 v .. x k-step j, the GEMM2 stage
+      // shape: 8 MFMAs acc2[8 v + t] += Wp tile t . ao fragment j, same software pipeline as below
+      auto read_half_p = [&](auto jc, auto hc, int cv) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value, h = decltype(hc)::value;
+        u32x4_t(&fa)[4] = h ? fa1 : fa0;
+        const bf16_t* st = sm + ((cv * SPC + j) & (NS - 1)) * TILE_EL;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const u32x4_t*>(st + fo2 + (4 * h + t) * 16 * BK);
+      };
+      sync_group(H0{}, 0);
+      read_half_p(H0{}, H0{}, 0);
+      static_for<VOFF>([&](auto vc) __attribute__((always_inline)) {
+        constexpr int v = decltype(vc)::value;
+        static_for<SPC>([&](auto jc) __attribute__((always_inline)) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int jn = (j + 1) % SPC, vn = v + (j + 1) / SPC;
+          read_half_p(jc, H1{}, v);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc2[v * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa0[t]), __builtin_bit_cast(bf16x8_t, aof[j]),
+                                                                       acc2[v * 8 + t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (jn % GS == 0) sync_group(std::integral_constant<int, jn>{}, vn);
+          if constexpr (vn == VOFF) read_half(std::integral_constant<int, 0>{}, H0{}, vn);       // the seam: first MLP stage (GEMM1 fragments)
+          else read_half_p(std::integral_constant<int, jn>{}, H0{}, vn);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc2[v * 8 + 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa1[t]), __builtin_bit_cast(bf16x8_t, aof[j]),
+                                                                           acc2[v * 8 + 4 + t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      // ---- first residual + LayerNorm, from the accumulator layout: lane (l15 = row, lg) holds columns 16 t + 4 lg + r of its row.
+      //   x_new = x + row_scale1 * (acc + bp)  (fp32, the arithmetic of the GEMM epilogue it replaces) is stored -- the epilogue below
+      //   re-reads it as its residual term -- and normalised in place; the bf16 pairs are then moved into the B-fragment layout
+      //   (lane holds columns 32 s + 8 lg .. + 7) by two row swaps per register: for the tile pair (2 s, 2 s + 1)
+      //   permlane32_swap(P, Q) = {P0 P1 Q0 Q1, P2 P3 Q2 Q3} (rows = lane groups), then permlane16_swap of those two
+      //   = {P0 P2 Q0 Q2, P1 P3 Q1 Q3}: exactly columns 8 lg .. + 3 and 8 lg + 4 .. + 7 of the k-step for lane group lg.
+      {
+        const float rs1 = a.row_scale1 ? a.row_scale1[mc / a.rows_per_sample] : 1.0f;
+        const float* xr = a.x + (size_t)mc * D_ + 4 * lg;
+        float* xw = a.xo + (size_t)mc * D_ + 4 * lg;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+          const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sbp + 16 * t + 4 * lg);
+          f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
+          xv[0] += rs1 * (acc2[t][0] + bb[0]); xv[1] += rs1 * (acc2[t][1] + bb[1]);
+          xv[2] += rs1 * (acc2[t][2] + bb[2]); xv[3] += rs1 * (acc2[t][3] + bb[3]);
+          if (m < a.M) *reinterpret_cast<f32x4_t*>(xw + 16 * t) = xv;
+          acc2[t] = xv;
+          sum += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+          if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float mu = rows_sum4(sum) * (1.0f / D_);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = acc2[t][e] - mu; q += d * d; }
+        const float rs = rsqrtf(rows_sum4(q) * (1.0f / D_) + a.eps);
+        // (the 48 affine reads must not all be issued up front: 192 live registers = spills whose reloads stall the weight ring; the offset
+        // of every k-step is made to depend on the fragment the previous one produced)
+        int ko = 4 * lg;
+        asm volatile("" : "+v"(ko) : "v"(rs));
+#pragma unroll
+        for (int sI = 0; sI < KS1; ++sI) {
+          if (sI > 0) asm volatile("" : "+v"(ko) : "v"(xn[sI - 1][3]));
+          unsigned pk[2][2];                         // [tile of the pair][dword]
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int t = 2 * sI + e;
+            const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(sgam + 16 * t + ko);
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(sbet + 16 * t + ko);
+            pk[e][0] = pack_bf2((acc2[t][0] - mu) * rs * g4[0] + b4[0], (acc2[t][1] - mu) * rs * g4[1] + b4[1]);
+            pk[e][1] = pack_bf2((acc2[t][2] - mu) * rs * g4[2] + b4[2], (acc2[t][3] - mu) * rs * g4[3] + b4[3]);
+          }
+          unsigned out4[4];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const auto w32 = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+            const auto w16 = __builtin_amdgcn_permlane16_swap(w32[0], w32[1], false, false);
+            out4[d] = w16[0];                        // columns 8 lg + 2 d, + 1
+            out4[2 + d] = w16[1];                    // columns 8 lg + 4 + 2 d, + 1
+          }
+          xn[sI] = u32x4_t{out4[0], out4[1], out4[2], out4[3]};
+          if (sI & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     {
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
-      acc1_start(I0{}, I0{}, 0); acc1_start(I0{}, I1{}, 0); acc1_start(I1{}, I0{}, 0); acc1_start(I1{}, I1{}, 0);
+      acc1_start(I0{}, I0{}, VOFF); acc1_start(I0{}, I1{}, VOFF); acc1_start(I1{}, I0{}, VOFF); acc1_start(I1{}, I1{}, VOFF);
     }
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    sync_group(H0{}, 0);
-    read_half(H0{}, H0{}, 0);
-    for (int c = 0; c < nch; ++c)
+    if constexpr (!PROJ) {
+      sync_group(H0{}, 0);
+      read_half(H0{}, H0{}, 0);
+    }
+    for (int c = VOFF; c < nchv; ++c)
       static_for<SPC>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         constexpr int jn = (j + 1) % SPC;
@@ -331,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     // ---- epilogue: lane holds y[m][16 t + 4 g + r]
     if (m < a.M) {
       const float rsc = a.row_scale ? a.row_scale[m / a.rows_per_sample] : 1.0f;
-      const float* xr = a.x + (size_t)m * D_ + 4 * lg;
+      const float* xr = (PROJ ? a.xo : a.x) + (size_t)m * D_ + 4 * lg;     // PROJ: the x_new this lane stored after the projection
       float* xw = a.xo + (size_t)m * D_ + 4 * lg;
 #pragma unroll
       for (int t = 0; t < NT2; ++t) {
@@ -375,7 +495,8 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
   a.save_rows = save_rows;
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 3 * D) * sizeof(float);
+  a.ao = nullptr; a.Wp = nullptr; a.bp = nullptr; a.row_scale1 = nullptr;
+  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 4 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4>;
 #ifdef SRHIP_TUNING
   switch (getenv("SRHIP_MLP_DEBUG") ? atoi(getenv("SRHIP_MLP_DEBUG")) : 0) {
@@ -390,6 +511,32 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
     default: break;
   }
 #endif
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int ntiles = cdiv(M, FBM);
+  hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+// Attention output projection + first residual + the whole MLP half of a block in ONE launch (rows without a backward):
+//   x1 = x + row_scale1 * (ao Wp^T + bp);   x_out = x1 + row_scale2 * (fc2(GELU(fc1(LayerNorm(x1)))) + b2)
+// (vit.py:163 tail: proj :105-106 + drop_path1 + residual, and :165).  Saves the proj GEMM launch and one read + write of the residual stream.
+extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
+                                    const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
+                                    const float* b2, const float* row_scale2, int rows_per_sample, int M, int D, int Hd, void* stream) {
+  if (!x || !x_out || !ao || !Wp || !bp || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return SR_EINVAL;
+  if (D != 384 || Hd < 128 || (Hd % RT) || Hd > 4096) return SR_EINVAL;
+  if ((row_scale1 || row_scale2) && rows_per_sample <= 0) return SR_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)x_out | (uintptr_t)ao | (uintptr_t)Wp | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15)
+    return SR_EINVAL;
+  MlpArgs a;
+  a.x = x; a.xo = x_out; a.gamma = ln_gamma; a.beta = ln_beta; a.b1 = b1; a.b2 = b2; a.row_scale = row_scale2;
+  a.s_ln2 = a.s_pre = a.s_h = nullptr; a.s_mean = a.s_rstd = nullptr; a.save_rows = 0;
+  a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
+  a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+  a.ao = (const bf16_t*)ao; a.Wp = (const bf16_t*)Wp; a.bp = bp; a.row_scale1 = row_scale1;
+  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 4 * D) * sizeof(float);
+  void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4, true>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int ntiles = cdiv(M, FBM);
   hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);

@@ -62,6 +62,7 @@ DW_GROUPS = 3              # layer groups of the weight-gradient launch when a g
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.layernorm_bwd_part)
 _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 _FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
+_FUSED_PROJ = os.environ.get("SRHIP_FUSED_PROJ", "1") != "0"        # attention projection + residual inside the fused MLP launch
 # the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
 # pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
 _FUSED_MLP_MIN_ROWS = int(os.environ.get("SRHIP_FUSED_MLP_MIN_ROWS", "16384"))
@@ -286,6 +287,11 @@ class VisionTransformer:
                 ops.gemm_nt(ops.EPI_RESID_F32, ctx.h[i], P(b + "mlp.fc2.weight", wb), xn, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
                             row_scale=s2, rows_per_sample=N, aux_in=xm, ldaux=D)
                 x = xn
+            elif fused_mlp and _FUSED_PROJ:
+                # rows without a backward: proj + residual + LN2 + fc1 + GELU + fc2 + residual as ONE launch
+                ops.mlp_fused_proj(x, ao, P(b + "attn.proj.weight", wb), P(b + "attn.proj.bias"), s1, P(b + "norm2.weight"),
+                                   P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb), P(b + "mlp.fc1.bias"),
+                                   P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd)
             else:
                 ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), x, M, D, D, bias=P(b + "attn.proj.bias"),
                             row_scale=s1, rows_per_sample=N)

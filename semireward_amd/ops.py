@@ -275,6 +275,23 @@ def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M
     _call("srhip_mlp_fused", *args, _s())
 
 
+def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, row_scale2, rows_per_sample, M, D, Hd, x_out=None):
+    """x_out (default: x, in place) = x1 + row_scale2 * (fc2(gelu(fc1(LN(x1)))) + b2) with x1 = x + row_scale1 * (ao Wp^T + bp): the attention
+    projection, both residuals and the MLP half of a block in ONE launch (rows without a backward)."""
+    args = (_p(x), _p(x_out if x_out is not None else x), _p(ao), _p(Wp), _p(bp), _p(row_scale1), _p(gamma), _p(beta), eps, _p(W1), _p(b1),
+            _p(W2), _p(b2), _p(row_scale2), rows_per_sample, M, D, Hd)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("srhip_mlp_fused_proj", *args, _s())
+        e1.record()
+        # algorithmic: fc1 + fc2 + proj products; bytes: x in, x1 out + in, x out (fp32), ao in (bf16), the weights once
+        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_fused_kernel<384, 0, 4, true>",
+                              16.0 * M * D + 2.0 * M * D + 4.0 * D * Hd + 2.0 * D * D))
+        return
+    _call("srhip_mlp_fused_proj", *args, _s())
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M, D):
     _call("srhip_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), M, D, _s())
 

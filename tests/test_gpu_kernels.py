@@ -172,6 +172,55 @@ def attn_ref(qkv, B, N, H, scale):
     return (a @ v).transpose(1, 2).reshape(B * N, H * 64), torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)
 
 
+@pytest.mark.parametrize("M,rows_per_sample", [(128, 0), (257 * 3, 257), (1000, 0), (257 * 40 + 5, 257), (257 * 127, 257)])
+def test_mlp_fused_proj(M, rows_per_sample):
+    """Attention projection + first residual + LN2 + fc1 + GELU + fc2 + second residual in ONE launch (srhip_mlp_fused_proj, vit.py:105-106,
+    :163-165) against (a) the fp32 torch formula on the bf16-rounded operands and (b) the two launches it replaces (srhip_gemm_nt with the
+    residual epilogue + srhip_mlp_fused), incl. per-sample DropPath scales on both branches and in-place operation."""
+    D, Hd = 384, 1536
+    x0 = rnd(M, D, seed=1)
+    x0[:, 7] += 3.0
+    ao = bf(rnd(M, D, seed=11, scale=0.7))
+    ao[:, 300] += 2.0                                          # uneven columns: a wrong fragment transpose would show
+    Wp, bp = bf(rnd(D, D, seed=12, scale=0.06)), rnd(D, seed=13, scale=0.2)
+    g, b = rnd(D, seed=2, scale=0.2) + 1.0, rnd(D, seed=3, scale=0.1)
+    W1, W2 = bf(rnd(Hd, D, seed=4, scale=0.05)), bf(rnd(D, Hd, seed=5, scale=0.03))
+    b1, b2 = rnd(Hd, seed=6, scale=0.1), rnd(D, seed=7, scale=0.1)
+    rs1 = rs2 = None
+    if rows_per_sample:
+        ns = (M + rows_per_sample - 1) // rows_per_sample
+        rng = np.random.Generator(np.random.PCG64(8))
+        rs1 = torch.from_numpy(rng.choice([0.0, 1.0 / 0.95], size=ns, p=[0.3, 0.7]).astype(np.float32)).to(DEV)
+        rs2 = torch.from_numpy(rng.choice([0.0, 1.0 / 0.9], size=ns).astype(np.float32)).to(DEV)
+    sc = lambda r: r.repeat_interleave(rows_per_sample)[:M, None] if r is not None else 1.0   # noqa: E731
+    # (a) fp32 reference
+    x1 = x0 + sc(rs1) * (ao.float() @ Wp.float().T + bp)
+    xn = torch.nn.functional.layer_norm(x1, (D,), g, b, 1e-6)
+    want = x1 + sc(rs2) * (gelu(xn @ W1.float().T + b1) @ W2.float().T + b2)
+    # (b) the two launches it replaces
+    xu = x0.clone()
+    ops.gemm_nt(ops.EPI_RESID_F32, ao, Wp, xu, M, D, D, bias=bp, row_scale=rs1, rows_per_sample=rows_per_sample)
+    x1u = xu.clone()
+    ops.mlp_fused(xu, g, b, 1e-6, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd)
+    # fused, in place
+    xf = x0.clone()
+    ops.mlp_fused_proj(xf, ao, Wp, bp, rs1, g, b, 1e-6, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd)
+    # fused, out of place
+    xo = torch.zeros_like(x0)
+    ops.mlp_fused_proj(x0, ao, Wp, bp, rs1, g, b, 1e-6, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd, x_out=xo)
+    torch.cuda.synchronize()
+    assert torch.equal(xo, xf)
+    assert relerr(xf - x0, want - x0) < 6e-3
+    assert relerr(xf - x0, xu - x0) < 1.5e-3                   # same rounding points; accumulation / LN summation order differs
+    assert relerr(xf, xu) < 2e-4
+    if rs1 is not None:                                        # rows whose both branches are dropped are untouched, bit for bit
+        dead = (rs1.repeat_interleave(rows_per_sample)[:M] == 0) & (rs2.repeat_interleave(rows_per_sample)[:M] == 0)
+        assert (M < 257 * 20 or bool(dead.any())) and torch.equal(xf[dead], x0[dead])
+        only2 = (rs1.repeat_interleave(rows_per_sample)[:M] != 0) & (rs2.repeat_interleave(rows_per_sample)[:M] == 0)
+        if bool(only2.any()):                                  # MLP branch dropped: exactly the projection residual
+            assert float((xf[only2] - x1u[only2]).abs().max()) < 2e-5 * float(x1u.abs().max())
+
+
 @pytest.mark.parametrize("B,N,H", [(3, 17, 2), (2, 197, 6), (4, 257, 6), (1, 64, 1), (2, 33, 3)])
 def test_attention_fwd_bwd(B, N, H):
     D = H * 64

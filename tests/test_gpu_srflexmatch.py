@@ -330,6 +330,8 @@ def test_mixed_forward_computes_every_row(monkeypatch):
     dps = [torch.from_numpy(synth.synth_droppath(500 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
     traces = []
     monkeypatch.setattr(vit, "_FUSED_ATTN", False)     # the mixed forward keeps qkv for its gradient rows: same (unfused) attention kernels on both sides
+    monkeypatch.setattr(vit, "_FUSED_PROJ", False)     # ... and the residual stream after the projection
+    monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1024)   # the direct 8-image forwards below on the kernels of the big launches
     for mixed in (False, True):
         monkeypatch.setattr(vit, "MIXED_FWD", mixed)
         alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)

@@ -114,9 +114,11 @@ def test_vit_backward_matches_oracle_fp32_on_bf16_weights():
 def test_forward_mixed_matches_separate_forwards(monkeypatch):
     """forward_mixed (gradient images first, one launch train, backward operands kept by the inference kernels) against the two
     separate forwards it replaces: same logits / features for every image, and the same backbone gradients.  (The mixed forward keeps
-    qkv for its gradient rows, so it runs the separate qkv GEMM + attention kernels: compared here against the same kernels.)"""
+    qkv / the projection residual for its gradient rows, so it runs the separate qkv GEMM, attention and proj kernels: compared here against the same.)"""
     from semireward_amd.nets import vit as _v
     monkeypatch.setattr(_v, "_FUSED_ATTN", False)
+    monkeypatch.setattr(_v, "_FUSED_PROJ", False)
+    monkeypatch.setattr(_v, "_FUSED_MLP_MIN_ROWS", 1024)     # the 19-image inference forward on the fused MLP kernel, as inside the mixed launch
     torch.manual_seed(0)
     model, cfg = build("small_p2_32")
     assert model.supports_mixed(24)

@@ -123,6 +123,32 @@ def attn_block():
                   flush=True)
 
 
+def mlp_proj():
+    """proj GEMM (+ residual) + fused MLP as two launches vs srhip_mlp_fused_proj, launch sizes of a step."""
+    D, Hd, N = 384, 1536, 257
+    for B in (73, 127, 200):
+        M = B * N
+        x = torch.randn(M, D, device=DEV)
+        ao = torch.randn(M, D, device=DEV).to(torch.bfloat16)
+        Wp = (torch.randn(D, D, device=DEV) * 0.05).to(torch.bfloat16)
+        bp = torch.randn(D, device=DEV) * 0.1
+        g, b = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
+        W1 = (torch.randn(Hd, D, device=DEV) * 0.05).to(torch.bfloat16)
+        W2 = (torch.randn(D, Hd, device=DEV) * 0.02).to(torch.bfloat16)
+        b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(D, device=DEV) * 0.1
+
+        def two():
+            ops.gemm_nt(ops.EPI_RESID_F32, ao, Wp, x, M, D, D, bias=bp)
+            ops.mlp_fused(x, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd)
+        t0 = timeit(two, reps=10)
+        x.normal_()
+        t1 = timeit(lambda: ops.mlp_fused_proj(x, ao, Wp, bp, None, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd), reps=10)
+        t2 = timeit(lambda: ops.mlp_fused(x, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd), reps=10)
+        x.normal_()
+        fl = 4.0 * M * D * Hd + 2.0 * M * D * D
+        print("proj+mlp B=%3d: two launches %7.1f us | fused %7.1f us %6.1f TF/s | (mlp alone %7.1f us)" % (B, t0, t1, fl / t1 / 1e6, t2), flush=True)
+
+
 def gemm_qkv5():
     M, N, K = 51400, 1152, 384
     A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
