@@ -27,6 +27,7 @@ from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
 _PHASES = os.environ.get("SR_PHASES", "0") != "0"
+_RESERVE_CUS = int(os.environ.get("SR_RESERVE_CUS", "64"))     # measured: 0 -> 1324, 32 -> 1373, 64-72 -> 1398, 80 -> 1324 img/s (same box)
 
 
 class _Plan:
@@ -50,6 +51,16 @@ class _Plan:
             if 0 < over <= 8:
                 nmove = min(-(-over * 128 // rows_per_col), len(rest_cols) - 1)
                 inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
+            # CUs kept free of the deferred launches (SR_RESERVE_CUS): their workgroups own a CU outright (147 KB of LDS, all registers) for
+            # ~100 us, so while they run every small launch of the critical chain (masks, rewards, losses, the backward of the 16 gradient
+            # images) waits for one of them to retire; a one-round deferred launch that leaves a few CUs alone lets those start at once
+            reserve = _RESERVE_CUS
+            tiles = -(-len(rest_cols) * rows_per_col // 128)
+            if reserve > 0 and 256 - reserve < tiles <= 256:
+                keep = (256 - reserve) * 128 // rows_per_col
+                nmove = min(len(rest_cols) - keep, len(rest_cols) - 1)
+                if nmove > 0:
+                    inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
         if rest_cols and rows_per_col and len(rest_cols) * rows_per_col < 16384:
             # a deferred launch below the size from which the fused row-streaming kernels are used (nets/vit.py _FUSED_MLP_MIN_ROWS) would
             # run different kernels than the same rows do inside a large launch: it rides in the launch that is read (elide mode: 8 images)
