@@ -27,7 +27,7 @@ from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
 _PHASES = os.environ.get("SR_PHASES", "0") != "0"
-_RESERVE_CUS = int(os.environ.get("SR_RESERVE_CUS", "64"))     # measured: 0 -> 1324, 32 -> 1373, 64-72 -> 1398, 80 -> 1324 img/s (same box)
+_DEFER_FRACTION = float(os.environ.get("SR_DEFER_FRACTION", "0.475"))   # share of the inference images on the second stream (see _Plan)
 
 
 class _Plan:
@@ -51,16 +51,17 @@ class _Plan:
             if 0 < over <= 8:
                 nmove = min(-(-over * 128 // rows_per_col), len(rest_cols) - 1)
                 inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
-            # CUs kept free of the deferred launches (SR_RESERVE_CUS): their workgroups own a CU outright (147 KB of LDS, all registers) for
-            # ~100 us, so while they run every small launch of the critical chain (masks, rewards, losses, the backward of the 16 gradient
-            # images) waits for one of them to retire; a one-round deferred launch that leaves a few CUs alone lets those start at once
-            reserve = _RESERVE_CUS
+            # How many of the inference images are deferred (SR_DEFER_FRACTION).  The workgroups of the row-streaming kernels own a CU
+            # outright (147 KB of LDS, all registers) for ~100 us: while a deferred launch fills the chip, every small launch of the critical
+            # chain (masks, rewards, losses, the backward of the 16 gradient images) waits for one of them to retire.  Deferring a little
+            # under half of the inference images -- instead of all 127 nothing reads -- keeps both launch trains at one round and leaves the
+            # deferred one ~64 CUs short of the chip.  Measured on one box, ViT-S/2 (rest images -> img/s): 127 -> 1324, 111 -> 1373,
+            # 95 -> 1398, 91 -> 1398, 87 -> 1324; ViT-S/16 at 224: 127 -> 1473, 103 -> 1646, 93 -> 1670, 83 (folded, below) -> 1396.
             tiles = -(-len(rest_cols) * rows_per_col // 128)
-            if reserve > 0 and 256 - reserve < tiles <= 256:
-                keep = (256 - reserve) * 128 // rows_per_col
-                nmove = min(len(rest_cols) - keep, len(rest_cols) - 1)
-                if nmove > 0:
-                    inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
+            keep = int(_DEFER_FRACTION * (len(inf_cols) + len(rest_cols)))
+            if 0.0 < _DEFER_FRACTION < 1.0 and tiles <= 256 and 0 < keep < len(rest_cols):
+                nmove = len(rest_cols) - keep
+                inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
         if rest_cols and rows_per_col and len(rest_cols) * rows_per_col < 16384:
             # a deferred launch below the size from which the fused row-streaming kernels are used (nets/vit.py _FUSED_MLP_MIN_ROWS) would
             # run different kernels than the same rows do inside a large launch: it rides in the launch that is read (elide mode: 8 images)
