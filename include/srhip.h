@@ -125,10 +125,13 @@ int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const f
 /* The same with the attention output projection and the first residual of the block in front (rows without a backward):
  *   x1 = x + row_scale1 * (ao Wp^T + bp);  x_out = x1 + row_scale2 * (fc2(GELU(fc1(LayerNorm(x1)))) + b2)
  * -- vit.py:105-106 (proj) + :163 (drop_path1, residual) + :165 in ONE launch; replaces srhip_gemm_nt(EPI_RESID_F32) + srhip_mlp_fused.
- * ao bf16 [M, D] (attention output, heads concatenated), Wp bf16 [D, D]; x_out may alias x. */
+ * ao bf16 [M, D] (attention output, heads concatenated), Wp bf16 [D, D]; x_out may alias x.
+ * ln_next (bf16 [M, D], may be NULL): LayerNorm(x_out) with (next_gamma, next_beta) = the NEXT block's norm1 -- the operand of its
+ * srhip_attn_block_fused -- written by the same launch (replaces that block's srhip_layernorm_fwd). */
 int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
                          const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
-                         const float* b2, const float* row_scale2, int rows_per_sample, int M, int D, int Hd, void* stream);
+                         const float* b2, const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma,
+                         const float* next_beta, int M, int D, int Hd, void* stream);
 
 /* Fused qkv projection + attention of a ViT block for rows without a backward: ao = softmax(q k^T * scale) v with [q | k | v] = xn Wqkv^T +
  * bqkv -- Attention.forward up to the output projection (semilearn/nets/vit/vit.py:93-104) on the norm1 output (:163) in ONE launch, one

@@ -72,6 +72,10 @@ struct MlpArgs {
   //   x <- x + row_scale1 * (ao Wp^T + bp)      (vit.py:163 after Attention.forward :105-106), then the MLP half on the result
   const bf16_t *ao, *Wp;   // [M, D] attention output (heads concatenated), [D, D]
   const float *bp, *row_scale1;
+  // PROJ variant, optional: LayerNorm of the OUTPUT rows with the next block's norm1 affine, written as bf16 [M, D] -- the operand of the next
+  // block's qkv projection (srhip_attn_block_fused), which saves that block's srhip_layernorm_fwd launch and its read of the residual stream
+  bf16_t* ln_next;
+  const float *gamma_n, *beta_n;
   float eps;
   int M, Hd, rows_per_sample;
 };
@@ -101,13 +105,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   float* sgam = sb2 + D_;                 // LayerNorm affine, read per k-step in the prologue: 48 16-byte reads per lane that came from
   float* sbet = sgam + D_;                // L1 / L2 in groups of 8 behind a scheduling barrier = six exposed round trips per tile
   float* sbp = sbet + D_;                 // PROJ: bias of the attention projection
+  float* sgn = sbp + D_;                  // PROJ + ln_next: the next block's norm1 affine
+  float* sbn = sgn + D_;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: LDS-DMA destinations (M0) stay scalar arithmetic
   const int l15 = lane & 15, lg = lane >> 4;
   const int nch = a.Hd / CH;
   for (int i = tid; i < a.Hd; i += 512) sb1[i] = a.b1[i];
   for (int i = tid; i < D_; i += 512) { sb2[i] = a.b2[i]; sgam[i] = a.gamma[i]; sbet[i] = a.beta[i]; }
-  if constexpr (PROJ) for (int i = tid; i < D_; i += 512) sbp[i] = a.bp[i];
+  if constexpr (PROJ) {
+    for (int i = tid; i < D_; i += 512) sbp[i] = a.bp[i];
+    if (a.ln_next) for (int i = tid; i < D_; i += 512) { sgn[i] = a.gamma_n[i]; sbn[i] = a.beta_n[i]; }
+  }
   __syncthreads();
 
   // ---- producer: one LDS-DMA instruction (16 LDS rows x 64 B) per wave and stage.  Buffer addressing: (SGPR resource
@@ -449,7 +458,57 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       });
     MDBG_T(2);
     // ---- epilogue: lane holds y[m][16 t + 4 g + r]
-    if (m < a.M) {
+    if (PROJ && a.ln_next) {                // wave-uniform: the rows leave as fp32 (residual stream) AND normalised for the next block
+      const float rsc = a.row_scale ? a.row_scale[mc / a.rows_per_sample] : 1.0f;
+      const float* xr = a.xo + (size_t)mc * D_ + 4 * lg;
+      float* xw = a.xo + (size_t)mc * D_ + 4 * lg;
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sb2 + 16 * t + 4 * lg);
+        f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
+        xv[0] += rsc * (acc2[t][0] + bb[0]); xv[1] += rsc * (acc2[t][1] + bb[1]);
+        xv[2] += rsc * (acc2[t][2] + bb[2]); xv[3] += rsc * (acc2[t][3] + bb[3]);
+        if (m < a.M) *reinterpret_cast<f32x4_t*>(xw + 16 * t) = xv;
+        acc2[t] = xv;
+        sum += (xv[0] + xv[1]) + (xv[2] + xv[3]);
+        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      const float mu = rows_sum4(sum) * (1.0f / D_);
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = acc2[t][e] - mu; q += d * d; }
+      const float rs = rsqrtf(rows_sum4(q) * (1.0f / D_) + a.eps);
+      bf16_t* lw = a.ln_next + (size_t)mc * D_ + 8 * lg;
+      int ko = 4 * lg;
+      asm volatile("" : "+v"(ko) : "v"(rs));
+      unsigned chain = 0;
+#pragma unroll
+      for (int sI = 0; sI < KS1; ++sI) {     // same re-layout as after the projection: 16 bytes per lane and k-step leave
+        if (sI > 0) asm volatile("" : "+v"(ko) : "v"(chain));
+        unsigned pk[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int t = 2 * sI + e;
+          const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(sgn + 16 * t + ko);
+          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(sbn + 16 * t + ko);
+          pk[e][0] = pack_bf2((acc2[t][0] - mu) * rs * g4[0] + b4[0], (acc2[t][1] - mu) * rs * g4[1] + b4[1]);
+          pk[e][1] = pack_bf2((acc2[t][2] - mu) * rs * g4[2] + b4[2], (acc2[t][3] - mu) * rs * g4[3] + b4[3]);
+        }
+        unsigned out4[4];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const auto w32 = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+          const auto w16 = __builtin_amdgcn_permlane16_swap(w32[0], w32[1], false, false);
+          out4[d] = w16[0];
+          out4[2 + d] = w16[1];
+        }
+        chain = out4[3];
+        if (m < a.M) *reinterpret_cast<u32x4_t*>(lw + 32 * sI) = u32x4_t{out4[0], out4[1], out4[2], out4[3]};
+      }
+    } else if (m < a.M) {
       const float rsc = a.row_scale ? a.row_scale[m / a.rows_per_sample] : 1.0f;
       const float* xr = (PROJ ? a.xo : a.x) + (size_t)m * D_ + 4 * lg;     // PROJ: the x_new this lane stored after the projection
       float* xw = a.xo + (size_t)m * D_ + 4 * lg;
@@ -495,8 +554,8 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
   a.save_rows = save_rows;
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-  a.ao = nullptr; a.Wp = nullptr; a.bp = nullptr; a.row_scale1 = nullptr;
-  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 4 * D) * sizeof(float);
+  a.ao = nullptr; a.Wp = nullptr; a.bp = nullptr; a.row_scale1 = nullptr; a.ln_next = nullptr; a.gamma_n = a.beta_n = nullptr;
+  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4>;
 #ifdef SRHIP_TUNING
   switch (getenv("SRHIP_MLP_DEBUG") ? atoi(getenv("SRHIP_MLP_DEBUG")) : 0) {
@@ -521,10 +580,13 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
 // Attention output projection + first residual + the whole MLP half of a block in ONE launch (rows without a backward):
 //   x1 = x + row_scale1 * (ao Wp^T + bp);   x_out = x1 + row_scale2 * (fc2(GELU(fc1(LayerNorm(x1)))) + b2)
 // (vit.py:163 tail: proj :105-106 + drop_path1 + residual, and :165).  Saves the proj GEMM launch and one read + write of the residual stream.
+// ln_next != NULL: also LayerNorm(x_out) with (next_gamma, next_beta) -- the next block's norm1 (vit.py:163) -- as bf16 [M, D].
 extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
                                     const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
-                                    const float* b2, const float* row_scale2, int rows_per_sample, int M, int D, int Hd, void* stream) {
+                                    const float* b2, const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma,
+                                    const float* next_beta, int M, int D, int Hd, void* stream) {
   if (!x || !x_out || !ao || !Wp || !bp || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return SR_EINVAL;
+  if (ln_next && (!next_gamma || !next_beta || ((uintptr_t)ln_next & 15))) return SR_EINVAL;
   if (D != 384 || Hd < 128 || (Hd % RT) || Hd > 4096) return SR_EINVAL;
   if ((row_scale1 || row_scale2) && rows_per_sample <= 0) return SR_EINVAL;
   if (((uintptr_t)x | (uintptr_t)x_out | (uintptr_t)ao | (uintptr_t)Wp | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15)
@@ -535,7 +597,8 @@ extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   a.ao = (const bf16_t*)ao; a.Wp = (const bf16_t*)Wp; a.bp = bp; a.row_scale1 = row_scale1;
-  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 4 * D) * sizeof(float);
+  a.ln_next = (bf16_t*)ln_next; a.gamma_n = next_gamma; a.beta_n = next_beta;
+  const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4, true>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int ntiles = cdiv(M, FBM);

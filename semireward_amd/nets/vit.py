@@ -63,6 +63,7 @@ LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in t
 _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 _FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
 _FUSED_PROJ = os.environ.get("SRHIP_FUSED_PROJ", "1") != "0"        # attention projection + residual inside the fused MLP launch
+_FUSED_NEXT_LN = os.environ.get("SRHIP_FUSED_NEXT_LN", "1") != "0"  # ... which then also writes the next block's norm1 output
 # the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
 # pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
 _FUSED_MLP_MIN_ROWS = int(os.environ.get("SRHIP_FUSED_MLP_MIN_ROWS", "16384"))
@@ -260,6 +261,7 @@ class VisionTransformer:
             ops.gemm_nt(ops.EPI_F32, col, P("patch_embed.proj.weight", wb), tok, B * Np, D, Kp)
             ops.patch_assemble(tok, P("patch_embed.proj.bias"), P("cls_token"), P("pos_embed"), x, B, Np, D)
         scale = 64 ** -0.5
+        ln_ready = False           # the previous block's fused launch already wrote this block's norm1 output
         for i in range(cfg.depth):
             b = "blocks.%d." % i
             s1 = droppath[i, 0] if droppath is not None else None
@@ -267,7 +269,7 @@ class VisionTransformer:
             if save:
                 ln, qkv, ao = ctx.ln1[i], ctx.qkv[i], ctx.ao[i]
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
-            else:
+            elif not ln_ready:
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, None, None, M, D)
             if fused_attn:
                 # rows without a backward: qkv Linear + attention as ONE launch (one workgroup per image; qkv never reaches HBM)
@@ -288,10 +290,15 @@ class VisionTransformer:
                             row_scale=s2, rows_per_sample=N, aux_in=xm, ldaux=D)
                 x = xn
             elif fused_mlp and _FUSED_PROJ:
-                # rows without a backward: proj + residual + LN2 + fc1 + GELU + fc2 + residual as ONE launch
+                # rows without a backward: proj + residual + LN2 + fc1 + GELU + fc2 + residual as ONE launch -- which also writes the NEXT
+                # block's norm1 output (the operand of its fused qkv + attention launch) when there is a next block
+                nb = "blocks.%d." % (i + 1)
+                ln_ready = _FUSED_NEXT_LN and i + 1 < cfg.depth
                 ops.mlp_fused_proj(x, ao, P(b + "attn.proj.weight", wb), P(b + "attn.proj.bias"), s1, P(b + "norm2.weight"),
                                    P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb), P(b + "mlp.fc1.bias"),
-                                   P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd)
+                                   P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd,
+                                   ln_next=ln if ln_ready else None, next_gamma=P(nb + "norm1.weight") if ln_ready else None,
+                                   next_beta=P(nb + "norm1.bias") if ln_ready else None)
             else:
                 ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), x, M, D, D, bias=P(b + "attn.proj.bias"),
                             row_scale=s1, rows_per_sample=N)

@@ -275,11 +275,13 @@ def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M
     _call("srhip_mlp_fused", *args, _s())
 
 
-def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, row_scale2, rows_per_sample, M, D, Hd, x_out=None):
+def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, row_scale2, rows_per_sample, M, D, Hd, x_out=None,
+                   ln_next=None, next_gamma=None, next_beta=None):
     """x_out (default: x, in place) = x1 + row_scale2 * (fc2(gelu(fc1(LN(x1)))) + b2) with x1 = x + row_scale1 * (ao Wp^T + bp): the attention
-    projection, both residuals and the MLP half of a block in ONE launch (rows without a backward)."""
+    projection, both residuals and the MLP half of a block in ONE launch (rows without a backward).  ln_next (bf16 [M, D]): also
+    LayerNorm(x_out) with the next block's norm1 affine."""
     args = (_p(x), _p(x_out if x_out is not None else x), _p(ao), _p(Wp), _p(bp), _p(row_scale1), _p(gamma), _p(beta), eps, _p(W1), _p(b1),
-            _p(W2), _p(b2), _p(row_scale2), rows_per_sample, M, D, Hd)
+            _p(W2), _p(b2), _p(row_scale2), rows_per_sample, _p(ln_next), _p(next_gamma), _p(next_beta), M, D, Hd)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

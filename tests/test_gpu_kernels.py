@@ -208,7 +208,21 @@ def test_mlp_fused_proj(M, rows_per_sample):
     # fused, out of place
     xo = torch.zeros_like(x0)
     ops.mlp_fused_proj(x0, ao, Wp, bp, rs1, g, b, 1e-6, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd, x_out=xo)
+    # ... and with the next block's norm1 output written by the same launch
+    gn, bn = rnd(D, seed=21, scale=0.3) + 1.0, rnd(D, seed=22, scale=0.2)
+    xo2 = torch.zeros_like(x0)
+    lnn = torch.full((M, D), 9.0, dtype=torch.bfloat16, device=DEV)
+    ops.mlp_fused_proj(x0, ao, Wp, bp, rs1, g, b, 1e-6, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd, x_out=xo2, ln_next=lnn, next_gamma=gn,
+                       next_beta=bn)
+    lnu = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_fwd(xf, gn, bn, 1e-6, lnu, None, None, M, D)
     torch.cuda.synchronize()
+    assert torch.equal(xo2, xf)
+    # LayerNorm of identical fp32 rows by two kernels with different summation orders: bf16 outputs agree except where a value sits on a
+    # rounding boundary (one bf16 ulp = 2^-8 relative)
+    dl = (lnn.float() - lnu.float()).abs()
+    assert float(dl.max()) <= 2.0 ** -7 * float(lnu.float().abs().max()) and float((dl > 0).float().mean()) < 0.02
+    assert relerr(lnn.float(), torch.nn.functional.layer_norm(xf, (D,), gn, bn, 1e-6)) < 3e-3
     assert torch.equal(xo, xf)
     assert relerr(xf - x0, want - x0) < 6e-3
     assert relerr(xf - x0, xu - x0) < 1.5e-3                   # same rounding points; accumulation / LN summation order differs
