@@ -125,11 +125,14 @@ int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const f
 /* The same with the attention output projection and the first residual of the block in front (rows without a backward):
  *   x1 = x + row_scale1 * (ao Wp^T + bp);  x_out = x1 + row_scale2 * (fc2(GELU(fc1(LayerNorm(x1)))) + b2)
  * -- vit.py:105-106 (proj) + :163 (drop_path1, residual) + :165 in ONE launch; replaces srhip_gemm_nt(EPI_RESID_F32) + srhip_mlp_fused.
- * ao bf16 [M, D] (attention output, heads concatenated), Wp bf16 [D, D]; x_out may alias x.
+ * ao bf16 [M, D] (attention output, heads concatenated), Wp bf16 [D, D]; x_out may alias x.  The residual stream makes no round trip inside
+ * the launch (x is the start value of the accumulators, x1 stays in them), so the DropPath factors act on the bf16 B operands of the products:
+ * row_scale2 on the GELU output before its (single) rounding; row_scale1 on ao -- ao_scaled != 0 says the launch that wrote ao applied it
+ * before rounding (srhip_attn_block_fused out_scale: one rounding, as in the unfused path), 0 has it applied here (a second rounding of ao).
  * ln_next (bf16 [M, D], may be NULL): LayerNorm(x_out) with (next_gamma, next_beta) = the NEXT block's norm1 -- the operand of its
  * srhip_attn_block_fused -- written by the same launch (replaces that block's srhip_layernorm_fwd). */
 int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
-                         const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
+                         int ao_scaled, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
                          const float* b2, const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma,
                          const float* next_beta, int M, int D, int Hd, void* stream);
 
@@ -139,10 +142,12 @@ int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const voi
  * xn_bf16 [B*N, D]: the rows normalised by srhip_layernorm_fwd; Wqkv bf16 [3D, D] (q | k | v rows, head-major); out bf16 [B*N, D].
  * Built for D = 384, H = 6 and N in {257, 197} (ViT-S/2 at 32x32, ViT-S/16 at 224x224): srhip_attn_block_supported() tells, anything else
  * is an argument error.  N = 257 = 16 token tiles + one token: qkv_extra bf16 [B, 3D] = q | k | v of token 256 of every image (one
- * srhip_gemm_nt over the B rows xn_bf16 + 256 * D with lda = N * D) must be given; ignored for N = 197. */
+ * srhip_gemm_nt over the B rows xn_bf16 + 256 * D with lda = N * D) must be given; ignored for N = 197.
+ * out_scale fp32 [B] or NULL: factor on every output row of image b, applied before the bf16 rounding -- the DropPath factor of the attention
+ * branch (vit.py:163) when the consumer is srhip_mlp_fused_proj(ao_scaled = 1). */
 int srhip_attn_block_supported(int N, int D, int H);
-int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, const float* bqkv, const void* qkv_extra, void* out, int B, int N, int D, int H,
-                           float scale, void* stream);
+int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, const float* bqkv, const void* qkv_extra, void* out, const float* out_scale,
+                           int B, int N, int D, int H, float scale, void* stream);
 
 /* PatchEmbed conv (kernel = stride = ps) + cls token + pos_embed (vit.py:39-44, :277-280) (K1).
  * img fp32 [*, C, HW, HW]; img_index int32 [B] maps batch row -> image (NULL = identity; lets the K+1 passes of

@@ -106,6 +106,7 @@ struct AbArgs {
   const float* bqkv;
   const bf16_t* W;         // [1152, 384] bf16: q | k | v rows, head-major inside each third (vit.py:93-98)
   bf16_t* out;             // [B * N, 384] attention output, heads concatenated (vit.py:104 transpose + reshape)
+  const float* osc;        // [B] factor on the image's output rows (DropPath of the branch, vit.py:163), applied before the bf16 rounding; or NULL
   float scale;
   int B;
 };
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
   const int img = blockIdx.x;
+  const float osc = a.osc ? a.osc[img] : 1.0f;       // uniform: one scalar load
   // heads of this workgroup: the grid is (images, head groups) -- a launch of few images gives every image to 2 or 3 workgroups (each
   // re-reads the image's normalised rows: 197 KB from L2) so that its latency is that of 3 or 2 heads instead of 6
   const int hpw = NH / gridDim.y, hbeg = blockIdx.y * hpw, hend = hbeg + hpw;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
       });
       sum = rows_sum(sum);
       if (qtok < N && (!ext || l15 == 0)) {
-        const float inv = 1.0f / sum;
+        const float inv = osc / sum;
         bf16_t* op = a.out + (row0 + qtok) * DM + h * HD + g * 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -402,15 +404,15 @@ int launch(const AbArgs& a, hipStream_t s) {
 
 extern "C" int srhip_attn_block_supported(int N, int D, int H) { return (D == DM && H == NH && (N == 257 || N == 197)) ? 1 : 0; }
 
-extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, const float* bqkv, const void* qkv_extra, void* out, int B, int N,
-                                      int D, int H, float scale, void* stream) {
+extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, const float* bqkv, const void* qkv_extra, void* out,
+                                      const float* out_scale, int B, int N, int D, int H, float scale, void* stream) {
   if (!xn_bf16 || !Wqkv || !bqkv || !out || B <= 0) return SR_EINVAL;
   if (!srhip_attn_block_supported(N, D, H)) return SR_EINVAL;
   if (N == 257 && !qkv_extra) return SR_EINVAL;
   if (((uintptr_t)xn_bf16 | (uintptr_t)Wqkv | (uintptr_t)out | (uintptr_t)bqkv | (uintptr_t)qkv_extra) & 15) return SR_EINVAL;
   AbArgs a;
   a.xnb = (const bf16_t*)xn_bf16; a.qx = (const bf16_t*)qkv_extra; a.bqkv = bqkv; a.W = (const bf16_t*)Wqkv; a.out = (bf16_t*)out;
-  a.scale = scale; a.B = B;
+  a.scale = scale; a.B = B; a.osc = out_scale;
   hipStream_t s = (hipStream_t)stream;
 #ifdef SRHIP_TUNING
   switch (getenv("SRHIP_AB_DEBUG") ? atoi(getenv("SRHIP_AB_DEBUG")) : 0) {

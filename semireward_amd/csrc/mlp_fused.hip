@@ -72,6 +72,7 @@ struct MlpArgs {
   //   x <- x + row_scale1 * (ao Wp^T + bp)      (vit.py:163 after Attention.forward :105-106), then the MLP half on the result
   const bf16_t *ao, *Wp;   // [M, D] attention output (heads concatenated), [D, D]
   const float *bp, *row_scale1;
+  int ao_scaled;           // the producer of ao (srhip_attn_block_fused out_scale) already applied row_scale1 to it
   // PROJ variant, optional: LayerNorm of the OUTPUT rows with the next block's norm1 affine, written as bf16 [M, D] -- the operand of the next
   // block's qkv projection (srhip_attn_block_fused), which saves that block's srhip_layernorm_fwd launch and its read of the residual stream
   bf16_t* ln_next;
@@ -82,8 +83,8 @@ struct MlpArgs {
 
 // DBG (tuning builds only, SRHIP_MLP_DEBUG): 1 = no GELU, 2 = no DMA / no vmcnt waits, 4 = no ds_reads, 8 = no MFMA
 #ifdef SRHIP_TUNING
-__device__ long long srhip_mlp_dbg[4 * 1024];
-#define MDBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) srhip_mlp_dbg[4 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+__device__ long long srhip_mlp_dbg[8 * 1024];
+#define MDBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) srhip_mlp_dbg[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
 #else
 #define MDBG_T(i) do { } while (0)
 #endif
@@ -224,15 +225,45 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
       for (int k = 0; k < KS1; ++k) aof[k] = *reinterpret_cast<const u32x4_t*>(ar + 32 * k);
     }
+    // PROJ: the residual stream never makes a round trip through memory inside the launch.  The rows' x enters as the START VALUE of the
+    // output accumulators (lane (l15 = row, lg) holds columns 16 t + 4 lg + r), the projection accumulates on top of it, and the same
+    // registers, then holding x1, are the start value of fc2.  The per-row drop-path factors (vit.py:163, :165; 0 or 1 / keep_prob) ride on
+    // the B operands of the two products -- the bf16 attention-output fragments and the bf16 GELU output -- since a B column is one row:
+    // a factor of 1 (block 0, eval) is exact, 0 leaves x untouched, any other means bf16(rs * value) instead of rs * bf16(value): for GELU
+    // the ONE rounding of the operand either way; for ao a second one unless the attention launch applied rs1 before ITS rounding
+    // (ao_scaled: srhip_attn_block_fused out_scale).
+    float rs1v = 1.0f, rs2v = 1.0f;
+    f32x4_t acc2[NT2];
+    if constexpr (PROJ) {
+      if (a.row_scale1) rs1v = a.row_scale1[mc / a.rows_per_sample];
+      if (a.row_scale) rs2v = a.row_scale[mc / a.rows_per_sample];
+      const float* xr = a.x + (size_t)mc * D_ + 4 * lg;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) acc2[t] = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
+      if (rs1v != 1.0f && !a.ao_scaled) {
+#pragma unroll
+        for (int k = 0; k < KS1; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            aof[k][e] = pack_bf2(rs1v * __builtin_bit_cast(float, aof[k][e] << 16), rs1v * __builtin_bit_cast(float, aof[k][e] & 0xffff0000u));
+      }
+    }
     __syncthreads();                       // previous tile's ring reads are over (and sb1/sb2 are written)
     MDBG_T(1);
 #pragma unroll
     for (int p = 0; p < PD; ++p) issue(p / SPC, p % SPC, p);   // groups 0 .. NG-3
 
     __builtin_amdgcn_sched_barrier(0);     // the accumulators must not become live (zeroed early) across the LayerNorm above
-    f32x4_t acc2[NT2];
+    if constexpr (!PROJ) {
 #pragma unroll
-    for (int t = 0; t < NT2; ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT2; ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    } else {                               // + rs1 * bp while the first ring stages are in flight
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sbp + 16 * t + 4 * lg);
+        acc2[t][0] += rs1v * bb[0]; acc2[t][1] += rs1v * bb[1]; acc2[t][2] += rs1v * bb[2]; acc2[t][3] += rs1v * bb[3];
+      }
+    }
     f32x4_t acc1[4];                       // [2 u + {P, Q}], started at the fc1 bias of the tile's hidden units
     u32x4_t hf[2];
     u32x4_t fa0[4], fa1[4];                // A fragments of half-stage h of stage j in fa[h]: 4 fragments = 4 MFMAs
@@ -283,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       const float v = acc1[2 * u + X][r];
       float gv;
       if constexpr ((DBG & 1) != 0) gv = v; else gv = gelu_erf(v);
+      if constexpr (PROJ) gv *= rs2v;          // drop-path factor of the row (lane column of the B fragment)
       if constexpr ((e & 1) == 0) { gcarry = gv; pcarry = v; } else hf[u][e >> 1] = pack_bf2(gcarry, gv);
       if constexpr ((e & 1) == 1) {
         // gradient rows: keep the fc1 pre-activation and the GELU output (bf16, as the unfused path saves them); rare (8 % of the
@@ -376,28 +408,17 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         });
       });
+      MDBG_T(4);
       // ---- first residual + LayerNorm, from the accumulator layout: lane (l15 = row, lg) holds columns 16 t + 4 lg + r of its row.
-      //   x_new = x + row_scale1 * (acc + bp)  (fp32, the arithmetic of the GEMM epilogue it replaces) is stored -- the epilogue below
-      //   re-reads it as its residual term -- and normalised in place; the bf16 pairs are then moved into the B-fragment layout
-      //   (lane holds columns 32 s + 8 lg .. + 7) by two row swaps per register: for the tile pair (2 s, 2 s + 1)
+      //   acc2 = x + rs1 * (ao Wp^T + bp) = x1 (vit.py:163) stays in the accumulators as the start value of fc2 and is normalised from
+      //   there; the bf16 pairs are moved into the B-fragment layout (lane holds columns 32 s + 8 lg .. + 7) by two row
+      //   swaps per register: for the tile pair (2 s, 2 s + 1)
       //   permlane32_swap(P, Q) = {P0 P1 Q0 Q1, P2 P3 Q2 Q3} (rows = lane groups), then permlane16_swap of those two
       //   = {P0 P2 Q0 Q2, P1 P3 Q1 Q3}: exactly columns 8 lg .. + 3 and 8 lg + 4 .. + 7 of the k-step for lane group lg.
       {
-        const float rs1 = a.row_scale1 ? a.row_scale1[mc / a.rows_per_sample] : 1.0f;
-        const float* xr = a.x + (size_t)mc * D_ + 4 * lg;
-        float* xw = a.xo + (size_t)mc * D_ + 4 * lg;
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) {
-          const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sbp + 16 * t + 4 * lg);
-          f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
-          xv[0] += rs1 * (acc2[t][0] + bb[0]); xv[1] += rs1 * (acc2[t][1] + bb[1]);
-          xv[2] += rs1 * (acc2[t][2] + bb[2]); xv[3] += rs1 * (acc2[t][3] + bb[3]);
-          if (m < a.M) *reinterpret_cast<f32x4_t*>(xw + 16 * t) = xv;
-          acc2[t] = xv;
-          sum += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-          if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int t = 0; t < NT2; ++t) sum += (acc2[t][0] + acc2[t][1]) + (acc2[t][2] + acc2[t][3]);
         const float mu = rows_sum4(sum) * (1.0f / D_);
         float q = 0.f;
 #pragma unroll
@@ -433,8 +454,13 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
           if (sI & 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
+      MDBG_T(5);
+      // fc2 accumulates on x1 + rs2 * b2: the block's output needs no epilogue arithmetic
 #pragma unroll
-      for (int t = 0; t < NT2; ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT2; ++t) {
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sb2 + 16 * t + 4 * lg);
+        acc2[t][0] += rs2v * bb[0]; acc2[t][1] += rs2v * bb[1]; acc2[t][2] += rs2v * bb[2]; acc2[t][3] += rs2v * bb[3];
+      }
     }
     {
       using I0 = std::integral_constant<int, 0>;
@@ -459,20 +485,13 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     MDBG_T(2);
     // ---- epilogue: lane holds y[m][16 t + 4 g + r]
     if (PROJ && a.ln_next) {                // wave-uniform: the rows leave as fp32 (residual stream) AND normalised for the next block
-      const float rsc = a.row_scale ? a.row_scale[mc / a.rows_per_sample] : 1.0f;
-      const float* xr = a.xo + (size_t)mc * D_ + 4 * lg;
       float* xw = a.xo + (size_t)mc * D_ + 4 * lg;
       float sum = 0.f;
 #pragma unroll
       for (int t = 0; t < NT2; ++t) {
-        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(sb2 + 16 * t + 4 * lg);
-        f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xr + 16 * t);
-        xv[0] += rsc * (acc2[t][0] + bb[0]); xv[1] += rsc * (acc2[t][1] + bb[1]);
-        xv[2] += rsc * (acc2[t][2] + bb[2]); xv[3] += rsc * (acc2[t][3] + bb[3]);
+        const f32x4_t xv = acc2[t];
         if (m < a.M) *reinterpret_cast<f32x4_t*>(xw + 16 * t) = xv;
-        acc2[t] = xv;
         sum += (xv[0] + xv[1]) + (xv[2] + xv[3]);
-        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       const float mu = rows_sum4(sum) * (1.0f / D_);
       float q = 0.f;
@@ -508,9 +527,15 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
         chain = out4[3];
         if (m < a.M) *reinterpret_cast<u32x4_t*>(lw + 32 * sI) = u32x4_t{out4[0], out4[1], out4[2], out4[3]};
       }
+    } else if (PROJ) {
+      float* xw = a.xo + (size_t)mc * D_ + 4 * lg;
+      if (m < a.M) {
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) *reinterpret_cast<f32x4_t*>(xw + 16 * t) = acc2[t];
+      }
     } else if (m < a.M) {
       const float rsc = a.row_scale ? a.row_scale[m / a.rows_per_sample] : 1.0f;
-      const float* xr = (PROJ ? a.xo : a.x) + (size_t)m * D_ + 4 * lg;     // PROJ: the x_new this lane stored after the projection
+      const float* xr = a.x + (size_t)m * D_ + 4 * lg;
       float* xw = a.xo + (size_t)m * D_ + 4 * lg;
 #pragma unroll
       for (int t = 0; t < NT2; ++t) {
@@ -554,7 +579,7 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
   a.save_rows = save_rows;
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-  a.ao = nullptr; a.Wp = nullptr; a.bp = nullptr; a.row_scale1 = nullptr; a.ln_next = nullptr; a.gamma_n = a.beta_n = nullptr;
+  a.ao = nullptr; a.Wp = nullptr; a.bp = nullptr; a.row_scale1 = nullptr; a.ao_scaled = 0; a.ln_next = nullptr; a.gamma_n = a.beta_n = nullptr;
   const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4>;
 #ifdef SRHIP_TUNING
@@ -579,10 +604,11 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
 
 // Attention output projection + first residual + the whole MLP half of a block in ONE launch (rows without a backward):
 //   x1 = x + row_scale1 * (ao Wp^T + bp);   x_out = x1 + row_scale2 * (fc2(GELU(fc1(LayerNorm(x1)))) + b2)
-// (vit.py:163 tail: proj :105-106 + drop_path1 + residual, and :165).  Saves the proj GEMM launch and one read + write of the residual stream.
+// (vit.py:163 tail: proj :105-106 + drop_path1 + residual, and :165).  Saves the proj GEMM launch and two reads + a write of the residual stream:
+// x enters as the start value of the accumulators and x1 stays there.  ao_scaled != 0: ao already carries row_scale1 (only bp is scaled here).
 // ln_next != NULL: also LayerNorm(x_out) with (next_gamma, next_beta) -- the next block's norm1 (vit.py:163) -- as bf16 [M, D].
 extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
-                                    const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
+                                    int ao_scaled, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
                                     const float* b2, const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma,
                                     const float* next_beta, int M, int D, int Hd, void* stream) {
   if (!x || !x_out || !ao || !Wp || !bp || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return SR_EINVAL;
@@ -596,7 +622,7 @@ extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao
   a.s_ln2 = a.s_pre = a.s_h = nullptr; a.s_mean = a.s_rstd = nullptr; a.save_rows = 0;
   a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2; a.eps = eps; a.M = M; a.Hd = Hd;
   a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-  a.ao = (const bf16_t*)ao; a.Wp = (const bf16_t*)Wp; a.bp = bp; a.row_scale1 = row_scale1;
+  a.ao = (const bf16_t*)ao; a.Wp = (const bf16_t*)Wp; a.bp = bp; a.row_scale1 = row_scale1; a.ao_scaled = ao_scaled;
   a.ln_next = (bf16_t*)ln_next; a.gamma_n = next_gamma; a.beta_n = next_beta;
   const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4, true>;

@@ -271,9 +271,13 @@ class VisionTransformer:
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
             elif not ln_ready:
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, None, None, M, D)
+            ao_scaled = False
             if fused_attn:
                 # rows without a backward: qkv Linear + attention as ONE launch (one workgroup per image; qkv never reaches HBM)
-                ops.attn_block_fused(ln, P(b + "attn.qkv.weight", wb), P(b + "attn.qkv.bias"), ao, B, N, D, H, scale, qkv_extra=qkvx)
+                # (the DropPath factor of the branch rides on its bf16 output when the fused proj + MLP launch consumes it)
+                ao_scaled = fused_mlp and _FUSED_PROJ and s1 is not None
+                ops.attn_block_fused(ln, P(b + "attn.qkv.weight", wb), P(b + "attn.qkv.bias"), ao, B, N, D, H, scale, qkv_extra=qkvx,
+                                     out_scale=s1 if ao_scaled else None)
             else:
                 ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
                 ops.attn_fwd(qkv, ao, ctx.lse[i] if save else None, B, N, H, scale)
@@ -298,7 +302,7 @@ class VisionTransformer:
                                    P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb), P(b + "mlp.fc1.bias"),
                                    P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd,
                                    ln_next=ln if ln_ready else None, next_gamma=P(nb + "norm1.weight") if ln_ready else None,
-                                   next_beta=P(nb + "norm1.bias") if ln_ready else None)
+                                   next_beta=P(nb + "norm1.bias") if ln_ready else None, ao_scaled=ao_scaled)
             else:
                 ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), x, M, D, D, bias=P(b + "attn.proj.bias"),
                             row_scale=s1, rows_per_sample=N)

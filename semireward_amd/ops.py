@@ -205,23 +205,24 @@ def attn_block_supported(N, D, H):
     return bool(lib().srhip_attn_block_supported(N, D, H))
 
 
-def attn_block_fused(xn, Wqkv, bqkv, out, B, N, D, H, scale, qkv_extra=None):
+def attn_block_fused(xn, Wqkv, bqkv, out, B, N, D, H, scale, qkv_extra=None, out_scale=None):
     """out = attention(xn Wqkv^T + bqkv) for rows without a backward: qkv Linear + attention in one launch (xn = norm1 output, bf16).
-    N = 257: the q | k | v row of the 257th token of every image comes from one small GEMM (qkv_extra [B, 3D] workspace, filled here)."""
+    N = 257: the q | k | v row of the 257th token of every image comes from one small GEMM (qkv_extra [B, 3D] workspace, filled here).
+    out_scale [B] fp32: per-image factor on the output rows, applied before their bf16 rounding (DropPath of the branch)."""
     if N == 257:
         # rows 256, 256 + N, ... of xn: a strided A operand (lda = N * D), no gather
         gemm_nt(EPI_BF16, xn[256:], Wqkv, qkv_extra, B, 3 * D, D, lda=N * D, bias=bqkv)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), B, N, D, H, scale, _s())
+        _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), _p(out_scale), B, N, D, H, scale, _s())
         e1.record()
         M = B * N
         # algorithmic work: the qkv product + QK^T + PV; bytes: xn bf16 in, bf16 out, the weights once
         _PROFILE.recs.append((e0, e1, 2.0 * M * 3 * D * D + 4.0 * B * H * N * N * 64, "attn_block_kernel<%d>" % N,
                               2.0 * M * D + 2.0 * M * D + 2.0 * 3 * D * D))
         return
-    _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), B, N, D, H, scale, _s())
+    _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), _p(out_scale), B, N, D, H, scale, _s())
 
 
 def attn_fwd(qkv, out, lse, B, N, H, scale):
@@ -276,21 +277,22 @@ def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M
 
 
 def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, row_scale2, rows_per_sample, M, D, Hd, x_out=None,
-                   ln_next=None, next_gamma=None, next_beta=None):
+                   ln_next=None, next_gamma=None, next_beta=None, ao_scaled=False):
     """x_out (default: x, in place) = x1 + row_scale2 * (fc2(gelu(fc1(LN(x1)))) + b2) with x1 = x + row_scale1 * (ao Wp^T + bp): the attention
     projection, both residuals and the MLP half of a block in ONE launch (rows without a backward).  ln_next (bf16 [M, D]): also
-    LayerNorm(x_out) with the next block's norm1 affine."""
-    args = (_p(x), _p(x_out if x_out is not None else x), _p(ao), _p(Wp), _p(bp), _p(row_scale1), _p(gamma), _p(beta), eps, _p(W1), _p(b1),
+    LayerNorm(x_out) with the next block's norm1 affine.  ao_scaled: ao already carries row_scale1 (attn_block_fused out_scale)."""
+    args = (_p(x), _p(x_out if x_out is not None else x), _p(ao), _p(Wp), _p(bp), _p(row_scale1), int(bool(ao_scaled)), _p(gamma), _p(beta), eps,
+            _p(W1), _p(b1),
             _p(W2), _p(b2), _p(row_scale2), rows_per_sample, _p(ln_next), _p(next_gamma), _p(next_beta), M, D, Hd)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _call("srhip_mlp_fused_proj", *args, _s())
         e1.record()
-        # algorithmic: fc1 + fc2 + proj products; bytes: x in, x1 out + in, x out (fp32), ao in (bf16), [next norm1 output out (bf16)],
-        # the weights once
+        # algorithmic: fc1 + fc2 + proj products; bytes: x in, x out (fp32; x1 never leaves the accumulators), ao in (bf16), [next norm1
+        # output out (bf16)], the weights once
         _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_fused_kernel<384, 0, 4, true>",
-                              16.0 * M * D + 2.0 * M * D + (2.0 * M * D if ln_next is not None else 0.0) + 4.0 * D * Hd + 2.0 * D * D))
+                              8.0 * M * D + 2.0 * M * D + (2.0 * M * D if ln_next is not None else 0.0) + 4.0 * D * Hd + 2.0 * D * D))
         return
     _call("srhip_mlp_fused_proj", *args, _s())
 

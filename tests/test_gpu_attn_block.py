@@ -56,6 +56,20 @@ def test_fused_attention_half_matches_unfused_and_fp32(N, B):
     out1 = torch.empty(N, D, dtype=torch.bfloat16, device=DEV)
     ops.attn_block_fused(ln[:N].contiguous(), Wb, bq, out1, 1, N, D, H, 0.125, qkv_extra=qx[:1] if qx is not None else None)
     assert torch.equal(out1, out[:N])
+    # out_scale: the per-image DropPath factor of the branch (vit.py:163) applied before the bf16 rounding -- 1 is the identity, 0 gives
+    # zeros, anything else the scaled fp32 result rounded once
+    sc = torch.tensor([1.0, 0.0, 1.0 / 0.85] * B, device=DEV)[:B].contiguous()
+    outs = torch.full((M, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.attn_block_fused(ln, Wb, bq, outs, B, N, D, H, 0.125, qkv_extra=qx, out_scale=sc)
+    torch.cuda.synchronize()
+    for bi in range(B):
+        o_s, o_1 = outs[bi * N:(bi + 1) * N].float(), out[bi * N:(bi + 1) * N].float()
+        if bi % 3 == 0:
+            assert torch.equal(o_s, o_1)
+        elif bi % 3 == 1:
+            assert float(o_s.abs().max()) == 0.0
+        else:                                                     # within one bf16 ulp of the scaled, once-rounded value
+            assert float((o_s - o_1 / 0.85).abs().max()) <= 2.0 ** -7 * float(o_1.abs().max()) / 0.85
 
 
 def test_unsupported_shapes_are_an_argument_error():
@@ -67,7 +81,7 @@ def test_unsupported_shapes_are_an_argument_error():
         ops.attn_block_fused(x, w, b, o, 2, 37, 384, 6, 0.125)
     x257 = torch.zeros(257, 384, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError):                              # N = 257 without the extra-token row
-        ops._call("srhip_attn_block_fused", x257.data_ptr(), w.data_ptr(), b.data_ptr(), None, o.data_ptr(), 1, 257, 384, 6, 0.125, None)
+        ops._call("srhip_attn_block_fused", x257.data_ptr(), w.data_ptr(), b.data_ptr(), None, o.data_ptr(), None, 1, 257, 384, 6, 0.125, None)
 
 
 @pytest.mark.parametrize("tag", ["small_p2_32"])

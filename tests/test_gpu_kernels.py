@@ -180,8 +180,9 @@ def test_mlp_fused_proj(M, rows_per_sample):
     D, Hd = 384, 1536
     x0 = rnd(M, D, seed=1)
     x0[:, 7] += 3.0
-    ao = bf(rnd(M, D, seed=11, scale=0.7))
-    ao[:, 300] += 2.0                                          # uneven columns: a wrong fragment transpose would show
+    ao32 = rnd(M, D, seed=11, scale=0.7)
+    ao32[:, 300] += 2.0                                        # uneven columns: a wrong fragment transpose would show
+    ao = bf(ao32)
     Wp, bp = bf(rnd(D, D, seed=12, scale=0.06)), rnd(D, seed=13, scale=0.2)
     g, b = rnd(D, seed=2, scale=0.2) + 1.0, rnd(D, seed=3, scale=0.1)
     W1, W2 = bf(rnd(Hd, D, seed=4, scale=0.05)), bf(rnd(D, Hd, seed=5, scale=0.03))
@@ -225,14 +226,29 @@ def test_mlp_fused_proj(M, rows_per_sample):
     assert relerr(lnn.float(), torch.nn.functional.layer_norm(xf, (D,), gn, bn, 1e-6)) < 3e-3
     assert torch.equal(xo, xf)
     assert relerr(xf - x0, want - x0) < 6e-3
-    assert relerr(xf - x0, xu - x0) < 1.5e-3                   # same rounding points; accumulation / LN summation order differs
-    assert relerr(xf, xu) < 2e-4
+    # same rounding points (accumulation / LN summation order differs) unless a DropPath factor is in play: the fused launch applies it to
+    # the bf16 B operand of the product (one rounding of rs * value instead of value), the unfused pair to the fp32 result
+    assert relerr(xf - x0, xu - x0) < (1.5e-3 if rs1 is None else 4e-3)
+    assert relerr(xf, xu) < (2e-4 if rs1 is None else 3e-3), relerr(xf, xu)
+    if rs1 is not None:
+        # the form the backbone uses: the attention launch applied rs1 BEFORE rounding its output (srhip_attn_block_fused out_scale) -> one
+        # rounding per operand as in the unfused pair, and no further from the fp32 formula than that pair
+        xs = x0.clone()
+        ops.mlp_fused_proj(xs, bf(sc(rs1) * ao32), Wp, bp, rs1, g, b, 1e-6, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd, ao_scaled=True)
+        torch.cuda.synchronize()
+        want32 = x0 + sc(rs1) * (ao32 @ Wp.float().T + bp)
+        want32 = want32 + sc(rs2) * (gelu(torch.nn.functional.layer_norm(want32, (D,), g, b, 1e-6) @ W1.float().T + b1) @ W2.float().T + b2)
+        e_f, e_u = relerr(xs - x0, want32 - x0), relerr(xu - x0, want32 - x0)
+        assert e_f < 1.1 * e_u + 1e-4, (e_f, e_u)
     if rs1 is not None:                                        # rows whose both branches are dropped are untouched, bit for bit
         dead = (rs1.repeat_interleave(rows_per_sample)[:M] == 0) & (rs2.repeat_interleave(rows_per_sample)[:M] == 0)
         assert (M < 257 * 20 or bool(dead.any())) and torch.equal(xf[dead], x0[dead])
         only2 = (rs1.repeat_interleave(rows_per_sample)[:M] != 0) & (rs2.repeat_interleave(rows_per_sample)[:M] == 0)
-        if bool(only2.any()):                                  # MLP branch dropped: exactly the projection residual
-            assert float((xf[only2] - x1u[only2]).abs().max()) < 2e-5 * float(x1u.abs().max())
+        if bool(only2.any()):                                  # MLP branch dropped: the projection residual alone (rs1 on the bf16 operand)
+            assert relerr(xf[only2] - x0[only2], x1u[only2] - x0[only2]) < 4e-3
+        only1 = (rs1.repeat_interleave(rows_per_sample)[:M] == 0) & (rs2.repeat_interleave(rows_per_sample)[:M] != 0)
+        if bool(only1.any()):                                  # projection dropped: LN + MLP of the untouched rows
+            assert relerr(xf[only1] - x0[only1], xu[only1] - x0[only1]) < 4e-3
 
 
 @pytest.mark.parametrize("B,N,H", [(3, 17, 2), (2, 197, 6), (4, 257, 6), (1, 64, 1), (2, 33, 3)])

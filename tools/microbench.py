@@ -112,7 +112,7 @@ def attn_block():
             t0 = timeit(unfused, reps=20)
             t1 = timeit(fused, reps=20)
             if os.environ.get("SRHIP_TUNING_BUILD") and B == 200:
-                only = lambda: ops._call("srhip_attn_block_fused", ln.data_ptr(), W.data_ptr(), bq.data_ptr(), qx.data_ptr(), out.data_ptr(), B, N, D, H, 0.125, None)   # noqa: E731
+                only = lambda: ops._call("srhip_attn_block_fused", ln.data_ptr(), W.data_ptr(), bq.data_ptr(), qx.data_ptr(), out.data_ptr(), None, B, N, D, H, 0.125, None)   # noqa: E731
                 print("   kernel alone %7.1f us" % timeit(only, reps=20), flush=True)
                 for dbg in (1, 2, 3, 4, 6, 7):
                     os.environ["SRHIP_AB_DEBUG"] = str(dbg)
