@@ -30,6 +30,28 @@ _PHASES = os.environ.get("SR_PHASES", "0") != "0"
 _DEFER_FRACTION = float(os.environ.get("SR_DEFER_FRACTION", "0.475"))   # share of the inference images on the second stream (see _Plan)
 
 
+class _OwnStreamScope:
+    """Run a step on ``stream`` (ordered after the caller's current stream on entry, the caller's stream ordered after it on exit)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.outer = torch.cuda.current_stream()
+        self.stream.wait_stream(self.outer)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        self.pin = ops.stream_scope()
+        self.pin.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.pin.__exit__(*a)
+        self.ctx.__exit__(*a)
+        self.outer.wait_stream(self.stream)
+        return False
+
+
 class _Plan:
     """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
     rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
@@ -126,6 +148,13 @@ class SRConsistencyBase(AlgorithmBase):
         self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", os.environ.get("SR_OVERLAP_GRAD_ROWS", "1") != "0")) \
             and torch.cuda.is_available()
         self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
+        # the rows nothing reads: optionally on a stream of their own that is confined to SR_REST_CUS compute units (ops.masked_stream)
+        rest_cus = int(os.environ.get("SR_REST_CUS", "0"))
+        self._rest_stream = ops.masked_stream(rest_cus, self.device) if (self.overlap_grad_rows and rest_cus > 0) else None
+        self._rest_after_grad = os.environ.get("SR_REST_AFTER_GRAD", "1") != "0"
+        # hipExtStreamCreateWithCUMask only makes BLOCKING streams (they synchronise with the NULL stream, torch's default current stream):
+        # with one in play the step itself runs on a non-blocking stream of its own, joined to the caller's stream at both ends
+        self._main_stream = torch.cuda.Stream(device=self.device) if self._rest_stream is not None else None
         # rows nothing downstream reads (see _Plan) go behind the gradient rows on the second stream; the step end waits for them
         self.defer_unread_rows = self.overlap_grad_rows and os.environ.get("SR_DEFER_UNREAD_ROWS", "1") != "0"
         # opt-in: do not compute the rows nothing reads (see _Plan.cat_passes); never on by default -- the reference computes them
@@ -231,6 +260,14 @@ class SRConsistencyBase(AlgorithmBase):
                 lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
                 grad_done = torch.cuda.Event()
                 grad_done.record(side)
+            rs = self._rest_stream if self._rest_stream is not None else side
+            if nr and rs is not side:
+                rs.wait_event(grad_done if self._rest_after_grad else ready)
+                for t_ in (logits, feats, dp_rest, imgs, getattr(imgs, "ids", None), getattr(imgs, "key_len", None),
+                           getattr(imgs, "seq_len", None)):
+                    if torch.is_tensor(t_):
+                        t_.record_stream(rs)
+            with torch.cuda.stream(rs), ops.stream_scope():
                 if nr:
                     # Rows whose outputs nothing reads before the step ends (strong / labelled rows of the passes whose loss the
                     # reference discards): 60 % of the forward work, off the critical path.  The masks, losses and the latency-bound
@@ -239,7 +276,7 @@ class SRConsistencyBase(AlgorithmBase):
                     logits.index_copy_(0, pl.rest_cols, lg_r)
                     feats.index_copy_(0, pl.rest_cols, ft_r)
                     self._rest_done = torch.cuda.Event()
-                    self._rest_done.record(side)
+                    self._rest_done.record(rs)
             # The gradient rows are joined LATER (_join_grad): masks, pseudo labels and reward scores only read the weak rows of the launch
             # above, so that chain (~0.3 ms of tiny sequential launches) runs while the second stream still works on the gradient rows.
             self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, pl.grad_cols)
@@ -265,7 +302,9 @@ class SRConsistencyBase(AlgorithmBase):
         # (tried and measured on MI355X, both without gain: running the step on a high-priority stream -- the hardware offers two levels and
         # a small launch still waits for a 100-us workgroup of the other stream to retire -- and confining the second stream to a CU subset
         # with hipExtStreamCreateWithCUMask, which slows the full-chip launches by more than it speeds the small ones up)
-        return ops.stream_scope()
+        if self._rest_stream is None:
+            return ops.stream_scope()
+        return _OwnStreamScope(self._main_stream)
 
     def _phase_mark(self, name):
         """Tuning aid (SR_PHASES=1): GPU timestamps (events on the step's stream) + host timestamps of the phases of train_step."""

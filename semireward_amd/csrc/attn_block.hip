@@ -67,14 +67,21 @@ __device__ __forceinline__ int fresh_lane() {
   return l;
 }
 
+// max of three without the canonicalising v_max_f32 x, x, x that fmaxf() / __builtin_fmaxf() put in front of every operand (an MFMA result
+// is not known to be canonical to the compiler): 30 instead of 8 instructions per chunk of 16 scores in the attention phase.  The median of
+// {a, b, +inf} is max(a, b) and v_med3_f32 takes its operands as they are.  (Inline asm is not an option: the MFMA -> VALU read hazard is
+// software-managed and the hazard recogniser does not look inside asm statements -- stale accumulator reads.)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a, b, INFINITY), c, INFINITY);
+}
 // all-reduce over the four 16-lane rows of a wave (the four key groups of one query) with the gfx950 row-swap instructions instead of two
 // ds_bpermute round trips: permlane16_swap(x, x) = {rows 0 0 2 2, rows 1 1 3 3}, permlane32_swap(x, x) = {lo lo, hi hi} (tools/pl_probe.hip)
 __device__ __forceinline__ float rows_max(float x) {
   const unsigned u = __float_as_uint(x);
   const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const unsigned v = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  const unsigned v = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(a[0]), __uint_as_float(a[1]), INFINITY));
   const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  return __builtin_amdgcn_fmed3f(__uint_as_float(b[0]), __uint_as_float(b[1]), INFINITY);
 }
 __device__ __forceinline__ float rows_sum(float x) {
   const unsigned u = __float_as_uint(x);
@@ -111,7 +118,8 @@ struct AbArgs {
   int B;
 };
 
-// DBG (tuning builds only, SRHIP_AB_DEBUG): 1 = no attention phase, 2 = no projection MFMAs, 4 = no DMA / no vmcnt waits (wrong results by design)
+// DBG (tuning builds only, SRHIP_AB_DEBUG): 1 = no attention phase, 2 = no projection MFMAs, 4 = no DMA / no vmcnt waits, 8 = no pass for the
+// 257th query (wrong results by design)
 template <int N, int DBG>
 __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
   constexpr int NKT = nkt_of(N), NP = NKT * 16, TP = vt_pitch(NP);
@@ -259,27 +267,31 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
     });
     // ---- results of the matrix leave the accumulators
     if constexpr (M == 0) {                            // K image: row = key, 16-byte chunk 4 blk + g holds features 32 blk + 8 g .. + 7
+      // (store addresses from a lane id read HERE: computed from l15 / g they are head-invariant, get hoisted out of the head loop and held
+      // in four registers across the attention phase -- one of them spilled, and its reload drained the weight ring once per head)
+      const int lnk = fresh_lane(), l15k = lnk & 15, gk = lnk >> 4;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         if (tt == 1 && !tile1) break;
-        const int key = 16 * (wave + 8 * tt) + l15;
+        const int key = 16 * (wave + 8 * tt) + l15k;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
-          *reinterpret_cast<u32x4_t*>(Ks + key * HD + (((4 * blk + g) ^ ((key >> 1) & 7)) << 3)) = pack8v(acc[tt][2 * blk], acc[tt][2 * blk + 1]);
+          *reinterpret_cast<u32x4_t*>(Ks + key * HD + (((4 * blk + gk) ^ ((key >> 1) & 7)) << 3)) = pack8v(acc[tt][2 * blk], acc[tt][2 * blk + 1]);
       }
       if (EXTRA && wave == 0) {                        // key 256 of this head from the pre-computed row ((256 >> 1) & 7 = 0: chunks in place)
         const int ln_ = fresh_lane();
         if (ln_ < 8) *reinterpret_cast<u32x4_t*>(Ks + 256 * HD + (ln_ << 3)) = ldf(sx + DM + h * HD + 8 * ln_);
       }
     } else if constexpr (M == 1) {                     // V^T image: lane holds keys 4 g .. 4 g + 3 of its tile for feature 16 t + l15
+      const int lnv = fresh_lane(), l15v = lnv & 15, gv = lnv >> 4;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         if (tt == 1 && !tile1) break;
         const int T = wave + 8 * tt, u = T >> 1, e = T & 1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int d = 16 * t + l15;
-          *reinterpret_cast<u32x2_t*>(Vt + d * TP + 32 * u + ((g ^ swz4(d)) << 3) + 4 * e) =
+          const int d = 16 * t + l15v;
+          *reinterpret_cast<u32x2_t*>(Vt + d * TP + 32 * u + ((gv ^ swz4(d)) << 3) + 4 * e) =
               u32x2_t{pack_bf2(acc[tt][t][0], acc[tt][t][1]), pack_bf2(acc[tt][t][2], acc[tt][t][3])};
         }
       }
@@ -308,15 +320,15 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
     lds_barrier();                                     // K / V^T images of this head are complete
 
     // =============== attention of this head: the wave's query tiles against all keys ===============
-    const int nq = (DBG & 1) ? 0 : (tile1 ? 2 : 1) + ((EXTRA && (h & 7) == wave) ? 1 : 0);
+    const int nq = (DBG & 1) ? 0 : (tile1 ? 2 : 1) + ((EXTRA && (DBG & 8) == 0 && (h & 7) == wave) ? 1 : 0);
 #pragma unroll 1
     for (int qi = 0; qi < nq; ++qi) {
       const bool ext = EXTRA && qi == (tile1 ? 2 : 1);
-      u32x4_t q0, q1;
+      // the tile's Q fragments are always qf[0] (the next tile's move up at the end of the iteration): no selected copy held next to both
       int qtok;
-      if (ext) { q0 = ldf(sx + h * HD + 8 * g); q1 = ldf(sx + h * HD + 32 + 8 * g); qtok = 256 + l15; }
-      else if (qi == 0) { q0 = qf[0][0]; q1 = qf[0][1]; qtok = 16 * wave + l15; }
-      else { q0 = qf[1][0]; q1 = qf[1][1]; qtok = 16 * (wave + 8) + l15; }
+      if (ext) { qf[0][0] = ldf(sx + h * HD + 8 * g); qf[0][1] = ldf(sx + h * HD + 32 + 8 * g); qtok = 256 + l15; }
+      else qtok = 16 * (wave + 8 * qi) + l15;
+      const u32x4_t q0 = qf[0][0], q1 = qf[0][1];
       // Scores in chunks of 4 key tiles with a running maximum (16 score registers instead of 72 next to the 96 of the token fragments):
       // p = 2^(s c - m c) against the maximum so far; partial output and row sum are rescaled by 2^((m_old - m_new) c) whenever a later
       // chunk raises it.  Same rounding points as attention.hip (p bf16, fp32 sums).
@@ -324,7 +336,12 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
       f32x4_t o[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      float mrun = -INFINITY, sum = 0.f;
+      // The phase is bound by the vector ALU, not by the matrix pipe (per lane and head 136 scores: fma + v_exp_f32 at quarter rate + sum +
+      // max): everything around the exponential is kept to the instruction minimum -- v_max3_f32 without the canonicalising v_max x, x that
+      // fmaxf() costs per operand, the scale-and-shift and the row sums as 2-wide packed fp32 operations (two partial sums per lane), and no
+      // work at all on key positions that are padding at compile time (N = 257: one register of tile 16, nothing of tile 17).
+      float mrun = -INFINITY;
+      f32x2_t psum = {0.f, 0.f};
       static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
         constexpr int ch = decltype(cc)::value, t0 = ch * CHT, nt = (NKT - t0 < CHT) ? NKT - t0 : CHT;
         static_assert(nt % 2 == 0, "the PV product consumes key-tile pairs");
@@ -333,35 +350,51 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
 #pragma unroll
         for (int i = 0; i < nt; ++i) {
           const int t = t0 + i;
+          const int nvalid = N - 16 * t;                // keys of this tile that exist (compile-time after unrolling)
+          if (nvalid <= 0) continue;                    // all padding: no scores, p = 0 below
           f32x4_t c = {0.f, 0.f, 0.f, 0.f};
           c = mfma16(ldf(Ks + t * 16 * HD + kof0), q0, c);
           c = mfma16(ldf(Ks + t * 16 * HD + kof1), q1, c);
-          if (t >= NKT_LO && t * 16 + 16 > N) {
+          if (nvalid >= 16) {
+            mx = max3_raw(mx, c[0], c[1]);
+            mx = max3_raw(mx, c[2], c[3]);
+          } else {                                      // key 16 t + 4 g + r: register r can only be valid while r < nvalid
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = (t * 16 + g * 4 + r < N) ? c[r] : -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+              if (r < nvalid) { c[r] = (4 * g + r < nvalid) ? c[r] : -INFINITY; mx = max3_raw(mx, c[r], c[r]); }
+            }
           }
-          mx = fmaxf(mx, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
           s[i] = c;
           if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         mx = rows_max(mx);
-        const float mnew = fmaxf(mrun, mx);            // (finite from the first chunk on: key 0 is never masked)
+        const float mnew = max3_raw(mrun, mx, mx);      // (finite from the first chunk on: key 0 is never masked)
         const float nmx = -mnew * sc2;
         if constexpr (ch > 0) {
           const float corr = fast_exp2(fmaf(mrun, sc2, nmx));
-          sum *= corr;
+          psum *= corr;
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) { o[dt][0] *= corr; o[dt][1] *= corr; o[dt][2] *= corr; o[dt][3] *= corr; }
+          for (int dt = 0; dt < 4; ++dt) o[dt] *= corr;
         }
         mrun = mnew;
+        const f32x4_t sc4 = {sc2, sc2, sc2, sc2}, nm4 = {nmx, nmx, nmx, nmx};
 #pragma unroll
-        for (int i = 0; i < nt; ++i)
+        for (int i = 0; i < nt; ++i) {
+          const int nvalid = N - 16 * (t0 + i);
+          if (nvalid >= 16) {
+            const f32x4_t e = __builtin_elementwise_fma(s[i], sc4, nm4);
+            const f32x4_t p = {fast_exp2(e[0]), fast_exp2(e[1]), fast_exp2(e[2]), fast_exp2(e[3])};
+            s[i] = p;
+            psum += f32x2_t{p[0], p[1]};
+            psum += f32x2_t{p[2], p[3]};
+          } else {
+            f32x4_t p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = fast_exp2(fmaf(s[i][r], sc2, nmx));
-            s[i][r] = p;
-            sum += p;
+            for (int r = 0; r < 4; ++r)
+              if (r < nvalid) { p[r] = fast_exp2(fmaf(s[i][r], sc2, nmx)); psum[r & 1] += p[r]; }
+            s[i] = p;
           }
+        }
 #pragma unroll
         for (int u = 0; u < nt / 2; ++u) {
           const u32x4_t pb = pack8v(s[2 * u], s[2 * u + 1]);
@@ -370,6 +403,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       });
+      float sum = psum[0] + psum[1];
       sum = rows_sum(sum);
       if (qtok < N && (!ext || l15 == 0)) {
         const float inv = osc / sum;
@@ -380,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
           *reinterpret_cast<uint2*>(op + dt * 16) = v;
         }
       }
+      qf[0][0] = qf[1][0]; qf[0][1] = qf[1][1];
     }
     // (no barrier here: the next head's first image write comes after three group syncs, which every wave reaches after its attention)
   }
@@ -422,6 +457,7 @@ extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, con
     case 4: return N == 257 ? launch<257, 4>(a, s) : launch<197, 4>(a, s);
     case 6: return N == 257 ? launch<257, 6>(a, s) : launch<197, 6>(a, s);
     case 7: return N == 257 ? launch<257, 7>(a, s) : launch<197, 7>(a, s);
+    case 8: return N == 257 ? launch<257, 8>(a, s) : launch<197, 8>(a, s);
     default: break;
   }
 #endif

@@ -35,6 +35,17 @@ def _s():
     return _STREAM if _STREAM is not None else torch.cuda.current_stream().cuda_stream
 
 
+def masked_stream(n_cus, device=None):
+    """A HIP stream whose launches may only use the first ``n_cus`` compute units of the driver's numbering (MI355X: bit i of the mask is a CU
+    of XCD i % 8, so 192 = 24 CUs of every XCD), wrapped for torch.cuda.stream().  The stream lives as long as the process."""
+    import ctypes
+    words = (max(n_cus, 1) + 31) // 32
+    mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if 32 * (w + 1) <= n_cus else ((1 << (n_cus - 32 * w)) - 1)) for w in range(words)])
+    out = ctypes.c_void_p()
+    _call("srhip_stream_create_cu_mask", ctypes.cast(mask, ctypes.c_void_p), words, ctypes.cast(ctypes.byref(out), ctypes.c_void_p))
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 class stream_scope:
     """Pin the hipStream_t for a burst of launches (torch.cuda.current_stream() costs ~2.5 us per call, 40 % of the host
     time of a training step).  Use as a context manager around code that does not switch streams."""

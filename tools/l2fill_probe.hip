@@ -96,6 +96,12 @@ int main(int argc, char** argv) {
       run<0, 1024, 4, 4>("dma seg1024 4KiB/wave ring4 8w", 512, src, sb, 1024, sink, 1);
       run<0, 64, 4, 4>("dma seg64 4KiB/wave ring4 8w", 512, src, sb, 64, sink, 1);
       run<0, 128, 2, 8>("dma seg128 2KiB/wave ring8 8w", 512, src, sb, 768, sink, 1);
+      // the row pitches of the fused MLP kernel's ring stages: fc1 weight rows (64 B pieces, 768 B apart), fc2 weight rows (64 B, 3072 B apart)
+      run<0, 64, 4, 4>("dma seg64 pitch 768 (W1 stage)", 512, src, sb, 768, sink, 1);
+      run<0, 64, 4, 4>("dma seg64 pitch 3072 (W2 stage)", 512, src, sb, 3072, sink, 1);
+      run<0, 64, 4, 4>("dma seg64 pitch 3072 on 32 WGs", 512, src, sb, 3072, sink, 1, 32);
+      run<0, 64, 1, 16>("dma seg64 pitch 3072 1KiB/wave ring16", 512, src, sb, 3072, sink, 1);
+      run<0, 64, 1, 16>("dma seg64 pitch 64 1KiB/wave ring16", 512, src, sb, 64, sink, 1);
       run<0, 128, 4, 4>("dma 8w ring4 on 32 WGs", 512, src, sb, 768, sink, 1, 32);
       run<1, 128, 4, 5>("reg seg128 4KiB/wave pd4 8w", 512, src, sb, 768, sink, 1);
       run<1, 128, 4, 5>("reg seg128 4KiB/wave pd4 8w x2", 512, src, sb, 768, sink, 2);
