@@ -119,7 +119,7 @@ struct AbArgs {
 };
 
 // DBG (tuning builds only, SRHIP_AB_DEBUG): 1 = no attention phase, 2 = no projection MFMAs, 4 = no DMA / no vmcnt waits, 8 = no pass for the
-// 257th query (wrong results by design)
+// 257th query, 16 = no v_exp (wrong results by design)
 template <int N, int DBG>
 __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
   constexpr int NKT = nkt_of(N), NP = NKT * 16, TP = vt_pitch(NP);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
           const int nvalid = N - 16 * (t0 + i);
           if (nvalid >= 16) {
             const f32x4_t e = __builtin_elementwise_fma(s[i], sc4, nm4);
-            const f32x4_t p = {fast_exp2(e[0]), fast_exp2(e[1]), fast_exp2(e[2]), fast_exp2(e[3])};
+            const f32x4_t p = (DBG & 16) ? e : f32x4_t{fast_exp2(e[0]), fast_exp2(e[1]), fast_exp2(e[2]), fast_exp2(e[3])};
             s[i] = p;
             psum += f32x2_t{p[0], p[1]};
             psum += f32x2_t{p[2], p[3]};
@@ -458,6 +458,7 @@ extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, con
     case 6: return N == 257 ? launch<257, 6>(a, s) : launch<197, 6>(a, s);
     case 7: return N == 257 ? launch<257, 7>(a, s) : launch<197, 7>(a, s);
     case 8: return N == 257 ? launch<257, 8>(a, s) : launch<197, 8>(a, s);
+    case 16: return N == 257 ? launch<257, 16>(a, s) : launch<197, 16>(a, s);
     default: break;
   }
 #endif

@@ -114,9 +114,9 @@ def attn_block():
             if os.environ.get("SRHIP_TUNING_BUILD") and B == 200:
                 only = lambda: ops._call("srhip_attn_block_fused", ln.data_ptr(), W.data_ptr(), bq.data_ptr(), qx.data_ptr(), out.data_ptr(), None, B, N, D, H, 0.125, None)   # noqa: E731
                 print("   kernel alone %7.1f us" % timeit(only, reps=20), flush=True)
-                for dbg in (1, 2, 3, 4, 6, 7, 8):
+                for dbg in (1, 2, 3, 4, 6, 7, 8, 16):
                     os.environ["SRHIP_AB_DEBUG"] = str(dbg)
-                    print("   debug=%d (1 no attention, 2 no projection MFMAs, 4 no DMA, 8 no pass for query 256): %7.1f us" % (dbg, timeit(only, reps=10)), flush=True)
+                    print("   debug=%d (1 no attention, 2 no projection MFMAs, 4 no DMA, 8 no pass for query 256, 16 no v_exp): %7.1f us" % (dbg, timeit(only, reps=10)), flush=True)
                 os.environ.pop("SRHIP_AB_DEBUG")
             fl = 2.0 * M * 3 * D * D + 4.0 * B * H * N * N * 64
             print("attn half N=%3d B=%3d: three launches %7.1f us %6.1f TF/s | fused %7.1f us %6.1f TF/s" % (N, B, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6),
