@@ -178,6 +178,11 @@ int srhip_patch_grad_operands(const float* dx, void* dx_tok_bf16, float* dpos, f
  * feat fp32 [B,D], logits fp32 [B,C]; xhat [B,D] / rstd [B] saved for the backward when non-NULL. */
 int srhip_cls_head_fwd(const float* x, const float* gamma, const float* beta, float eps, const float* Wh, const float* bh,
                        float* feat, float* logits, float* xhat, float* rstd, int B, int N, int D, int C, void* stream);
+/* The same, ALSO (or only: feat / logits may then be NULL) writing image b's outputs to row out_rows[b] of feat_all [*, D] / logits_all [*, C]:
+ * the step's buffers over all (pass, image) rows, filled by the launch trains directly instead of by an index_copy_ each. */
+int srhip_cls_head_fwd_scatter(const float* x, const float* gamma, const float* beta, float eps, const float* Wh, const float* bh,
+                               float* feat, float* logits, float* xhat, float* rstd, float* feat_all, float* logits_all,
+                               const long long* out_rows, int B, int N, int D, int C, void* stream);
 /* dx[b,0,:] = ...(rows other than the cls row are left untouched: zero dx first); dWh/dbh/dgamma/dbeta += */
 int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const float* gamma, const float* feat, const float* xhat,
                        const float* rstd, float* dx, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int N,
@@ -199,6 +204,11 @@ int srhip_transpose_batched(const srhip_transpose_desc* desc_dev, int n, int tot
 int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stream);
 /* timm DropPath (vit.py:148,161): out[depth,2,B] = Bernoulli(1-p_l)/(1-p_l), counter-based RNG. */
 int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream);
+/* The same draw, but only (and in the order of) the columns cols[0 .. n_cols): out [depth, 2, n_cols], out[l, j, q] = table[l, j, cols[q]].
+ * One launch lays the table out in the order of the step's launch trains (gradient rows | read rows | deferred rows), each of which then
+ * takes a contiguous column slice -- instead of an index_select per train on the step's critical path. */
+int srhip_droppath_fill_cols(float* out, const float* probs, const long long* cols, int depth, int B, int n_cols, unsigned long long seed,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Score filter (K8, K9, K11, K12, K13).
@@ -207,6 +217,11 @@ int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsign
  *   (in_is_probs = 0) or probabilities (1); probs_out optional. */
 int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B, int C,
                   void* stream);
+/* The same on rows read in place from a [groups, rows, C] buffer: input row r = in + (r / rows_per_group) * group_stride +
+ * (r % rows_per_group) * C (elements) -- the weak rows of every pass inside the step's logits (srflexmatch.py:75-104 takes them pass by pass
+ * out of separate forward calls); outputs dense. */
+int srhip_row_max_strided(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B, int C,
+                          int rows_per_group, long long group_stride, void* stream);
 /* FlexMatchThresholdingHook.masking + update (semilearn/algorithms/srflexmatch/utils.py:24-63).  State on device:
  * selected_label int64 [ulb_dest_len] (-1 = unused), classwise_acc fp32 [C], hist int32 [C+1] (bin C = unused).
  * idx_ulb must be unique within the batch (reference sampler property). */
@@ -274,6 +289,12 @@ int srhip_rewarder_prepare(const float* params, float* params_t, int F, int L, v
 int srhip_generator_prepare(const float* params, float* params_t, int F, void* stream);
 int srhip_rewarder_fwd(const float* params, const float* params_t, const float* feats, const long long* labels, float* reward,
                        float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream);
+/* The same with the feature rows of group g at feats + g * feat_group_stride (elements; >= B * F): the weak-row block of every pass read in
+ * place from the step's [passes, batch, F] feature buffer.  Both entries run as ONE launch when a group is one row tile (B <= 8, the
+ * reference batch), two otherwise (the batch softmax over a group's 2B attention logits, semireward.py:60-62, is the only dependency
+ * between workgroups). */
+int srhip_rewarder_fwd_strided(const float* params, const float* params_t, const float* feats, long long feat_group_stride,
+                               const long long* labels, float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream);
 /* Gradient of MSE(r,1) + MSE(r,target) w.r.t. every rewarder parameter (srflexmatch.py:183-190 / :198-205);
  * grads is overwritten; losses[0..1] = (generator_loss, rewarder_loss) when non-NULL. */
 int srhip_rewarder_bwd(const float* params, const float* feats, const long long* labels, const float* target, float* ws,

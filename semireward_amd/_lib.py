@@ -5,7 +5,7 @@ raises.  Signatures mirror include/srhip.h one to one.
 """
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
+from ctypes import c_double, c_float, c_int, c_long, c_longlong, c_uint, c_ulonglong, c_void_p
 
 # torch must be imported BEFORE libsrhip.so is dlopen'ed: torch ships its own libamdhip64; if libsrhip pulled the
 # system copy in first the process would hold two HIP runtimes and our launches would see "no device" (hipError 100).
@@ -40,13 +40,16 @@ SIGNATURES = {
     "srhip_patch_assemble": (I, [P, P, P, P, P, I, I, I, P]),
     "srhip_patch_grad_operands": (I, [P, P, P, P, I, I, I, P]),
     "srhip_cls_head_fwd": (I, [P, P, P, F, P, P, P, P, P, P, I, I, I, I, P]),
+    "srhip_cls_head_fwd_scatter": (I, [P, P, P, F, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "srhip_cls_head_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "srhip_cast_scale_rows": (I, [P, P, I, P, L, I, P]),
     "srhip_transpose_to_bf16": (I, [P, I, I, P, I, I, I, I, I, P, P]),
     "srhip_transpose_batched": (I, [P, I, I, P]),
     "srhip_cast_f32_bf16": (I, [P, P, L, P]),
     "srhip_droppath_fill": (I, [P, P, I, I, c_ulonglong, P]),
+    "srhip_droppath_fill_cols": (I, [P, P, P, I, I, I, c_ulonglong, P]),
     "srhip_row_max": (I, [P, I, P, P, P, I, I, P]),
+    "srhip_row_max_strided": (I, [P, I, P, P, P, I, I, I, c_longlong, P]),
     "srhip_flexmatch_mask": (I, [P, P, P, F, P, P, P, P, I, I, I, I, P]),
     "srhip_flexmatch_mask_passes": (I, [P, P, P, F, P, P, P, P, I, I, I, I, I, P]),
     "srhip_flexmatch_rebuild_hist": (I, [P, P, I, I, P]),
@@ -66,6 +69,7 @@ SIGNATURES = {
     "srhip_rewarder_prepare": (I, [P, P, I, I, P]),
     "srhip_generator_prepare": (I, [P, P, I, P]),
     "srhip_rewarder_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_rewarder_fwd_strided": (I, [P, P, P, c_longlong, P, P, P, I, I, I, I, I, P]),
     "srhip_rewarder_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "srhip_generator_fwd": (I, [P, P, P, P, P, I, I, P]),
     "srhip_sr_target": (I, [P, P, P, I, I, P]),

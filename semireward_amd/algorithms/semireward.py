@@ -149,6 +149,14 @@ class Rewarder(_FlatModule):
                          groups, B, self.feature_dim, self.label_dim, save_for_bwd)
         return reward
 
+    def score_in_place(self, feat_buffer, first_row, group_rows, rows_per_group, label_indices, groups):
+        """score() on feature rows read where they are: group g = rows first_row + g * group_rows .. + rows_per_group of the contiguous
+        [*, F] buffer (the weak rows of pass g + 1 inside the step's feature buffer) -- no gathered copy."""
+        reward = torch.empty(groups * rows_per_group, dtype=torch.float32, device=self.device)
+        ops.rewarder_fwd(self.flat, self.flat_t, feat_buffer, label_indices.contiguous(), reward, self._workspace(groups, rows_per_group),
+                         groups, rows_per_group, self.feature_dim, self.label_dim, False, feats_first_row=first_row, group_rows=group_rows)
+        return reward
+
     def __call__(self, features, label_indices):
         return self.score(features, label_indices).view(-1, 1)
 

@@ -90,6 +90,8 @@ class _Plan:
             inf_cols, rest_cols = sorted(inf_cols + rest_cols), []
         t = lambda v, dt: torch.tensor(v, dtype=dt, device=device)   # noqa: E731
         self.grad_cols, self.inf_cols, self.rest_cols = t(list(grad_cols), torch.int64), t(inf_cols, torch.int64), t(rest_cols, torch.int64)
+        # the columns in launch order (gradient | read | deferred): a DropPath table drawn in THIS column order hands every launch train a slice
+        self.perm_cols = t(list(grad_cols) + list(inf_cols) + list(rest_cols), torch.int64)
         self.grad_img = t([cols_img[c] for c in grad_cols], torch.int32)
         self.inf_img = t([cols_img[c] for c in inf_cols], torch.int32)
         self.rest_img = t([cols_img[c] for c in rest_cols], torch.int32)
@@ -184,13 +186,22 @@ class SRConsistencyBase(AlgorithmBase):
         rows with activations kept).  Returns (logits [ncols,C], feats [ncols,D], ctx)."""
         m = self.model
         C, D = self.num_classes, m.cfg.embed_dim
+        ng_, ni_ = pl.grad_cols.numel(), pl.inf_cols.numel()
         if droppath_cols is not None:
             dp_all = droppath_cols.to(self.device)                                                   # [depth,2,ncols]
+            sel = lambda cols, a: dp_all.index_select(2, cols).contiguous()                          # noqa: E731
         elif m.training and m.cfg.drop_path_rate > 0:
-            dp_all = m.make_droppath(pl.ncols)
+            if getattr(m, "droppath_by_cols", False):
+                # ONE launch: the columns of the draw in launch order; a launch train's table is the slice [a, a + len(cols))
+                dp_all = m.make_droppath(pl.ncols, cols=pl.perm_cols)
+                sel = lambda cols, a: dp_all[:, :, a:a + cols.numel()]                               # noqa: E731
+            else:
+                dp_all = m.make_droppath(pl.ncols)
+                sel = lambda cols, a: dp_all.index_select(2, cols).contiguous()                      # noqa: E731
         else:
             dp_all = None
-        sel = (lambda cols: dp_all.index_select(2, cols).contiguous()) if dp_all is not None else (lambda cols: None)
+            sel = lambda cols, a: None                                                               # noqa: E731
+        scatter = getattr(m, "scatter_outputs", False)
         logits = torch.empty(pl.ncols, C, dtype=torch.float32, device=self.device)
         feats = torch.empty(pl.ncols, D, dtype=torch.float32, device=self.device)
         if _vit.MIXED_FWD and m.supports_mixed(pl.ncols):
@@ -201,7 +212,7 @@ class SRConsistencyBase(AlgorithmBase):
                 pl.mixed_img = torch.cat((pl.grad_img, pl.inf_img)).contiguous()
             nr_ = pl.rest_cols.numel()
             side_ = self._side_stream if (self.overlap_grad_rows and nr_) else None
-            dp_mixed, dp_rest_ = sel(pl.mixed_cols), (sel(pl.rest_cols) if nr_ else None)
+            dp_mixed, dp_rest_ = sel(pl.mixed_cols, 0), (sel(pl.rest_cols, ng_ + ni_) if nr_ else None)
             if side_ is not None:                     # the unread rows: second stream, from the start of the step (see below)
                 ready_ = torch.cuda.Event()
                 ready_.record(torch.cuda.current_stream())
@@ -233,21 +244,25 @@ class SRConsistencyBase(AlgorithmBase):
         # the side stream (rocprof timeline: a 1.28 ms hole).
         main = torch.cuda.current_stream()
         side = self._side_stream if self.overlap_grad_rows else None
-        dp_grad = sel(pl.grad_cols)
+        dp_grad = sel(pl.grad_cols, 0)
         ni, nr = pl.inf_cols.numel(), pl.rest_cols.numel()
         step = self.infer_chunk if self.infer_chunk > 0 else max(ni, 1)
-        chunks = [(pl.inf_cols[s:s + step], pl.inf_img[s:s + step].contiguous()) for s in range(0, ni, step)]
+        chunks = [(pl.inf_cols[s:s + step], pl.inf_img[s:s + step].contiguous(), ng_ + s) for s in range(0, ni, step)]
         if side is None and nr:
-            chunks.append((pl.rest_cols, pl.rest_img))
-        dps = [sel(cols) for cols, _ in chunks]
-        dp_rest = sel(pl.rest_cols) if (side is not None and nr) else None
+            chunks.append((pl.rest_cols, pl.rest_img, ng_ + ni))
+        dps = [sel(cols, a) for cols, _, a in chunks]
+        dp_rest = sel(pl.rest_cols, ng_ + ni) if (side is not None and nr) else None
+        chunks = [(cols, imgi) for cols, imgi, _ in chunks]
         if side is not None:
             ready = torch.cuda.Event()
             ready.record(main)                       # parameters, images, DropPath draws are final here
         for (cols, imgi), dpi in zip(chunks, dps):
-            lg, ft, _ = m.forward_features(imgs, imgi, dpi, save=False)
-            logits.index_copy_(0, cols, lg)
-            feats.index_copy_(0, cols, ft)
+            if scatter:                  # the head writes the rows of the step's tables itself
+                m.forward_features(imgs, imgi, dpi, save=False, out=(logits, feats, cols))
+            else:
+                lg, ft, _ = m.forward_features(imgs, imgi, dpi, save=False)
+                logits.index_copy_(0, cols, lg)
+                feats.index_copy_(0, cols, ft)
         if side is not None:
             side.wait_event(ready)
             # tensors allocated on the main stream that the second stream keeps reading after this function returns: tell the caching
@@ -257,7 +272,8 @@ class SRConsistencyBase(AlgorithmBase):
                 if torch.is_tensor(t_):
                     t_.record_stream(side)
             with torch.cuda.stream(side), ops.stream_scope():
-                lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
+                lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True,
+                                                     **(dict(out=(logits, feats, pl.grad_cols)) if scatter else {}))
                 grad_done = torch.cuda.Event()
                 grad_done.record(side)
             rs = self._rest_stream if self._rest_stream is not None else side
@@ -272,14 +288,20 @@ class SRConsistencyBase(AlgorithmBase):
                     # Rows whose outputs nothing reads before the step ends (strong / labelled rows of the passes whose loss the
                     # reference discards): 60 % of the forward work, off the critical path.  The masks, losses and the latency-bound
                     # backward of the 16 gradient images (small launches that leave most CUs idle) run on the main stream meanwhile.
-                    lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest, save=False, buftag="r")
-                    logits.index_copy_(0, pl.rest_cols, lg_r)
-                    feats.index_copy_(0, pl.rest_cols, ft_r)
+                    if scatter:
+                        m.forward_features(imgs, pl.rest_img, dp_rest, save=False, buftag="r", out=(logits, feats, pl.rest_cols))
+                    else:
+                        lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest, save=False, buftag="r")
+                        logits.index_copy_(0, pl.rest_cols, lg_r)
+                        feats.index_copy_(0, pl.rest_cols, ft_r)
                     self._rest_done = torch.cuda.Event()
                     self._rest_done.record(rs)
             # The gradient rows are joined LATER (_join_grad): masks, pseudo labels and reward scores only read the weak rows of the launch
             # above, so that chain (~0.3 ms of tiny sequential launches) runs while the second stream still works on the gradient rows.
-            self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, pl.grad_cols)
+            self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, None if scatter else pl.grad_cols)
+            return logits, feats, ctx
+        if scatter:
+            _, _, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True, out=(logits, feats, pl.grad_cols))
             return logits, feats, ctx
         lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True)
         logits.index_copy_(0, pl.grad_cols, lg_g)
@@ -293,6 +315,8 @@ class SRConsistencyBase(AlgorithmBase):
             self._grad_pending = None
             main = torch.cuda.current_stream()
             main.wait_event(grad_done)
+            if cols is None:              # the gradient rows' head wrote the step's tables itself
+                return
             lg_g.record_stream(main)
             ft_g.record_stream(main)
             logits.index_copy_(0, cols, lg_g)
@@ -338,6 +362,7 @@ class SRConsistencyBase(AlgorithmBase):
 
     fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient
     masks_read_labelled_rows = False      # SoftMatch with the 'model' alignment target: the masks need the labelled logits of pass 0
+    masks_need_weak_logits = True         # the thresholding hook reads the weak logits themselves (FreeMatch, SoftMatch), not only max / argmax
 
     def _tokens(self, x):
         from ..nets.bert import TokenBatch
@@ -399,10 +424,17 @@ class SRConsistencyBase(AlgorithmBase):
         ph("forward_joined")
         P, C = K + 1, self.num_classes
         # softmax + max/argmax of the weak logits of ALL passes: one launch (compute_prob :135, argmax :142-146)
-        Lw = L[:, nl:nl + nu].reshape(P * nu, C)
+        # (the weak rows of pass p are rows p * Bt + nl .. + nu of the logits table: read in place; only the thresholding hooks that want the
+        # logits themselves -- FreeMatch, SoftMatch -- get a gathered copy)
+        Bt = L.shape[1]
         mp = torch.empty(P * nu, dtype=torch.float32, device=self.device)
         mi = torch.empty(P * nu, dtype=torch.int64, device=self.device)
-        ops.row_max(Lw, False, None, mp, mi, P * nu, C)
+        if self.masks_need_weak_logits:
+            Lw = L[:, nl:nl + nu].reshape(P * nu, C)
+            ops.row_max(Lw, False, None, mp, mi, P * nu, C)
+        else:
+            Lw = None
+            ops.row_max_strided(L, nl, False, None, mp, mi, P * nu, C, nu, Bt)
         self._lb_logits0 = L[0, :nl]                       # SoftMatch's 'model' alignment target reads the labelled rows of pass 0
         if self.masks_read_labelled_rows:
             self._join_grad()
@@ -410,19 +442,26 @@ class SRConsistencyBase(AlgorithmBase):
         pl0 = mi[:nu]
         if K > 0:
             self.rewarder.eval()                                                                  # :74
-            fw = Fe[1:, nl:nl + nu].reshape(K * nu, -1)
-            reward = self.rewarder.score(fw, mi[nu:], groups=K)                                    # :99
+            # the weak rows of passes 1 .. K, scored where they are in the feature table (group g = rows (g + 1) * Bt + nl .. + nu)
+            reward = self.rewarder.score_in_place(Fe, Bt + nl, Bt, nu, mi[nu:], groups=K)          # :99
             mask2 = torch.empty_like(reward)
             mean_in = self.dp.reward_means(reward, K).contiguous() if (self.dp.global_reward_threshold and self.dp.active) else None
             ops.reward_mask2(reward, mask2, None, K, nu, mean_in=mean_in)                          # :100-101
         self._join_grad()                                  # from here on the labelled / strong rows of the loss are read
-        sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean")                          # :132
+        # the upstream gradient of the gradient rows (labelled rows of pass 0 | strong rows of the last pass) is ONE buffer the two loss
+        # launches fill (the fairness rows of FreeMatch with K > 0 sit between them: that case still concatenates)
+        n_strong = L.shape[1] - nl - nu
+        two_blocks = not (self.fairness_rows and K > 0)
+        dl_buf = torch.empty(nl + n_strong, C, dtype=torch.float32, device=self.device) if two_blocks else None
+        sup_loss, dl_lb = self.ce_loss(L[0, :nl], y_lb, reduction="mean", dl_out=dl_buf[:nl] if two_blocks else None)          # :132
         if K > 0:
             plK, mK, m2K = mi[K * nu:], masks[K], mask2[(K - 1) * nu:]
-            unsup_loss, dl_s = self.consistency_loss(L[K, nl + nu:], plK, "ce", mask=mK, mask2=m2K, grad_scale=self.lambda_u)   # :102
+            unsup_loss, dl_s = self.consistency_loss(L[K, nl + nu:], plK, "ce", mask=mK, mask2=m2K, grad_scale=self.lambda_u,
+                                                     dl_out=dl_buf[nl:] if two_blocks else None)                                # :102
         else:
             reward = mask2 = None
-            unsup_loss, dl_s = self.consistency_loss(L[0, nl + nu:], pl0, "ce", mask=masks[0], grad_scale=self.lambda_u)        # :152
+            unsup_loss, dl_s = self.consistency_loss(L[0, nl + nu:], pl0, "ce", mask=masks[0], grad_scale=self.lambda_u,
+                                                     dl_out=dl_buf[nl:] if two_blocks else None)                                # :152
         # optional fairness term on the pass-0 strong rows (FreeMatch): same rows as dl_s when K == 0, extra grad rows otherwise
         if K > 0:
             ent_loss, dl_e = self._fairness(L[0, nl + nu:], masks[0], None)
@@ -432,7 +471,7 @@ class SRConsistencyBase(AlgorithmBase):
             dl_all = (dl_lb, dl_s)
         # ---- backbone backward: only the rows with a non-zero upstream gradient (see module docstring)
         ph("losses")
-        self.model.backward(ctx, torch.cat(dl_all))
+        self.model.backward(ctx, dl_buf if (two_blocks and len(dl_all) == 2) else torch.cat(dl_all))
         ph("backward")
         # ---- rewarder / generator training (:154-208)
         fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
@@ -447,7 +486,7 @@ class SRConsistencyBase(AlgorithmBase):
             else:
                 gen = self.generator.forward_with_labels(fx.contiguous())[1]                      # :158-159
                 self._sr_update(fx, gen, y_lb)                                                    # :194-208
-        total_loss = sup_loss + self.lambda_u * unsup_loss                                        # :210
+        total_loss = torch.add(sup_loss, unsup_loss, alpha=self.lambda_u)                         # :210 (one launch)
         if ent_loss is not None:
             total_loss = total_loss + self.lambda_e * ent_loss                                    # srfreematch.py:220
         if self.trace is not None:
@@ -458,7 +497,7 @@ class SRConsistencyBase(AlgorithmBase):
         feat_dict = {"x_lb": fx, "x_ulb_w": fw0, "x_ulb_s": Fe[0, nl + nu:]}
         out_dict = self.process_out_dict(loss=total_loss, feat=feat_dict)
         log_dict = self.process_log_dict(sup_loss=DeferredScalar(sup_loss), unsup_loss=DeferredScalar(unsup_loss),
-                                         total_loss=DeferredScalar(total_loss), util_ratio=DeferredScalar(masks[0].mean()))
+                                         total_loss=DeferredScalar(total_loss), util_ratio=DeferredScalar(lambda m=masks[0]: m.mean()))
         return out_dict, log_dict
 
     def _sr_save(self, d):
@@ -484,6 +523,8 @@ class SRConsistencyBase(AlgorithmBase):
 @ALGORITHMS.register("srflexmatch")
 class SRFlexMatch(SRConsistencyBase):
     """semilearn/algorithms/srflexmatch/srflexmatch.py:15-246."""
+
+    masks_need_weak_logits = False        # FlexMatch thresholds on (max prob, argmax) only
 
     def _init_thresholds(self, args):
         self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label, thresh_warmup=args.thresh_warmup)
@@ -532,6 +573,8 @@ class SRFlexMatch(SRConsistencyBase):
 class SRFixMatch(SRConsistencyBase):
     """semilearn/algorithms/srfixmatch/fixmatch.py:13-225: FixMatch + SemiReward.  Same step as SRFlexMatch with the
     stateless FixedThresholdingHook (masking.py:42-57) -> the masks of all passes come from ONE launch."""
+
+    masks_need_weak_logits = False        # a fixed threshold on the max probability
 
     def _init_thresholds(self, args):
         self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label)

@@ -25,7 +25,8 @@ from .hooks import EMAHook, Hook, ParamUpdateHook, TimerHook, get_priority
 class DeferredScalar:
     """A device scalar that becomes a python float on first use (float(), format, comparison).  The reference calls
     .item() four times per step (srflexmatch.py:213-216): four host syncs.  LoggingHook only reads them every
-    num_log_iter steps, so the sync is deferred to that moment."""
+    num_log_iter steps, so the sync is deferred to that moment.  ``t`` may also be a callable returning the device scalar: then even
+    the reduction that produces it (util_ratio = mask.mean(), :216) is only launched when somebody reads the value."""
     __slots__ = ("_t", "_v")
 
     def __init__(self, t):
@@ -33,7 +34,8 @@ class DeferredScalar:
 
     def __float__(self):
         if self._v is None:
-            self._v = float(self._t.item())
+            t = self._t() if callable(self._t) else self._t
+            self._v = float(t.item())
             self._t = None
         return self._v
 

@@ -151,20 +151,21 @@ __device__ int srhip_label_err;
 // Kernel 1: a tile of 8 feature rows AND the matching 8 label rows of one group.
 // feature_fc (F->128) through tile_linear, then one wave per 2 rows for the two LayerNorms and the attention logit.
 // grid = (ceil(B/8), G), block 256, dyn LDS = (F*8 + 128*8 + 256*8) floats.
-__global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict__ P, const float* __restrict__ PT,
-                                                       const float* __restrict__ feats, const long long* __restrict__ labels,
-                                                       float* __restrict__ ws, int G, int B, int F, int L, int save) {
+// feat_gs: elements between the first feature rows of consecutive groups (B * F when the groups are stacked densely; the weak-row block of every
+// pass inside the step's [passes, batch, F] feature buffer otherwise -- read in place instead of from a gathered copy)
+__device__ __forceinline__ void rew_embed_body(const float* __restrict__ P, const float* __restrict__ PT,
+                                               const float* __restrict__ feats, const long long* __restrict__ labels,
+                                               float* __restrict__ ws, int G, int B, int F, int L, int save, long long feat_gs, float* sm) {
   const RewOff o(F, L);
   const RewTOff ot(F);
   const RewWs w(G, B);
-  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* xT = sm;                  // [F][8]
   float* hT = xT + F * RT;         // [128][8]
   float* scratch = hT + E * RT;    // [256*8]
   const int grp = blockIdx.y, r0 = blockIdx.x * RT;
   for (int e = threadIdx.x; e < F * RT; e += 256) {
     const int r = e / F, k = e % F;
-    xT[k * RT + r] = (r0 + r < B) ? feats[((size_t)grp * B + r0 + r) * F + k] : 0.f;
+    xT[k * RT + r] = (r0 + r < B) ? feats[(size_t)grp * feat_gs + (size_t)(r0 + r) * F + k] : 0.f;
   }
   __syncthreads();
   tile_linear<E, 0>(PT + ot.WfT, P + o.bf, xT, hT, scratch, F);
@@ -199,18 +200,30 @@ __global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                       const float* __restrict__ feats, const long long* __restrict__ labels,
+                                                       float* __restrict__ ws, int G, int B, int F, int L, int save, long long feat_gs) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  rew_embed_body(P, PT, feats, labels, ws, G, B, F, L, save, feat_gs, sm);
+}
+
 // Kernel 2: softmax over the group's 2B logits, context vector, then the MLP/FFN head for a tile of 8 rows.
 // grid = (ceil(B/8), G), block 256.  Every workgroup re-derives the group context (2B x 128 reads) instead of
 // paying a third launch.
-__global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict__ P, const float* __restrict__ PT,
-                                                       float* __restrict__ ws, float* __restrict__ reward,
-                                                       int G, int B, int F, int L, int save) {
+constexpr int SCORE_LDS_FLOATS = E + 8 + E * RT + 256 * RT + E * RT + 64 * RT + 256 * RT;
+__device__ __forceinline__ void rew_score_body(const float* __restrict__ P, const float* __restrict__ PT,
+                                               float* __restrict__ ws, float* __restrict__ reward,
+                                               int G, int B, int F, int L, int save, float* lds) {
   const RewOff o(F, L);
   const RewTOff ot(F);
   const RewWs w(G, B);
-  __shared__ float ctx[E];
-  __shared__ float red[8];
-  __shared__ __attribute__((aligned(16))) float uT[E * RT], m1T[256 * RT], m2T[E * RT], f1T[64 * RT], scratch[256 * RT];
+  float* uT = lds;                 // 16-byte aligned tiles first
+  float* m1T = uT + E * RT;
+  float* m2T = m1T + 256 * RT;
+  float* f1T = m2T + E * RT;
+  float* scratch = f1T + 64 * RT;
+  float* ctx = scratch + 256 * RT;
+  float* red = ctx + E;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = blockIdx.y, r0 = blockIdx.x * RT;
   const float* sl = ws + w.slog + (size_t)grp * 2 * B;
   const float* z = ws + w.z + (size_t)grp * 2 * B * E;
@@ -266,6 +279,27 @@ __global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict_
       if (lane == 0) ws[w.r + gr] = rr;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                       float* __restrict__ ws, float* __restrict__ reward,
+                                                       int G, int B, int F, int L, int save) {
+  __shared__ __attribute__((aligned(16))) float lds[SCORE_LDS_FLOATS];
+  rew_score_body(P, PT, ws, reward, G, B, F, L, save, lds);
+}
+
+// Both kernels as ONE launch when a group is a single row tile (B <= 8: the reference batch, uratio 1 with 8 unlabeled images per pass):
+// the only cross-workgroup dependency -- the batch softmax over the group's 2B attention logits (semireward.py:60-62) -- is then inside the
+// workgroup, and the rows' z / logit vectors travel through the workspace between two workgroup barriers instead of between two launches.
+__global__ __launch_bounds__(256) void rew_fused_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                       const float* __restrict__ feats, const long long* __restrict__ labels,
+                                                       float* __restrict__ ws, float* __restrict__ reward, int G, int B, int F, int L,
+                                                       int save, long long feat_gs) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // max(embed tiles, score tiles)
+  rew_embed_body(P, PT, feats, labels, ws, G, B, F, L, save, feat_gs, sm);
+  __threadfence_block();
+  __syncthreads();                 // the workspace rows of this group (z, logits) are visible to the whole workgroup
+  rew_score_body(P, PT, ws, reward, G, B, F, L, save, sm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,10 +537,25 @@ extern "C" int srhip_generator_prepare(const float* params, float* params_t, int
 
 extern "C" int srhip_rewarder_fwd(const float* params, const float* params_t, const float* feats, const long long* labels,
                                   float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream) {
+  return srhip_rewarder_fwd_strided(params, params_t, feats, (long long)B * F, labels, reward, ws, G, B, F, L, save_for_bwd, stream);
+}
+extern "C" int srhip_rewarder_fwd_strided(const float* params, const float* params_t, const float* feats, long long feat_group_stride,
+                                          const long long* labels, float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd,
+                                          void* stream) {
   if (G <= 0 || B <= 0 || F <= 0 || F > 1024 || L <= 0 || (save_for_bwd && G != 1) || !params_t) return SR_EINVAL;
+  if (feat_group_stride < (long long)B * F) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t sm1 = ((size_t)F * RT + E * RT + 256 * RT) * sizeof(float);
-  hipLaunchKernelGGL(rew_embed_kernel, dim3(cdiv(B, RT), G), dim3(256), sm1, s, params, params_t, feats, labels, ws, G, B, F, L, save_for_bwd);
+  static const bool two = getenv("SRHIP_REWARDER_TWO_LAUNCHES") != nullptr;
+  if (B <= RT && !two) {
+    const size_t smf = sm1 > SCORE_LDS_FLOATS * sizeof(float) ? sm1 : SCORE_LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL(rew_fused_kernel, dim3(1, G), dim3(256), smf, s, params, params_t, feats, labels, ws, reward, G, B, F, L, save_for_bwd,
+                       feat_group_stride);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  }
+  hipLaunchKernelGGL(rew_embed_kernel, dim3(cdiv(B, RT), G), dim3(256), sm1, s, params, params_t, feats, labels, ws, G, B, F, L, save_for_bwd,
+                     feat_group_stride);
   SR_CHECK_LAUNCH();
   hipLaunchKernelGGL(rew_score_kernel, dim3(cdiv(B, RT), G), dim3(256), 0, s, params, params_t, ws, reward, G, B, F, L, save_for_bwd);
   SR_CHECK_LAUNCH();

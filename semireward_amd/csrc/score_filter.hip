@@ -37,10 +37,14 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 
 // One wave per row.  in_is_probs = 0: logits -> softmax (fp32) ; 1: rows are already probabilities.
 __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ in, int in_is_probs, float* __restrict__ probs_out,
-                                                     float* __restrict__ max_probs, long long* __restrict__ max_idx, int B, int C) {
+                                                     float* __restrict__ max_probs, long long* __restrict__ max_idx, int B, int C,
+                                                     int rows_per_group, long long group_stride) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B) return;
-  const float* r = in + (size_t)row * C;
+  // rows_per_group > 0: input row r lives at in + (r / rows_per_group) * group_stride + (r % rows_per_group) * C (a column block of a
+  // [groups, rows, C] buffer: the weak rows of every pass, read in place); outputs are dense
+  const float* r = rows_per_group > 0 ? in + (size_t)(row / rows_per_group) * group_stride + (size_t)(row % rows_per_group) * C
+                                      : in + (size_t)row * C;
   float inv = 1.0f, mx = 0.f;
   if (!in_is_probs) {
     mx = -INFINITY;
@@ -482,7 +486,16 @@ __global__ __launch_bounds__(256) void freematch_entropy_kernel(const float* __r
 extern "C" int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B,
                              int C, void* stream) {
   if (B <= 0 || C <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C);
+  hipLaunchKernelGGL(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C, 0,
+                     0LL);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_row_max_strided(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B, int C,
+                                     int rows_per_group, long long group_stride, void* stream) {
+  if (B <= 0 || C <= 0 || rows_per_group <= 0 || group_stride < (long long)rows_per_group * C) return SR_EINVAL;
+  hipLaunchKernelGGL(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C,
+                     rows_per_group, group_stride);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

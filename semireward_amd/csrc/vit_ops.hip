@@ -325,10 +325,14 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const float* __restri
                                                           const float* __restrict__ Wh, const float* __restrict__ bh,
                                                           float* __restrict__ feat, float* __restrict__ logits,
                                                           float* __restrict__ xhat, float* __restrict__ rstd,
-                                                          int N, int D, int C) {
+                                                          float* __restrict__ feat_all, float* __restrict__ logits_all,
+                                                          const long long* __restrict__ out_rows, int N, int D, int C) {
   extern __shared__ float f[];        // [D] + 4
   float* sh = f + D;
   const int b = blockIdx.x;
+  // feat / logits [B, .] (may be NULL) are the launch's own dense outputs (the backward reads feat); feat_all / logits_all are the step's
+  // [all (pass, image) rows, .] buffers, where image b of this launch is row out_rows[b]: written here instead of by an index_copy_ each
+  const size_t ob = out_rows ? (size_t)out_rows[b] : (size_t)b;
   const float* xr = x + (size_t)b * N * D;     // token 0 of image b
   // the cls row stays in registers (D <= 1024: at most 4 values per thread): ONE global round trip instead of three dependent passes
   float xv[4], gv[4], bv[4];
@@ -356,7 +360,8 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const float* __restri
       const float xh = (xv[i] - mu) * rs, v = xh * gv[i] + bv[i];
       f[d] = v;
       if (first) {
-        feat[(size_t)b * D + d] = v;
+        if (feat) feat[(size_t)b * D + d] = v;
+        if (feat_all) feat_all[ob * D + d] = v;
         if (xhat) xhat[(size_t)b * D + d] = xh;
       }
     }
@@ -373,8 +378,14 @@ __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const float* __restri
     for (int d = lane; d < D; d += 64) { const float fv = f[d]; a += fv * w[d]; a2 += fv * w2[d]; }
     a = wave_sum(a); a2 = wave_sum(a2);
     if (lane == 0) {
-      logits[(size_t)b * C + c] = a + bh[c];
-      if (c2 < C) logits[(size_t)b * C + c2] = a2 + bh[c2];
+      if (logits) {
+        logits[(size_t)b * C + c] = a + bh[c];
+        if (c2 < C) logits[(size_t)b * C + c2] = a2 + bh[c2];
+      }
+      if (logits_all) {
+        logits_all[ob * C + c] = a + bh[c];
+        if (c2 < C) logits_all[ob * C + c2] = a2 + bh[c2];
+      }
     }
   }
 }
@@ -501,10 +512,15 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __rest
 }
 
 // DropPath per-sample scales: out[l, j, b] = Bernoulli(1 - p_l) / (1 - p_l), counter-based hash RNG.
+// cols != NULL: out is [depth, 2, n] and column q of it is column cols[q] of the [depth, 2, B] table (any selection / order of the columns of ONE
+// draw, produced directly: the step's launch trains each take a contiguous slice instead of an index_select each)
 __global__ void droppath_fill_kernel(float* __restrict__ out, const float* __restrict__ probs, int depth, int B,
-                                     unsigned long long seed) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= depth * 2 * B) return;
+                                     unsigned long long seed, const long long* __restrict__ cols, int n) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= depth * 2 * n) return;
+  long long col = o % n;
+  if (cols) { col = cols[col]; if (col < 0 || col >= B) col = 0; }
+  const int i = (o / n) * B + (int)col;
   const float p = probs[i / (2 * B)];
   unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -512,7 +528,7 @@ __global__ void droppath_fill_kernel(float* __restrict__ out, const float* __res
   z ^= z >> 31;
   const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
   const float keep = 1.0f - p;
-  out[i] = (p <= 0.f) ? 1.0f : (u < keep ? 1.0f / keep : 0.0f);
+  out[o] = (p <= 0.f) ? 1.0f : (u < keep ? 1.0f / keep : 0.0f);
 }
 
 }  // namespace
@@ -672,9 +688,16 @@ extern "C" int srhip_patch_embed_bwd_ws(const float* dx, const float* img, const
 extern "C" int srhip_cls_head_fwd(const float* x, const float* gamma, const float* beta, float eps, const float* Wh,
                                   const float* bh, float* feat, float* logits, float* xhat, float* rstd, int B, int N, int D,
                                   int C, void* stream) {
+  return srhip_cls_head_fwd_scatter(x, gamma, beta, eps, Wh, bh, feat, logits, xhat, rstd, nullptr, nullptr, nullptr, B, N, D, C, stream);
+}
+extern "C" int srhip_cls_head_fwd_scatter(const float* x, const float* gamma, const float* beta, float eps, const float* Wh, const float* bh,
+                                          float* feat, float* logits, float* xhat, float* rstd, float* feat_all, float* logits_all,
+                                          const long long* out_rows, int B, int N, int D, int C, void* stream) {
   if (B <= 0 || D > 1024 || C <= 0) return SR_EINVAL;
+  if ((!feat || !logits) && (!feat_all || !logits_all)) return SR_EINVAL;       // some complete (feat, logits) destination
+  if ((feat_all || logits_all) && !out_rows) return SR_EINVAL;
   hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(B, C >= 32 ? 4 : 1), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream, x, gamma, beta, eps,
-                     Wh, bh, feat, logits, xhat, rstd, N, D, C);
+                     Wh, bh, feat, logits, xhat, rstd, feat_all, logits_all, out_rows, N, D, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -728,7 +751,16 @@ extern "C" int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stre
 
 extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream) {
   if (depth <= 0 || B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed);
+  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
+                     (const long long*)nullptr, B);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_droppath_fill_cols(float* out, const float* probs, const long long* cols, int depth, int B, int n_cols,
+                                        unsigned long long seed, void* stream) {
+  if (depth <= 0 || B <= 0 || n_cols <= 0 || !cols) return SR_EINVAL;
+  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
+                     cols, n_cols);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -85,6 +85,8 @@ class FwdContext:
 class VisionTransformer:
     GEMM_WEIGHTS = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
     rows_independent = True       # LayerNorm only: a row's outputs do not depend on which other rows share the launch
+    scatter_outputs = True        # forward_features(out=...) writes logits / features at the caller's row numbers (no index_copy_)
+    droppath_by_cols = True       # make_droppath(cols=...) lays the DropPath table out in the caller's column order (no index_select)
 
     def __init__(self, cfg=None, device="cuda", **kw):
         self.cfg = cfg if cfg is not None else VitConfig(**kw)
@@ -193,11 +195,12 @@ class VisionTransformer:
             self._ws[key] = t
         return t
 
-    def make_droppath(self, B):
-        """timm DropPath scales [depth, 2, B] for one forward (vit.py:148,161)."""
-        dp = torch.empty(self.cfg.depth, 2, B, dtype=torch.float32, device=self.device)
+    def make_droppath(self, B, cols=None):
+        """timm DropPath scales [depth, 2, B] for one forward (vit.py:148,161); cols (int64 device tensor): only those columns of the draw, in
+        that order ([depth, 2, len(cols)])."""
+        dp = torch.empty(self.cfg.depth, 2, B if cols is None else cols.numel(), dtype=torch.float32, device=self.device)
         self._rng_calls += 1
-        ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, (self.seed << 32) + self._rng_calls)
+        ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, (self.seed << 32) + self._rng_calls, cols=cols)
         return dp
 
     def _ctx_buffers(self, B):
@@ -223,7 +226,7 @@ class VisionTransformer:
         return ctx
 
     # ---- forward ----------------------------------------------------------------------------------
-    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None, buftag=""):
+    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None, buftag="", out=None):
         """img fp32 [n_img, C, H, W]; img_index int32 [B] (optional gather); droppath fp32 [depth,2,B] or None.
         Returns (logits [B,C], feat [B,D], ctx or None)."""
         cfg = self.cfg
@@ -314,6 +317,17 @@ class VisionTransformer:
                     ops.gemm_nt(ops.EPI_GELU_BF16, ln, P(b + "mlp.fc1.weight", wb), hbuf, M, Hd, D, bias=P(b + "mlp.fc1.bias"))
                     ops.gemm_nt(ops.EPI_RESID_F32, hbuf, P(b + "mlp.fc2.weight", wb), x, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
                                 row_scale=s2, rows_per_sample=N)
+        if out is not None:
+            # out = (logits_all, feats_all, rows): the head writes image b's outputs to row rows[b] of the caller's buffers (the step's
+            # [(pass, image), .] tables) -- no index_copy_ launches behind this forward; the dense feat is only kept for a backward
+            logits_all, feats_all, rows = out
+            feat = torch.empty(B, D, dtype=f32, device=self.device) if save else None
+            logits = torch.empty(B, C, dtype=f32, device=self.device) if save else None
+            if save:
+                ctx.feat = feat
+            ops.cls_head_fwd_scatter(x, P("norm.weight"), P("norm.bias"), cfg.eps, P("head.weight"), P("head.bias"), feat, logits,
+                                     ctx.xhat if save else None, ctx.rstd if save else None, feats_all, logits_all, rows, B, N, D, C)
+            return logits, feat, ctx
         feat = torch.empty(B, D, dtype=f32, device=self.device)
         logits = torch.empty(B, C, dtype=f32, device=self.device)
         if save:

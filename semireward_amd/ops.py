@@ -341,6 +341,12 @@ def patch_grad_operands(dx, dx_tok, dpos, dcls, B, Np, D):
     _call("srhip_patch_grad_operands", _p(dx), _p(dx_tok), _p(dpos), _p(dcls), B, Np, D, _s())
 
 
+def cls_head_fwd_scatter(x, gamma, beta, eps, Wh, bh, feat, logits, xhat, rstd, feat_all, logits_all, out_rows, B, N, D, C):
+    """cls_head_fwd that also (or only: feat / logits None) writes image b's outputs to row out_rows[b] of feat_all / logits_all."""
+    _call("srhip_cls_head_fwd_scatter", _p(x), _p(gamma), _p(beta), eps, _p(Wh), _p(bh), _p(feat), _p(logits), _p(xhat), _p(rstd), _p(feat_all),
+          _p(logits_all), _p(out_rows), B, N, D, C, _s())
+
+
 def cls_head_fwd(x, gamma, beta, eps, Wh, bh, feat, logits, xhat, rstd, B, N, D, C):
     _call("srhip_cls_head_fwd", _p(x), _p(gamma), _p(beta), eps, _p(Wh), _p(bh), _p(feat), _p(logits), _p(xhat), _p(rstd),
           B, N, D, C, _s())
@@ -384,13 +390,24 @@ def cast_f32_bf16(x, out, n):
     _call("srhip_cast_f32_bf16", _p(x), _p(out), n, _s())
 
 
-def droppath_fill(out, probs, depth, B, seed):
-    _call("srhip_droppath_fill", _p(out), _p(probs), depth, B, seed, _s())
+def droppath_fill(out, probs, depth, B, seed, cols=None):
+    """out [depth, 2, B] (cols None) or [depth, 2, len(cols)]: the columns cols of the same [depth, 2, B] draw, in that order."""
+    if cols is None:
+        _call("srhip_droppath_fill", _p(out), _p(probs), depth, B, seed, _s())
+    else:
+        _call("srhip_droppath_fill_cols", _p(out), _p(probs), _p(cols), depth, B, cols.numel(), seed, _s())
 
 
 # ---- score filter -----------------------------------------------------------------------------
 def row_max(inp, in_is_probs, probs_out, max_probs, max_idx, B, C):
     _call("srhip_row_max", _p(inp), int(in_is_probs), _p(probs_out), _p(max_probs), _p(max_idx), B, C, _s())
+
+
+def row_max_strided(base, first_row, in_is_probs, probs_out, max_probs, max_idx, B, C, rows_per_group, group_rows):
+    """row_max over B rows read in place from the contiguous [*, C] buffer ``base``: row r is buffer row
+    first_row + (r // rows_per_group) * group_rows + r % rows_per_group."""
+    _call("srhip_row_max_strided", _pa(base, first_row * C), int(in_is_probs), _p(probs_out), _p(max_probs), _p(max_idx), B, C, rows_per_group,
+          group_rows * C, _s())
 
 
 def flexmatch_mask(max_probs, max_idx, idx_ulb, p_cutoff, selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len,
@@ -475,8 +492,14 @@ def generator_prepare(params, params_t, F):
     _call("srhip_generator_prepare", _p(params), _p(params_t), F, _s())
 
 
-def rewarder_fwd(params, params_t, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False):
-    _call("srhip_rewarder_fwd", _p(params), _p(params_t), _p(feats), _p(labels), _p(reward), _p(ws), G, B, F, L, int(save_for_bwd), _s())
+def rewarder_fwd(params, params_t, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False, feats_first_row=0, group_rows=None):
+    """feats [G * B, F] dense, or (group_rows given) a contiguous [*, F] buffer in which group g's B rows start at row
+    feats_first_row + g * group_rows."""
+    if group_rows is None:
+        _call("srhip_rewarder_fwd", _p(params), _p(params_t), _p(feats), _p(labels), _p(reward), _p(ws), G, B, F, L, int(save_for_bwd), _s())
+    else:
+        _call("srhip_rewarder_fwd_strided", _p(params), _p(params_t), _pa(feats, feats_first_row * F), group_rows * F, _p(labels), _p(reward),
+              _p(ws), G, B, F, L, int(save_for_bwd), _s())
 
 
 def rewarder_bwd(params, feats, labels, target, ws, grads, losses, B, F, L):

@@ -337,6 +337,21 @@ def test_patch_embed_and_head(cfgd):
     f = torch.nn.functional.layer_norm(xc[:, 0], (D,), Pc["norm.weight"], Pc["norm.bias"], 1e-6)
     lg = f @ Pc["head.weight"].t() + Pc["head.bias"]
     assert relerr(feat, f) < 1e-6 and relerr(logits, lg) < 1e-6
+    # the scattering form: image b's outputs at row rows[b] of larger tables, with and without the dense copies
+    rows = torch.tensor([(7 * b + 3) % (2 * B + 5) for b in range(B)], dtype=torch.int64, device=DEV)
+    assert len(set(rows.tolist())) == B
+    fa, la = torch.full((2 * B + 5, D), 5.0, device=DEV), torch.full((2 * B + 5, C), 5.0, device=DEV)
+    f2, l2 = torch.empty_like(feat), torch.empty_like(logits)
+    ops.cls_head_fwd_scatter(x, P["norm.weight"], P["norm.bias"], 1e-6, P["head.weight"], P["head.bias"], f2, l2, None, None, fa, la, rows,
+                             B, N, D, C)
+    assert torch.equal(f2, feat) and torch.equal(l2, logits) and torch.equal(fa[rows], feat) and torch.equal(la[rows], logits)
+    untouched = torch.ones(2 * B + 5, dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    assert bool((fa[untouched] == 5.0).all()) and bool((la[untouched] == 5.0).all())
+    fb_, lb_ = torch.zeros_like(fa), torch.zeros_like(la)
+    ops.cls_head_fwd_scatter(x, P["norm.weight"], P["norm.bias"], 1e-6, P["head.weight"], P["head.bias"], None, None, None, None, fb_, lb_,
+                             rows, B, N, D, C)
+    assert torch.equal(fb_[rows], feat) and torch.equal(lb_[rows], logits)
     dl = rnd(B, C, seed=17)
     lg.backward(dl.double().cpu())
     dxh = torch.zeros(B, N, D, device=DEV)
@@ -373,6 +388,11 @@ def test_glue_kernels():
     probs = torch.tensor(V.drop_path_probs(V.VitCfg(**V.VIT_SMALL_P2_32)), device=DEV)
     dp = torch.empty(12, 2, 4096, device=DEV)
     ops.droppath_fill(dp, probs, 12, 4096, 1234)
+    # any selection / order of the columns of the same draw in one launch (the step's launch trains take slices of it)
+    cols = torch.tensor([4095, 0, 17, 17, 2048, 1], dtype=torch.int64, device=DEV)
+    dpc = torch.empty(12, 2, cols.numel(), device=DEV)
+    ops.droppath_fill(dpc, probs, 12, 4096, 1234, cols=cols)
+    assert torch.equal(dpc, dp.index_select(2, cols))
     keep = 1 - probs.cpu().numpy()
     vals = dp.cpu().numpy()
     assert np.all(vals[0] == 1.0)
@@ -412,6 +432,15 @@ def test_flexmatch_score_filter_bit_exact(golden, tag):
     lg = torch.from_numpy(g[f"{tag}/logits"][0]).to(DEV)
     po = torch.empty(Bu, C, device=DEV)
     ops.row_max(lg, False, po, mp, mi, Bu, C)
+    # rows read in place from a [groups, rows, C] table (the weak rows of every pass inside the step's logits): same bits, no gathered copy
+    if Bu % 4 == 0:
+        rpg, grows, first = Bu // 4, Bu // 4 + 3, 2
+        table = torch.full((4 * grows + first, C), -7.0, device=DEV)
+        for gi in range(4):
+            table[first + gi * grows:first + gi * grows + rpg] = lg[gi * rpg:(gi + 1) * rpg]
+        mp2, mi2 = torch.empty_like(mp), torch.empty_like(mi)
+        ops.row_max_strided(table, first, False, None, mp2, mi2, Bu, C, rpg, grows)
+        assert torch.equal(mp2, mp) and torch.equal(mi2, mi)
     ref = g[f"{tag}/probs"][0]
     assert np.array_equal(mi.cpu().numpy(), ref.argmax(-1))
     np.testing.assert_allclose(mp.cpu().numpy(), ref.max(-1), rtol=3e-7)
@@ -485,6 +514,19 @@ def test_rewarder_generator(golden, tag):
     for gi in range(G):
         ops.rewarder_fwd(rp, rpt, fe3[gi * B:(gi + 1) * B].contiguous(), lb3[gi * B:(gi + 1) * B].contiguous(), r, ws, 1, B, Fd, L)
         assert torch.equal(r, r3[gi * B:(gi + 1) * B])
+    # ... == the groups read in place from a [passes, batch, F] table (group g = rows first + g * group_rows .. + B), as the step does
+    Bt, first = B + 5, 3
+    table = torch.full((G + 1, Bt, Fd), 99.0, device=DEV)
+    for gi in range(G):
+        table[gi + 1, first:first + B] = fe3[gi * B:(gi + 1) * B]
+    r3s = torch.empty(G * B, device=DEV)
+    ops.rewarder_fwd(rp, rpt, table, lb3, r3s, ws3, G, B, Fd, L, feats_first_row=Bt + first, group_rows=Bt)
+    assert torch.equal(r3s, r3)
+    # a group of one row tile (B <= 8) runs as ONE launch, larger groups as two: same arithmetic, same bits
+    for Bs in (8, 5):
+        rs_, ws_ = torch.empty(Bs, device=DEV), torch.empty(ops.rewarder_ws_floats(1, Bs), device=DEV)
+        ops.rewarder_fwd(rp, rpt, feats[:Bs].contiguous(), labels[:Bs].contiguous(), rs_, ws_, 1, Bs, Fd, L)
+        assert bool(torch.isfinite(rs_).all()) and float(rs_.min()) > 0.0 and float(rs_.max()) < 1.0
     # generator
     go, gl = torch.empty(B, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
     ops.generator_fwd(gp, gpt, feats, go, gl, B, Fd)
