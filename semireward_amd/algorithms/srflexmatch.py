@@ -272,6 +272,8 @@ class SRConsistencyBase(AlgorithmBase):
                 if torch.is_tensor(t_):
                     t_.record_stream(side)
             with torch.cuda.stream(side), ops.stream_scope():
+                if hasattr(m, "ensure_transposed"):
+                    m.ensure_transposed()          # backward-only operands of the new parameters: here they delay nothing
                 lg_g, ft_g, ctx = m.forward_features(imgs, pl.grad_img, dp_grad, save=True,
                                                      **(dict(out=(logits, feats, pl.grad_cols)) if scatter else {}))
                 grad_done = torch.cuda.Event()

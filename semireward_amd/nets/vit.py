@@ -105,6 +105,7 @@ class VisionTransformer:
         self.grad = torch.zeros(o, dtype=torch.float32, device=self.device)
         self.flat_bf16 = torch.zeros(o, dtype=torch.bfloat16, device=self.device)
         self.wT = {}
+        self._wT_stale = True
         for i in range(cfg.depth):
             for w in self.GEMM_WEIGHTS:
                 n = "blocks.%d.%s" % (i, w)
@@ -164,8 +165,18 @@ class VisionTransformer:
         ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
         self.refresh_transposed()
 
+    lazy_transposed = os.environ.get("SR_LAZY_WT", "1") != "0"   # the optimizer only marks the transposed weight copies stale (ensure_transposed)
+
+    def ensure_transposed(self):
+        """The transposed bf16 weight copies are operands of the BACKWARD only (dX products).  After an optimizer step they are refreshed
+        where it costs nothing -- the step's second stream, before the gradient rows' forward (srflexmatch._forward_plan) -- instead of at
+        the end of the optimizer step, on the critical path (40 us per step); backward() calls this again as the safety net."""
+        if self._wT_stale:
+            self.refresh_transposed()
+
     def refresh_transposed(self):
         """W [out,in] fp32 -> W^T [in,out] bf16 for all 4*depth GEMM weights: one batched launch."""
+        self._wT_stale = False
         if self._wT_desc is None:
             items = []
             for n, t in self.wT.items():
@@ -495,6 +506,7 @@ class VisionTransformer:
         M = B * N
         f32, bf16 = torch.float32, torch.bfloat16
         P, G, wb = self.p, (lambda n: self.p(n, self.grad)), self.flat_bf16
+        self.ensure_transposed()
         dx = self._buf("b_dx", (M, D), f32)
         dx.zero_()
         ops.cls_head_bwd(dlogits, P("head.weight"), P("norm.weight"), ctx.feat, ctx.xhat, ctx.rstd, dx, G("head.weight"),

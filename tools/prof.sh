@@ -9,7 +9,7 @@ db=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/$tag/*.db")[0]
 c=sqlite3.connect(db)
 rows=list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
 with open("$GRAFT_REPO_ROOT/gpurun_out/$tag.stats.txt","w") as f:
-    for n,cl,t,a,p in rows[:40]:
+    for n,cl,t,a,p in rows[:70]:
         f.write("%-100s %6d %10.0f %9.1f %6.2f\n"%(n[:100],cl,t,a,p))
     f.write("TOTAL_US %.0f\n"%sum(r[2] for r in rows))
 cols=[r[1] for r in c.execute("pragma table_info(kernels)")]
