@@ -131,6 +131,11 @@ int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const f
  * before rounding (srhip_attn_block_fused out_scale: one rounding, as in the unfused path), 0 has it applied here (a second rounding of ao).
  * ln_next (bf16 [M, D], may be NULL): LayerNorm(x_out) with (next_gamma, next_beta) = the NEXT block's norm1 -- the operand of its
  * srhip_attn_block_fused -- written by the same launch (replaces that block's srhip_layernorm_fwd). */
+/* GELU inside srhip_mlp_fused_proj: x * Phi(x) with Phi = 1/2 + xc R(xc^2), xc = x clamped to +-4.252893, R a degree-8 polynomial (no
+ * v_rcp / v_exp: the kernel's main loop is bound by the vector ALU).  |result - exact-erf GELU| <= max(7e-5, 5e-6 |x|), below half a bf16
+ * quantum of the result wherever |GELU| >= 0.03; the result is rounded to bf16 right after.  srhip_gelu_eval evaluates both forms of the
+ * library (y_erf: the 1.5e-7 form every other path uses) on n values. */
+int srhip_gelu_eval(const float* x, float* y_erf, float* y_poly, int n, void* stream);
 int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const void* Wp, const float* bp, const float* row_scale1,
                          int ao_scaled, const float* ln_gamma, const float* ln_beta, float eps, const void* W1, const float* b1, const void* W2,
                          const float* b2, const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "srhip_mlp_fused": (I, [P, P, P, P, F, P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
     "srhip_attn_block_supported": (I, [I, I, I]),
     "srhip_attn_block_fused": (I, [P, P, P, P, P, P, I, I, I, I, F, P]),
+    "srhip_gelu_eval": (I, [P, P, P, I, P]),
     "srhip_mlp_fused_proj": (I, [P, P, P, P, P, P, I, P, P, F, P, P, P, P, P, I, P, P, P, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),

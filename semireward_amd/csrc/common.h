@@ -78,6 +78,30 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float h = 0.5f * x;
   return fmaf(fabsf(h), r, h);
 }
+// GELU of TWO values without transcendentals, for the fused projection + MLP kernel (rows without a backward), whose main loop is bound by the
+// vector ALU: gelu(x) = x * Phi(x), Phi(x) = 1/2 + xc * R(xc^2), xc = x clamped to +-X*, R = a degree-8 polynomial in xc^2 (weighted minimax
+// fit of erf(x / sqrt 2) / (2 x) on [0, 4.25]); X* = 4.252893 is where the polynomial's Phi reaches 1 (so beyond it Phi is exactly 0 / 1 up to
+// fp32 rounding of the Horner chain, 5e-6).  15 instructions per PAIR (2 v_med3 + 12 packed fp32 + the bf16 pack) against 11 + v_rcp + v_exp
+// (quarter rate: 19 issue slots) per VALUE for gelu_erf.  |gelu - exact| <= max(7e-5, 5e-6 |x|): 6.7e-5 inside the clamp, |x| times the
+// fp32 residue of Phi(+-X*) beyond it (tests/test_gpu_kernels.py pins the bound) -- below half a bf16 quantum of the result wherever
+// |gelu| >= 0.03, and the result is rounded to bf16 right after.  The gradient rows keep gelu_erf (their pre-activation and GELU output feed the backward).
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t v) {
+  constexpr float XS = 4.252893f;
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(v[0], -XS, XS), __builtin_amdgcn_fmed3f(v[1], -XS, XS)};
+  const f32x2_t t = xc * xc;
+  auto sp = [](float c) { return f32x2_t{c, c}; };
+  f32x2_t p = sp(5.564872638e-11f);
+  p = __builtin_elementwise_fma(p, t, sp(-5.327768675e-09f));
+  p = __builtin_elementwise_fma(p, t, sp(2.255431416e-07f));
+  p = __builtin_elementwise_fma(p, t, sp(-5.626433893e-06f));
+  p = __builtin_elementwise_fma(p, t, sp(9.341875929e-05f));
+  p = __builtin_elementwise_fma(p, t, sp(-1.108561217e-03f));
+  p = __builtin_elementwise_fma(p, t, sp(9.815971766e-03f));
+  p = __builtin_elementwise_fma(p, t, sp(-6.634449185e-02f));
+  p = __builtin_elementwise_fma(p, t, sp(3.989023390e-01f));
+  const f32x2_t phi = __builtin_elementwise_fma(p, xc, sp(0.5f));
+  return v * phi;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f);

@@ -312,10 +312,19 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
     auto gelu_elem = [&](auto uc, auto ec, int c) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value, e = decltype(ec)::value, X = e >> 2, r = e & 3;
       const float v = acc1[2 * u + X][r];
+      if constexpr (PROJ && (DBG & 1) == 0) {
+        // rows without a backward: the two values of a bf16 pair together, packed fp32 math, no transcendentals (gelu_poly2); the row's
+        // drop-path factor (lane column of the B fragment) rides on the result before its rounding
+        if constexpr ((e & 1) == 1) {
+          const f32x2_t g2 = gelu_poly2(f32x2_t{acc1[2 * u + X][r - 1], v}) * f32x2_t{rs2v, rs2v};
+          hf[u][e >> 1] = pack_bf2(g2[0], g2[1]);
+        }
+      } else {
       float gv;
       if constexpr ((DBG & 1) != 0) gv = v; else gv = gelu_erf(v);
       if constexpr (PROJ) gv *= rs2v;          // drop-path factor of the row (lane column of the B fragment)
       if constexpr ((e & 1) == 0) { gcarry = gv; pcarry = v; } else hf[u][e >> 1] = pack_bf2(gcarry, gv);
+      }
       if constexpr ((e & 1) == 1) {
         // gradient rows: keep the fc1 pre-activation and the GELU output (bf16, as the unfused path saves them); rare (8 % of the
         // tiles) and conservative for the counted vmcnt waits (extra younger stores can only make a wait longer)
@@ -555,6 +564,15 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
 }
 
 
+__global__ void gelu_eval_kernel(const float* __restrict__ x, float* __restrict__ y_erf, float* __restrict__ y_poly, int n) {
+  const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const float a = x[i], b = i + 1 < n ? x[i + 1] : 0.f;
+  const f32x2_t g = gelu_poly2(f32x2_t{a, b});
+  y_erf[i] = gelu_erf(a); y_poly[i] = g[0];
+  if (i + 1 < n) { y_erf[i + 1] = gelu_erf(b); y_poly[i + 1] = g[1]; }
+}
+
 }  // namespace
 
 #ifdef SRHIP_TUNING
@@ -562,6 +580,14 @@ extern "C" int srhip_mlp_debug(long long* out_host, int n) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(srhip_mlp_dbg), (size_t)n * sizeof(long long)) == hipSuccess ? SR_OK : SR_EINVAL;
 }
 #endif
+// The two GELU evaluations of the library on n values: y_erf = gelu_erf (exact-erf GELU to 1.5e-7, every path with a backward and every unfused
+// epilogue), y_poly = gelu_poly2 (the transcendental-free form inside srhip_mlp_fused_proj) -- so that a test can pin the distance between them.
+extern "C" int srhip_gelu_eval(const float* x, float* y_erf, float* y_poly, int n, void* stream) {
+  if (!x || !y_erf || !y_poly || n <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(gelu_eval_kernel, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, y_erf, y_poly, n);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
 extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gamma, const float* ln_beta, float eps, const void* W1,
                                const float* b1, const void* W2, const float* b2, const float* row_scale, int rows_per_sample,
                                int save_rows, void* save_ln2, void* save_pre, void* save_h, float* save_mean, float* save_rstd,

@@ -308,6 +308,10 @@ def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, 
     _call("srhip_mlp_fused_proj", *args, _s())
 
 
+def gelu_eval(x, y_erf, y_poly):
+    _call("srhip_gelu_eval", _p(x), _p(y_erf), _p(y_poly), x.numel(), _s())
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M, D):
     _call("srhip_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), M, D, _s())
 

@@ -251,6 +251,23 @@ def test_mlp_fused_proj(M, rows_per_sample):
             assert relerr(xf[only1] - x0[only1], xu[only1] - x0[only1]) < 4e-3
 
 
+def test_gelu_forms_against_exact_erf():
+    """The library's two GELU evaluations against nn.GELU() (exact erf, vit.py:63) in float64: gelu_erf (every path with a backward, every
+    unfused epilogue) to 1e-6; gelu_poly2 (inside srhip_mlp_fused_proj, no transcendentals) to max(7e-5, 5e-6 |x|) over |x| <= 30 and below
+    half a bf16 quantum of the result wherever |GELU| >= 0.03 -- its result is rounded to bf16 right away."""
+    x = torch.cat([torch.linspace(-30, 30, 600001), torch.linspace(-4.3, -4.2, 20001), torch.tensor([0.0, -0.0, 1e-30, -1e-30, 4.252893, -4.252893])]).to(DEV)
+    ye, yp = torch.empty_like(x), torch.empty_like(x)
+    ops.gelu_eval(x, ye, yp)
+    xd = x.double().cpu()
+    want = 0.5 * xd * (1 + torch.erf(xd / 2 ** 0.5))
+    assert float((ye.double().cpu() - want).abs().max()) < 1e-6
+    ep = (yp.double().cpu() - want).abs()
+    assert bool((ep <= torch.maximum(torch.full_like(ep, 7e-5), 5e-6 * xd.abs())).all()), float(ep.max())
+    big = want.abs() >= 0.03
+    assert bool((ep[big] <= 0.5 * 2.0 ** -8 * want.abs()[big]).all())          # < half a bf16 quantum (2^-8 relative at worst)
+    assert bool(torch.isfinite(yp).all()) and float(yp[x == 0].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,N,H", [(3, 17, 2), (2, 197, 6), (4, 257, 6), (1, 64, 1), (2, 33, 3)])
 def test_attention_fwd_bwd(B, N, H):
     D = H * 64

@@ -60,7 +60,7 @@ def gemm_small():
 
 def mlp():
     """Fused LN2+fc1+GELU+fc2+residual vs the three unfused launches (inference rows of the reference batch)."""
-    M, D, Hd = 51400, 384, 1536
+    M, D, Hd = int(os.environ.get("MB_ROWS", "51400")), 384, 1536      # MB_ROWS=26985: the 105 read images of a step, one round of tiles
     x = torch.randn(M, D, device=DEV)
     g, b = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
     W1 = (torch.randn(Hd, D, device=DEV) * 0.05).to(torch.bfloat16)
