@@ -17,7 +17,8 @@ batch 8 labelled + 8 weak + 8 strong).
 Prints ONE JSON line on rank 0 (contract in the task statement).  ``value`` is the median of ``--repeats`` timed regions of exactly
 ``--steps`` steps, each bracketed by barrier + synchronize (all of them are listed in ``repeats``).  Besides ``roofline`` and
 ``cpu_baseline`` the line carries ``also``: short legs of the other workloads BASELINE.json's north_star names (ViT-S/16 on 224x224x3, a
-scaled per-GPU batch, the pre-start_timing regime K = 0), each with its own ms_per_step and dominant-kernel roofline.
+scaled per-GPU batch, the pre-start_timing regime K = 0: each with its own ms_per_step and dominant-kernel roofline; the usb_nlp BERT-base
+and usb_audio Wav2Vec2-base + FreeMatch steps of configs[3] / [4] under their own metric names).
 """
 import argparse
 import json
@@ -64,7 +65,7 @@ def parse_args(argv=None):
                     help="NOT the reference's work (never the default, flagged in config): skip the (pass, image) rows whose outputs nothing reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary legs (224x224, scaled batch, K = 0 regime)")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary legs (224x224, scaled batch, K = 0 regime, BERT, Wav2Vec2)")
     return ap.parse_args(argv)
 
 
@@ -379,18 +380,29 @@ def worker(a):
     if default_headline and not a.no_also:
         # the other workloads north_star names, short legs in the same process: fewer steps, one timed region each
         also = []
-        for tag, kw in (("vit_s16_224", dict(img=224)), ("scaled_batch_bu64", dict(bu=64)), ("pre_start_timing_K0", dict(regime="pre"))):
-            leg = Leg(a, ctx, **kw)
-            o = leg.run(max(4, a.steps // 2), 2, 3, roofline=not a.no_roofline)
-            keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "repeats", "n_gpus") if k in o}
-            keep.update(leg=tag, workload=o["config"]["workload"], per_gpu_batch=o["config"]["per_gpu_batch"], K_passes=o["config"]["K_passes"],
-                        forward_image_passes_per_step=o["config"]["forward_image_passes_per_step"])
-            if "roofline" in o:
-                keep["roofline"] = {k: o["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_us",
-                                                                  "flop_per_launch", "algorithmic_bytes_per_launch")}
-            if "allreduce_ms_per_step" in o:
-                keep["allreduce_ms_per_step"] = o["allreduce_ms_per_step"]
-            also.append(keep)
+        # (BASELINE.json configs[3] and [4] -- the usb_nlp BERT-base and usb_audio Wav2Vec2-base + FreeMatch steps -- ride along with their own
+        # metric names and fewer steps; a leg that fails is reported as such and never costs the line)
+        legs = (("vit_s16_224", dict(img=224), max(4, a.steps // 2), True), ("scaled_batch_bu64", dict(bu=64), max(4, a.steps // 2), True),
+                ("pre_start_timing_K0", dict(regime="pre"), max(4, a.steps // 2), True),
+                ("usb_nlp_bert_base_srsoftmatch", dict(net="bert"), max(3, a.steps // 5), False),
+                ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), False))
+        for tag, kw, nsteps, roof in legs:
+            leg = None
+            try:
+                leg = Leg(a, ctx, **kw)
+                o = leg.run(nsteps, 2, 3, roofline=roof and not a.no_roofline)
+                keep = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "repeats", "n_gpus") if k in o}
+                keep.update(leg=tag, workload=o["config"]["workload"], per_gpu_batch=o["config"]["per_gpu_batch"], K_passes=o["config"]["K_passes"])
+                if "forward_image_passes_per_step" in o["config"]:
+                    keep["forward_image_passes_per_step"] = o["config"]["forward_image_passes_per_step"]
+                if "roofline" in o:
+                    keep["roofline"] = {k: o["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_us",
+                                                                      "flop_per_launch", "algorithmic_bytes_per_launch")}
+                if "allreduce_ms_per_step" in o:
+                    keep["allreduce_ms_per_step"] = o["allreduce_ms_per_step"]
+                also.append(keep)
+            except Exception as e:                       # noqa: BLE001
+                also.append({"leg": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
             del leg
             torch.cuda.empty_cache()
         out["also"] = also
