@@ -51,6 +51,12 @@ def _worker(rank, world, port, q):
     w2 = W.clone().requires_grad_(True)
     H.ce_loss_mean(X @ w2.t(), Y).backward()
     ok_grad = torch.allclose(got, w2.grad.reshape(-1), rtol=1e-5, atol=1e-7)
+    # (2b) opt-in bf16 exchange of the gradient block: the same sum to bf16 precision (every rank rounds its block, the sum is rounded)
+    dp16 = DataParallel(world, rank)
+    dp16.bf16_grads = True
+    m.grad = w.grad.reshape(-1).clone()
+    dp16.all_reduce_grads(m)
+    ok_grad = ok_grad and m.grad.dtype == torch.float32 and torch.allclose(m.grad / world, w2.grad.reshape(-1), rtol=2e-2, atol=1e-4)
     # (3) global reward threshold extension: packed (sum..., n) all-reduce == mean over the concatenated ranks
     r_all = torch.from_numpy(rng.random((world, 3, 8)).astype(np.float32))      # [rank, groups, B]
     means = dp.reward_means(r_all[rank].reshape(-1), 3)
