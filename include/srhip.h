@@ -297,9 +297,11 @@ int srhip_rewarder_fwd(const float* params, const float* params_t, const float* 
 /* The same with the feature rows of group g at feats + g * feat_group_stride (elements; >= B * F): the weak-row block of every pass read in
  * place from the step's [passes, batch, F] feature buffer.  Both entries run as ONE launch when a group is one row tile (B <= 8, the
  * reference batch), two otherwise (the batch softmax over a group's 2B attention logits, semireward.py:60-62, is the only dependency
- * between workgroups). */
+ * between workgroups).  max_reward_inout (device scalar or NULL; G == 1 and B <= 8 only): *max_reward = max(*max_reward, mean(reward)) in
+ * the same launch -- `reward.mean()` and the running maximum of srflexmatch.py:166-170. */
 int srhip_rewarder_fwd_strided(const float* params, const float* params_t, const float* feats, long long feat_group_stride,
-                               const long long* labels, float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream);
+                               const long long* labels, float* reward, float* ws, float* max_reward_inout, int G, int B, int F, int L,
+                               int save_for_bwd, void* stream);
 /* Gradient of MSE(r,1) + MSE(r,target) w.r.t. every rewarder parameter (srflexmatch.py:183-190 / :198-205);
  * grads is overwritten; losses[0..1] = (generator_loss, rewarder_loss) when non-NULL. */
 int srhip_rewarder_bwd(const float* params, const float* feats, const long long* labels, const float* target, float* ws,

@@ -70,7 +70,7 @@ SIGNATURES = {
     "srhip_rewarder_prepare": (I, [P, P, I, I, P]),
     "srhip_generator_prepare": (I, [P, P, I, P]),
     "srhip_rewarder_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
-    "srhip_rewarder_fwd_strided": (I, [P, P, P, c_longlong, P, P, P, I, I, I, I, I, P]),
+    "srhip_rewarder_fwd_strided": (I, [P, P, P, c_longlong, P, P, P, P, I, I, I, I, I, P]),
     "srhip_rewarder_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "srhip_generator_fwd": (I, [P, P, P, P, P, I, I, P]),
     "srhip_sr_target": (I, [P, P, P, I, I, P]),

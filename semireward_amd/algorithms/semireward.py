@@ -140,13 +140,17 @@ class Rewarder(_FlatModule):
             self._ws[key] = torch.empty(ops.rewarder_ws_floats(G, B), dtype=torch.float32, device=self.device)
         return self._ws[key]
 
-    def score(self, features, label_indices, groups=1, save_for_bwd=False):
-        """reward [groups*B]; every group of B consecutive rows has its own batch-softmax (semireward.py:60-62)."""
+    def score(self, features, label_indices, groups=1, save_for_bwd=False, max_reward=None):
+        """reward [groups*B]; every group of B consecutive rows has its own batch-softmax (semireward.py:60-62).  max_reward (0-d device
+        tensor): also max_reward <- max(max_reward, reward.mean()) (srflexmatch.py:166-170), inside the launch when it is a single row tile."""
         R = features.shape[0]
         B = R // groups
         reward = torch.empty(R, dtype=torch.float32, device=self.device)
+        fused_max = max_reward is not None and groups == 1 and B <= 8
         ops.rewarder_fwd(self.flat, self.flat_t, features.contiguous(), label_indices.contiguous(), reward, self._workspace(groups, B),
-                         groups, B, self.feature_dim, self.label_dim, save_for_bwd)
+                         groups, B, self.feature_dim, self.label_dim, save_for_bwd, max_reward=max_reward if fused_max else None)
+        if max_reward is not None and not fused_max:
+            torch.maximum(max_reward, reward.mean(), out=max_reward)
         return reward
 
     def score_in_place(self, feat_buffer, first_row, group_rows, rows_per_group, label_indices, groups):

@@ -479,8 +479,8 @@ class SRConsistencyBase(AlgorithmBase):
         fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
         if it > 0:
             if it >= self.start_timing:                                                           # :163
-                r0 = self.rewarder.score(fw0.contiguous(), pl0)                                   # :166
-                self.max_reward = torch.maximum(self.max_reward, r0.mean())                       # :167-170 (filter is a no-op, A.2)
+                # :166-170 (the filter is a no-op, A.2): reward.mean() and the running maximum ride in the scoring launch
+                self.rewarder.score(fw0.contiguous(), pl0, max_reward=self.max_reward)
                 if it % self.N_k == 0 and it > self.start_timing:                                 # :173
                     self.max_reward = torch.full((), -float("inf"), device=self.device)
                     gen2 = self.generator.forward_with_labels(fw0.contiguous())[1]                # :177-178

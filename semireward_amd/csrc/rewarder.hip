@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void rew_embed_kernel(const float* __restrict_
 constexpr int SCORE_LDS_FLOATS = E + 8 + E * RT + 256 * RT + E * RT + 64 * RT + 256 * RT;
 __device__ __forceinline__ void rew_score_body(const float* __restrict__ P, const float* __restrict__ PT,
                                                float* __restrict__ ws, float* __restrict__ reward,
-                                               int G, int B, int F, int L, int save, float* lds) {
+                                               int G, int B, int F, int L, int save, float* lds, float* __restrict__ max_reward = nullptr) {
   const RewOff o(F, L);
   const RewTOff ot(F);
   const RewWs w(G, B);
@@ -279,6 +279,17 @@ __device__ __forceinline__ void rew_score_body(const float* __restrict__ P, cons
       if (lane == 0) ws[w.r + gr] = rr;
     }
   }
+  // max_reward = max(max_reward, mean(reward)) of a single-tile, single-group scoring call (srflexmatch.py:166-170: `reward.mean()` and the
+  // running maximum the stage-2 update compares against) in the same launch: rows summed in index order by one thread
+  if (max_reward && G == 1 && gridDim.x == 1) {
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int i = 0; i < B; ++i) s += reward[i];
+      *max_reward = fmaxf(*max_reward, s / (float)B);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict__ P, const float* __restrict__ PT,
@@ -294,12 +305,12 @@ __global__ __launch_bounds__(256) void rew_score_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void rew_fused_kernel(const float* __restrict__ P, const float* __restrict__ PT,
                                                        const float* __restrict__ feats, const long long* __restrict__ labels,
                                                        float* __restrict__ ws, float* __restrict__ reward, int G, int B, int F, int L,
-                                                       int save, long long feat_gs) {
+                                                       int save, long long feat_gs, float* __restrict__ max_reward) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // max(embed tiles, score tiles)
   rew_embed_body(P, PT, feats, labels, ws, G, B, F, L, save, feat_gs, sm);
   __threadfence_block();
   __syncthreads();                 // the workspace rows of this group (z, logits) are visible to the whole workgroup
-  rew_score_body(P, PT, ws, reward, G, B, F, L, save, sm);
+  rew_score_body(P, PT, ws, reward, G, B, F, L, save, sm, max_reward);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,20 +548,21 @@ extern "C" int srhip_generator_prepare(const float* params, float* params_t, int
 
 extern "C" int srhip_rewarder_fwd(const float* params, const float* params_t, const float* feats, const long long* labels,
                                   float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd, void* stream) {
-  return srhip_rewarder_fwd_strided(params, params_t, feats, (long long)B * F, labels, reward, ws, G, B, F, L, save_for_bwd, stream);
+  return srhip_rewarder_fwd_strided(params, params_t, feats, (long long)B * F, labels, reward, ws, nullptr, G, B, F, L, save_for_bwd, stream);
 }
 extern "C" int srhip_rewarder_fwd_strided(const float* params, const float* params_t, const float* feats, long long feat_group_stride,
-                                          const long long* labels, float* reward, float* ws, int G, int B, int F, int L, int save_for_bwd,
-                                          void* stream) {
+                                          const long long* labels, float* reward, float* ws, float* max_reward_inout, int G, int B, int F,
+                                          int L, int save_for_bwd, void* stream) {
   if (G <= 0 || B <= 0 || F <= 0 || F > 1024 || L <= 0 || (save_for_bwd && G != 1) || !params_t) return SR_EINVAL;
   if (feat_group_stride < (long long)B * F) return SR_EINVAL;
+  if (max_reward_inout && (G != 1 || B > RT)) return SR_EINVAL;            // the running maximum rides in the one-launch form only
   hipStream_t s = (hipStream_t)stream;
   const size_t sm1 = ((size_t)F * RT + E * RT + 256 * RT) * sizeof(float);
   static const bool two = getenv("SRHIP_REWARDER_TWO_LAUNCHES") != nullptr;
-  if (B <= RT && !two) {
+  if (B <= RT && (!two || max_reward_inout)) {
     const size_t smf = sm1 > SCORE_LDS_FLOATS * sizeof(float) ? sm1 : SCORE_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(rew_fused_kernel, dim3(1, G), dim3(256), smf, s, params, params_t, feats, labels, ws, reward, G, B, F, L, save_for_bwd,
-                       feat_group_stride);
+                       feat_group_stride, max_reward_inout);
     SR_CHECK_LAUNCH();
     return SR_OK;
   }

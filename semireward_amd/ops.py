@@ -496,14 +496,15 @@ def generator_prepare(params, params_t, F):
     _call("srhip_generator_prepare", _p(params), _p(params_t), F, _s())
 
 
-def rewarder_fwd(params, params_t, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False, feats_first_row=0, group_rows=None):
+def rewarder_fwd(params, params_t, feats, labels, reward, ws, G, B, F, L, save_for_bwd=False, feats_first_row=0, group_rows=None,
+                 max_reward=None):
     """feats [G * B, F] dense, or (group_rows given) a contiguous [*, F] buffer in which group g's B rows start at row
-    feats_first_row + g * group_rows."""
-    if group_rows is None:
+    feats_first_row + g * group_rows.  max_reward (0-d device tensor; G == 1, B <= 8): updated to max(max_reward, mean(reward)) in place."""
+    if group_rows is None and max_reward is None:
         _call("srhip_rewarder_fwd", _p(params), _p(params_t), _p(feats), _p(labels), _p(reward), _p(ws), G, B, F, L, int(save_for_bwd), _s())
     else:
-        _call("srhip_rewarder_fwd_strided", _p(params), _p(params_t), _pa(feats, feats_first_row * F), group_rows * F, _p(labels), _p(reward),
-              _p(ws), G, B, F, L, int(save_for_bwd), _s())
+        _call("srhip_rewarder_fwd_strided", _p(params), _p(params_t), _pa(feats, feats_first_row * F), (group_rows if group_rows else B) * F,
+              _p(labels), _p(reward), _p(ws), _p(max_reward), G, B, F, L, int(save_for_bwd), _s())
 
 
 def rewarder_bwd(params, feats, labels, target, ws, grads, losses, B, F, L):
