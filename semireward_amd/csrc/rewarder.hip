@@ -99,9 +99,9 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ WT, const 
   float acc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-  // 16 weight loads in flight per thread: the k loop is a chain of L2 round trips (~0.7 us each) -- with 4 per trip the three layers of the
+  // 32 weight loads in flight per thread: the k loop is a chain of L2 round trips (~0.7 us each) -- with 4 per trip the three layers of the
   // score kernel took 72 trips = 51 us for 64 rows; same summation order, so the results do not change.
-  constexpr int CH = 16;
+  constexpr int CH = 32;
   for (int kb = k0; kb < k1; kb += CH) {
     float w[CH];
 #pragma unroll
