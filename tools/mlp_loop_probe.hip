@@ -19,7 +19,7 @@ template <int N_> __device__ __forceinline__ void wait_vm() { asm volatile("s_wa
 constexpr int NS = 16, GS = 4, NG = NS / GS, ST = 8192;          // ring slots, stages per group, groups, bytes per stage
 
 // BIG = false: shape A (blockDim 512), BIG = true: shape B (blockDim 256).  VF = filler operations (packed fma) per stage and wave.
-template <bool BIG, int VF, bool DMA, bool RD>
+template <bool BIG, int VF, bool DMA, bool RD, int VAR = 0>
 __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict__ w, size_t wbytes, int chunks, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NW = BIG ? 4 : 8, IPS = 8 / NW;                  // waves, DMA instructions per wave and stage
@@ -71,17 +71,23 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
   };
   sync(0);
   rd(0, 0);
+  // VAR 0: as the kernel (a scheduling barrier after every half-stage).  1: no scheduling barriers at all.  2: s_setprio 1 around the MFMAs.
+  // 3: barriers only at the group syncs.
   for (int s0 = 0; s0 < nst; s0 += 12) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       const int s = s0 + j;
       rd(s, 1);
+      if (VAR == 2) __builtin_amdgcn_s_setprio(1);
       mm(j, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if ((j + 1) % GS == 0) sync(s + 1);
+      if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+      if (VAR == 0 || VAR == 2) __builtin_amdgcn_sched_barrier(0);
+      if ((j + 1) % GS == 0) { if (VAR == 3) __builtin_amdgcn_sched_barrier(0); sync(s + 1); }
       rd(s + 1, 0);
+      if (VAR == 2) __builtin_amdgcn_s_setprio(1);
       mm(j, 1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+      if (VAR == 0 || VAR == 2) __builtin_amdgcn_sched_barrier(0);
     }
   }
   float r = fill[0][0] + fill[1][1] + fill[2][0] + fill[3][1];
@@ -90,10 +96,10 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
   if (r == 123.456f) sink[0] = r;
 }
 
-template <bool BIG, int VF, bool DMA, bool RD>
+template <bool BIG, int VF, bool DMA, bool RD, int VAR = 0>
 static void run(const char* name, const char* w, size_t wb, int wgs) {
   float* sink; hipMalloc(&sink, 4);
-  auto kern = probe<BIG, VF, DMA, RD>;
+  auto kern = probe<BIG, VF, DMA, RD, VAR>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * ST);
   const int chunks = 24 * 20;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -113,8 +119,11 @@ static void run(const char* name, const char* w, size_t wb, int wgs) {
 int main() {
   const size_t wb = 4u << 20;          // (the probe walks the first half: 2 MiB, L2-resident like the 2.65 MB of a block's weights)
   char* w; hipMalloc(&w, wb); hipMemset(w, 0x11, wb);
-  for (int wgs : {8, 211}) {
+  for (int wgs : {211}) {
     run<false, 12, true, true>("A 8 waves 16x16x32, GELU filler 12 pk/stage", w, wb, wgs);
+    run<false, 12, true, true, 1>("A, no scheduling barriers", w, wb, wgs);
+    run<false, 12, true, true, 2>("A, s_setprio 1 around the MFMAs", w, wb, wgs);
+    run<false, 12, true, true, 3>("A, scheduling barriers at group syncs only", w, wb, wgs);
     run<false, 0, true, true>("A, no filler", w, wb, wgs);
     run<false, 12, false, true>("A, no DMA", w, wb, wgs);
     run<false, 0, false, false>("A, MFMA + barriers only", w, wb, wgs);
