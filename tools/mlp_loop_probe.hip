@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
   auto mm = [&](int j, int h) __attribute__((always_inline)) {       // j: stage inside the chunk (compile-time after unrolling)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int a_ = (j * 8 + 4 * h + t) % NACC;
+      const int a_ = VAR == 4 ? (j < 6 ? (j / 3) : 2 + ((j - 6) % 3) * 4 + t) % NACC : (j * 8 + 4 * h + t) % NACC;   // VAR 4: the 8 MFMAs of a GEMM1 stage chain on ONE accumulator
       if constexpr (BIG) acc[a_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[h][t]), __builtin_bit_cast(bf16x8_t, xb), acc[a_], 0, 0, 0);
       else acc[a_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[h][t]), __builtin_bit_cast(bf16x8_t, xb), acc[a_], 0, 0, 0);
     }
@@ -128,6 +128,7 @@ int main() {
     run<false, 12, false, true>("A, no DMA", w, wb, wgs);
     run<false, 0, false, false>("A, MFMA + barriers only", w, wb, wgs);
     run<true, 24, true, true>("B 4 waves 32x32x16, GELU filler 24 pk/stage", w, wb, wgs);
+    run<true, 24, true, true, 4>("B, GEMM1 stages as dependent chains on one accumulator", w, wb, wgs);
     run<true, 0, true, true>("B, no filler", w, wb, wgs);
     run<true, 24, false, true>("B, no DMA", w, wb, wgs);
     run<true, 0, false, false>("B, MFMA + barriers only", w, wb, wgs);
