@@ -16,7 +16,29 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 template <int N_> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-constexpr int NS = 16, GS = 4, NG = NS / GS, ST = 8192;          // ring slots, stages per group, groups, bytes per stage
+constexpr int NS = 16, GS = 4, NG = NS / GS, ST = 8192;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t v) {                 // as in the library (common.h)
+  constexpr float XS = 4.252893f;
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(v[0], -XS, XS), __builtin_amdgcn_fmed3f(v[1], -XS, XS)};
+  const f32x2_t t = xc * xc;
+  auto sp = [](float c) { return f32x2_t{c, c}; };
+  f32x2_t p = sp(5.564872638e-11f);
+  p = __builtin_elementwise_fma(p, t, sp(-5.327768675e-09f));
+  p = __builtin_elementwise_fma(p, t, sp(2.255431416e-07f));
+  p = __builtin_elementwise_fma(p, t, sp(-5.626433893e-06f));
+  p = __builtin_elementwise_fma(p, t, sp(9.341875929e-05f));
+  p = __builtin_elementwise_fma(p, t, sp(-1.108561217e-03f));
+  p = __builtin_elementwise_fma(p, t, sp(9.815971766e-03f));
+  p = __builtin_elementwise_fma(p, t, sp(-6.634449185e-02f));
+  p = __builtin_elementwise_fma(p, t, sp(3.989023390e-01f));
+  const f32x2_t phi = __builtin_elementwise_fma(p, xc, sp(0.5f));
+  return v * phi;
+}          // ring slots, stages per group, groups, bytes per stage
 
 // BIG = false: shape A (blockDim 512), BIG = true: shape B (blockDim 256).  VF = filler operations (packed fma) per stage and wave.
 template <bool BIG, int VF, bool DMA, bool RD, int VAR = 0>
@@ -53,7 +75,32 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
 #pragma unroll
     for (int t = 0; t < 4; ++t) fa[h][t] = RD ? *(const u32x4_t*)(st + (4 * h + t) * 1024) : u32x4_t{(unsigned)s, 1u, 2u, (unsigned)t};
   };
+  // VAR 5 (shape B only): the dependency structure of the real kernel -- fc1 stages chain on acc[0 / 1], their GELU (gelu_poly2 on pairs read
+  // from the accumulators, packed to bf16) produces the B fragments of the fc2 stages, pairs placed 2,1,1,2,1,1 behind stages 3-5 / 6-8
+  u32x4_t hfr[2][2] = {{xb, xb}, {xb, xb}};
+  auto mm5 = [&](int j, int h) __attribute__((always_inline)) {
+    if constexpr (BIG) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (j < 6) acc[j / 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[h][t]), __builtin_bit_cast(bf16x8_t, xb), acc[j / 3], 0, 0, 0);
+        else {
+          const int u = (j - 6) / 3, th = (j - 6) % 3, a_ = 2 + th * 4 + 2 * h + (t >> 1);
+          acc[a_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[h][t]), __builtin_bit_cast(bf16x8_t, hfr[u][t & 1]), acc[a_], 0, 0, 0);
+        }
+      }
+      if (j >= 3 && j <= 8) {
+        const int u = (j - 3) / 3, qq = 2 * ((j - 3) % 3) + h;
+        const int first[7] = {0, 2, 3, 4, 6, 7, 8};
+        for (int p = first[qq]; p < first[qq + 1]; ++p) {
+          const f32x2_t g2 = gelu_poly2(f32x2_t{acc[u][2 * p], acc[u][2 * p + 1]});
+          hfr[u][p >> 2][p & 3] = pack_bf2(g2[0], g2[1]);
+          if (p == 7) for (int e = 0; e < 16; ++e) acc[u][e] = 0.25f;
+        }
+      }
+    }
+  };
   auto mm = [&](int j, int h) __attribute__((always_inline)) {       // j: stage inside the chunk (compile-time after unrolling)
+    if constexpr (VAR == 5) { mm5(j, h); return; }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int a_ = VAR == 4 ? (j < 6 ? (j / 3) : 2 + ((j - 6) % 3) * 4 + t) % NACC : (j * 8 + 4 * h + t) % NACC;   // VAR 4: the 8 MFMAs of a GEMM1 stage chain on ONE accumulator
@@ -90,7 +137,7 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
       if (VAR == 0 || VAR == 2) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float r = fill[0][0] + fill[1][1] + fill[2][0] + fill[3][1];
+  float r = fill[0][0] + fill[1][1] + fill[2][0] + fill[3][1] + (float)hfr[0][0][0] + (float)hfr[1][1][3];
 #pragma unroll
   for (int t = 0; t < NACC; ++t) r += acc[t][0] + acc[t][3];
   if (r == 123.456f) sink[0] = r;
@@ -129,6 +176,7 @@ int main() {
     run<false, 0, false, false>("A, MFMA + barriers only", w, wb, wgs);
     run<true, 24, true, true>("B 4 waves 32x32x16, GELU filler 24 pk/stage", w, wb, wgs);
     run<true, 24, true, true, 4>("B, GEMM1 stages as dependent chains on one accumulator", w, wb, wgs);
+    run<true, 0, true, true, 5>("B, real dependency structure + gelu_poly2 pairs", w, wb, wgs);
     run<true, 0, true, true>("B, no filler", w, wb, wgs);
     run<true, 24, false, true>("B, no DMA", w, wb, wgs);
     run<true, 0, false, false>("B, MFMA + barriers only", w, wb, wgs);
