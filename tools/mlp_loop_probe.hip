@@ -60,8 +60,15 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
   // as in the kernel: buffer addressing = resource (SGPRs) + per-lane byte offset (one VGPR, loop-invariant) + uniform byte offset (SGPR)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, (int)wbytes, 0x00020000);
   const int lo = lane * 16;
+  // VAR 6 (shape A): the source pattern of the real kernel's stages -- a wave instruction fetches 16 rows x 64 B, rows `pitch` bytes apart
+  const int lo_str = (16 * wave + (lane >> 2)) * 768 + (lane & 3) * 16;
   auto issue = [&](int s) __attribute__((always_inline)) {
     if (!DMA) return;
+    if constexpr (VAR == 6) {
+      const unsigned so = (((unsigned)s % 12u) * 64u + ((unsigned)s / 12u) * 128u * 768u) & (unsigned)(wbytes / 2 - 1);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + (s & (NS - 1)) * ST + wave * 1024), 16, lo_str, (int)so, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < IPS; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + (s & (NS - 1)) * ST + (wave * IPS + i) * 1024), 16, lo,
@@ -171,6 +178,8 @@ int main() {
     run<false, 12, true, true, 1>("A, no scheduling barriers", w, wb, wgs);
     run<false, 12, true, true, 2>("A, s_setprio 1 around the MFMAs", w, wb, wgs);
     run<false, 12, true, true, 3>("A, scheduling barriers at group syncs only", w, wb, wgs);
+    run<false, 12, true, true, 6>("A, stage sources as 16 rows x 64 B pieces (pitch 768)", w, wb, wgs);
+    run<false, 0, true, true, 6>("A, the same without filler", w, wb, wgs);
     run<false, 0, true, true>("A, no filler", w, wb, wgs);
     run<false, 12, false, true>("A, no DMA", w, wb, wgs);
     run<false, 0, false, false>("A, MFMA + barriers only", w, wb, wgs);
