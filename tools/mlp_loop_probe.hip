@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
   };
   constexpr int PD = (NG - 2) * GS;
   for (int p = 0; p < PD; ++p) issue(p);
-  u32x4_t fa[2][4];
+  u32x4_t fa[VAR == 7 ? 3 : 2][4];
   auto rd = [&](int s, int h) __attribute__((always_inline)) {                                   // the 4 fragments of half-stage (s, h)
     const char* st = lds + (s & (NS - 1)) * ST + lane * 16;
 #pragma unroll
@@ -125,6 +125,46 @@ __global__ __launch_bounds__(BIG ? 256 : 512) void probe(const char* __restrict_
   };
   sync(0);
   rd(0, 0);
+  // VAR 7 (shape A): fragments requested TWO half-stages ahead (three buffers)
+  if constexpr (VAR == 7) {
+    rd(0, 1);                                  // buffer 1 <- (stage 0, half 1); buffer 0 already holds (0, 0)
+    for (int s0 = 0; s0 < nst; s0 += 12) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int s = s0 + j;
+        // half-stage index hs = 2 j + h uses buffer hs % 3; request hs + 2
+        {
+          const int hs = 2 * j;                 // (j, 0): request (j + 1, 0) into buffer (hs + 2) % 3
+          if ((j + 1) % GS == 0) sync(s + 1);
+          const char* st = lds + ((s + 1) & (NS - 1)) * ST + lane * 16;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fa[(hs + 2) % 3][t] = *(const u32x4_t*)(st + t * 1024);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int a_ = (j * 8 + t) % NACC;
+            acc[a_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[hs % 3][t]), __builtin_bit_cast(bf16x8_t, xb), acc[a_], 0, 0, 0);
+          }
+#pragma unroll
+          for (int v = 0; v < VF / 2; ++v) fill[v & 3] = __builtin_elementwise_fma(fill[v & 3], fill[(v + 1) & 3], f32x2_t{0.5f, 0.25f});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const int hs = 2 * j + 1;             // (j, 1): request (j + 1, 1) into buffer (hs + 2) % 3
+          const char* st = lds + ((s + 1) & (NS - 1)) * ST + lane * 16;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fa[(hs + 2) % 3][t] = *(const u32x4_t*)(st + (4 + t) * 1024);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int a_ = (j * 8 + 4 + t) % NACC;
+            acc[a_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[hs % 3][t]), __builtin_bit_cast(bf16x8_t, xb), acc[a_], 0, 0, 0);
+          }
+#pragma unroll
+          for (int v = 0; v < VF / 2; ++v) fill[v & 3] = __builtin_elementwise_fma(fill[v & 3], fill[(v + 1) & 3], f32x2_t{0.5f, 0.25f});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else
   // VAR 0: as the kernel (a scheduling barrier after every half-stage).  1: no scheduling barriers at all.  2: s_setprio 1 around the MFMAs.
   // 3: barriers only at the group syncs.
   for (int s0 = 0; s0 < nst; s0 += 12) {
@@ -180,6 +220,7 @@ int main() {
     run<false, 12, true, true, 3>("A, scheduling barriers at group syncs only", w, wb, wgs);
     run<false, 12, true, true, 6>("A, stage sources as 16 rows x 64 B pieces (pitch 768)", w, wb, wgs);
     run<false, 0, true, true, 6>("A, the same without filler", w, wb, wgs);
+    run<false, 12, true, true, 7>("A, fragments two half-stages ahead", w, wb, wgs);
     run<false, 0, true, true>("A, no filler", w, wb, wgs);
     run<false, 12, false, true>("A, no DMA", w, wb, wgs);
     run<false, 0, false, false>("A, MFMA + barriers only", w, wb, wgs);
