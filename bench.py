@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--regime", choices=["sr", "pre"], default="sr", help="sr: it > start_timing (K=8); pre: K=0")
     ap.add_argument("--img", type=int, choices=[32, 224], default=32,
                     help="32: ViT-S/2 on 32x32 (north-star config); 224: ViT-S/16 on 224x224 (vit_small_patch16_224, 197 tokens)")
-    ap.add_argument("--net", choices=["vit", "bert", "hubert", "wave2vec"], default="vit",
+    ap.add_argument("--net", choices=["vit", "bert", "hubert", "wave2vec", "wrn"], default="vit",
                     help="vit: the headline workload (BASELINE.json metric); bert: bert_base_uncased on [B, --seq-len] token batches (usb_nlp "
                          "shapes, configs[3]); wave2vec / hubert: wave2vecv2_base / hubert_base on [B, --samples] waveforms (usb_audio shapes, "
                          "configs[4]) -- reported under their own metric names")
@@ -65,6 +65,7 @@ def parse_args(argv=None):
                     help="NOT the reference's work (never the default, flagged in config): skip the (pass, image) rows whose outputs nothing reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-allreduce-ab", action="store_true", help="N > 1: skip the overlap off / on / bf16 legs of the gradient exchange")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary legs (224x224, scaled batch, K = 0 regime, BERT, Wav2Vec2)")
     return ap.parse_args(argv)
 
@@ -102,10 +103,18 @@ def launch_ranks(n):
     return rc
 
 
+def _thread_candidates():
+    import torch
+    top = torch.get_num_threads()
+    return sorted({n for n in (8, 16, 32, 64, 128) if n <= top} | {top})
+
+
 def cpu_baseline(bl, bu):
-    """Reference-semantics step on the host cores, timed on a bounded sample with the CPU oracle (kind = 'port'): a (Bl+2Bu)-image
-    ViT-S/2 pass with autograd graph is timed three times, the backward of one such graph twice and one AdamW sweep; medians; the K = 8
-    step time is (1+K)*t_fwd + 2*t_bwd + t_opt, exactly the reference's work per step (two graphs are back-propagated)."""
+    """Reference-semantics step on the host cores, timed on a bounded sample with the CPU oracle (kind = 'port').  Protocol:
+    ``torch.set_num_threads`` is swept over {8, 16, 32, 64, 128, all} with ONE (Bl+2Bu)-image ViT-S/2 forward each (a 6-GFLOP-per-layer
+    problem is oversubscribed by 128 threads); at the best count three graph forwards (median), two one-graph backwards and one AdamW
+    sweep; the K = 8 step time is (1+K)*t_fwd + 2*t_bwd + t_opt, exactly the reference's work per step (two graphs are back-propagated).
+    The all-threads number is reported beside it (its forward scaled into the same formula)."""
     import numpy as np
     import torch
     from oracle import hooks_ref as H
@@ -118,11 +127,23 @@ def cpu_baseline(bl, bu):
     x = torch.from_numpy(np.concatenate([b["x_lb"], b["x_ulb_w"], b["x_ulb_s"]]))
     y = torch.from_numpy(np.concatenate([b["y_lb"], b["y_lb"][:1].repeat(2 * bu)]))
     dp = torch.from_numpy(synth.synth_droppath(1, V.drop_path_probs(cfg), x.shape[0]))
+    all_threads = torch.get_num_threads()
     V.vit_forward(P, x[:2], cfg, dp[:, :, :2], aten_ops=True)        # warm the allocator / threads
+    sweep = {}
+    for n in _thread_candidates():
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            V.vit_forward(P, x[:2], cfg, dp[:, :, :2], aten_ops=True)    # the pool at its new size
+        t0 = time.perf_counter()
+        with torch.no_grad():                                         # the sweep only ranks thread counts: no graph, the allocator reuses its blocks
+            V.vit_forward(P, x, cfg, dp, aten_ops=True)               # LayerNorm / GELU as the ATen kernels the reference's modules call
+        sweep[n] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     tf, tb, outs = [], [], []
     for _ in range(3):
         t0 = time.perf_counter()
-        outs.append(V.vit_forward(P, x, cfg, dp, aten_ops=True))    # LayerNorm / GELU as the ATen kernels the reference's modules call
+        outs.append(V.vit_forward(P, x, cfg, dp, aten_ops=True))
         tf.append(time.perf_counter() - t0)
     for o in outs[:2]:
         t0 = time.perf_counter()
@@ -135,14 +156,71 @@ def cpu_baseline(bl, bu):
         for k, p in P.items():
             O.adamw_step(p, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1, hp[k][0], hp[k][1])
     t_opt = time.perf_counter() - t0
+    torch.set_num_threads(all_threads)
     t_fwd, t_bwd = sorted(tf)[1], 0.5 * (tb[0] + tb[1])
     K = 8
     t_step = (1 + K) * t_fwd + 2 * t_bwd + t_opt
-    return {"value": bu / t_step, "unit": "unlabeled images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle ViT-S/2 fp32 (ATen LayerNorm / GELU as in the reference's modules), Bt=%d: 3 graph forwards (%s s, median %.2f) + 2 one-graph backwards (%s s, mean %.2f) + AdamW (%.2fs); "
-                      "K=8 step = 9*fwd + 2*bwd + opt = %.1fs" % (x.shape[0], "/".join("%.2f" % t for t in tf), t_fwd,
+    t_step_all = t_step * sweep[all_threads] / sweep[best]           # same formula with the all-threads forward (backward scaled alike)
+    return {"value": bu / t_step, "unit": "unlabeled images/s", "cores": best, "kind": "port",
+            "sample": "oracle ViT-S/2 fp32 (ATen LayerNorm / GELU as in the reference's modules), Bt=%d, %d threads (best of the sweep): 3 graph forwards (%s s, median %.2f) + 2 one-graph backwards (%s s, mean %.2f) + AdamW (%.2fs); "
+                      "K=8 step = 9*fwd + 2*bwd + opt = %.1fs" % (x.shape[0], best, "/".join("%.2f" % t for t in tf), t_fwd,
                                                                  "/".join("%.2f" % t for t in tb), t_bwd, t_opt, t_step),
-            "spread_pct": 100.0 * (max(tf) - min(tf)) / t_fwd}
+            "spread_pct": 100.0 * (max(tf) - min(tf)) / t_fwd,
+            "thread_sweep_fwd_s": {str(n): round(t, 3) for n, t in sweep.items()},
+            "all_threads": {"cores": all_threads, "value": bu / t_step_all, "note": "one forward at all host threads, scaled into the same step formula"}}
+
+
+def cpu_baseline_wrn(bl, bu):
+    """BASELINE.json configs[0] ("CPU reference"): SRPseudoLabel on WRN-28-2 at 64 / 64, oracle port (oracle/wrn_ref.py, fp32 ATen convolutions),
+    thread count swept like cpu_baseline.  The reference's step (srpseudolabel.py:92-201, K = 8): model(x_lb) with graph + (1 + K) x
+    model(x_ulb_w) with graph + one backward through the labelled graph and the last unlabelled graph + SGD."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import wrn_ref as W
+    from oracle.gen_golden import synth_wrn_params
+    from semireward_amd.utils import synth
+    cfg = W.WrnCfg(num_classes=100, **W.WRN_28_2)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth_wrn_params(cfg, 0).items()}
+    BUF = W.init_buffers(cfg)
+    b = synth.synth_batch(0, bl, bu, 32, 100, 50000)
+    xl, xu, y = torch.from_numpy(b["x_lb"]), torch.from_numpy(b["x_ulb_w"]), torch.from_numpy(b["y_lb"])
+    all_threads = torch.get_num_threads()
+    sweep = {}
+    for n in _thread_candidates():
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            W.wrn_forward(P, BUF, xu[:4], cfg, train=True, update_stats=False)
+            W.wrn_forward(P, BUF, xu, cfg, train=True, update_stats=False)       # (first call at this size: oneDNN primitives are built)
+            t0 = time.perf_counter()
+            W.wrn_forward(P, BUF, xu, cfg, train=True, update_stats=False)
+            sweep[n] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    tf, tb = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ol = W.wrn_forward(P, BUF, xl, cfg, train=True, update_stats=True)
+        ou = W.wrn_forward(P, BUF, xu, cfg, train=True, update_stats=False)
+        tf.append(0.5 * (time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        (F.cross_entropy(ol["logits"], y) + F.cross_entropy(ou["logits"], y)).backward()
+        tb.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for k, p in P.items():
+            if p.grad is not None:                                   # (a bn1 whose output feeds nothing has no gradient, as in the reference)
+                W.sgd_nesterov_step(p, p.grad, torch.zeros_like(p), 0.03, 0.9, 1e-3, True)
+    t_opt = time.perf_counter() - t0
+    torch.set_num_threads(all_threads)
+    K = 8
+    t_fwd, t_bwd = sorted(tf)[1], sorted(tb)[1]
+    t_step = (2 + K) * t_fwd + t_bwd + t_opt
+    return {"value": bu / t_step, "unit": "unlabeled images/s", "cores": best, "kind": "port",
+            "sample": "oracle WRN-28-2 fp32, %d / %d images, %d threads (best of the sweep): 3 graph forwards (%s s, median %.3f), 3 backwards of (labelled + last unlabelled) graph (%s s, median), SGD %.3fs; "
+                      "K=8 step = 10*fwd + bwd + opt = %.2fs" % (bl, bu, best, "/".join("%.3f" % t for t in tf), t_fwd, "/".join("%.3f" % t for t in tb),
+                                                                 t_opt, t_step),
+            "spread_pct": 100.0 * (max(tf) - min(tf)) / t_fwd, "thread_sweep_fwd_s": {str(n): round(t, 3) for n, t in sweep.items()}}
 
 
 class Leg:
@@ -170,6 +248,20 @@ class Leg:
             self.metric, self.unit = "unlabeled images/sec/node (FlexMatch+SR, ViT-S CIFAR-100)", "unlabeled images/s"
             self.workload = ("SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, " if img == 32 else
                              "SRFlexMatch ViT-S/16@224 (vit_small_patch16_224) 224x224x3 batches, 100 classes, ")
+        elif net == "wrn":
+            # BASELINE.json configs[0]: config/classic_cv/pseudolabel/pseudolabel_cifar100_400_0.yaml + the SR keys (SURVEY Appendix C:
+            # feature_dim 128): WRN-28-2, batch 64 / uratio 1, SGD-Nesterov lr 0.03 momentum 0.9 wd 1e-3, ema_m 0.999, 2^20 iterations
+            from semireward_amd.nets import wrn
+            self.alg_name = "srpseudolabel"
+            cfg = dict(NS, algorithm="srpseudolabel", num_train_iter=1048576, ema_m=0.999, optim="SGD", lr=0.03, momentum=0.9, weight_decay=1e-3,
+                       layer_decay=1.0, num_warmup_iter=0, feature_dim=128, unsup_warm_up=0.4)
+            m = get_algorithm(argparse.Namespace(**common, **cfg), wrn.wrn_28_2)          # reference init (wrn.py:108-117), seed 0
+            m.dp.broadcast_params(m.model, m.rewarder, m.generator)
+            b = synth.synth_batch(100 + rank, self.bl, bu, 32, 100, 50000)
+            self.batch = m.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+            start = 200001                                               # sr_decay(): max(8, 1 + 2^20 / it) = 8
+            self.metric, self.unit = "unlabeled images/sec/node (PseudoLabel+SR, WRN-28-2 CIFAR-100)", "unlabeled images/s"
+            self.workload = "SRPseudoLabel WRN-28-2@32 CIFAR-100 shapes, classic_cv pseudolabel_cifar100_400_0.yaml + SR keys, SGD, "
         else:
             # usb_nlp / usb_audio SR yamls (config/SemiReward/usb_nlp/softmatch/softmatch_ag_news_40_0.yaml, usb_audio/{softmatch,freematch}/
             # *_urbansound8k_100_0.yaml): batch 8 / uratio 1, use_cat False, AdamW lr 5e-5 wd 5e-4, num_train_iter 102400, start_timing 10000
@@ -250,6 +342,12 @@ class Leg:
         from semireward_amd import ops
         a, world = self.a, self.ctx["world"]
         m = self.alg
+        # set-up, untimed like building the model: the start-up autotune of the step schedule (share of the inference rows on the second
+        # stream, srflexmatch._DeferTuner) runs its candidates as real training steps; the W warm-up and the K timed steps follow it
+        tune_steps = 0
+        while getattr(m, "_tuners", None) is not None and (tune_steps == 0 or m._tuners) and tune_steps < 64:
+            self.step()
+            tune_steps += 1
         for _ in range(warmup):
             self.step()
         m.dp.comm_events = [] if world > 1 else None          # event pairs around the gradient all-reduce of every timed step
@@ -269,14 +367,20 @@ class Leg:
                "data": "synthetic",
                "repeats": {"n": len(dts), "ms_per_step": [round(1e3 * d / steps, 4) for d in dts], "value_is": "median",
                            "spread_pct": round(100.0 * (max(dts) - min(dts)) / dt, 2)},
-               "config": {"workload": self.workload, "algorithm": self.alg_name, "per_gpu_batch": {"lb": bl, "ulb_w": bu, "ulb_s": bu},
+               "config": {"workload": self.workload, "algorithm": self.alg_name,
+                          "per_gpu_batch": {"lb": bl, "ulb_w": bu} if self.net == "wrn" else {"lb": bl, "ulb_w": bu, "ulb_s": bu},
                           "K_passes": K,
-                          "forward_image_passes_per_step": (1 + K) * (bl + 2 * bu) - (K * bl if self.net != "vit" else 0) -
+                          "forward_image_passes_per_step": (bl + (1 + K) * bu) if self.net == "wrn" else
+                          (1 + K) * (bl + 2 * bu) - (K * bl if self.net != "vit" else 0) -
                           ((K * bl if self.net == "vit" else 0) + max(K - 1, 0) * bu if self.elide else 0),
                           "unread_rows": "ELIDED (opt-in extension: fewer forward rows than the reference executes, results identical)"
                           if self.elide else "computed, as in the reference",
                           "backward_images_per_step": bl + bu, "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
+        rep = list(getattr(m, "defer_report", {}).values())
+        if rep:
+            out["config"]["step_schedule"] = {"deferred_share": rep[-1]["chosen"], "deferred_images": rep[-1]["deferred_images"],
+                                              "autotune_ms_per_step_by_share": rep[-1]["ms_per_step"], "autotune_steps": tune_steps}
         if world > 1:
             out["config"]["backend"] = self.ctx["backend_note"]
             out["rccl_ranks"] = self.ctx["rccl_ranks"]
@@ -384,8 +488,9 @@ def worker(a):
         # metric names and fewer steps; a leg that fails is reported as such and never costs the line)
         legs = (("vit_s16_224", dict(img=224), max(4, a.steps // 2), True), ("scaled_batch_bu64", dict(bu=64), max(4, a.steps // 2), True),
                 ("pre_start_timing_K0", dict(regime="pre"), max(4, a.steps // 2), True),
-                ("usb_nlp_bert_base_srsoftmatch", dict(net="bert"), max(3, a.steps // 5), False),
-                ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), False))
+                ("classic_cv_wrn_28_2_srpseudolabel", dict(net="wrn", bu=64), max(4, a.steps // 2), True),
+                ("usb_nlp_bert_base_srsoftmatch", dict(net="bert"), max(3, a.steps // 5), True),
+                ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), True))
         for tag, kw, nsteps, roof in legs:
             leg = None
             try:
@@ -400,12 +505,36 @@ def worker(a):
                                                                       "flop_per_launch", "algorithmic_bytes_per_launch")}
                 if "allreduce_ms_per_step" in o:
                     keep["allreduce_ms_per_step"] = o["allreduce_ms_per_step"]
+                if tag.startswith("classic_cv") and rank == 0 and world == 1 and not a.no_cpu_baseline:
+                    keep["cpu_baseline"] = cpu_baseline_wrn(64, 64)       # the configuration BASELINE.json labels "CPU reference"
                 also.append(keep)
             except Exception as e:                       # noqa: BLE001
                 also.append({"leg": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
             del leg
             torch.cuda.empty_cache()
         out["also"] = also
+    if world > 1 and default_headline and not a.no_allreduce_ab:
+        # A/B of the gradient exchange in the SAME run (decides the default once it has been timed on RCCL over xGMI): the headline above is
+        # "off" = one all-reduce of the flat block after the backward; "on" = layer-group slices reduced on a communication stream under the
+        # backward (SR_OVERLAP_ALLREDUCE, distributed.DataParallel.install_overlap); "on_bf16" = the same exchange in bf16 (never the default)
+        ab = {"off": {"ms_per_step": out["ms_per_step"], "value": out["value"], "allreduce_ms_per_step": out.get("allreduce_ms_per_step")}}
+        for tag, env in (("on", {"SR_OVERLAP_ALLREDUCE": "1"}), ("off_bf16", {"SR_ALLREDUCE_BF16": "1"})):
+            leg, old_env = None, {k: os.environ.get(k) for k in env}
+            try:
+                os.environ.update(env)
+                leg = Leg(a, ctx, net=a.net, img=a.img, bu=a.bu, bl=a.bl, regime=a.regime, alg=a.alg)
+                o = leg.run(max(4, a.steps // 2), 2, 3, roofline=False)
+                ab[tag] = {"ms_per_step": o["ms_per_step"], "value": o["value"], "allreduce_ms_per_step": o.get("allreduce_ms_per_step"),
+                           "note": "allreduce_ms_per_step = what is left exposed behind the backward (event pair around all_reduce_grads)"
+                           if tag == "on" else "gradient block exchanged as bf16 (a rounded sum: NOT the reference's fp32 DDP buckets)"}
+            except Exception as e:                       # noqa: BLE001
+                ab[tag] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            finally:
+                for k, v in old_env.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            del leg
+            torch.cuda.empty_cache()
+        out["overlap_allreduce"] = ab
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and default_headline:
             out["cpu_baseline"] = cpu_baseline(a.bl or a.bu, a.bu)

@@ -150,7 +150,8 @@ class Rewarder(_FlatModule):
         ops.rewarder_fwd(self.flat, self.flat_t, features.contiguous(), label_indices.contiguous(), reward, self._workspace(groups, B),
                          groups, B, self.feature_dim, self.label_dim, save_for_bwd, max_reward=max_reward if fused_max else None)
         if max_reward is not None and not fused_max:
-            torch.maximum(max_reward, reward.mean(), out=max_reward)
+            rm = reward.mean()
+            max_reward.copy_(torch.where(rm > max_reward, rm, max_reward))     # srflexmatch.py:170 (keeps the old maximum for a NaN mean, like fmaxf in the fused launch)
         return reward
 
     def score_in_place(self, feat_buffer, first_row, group_rows, rows_per_group, label_indices, groups):

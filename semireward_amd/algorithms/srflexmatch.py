@@ -27,7 +27,56 @@ from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
 _PHASES = os.environ.get("SR_PHASES", "0") != "0"
-_DEFER_FRACTION = float(os.environ.get("SR_DEFER_FRACTION", "0.475"))   # share of the inference images on the second stream (see _Plan)
+# Share of the inference images that run on the second stream (see _Plan).  SR_DEFER_FRACTION=<f> pins it; otherwise it is TUNED per
+# (batch, K, backbone) in the first steps of a regime (_DeferTuner) -- SR_DEFER_AUTOTUNE=0 falls back to the fixed _DEFER_SEED.
+_DEFER_SEED = 0.475           # measured optimum of ViT-S/2 at 8 / 8 / 8, K = 8 on one MI355X; the tuner's middle candidate
+_DEFER_FIXED = float(os.environ["SR_DEFER_FRACTION"]) if "SR_DEFER_FRACTION" in os.environ else None
+_DEFER_AUTOTUNE = os.environ.get("SR_DEFER_AUTOTUNE", "1") != "0" and _DEFER_FIXED is None
+_DEFER_FRACTION = _DEFER_FIXED if _DEFER_FIXED is not None else _DEFER_SEED
+
+
+class _DeferTuner:
+    """Start-up autotune of the deferred share.  Where the optimum lies depends on how the two launch trains of a step pack the chip: the
+    workgroups of the row-streaming kernels own a CU for ~100 us, so while a deferred launch fills the chip every small launch of the critical
+    chain (masks, losses, the backward of the gradient rows) waits for one of them to retire; too few deferred rows and the read launch alone
+    delays that chain.  The balance moves with the token count, the batch, K and the CU count, and it is sharp (95 deferred images
+    1542 img/s, 98 -> 1469), so it is MEASURED: every candidate share runs WARM + TIMED real training steps (nothing is thrown away; the split
+    does not change a single result -- rows are independent), step time = HIP events at consecutive step starts, one host synchronisation when
+    the last candidate is done; the median-fastest candidate is kept for the rest of the run.  Cached per plan key."""
+    CANDIDATES = (0.35, 0.42, _DEFER_SEED, 0.53, 0.58, 1.0)      # 1.0 = every row nothing reads (clipped to what may be deferred)
+    WARM, TIMED = 1, 3
+
+    def __init__(self, fractions):
+        self.fracs = list(fractions)
+        self.marks = []                     # one event per step start, + the end marker
+        self.best = None
+        self.report = None
+
+    @property
+    def done(self):
+        return self.best is not None
+
+    def fraction(self):
+        """Share for the step that starts now (records the step-start event while tuning)."""
+        if self.done:
+            return self.best
+        per = self.WARM + self.TIMED
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append(e)
+        i = len(self.marks) - 1             # index of this step
+        if i < per * len(self.fracs):
+            return self.fracs[i // per]
+        self.marks[-1].synchronize()
+        ms = [self.marks[j].elapsed_time(self.marks[j + 1]) for j in range(i)]
+        med = []
+        for c in range(len(self.fracs)):
+            t = sorted(ms[c * per + self.WARM:(c + 1) * per])
+            med.append(t[len(t) // 2])
+        self.best = self.fracs[min(range(len(med)), key=med.__getitem__)]
+        self.report = {"%.3f" % f: round(m, 4) for f, m in zip(self.fracs, med)}
+        self.marks = []
+        return self.best
 
 
 class _OwnStreamScope:
@@ -56,7 +105,7 @@ class _Plan:
     """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
     rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
 
-    def __init__(self, cols_img, grad_cols, device, skip_cols=(), read_cols=None, rows_per_col=None):
+    def __init__(self, cols_img, grad_cols, device, skip_cols=(), read_cols=None, rows_per_col=None, defer_fraction=None):
         """read_cols: the inference columns whose logits / features the step actually READS (weak rows of every pass).  The others are
         computed because the reference computes them (the strong and labelled rows of the passes whose loss is thrown away) -- same
         launches, but nothing waits for them: they run on the second stream behind the gradient rows (``rest``)."""
@@ -79,12 +128,15 @@ class _Plan:
             # under half of the inference images -- instead of all 127 nothing reads -- keeps both launch trains at one round and leaves the
             # deferred one ~64 CUs short of the chip.  Measured on one box, ViT-S/2 (rest images -> img/s): 127 -> 1324, 111 -> 1373,
             # 95 -> 1398, 91 -> 1398, 87 -> 1324; ViT-S/16 at 224: 127 -> 1473, 103 -> 1646, 93 -> 1670, 83 (folded, below) -> 1396.
+            # defer_fraction None = the untuned rule (share _DEFER_FRACTION while the deferred launch is a single round of tiles); a tuner's
+            # candidate applies at any size
+            frac = _DEFER_FRACTION if defer_fraction is None else defer_fraction
             tiles = -(-len(rest_cols) * rows_per_col // 128)
-            keep = int(_DEFER_FRACTION * (len(inf_cols) + len(rest_cols)))
-            if 0.0 < _DEFER_FRACTION < 1.0 and tiles <= 256 and 0 < keep < len(rest_cols):
+            keep = int(frac * (len(inf_cols) + len(rest_cols)))
+            if 0.0 < frac < 1.0 and (tiles <= 256 or defer_fraction is not None) and 0 < keep < len(rest_cols):
                 nmove = len(rest_cols) - keep
                 inf_cols, rest_cols = sorted(inf_cols + rest_cols[-nmove:]), rest_cols[:-nmove]
-        if rest_cols and rows_per_col and len(rest_cols) * rows_per_col < 16384:
+        if rest_cols and rows_per_col and len(rest_cols) * rows_per_col < _vit._FUSED_MLP_MIN_ROWS:
             # a deferred launch below the size from which the fused row-streaming kernels are used (nets/vit.py _FUSED_MLP_MIN_ROWS) would
             # run different kernels than the same rows do inside a large launch: it rides in the launch that is read (elide mode: 8 images)
             inf_cols, rest_cols = sorted(inf_cols + rest_cols), []
@@ -100,7 +152,7 @@ class _Plan:
 
     @classmethod
     def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False, rows_per_col=None,
-                   elide_unread=False):
+                   elide_unread=False, defer_fraction=None):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
         labelled rows of pass 0 and the strong rows of the last pass.  lb_every_pass=False (use_cat=False, the usb_nlp / usb_audio
         configs): data_generator forwards only x_ulb_s and x_ulb_w (srflexmatch.py:83-90), so the labelled columns of the passes
@@ -117,7 +169,7 @@ class _Plan:
             skip = sorted(set(skip) | {k * Bt + j for k in range(1, K + 1) for j in range(nl)} |
                           {k * Bt + j for k in range(1, K) for j in range(nl + nu, Bt)})
         read = [k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)] if defer_unread else None      # the weak rows
-        p = cls(cols_img, grad, device, skip, read, rows_per_col)
+        p = cls(cols_img, grad, device, skip, read, rows_per_col, defer_fraction)
         p.P, p.Bt = K + 1, Bt
         return p
 
@@ -145,6 +197,8 @@ class SRConsistencyBase(AlgorithmBase):
         if os.environ.get("SR_OVERLAP_ALLREDUCE", "0") != "0":
             self.dp.install_overlap(self.model)
         self._plans = {}
+        self._tuners = {}                      # plan key -> (_DeferTuner, {share: _Plan}) while the deferred share of that regime is being tuned
+        self.defer_report = {}                 # plan key -> what the tuner measured and chose
         self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
         # gradient-row forward on a second HIP stream (SR_OVERLAP_GRAD_ROWS=0 serialises it behind the inference forward)
         self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", os.environ.get("SR_OVERLAP_GRAD_ROWS", "1") != "0")) \
@@ -374,15 +428,37 @@ class SRConsistencyBase(AlgorithmBase):
         from ..nets.bert import TokenBatch
         return TokenBatch.cat(batches)
 
+    def _make_plan(self, nl, nu, K, defer_fraction=None):
+        return _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
+                                lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows,
+                                rows_per_col=getattr(self.model.cfg, "num_tokens", None),
+                                elide_unread=self.elide_unread_rows, defer_fraction=defer_fraction)
+
     def _forward_passes(self, imgs, nl, nu, K):
         key = (nl, nu, K, bool(self.use_cat), self.elide_unread_rows)
         if key not in self._plans:
             if self.elide_unread_rows and not getattr(self.model, "rows_independent", False):
                 raise ValueError("elide_unread_rows needs a backbone without batch statistics (ViT / BERT / Wav2Vec2 engines)")
-            self._plans[key] = _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
-                                                lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows,
-                                                rows_per_col=getattr(self.model.cfg, "num_tokens", None),
-                                                elide_unread=self.elide_unread_rows)
+            self._plans[key] = self._make_plan(nl, nu, K)
+            if _DEFER_AUTOTUNE and self.defer_unread_rows and self._plans[key].rest_cols.numel() > 0:
+                # candidates that give distinct (read | deferred) splits; a split whose deferred launch would fall below the fused kernels'
+                # launch size is folded by _Plan and drops out here
+                cand, seen = {}, set()
+                for f in _DeferTuner.CANDIDATES:
+                    p_ = self._make_plan(nl, nu, K, defer_fraction=f)
+                    n_ = int(p_.rest_cols.numel())
+                    if n_ > 0 and n_ not in seen:
+                        seen.add(n_)
+                        cand[f] = p_
+                if len(cand) > 1:
+                    self._tuners[key] = (_DeferTuner(cand.keys()), cand)
+        tn = self._tuners.get(key)
+        if tn is not None:
+            tuner, cand = tn
+            self._plans[key] = cand[tuner.fraction()]
+            if tuner.done:
+                self.defer_report[key] = dict(chosen=tuner.best, deferred_images=int(self._plans[key].rest_cols.numel()), ms_per_step=tuner.report)
+                del self._tuners[key]
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)

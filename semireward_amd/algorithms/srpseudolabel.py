@@ -108,7 +108,8 @@ class SRPseudoLabel(SRConsistencyBase):
         if it > 0:                                                                                  # :135-191
             if it >= self.start_timing:
                 r0 = self.rewarder.score(fu0.contiguous(), pl0)
-                self.max_reward = torch.maximum(self.max_reward, r0.mean())
+                rm = r0.mean()
+                self.max_reward = torch.where(rm > self.max_reward, rm, self.max_reward)     # srpseudolabel.py:153 (a NaN mean keeps the old maximum)
                 if it % self.N_k == 0 and it > self.start_timing:
                     self.max_reward = torch.full((), -float("inf"), device=self.device)
                     gen2 = self.generator.forward_with_labels(fu0.contiguous())[1]

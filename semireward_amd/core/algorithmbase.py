@@ -200,6 +200,10 @@ class AlgorithmBase:
                 self.out_dict, self.log_dict = self.train_step(**self.process_batch(**data_lb, **data_ulb))
                 self.call_hook("after_train_step")
                 self.it += 1
+                # out-of-range label / idx_ulb (IndexError at the offending call in the reference): the device flag is read at the logging
+                # cadence, where the log scalars synchronise anyway -- bad data stops training within num_log_iter steps, not at the epoch end
+                if self.num_log_iter and self.it % self.num_log_iter == 0:
+                    ops.check_label_errors()
             self.call_hook("after_train_epoch")
             ops.check_label_errors()        # IndexError of nn.Embedding / F.one_hot in the reference; the device flag is read where the host may wait
         self.call_hook("after_run")

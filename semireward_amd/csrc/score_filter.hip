@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void flexmatch_mask_lds_kernel(const float* __
     const int max_cls = smax[0], max_all = max(max_cls, s_hist[C]);
     if (max_all < ulb_dest_len) {
       const int den = thresh_warmup ? max_all : max_cls;
-      for (int c = tid; c < C; c += nt) s_acc[c] = (float)((double)s_hist[c] / (double)den);
+      // thresh_warmup False and no row selected yet: the reference's max() over an empty Counter raises ValueError (srflexmatch/utils.py:35);
+      // here classwise_acc stays as it is and bit 1 of the error word is set for the host (ops.check_label_errors)
+      if (den == 0) { if (tid == 0) atomicOr(&srhip_index_err, 2); }
+      else for (int c = tid; c < C; c += nt) s_acc[c] = (float)((double)s_hist[c] / (double)den);
     }
     __syncthreads();                  // the next pass reads s_acc / s_sel / s_hist; smax is reset after this point
   }
@@ -206,7 +209,8 @@ __global__ __launch_bounds__(256) void flexmatch_mask_kernel(const float* __rest
     const int max_all = smax[1];
     if (max_all < ulb_dest_len) {
       const int den = thresh_warmup ? max_all : smax[0];
-      for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      if (den == 0) { if (threadIdx.x == 0) atomicOr(&srhip_index_err, 2); }         // (see the LDS kernel)
+      else for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int cnt = __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(classwise_acc + c, (float)((double)cnt / (double)den), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -510,9 +514,13 @@ extern "C" int srhip_flexmatch_mask_passes(const float* max_probs, const long lo
                                            long long* selected_label, int* hist, float* classwise_acc, float* mask, int n_pass, int B, int C,
                                            int ulb_dest_len, int thresh_warmup, void* stream) {
   if (n_pass <= 0 || B <= 0 || C <= 0 || ulb_dest_len <= 0 || !idx_ulb) return SR_EINVAL;
-  if (C <= 8192 && B <= 4096 && !getenv("SRHIP_FLEXMATCH_GENERAL")) {
-    const size_t smem = (size_t)(2 * C + 1) * 4 + (size_t)B * 6 * 4;
-    (void)hipFuncSetAttribute((const void*)flexmatch_mask_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  // state-in-LDS path only when its request fits the 160 KiB of a CU (minus the kernel's static LDS) AND the attribute call accepts it;
+  // anything larger takes the general global-memory kernel instead of failing the launch
+  const size_t smem = (size_t)(2 * C + 1) * 4 + (size_t)B * 6 * 4;
+  bool lds_path = C <= 8192 && B <= 4096 && smem <= 160 * 1024 - 4096 && !getenv("SRHIP_FLEXMATCH_GENERAL");
+  if (lds_path && smem > 48 * 1024)
+    lds_path = hipFuncSetAttribute((const void*)flexmatch_mask_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+  if (lds_path) {
     hipLaunchKernelGGL(flexmatch_mask_lds_kernel, dim3(1), dim3(256), smem, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
                        selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
   } else {

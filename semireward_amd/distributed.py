@@ -4,8 +4,9 @@ Reference: plain DDP (semilearn/core/utils/misc.py:55-58) -> bucketed gradient a
 Here parameters/gradients are ONE flat fp32 block, so the gradient exchange is a single large all-reduce
 (85.7 MB for ViT-S) issued right after the hand-written backward -- the "few, large collectives" shape that suits
 xGMI's point-to-point links -- and the 1/world scaling is folded into the AdamW launch (grad_scale).
-Optional extensions named in BASELINE.json (off by default = reference parity): a global reward threshold
-(all-reduce of (sum reward, n)) and a global FlexMatch class histogram; and (SR_ALLREDUCE_BF16=1) the gradient block exchanged as bf16 --
+Optional extension named in BASELINE.json (off by default = reference parity): a global reward threshold (``global_reward_threshold``:
+one packed all-reduce of (sum reward per pass, n) per step, ``reward_means``).  The FlexMatch class histogram stays per rank, as under the
+reference's DDP (srflexmatch/utils.py:24-35 recounts the rank's own ``selected_label``).  And (SR_ALLREDUCE_BF16=1) the gradient block exchanged as bf16 --
 half the xGMI ring time of the one large all-reduce (42.9 instead of 85.7 MB for ViT-S), at the price of a gradient sum rounded to 8 bits
 of mantissa per hop, which DDP's fp32 buckets do not do: opt-in, never the default.
 """

@@ -217,5 +217,33 @@ class FusedSGD:
         return dict(momentum_buffer=self.buf.cpu(), step=self.step_count, sched_step=self.sched_step)
 
     def load_state_dict(self, sd):
+        if "state" in sd and "param_groups" in sd:                 # torch.optim.SGD.state_dict() of a reference checkpoint
+            return self._load_torch_state(sd)
         self.buf.copy_(sd["momentum_buffer"])
         self.step_count, self.sched_step = int(sd["step"]), int(sd["sched_step"])
+
+    def _load_torch_state(self, sd):
+        """torch layout of the reference's SGD (build.py:193-224 without layer decay): param_groups = [no_decay, decay] (nets/utils.py:77-97),
+        state[idx] = {'momentum_buffer'}.  torch keeps no step counter for SGD; what matters here is only whether a momentum buffer exists
+        (the first step initialises it with the gradient): step_count = 1 if any buffer was loaded; the LambdaLR position comes from the
+        checkpoint's scheduler entry (AlgorithmBase.load_model)."""
+        order = torch_group_order(self.model, 1.0)
+        assert len(sd["param_groups"]) == len(order), "optimizer state does not match this model's parameter groups"
+        idx_of = {}
+        for g, names in zip(sd["param_groups"], order):
+            assert len(g["params"]) == len(names), "optimizer state does not match this model's parameter groups"
+            for i, n in zip(g["params"], names):
+                idx_of[n] = i
+        self.buf.zero_()
+        loaded = 0
+        for n, _ in self.model.names_shapes:
+            st = sd["state"].get(idx_of[n])
+            mb = None if st is None else st.get("momentum_buffer")
+            if mb is None:
+                continue
+            o = self.model.offsets[n][0]
+            self.buf[o:o + int(mb.numel())].copy_(mb.reshape(-1))
+            loaded += 1
+        assert loaded in (0, len(self.model.names_shapes)), "momentum buffers for only part of the parameters"
+        self.step_count = 1 if loaded else 0
+        return self

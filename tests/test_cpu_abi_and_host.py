@@ -241,3 +241,42 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     assert len(gemm) == 5
     for k, v in gemm.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["Occupancy [waves/SIMD]"] >= 3, (k, v)
+
+
+def test_torch_group_order_of_sgd_matches_the_reference(golden):
+    """optim.torch_group_order(model, 1.0) -- the running index -> name map FusedSGD._load_torch_state relies on -- against the group order
+    the reference's get_optimizer produced for the tiny WideResNet (ema.npz wrn/opt/*, written by oracle/gen_golden.py gen_ema)."""
+    import types
+    from oracle import wrn_ref as W
+    from semireward_amd.optim import torch_group_order
+    g = golden("ema")
+    wcfg = W.WrnCfg(num_classes=10, **W.WRN_TINY_TEST)
+    m = types.SimpleNamespace(names_shapes=[(n, tuple(s)) for n, s in W.param_shapes(wcfg)])
+    order = torch_group_order(m, 1.0)
+    assert [len(x) for x in order] == [int(v) for v in g["wrn/opt/group_sizes"]]
+    assert [n for grp in order for n in grp] == [str(n) for n in g["wrn/opt/names_by_index"]]
+    assert float(g["wrn/opt/group_wd"][0]) == 0.0 and float(g["wrn/opt/group_wd"][1]) > 0.0
+
+
+def test_step_plan_partitions_every_column_for_every_deferred_share():
+    """srflexmatch._Plan: whatever share of the inference rows a tuner candidate defers, the (gradient | read | deferred) launches partition the
+    (pass, image) columns of the step, the rows the step reads are never deferred, and a deferred launch below the fused kernels' launch size is
+    folded into the read launch."""
+    from semireward_amd.algorithms.srflexmatch import _DeferTuner, _Plan
+    from semireward_amd.nets import vit
+    nl = nu = 8
+    for K, N in ((8, 257), (8, 197), (11, 257), (8, 17)):
+        Bt = nl + 2 * nu
+        read = {k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)}
+        sizes = set()
+        for f in (None,) + _DeferTuner.CANDIDATES:
+            p = _Plan.cat_passes(nl, nu, K, "cpu", defer_unread=True, rows_per_col=N, defer_fraction=f)
+            g, i, r = (set(t.tolist()) for t in (p.grad_cols, p.inf_cols, p.rest_cols))
+            assert g | i | r == set(range((K + 1) * Bt)) and not (g & i or g & r or i & r)
+            assert read <= i and len(g) == nl + nu
+            assert p.perm_cols.tolist() == p.grad_cols.tolist() + p.inf_cols.tolist() + p.rest_cols.tolist()
+            assert len(r) == 0 or len(r) * N >= vit._FUSED_MLP_MIN_ROWS
+            if f is not None and 0 < f < 1 and r:
+                assert len(r) <= int(f * (len(i) + len(r))) + 1
+            sizes.add(len(r))
+        assert (len(sizes) > 2) == (N > 100)          # tiny backbones: nothing to tune (everything rides in the read launch)

@@ -103,7 +103,11 @@ def test_backbone_inference_logits_with_and_without_the_fused_kernel(golden, tag
     lg1, ft1, _ = m.forward_features(x, None, None, save=False)
     monkeypatch.setattr(vit, "_FUSED_ATTN", False)
     lg0, ft0, _ = m.forward_features(x, None, None, save=False)
-    want = torch.from_numpy(g[f"{tag}/eval_logits"]) if f"{tag}/eval_logits" in g.z.files else None
+    want = torch.from_numpy(g[f"{tag}/eval_logits"])              # KeyError if the fixture ever loses the key: the oracle assertion is not optional
     assert rel(lg1, lg0) < 6e-3 and rel(ft1, ft0) < 6e-3
-    if want is not None:
-        assert rel(lg1.cpu(), want) < 2e-2
+    assert rel(lg1.cpu(), want) < 2e-2 and rel(lg0.cpu(), want) < 2e-2
+    # the same 24 images through the production chain (fused proj + MLP + next-LN launches, as in every launch of >= _FUSED_MLP_MIN_ROWS rows)
+    monkeypatch.setattr(vit, "_FUSED_ATTN", True)
+    monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1024)
+    lg2, ft2, _ = m.forward_features(x, None, None, save=False)
+    assert rel(lg2.cpu(), want) < 2e-2 and rel(lg2, lg1) < 6e-3 and rel(ft2, ft1) < 6e-3

@@ -22,3 +22,70 @@ def test_sliced_all_reduce_under_the_backward_equals_single_all_reduce():
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() + r.stderr.splitlines() if l.startswith("rank ")]
     assert r.returncode == 0 and len(lines) == 2, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_global_reward_threshold_through_the_engine_with_two_ranks():
+    """BASELINE.json configs[2]: ``global_reward_threshold`` through SRFlexMatch.train_step on the HIP engine with two gloo ranks on one GPU
+    (tools/dp_global_threshold_check.py): mask2 == (reward >= mean over both ranks' rewards) bit for bit with the flag on, the rank-local mask
+    (reference semantics) with it off, parameters identical on both ranks after the step."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "dp_global_threshold_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() + r.stderr.splitlines() if l.startswith("rank ")]
+    assert r.returncode == 0 and len(lines) == 4, (r.stdout[-2000:], r.stderr[-3000:])
+    assert all("expected: True" in l for l in lines)
+
+
+def test_allreduce_streams_are_ordered_by_events_not_by_the_backend():
+    """The all-reduce under the backward runs on a communication stream (distributed.DataParallel.install_overlap).  gloo's all_reduce
+    synchronises the stream it is called on, so the two-rank tests cannot see a missing event; RCCL does not.  Here the collective is replaced by
+    an asynchronous stand-in on the communication stream and the compute stream is made slow with a spin kernel:
+      * _reduce_range(lo, hi): the collective must see the gradient slice as the compute stream leaves it (comm stream waited on the event
+        recorded after the producing launch), although that launch sits behind ~50 ms of queued work when the collective is enqueued;
+      * all_reduce_grads: the compute stream must see the collective's result (it waits on the event recorded behind the last slice), although
+        the stand-in spins before it writes; the not-yet-reported ranges are reduced there, each exactly once."""
+    import torch
+    import torch.distributed as dist
+    from semireward_amd.distributed import DataParallel
+
+    class FakeDP(DataParallel):
+        active = True
+
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    model = type("M", (), {})()
+    model.grad, model.grad_ready_cb = torch.zeros(n, device=dev), None
+    dp = FakeDP(world_size=2, rank=0)
+    assert dp.install_overlap(model) and model.grad_ready_cb is not None
+    seen, calls = [], []
+    spin = int(1e8)                                        # ~50 ms at 2 GHz
+
+    def fake_all_reduce(t, op=None):
+        cur = torch.cuda.current_stream()
+        assert cur == dp._comm, "the collective of a slice belongs on the communication stream"
+        calls.append((t.data_ptr() - model.grad.data_ptr()) // 4)
+        seen.append(t.clone())                             # what the collective reads (stream-ordered on the comm stream)
+        torch.cuda._sleep(spin)
+        t.mul_(2.0)                                        # "sum over two ranks holding the same gradients"
+    real = dist.all_reduce
+    dist.all_reduce = fake_all_reduce
+    try:
+        lo, hi = n // 2, n
+        torch.cuda._sleep(spin)                            # the backward is still busy ...
+        model.grad[lo:hi].fill_(3.0)                       # ... and only then produces the slice
+        model.grad_ready_cb(lo, hi)                        # = dp._reduce_range: enqueued while the producer has not run yet
+        torch.cuda._sleep(spin)
+        model.grad[:lo].fill_(5.0)                         # the rest of the backward
+        dp.all_reduce_grads(model)                         # reduces [0, lo) and joins the communication stream
+        got = model.grad.clone()                           # compute stream: must be ordered behind both collectives
+        torch.cuda.synchronize()
+    finally:
+        dist.all_reduce = real
+    assert calls == [lo, 0], calls                         # every range exactly once
+    assert float(seen[0].min()) == 3.0 and float(seen[0].max()) == 3.0, "the comm stream did not wait for the producer of the slice"
+    assert float(seen[1].min()) == 5.0 and float(seen[1].max()) == 5.0
+    assert float(got[lo:].min()) == 6.0 and float(got[:lo].min()) == 10.0 and float(got.max()) == 10.0, "the compute stream did not wait for the collectives"

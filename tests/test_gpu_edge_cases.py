@@ -1,5 +1,6 @@
 """Edge cases of the score filter / masked loss kernels against the CPU oracle (through the C ABI; needs a MI355X): ties, values exactly
 on a threshold, empty and full masks, single-row and ragged batches, a saturated selected_label table, extreme logits."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -255,4 +256,51 @@ def test_out_of_range_indices_and_labels_raise_like_the_reference():
     assert int(lab.max()) == -1
     with pytest.raises(IndexError, match="NaN"):
         ops.check_label_errors()
+    ops.check_label_errors()
+
+
+def test_flexmatch_without_warmup_before_any_selection_raises_like_the_reference():
+    """thresh_warmup False and not one row over the cut-off yet: the reference's update() takes max() of an empty Counter and raises ValueError
+    (srflexmatch/utils.py:30-35).  The kernels leave classwise_acc untouched (no 0 / 0 = NaN) and flag it for the next host check."""
+    C, U, Bu = 5, 16, 4
+    ops.check_label_errors()
+    for general in (False, True):
+        if general:
+            os.environ["SRHIP_FLEXMATCH_GENERAL"] = "1"
+        try:
+            sel, hist, acc = _flex_engine(C, U, False)
+            probs = _probs_with_max([(1, 0.5)] * Bu, C)                    # nothing reaches p_cutoff
+            mp, mi = torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV)
+            ops.row_max(_dev(probs), True, None, mp, mi, Bu, C)
+            mask = torch.empty(Bu, device=DEV)
+            ops.flexmatch_mask(mp, mi, _dev(np.arange(Bu, dtype=np.int64)), 0.95, sel, hist, acc, mask, Bu, C, U, False)
+            assert bool(torch.isfinite(acc).all()) and float(acc.abs().max()) == 0.0
+            with pytest.raises(ValueError, match="empty sequence"):
+                ops.check_label_errors()
+            ops.check_label_errors()
+        finally:
+            os.environ.pop("SRHIP_FLEXMATCH_GENERAL", None)
+
+
+def test_flexmatch_state_larger_than_lds_takes_the_general_kernel():
+    """C = 8192 classes x B = 4096 rows would ask the state-in-LDS kernel for 163 844 B (> 160 KiB): the call must fall back to the general
+    kernel instead of failing the launch, with the same masks as the numpy oracle."""
+    from oracle import hooks_ref as H
+    C, U, Bu = 8192, 20000, 4096
+    rng = np.random.Generator(np.random.PCG64(5))
+    sel, hist, acc = _flex_engine(C, U, True)
+    mpn = rng.random(Bu).astype(np.float32)
+    mpn[::3] = 0.99
+    min_ = rng.integers(0, C, size=Bu, dtype=np.int64)
+    idx = rng.permutation(U)[:Bu].astype(np.int64)
+    mask = torch.empty(Bu, device=DEV)
+    ops.flexmatch_mask(_dev(mpn), _dev(min_), _dev(idx), 0.95, sel, hist, acc, mask, Bu, C, U, True)
+    torch.cuda.synchronize()
+    st = H.FlexMatchState(U, C, True)
+    probs = np.zeros((Bu, C), np.float32)
+    probs[np.arange(Bu), min_] = mpn
+    want = st.masking(probs, idx, 0.95)
+    assert np.array_equal(mask.cpu().numpy(), want)
+    assert np.array_equal(sel.cpu().numpy(), st.selected_label)
+    assert np.array_equal(acc.cpu().numpy().view(np.uint32), st.classwise_acc.view(np.uint32))
     ops.check_label_errors()

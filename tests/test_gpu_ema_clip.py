@@ -139,3 +139,37 @@ def test_torch_layout_optimizer_state_loads_in_reference_group_order(golden):
 def test_amp_is_refused_not_ignored():
     with pytest.raises(NotImplementedError):
         get_algorithm(_args(amp=True), vit.vit_tiny_test)
+
+
+def test_torch_layout_sgd_state_loads_in_reference_group_order(golden):
+    """classic_cv checkpoints of the reference hold torch.optim.SGD.state_dict() (algorithmbase.py:466): param_groups = [no_decay, decay]
+    (nets/utils.py:77-97), state[idx] = {'momentum_buffer'}.  Index -> name map and group sizes come from the reference run (ema.npz wrn/opt/*)."""
+    g = golden("ema")
+    wcfg = W.WrnCfg(num_classes=10, **W.WRN_TINY_TEST)
+    shapes = dict(W.param_shapes(wcfg))
+    names = [str(n) for n in g["wrn/opt/names_by_index"]]
+    sizes = [int(v) for v in g["wrn/opt/group_sizes"]]
+    assert [str(k) for k in g["wrn/opt/state_keys"]] == ["momentum_buffer"]
+    rng = np.random.Generator(np.random.PCG64(19))
+    state, groups, i, want = {}, [], 0, {}
+    for sz, wd in zip(sizes, g["wrn/opt/group_wd"]):
+        groups.append({"params": list(range(i, i + sz)), "lr": 0.03, "weight_decay": float(wd), "momentum": 0.9, "nesterov": True})
+        for j in range(i, i + sz):
+            want[names[j]] = rng.standard_normal(shapes[names[j]]).astype(np.float32)
+            state[j] = {"momentum_buffer": torch.from_numpy(want[names[j]])}
+        i += sz
+    alg = get_algorithm(_args(algorithm="srpseudolabel", optim="SGD", lr=0.03, momentum=0.9, weight_decay=5e-4, layer_decay=1.0,
+                              num_warmup_iter=0, p_cutoff=0.95, unsup_warm_up=0.4, feature_dim=W.channels(wcfg)[3]), wrn.wrn_tiny_test)
+    alg.optimizer.load_state_dict({"state": state, "param_groups": groups})
+    assert alg.optimizer.step_count == 1              # buffers exist: the next step must not re-initialise them with the gradient
+    for n in names:
+        o = alg.model.offsets[n][0]
+        assert np.array_equal(alg.optimizer.buf[o:o + want[n].size].cpu().numpy(), want[n].ravel()), n
+    # the engine's own weight-decay table agrees with the reference's two groups
+    wd_of = {n: float(wd) for sz, wd, lo in zip(sizes, g["wrn/opt/group_wd"], np.cumsum([0] + sizes[:-1])) for n in names[lo:lo + sz]}
+    tab = alg.optimizer.table.cpu().numpy().view([("end", "<i8"), ("wd", "<f4"), ("pad", "<f4")])
+    for (n, _), row in zip(alg.model.names_shapes, tab):
+        assert float(row["wd"]) == pytest.approx(wd_of[n]), n
+    # an empty torch state (checkpoint written before the first step) leaves the first-step initialisation in place
+    alg.optimizer.load_state_dict({"state": {}, "param_groups": groups})
+    assert alg.optimizer.step_count == 0 and float(alg.optimizer.buf.abs().max()) == 0.0

@@ -91,7 +91,9 @@ def test_sr_train_step_trace(golden, name, tr):
         if free:
             h = alg.hooks_dict["MaskingHook"]
             assert float(h.time_p) == pytest.approx(float(g[f"{p}/time_p"]), rel=2e-2)
-            assert rel(h.p_model.cpu(), g[f"{p}/p_model"]) < 2e-2 and rel(h.label_hist.cpu(), g[f"{p}/label_hist"]) < 0.2
+            assert rel(h.p_model.cpu(), g[f"{p}/p_model"]) < 2e-2
+            # label_hist is an EMA of an argmax HISTOGRAM (freematch/utils.py:44-49): identical pseudo labels -> equal to round-off
+            assert rel(h.label_hist.cpu(), g[f"{p}/label_hist"]) < 2e-2, rel(h.label_hist.cpu(), g[f"{p}/label_hist"])
         mr = float(g[f"{p}/max_reward"])
         assert (np.isinf(mr) and np.isinf(float(alg.max_reward))) or float(alg.max_reward) == pytest.approx(mr, rel=1e-2), p
         if not fix and masks.shape == want.shape and (masks == want).all():
@@ -142,7 +144,6 @@ def test_srpseudolabel_trace(golden):
     alg.model.load_state_dict(T(synth.synth_params(V.param_shapes(cfg), seed)))
     alg.rewarder.load_state_dict(T(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), seed + 1)))
     alg.generator.load_state_dict(T(synth.synth_params(S.generator_shapes(cfg.embed_dim), seed + 2)))
-    flips = total = 0
     for n, it in enumerate(tr["its"]):
         p = f"it{it}"
         alg.it = it
@@ -159,23 +160,18 @@ def test_srpseudolabel_trace(golden):
         alg.call_hook("after_train_step")
         assert alg.trace["K"] == K
         masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
-        bad = masks != g[f"{p}/masks"]
-        flips += int(bad.sum())
-        total += bad.size
-        # a flipped row must sit ON the threshold: |max_prob - p_cutoff| within the bf16-backbone noise of the probabilities
+        # the fixture's cut-off (0.165) is at least 6.6e-3 away from every max-prob the reference thresholds (`mask_probs`, swept in
+        # oracle/gen_golden.py): the bf16-operand backbone moves a max-prob by far less, so EVERY mask of every pass must match
         mpv = alg.trace["max_probs"].cpu().numpy().reshape(masks.shape)
-        assert np.all(np.abs(mpv[bad] - tr["p_cutoff"]) < 6e-3), (p, mpv[bad])
-        if bad.any():
-            continue          # a flipped mask changes this step's loss by construction; later steps are still checked
+        assert float(np.abs(g[f"{p}/mask_probs"] - tr["p_cutoff"]).min()) > 6e-3
+        assert float(np.abs(mpv - g[f"{p}/mask_probs"]).max()) < 3e-3, (p, float(np.abs(mpv - g[f"{p}/mask_probs"]).max()))
+        assert np.array_equal(masks, g[f"{p}/masks"]), (p, mpv[masks != g[f"{p}/masks"]])
         for k_ in ("sup_loss", "unsup_loss", "total_loss"):
             assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
         ftol = 2e-2 + 1.5e-2 * sum(1 for j in tr["its"][:n] if j >= tr["num_warmup_iter"])
         for k_ in ("x_lb", "x_ulb_w"):
             assert rel(out["feat"][k_].cpu(), g[f"{p}/feat/{k_}"]) < ftol, (p, k_)
         assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
-    # the fixture puts the cut-off (0.16) in the bulk of a random-init model's max-prob distribution, so a few rows sit on
-    # it; identical masks on identical probabilities are covered bit-exactly by test_gpu_kernels (golden probs)
-    assert flips <= 0.03 * total, (flips, total)
 
 
 def test_evaluate_matches_oracle_forward():
@@ -261,6 +257,26 @@ def test_full_size_step_properties():
     assert float(log["train/util_ratio"]) == pytest.approx(float(tr["masks"][0].mean()), abs=1e-7)
     for k_ in ("sup_loss", "unsup_loss", "total_loss"):
         assert np.isfinite(float(log["train/" + k_]))
+    # --- the step's logits against the fp32 CPU oracle (oracle/vit_ref.py, pinned to the reference by tests/golden/vit.npz) on the same 24 images
+    # and the same DropPath draws: pass 0 (labelled rows = gradient rows with activations kept; weak rows = the 105-image launch that is read;
+    # strong rows = read or deferred launch, both the production fused chain attn_block -> mlp_fused_proj + ln_next) and the last pass
+    # (strong rows = gradient rows).  One 24-image CPU forward of ViT-S/2 takes a few seconds.
+    Pt = {k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()}
+    x24 = torch.from_numpy(np.concatenate([b["x_lb"], b["x_ulb_w"], b["x_ulb_s"]]))
+    plan = alg._plans[(8, 8, 8, True, False)]
+    assert plan.inf_cols.numel() * 257 >= vit._FUSED_MLP_MIN_ROWS and plan.rest_cols.numel() * 257 >= vit._FUSED_MLP_MIN_ROWS   # fused launches
+    L = tr["logits"].cpu().numpy()
+    for k in (0, K):
+        with torch.no_grad():
+            ref = V.vit_forward(Pt, x24, cfg, dps[k])
+        want_l, want_f = ref["logits"].numpy(), ref["feat"].numpy()
+        for name, rows in (("lb", slice(0, 8)), ("weak", slice(8, 16)), ("strong", slice(16, 24))):
+            assert rel(L[k, rows], want_l[rows]) < 2e-2, (k, name, rel(L[k, rows], want_l[rows]))
+            assert rel(tr["feats"][k, rows].cpu().numpy(), want_f[rows]) < 2e-2, (k, name)
+        # ... so the engine's pseudo labels are the oracle's wherever the oracle's own top-2 margin exceeds the logit tolerance
+        top2 = np.sort(want_l[8:16], axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 4e-2 * np.abs(want_l[8:16]).max()
+        assert np.array_equal(mi[k][clear], want_l[8:16].argmax(1)[clear]), k
     # --- reproducibility of the forward / filter
     tr2 = runs[1][3]
     assert torch.equal(tr["logits"], tr2["logits"]) and all(torch.equal(a, b_) for a, b_ in zip(tr["masks"], tr2["masks"]))
@@ -405,3 +421,62 @@ def test_mixed_forward_computes_every_row(monkeypatch):
         lg, _, _ = alg.model.forward_features(imgs, idx, dpk, save=False)
         torch.cuda.synchronize()
         assert torch.equal(lg.cpu(), L0[k, rows].cpu()), k
+
+
+def test_deferred_share_autotune_picks_a_candidate_and_changes_no_result():
+    """srflexmatch._DeferTuner: in the first steps of a regime every candidate share of deferred inference rows runs WARM + TIMED real training
+    steps; afterwards the median-fastest one is kept.  The split is pure scheduling: the logits / masks / losses of a step under ANY candidate equal
+    those under the untuned rule bit for bit (same kernels, rows independent)."""
+    from semireward_amd.algorithms import srflexmatch as SF
+    assert SF._DEFER_AUTOTUNE
+    NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
+               num_warmup_iter=5120)
+    b = synth.synth_batch(104, 8, 8, 32, 100, 50000)
+    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
+    dps = [torch.from_numpy(synth.synth_droppath(300 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
+
+    def fresh():
+        alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
+        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+        alg.it = 30000
+        alg.optimizer.sched_step = alg.it
+        alg.inject_droppath = dps
+        return alg
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    key = (8, 8, 8, True, False)
+    # (a) every candidate split gives the bits of the untuned rule
+    ref = None
+    for frac in (None,) + SF._DeferTuner.CANDIDATES:
+        alg = fresh()
+        alg._plans[key] = alg._make_plan(8, 8, 8, defer_fraction=frac)       # pinned plan: no tuner is created for an existing key
+        alg.trace = {}
+        out, log = alg.train_step(**alg.process_batch(**batch))
+        torch.cuda.synchronize()
+        assert key not in alg._tuners
+        got = (alg.trace["logits"].clone(), [m.clone() for m in alg.trace["masks"]], alg.trace["reward"].clone(), float(log["train/total_loss"]),
+               int(alg._plans[key].rest_cols.numel()))
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]) and all(torch.equal(x, y) for x, y in zip(got[1], ref[1])) and torch.equal(got[2], ref[2])
+            assert got[3] == ref[3]
+    # (b) the tuner runs its schedule over real steps and settles
+    alg = fresh()
+    alg.inject_droppath = None
+    per = SF._DeferTuner.WARM + SF._DeferTuner.TIMED
+    seen = []
+    for i in range(per * len(SF._DeferTuner.CANDIDATES) + 3):
+        alg.out_dict, alg.log_dict = alg.train_step(**alg.process_batch(**batch))
+        alg.call_hook("after_train_step")
+        alg.it += 1
+        seen.append(int(alg._plans[key].rest_cols.numel()))
+        if i == 0:
+            ncand = len(alg._tuners[key][1])
+            assert ncand >= 4
+    assert key not in alg._tuners and key in alg.defer_report
+    rep = alg.defer_report[key]
+    assert rep["deferred_images"] == seen[-1] and len(set(seen[:per * ncand])) == ncand and len(set(seen[per * ncand:])) == 1
+    assert len(rep["ms_per_step"]) == ncand and all(0.5 < v < 1000.0 for v in rep["ms_per_step"].values())
+    best = min(rep["ms_per_step"], key=rep["ms_per_step"].get)
+    assert abs(float(best) - rep["chosen"]) < 1e-3
+    assert np.isfinite(float(alg.log_dict["train/total_loss"]))

@@ -32,8 +32,20 @@ def build(tag):
     return vit.vit_small_patch2_32(num_classes=100, device=DEV), V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
 
 
+class _Calls:
+    """Counts the calls of one ops entry point (which kernels a forward really took)."""
+
+    def __init__(self, monkeypatch, name):
+        self.n, fn = 0, getattr(ops, name)
+
+        def wrapped(*a, **k):
+            self.n += 1
+            return fn(*a, **k)
+        monkeypatch.setattr(ops, name, wrapped)
+
+
 @pytest.mark.parametrize("tag", ["tiny", "small_p2_32", "small_p16_224", "base_p16_96"])
-def test_vit_matches_reference_golden(golden, tag):
+def test_vit_matches_reference_golden(golden, tag, monkeypatch):
     g = golden({"small_p16_224": "vit_p16", "base_p16_96": "vit_b16_96"}.get(tag, "vit"))
     C, B, seed = [int(v) for v in g[f"{tag}/meta"]]
     model, cfg = build(tag)
@@ -53,8 +65,26 @@ def test_vit_matches_reference_golden(golden, tag):
     lg3, ft3, _ = model.forward_features(x, None, dp, save=False)
     if tag in ("tiny", "base_p16_96"):           # no fused-MLP path at these widths: the same kernels, the same bits
         assert torch.equal(lg2, lg3) and torch.equal(ft2, ft3)
-    else:   # ViT-S width: rows without a backward take the fused LN2+MLP kernel (same rounding points, other fp32 sum order)
-        assert rel(lg3.cpu(), lg2.cpu().numpy()) < 6e-3 and rel(ft3.cpu(), ft2.cpu().numpy()) < 6e-3   # (inference rows: fused qkv + attention kernel)
+    else:   # ViT-S width, a launch below _FUSED_MLP_MIN_ROWS: fused qkv + attention kernel, then proj GEMM + LayerNorm + two MLP GEMMs
+        assert rel(lg3.cpu(), lg2.cpu().numpy()) < 6e-3 and rel(ft3.cpu(), ft2.cpu().numpy()) < 6e-3
+        # ---- the PRODUCTION inference chain of a training step (the launches of >= _FUSED_MLP_MIN_ROWS rows that bench.py times): per block
+        # attn_block(out_scale = DropPath factor) -> mlp_fused_proj(ao_scaled, row_scale1 / row_scale2, ln_next) -- against the REFERENCE's
+        # golden logits, in eval mode and with the injected DropPath table (factors 0 and 1 / keep_prob live in every block after the first)
+        monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1024)
+        fused, attn, lnf = _Calls(monkeypatch, "mlp_fused_proj"), _Calls(monkeypatch, "attn_block_fused"), _Calls(monkeypatch, "layernorm_fwd")
+        lg5, ft5, _ = model.forward_features(x, None, None, save=False)
+        assert fused.n == cfg.depth and attn.n == cfg.depth and lnf.n == 1, (fused.n, attn.n, lnf.n)    # ln_next hand-off: ONE norm1 launch
+        assert rel(lg5.cpu(), g[f"{tag}/eval_logits"]) < LOGIT_REL_L2 and rel(ft5.cpu(), g[f"{tag}/eval_feat"]) < LOGIT_REL_L2
+        lg6, ft6, _ = model.forward_features(x, None, dp, save=False)
+        assert fused.n == 2 * cfg.depth and lnf.n == 2
+        assert float(dp.min()) == 0.0 and float(dp.max()) > 1.0                                       # dropped and re-scaled rows both present
+        assert rel(lg6.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft6.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
+        assert rel(lg6.cpu(), lg2.cpu().numpy()) < 6e-3 and rel(ft6.cpu(), ft2.cpu().numpy()) < 6e-3  # ... and against the rows with a backward
+        # rows permuted through img_index: the fused chain gives the permuted rows bit for bit (rows are independent)
+        permf = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(DEV)
+        lg7, _, _ = model.forward_features(x, permf.to(torch.int32), dp[:, :, permf].contiguous(), save=False)
+        assert torch.equal(lg7, lg6[permf])
+        monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1 << 30)       # the rest of the test: the small-launch kernels again
     assert rel(lg2.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft2.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
     # gather path: rows permuted through img_index give permuted outputs
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
