@@ -41,16 +41,19 @@ class _DeferTuner:
     chain (masks, losses, the backward of the gradient rows) waits for one of them to retire; too few deferred rows and the read launch alone
     delays that chain.  The balance moves with the token count, the batch, K and the CU count, and it is sharp (95 deferred images
     1542 img/s, 98 -> 1469), so it is MEASURED: every candidate share runs WARM + TIMED real training steps (nothing is thrown away; the split
-    does not change a single result -- rows are independent), step time = HIP events at consecutive step starts, one host synchronisation when
-    the last candidate is done; the median-fastest candidate is kept for the rest of the run.  Cached per plan key."""
+    does not change a single result -- rows are independent), step time = HIP events at consecutive step starts (one host synchronisation per
+    candidate); after the coarse candidates the two neighbours of the winner are measured as well, and the median-fastest share is kept for the
+    rest of the run.  Cached per plan key."""
     CANDIDATES = (0.35, 0.42, _DEFER_SEED, 0.53, 0.58, 1.0)      # 1.0 = every row nothing reads (clipped to what may be deferred)
+    REFINE = 0.025
     WARM, TIMED = 1, 3
 
-    def __init__(self, fractions):
-        self.fracs = list(fractions)
-        self.marks = []                     # one event per step start, + the end marker
-        self.best = None
-        self.report = None
+    def __init__(self, fractions, refine=True):
+        self.queue = list(fractions)        # candidates still to run
+        self.refine = refine
+        self.results = {}                   # share -> median ms per step
+        self.cur, self.marks = None, []
+        self.best = self.report = None
 
     @property
     def done(self):
@@ -58,25 +61,29 @@ class _DeferTuner:
 
     def fraction(self):
         """Share for the step that starts now (records the step-start event while tuning)."""
-        if self.done:
+        if self.best is not None:
             return self.best
         per = self.WARM + self.TIMED
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.marks.append(e)
-        i = len(self.marks) - 1             # index of this step
-        if i < per * len(self.fracs):
-            return self.fracs[i // per]
-        self.marks[-1].synchronize()
-        ms = [self.marks[j].elapsed_time(self.marks[j + 1]) for j in range(i)]
-        med = []
-        for c in range(len(self.fracs)):
-            t = sorted(ms[c * per + self.WARM:(c + 1) * per])
-            med.append(t[len(t) // 2])
-        self.best = self.fracs[min(range(len(med)), key=med.__getitem__)]
-        self.report = {"%.3f" % f: round(m, 4) for f, m in zip(self.fracs, med)}
-        self.marks = []
-        return self.best
+        if self.cur is not None and len(self.marks) == per + 1:          # the current candidate's steps are marks[0] .. marks[per]
+            e.synchronize()
+            ms = sorted(self.marks[j].elapsed_time(self.marks[j + 1]) for j in range(self.WARM, per))
+            self.results[self.cur] = ms[len(ms) // 2]
+            self.marks, self.cur = self.marks[-1:], None                 # this event also starts the next candidate's first step
+        if self.cur is None:
+            if not self.queue and self.refine and self.results:
+                b = min(self.results, key=self.results.get)
+                self.queue = [f for f in (round(b - self.REFINE, 4), round(b + self.REFINE, 4)) if 0.05 < f < 0.95 and b < 1.0 and f not in self.results]
+                self.refine = False
+            if not self.queue:
+                self.best = min(self.results, key=self.results.get)
+                self.report = {"%.3f" % f: round(m, 4) for f, m in sorted(self.results.items())}
+                self.marks = []
+                return self.best
+            self.cur = self.queue.pop(0)
+        return self.cur
 
 
 class _OwnStreamScope:
@@ -455,7 +462,10 @@ class SRConsistencyBase(AlgorithmBase):
         tn = self._tuners.get(key)
         if tn is not None:
             tuner, cand = tn
-            self._plans[key] = cand[tuner.fraction()]
+            f = tuner.fraction()
+            if f not in cand:                  # a neighbour of the coarse winner (second pass)
+                cand[f] = self._make_plan(nl, nu, K, defer_fraction=f)
+            self._plans[key] = cand[f]
             if tuner.done:
                 self.defer_report[key] = dict(chosen=tuner.best, deferred_images=int(self._plans[key].rest_cols.numel()), ms_per_step=tuner.report)
                 del self._tuners[key]

@@ -154,10 +154,11 @@ __global__ __launch_bounds__(256) void flexmatch_mask_lds_kernel(const float* __
     const int max_cls = smax[0], max_all = max(max_cls, s_hist[C]);
     if (max_all < ulb_dest_len) {
       const int den = thresh_warmup ? max_all : max_cls;
-      // thresh_warmup False and no row selected yet: the reference's max() over an empty Counter raises ValueError (srflexmatch/utils.py:35);
-      // here classwise_acc stays as it is and bit 1 of the error word is set for the host (ops.check_label_errors)
-      if (den == 0) { if (tid == 0) atomicOr(&srhip_index_err, 2); }
-      else for (int c = tid; c < C; c += nt) s_acc[c] = (float)((double)s_hist[c] / (double)den);
+      // den == 0 (thresh_warmup False, no entry of the table holds a class in [0, C)) cannot coexist with max_all < ulb_dest_len for a table of
+      // -1 / class entries -- the reference's update() is skipped there too (srflexmatch/utils.py:27) -- but a table loaded with foreign
+      // values could get here: classwise_acc then stays as it is instead of becoming 0 / 0
+      if (den != 0)
+        for (int c = tid; c < C; c += nt) s_acc[c] = (float)((double)s_hist[c] / (double)den);
     }
     __syncthreads();                  // the next pass reads s_acc / s_sel / s_hist; smax is reset after this point
   }
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(256) void flexmatch_mask_kernel(const float* __rest
     const int max_all = smax[1];
     if (max_all < ulb_dest_len) {
       const int den = thresh_warmup ? max_all : smax[0];
-      if (den == 0) { if (threadIdx.x == 0) atomicOr(&srhip_index_err, 2); }         // (see the LDS kernel)
-      else for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      if (den != 0)                                                                   // (see the LDS kernel)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int cnt = __hip_atomic_load(hist + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(classwise_acc + c, (float)((double)cnt / (double)den), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

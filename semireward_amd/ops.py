@@ -533,13 +533,10 @@ def check_label_errors(reset=True):
     _call("srhip_label_error", ctypes.addressof(bits), int(reset), _s())
     _call("srhip_index_error", ctypes.addressof(ibits), int(reset), _s())
     msgs = [m for i, m in enumerate(_LABEL_ERR) if bits.value >> i & 1]
-    if ibits.value & 1:
+    if ibits.value:
         msgs.append("an idx_ulb entry outside [0, ulb_dest_len) reached FlexMatchThresholdingHook.update (srflexmatch/utils.py:59)")
     if msgs:
         raise IndexError("libsrhip: " + "; ".join(msgs))
-    if ibits.value & 2:
-        raise ValueError("libsrhip: FlexMatchThresholdingHook.update with thresh_warmup False before any row was selected: max() arg is an "
-                         "empty sequence (srflexmatch/utils.py:35)")
 
 
 def adam_flat(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):

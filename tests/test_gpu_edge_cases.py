@@ -259,9 +259,10 @@ def test_out_of_range_indices_and_labels_raise_like_the_reference():
     ops.check_label_errors()
 
 
-def test_flexmatch_without_warmup_before_any_selection_raises_like_the_reference():
-    """thresh_warmup False and not one row over the cut-off yet: the reference's update() takes max() of an empty Counter and raises ValueError
-    (srflexmatch/utils.py:30-35).  The kernels leave classwise_acc untouched (no 0 / 0 = NaN) and flag it for the next host check."""
+def test_flexmatch_without_warmup_before_any_selection_keeps_the_state():
+    """thresh_warmup False and not one row over the cut-off yet: every entry of selected_label is -1, so max(Counter) == ulb_dest_len and the
+    reference's update() does nothing (srflexmatch/utils.py:27) -- the kernels must leave classwise_acc at 0 (no 0 / 0 = NaN from the
+    "without -1" denominator of :31-35), in the LDS kernel and the general one, and the oracle agrees."""
     C, U, Bu = 5, 16, 4
     ops.check_label_errors()
     for general in (False, True):
@@ -269,14 +270,18 @@ def test_flexmatch_without_warmup_before_any_selection_raises_like_the_reference
             os.environ["SRHIP_FLEXMATCH_GENERAL"] = "1"
         try:
             sel, hist, acc = _flex_engine(C, U, False)
+            st = H.FlexMatchState(U, C, False)
             probs = _probs_with_max([(1, 0.5)] * Bu, C)                    # nothing reaches p_cutoff
             mp, mi = torch.empty(Bu, device=DEV), torch.empty(Bu, dtype=torch.int64, device=DEV)
             ops.row_max(_dev(probs), True, None, mp, mi, Bu, C)
             mask = torch.empty(Bu, device=DEV)
-            ops.flexmatch_mask(mp, mi, _dev(np.arange(Bu, dtype=np.int64)), 0.95, sel, hist, acc, mask, Bu, C, U, False)
-            assert bool(torch.isfinite(acc).all()) and float(acc.abs().max()) == 0.0
-            with pytest.raises(ValueError, match="empty sequence"):
-                ops.check_label_errors()
+            idx = np.arange(Bu, dtype=np.int64)
+            for _ in range(2):
+                ops.flexmatch_mask(mp, mi, _dev(idx), 0.95, sel, hist, acc, mask, Bu, C, U, False)
+                want = st.masking(probs, idx, 0.95)
+                assert np.array_equal(mask.cpu().numpy(), want)
+                assert bool(torch.isfinite(acc).all()) and np.array_equal(acc.cpu().numpy(), st.classwise_acc)
+            assert float(acc.abs().max()) == 0.0 and int(hist[C]) == U
             ops.check_label_errors()
         finally:
             os.environ.pop("SRHIP_FLEXMATCH_GENERAL", None)

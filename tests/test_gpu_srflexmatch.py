@@ -465,7 +465,7 @@ def test_deferred_share_autotune_picks_a_candidate_and_changes_no_result():
     alg.inject_droppath = None
     per = SF._DeferTuner.WARM + SF._DeferTuner.TIMED
     seen = []
-    for i in range(per * len(SF._DeferTuner.CANDIDATES) + 3):
+    for i in range(per * (len(SF._DeferTuner.CANDIDATES) + 2) + 3):
         alg.out_dict, alg.log_dict = alg.train_step(**alg.process_batch(**batch))
         alg.call_hook("after_train_step")
         alg.it += 1
@@ -475,8 +475,8 @@ def test_deferred_share_autotune_picks_a_candidate_and_changes_no_result():
             assert ncand >= 4
     assert key not in alg._tuners and key in alg.defer_report
     rep = alg.defer_report[key]
-    assert rep["deferred_images"] == seen[-1] and len(set(seen[:per * ncand])) == ncand and len(set(seen[per * ncand:])) == 1
-    assert len(rep["ms_per_step"]) == ncand and all(0.5 < v < 1000.0 for v in rep["ms_per_step"].values())
+    assert rep["deferred_images"] == seen[-1] == seen[-2] and len(set(seen[:per * ncand])) == ncand       # coarse pass: every candidate ran
+    assert ncand <= len(rep["ms_per_step"]) <= ncand + 2 and all(0.5 < v < 1000.0 for v in rep["ms_per_step"].values())
     best = min(rep["ms_per_step"], key=rep["ms_per_step"].get)
     assert abs(float(best) - rep["chosen"]) < 1e-3
     assert np.isfinite(float(alg.log_dict["train/total_loss"]))
