@@ -33,6 +33,10 @@ SIGNATURES = {
     "srhip_attn_block_fused": (I, [P, P, P, P, P, P, I, I, I, I, F, P]),
     "srhip_gelu_eval": (I, [P, P, P, I, P]),
     "srhip_mlp_fused_proj": (I, [P, P, P, P, P, P, I, P, P, F, P, P, P, P, P, I, P, P, P, I, I, I, P]),
+    "srhip_mlp_ps_pack_bytes": (c_longlong, [I, I]),
+    "srhip_mlp_ps_pack": (I, [P, P, P, P, I, I, P]),
+    "srhip_mlp_ps_pack_blocks": (I, [P, P, I, P, I, I, P]),
+    "srhip_mlp_ps_proj": (I, [P, P, P, P, P, P, I, P, P, F, P, P, P, I, P, P, P, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd_ws_floats": (L, [I, I, I, I, I]),

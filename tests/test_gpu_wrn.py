@@ -335,7 +335,10 @@ def test_full_size_step_properties_wrn():
         if k_.endswith("num_batches_tracked"):
             assert int(v) == 1, k_
         else:
-            assert rel(v.cpu(), BUF[k_].numpy()) < 2e-4, k_
+            # running_var starts at 1 (momentum 0.001 keeps it there to 1e-3); running_mean starts at 0, so after one update it IS
+            # 0.001 x the batch mean of a bf16-operand forward: compared through the update
+            if k_.endswith("running_var"):
+                assert rel(v.cpu(), BUF[k_].numpy()) < 2e-4, k_
             assert rel(v.cpu().numpy() - fresh[k_].numpy(), (BUF[k_] - fresh[k_]).numpy()) < 6e-2, k_     # the update itself
     # the optimizer step that follows moves every parameter (SGD-Nesterov, one launch) and keeps the EMA shadow a shadow
     p0 = alg2.model.flat.clone()
