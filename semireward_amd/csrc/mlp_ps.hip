@@ -21,7 +21,8 @@
 // in consumption order, every fragment 1 KiB in lane order, so a DMA instruction reads 1 KiB of contiguous memory and a consumer lane reads its
 // 16 bytes at 16 * lane (no swizzle, no bank conflict).  The attention output rows take the same road (one 8 KiB stage per 32 input columns).
 //
-// Schedule of one 128-row tile (group = 2 ring stages, one s_barrier per group, the DMA 5 groups ahead):
+// Schedule of one 128-row tile (group = 2 ring stages, one s_barrier per group, the DMA 5 groups ahead; the stream is issued by the
+// producer waves during the projection and by the consumer waves during the MLP -- the role with spare issue slots in that phase):
 //   projection   12 half-phases x [ao | Wp0] [Wp1 | Wp2]   C: 24 MFMAs per half-phase on x (the accumulators start at x + rs1 bp); P: idle
 //   LayerNorm    C normalises x1 from its accumulators and hands the bf16 rows to P through the exchange buffers (6 rounds of 16 KiB)
 //   MLP          2 nch + 2 half-phases x 3 groups [W1 (tile h, k-third) | W2 (tile h - 2, output third)]:
@@ -170,53 +171,44 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
                                           // it plus an immediate, the weight DMA takes it as its per-lane offset with wave * FRB in the scalar offset)
 #define LRG (lfo + 2 * rg * FRB)          /* ... inside the wave's pair of B fragments (exchange buffers, attention-output stages): re-made per use */
   const int ntiles = (a.M + 127) / 128;
-  int ao_lane = 0;                        // (per tile) byte offset of the lane's 16 bytes inside the attention-output rows it moves
+  int ao_lane = 0;                        // producer, per tile: byte offset of the lane's 16 bytes inside the attention-output rows its wave moves
 
-  auto issue_stage = [&](auto slotc, bool is_ao, bool valid, int soff) __attribute__((always_inline)) {
-    constexpr int slot = decltype(slotc)::value;
+  // ---- who issues the DMA.  An LDS-DMA instruction blocks its wave for ~100+ cycles, and when all eight waves issue right behind a barrier
+  // both waves of every SIMD are stuck in it together: the matrix pipe idles ~250 cycles per group (first version: 80 us per launch with the
+  // MFMAs, reads and DMAs knocked out).  So the stream is issued by ONE role at a time, the other one computes meanwhile:
+  //   projection groups (and the initial fill): the PRODUCER waves, which have nothing else to do there -- 4 instructions per group behind the barrier;
+  //   MLP groups: the CONSUMER waves, one instruction behind each of the four MFMA pairs of a group -- beside the producer's GELU + MFMAs.
+  // A wave of the issuing role moves pieces 2 r and 2 r + 1 (r = its row group) of both stages of a group: part = 2 * stage + which.
+  auto issue_part = [&](auto rqc, auto partc, int gi) __attribute__((always_inline)) {
+    constexpr int RQ = decltype(rqc)::value, part = decltype(partc)::value, st = part >> 1, slot = 2 * RQ + st;
     if (DBG & 2) return;
-    lds_void* dst = (lds_void*)(ring + slot * STB + wave * FRB);
-    if (is_ao) __builtin_amdgcn_raw_ptr_buffer_load_lds(rao, dst, 16, ao_lane, soff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(valid ? rpk : rnull, dst, 16, lfo, valid ? soff + wave * FRB : 0, 0, 0);
-  };
-  // group gi (ring group RQ = gi % NGR) = ring stages 2 gi, 2 gi + 1 (schedule in the header); groups past the end are out-of-range
-  // no-ops that keep the vmcnt arithmetic uniform
-  auto issue_group = [&](auto rqc, int gi) __attribute__((always_inline)) {
-    constexpr int RQ = decltype(rqc)::value;
-    using S0 = std::integral_constant<int, 2 * RQ>;
-    using S1 = std::integral_constant<int, 2 * RQ + 1>;
+    const int piece = 2 * rg + (part & 1);
+    lds_void* dst = (lds_void*)(ring + slot * STB + piece * FRB);
     if (gi < PROJ_G) {
       const int hp = gi >> 1;
-      if constexpr ((RQ & 1) == 0) {        // PROJ_G is a multiple of NGR (even): the group's parity is the ring group's
-        issue_stage(S0{}, true, true, 64 * hp);
-        issue_stage(S1{}, false, true, (3 * hp) * STB);
-      } else {
-        issue_stage(S0{}, false, true, (3 * hp + 1) * STB);
-        issue_stage(S1{}, false, true, (3 * hp + 2) * STB);
-      }
+      // attention-output stage of half-phase hp: fragment (i, kk) = rows 32 i .. of the tile, columns 32 hp + 16 kk ..: the wave's two pieces are
+      // its own row group, kk = 0 / 1 (32 bytes apart)
+      if constexpr ((RQ & 1) == 0 && st == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rao, dst, 16, ao_lane, 64 * hp + 32 * (part & 1), 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rpk, dst, 16, lfo, (3 * hp + ((RQ & 1) ? 1 + st : 0)) * STB + piece * FRB, 0, 0);   // [ao | Wp0] [Wp1 | Wp2]
     } else {
       const int gm = gi - PROJ_G, h = gm / 3, kt = gm - 3 * h;
-      issue_stage(S0{}, false, h < NH, (3 * PROJ_HP + 3 * h + kt) * STB);
-      issue_stage(S1{}, false, h >= 2 && h < NH + 2, (3 * PROJ_HP + 6 * nch + 3 * (h - 2) + kt) * STB);
+      const bool valid = st == 0 ? h < NH : (h >= 2 && h < NH + 2);       // positions of the schedule that carry nothing: no-op DMAs (vmcnt stays uniform)
+      const int stage = st == 0 ? 3 * PROJ_HP + 3 * h + kt : 3 * PROJ_HP + 6 * nch + 3 * (h - 2) + kt;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(valid ? rpk : rnull, dst, 16, lfo, valid ? stage * STB + piece * FRB : 0, 0, 0);
     }
   };
-  // before the MFMAs of group G (ring group RQ): group G + 1 has landed for everybody (own pieces by the counted wait, the others' by the
-  // barrier), and the slots of group G - 1 -- consumed by every wave before it arrived here -- take group G + AHEAD
-  auto sync = [&](auto rqc, int G) __attribute__((always_inline)) {
-    constexpr int RQ = decltype(rqc)::value;
-    if constexpr ((DBG & 2) == 0) wait_vm<2 * (AHEAD - 2)>();
-    __builtin_amdgcn_s_barrier();
-    issue_group(std::integral_constant<int, (RQ + AHEAD) % NGR>{}, G + AHEAD);
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  auto issue_group = [&](auto rqc, int gi) __attribute__((always_inline)) {
+    issue_part(rqc, P0{}, gi); issue_part(rqc, P1{}, gi); issue_part(rqc, P2{}, gi); issue_part(rqc, P3{}, gi);
   };
-  auto tile_start = [&](int tile) __attribute__((always_inline)) {
-    // attention-output stage of half-phase hp: fragment (i, kk) = rows 32 i .. of the tile, columns 32 hp + 16 kk ..; piece = wave
-    const int ao_row = min(tile * 128 + 32 * (wave >> 1) + j, a.M - 1);
-    ao_lane = (ao_row * D_ + 16 * (wave & 1) + 8 * hf) * 2;
-    __syncthreads();                       // the previous tile is done with the ring, the exchange buffers (and the bias tables are written)
-    sfor<AHEAD>([&](auto gc) __attribute__((always_inline)) { issue_group(gc, decltype(gc)::value); });
-    if constexpr ((DBG & 2) == 0) wait_vm<2 * (AHEAD - 1)>();       // own pieces of group 0
-    __builtin_amdgcn_s_barrier();
-  };
+  // Group protocol (G = group about to be multiplied, ring group RQ = G % NGR): behind the barrier group G + 1 has landed for everybody -- the
+  // issuing role waited for its own pieces (counted vmcnt: the AHEAD - 2 younger groups stay in flight), the barrier covers the others' -- and the
+  // slots of group G - 1, consumed by every wave before it arrived, take group G + AHEAD.
+  constexpr int VM_STEADY = 4 * (AHEAD - 2);
+#define RQ_OF(RQ, D) std::integral_constant<int, ((RQ) + (D)) % NGR>{}
 #define FRAG(SLOT, F) (((DBG & 4) != 0) ? u32x4_t{(unsigned)(SLOT), 1u, 2u, (unsigned)(F)} \
                                         : *reinterpret_cast<const u32x4_t*>(ring + (SLOT) * STB + (F) * FRB + lfo))
 
@@ -226,13 +218,30 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
       const int rowc = min(tile * 128 + 32 * rg + j, a.M - 1);
       float rs2v = 1.0f;
       if (a.rs2) rs2v = a.rs2[rowc / a.rows_per_sample];
-      tile_start(tile);
-      for (int u3 = 0; u3 < PROJ_G / NGR; ++u3)
-        sfor<NGR>([&](auto rqc) __attribute__((always_inline)) { sync(rqc, NGR * u3 + decltype(rqc)::value); });
+      {
+        const int ao_row = min(tile * 128 + 32 * rg + j, a.M - 1);
+        ao_lane = (ao_row * D_ + 8 * hf) * 2;
+      }
+      __syncthreads();                     // the previous tile is done with the ring, the exchange buffers (and the bias tables are written)
+      sfor<AHEAD>([&](auto gc) __attribute__((always_inline)) { issue_group(gc, decltype(gc)::value); });
+      if constexpr ((DBG & 2) == 0) wait_vm<4 * (AHEAD - 1)>();       // own pieces of group 0
+      __builtin_amdgcn_s_barrier();
+      // projection groups: wait for the own pieces of group G + 1, barrier, issue group G + AHEAD while it is a projection group (the consumer
+      // takes over with the first MLP group: the last AHEAD iterations only drain, with the exact count of what is still in flight)
+      for (int u3 = 0; u3 < PROJ_G / NGR - 1; ++u3)
+        sfor<NGR>([&](auto rqc) __attribute__((always_inline)) {
+          if constexpr ((DBG & 2) == 0) wait_vm<VM_STEADY>();
+          __builtin_amdgcn_s_barrier();
+          issue_group(RQ_OF(decltype(rqc)::value, AHEAD), NGR * u3 + decltype(rqc)::value + AHEAD);
+        });
+      sfor<NGR>([&](auto rqc) __attribute__((always_inline)) {
+        constexpr int RQ = decltype(rqc)::value, G = PROJ_G - NGR + RQ;                 // group G + 1 must have landed; issued: up to PROJ_G - 1
+        constexpr int infl = (PROJ_G - 1) - (G + 1);                                     // own groups younger than G + 1
+        if constexpr ((DBG & 2) == 0) wait_vm<4 * (infl < 0 ? 0 : infl > AHEAD - 2 ? AHEAD - 2 : infl)>();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (G + AHEAD < PROJ_G) issue_group(RQ_OF(RQ, AHEAD), G + AHEAD);
+      });
       u32x4_t fa0[4], fa1[4];
-      // first quad of the first fc1 stage (group PROJ_G = ring group 0 landed with the last sync)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) fa0[f] = FRAG(0, f);
       // ---- LayerNorm'ed rows from the consumer: 6 rounds of 4 k-steps through the exchange buffers
       u32x4_t xn[KS];
 #pragma unroll
@@ -243,6 +252,10 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();      // ... and read
       }
+      // first quad of the first fc1 stage: group PROJ_G (ring group 0), issued by the consumer waves behind the projection, landed for everybody with
+      // the last hand-off round (the consumer waited for its pieces in front of that barrier)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fa0[f] = FRAG(0, f);
       f32x16_t acc1[2];
       u32x4_t hq;
       auto acc_start = [&](auto pc, int T) __attribute__((always_inline)) {       // fc1 bias of tile T in the result layout
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
           constexpr int kt = decltype(ktc)::value;
           constexpr int RQ = 3 * p + kt, slot = 2 * RQ, nslot = 2 * ((RQ + 1) % NGR);
           constexpr bool G = GEL && kt < 2;
-          sync(std::integral_constant<int, RQ>{}, PROJ_G + 3 * h + kt);
+          __builtin_amdgcn_s_barrier();    // (the consumer waves issue and wait for the MLP groups)
           if constexpr (ACT) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) fa1[f] = FRAG(slot, 4 + f);
@@ -400,7 +413,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
           }
       }
       PDBG_T(0);
-      tile_start(tile);
+      __syncthreads();                     // the previous tile is done with the ring, the exchange buffers (and the bias tables are written)
+      __builtin_amdgcn_s_barrier();        // group 0 has landed (the producer waves issued and waited)
 #pragma unroll
       for (int T = 0; T < NT; ++T)
 #pragma unroll
@@ -430,13 +444,14 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
       };
       // one half-phase = 12 pairs over three stages in slots S0, S1, S2; SYNC(i) runs in front of pair i (i = 0, 4, 8); the look-ahead of the last
       // two pairs goes to the NEXT half-phase's first stage (slot SN) and its B fragments (NEXTB(kk))
-#define CHALF(S0, S1, S2, SN, SYNC, NEXTB)                                                                                   \
+#define CHALF(S0, S1, S2, SN, SYNC, NEXTB, ISSUE)                                                                                   \
       sfor<12>([&](auto ic) __attribute__((always_inline)) {                                                                 \
         constexpr int i = decltype(ic)::value, st = i / 4, q = i % 4, n = i + 2, nst = (n % 12) / 4, nq = n % 4;             \
         constexpr int nslot = n >= 12 ? (SN) : nst == 0 ? (S0) : nst == 1 ? (S1) : (S2);                                      \
         if constexpr (q == 0) { SYNC(st); }                                                                                  \
         CREAD(n % 3, nslot, nq)                                                                                              \
         cmma(std::integral_constant<int, i % 3>{}, std::integral_constant<int, q>{}, std::integral_constant<int, st>{});      \
+        ISSUE(st, q);                                                                                                        \
         if constexpr (i == 9) { NEXTB(0); }                                                                                  \
         if constexpr (i == 11) { NEXTB(1); }                                                                                 \
       });
@@ -453,13 +468,18 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
         sfor<3>([&](auto uc) __attribute__((always_inline)) {
           constexpr int u = decltype(uc)::value, sa = 4 * u, sn = (4 * u + 4) % NSL;      // slots sa (ao), sa + 1 (Wp0), sa + 2 (Wp1), sa + 3 (Wp2)
           const int hp = 3 * u3 + u;
-#define PSYNC(st) if constexpr ((st) == 0) sync(std::integral_constant<int, 2 * u>{}, 2 * hp); else if constexpr ((st) == 1) sync(std::integral_constant<int, 2 * u + 1>{}, 2 * hp + 1)
+#define PSYNC(st) if constexpr ((st) < 2) __builtin_amdgcn_s_barrier()                  /* (the producer waves issue and wait for the projection groups) */
 #define PNEXTB(kk) hb[kk] = *reinterpret_cast<const u32x4_t*>(ring + sn * STB + (kk) * FRB + LRG)
-          CHALF(sa + 1, sa + 2, sa + 3, sn + 1, PSYNC, PNEXTB)
+#define PISSUE(st, q)
+          CHALF(sa + 1, sa + 2, sa + 3, sn + 1, PSYNC, PNEXTB, PISSUE)
 #undef PSYNC
 #undef PNEXTB
+#undef PISSUE
         });
       PDBG_T(4);
+      // the consumer takes the DMA stream over: the first AHEAD MLP groups go into the ring groups the projection has left (all but the last one
+      // were free a barrier ago; the last projection group -- ring group NGR - 1 -- is not among them), and land under the LayerNorm below
+      sfor<AHEAD>([&](auto gc) __attribute__((always_inline)) { issue_group(gc, PROJ_G + decltype(gc)::value); });
       // ---- x1 = the accumulators; LayerNorm (vit.py:165 norm2) from the accumulator layout; bf16 rows to the producer in ITS B-fragment order:
       // columns 32 To + 8 q + 4 hf .. + 3 of row j -> fragment k-step 2 To + q / 2, lane (j, q % 2), bytes 8 hf .. + 7
       {
@@ -495,6 +515,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
             }
           }
           wait_lgkm0();
+          if constexpr ((DBG & 2) == 0) { if (r == KS / 4 - 1) wait_vm<4 * (AHEAD - 1)>(); }     // own pieces of the first MLP group: the producer reads it behind this barrier
           __builtin_amdgcn_s_barrier();    // round r is written
           __builtin_amdgcn_s_barrier();    // ... and read
         }
@@ -513,7 +534,11 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
       // fragments were written by the producer in half-phase h - 1, groups 0 and 1, and are requested behind pairs 9 and 11 of that half-phase
       // (group 2).  Half-phases 0 and 1 are syncs only (the producer is two tiles ahead); the steady loop has no branch (the look-ahead behind
       // the last half-phase reads stale LDS that nothing multiplies).
-      sfor<NGR>([&](auto rqc) __attribute__((always_inline)) { sync(rqc, PROJ_G + decltype(rqc)::value); });
+      sfor<NGR>([&](auto rqc) __attribute__((always_inline)) {
+        if constexpr ((DBG & 2) == 0) wait_vm<VM_STEADY>();
+        __builtin_amdgcn_s_barrier();
+        issue_group(RQ_OF(decltype(rqc)::value, AHEAD), PROJ_G + decltype(rqc)::value + AHEAD);
+      });
       hb[0] = *reinterpret_cast<const u32x4_t*>(exch + LRG);              // hidden tile 0 (buffer 0), complete since group 1 of half-phase 1
       hb[1] = *reinterpret_cast<const u32x4_t*>(exch + FRB + LRG);
       CREAD(0, 1, 0)                                                       // first stage of half-phase 2: ring group 0, slot 1
@@ -522,11 +547,13 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
         sfor<2>([&](auto pc) __attribute__((always_inline)) {
           constexpr int p = decltype(pc)::value;
           const int h = 2 * h2 + p;
-#define MSYNC(st) sync(std::integral_constant<int, 3 * p + (st)>{}, PROJ_G + 3 * h + (st))
+#define MSYNC(st) { if constexpr ((DBG & 2) == 0) wait_vm<VM_STEADY>(); __builtin_amdgcn_s_barrier(); }
 #define MNEXTB(kk) hb[kk] = *reinterpret_cast<const u32x4_t*>(exch + (1 - p) * STB + (kk) * FRB + LRG)     /* tile h - 1: buffer (h - 1) & 1 */
-          CHALF(6 * p + 1, 6 * p + 3, 6 * p + 5, (6 * p + 7) % NSL, MSYNC, MNEXTB)
+#define MISSUE(st, q) issue_part(RQ_OF(3 * p + (st), AHEAD), std::integral_constant<int, (q)>{}, PROJ_G + 3 * h + (st) + AHEAD)
+          CHALF(6 * p + 1, 6 * p + 3, 6 * p + 5, (6 * p + 7) % NSL, MSYNC, MNEXTB, MISSUE)
 #undef MSYNC
 #undef MNEXTB
+#undef MISSUE
         });
 #undef CHALF
 #undef CREAD
@@ -584,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ps_kernel(PsArgs a) {
   }
 #undef FRAG
 #undef LRG
+#undef RQ_OF
 }
 
 
@@ -642,10 +670,11 @@ extern "C" int srhip_mlp_ps_proj(const float* x, float* x_out, const void* ao, c
   switch (getenv("SRHIP_PS_DEBUG") ? atoi(getenv("SRHIP_PS_DEBUG")) : 0) {
     case 1: kern = mlp_ps_kernel<1>; break;
     case 2: kern = mlp_ps_kernel<2>; break;
-    case 4: kern = mlp_ps_kernel<4>; break;
-    case 6: kern = mlp_ps_kernel<6>; break;
     case 8: kern = mlp_ps_kernel<8>; break;
+    case 9: kern = mlp_ps_kernel<9>; break;
+    case 10: kern = mlp_ps_kernel<10>; break;
     case 14: kern = mlp_ps_kernel<14>; break;
+    case 15: kern = mlp_ps_kernel<15>; break;
     default: break;
   }
 #endif

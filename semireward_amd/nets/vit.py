@@ -64,8 +64,11 @@ _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 _FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
 _FUSED_PROJ = os.environ.get("SRHIP_FUSED_PROJ", "1") != "0"        # attention projection + residual inside the fused MLP launch
 _FUSED_NEXT_LN = os.environ.get("SRHIP_FUSED_NEXT_LN", "1") != "0"  # ... which then also writes the next block's norm1 output
-# that launch as producer / consumer waves on 32x32x16 MFMAs fed from a packed weight image (csrc/mlp_ps.hip); 0: the 8 x 16-row kernel
-_MLP_PS = os.environ.get("SRHIP_MLP_PS", "1") != "0"
+# that launch as producer / consumer waves on 32x32x16 MFMAs fed from a packed weight image (csrc/mlp_ps.hip).  Opt-in (SRHIP_MLP_PS=1): correct and
+# pinned by the same tests, but measured 12 % SLOWER than the 8 x 16-row kernel at the launch sizes of a step (127 vs 111 us for 105 images on
+# the same box; profiles/r03_mlp_ps_*: half the fragment reads and MFMA issue slots, but the producer waves idle through projection / LayerNorm /
+# epilogue and the consumer waves wait for the producer's GELU inside the MLP loop -- 41 % of the wave cycles are parked at barriers)
+_MLP_PS = os.environ.get("SRHIP_MLP_PS", "0") != "0"
 # the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
 # pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
 _FUSED_MLP_MIN_ROWS = int(os.environ.get("SRHIP_FUSED_MLP_MIN_ROWS", "16384"))
@@ -115,7 +118,7 @@ class VisionTransformer:
                 self.wT[n] = torch.zeros(c, r, dtype=torch.bfloat16, device=self.device)
         # packed (proj | fc1 | fc2) fragment streams of every block for srhip_mlp_ps_proj (inference rows), refreshed with the bf16 operands
         self.mlp_pk = None
-        if ops.mlp_ps_supported(cfg.embed_dim, cfg.hidden) and self.device.type == "cuda":
+        if _MLP_PS and ops.mlp_ps_supported(cfg.embed_dim, cfg.hidden) and self.device.type == "cuda":
             nb = ops.mlp_ps_pack_bytes(cfg.embed_dim, cfg.hidden)
             self.mlp_pk = torch.empty(cfg.depth, nb, dtype=torch.uint8, device=self.device)
             self._pk_offs = torch.tensor([[self.offsets["blocks.%d.%s" % (i, w)][0] for w in ("attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")]

@@ -71,10 +71,15 @@ def test_vit_matches_reference_golden(golden, tag, monkeypatch):
         # attn_block(out_scale = DropPath factor) -> mlp_fused_proj(ao_scaled, row_scale1 / row_scale2, ln_next) -- against the REFERENCE's
         # golden logits, in eval mode and with the injected DropPath table (factors 0 and 1 / keep_prob live in every block after the first)
         monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1024)
-        assert vit._MLP_PS and model.mlp_pk is not None                  # default: the producer / consumer launch (srhip_mlp_ps_proj)
         attn, lnf = _Calls(monkeypatch, "attn_block_fused"), _Calls(monkeypatch, "layernorm_fwd")
-        for ps, entry in ((True, "mlp_ps_proj"), (False, "mlp_fused_proj")):      # ... and the 8 x 16-row kernel it replaced (SRHIP_MLP_PS=0)
+        # the default launch (8 waves x 16 rows, srhip_mlp_fused_proj) and the opt-in producer / consumer launch (SRHIP_MLP_PS=1, srhip_mlp_ps_proj)
+        for ps, entry in ((False, "mlp_fused_proj"), (True, "mlp_ps_proj")):
             monkeypatch.setattr(vit, "_MLP_PS", ps)
+            if ps and model.mlp_pk is None:          # what the constructor does under SRHIP_MLP_PS=1
+                model.mlp_pk = torch.empty(cfg.depth, ops.mlp_ps_pack_bytes(cfg.embed_dim, cfg.hidden), dtype=torch.uint8, device=DEV)
+                model._pk_offs = torch.tensor([[model.offsets["blocks.%d.%s" % (i, w)][0] for w in ("attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")]
+                                               for i in range(cfg.depth)], dtype=torch.int64, device=DEV)
+                model.refresh_packed()
             fused = _Calls(monkeypatch, entry)
             a0, l0 = attn.n, lnf.n
             lg5, ft5, _ = model.forward_features(x, None, None, save=False)
@@ -89,7 +94,7 @@ def test_vit_matches_reference_golden(golden, tag, monkeypatch):
             permf = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(DEV)
             lg7, _, _ = model.forward_features(x, permf.to(torch.int32), dp[:, :, permf].contiguous(), save=False)
             assert torch.equal(lg7, lg6[permf])
-        monkeypatch.setattr(vit, "_MLP_PS", True)
+        monkeypatch.setattr(vit, "_MLP_PS", False)
         monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1 << 30)       # the rest of the test: the small-launch kernels again
     assert rel(lg2.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft2.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
     # gather path: rows permuted through img_index give permuted outputs

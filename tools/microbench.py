@@ -176,22 +176,21 @@ def mlp_ps():
         print("proj+mlp+ln B=%4d (%4d tiles): rows16 %7.1f us %6.1f TF/s | producer/consumer %7.1f us %6.1f TF/s | pack %5.1f us" % (
             B, (M + 127) // 128, t1, fl / t1 / 1e6, t2, fl / t2 / 1e6, tp), flush=True)
         if tuning and B in (105, 200):
-            for dbg in (1, 2, 4, 6, 8, 14):
+            import numpy as np
+            for dbg in (0, 1, 2, 8, 9, 10, 14, 15):
                 os.environ["SRHIP_PS_DEBUG"] = str(dbg)
                 t = timeit(lambda: ops.mlp_ps_proj(x, ao, pk, bp, None, g, b, 1e-6, b1, b2, None, 0, M, D, Hd, ln_next=ln, next_gamma=g, next_beta=b), reps=6)
+                torch.cuda.synchronize()
+                nb = min((M + 127) // 128, 256)
+                buf = (ctypes.c_longlong * (8 * nb))()
+                ops._lib.lib().srhip_mlp_ps_debug(ctypes.cast(buf, ctypes.c_void_p), 8 * nb)
+                st = np.frombuffer(buf, dtype=np.int64).reshape(nb, 8).astype(np.float64)
+                d = lambda i, k: float(np.median(st[:, k] - st[:, i])) / 100.0     # wall_clock64: 100 MHz
+                span = (st[:, 3].max() - st[:, 0].min()) / 100.0
                 x.normal_()
-                print("    debug=%2d (1 no GELU, 2 no DMA, 4 no fragment reads, 8 no MFMA): %7.1f us" % (dbg, t), flush=True)
+                print("    debug=%2d (1 no GELU, 2 no DMA, 4 no reads, 8 no MFMA): %7.1f us | stamps (median over WGs, consumer wave): start %.1f | proj %.1f | LN %.1f | "
+                      "MLP %.1f | epilogue %.1f | total %.1f | first start -> last end %.1f" % (dbg, t, d(0, 1), d(1, 4), d(4, 5), d(5, 2), d(2, 3), d(0, 3), span), flush=True)
             os.environ.pop("SRHIP_PS_DEBUG", None)
-            ops.mlp_ps_proj(x, ao, pk, bp, None, g, b, 1e-6, b1, b2, None, 0, M, D, Hd, ln_next=ln, next_gamma=g, next_beta=b)
-            torch.cuda.synchronize()
-            nb = min((M + 127) // 128, 256)
-            buf = (ctypes.c_longlong * (8 * nb))()
-            ops._lib.lib().srhip_mlp_ps_debug(ctypes.cast(buf, ctypes.c_void_p), 8 * nb)
-            import numpy as np
-            st = np.frombuffer(buf, dtype=np.int64).reshape(nb, 8).astype(np.float64)
-            d = lambda i, k: float(np.median(st[:, k] - st[:, i])) / 100.0     # wall_clock64: 100 MHz
-            print("    stamps (us, median over workgroups; consumer wave 4): start->proj %.1f | proj %.1f | LN hand-off %.1f | MLP %.1f | epilogue %.1f | total %.1f" % (
-                d(0, 1), d(1, 4), d(4, 5), d(5, 2), d(2, 3), d(0, 3)), flush=True)
 
 
 def gemm_qkv5():
