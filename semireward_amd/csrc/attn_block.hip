@@ -200,10 +200,14 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
     constexpr int r = decltype(rc)::value;
     if constexpr ((DBG & 4) == 0) wait_vm<GS*(NG - 3)>();
     __builtin_amdgcn_s_barrier();
-    issue(std::integral_constant<int, r + (NG - 2) * GS>{}, h);
-    issue(std::integral_constant<int, r + (NG - 2) * GS + 1>{}, h);
+    if constexpr ((DBG & 32) == 0) {
+      issue(std::integral_constant<int, r + (NG - 2) * GS>{}, h);
+      issue(std::integral_constant<int, r + (NG - 2) * GS + 1>{}, h);
+    }
     static_assert(GS == 2, "two stages per group");
   };
+  // DBG & 32 ("spread"): the refills are issued one per stage behind the stage's first unit of MFMAs ("stage s asks for stage s + 4") instead of
+  // two in a row behind the group barrier, where all eight waves -- both waves of every SIMD -- block in the DMA issue together (mlp_fused.hip)
   constexpr bool ALL2 = NQT - (EXTRA ? 1 : 0) == 16;          // every wave has two full tiles (N = 257)
   const bool tile1 = ALL2 || wave + 8 < NQT - (EXTRA ? 1 : 0);   // wave-uniform: the second tile exists
 
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_kernel(AbArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       mm(uc);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((DBG & 32) != 0 && u % 4 == 0) issue(std::integral_constant<int, M * SPM + u / 4 + (NG - 2) * GS>{}, h);
     });
     // ---- results of the matrix leave the accumulators
     if constexpr (M == 0) {                            // K image: row = key, 16-byte chunk 4 blk + g holds features 32 blk + 8 g .. + 7
@@ -462,5 +467,8 @@ extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, con
     default: break;
   }
 #endif
+  // (A/B on one box: 41.5 -> 40.8 us per 105 images at N = 197, no difference at N = 257 -- unlike the fused MLP launch, where it is 5 %)
+  static const int spread = getenv("SRHIP_ATTN_SPREAD") ? atoi(getenv("SRHIP_ATTN_SPREAD")) : 1;
+  if (spread) return N == 257 ? launch<257, 32>(a, s) : launch<197, 32>(a, s);
   return N == 257 ? launch<257>(a, s) : launch<197>(a, s);
 }

@@ -88,7 +88,10 @@ __device__ long long srhip_mlp_dbg[8 * 1024];
 #else
 #define MDBG_T(i) do { } while (0)
 #endif
-template <int D_, int DBG, int GS, bool PROJ = false>
+// SPREAD: the ring refills are issued one per stage behind the stage's first MFMA half ("stage j asks for stage j + PD") instead of GS in a row
+// right behind the group barrier.  An LDS-DMA instruction blocks its wave for ~100 cycles, and behind a barrier all eight waves -- both waves of
+// every SIMD -- sit in that block together while the matrix pipe idles (measured on the producer / consumer kernel, profiles/r03_mlp_ps_*).
+template <int D_, int DBG, int GS, bool PROJ = false, int SPREAD = 0>
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
   constexpr int KS1 = D_ / BK;            // 12 k-steps of GEMM1
   constexpr int KQ = 4;                   // k-steps per GEMM1 stage
@@ -276,11 +279,19 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
       static_assert(j % GS == 0, "group start");
       if constexpr ((DBG & 2) == 0) wait_vm<GS*(NG - 3)>();
       __builtin_amdgcn_s_barrier();
+      if constexpr (!SPREAD) {
 #pragma unroll
-      for (int i = 0; i < GS; ++i) {
-        const int jn = (j + PD + i) % SPC, cn = c + (j + PD + i) / SPC;
-        issue(cn, jn, (c * SPC + j + PD + i) & (NS - 1));
+        for (int i = 0; i < GS; ++i) {
+          const int jn = (j + PD + i) % SPC, cn = c + (j + PD + i) / SPC;
+          issue(cn, jn, (c * SPC + j + PD + i) & (NS - 1));
+        }
       }
+    };
+    // SPREAD: stage j of (virtual) chunk c asks for stage j + PD (its slot held stage j + PD - NS, consumed before the last group barrier)
+    auto issue_ahead = [&](auto jc, int c, bool late) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      // (tried: the SIMD partners -- waves 4-7 -- issuing behind the stage's second MFMA half instead: 30 spilled registers, not built)
+      if constexpr (SPREAD == 1) { if (!late) issue(c + (j + PD) / SPC, (j + PD) % SPC, (c * SPC + j + PD) & (NS - 1)); }
     };
     // half-stage (j, h): GEMM1: k-steps 2h, 2h+1 of the stage x tiles P, Q; GEMM2: output tiles 4h .. 4h+3 of the third
     auto read_half = [&](auto jc, auto hc, int c) __attribute__((always_inline)) {
@@ -407,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
             acc2[v * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa0[t]), __builtin_bit_cast(bf16x8_t, aof[j]),
                                                                        acc2[v * 8 + t], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          issue_ahead(jc, v, false);
           if constexpr (jn % GS == 0) sync_group(std::integral_constant<int, jn>{}, vn);
           if constexpr (vn == VOFF) read_half(std::integral_constant<int, 0>{}, H0{}, vn);       // the seam: first MLP stage (GEMM1 fragments)
           else read_half_p(std::integral_constant<int, jn>{}, H0{}, vn);
@@ -415,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
             acc2[v * 8 + 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa1[t]), __builtin_bit_cast(bf16x8_t, aof[j]),
                                                                            acc2[v * 8 + 4 + t], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          issue_ahead(jc, v, true);
         });
       });
       MDBG_T(4);
@@ -487,9 +500,11 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(MlpArgs a) {
         const int cn = c + (j + 1) / SPC;
         read_half(jc, H1{}, c);
         mfma_half(jc, H0{}, c);
+        issue_ahead(jc, c, false);
         if constexpr (jn % GS == 0) sync_group(std::integral_constant<int, jn>{}, cn);
         read_half(std::integral_constant<int, jn>{}, H0{}, cn);  // (one stage past the end: a stale slot, never multiplied)
         mfma_half(jc, H1{}, c);
+        issue_ahead(jc, c, true);
       });
     MDBG_T(2);
     // ---- epilogue: lane holds y[m][16 t + 4 g + r]
@@ -651,7 +666,10 @@ extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao
   a.ao = (const bf16_t*)ao; a.Wp = (const bf16_t*)Wp; a.bp = bp; a.row_scale1 = row_scale1; a.ao_scaled = ao_scaled;
   a.ln_next = (bf16_t*)ln_next; a.gamma_n = next_gamma; a.beta_n = next_beta;
   const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
-  void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4, true>;
+  // SRHIP_MLP_SPREAD=0: all GS refills of a group right behind its barrier (the round-2 schedule; A/B on one box: 104 -> 99.5 us per 105-image
+  // launch, 1547 -> 1574 img/s on the step)
+  static const int spread = getenv("SRHIP_MLP_SPREAD") ? atoi(getenv("SRHIP_MLP_SPREAD")) : 1;
+  void (*kern)(MlpArgs) = spread ? mlp_fused_kernel<384, 0, 4, true, 1> : mlp_fused_kernel<384, 0, 4, true, 0>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int ntiles = cdiv(M, FBM);
   hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);

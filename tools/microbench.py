@@ -193,6 +193,42 @@ def mlp_ps():
             os.environ.pop("SRHIP_PS_DEBUG", None)
 
 
+def attn_block_alone():
+    """srhip_attn_block_fused alone at the launch sizes of a step: A/B of SRHIP_ATTN_SPREAD (run the process once per setting)."""
+    D, H = 384, 6
+    for N, Bs in ((257, (95, 105)), (197, (95, 105))):
+        for B in Bs:
+            M = B * N
+            ln = torch.randn(M, D, device=DEV).to(torch.bfloat16)
+            W = (torch.randn(3 * D, D, device=DEV) * 0.05).to(torch.bfloat16)
+            bq = torch.randn(3 * D, device=DEV) * 0.1
+            out = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+            qx = torch.zeros(B, 3 * D, dtype=torch.bfloat16, device=DEV)
+            ts = [timeit(lambda: ops.attn_block_fused(ln, W, bq, out, B, N, D, H, 0.125, qkv_extra=qx if N == 257 else None), reps=20) for _ in range(3)]
+            print("SRHIP_ATTN_SPREAD=%s  attn_block N=%d B=%3d: %s us" % (os.environ.get("SRHIP_ATTN_SPREAD", "0"), N, B, " / ".join("%.1f" % t for t in ts)), flush=True)
+
+
+def mlp_rows16():
+    """srhip_mlp_fused_proj (+ next norm1) alone, launch sizes of a step: A/B of SRHIP_MLP_SPREAD (run the process once per setting)."""
+    D, Hd, N = 384, 1536, 257
+    for B in (95, 105, 200):
+        M = B * N
+        x = torch.randn(M, D, device=DEV)
+        ao = torch.randn(M, D, device=DEV).to(torch.bfloat16)
+        Wp = (torch.randn(D, D, device=DEV) * 0.05).to(torch.bfloat16)
+        bp = torch.randn(D, device=DEV) * 0.1
+        g, b = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
+        W1 = (torch.randn(Hd, D, device=DEV) * 0.05).to(torch.bfloat16)
+        W2 = (torch.randn(D, Hd, device=DEV) * 0.02).to(torch.bfloat16)
+        b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(D, device=DEV) * 0.1
+        ln = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+        ts = []
+        for _ in range(3):
+            ts.append(timeit(lambda: ops.mlp_fused_proj(x, ao, Wp, bp, None, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd, ln_next=ln, next_gamma=g, next_beta=b), reps=20))
+            x.normal_()
+        print("SRHIP_MLP_SPREAD=%s  proj+mlp+ln B=%3d: %s us" % (os.environ.get("SRHIP_MLP_SPREAD", "0"), B, " / ".join("%.1f" % t for t in ts)), flush=True)
+
+
 def gemm_qkv5():
     M, N, K = 51400, 1152, 384
     A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
