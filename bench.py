@@ -305,12 +305,22 @@ class Leg:
         m.optimizer.sched_step = m.it
         m.model.train()
         self.alg = m
+        # HIP-graph replay of the step (SR_HIP_GRAPH=0: eager launches): algorithms whose step keeps no Python-side state, single rank
+        self.graph = None
+        # Opt-in (SR_HIP_GRAPH=1): measured on one MI355X the replayed step is NOT faster -- 5.32 vs 5.23 ms in the K = 8 regime, 3.18 vs 3.19 ms at
+        # K = 0: the step is bound by the GPU (dependent small launches, total CU time), not by the 2.5 ms of host enqueue, which runs ahead of it
+        if os.environ.get("SR_HIP_GRAPH", "0") != "0" and getattr(m, "graph_safe", False) and world == 1 and net == "vit":
+            from semireward_amd.core.stepgraph import StepGraph
+            self.graph = StepGraph(m, warm=1)
         self.workload += "steady SR regime" if regime == "sr" else "pre-start_timing regime"
 
     def step(self):
         m = self.alg
-        m.out_dict, m.log_dict = m.train_step(**self.batch)
-        m.call_hook("after_train_step")
+        if self.graph is not None:         # train_step + ParamUpdateHook as ONE captured HIP graph per step variant (core/stepgraph.py)
+            self.graph.step(**self.batch)
+        else:
+            m.out_dict, m.log_dict = m.train_step(**self.batch)
+            m.call_hook("after_train_step")
         m.it += 1
 
     def fence(self):
@@ -348,6 +358,12 @@ class Leg:
         while getattr(m, "_tuners", None) is not None and (tune_steps == 0 or m._tuners) and tune_steps < 64:
             self.step()
             tune_steps += 1
+        # ... and the capture of the step's HIP graphs: every variant that occurs in the steady regime (with / without the SemiReward update of
+        # every N_k-th step) is run eagerly once and captured at its next occurrence
+        cap_steps = 0
+        while self.graph is not None and len(self.graph.graphs) < (2 if self.regime == "sr" else 1) and cap_steps < 3 * NS["N_k"]:
+            self.step()
+            cap_steps += 1
         for _ in range(warmup):
             self.step()
         m.dp.comm_events = [] if world > 1 else None          # event pairs around the gradient all-reduce of every timed step
@@ -381,6 +397,8 @@ class Leg:
         if rep:
             out["config"]["step_schedule"] = {"deferred_share": rep[-1]["chosen"], "deferred_images": rep[-1]["deferred_images"],
                                               "autotune_ms_per_step_by_share": rep[-1]["ms_per_step"], "autotune_steps": tune_steps}
+        out["config"]["launch"] = ("HIP graph replay of train_step + optimizer (%d variants captured; %d replays, %d eager steps incl. tuning / capture)" % (
+            len(self.graph.graphs), self.graph.replays, self.graph.eager_steps)) if self.graph is not None else "eager launches"
         if world > 1:
             out["config"]["backend"] = self.ctx["backend_note"]
             out["rccl_ranks"] = self.ctx["rccl_ranks"]

@@ -334,6 +334,19 @@ int srhip_sr_target(const long long* gen, const long long* ref, float* target, i
  * [0, num_classes) in srhip_sr_target (F.one_hot; num_classes <= 0 disables that check). */
 int srhip_label_error(int* bits_out, int reset, void* stream);
 /* torch.optim.Adam step on a flat block (srflexmatch.py:54, :192-193). */
+/* "_dyn" entry points: the scalars that change from step to step -- the scheduler's lr factor and Adam's bias corrections (param_update.py:33-40,
+ * build.py:227-251), the DropPath seed (vit.py:148,161) -- are read from DEVICE memory written by the host before the step, so that the launches
+ * of a training step can be captured once in a HIP graph and replayed (semireward_amd/core/stepgraph.py).  Same arithmetic as the by-value forms.
+ *   srhip_adamw_flat_dyn: dyn fp32 [3] = {lr_factor, 1 - beta1^step, sqrt(1 - beta2^step)};  srhip_adam_flat_dyn: dyn fp32 [2] = the two corrections;
+ *   srhip_droppath_fill_cols_dyn: seed = *seed_dev + seed_offset. */
+int srhip_adam_bias_corrections(float beta1, float beta2, int step, float* out2_host);   /* host helper: the two fp32 values of a dyn block */
+int srhip_adamw_flat_dyn(float* p, float* g, float* m, float* v, void* p_bf16, float* ema, const int* chunk_table, int n_chunks,
+                         const float* lr_t, const float* wd_t, const float* dyn, float beta1, float beta2, float eps, double ema_m,
+                         float grad_scale, const float* clip_coef, int zero_grad, void* stream);
+int srhip_adam_flat_dyn(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, const float* dyn,
+                        void* stream);
+int srhip_droppath_fill_cols_dyn(float* out, const float* probs, const long long* cols, int depth, int B, int n_cols,
+                                 const unsigned long long* seed_dev, unsigned long long seed_offset, void* stream);
 int srhip_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                     int step, void* stream);
 

@@ -185,7 +185,9 @@ class FlatAdam:
 
     def step(self):
         self.steps += 1
-        ops.adam_flat(self.module.flat, self.module.grad, self.m, self.v, self.module.flat.numel(), self.lr, self.steps)
+        sc = getattr(self, "step_scalars", None)            # core/stepgraph.py: the step's bias corrections in device memory
+        ops.adam_flat(self.module.flat, self.module.grad, self.m, self.v, self.module.flat.numel(), self.lr, self.steps,
+                      dyn=sc.adam_ptr if sc is not None else None)
         self.module.prepare()
 
     def state_dict(self):

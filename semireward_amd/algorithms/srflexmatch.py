@@ -248,6 +248,7 @@ class SRConsistencyBase(AlgorithmBase):
         m = self.model
         C, D = self.num_classes, m.cfg.embed_dim
         ng_, ni_ = pl.grad_cols.numel(), pl.inf_cols.numel()
+        capturing = torch.cuda.is_current_stream_capturing()      # (a captured step owns its allocations: no record_stream bookkeeping)
         if droppath_cols is not None:
             dp_all = droppath_cols.to(self.device)                                                   # [depth,2,ncols]
             sel = lambda cols, a: dp_all.index_select(2, cols).contiguous()                          # noqa: E731
@@ -287,7 +288,7 @@ class SRConsistencyBase(AlgorithmBase):
             elif nr_:
                 side_.wait_event(ready_)
                 for t_ in (logits, feats, dp_rest_, imgs):
-                    if torch.is_tensor(t_):
+                    if torch.is_tensor(t_) and not capturing:
                         t_.record_stream(side_)
                 with torch.cuda.stream(side_), ops.stream_scope():
                     lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest_, save=False, buftag="r")
@@ -330,7 +331,7 @@ class SRConsistencyBase(AlgorithmBase):
             # allocator (a freed DropPath table was handed to the next main-stream allocation while the deferred rows still read it)
             for t_ in (logits, feats, dp_grad, dp_rest, imgs, getattr(imgs, "ids", None), getattr(imgs, "key_len", None),
                        getattr(imgs, "seq_len", None)):
-                if torch.is_tensor(t_):
+                if torch.is_tensor(t_) and not capturing:
                     t_.record_stream(side)
             with torch.cuda.stream(side), ops.stream_scope():
                 if hasattr(m, "ensure_transposed"):
@@ -344,7 +345,7 @@ class SRConsistencyBase(AlgorithmBase):
                 rs.wait_event(grad_done if self._rest_after_grad else ready)
                 for t_ in (logits, feats, dp_rest, imgs, getattr(imgs, "ids", None), getattr(imgs, "key_len", None),
                            getattr(imgs, "seq_len", None)):
-                    if torch.is_tensor(t_):
+                    if torch.is_tensor(t_) and not capturing:
                         t_.record_stream(rs)
             with torch.cuda.stream(rs), ops.stream_scope():
                 if nr:
@@ -423,6 +424,15 @@ class SRConsistencyBase(AlgorithmBase):
             torch.cuda.current_stream().wait_event(self._rest_done)
             self._rest_done = None
 
+    graph_safe = False         # core/stepgraph.py: the step keeps no per-step state in Python objects (set by the subclasses that qualify)
+
+    def step_variant(self):
+        """What of the step's control flow depends on ``it`` (srflexmatch.py:147, :154-208): K = sr_decay() and which SemiReward update runs."""
+        it = self.it
+        K = self.sr_decay() if it > self.start_timing else 0
+        sr = 0 if it <= 0 else (1 if it < self.start_timing else (3 if (it % self.N_k == 0 and it > self.start_timing) else 2))
+        return (K, sr)
+
     fairness_rows = False      # FreeMatch: the pass-0 strong rows also carry a gradient
     masks_read_labelled_rows = False      # SoftMatch with the 'model' alignment target: the masks need the labelled logits of pass 0
     masks_need_weak_logits = True         # the thresholding hook reads the weak logits themselves (FreeMatch, SoftMatch), not only max / argmax
@@ -485,8 +495,8 @@ class SRConsistencyBase(AlgorithmBase):
         if self.dp.active:
             self.dp.all_reduce_flat(self.rewarder.grad).mul_(1.0 / self.world_size)
         self.rewarder_optimizer.step()
-        if ops._CHECK_ARGS:                 # test suite: surface an out-of-range label at the update itself (production: AlgorithmBase.train
-            ops.check_label_errors()        # checks at epoch boundaries and before a checkpoint -- the check synchronises)
+        if ops._CHECK_ARGS and not torch.cuda.is_current_stream_capturing():     # test suite: surface an out-of-range label at the update itself
+            ops.check_label_errors()        # (production: AlgorithmBase.train checks at the logging cadence and before a checkpoint -- the check synchronises)
         if self.trace is not None:
             self.trace.update(sr_target=target, sr_losses=losses)
 
@@ -568,7 +578,7 @@ class SRConsistencyBase(AlgorithmBase):
                 # :166-170 (the filter is a no-op, A.2): reward.mean() and the running maximum ride in the scoring launch
                 self.rewarder.score(fw0.contiguous(), pl0, max_reward=self.max_reward)
                 if it % self.N_k == 0 and it > self.start_timing:                                 # :173
-                    self.max_reward = torch.full((), -float("inf"), device=self.device)
+                    self.max_reward.fill_(-float("inf"))                                            # (in place: the buffer of a captured step)
                     gen2 = self.generator.forward_with_labels(fw0.contiguous())[1]                # :177-178
                     self._sr_update(fw0, gen2, pl0)
             else:
@@ -611,6 +621,8 @@ class SRConsistencyBase(AlgorithmBase):
 @ALGORITHMS.register("srflexmatch")
 class SRFlexMatch(SRConsistencyBase):
     """semilearn/algorithms/srflexmatch/srflexmatch.py:15-246."""
+
+    graph_safe = True          # hook state = persistent device tables updated in place
 
     masks_need_weak_logits = False        # FlexMatch thresholds on (max prob, argmax) only
 
@@ -663,6 +675,7 @@ class SRFixMatch(SRConsistencyBase):
     stateless FixedThresholdingHook (masking.py:42-57) -> the masks of all passes come from ONE launch."""
 
     masks_need_weak_logits = False        # a fixed threshold on the max probability
+    graph_safe = True                     # stateless hook
 
     def _init_thresholds(self, args):
         self.init(T=args.T, p_cutoff=args.p_cutoff, hard_label=args.hard_label)

@@ -1,0 +1,149 @@
+"""One training step as a HIP graph: captured once per step variant, replayed every step.
+
+Why: a step of the SemiReward hot path is ~270 small-to-medium launches on two or three HIP streams; enqueueing them from Python costs 2.5 ms of
+host time per step (tools/host_overhead.py) against ~5 ms of GPU time at the reference batch and MORE than the GPU time in the pre-start_timing
+regime -- the host is on the critical path there, and it is the first thing to de-phase data-parallel ranks.  A captured step replays with one call.
+
+What has to hold for a capture to be valid for every later step:
+  * every per-step host scalar reaches the kernels through device memory: the scheduler's lr factor and Adam's bias corrections (AdamW of the
+    backbone, Adam of the rewarder) and the DropPath seed are written into ``StepScalars`` (one 64-byte H2D copy per step, outside the graph) and
+    read by the "_dyn" entry points of the C ABI (include/srhip.h);
+  * control flow that depends on ``it`` selects a VARIANT, not a branch inside a graph: ``algorithm.step_variant()`` (K = sr_decay(), which
+    SemiReward update the step performs) keys the graph cache, together with the batch shapes;
+  * state the step mutates lives in persistent device buffers updated in place (FlexMatch table / histogram, rewarder parameters and moments,
+    ``max_reward``); Python-side counters the captured code advances (optimizer step, scheduler step, DropPath draw counter, rewarder-Adam step)
+    are advanced by the same amounts at every replay;
+  * inputs are copied into the static batch tensors of the capture (no copy when the caller hands over the very same tensors every step).
+The reference sequence this replaces per step: SRFlexMatch.train_step (srflexmatch.py:107-217) + ParamUpdateHook.after_train_step
+(param_update.py:21-45).  Results are bit-identical to the eager step (tests/test_gpu_stepgraph.py).
+"""
+import torch
+
+from .. import ops
+
+
+def _log_sources(log):
+    """What the DeferredScalars of a captured step's log_dict read (device tensors of the graph's memory pool / callables on them): a DeferredScalar
+    caches its value at the first read, so every replay gets fresh ones on the same sources."""
+    from .algorithmbase import DeferredScalar
+    return {k: (("d", v._t) if isinstance(v, DeferredScalar) else ("v", v)) for k, v in log.items()}
+
+
+def _fresh_log(src):
+    from .algorithmbase import DeferredScalar
+    return {k: (DeferredScalar(v) if kind == "d" else v) for k, (kind, v) in src.items()}
+
+
+class StepScalars:
+    """The per-step scalars of the "_dyn" launches: a ring of pinned host slots + one device slot (64 bytes):
+         bytes  0 ..  7   uint64  DropPath seed base of the step            (srhip_droppath_fill_cols_dyn)
+         bytes 16 .. 27   fp32    lr_factor, 1 - b1^t, sqrt(1 - b2^t)       (srhip_adamw_flat_dyn, backbone)
+         bytes 32 .. 39   fp32    1 - b1^t, sqrt(1 - b2^t)                  (srhip_adam_flat_dyn, rewarder)"""
+    SLOTS = 1024
+
+    def __init__(self, device):
+        self.dev = torch.zeros(16, dtype=torch.float32, device=device)
+        self.host = torch.zeros(self.SLOTS, 16, dtype=torch.float32).pin_memory()
+        self.n = 0
+
+    @property
+    def seed_ptr(self):
+        return self.dev.data_ptr()
+
+    @property
+    def adamw_ptr(self):
+        return self.dev.data_ptr() + 16
+
+    @property
+    def adam_ptr(self):
+        return self.dev.data_ptr() + 32
+
+    def push(self, algorithm):
+        """Values of the step that is about to run, from the host-side counters; one async copy on the current stream."""
+        slot = self.host[self.n % self.SLOTS]
+        self.n += 1
+        m, opt = algorithm.model, algorithm.optimizer
+        slot.view(torch.int64)[0] = (int(getattr(m, "seed", 0)) << 32) + int(getattr(m, "_rng_calls", 0))
+        m._step_draws = 0                                     # make_droppath numbers its draws inside the step (nets/vit.py)
+        if hasattr(opt, "betas"):
+            bc = ops.adam_bias_corrections(opt.betas[0], opt.betas[1], opt.step_count + 1)
+            slot[4], slot[5], slot[6] = opt.lr_factor(), bc[0], bc[1]
+        ro = getattr(algorithm, "rewarder_optimizer", None)
+        if ro is not None:
+            slot[8], slot[9] = ops.adam_bias_corrections(0.9, 0.999, ro.steps + 1)
+        self.dev.copy_(slot, non_blocking=True)
+
+
+class StepGraph:
+    """``step(**batch)`` == ``train_step(**batch)`` + ``ParamUpdateHook.after_train_step`` of the algorithm, eagerly for the first ``warm`` steps of
+    a variant (and while the step schedule is still being tuned), from then on as a captured HIP graph."""
+
+    COUNTERS = (("optimizer", "step_count"), ("optimizer", "sched_step"), ("model", "_rng_calls"), ("rewarder_optimizer", "steps"))
+
+    def __init__(self, algorithm, warm=2):
+        if not getattr(algorithm, "graph_safe", False):
+            raise ValueError("%s keeps per-step state in Python objects: not capturable" % type(algorithm).__name__)
+        self.alg, self.warm = algorithm, warm
+        self.scal = StepScalars(algorithm.device)
+        algorithm.step_scalars = algorithm.model.step_scalars = self.scal
+        if getattr(algorithm, "rewarder_optimizer", None) is not None:
+            algorithm.rewarder_optimizer.step_scalars = self.scal
+        algorithm.optimizer.step_scalars = self.scal
+        self.graphs, self.seen = {}, {}
+        self.replays = self.eager_steps = 0
+        self.hook = algorithm.hooks_dict["ParamUpdateHook"]
+
+    def _counters(self):
+        out = []
+        for obj, name in self.COUNTERS:
+            o = getattr(self.alg, obj, None)
+            out.append(getattr(o, name, 0) if o is not None else 0)
+        return out
+
+    def _advance(self, deltas):
+        for (obj, name), d in zip(self.COUNTERS, deltas):
+            o = getattr(self.alg, obj, None)
+            if o is not None and d:
+                setattr(o, name, getattr(o, name) + d)
+
+    def _eager(self, batch):
+        alg = self.alg
+        alg.out_dict, alg.log_dict = alg.train_step(**batch)
+        self.hook.after_train_step(alg)
+        return alg.out_dict, alg.log_dict
+
+    def step(self, **batch):
+        alg = self.alg
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        key = (alg.step_variant(), sig)
+        self.scal.push(alg)
+        ent = self.graphs.get(key)
+        if ent is not None:
+            g, static, deltas, out, log = ent
+            for k, v in batch.items():
+                if static[k] is not v:
+                    static[k].copy_(v, non_blocking=True)
+            g.replay()
+            self._advance(deltas)
+            alg.out_dict, alg.log_dict = out, _fresh_log(log)
+            self.replays += 1
+            return out, alg.log_dict
+        n = self.seen.get(key, 0)
+        self.seen[key] = n + 1
+        if n < self.warm or getattr(alg, "_tuners", None) or alg.trace is not None or alg.dp.active:
+            self.eager_steps += 1
+            return self._eager(batch)
+        # ---- capture this step (nothing executes during capture), then replay it once: that IS this step
+        static = dict(batch)
+        before = self._counters()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out, log = self._eager(static)
+        deltas = [a - b for a, b in zip(self._counters(), before)]
+        src = _log_sources(log)
+        self.graphs[key] = (g, static, deltas, out, src)
+        g.replay()
+        self.replays += 1
+        alg.out_dict, alg.log_dict = out, _fresh_log(src)
+        return out, alg.log_dict

@@ -19,7 +19,10 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                         const int4* __restrict__ chunks, const float* __restrict__ lr_t,
                                                         const float* __restrict__ wd_t, float lr_factor, float b1, float b2,
                                                         float eps, float bc1, float bc2_sqrt, float ema_m, float ema_1m, float grad_scale,
-                                                        const float* __restrict__ clip_coef, int zero_grad) {
+                                                        const float* __restrict__ clip_coef, int zero_grad, const float* __restrict__ dyn) {
+  // dyn != NULL (srhip_adamw_flat_dyn): this step's (lr_factor, 1 - beta1^t, sqrt(1 - beta2^t)) come from device memory, so that a launch
+  // captured in a HIP graph serves every step
+  if (dyn) { lr_factor = dyn[0]; bc1 = dyn[1]; bc2_sqrt = dyn[2]; }
   const int4 ck = chunks[blockIdx.x];                 // x = offset, y = length, z = tensor id
   const float lr = lr_t[ck.z] * lr_factor, wd = wd_t[ck.z];
   const float decay = 1.0f - lr * wd, step = lr / bc1;
@@ -86,7 +89,27 @@ extern "C" int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, ema,
-                     (const int4*)chunk_table, lr_t, wd_t, lr_factor, beta1, beta2, eps, bc1, bc2s, (float)ema_m, (float)(1.0 - ema_m), grad_scale, clip_coef, zero_grad);
+                     (const int4*)chunk_table, lr_t, wd_t, lr_factor, beta1, beta2, eps, bc1, bc2s, (float)ema_m, (float)(1.0 - ema_m), grad_scale, clip_coef, zero_grad,
+                     (const float*)nullptr);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+// (1 - beta1^step, sqrt(1 - beta2^step)) exactly as the by-value launches compute them (host function, fp32 powf): what the host writes into the
+// dyn block of a step, so that the graph-replayed step and the eager step agree bit for bit
+extern "C" int srhip_adam_bias_corrections(float beta1, float beta2, int step, float* out2) {
+  if (!out2 || step <= 0) return SR_EINVAL;
+  out2[0] = 1.0f - powf(beta1, (float)step);
+  out2[1] = sqrtf(1.0f - powf(beta2, (float)step));
+  return SR_OK;
+}
+// The same launch with the per-step scalars in DEVICE memory: dyn = {lr_factor, 1 - beta1^step, sqrt(1 - beta2^step)} (fp32, written by the host
+// before the step: semireward_amd/core/stepgraph.py).  Everything else is step-invariant, so the launch can sit in a captured HIP graph.
+extern "C" int srhip_adamw_flat_dyn(float* p, float* g, float* m, float* v, void* p_bf16, float* ema, const int* chunk_table,
+                                    int n_chunks, const float* lr_t, const float* wd_t, const float* dyn, float beta1, float beta2,
+                                    float eps, double ema_m, float grad_scale, const float* clip_coef, int zero_grad, void* stream) {
+  if (n_chunks <= 0 || !dyn) return SR_EINVAL;
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, ema,
+                     (const int4*)chunk_table, lr_t, wd_t, 0.f, beta1, beta2, eps, 1.f, 1.f, (float)ema_m, (float)(1.0 - ema_m), grad_scale, clip_coef, zero_grad, dyn);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

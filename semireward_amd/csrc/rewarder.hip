@@ -497,7 +497,8 @@ __global__ void sr_target_kernel(const long long* __restrict__ gen, const long l
 
 // torch.optim.Adam, flat fp32 block (betas 0.9/0.999, eps 1e-8, no weight decay)
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
-                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                                 float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ dyn) {
+  if (dyn) { bc1 = dyn[0]; bc2_sqrt = dyn[1]; }        // srhip_adam_flat_dyn: the bias corrections of this step from device memory (HIP graph replay)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
@@ -632,7 +633,15 @@ extern "C" int srhip_adam_flat(float* p, const float* g, float* m, float* v, lon
   if (n <= 0 || step <= 0) return SR_EINVAL;
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, bc1, bc2s);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, bc1, bc2s,
+                     (const float*)nullptr);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_adam_flat_dyn(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                                   const float* dyn, void* stream) {
+  if (n <= 0 || !dyn) return SR_EINVAL;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, 1.f, 1.f, dyn);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

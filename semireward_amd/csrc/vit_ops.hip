@@ -515,7 +515,9 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __rest
 // cols != NULL: out is [depth, 2, n] and column q of it is column cols[q] of the [depth, 2, B] table (any selection / order of the columns of ONE
 // draw, produced directly: the step's launch trains each take a contiguous slice instead of an index_select each)
 __global__ void droppath_fill_kernel(float* __restrict__ out, const float* __restrict__ probs, int depth, int B,
-                                     unsigned long long seed, const long long* __restrict__ cols, int n) {
+                                     unsigned long long seed, const long long* __restrict__ cols, int n,
+                                     const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) seed += seed_dev[0];                  // srhip_droppath_fill_cols_dyn: the step's seed from device memory (HIP graph replay) + a static offset
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= depth * 2 * n) return;
   long long col = o % n;
@@ -752,7 +754,7 @@ extern "C" int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stre
 extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream) {
   if (depth <= 0 || B <= 0) return SR_EINVAL;
   hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
-                     (const long long*)nullptr, B);
+                     (const long long*)nullptr, B, (const unsigned long long*)nullptr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -760,7 +762,16 @@ extern "C" int srhip_droppath_fill_cols(float* out, const float* probs, const lo
                                         unsigned long long seed, void* stream) {
   if (depth <= 0 || B <= 0 || n_cols <= 0 || !cols) return SR_EINVAL;
   hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
-                     cols, n_cols);
+                     cols, n_cols, (const unsigned long long*)nullptr);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+// seed = *seed_dev + seed_offset: the draw of a captured step follows the counter the host writes before every replay (cols may be NULL: all B columns)
+extern "C" int srhip_droppath_fill_cols_dyn(float* out, const float* probs, const long long* cols, int depth, int B, int n_cols,
+                                            const unsigned long long* seed_dev, unsigned long long seed_offset, void* stream) {
+  if (depth <= 0 || B <= 0 || n_cols <= 0 || !seed_dev) return SR_EINVAL;
+  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed_offset,
+                     cols, cols ? n_cols : B, seed_dev);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

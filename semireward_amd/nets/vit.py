@@ -229,7 +229,14 @@ class VisionTransformer:
         that order ([depth, 2, len(cols)])."""
         dp = torch.empty(self.cfg.depth, 2, B if cols is None else cols.numel(), dtype=torch.float32, device=self.device)
         self._rng_calls += 1
-        ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, (self.seed << 32) + self._rng_calls, cols=cols)
+        sc = getattr(self, "step_scalars", None)
+        if sc is not None:
+            # core/stepgraph.py: the step's seed base ((seed << 32) + the draw counter at the start of the step) sits in device memory; this call
+            # adds its own number inside the step -- the same 64-bit seed as below, from a launch that can be replayed
+            self._step_draws = getattr(self, "_step_draws", 0) + 1
+            ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, self._step_draws, cols=cols, seed_dev=sc.seed_ptr)
+        else:
+            ops.droppath_fill(dp, self.dp_probs, self.cfg.depth, B, (self.seed << 32) + self._rng_calls, cols=cols)
         return dp
 
     def _ctx_buffers(self, B):

@@ -433,9 +433,12 @@ def cast_f32_bf16(x, out, n):
     _call("srhip_cast_f32_bf16", _p(x), _p(out), n, _s())
 
 
-def droppath_fill(out, probs, depth, B, seed, cols=None):
-    """out [depth, 2, B] (cols None) or [depth, 2, len(cols)]: the columns cols of the same [depth, 2, B] draw, in that order."""
-    if cols is None:
+def droppath_fill(out, probs, depth, B, seed, cols=None, seed_dev=None):
+    """out [depth, 2, B] (cols None) or [depth, 2, len(cols)]: the columns cols of the same [depth, 2, B] draw, in that order.
+    seed_dev (device address of a uint64): the seed is *seed_dev + seed (a step captured in a HIP graph, core/stepgraph.py)."""
+    if seed_dev is not None:
+        _call("srhip_droppath_fill_cols_dyn", _p(out), _p(probs), _p(cols), depth, B, cols.numel() if cols is not None else B, seed_dev, seed, _s())
+    elif cols is None:
         _call("srhip_droppath_fill", _p(out), _p(probs), depth, B, seed, _s())
     else:
         _call("srhip_droppath_fill_cols", _p(out), _p(probs), _p(cols), depth, B, cols.numel(), seed, _s())
@@ -578,12 +581,29 @@ def check_label_errors(reset=True):
         raise IndexError("libsrhip: " + "; ".join(msgs))
 
 
-def adam_flat(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_flat(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, dyn=None):
+    """dyn (device address of fp32 [2] = the step's bias corrections): srhip_adam_flat_dyn, ``step`` is then ignored."""
+    if dyn is not None:
+        _call("srhip_adam_flat_dyn", _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, dyn, _s())
+        return
     _call("srhip_adam_flat", _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, step, _s())
 
 
+def adam_bias_corrections(beta1, beta2, step):
+    """(1 - beta1^step, sqrt(1 - beta2^step)) in the fp32 arithmetic of the optimizer launches (host function of the library)."""
+    import ctypes
+    out = (ctypes.c_float * 2)()
+    _call("srhip_adam_bias_corrections", beta1, beta2, int(step), ctypes.cast(out, ctypes.c_void_p))
+    return float(out[0]), float(out[1])
+
+
 def adamw_flat(p, g, m, v, p_bf16, ema, chunk_table, n_chunks, lr_t, wd_t, lr_factor, step, beta1=0.9, beta2=0.999, eps=1e-8,
-               ema_m=0.0, grad_scale=1.0, zero_grad=True, clip_coef=None):
+               ema_m=0.0, grad_scale=1.0, zero_grad=True, clip_coef=None, dyn=None):
+    """dyn (device address of fp32 [3] = lr_factor and the step's two bias corrections): srhip_adamw_flat_dyn; lr_factor / step are then ignored."""
+    if dyn is not None:
+        _call("srhip_adamw_flat_dyn", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(ema), _p(chunk_table), n_chunks, _p(lr_t), _p(wd_t),
+              dyn, beta1, beta2, eps, float(ema_m), grad_scale, _p(clip_coef), int(zero_grad), _s())
+        return
     _call("srhip_adamw_flat", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(ema), _p(chunk_table), n_chunks, _p(lr_t), _p(wd_t),
           lr_factor, beta1, beta2, eps, step, float(ema_m), grad_scale, _p(clip_coef), int(zero_grad), _s())
 

@@ -134,9 +134,11 @@ class FusedAdamW:
     def step(self, ema=None, ema_m=0.0, grad_scale=1.0, clip_grad=0.0):
         self.step_count += 1
         coef = _clip_coef(self, grad_scale, clip_grad)
+        sc = getattr(self, "step_scalars", None)            # core/stepgraph.py: this step's lr factor / bias corrections in device memory
         ops.adamw_flat(self.model.flat, self.model.grad, self.m, self.v, self.model.flat_bf16, ema, self.table,
                        self.table.shape[0], self.lr_t, self.wd_t, self.lr_factor(), self.step_count, self.betas[0],
-                       self.betas[1], self.eps, ema_m=ema_m, grad_scale=grad_scale, zero_grad=True, clip_coef=coef)
+                       self.betas[1], self.eps, ema_m=ema_m, grad_scale=grad_scale, zero_grad=True, clip_coef=coef,
+                       dyn=sc.adamw_ptr if sc is not None else None)
         if hasattr(self.model, "refresh_packed"):
             self.model.refresh_packed()          # fragment streams of the producer / consumer MLP launch (one launch for all blocks)
         if getattr(self.model, "lazy_transposed", False):
