@@ -70,9 +70,11 @@ class SRPseudoLabel(SRConsistencyBase):
             lws, fws, ctx_u = [], [], None
             xu = x_ulb_w.contiguous()
             for k in range(P):
-                lg, ft, cx = self.model.forward_features(xu, save=(k == K), update_stats=False, tag="ulb" if k == K else "ulb_inf")
+                if k == K:
+                    lg, ft, ctx_u = self.model.forward_features(xu, save=True, update_stats=False, tag="ulb")
+                else:            # the K passes whose loss data_generator discards: frozen statistics, no state -> one HIP-graph replay each
+                    lg, ft = self.model.forward_frozen(xu, tag="ulb_inf")
                 lws.append(lg); fws.append(ft)
-                ctx_u = cx if k == K else ctx_u
             logits, feats, ctx = torch.cat([lg_lb] + lws), torch.cat([ft_lb] + fws), (ctx_lb, ctx_u)
         else:
             logits, feats, ctx = self._forward_plan(imgs, pl, dpc)

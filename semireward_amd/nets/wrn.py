@@ -235,6 +235,36 @@ class WideResNet:
             ctx.final, ctx.feat = dict(x=out, st=stf, h=h, w=w), feat
         return logits, feat, ctx
 
+    # ---- the frozen-statistics inference forward as a HIP graph ------------------------------------------------------------------------
+    # SRPseudoLabel's data_generator forwards the SAME unlabelled batch K = sr_decay() >= 8 times under Bn_Controller.freeze_bn
+    # (srpseudolabel.py:59-90) -- ~110 launches of a few microseconds each per forward at the classic_cv batch (64 images of 32x32), i.e. a
+    # forward bound by launch latency, not by the GPU.  It has no per-call host state (no DropPath, no statistics update): captured once
+    # per input shape, replayed per pass.  SR_WRN_GRAPH=0: eager launches.
+    graph_frozen = __import__("os").environ.get("SR_WRN_GRAPH", "1") != "0"
+
+    def forward_frozen(self, img, tag="ulb_inf"):
+        """forward_features(img, save=False, update_stats=False) -> (logits, feat); the returned tensors are the caller's own copies."""
+        key = (tag, tuple(img.shape), bool(self.training))
+        st = self.__dict__.setdefault("_frozen_graphs", {})
+        ent = st.get(key)
+        if ent is None:
+            n = st.get(("seen",) + key, 0)
+            st[("seen",) + key] = n + 1
+            if not self.graph_frozen or n < 1 or not img.is_cuda or torch.cuda.is_current_stream_capturing():
+                lg, ft, _ = self.forward_features(img, save=False, update_stats=False, tag=tag)      # (first call: builds the workspaces)
+                return lg, ft
+            x_static = img.detach().clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), ops.stream_scope():
+                lg, ft, _ = self.forward_features(x_static, save=False, update_stats=False, tag=tag)
+            ent = st[key] = (g, x_static, lg, ft)
+        g, x_static, lg, ft = ent
+        if x_static.data_ptr() != img.data_ptr():
+            x_static.copy_(img, non_blocking=True)
+        g.replay()
+        return lg.clone(), ft.clone()
+
     def forward(self, x, only_fc=False, only_feat=False, **kw):
         assert not only_fc
         logits, feat, _ = self.forward_features(x.contiguous(), save=False)

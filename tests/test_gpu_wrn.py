@@ -293,13 +293,18 @@ def test_full_size_step_properties_wrn():
         calls = []
         ff = alg.model.forward_features
         alg.model.forward_features = lambda *a, **k: (calls.append(k.get("update_stats", True)), ff(*a, **k))[1]
+        fz = alg.model.forward_frozen
+        alg.model.forward_frozen = lambda *a, **k: (calls.append("frozen"), fz(*a, **k))[1]
         alg.trace = {}
         out, log = alg.train_step(**alg.process_batch(**batch))
         torch.cuda.synchronize()
         return alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}, calls
     alg, out, log, tr, calls = run(0.95)
     K = tr["K"]
-    assert K == 8 and calls == [True] + [False] * (K + 1)          # model(x_lb) moves the statistics; K + 1 frozen model(x_ulb_w) calls
+    # model(x_lb) moves the statistics; K frozen inference passes of model(x_ulb_w) (the first eager, the second captured as a HIP graph, the
+    # rest replays of it: forward_features itself runs only twice for them) and the saved frozen pass the backward belongs to
+    assert K == 8 and calls[0] is True and calls.count("frozen") == K and calls.count(True) == 1
+    assert calls[-1] is False and calls.count(False) == (3 if alg.model.graph_frozen else K + 1)
     mp = tr["max_probs"].cpu().numpy().reshape(K + 1, Bu)
     mi = tr["pseudo"].cpu().numpy().reshape(K + 1, Bu)
     assert all(float(m.sum()) == 0.0 for m in tr["masks"]) and mp.max() < 0.95      # random-init model: nothing reaches 0.95
