@@ -1,0 +1,5 @@
+python tools/_diag_sg.py > gpurun_out/r03o_diag.txt 2>&1
+python -m pytest tests/test_gpu_wrn.py -q 2>&1 | tail -5
+bash tools/prof.sh r03o_wrn --net wrn --bu 64 --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-roofline --no-also > /dev/null 2>&1
+head -12 gpurun_out/r03o_wrn.stats.txt
+grep -h '^{"metric"' gpurun_out/r03o_wrn.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
