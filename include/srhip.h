@@ -61,10 +61,14 @@ int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, 
  *   C[M,N] = alpha * A^T . B + beta * C,  A bf16 [K, M] (lda), B bf16 [K, N] (ldb), C fp32 [M, N] (ldc);  dbias[M] += colsum(A)
  * i.e. dW = dY^T X and db = sum_tokens dY of an nn.Linear (autograd of vit.py:69-75, :95-112) with K = tokens.
  * K is arbitrary (rows past K read as zero); M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0, operands 16-byte aligned.
- * tile_start / total_tiles as in srhip_group_desc.  dbias may be NULL. */
+ * tile_start / total_tiles as in srhip_group_desc.  dbias may be NULL.
+ * flags & SRHIP_TN_ATOMIC: the entry is one K slice of a product the caller split along the token axis (A, B point at the slice's first
+ * row, K = its rows): C += alpha * A^T B and dbias += column sums through fp32 atomic adds; beta is ignored for the entry (the sum over
+ * the slices is then order-dependent in the last bits, like any split-K reduction). */
+#define SRHIP_TN_ATOMIC 1
 typedef struct srhip_group_tn_desc {
   const void* A; const void* B; float* C; float* dbias;
-  int M, N, K, lda, ldb, ldc, tile_start, pad0;
+  int M, N, K, lda, ldb, ldc, tile_start, flags;
 } srhip_group_tn_desc;                   /* 64 bytes */
 int srhip_gemm_tn_grouped_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
                               void* stream);
@@ -473,10 +477,11 @@ int srhip_augment(const unsigned char* src, int n_src, int H0, int W0, int B, in
  * Feature maps are NHWC = row-major [rows = B*H*W, C].  conv = im2col (bf16) + srhip_gemm_nt; dW = srhip_gemm_tn_grouped_f32(dY, col);
  * dX = srhip_gemm_nt(dY, W^T) + col2im.
  *   nchw_to_nhwc_bf16 : the input batch [B,C,H,W] fp32 -> bf16 [B,H,W,C]
- *   im2col            : col[(b,yo,xo)][c*k*k + i*k + j] = act[b][yo*s+i-p][xo*s+j-p][c]  (k in {1,3}, p = k/2, zero fill, Kpad % 32 == 0;
+ *   im2col            : col[(b,yo,xo)][(i*k + j)*C + c] = act[b][yo*s+i-p][xo*s+j-p][c]  (k in {1,3}, p = k/2, zero fill, Kpad % 32 == 0;
  *                       column order == Conv2d weight.flatten(1), wrn.py:33-43)
  *   col2im            : the adjoint gather: dact (= | +=) sum of the dcol entries that read each input pixel
- *   conv_weight_prep  : W fp32 [Cout, K] -> bf16 [Cout, Kpad] and its transpose bf16 [Kpad, Cout];  add_unpad: dW[Cout,K] += dWpad[Cout,Kpad]
+ *   conv_weight_prep  : W fp32 [Cout, C, k, k] -> bf16 [Cout, Kpad] in col's tap-major K order and its transpose bf16 [Kpad, Cout];
+ *   add_unpad         : the inverse for the gradient: dW[Cout, C, k, k] += dWpad[Cout, Kpad]
  *   bn_fwd            : nn.BatchNorm2d + LeakyReLU(slope) (wrn.py:32-38, :104-105).  training != 0: statistics of THIS batch (saved in
  *                       save_mean / save_invstd), running_mean / running_var moved with ``momentum`` (unbiased variance) unless
  *                       update_running == 0 (Bn_Controller.freeze_bn, core/utils/misc.py:105-129); training == 0: running statistics.
@@ -488,8 +493,8 @@ int srhip_augment(const unsigned char* src, int n_src, int H0, int W0, int B, in
 int srhip_nchw_to_nhwc_bf16(const float* img, void* out, int B, int C, int H, int W, void* stream);
 int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream);
 int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int ksize, int stride, int Kpad, int accumulate, void* stream);
-int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int K, int Kpad, void* stream);
-int srhip_add_unpad(const float* src, float* dst, int Cout, int K, int Kpad, void* stream);
+int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int C, int ksize, int Kpad, void* stream);
+int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream);
 int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
                  int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* act_bf16,
                  float* act_f32, double* ws, int rows, int C, void* stream);

@@ -126,18 +126,26 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip
   }
 #undef ISSUE
 
+  const bool atomic = (d.flags & SRHIP_TN_ATOMIC) != 0;
   // ---- epilogue: lane holds C[m][n .. n+3], m = tile row (lane & 15), n = 4 (lane >> 4) + r
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + l15;
     if (m >= d.M) continue;
-    if (want_bias && lg == 0) d.dbias[m] += accb[mt][0];                 // every row of the ones-product equals the column sum
+    if (want_bias && lg == 0) {                                          // every row of the ones-product equals the column sum
+      if (atomic) unsafeAtomicAdd(d.dbias + m, accb[mt][0]); else d.dbias[m] += accb[mt][0];
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wn * 64 + nt * 16 + lg * 4;
       if (n >= d.N) continue;
       f32x4_t* cp = reinterpret_cast<f32x4_t*>(d.C + (size_t)m * d.ldc + n);
       f32x4_t x = {alpha * acc[nt][mt][0], alpha * acc[nt][mt][1], alpha * acc[nt][mt][2], alpha * acc[nt][mt][3]};
+      if (atomic) {                     // one K slice of a split problem: the slices meet in C through the hardware fp32 atomic add
+        float* cf = d.C + (size_t)m * d.ldc + n;
+        unsafeAtomicAdd(cf, x[0]); unsafeAtomicAdd(cf + 1, x[1]); unsafeAtomicAdd(cf + 2, x[2]); unsafeAtomicAdd(cf + 3, x[3]);
+        continue;
+      }
       if (beta != 0.0f) {
         const f32x4_t c = *cp;
         x[0] += beta * c[0]; x[1] += beta * c[1]; x[2] += beta * c[2]; x[3] += beta * c[3];

@@ -18,64 +18,96 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ img, bf16_t* __res
   out[i] = f2bf(img[(b * C + c) * HW2 + px]);
 }
 
-// col[(b, yo, xo)][c * k*k + i * k + j] = act[b][yo*s + i - pad][xo*s + j - pad][c]  (0 outside the image, 0 for columns >= C*k*k)
-__global__ void im2col_kernel(const bf16_t* __restrict__ act, bf16_t* __restrict__ col, int H, int W, int C, int ks, int stride,
-                              int Ho, int Wo, int Kpad) {
-  const int row = blockIdx.x;                     // b * Ho * Wo + yo * Wo + xo
-  const int b = row / (Ho * Wo), r = row % (Ho * Wo), yo = r / Wo, xo = r % Wo, pad = ks >> 1, K = C * ks * ks;
-  bf16_t* o = col + (size_t)row * Kpad;
-  for (int e = threadIdx.x; e < Kpad; e += blockDim.x) {
+// col[(b, yo, xo)][(i * k + j) * C + c] = act[b][yo*s + i - pad][xo*s + j - pad][c]  (0 outside the image, 0 for columns >= C*k*k).
+// The K axis is TAP-major: the C channels of one filter tap are contiguous in col exactly as they are in the NHWC activation, so a thread
+// moves V = 8 channels (16 bytes) per load / store and consecutive threads write consecutive 16-byte pieces of a col row.  The filter
+// matrix is permuted to the same order once per step (conv_weight_prep) and its gradient back (add_unpad).
+template <int V>
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ act, bf16_t* __restrict__ col, int H, int W, int C, int ks,
+                                                    int stride, int Ho, int Wo, int Kpad, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over rows * (Kpad / V)
+  if (idx >= total) return;
+  const int kv = Kpad / V;
+  const size_t row = idx / kv;                                          // b * Ho * Wo + yo * Wo + xo
+  const int k = (int)(idx % kv) * V, K = C * ks * ks, pad = ks >> 1;
+  const int b = (int)(row / (Ho * Wo)), r = (int)(row % (Ho * Wo)), yo = r / Wo, xo = r % Wo;
+  if (V == 8) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (k < K) {
+      const int t = k / C, c = k % C, y = yo * stride + t / ks - pad, x = xo * stride + t % ks - pad;
+      if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const u32x4_t*>(act + (((size_t)b * H + y) * W + x) * C + c);
+    }
+    *reinterpret_cast<u32x4_t*>(col + row * Kpad + k) = v;
+  } else {
     bf16_t v = 0;
-    if (e < K) {
-      const int c = e / (ks * ks), i = (e / ks) % ks, j = e % ks;
-      const int y = yo * stride + i - pad, x = xo * stride + j - pad;
+    if (k < K) {
+      const int t = k / C, c = k % C, y = yo * stride + t / ks - pad, x = xo * stride + t % ks - pad;
       if (y >= 0 && y < H && x >= 0 && x < W) v = act[(((size_t)b * H + y) * W + x) * C + c];
     }
-    o[e] = v;
+    col[row * Kpad + k] = v;
   }
 }
 
-// dact[b][y][x][c] (=|+=) sum over the (<= k*k) output positions that read this input pixel of dcol[(b,yo,xo)][c*k*k + i*k + j]
-__global__ void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dact, int H, int W, int C, int ks, int stride, int Ho,
-                              int Wo, int Kpad, int accumulate) {
-  const int pix = blockIdx.x;                     // b * H * W + y * W + x
-  const int b = pix / (H * W), r = pix % (H * W), y = r / W, x = r % W, pad = ks >> 1;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int i = 0; i < ks; ++i) {
-      const int ty = y + pad - i;
-      if (ty < 0 || ty % stride) continue;
-      const int yo = ty / stride;
-      if (yo >= Ho) continue;
-      for (int j = 0; j < ks; ++j) {
-        const int tx = x + pad - j;
-        if (tx < 0 || tx % stride) continue;
-        const int xo = tx / stride;
-        if (xo >= Wo) continue;
-        s += dcol[(((size_t)b * Ho + yo) * Wo + xo) * Kpad + c * ks * ks + i * ks + j];
+// dact[b][y][x][c] (=|+=) sum over the (<= k*k) output positions that read this input pixel of dcol[(b,yo,xo)][(i*k + j) * C + c];
+// a thread owns V channels of one input pixel (V = 4: 16-byte loads of dcol, consecutive threads consecutive channels)
+template <int V>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dact, int H, int W, int C, int ks,
+                                                    int stride, int Ho, int Wo, int Kpad, int accumulate, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over B*H*W * (C / V)
+  if (idx >= total) return;
+  const int cv = C / V, c = (int)(idx % cv) * V, pad = ks >> 1;
+  const size_t pix = idx / cv;                                          // b * H * W + y * W + x
+  const int b = (int)(pix / (H * W)), r = (int)(pix % (H * W)), y = r / W, x = r % W;
+  float s[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s[v] = 0.f;
+  for (int i = 0; i < ks; ++i) {
+    const int ty = y + pad - i;
+    if (ty < 0 || ty % stride) continue;
+    const int yo = ty / stride;
+    if (yo >= Ho) continue;
+    for (int j = 0; j < ks; ++j) {
+      const int tx = x + pad - j;
+      if (tx < 0 || tx % stride) continue;
+      const int xo = tx / stride;
+      if (xo >= Wo) continue;
+      const float* src = dcol + (((size_t)b * Ho + yo) * Wo + xo) * Kpad + (i * ks + j) * C + c;
+      if (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+      } else {
+        s[0] += src[0];
       }
     }
-    float* d = dact + (size_t)pix * C + c;
-    *d = accumulate ? *d + s : s;
+  }
+  float* d = dact + pix * C + c;
+  if (V == 4) {
+    float4 o = {s[0], s[1], s[2], s[3]};
+    if (accumulate) { const float4 p = *reinterpret_cast<const float4*>(d); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    *reinterpret_cast<float4*>(d) = o;
+  } else {
+    *d = accumulate ? *d + s[0] : s[0];
   }
 }
 
-// W fp32 [Cout, K] -> Wb bf16 [Cout, Kpad] (zero padded) and WbT bf16 [Kpad, Cout]
-__global__ void conv_weight_prep_kernel(const float* __restrict__ Wf, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT, int Cout, int K,
+// W fp32 [Cout, C, k, k] -> Wb bf16 [Cout, Kpad] with the K axis tap-major ((i*k + j) * C + c, zero padded) and WbT bf16 [Kpad, Cout]
+__global__ void conv_weight_prep_kernel(const float* __restrict__ Wf, bf16_t* __restrict__ Wb, bf16_t* __restrict__ WbT, int Cout, int C, int kk,
                                         int Kpad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cout * Kpad) return;
-  const int o = i / Kpad, k = i % Kpad;
-  const bf16_t v = k < K ? f2bf(Wf[(size_t)o * K + k]) : (bf16_t)0;
+  const int o = i / Kpad, k = i % Kpad, K = C * kk;
+  const bf16_t v = k < K ? f2bf(Wf[(size_t)o * K + (k % C) * kk + k / C]) : (bf16_t)0;
   Wb[i] = v;
   WbT[(size_t)k * Cout + o] = v;
 }
 
-// dW (fp32 [Cout, K], +=) <- dWpad [Cout, Kpad]
-__global__ void add_unpad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int K, int Kpad) {
+// dW (fp32 [Cout, C, k, k], +=) <- dWpad [Cout, Kpad] (tap-major K axis)
+__global__ void add_unpad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int C, int kk, int Kpad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = C * kk;
   if (i >= Cout * K) return;
-  dst[i] += src[(size_t)(i / K) * Kpad + i % K];
+  const int o = i / K, e = i % K, c = e / kk, t = e % kk;
+  dst[i] += src[(size_t)o * Kpad + t * C + c];
 }
 
 // ---- BatchNorm over the rows of x fp32 [rows, C] --------------------------------------------------------------------------------
@@ -131,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     const int which = o / C, c = o % C;
     double t = 0.0;
     for (int j = 0; j < rpb; ++j) t += red[which][j * C + c];
-    atomicAdd(ws + o, t);
+    unsafeAtomicAdd(ws + o, t);                     // global_atomic_add_f64 (the plain atomicAdd is a compare-and-swap loop)
   }
 }
 
@@ -281,8 +313,16 @@ extern "C" int srhip_nchw_to_nhwc_bf16(const float* img, void* out, int B, int C
 extern "C" int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream) {
   if (!act || !col || B <= 0 || (ksize != 1 && ksize != 3) || stride <= 0 || Kpad < C * ksize * ksize || (Kpad % 32)) return SR_EINVAL;
   const int pad = ksize >> 1, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-  hipLaunchKernelGGL(im2col_kernel, dim3(B * Ho * Wo), dim3(Kpad >= 256 ? 256 : 64), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H,
-                     W, C, ksize, stride, Ho, Wo, Kpad);
+  const size_t rows = (size_t)B * Ho * Wo;
+  if (C % 8 == 0) {
+    const size_t total = rows * (Kpad / 8);
+    hipLaunchKernelGGL(im2col_kernel<8>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
+                       ksize, stride, Ho, Wo, Kpad, total);
+  } else {
+    const size_t total = rows * Kpad;
+    hipLaunchKernelGGL(im2col_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
+                       ksize, stride, Ho, Wo, Kpad, total);
+  }
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -291,22 +331,30 @@ extern "C" int srhip_col2im(const float* dcol, float* dact, int B, int H, int W,
                             void* stream) {
   if (!dcol || !dact || B <= 0 || (ksize != 1 && ksize != 3) || stride <= 0 || Kpad < C * ksize * ksize) return SR_EINVAL;
   const int pad = ksize >> 1, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-  hipLaunchKernelGGL(col2im_kernel, dim3(B * H * W), dim3(C >= 128 ? 128 : 64), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho,
-                     Wo, Kpad, accumulate);
+  const size_t pix = (size_t)B * H * W;
+  if (C % 4 == 0 && Kpad % 4 == 0) {
+    const size_t total = pix * (C / 4);
+    hipLaunchKernelGGL(col2im_kernel<4>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho, Wo,
+                       Kpad, accumulate, total);
+  } else {
+    const size_t total = pix * C;
+    hipLaunchKernelGGL(col2im_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho, Wo,
+                       Kpad, accumulate, total);
+  }
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
-extern "C" int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int K, int Kpad, void* stream) {
-  if (!Wf || !Wb || !WbT || Cout <= 0 || K <= 0 || Kpad < K) return SR_EINVAL;
-  LAUNCH1D(conv_weight_prep_kernel, (long)Cout * Kpad, Wf, (bf16_t*)Wb, (bf16_t*)WbT, Cout, K, Kpad);
+extern "C" int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int C, int ksize, int Kpad, void* stream) {
+  if (!Wf || !Wb || !WbT || Cout <= 0 || C <= 0 || ksize <= 0 || Kpad < C * ksize * ksize) return SR_EINVAL;
+  LAUNCH1D(conv_weight_prep_kernel, (long)Cout * Kpad, Wf, (bf16_t*)Wb, (bf16_t*)WbT, Cout, C, ksize * ksize, Kpad);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
-extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int K, int Kpad, void* stream) {
-  if (!src || !dst || Cout <= 0 || K <= 0 || Kpad < K) return SR_EINVAL;
-  LAUNCH1D(add_unpad_kernel, (long)Cout * K, src, dst, Cout, K, Kpad);
+extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream) {
+  if (!src || !dst || Cout <= 0 || C <= 0 || ksize <= 0 || Kpad < C * ksize * ksize) return SR_EINVAL;
+  LAUNCH1D(add_unpad_kernel, (long)Cout * C * ksize * ksize, src, dst, Cout, C, ksize * ksize, Kpad);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -130,7 +130,7 @@ class WideResNet:
 
     def refresh_operands(self):
         for n, c in self.convs.items():
-            ops.conv_weight_prep(self.p(n), c["Wb"], c["WbT"], c["cout"], c["K"], c["Kp"])
+            ops.conv_weight_prep(self.p(n), c["Wb"], c["WbT"], c["cout"], c["cin"], c["k"], c["Kp"])
 
     def zero_grad(self):
         self.grad.zero_()
@@ -286,7 +286,7 @@ class WideResNet:
             c = self.convs[name]
             dyb = self._buf((tag, name, "dyb"), (rows_out, c["cout"]), bf16)
             ops.cast_f32_bf16(dy, dyb, rows_out * c["cout"])
-            if c["Kp"] == c["K"]:
+            if c["Kp"] == c["K"] and c["k"] == 1:          # (a 1x1 filter: the tap-major K axis IS the parameter's layout)
                 dst = self.view(name, self.grad).view(c["cout"], c["K"])
             else:
                 dst = self._buf((tag, name, "dwpad"), (c["cout"], c["Kp"]), f32)
@@ -333,11 +333,12 @@ class WideResNet:
                     dx = din                                   # raw-x path; this bn1 feeds nothing (no gradient, as in the reference)
             dy = dx
         conv_bwd("conv1.weight", dy, B * ctx.H * ctx.W, ctx.stem["col"], False, ctx.H, ctx.W, 1)
-        desc, npb, ntiles, flops, nbytes = ops.make_group_tn_desc(problems, self.device)
+        # 32 x 288 .. 128 x 1152 outputs over 4096 .. 65536 pixels: slices of 2048 pixels fill the chip (filter gradients meet through fp32 atomics)
+        desc, npb, ntiles, flops, nbytes = ops.make_group_tn_desc(problems, self.device, split_k=2048)
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         for src, name in unpad:
             c = self.convs[name]
-            ops.add_unpad(src, self.p(name, self.grad), c["cout"], c["K"], c["Kp"])
+            ops.add_unpad(src, self.p(name, self.grad), c["cout"], c["cin"], c["k"], c["Kp"])
 
 
 def wrn_28_2(num_classes=100, **kw):

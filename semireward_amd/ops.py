@@ -181,22 +181,36 @@ def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flop
 
 
 GROUP_TN_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
-                       ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("tile_start", "<i4"), ("pad0", "<i4")]
+                       ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("tile_start", "<i4"), ("flags", "<i4")]
 
 
-def make_group_tn_desc(problems, device):
+TN_ATOMIC = 1
+
+
+def make_group_tn_desc(problems, device, split_k=0):
     """problems: list of (A, B, C, dbias, M, N, K) with A bf16 [K,M], B bf16 [K,N] (dense rows), C fp32 [M,N], dbias fp32 [M]
-    or None.  Returns (device uint8 tensor holding srhip_group_tn_desc[], n_problems, total_tiles, flops, algorithmic bytes)."""
+    or None.  Returns (device uint8 tensor holding srhip_group_tn_desc[], n_entries, total_tiles, flops, algorithmic bytes).
+    split_k > 0: a problem with K >= 2 * split_k becomes ceil(K / split_k) entries over slices of its token axis, flagged
+    SRHIP_TN_ATOMIC (they add into C; the launch must then be a C += product, beta = 1)."""
     import numpy as np
-    arr = np.zeros(len(problems), dtype=GROUP_TN_DESC_DTYPE)
+    ent = []
     t = 0
-    for i, (A, B, C, db, M, N, K) in enumerate(problems):
-        arr[i] = (_p(A), _p(B), _p(C), _p(db) or 0, M, N, K, M, N, N, t, 0)
-        t += ((M + 127) // 128) * ((N + 127) // 128)
+    for A, B, C, db, M, N, K in problems:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if split_k > 0 and K >= 2 * split_k:
+            for k0 in range(0, K, split_k):
+                ent.append((_p(A) + 2 * k0 * M, _p(B) + 2 * k0 * N, _p(C), _p(db) or 0, M, N, min(split_k, K - k0), M, N, N, t, TN_ATOMIC))
+                t += tiles
+        else:
+            ent.append((_p(A), _p(B), _p(C), _p(db) or 0, M, N, K, M, N, N, t, 0))
+            t += tiles
+    arr = np.zeros(len(ent), dtype=GROUP_TN_DESC_DTYPE)
+    for i, e in enumerate(ent):
+        arr[i] = e
     assert arr.itemsize == 64
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
-    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(ent), t, flops, nbytes
 
 
 def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
@@ -631,12 +645,12 @@ def col2im(dcol, dact, B, H, W, C, ksize, stride, Kpad, accumulate=False):
     _call("srhip_col2im", _p(dcol), _p(dact), B, H, W, C, ksize, stride, Kpad, int(accumulate), _s())
 
 
-def conv_weight_prep(Wf, Wb, WbT, Cout, K, Kpad):
-    _call("srhip_conv_weight_prep", _p(Wf), _p(Wb), _p(WbT), Cout, K, Kpad, _s())
+def conv_weight_prep(Wf, Wb, WbT, Cout, C, ksize, Kpad):
+    _call("srhip_conv_weight_prep", _p(Wf), _p(Wb), _p(WbT), Cout, C, ksize, Kpad, _s())
 
 
-def add_unpad(src, dst, Cout, K, Kpad):
-    _call("srhip_add_unpad", _p(src), _p(dst), Cout, K, Kpad, _s())
+def add_unpad(src, dst, Cout, C, ksize, Kpad):
+    _call("srhip_add_unpad", _p(src), _p(dst), Cout, C, ksize, Kpad, _s())
 
 
 def bn_fwd(x, gamma, beta, eps, slope, momentum, training, update_running, running_mean, running_var, save_mean, save_invstd, act_bf16,

@@ -109,13 +109,13 @@ def test_conv_building_blocks(B, H, C, Cout, ks, stride):
     rows = B * Ho * Ho
     xd = x.to(DEV).contiguous()
     Wb, WbT = torch.zeros(Cout, Kp, dtype=torch.bfloat16, device=DEV), torch.zeros(Kp, Cout, dtype=torch.bfloat16, device=DEV)
-    ops.conv_weight_prep(torch.from_numpy(Wt).to(DEV).reshape(-1), Wb, WbT, Cout, K, Kp)
+    ops.conv_weight_prep(torch.from_numpy(Wt).to(DEV).reshape(-1), Wb, WbT, Cout, C, ks, Kp)
     col = torch.empty(rows, Kp, dtype=torch.bfloat16, device=DEV)
     ops.im2col(xd, col, B, H, H, C, ks, stride, Kp)
     out = torch.empty(rows, Cout, device=DEV)
     ops.gemm_nt(ops.EPI_F32, col, Wb, out, rows, Cout, Kp)
     xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-    Wr = Wb[:, :K].float().cpu().reshape(Cout, C, ks, ks).requires_grad_(True)
+    Wr = Wb[:, :K].float().cpu().reshape(Cout, ks, ks, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)   # K axis: (tap, channel)
     ref = F.conv2d(xr, Wr, None, stride, pad)
     assert rel(out.cpu().reshape(B, Ho, Ho, Cout), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
     dy = bfr(rng.standard_normal((rows, Cout)).astype(np.float32))
@@ -129,7 +129,16 @@ def test_conv_building_blocks(B, H, C, Cout, ks, stride):
     dW = torch.zeros(Cout, Kp, device=DEV)
     desc, npb, nt, _, _ = ops.make_group_tn_desc([(dyd, col, dW, None, Cout, Kp, rows)], DEV)
     ops.gemm_tn_grouped_f32(desc, npb, nt, alpha=1.0, beta=1.0)
-    assert rel(dW[:, :K].cpu().reshape(Cout, C, ks, ks), Wr.grad.numpy()) < 1e-5
+    assert rel(dW[:, :K].cpu().reshape(Cout, ks, ks, C).permute(0, 3, 1, 2), Wr.grad.numpy()) < 1e-5
+    # the same product as K slices meeting through atomic adds, and the gradient un-permuted into the parameter's [Cout, C, k, k] layout
+    dW2 = torch.zeros(Cout, Kp, device=DEV)
+    desc, npb, nt, _, _ = ops.make_group_tn_desc([(dyd, col, dW2, None, Cout, Kp, rows)], DEV, split_k=32)
+    assert npb == (rows + 31) // 32 if rows >= 64 else npb == 1
+    ops.gemm_tn_grouped_f32(desc, npb, nt, alpha=1.0, beta=1.0)
+    assert rel(dW2.cpu(), dW.cpu()) < 1e-5
+    g = torch.zeros(Cout * K, device=DEV)
+    ops.add_unpad(dW2, g, Cout, C, ks, Kp)
+    assert rel(g.cpu().reshape(Cout, C, ks, ks), Wr.grad.numpy()) < 1e-5
     assert float(dW[:, K:].abs().max()) == 0.0 if Kp > K else True
 
 
