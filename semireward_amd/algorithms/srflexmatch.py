@@ -48,9 +48,13 @@ class _DeferTuner:
     REFINE = 0.025
     WARM, TIMED = 1, 3
 
-    def __init__(self, fractions, refine=True):
+    def __init__(self, fractions, refine=True, agree=None):
         self.queue = list(fractions)        # candidates still to run
         self.refine = refine
+        # data parallel: every rank runs its own tuner over the same steps, and which candidates are queued next (hence how many tuning steps
+        # there are, hence how many gradient all-reduces) hangs on the measured times -- agree(ms) = the maximum over the ranks, so that all
+        # ranks see the same table, take the same decisions and keep the same share (the step of the slowest rank is the job's step anyway)
+        self.agree = agree
         self.results = {}                   # share -> median ms per step
         self.cur, self.marks = None, []
         self.best = self.report = None
@@ -70,7 +74,7 @@ class _DeferTuner:
         if self.cur is not None and len(self.marks) == per + 1:          # the current candidate's steps are marks[0] .. marks[per]
             e.synchronize()
             ms = sorted(self.marks[j].elapsed_time(self.marks[j + 1]) for j in range(self.WARM, per))
-            self.results[self.cur] = ms[len(ms) // 2]
+            self.results[self.cur] = self.agree(ms[len(ms) // 2]) if self.agree is not None else ms[len(ms) // 2]
             self.marks, self.cur = self.marks[-1:], None                 # this event also starts the next candidate's first step
         if self.cur is None:
             if not self.queue and self.refine and self.results:
@@ -468,7 +472,8 @@ class SRConsistencyBase(AlgorithmBase):
                         seen.add(n_)
                         cand[f] = p_
                 if len(cand) > 1:
-                    self._tuners[key] = (_DeferTuner(cand.keys()), cand)
+                    agree = (lambda ms: self.dp.max_over_ranks(ms, self.device)) if self.dp.active else None
+                    self._tuners[key] = (_DeferTuner(cand.keys(), agree=agree), cand)
         tn = self._tuners.get(key)
         if tn is not None:
             tuner, cand = tn

@@ -98,6 +98,14 @@ class DataParallel:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
+    def max_over_ranks(self, value, device):
+        """A host scalar every rank must agree on (a measured time a schedule decision hangs on): its maximum over the ranks."""
+        if not self.active:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
     def broadcast_params(self, *modules):
         """DDP broadcasts rank 0's parameters at construction; do the same for the flat blocks."""
         if self.active:

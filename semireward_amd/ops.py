@@ -316,7 +316,7 @@ def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, 
         e1.record()
         # algorithmic: fc1 + fc2 + proj products; bytes: x in, x out (fp32; x1 never leaves the accumulators), ao in (bf16), [next norm1
         # output out (bf16)], the weights once
-        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_fused_kernel<384, 0, 4, true>",
+        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_fused_kernel<384, 0, 4, true, 1>",
                               8.0 * M * D + 2.0 * M * D + (2.0 * M * D if ln_next is not None else 0.0) + 4.0 * D * Hd + 2.0 * D * D))
         return
     _call("srhip_mlp_fused_proj", *args, _s())

@@ -94,3 +94,64 @@ def test_local_mode_is_reference_semantics():
     assert not dp.active
     r = torch.arange(16, dtype=torch.float32)
     assert torch.equal(dp.reward_means(r, 2), torch.tensor([3.5, 11.5]))     # per-rank local mean (srflexmatch.py:100)
+
+
+class _FakeEvent:
+    """Stand-in for torch.cuda.Event in the tuner test: 'time' advances by a step cost that depends on the rank and on the share the
+    tuner handed out for the step that just ran (set by the worker)."""
+    clock = 0.0
+    cost = 1.0
+
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self):
+        _FakeEvent.clock += _FakeEvent.cost
+        self.t = _FakeEvent.clock
+
+    def synchronize(self):
+        pass
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+def _tuner_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semireward_amd.algorithms import srflexmatch as SF
+    from semireward_amd.distributed import DataParallel
+    dp = DataParallel(world, rank)
+    torch.cuda.Event = _FakeEvent
+    # the two ranks disagree about the best coarse share (rank 0: 0.42, rank 1: 1.0, which has no neighbours to refine): left alone they
+    # would queue different refinements, run a different number of tuning steps and issue a different number of gradient all-reduces
+    best_of = {0: 0.42, 1: 1.0}[rank]
+    cost = lambda f: (1.0 + abs(f - best_of)) * (1.0 + 0.5 * rank)      # noqa: E731
+    tuner = SF._DeferTuner(SF._DeferTuner.CANDIDATES, agree=lambda ms: dp.max_over_ranks(ms, "cpu"))
+    seq, prev = [], None
+    while not tuner.done and len(seq) < 200:
+        _FakeEvent.cost = cost(prev) if prev is not None else 1.0       # the step that just ended ran with the previous share
+        prev = tuner.fraction()
+        seq.append(prev)
+        g = torch.ones(4)
+        dist.all_reduce(g)                                               # the step's gradient exchange: hangs if the ranks' step counts differ
+    q.put((rank, seq, tuner.best, tuner.report))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_share_tuner_takes_the_same_decisions_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_tuner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, b0, r0), (_, s1, b1, r1) = res
+    assert s0 == s1 and b0 == b1 and r0 == r1 and len(s0) > len(_FakeEvent.__mro__)       # same shares step for step, same choice, same table
+    from semireward_amd.algorithms.srflexmatch import _DeferTuner
+    assert len(s0) >= len(_DeferTuner.CANDIDATES) * (_DeferTuner.WARM + _DeferTuner.TIMED)
