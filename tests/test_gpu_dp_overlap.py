@@ -20,8 +20,8 @@ def test_sliced_all_reduce_under_the_backward_equals_single_all_reduce():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tools", "dp_overlap_check.py")],
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    lines = [l for l in r.stdout.splitlines() + r.stderr.splitlines() if l.startswith("rank ")]
-    assert r.returncode == 0 and len(lines) == 2, (r.stdout[-2000:], r.stderr[-3000:])
+    out = r.stdout + r.stderr                  # (the two ranks' lines may interleave on one line: count the verdicts, not the lines)
+    assert r.returncode == 0 and out.count("ranks agree: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_global_reward_threshold_through_the_engine_with_two_ranks():
