@@ -485,7 +485,8 @@ int srhip_augment(const unsigned char* src, int n_src, int H0, int W0, int B, in
  *   bn_fwd            : nn.BatchNorm2d + LeakyReLU(slope) (wrn.py:32-38, :104-105).  training != 0: statistics of THIS batch (saved in
  *                       save_mean / save_invstd), running_mean / running_var moved with ``momentum`` (unbiased variance) unless
  *                       update_running == 0 (Bn_Controller.freeze_bn, core/utils/misc.py:105-129); training == 0: running statistics.
- *                       Outputs: act_bf16 and/or act_f32 (either may be NULL).  ws: 2*C doubles of scratch.  256 % C == 0.
+ *                       Outputs: act_bf16 and/or act_f32 (either may be NULL).  256 % C == 0.  ws: srhip_bn_ws_doubles() doubles of scratch the
+ *                       caller ZEROES ONCE (every launch leaves its accumulator copies and arrival counter at zero: no memset per call).
  *   bn_bwd            : dx = resid (or 0) + BN'(LeakyReLU'(dact)); dgamma += , dbeta += .
  *   avgpool_fwd/bwd   : F.adaptive_avg_pool2d(.,1) (wrn.py:121);  fc_fwd/bwd: the classifier Linear (wrn.py:106, :126)
  *   sgd_flat          : torch.optim.SGD(momentum, nesterov=True) on a flat block (core/utils/build.py:193-224, optim 'SGD'); chunk table =
@@ -495,6 +496,7 @@ int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksi
 int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int ksize, int stride, int Kpad, int accumulate, void* stream);
 int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int C, int ksize, int Kpad, void* stream);
 int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream);
+long long srhip_bn_ws_doubles(void);
 int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
                  int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* act_bf16,
                  float* act_f32, double* ws, int rows, int C, void* stream);

@@ -96,6 +96,7 @@ SIGNATURES = {
     "srhip_col2im": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "srhip_conv_weight_prep": (I, [P, P, P, I, I, I, I, P]),
     "srhip_add_unpad": (I, [P, P, I, I, I, I, P]),
+    "srhip_bn_ws_doubles": (ctypes.c_longlong, []),
     "srhip_bn_fwd": (I, [P, P, P, F, F, F, I, I, P, P, P, P, P, P, P, I, I, P]),
     "srhip_bn_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, P, I, I, P]),
     "srhip_avgpool_fwd": (I, [P, P, I, I, I, P]),

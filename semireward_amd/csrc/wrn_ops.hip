@@ -113,15 +113,61 @@ __global__ void add_unpad_kernel(const float* __restrict__ src, float* __restric
 // ---- BatchNorm over the rows of x fp32 [rows, C] --------------------------------------------------------------------------------
 // column sums in double: ws[0..C) = sum, ws[C..2C) = sum of squares (forward) / sum dy', sum dy' * xhat (backward).
 // A workgroup covers rows_per_block rows; a thread owns V consecutive channels (V = 4: one 16-byte load per row) of every (256 / (C / V))-th
-// row, the per-thread partials meet in LDS, and the first 2C threads add the workgroup's sums to ws with one fp64 atomic each.  The launch
-// picks rows_per_block so that the grid is ~512 workgroups when the tensor allows it: the statistics pass of a 64 x 32 x 32 x 32
-// activation (8 MB) is an HBM/L2 read, not a serial loop of 64 workgroups.
+// row, four rows requested before the first is used; the per-thread partials meet in LDS and the workgroup adds its 2C sums with hardware
+// fp64 atomics (global_atomic_add_f64) into copy (workgroup % BN_COPIES) of the accumulator -- one copy for everybody was 512 workgroups
+// queueing on four cache lines, 10 of the pass's 13 us.  The workgroup that arrives last (one integer atomic each) adds the copies into
+// ws[0..2C) for the apply launch and leaves copies and counter at ZERO: no memset launch per BatchNorm, the caller zeroes ws once.
+// (fp64 sums are order-dependent in the last bit of a double, 29 bits below the float the statistics are rounded to.)
+// ws layout (doubles): [0, 512) result | [512] counter (low 32 bits) | [520, 520 + BN_COPIES * 512) accumulator copies.
+constexpr int BN_COPIES = 16, BN_WS_COUNTER = 512, BN_WS_ACC = 520;
+
+// the tail every statistics producer shares: add this workgroup's 2C sums (red2c in LDS, [2C] doubles), and if it is the last one of the
+// launch, fold the copies.  Returns true in the last workgroup (all threads), with the totals in ws[0..2C) AND in red2c.
+__device__ __forceinline__ bool bn_accumulate_and_fold(double* __restrict__ ws, double* red2c, int C, unsigned n_workgroups, unsigned my_index,
+                                                       int* is_last_lds) {
+  double* acc = ws + BN_WS_ACC + (size_t)(my_index % BN_COPIES) * 512;
+  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) unsafeAtomicAdd(acc + o, red2c[o]);
+  // The adds above must be performed before the arrival is counted.  They are device-scope atomics (performed at the memory side, not held
+  // dirty in this XCD's L2), so waiting for their acknowledgement is enough: a workgroup-scope release is that s_waitcnt and nothing else.
+  // __threadfence() here is a device-scope release = buffer_wbl2, a walk over the XCD's 4 MB L2 (~1 us, serialised per XCD): 64 workgroups
+  // per XCD each paying for one made this pass 35 us instead of 5.  (MI355X_MICROARCH.md, inter-workgroup visibility: 8-byte device-scope
+  // atomics on both sides are a valid hand-off without fences.)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (explicit: the fence above may lower to nothing)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* counter = reinterpret_cast<unsigned*>(ws + BN_WS_COUNTER);
+    const unsigned seen = atomicAdd(counter, 1u);
+    *is_last_lds = seen == n_workgroups - 1;
+    if (seen == n_workgroups - 1) *counter = 0u;            // (everybody has arrived: nobody touches it again in this launch)
+  }
+  __syncthreads();
+  if (!*is_last_lds) return false;
+  // (acquire side: device-scope atomic loads below read at the memory side; nothing of this data is in a cache of this workgroup)
+  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
+    double u[BN_COPIES], t = 0.0;
+#pragma unroll
+    for (int q = 0; q < BN_COPIES; ++q) u[q] = __hip_atomic_load(ws + BN_WS_ACC + (size_t)q * 512 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < BN_COPIES; ++q) {
+      t += u[q];
+      __hip_atomic_store(ws + BN_WS_ACC + (size_t)q * 512 + o, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ws[o] = t;
+    red2c[o] = t;
+  }
+  __syncthreads();
+  return true;
+}
+
 template <bool BWD, int V>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dact, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float slope, double* __restrict__ ws, int rows, int C,
                                                        int rows_per_block) {
   __shared__ double red[2][256 * V];
+  __shared__ double red2c[512];
+  __shared__ int is_last;
   const int cl = C / V;                                   // threads along a row
   const int c0 = (threadIdx.x % cl) * V, lane_row = threadIdx.x / cl, rpb = 256 / cl;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -132,27 +178,40 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     s1[v] = 0.0; s2[v] = 0.0;
     if (BWD) { mu[v] = mean[c0 + v]; is[v] = invstd[c0 + v]; g[v] = gamma[c0 + v]; bt[v] = beta[c0 + v]; }
   }
-  for (int r = r0 + lane_row; r < r1; r += rpb) {
-    float xv[V], dv[V];
-    if (V == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
-      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-      if (BWD) {
-        const float4 u = *reinterpret_cast<const float4*>(dact + (size_t)r * C + c0);
-        dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
+  constexpr int U = 4;                                    // rows in flight per thread
+  for (int rb = r0 + lane_row; rb < r1; rb += U * rpb) {
+    float xv[U][V], dv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + u * rpb;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { xv[u][v] = 0.f; dv[u][v] = 0.f; }
+      if (r < r1) {
+        if (V == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
+          xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+          if (BWD) {
+            const float4 w = *reinterpret_cast<const float4*>(dact + (size_t)r * C + c0);
+            dv[u][0] = w.x; dv[u][1] = w.y; dv[u][2] = w.z; dv[u][3] = w.w;
+          }
+        } else {
+          xv[u][0] = x[(size_t)r * C + c0];
+          if (BWD) dv[u][0] = dact[(size_t)r * C + c0];
+        }
       }
-    } else {
-      xv[0] = x[(size_t)r * C + c0];
-      if (BWD) dv[0] = dact[(size_t)r * C + c0];
     }
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      if (!BWD) {
-        s1[v] += (double)xv[v]; s2[v] += (double)xv[v] * (double)xv[v];
-      } else {
-        const float xh = (xv[v] - mu[v]) * is[v], yv = g[v] * xh + bt[v];
-        const float dy = dv[v] * (yv > 0.f ? 1.0f : slope);
-        s1[v] += (double)dy; s2[v] += (double)dy * (double)xh;
+    for (int u = 0; u < U; ++u) {
+      if (rb + u * rpb >= r1) continue;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (!BWD) {
+          s1[v] += (double)xv[u][v]; s2[v] += (double)xv[u][v] * (double)xv[u][v];
+        } else {
+          const float xh = (xv[u][v] - mu[v]) * is[v], yv = g[v] * xh + bt[v];
+          const float dy = dv[u][v] * (yv > 0.f ? 1.0f : slope);
+          s1[v] += (double)dy; s2[v] += (double)dy * (double)xh;
+        }
       }
     }
   }
@@ -163,8 +222,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     const int which = o / C, c = o % C;
     double t = 0.0;
     for (int j = 0; j < rpb; ++j) t += red[which][j * C + c];
-    unsafeAtomicAdd(ws + o, t);                     // global_atomic_add_f64 (the plain atomicAdd is a compare-and-swap loop)
+    red2c[o] = t;
   }
+  __syncthreads();
+  bn_accumulate_and_fold(ws, red2c, C, gridDim.x, blockIdx.x, &is_last);
 }
 
 // rows per workgroup of bn_reduce_kernel: a multiple of the rows one pass of the workgroup covers, ~512 workgroups, at most 1024 rows
@@ -359,6 +420,8 @@ extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int C, in
   return SR_OK;
 }
 
+extern "C" long long srhip_bn_ws_doubles(void) { return (long long)BN_WS_ACC + (long long)BN_COPIES * 512; }
+
 extern "C" int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
                             int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                             void* act_bf16, float* act_f32, double* ws, int rows, int C, void* stream) {
@@ -366,7 +429,6 @@ extern "C" int srhip_bn_fwd(const float* x, const float* gamma, const float* bet
   if (training && (!save_mean || !save_invstd || !ws)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (training) {
-    if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), s) != hipSuccess) return SR_ELAUNCH;
     if (C % 4 == 0) {
       const int rpb = bn_rows_per_block(rows, C, 4);
       hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
@@ -390,7 +452,6 @@ extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save
   if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !ws || rows <= 0 || C <= 0 || C > 256 || (256 % C))
     return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), s) != hipSuccess) return SR_ELAUNCH;
   if (C % 4 == 0) {
     const int rpb = bn_rows_per_block(rows, C, 4);
     hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,

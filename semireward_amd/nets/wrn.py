@@ -74,7 +74,7 @@ class WideResNet:
                 self.convs[nme] = dict(cout=cout, cin=cin, k=k, K=K, Kp=Kp,
                                        Wb=torch.zeros(cout, Kp, dtype=torch.bfloat16, device=self.device),
                                        WbT=torch.zeros(Kp, cout, dtype=torch.bfloat16, device=self.device))
-        self.ws = torch.zeros(512, dtype=torch.float64, device=self.device)
+        self.ws = torch.zeros(ops.bn_ws_doubles(), dtype=torch.float64, device=self.device)      # (zeroed once: srhip_bn_fwd keeps its counter at 0)
         self.training = True
         self.couples_batch_rows = True      # BatchNorm: every forward call is its own statistics group (no cross-pass batching)
         self._buf_cache = {}

@@ -653,6 +653,11 @@ def add_unpad(src, dst, Cout, C, ksize, Kpad):
     _call("srhip_add_unpad", _p(src), _p(dst), Cout, C, ksize, Kpad, _s())
 
 
+def bn_ws_doubles():
+    from ._lib import lib
+    return int(lib().srhip_bn_ws_doubles())
+
+
 def bn_fwd(x, gamma, beta, eps, slope, momentum, training, update_running, running_mean, running_var, save_mean, save_invstd, act_bf16,
            act_f32, ws, rows, C):
     _call("srhip_bn_fwd", _p(x), _p(gamma), _p(beta), eps, slope, momentum, int(training), int(update_running), _p(running_mean),

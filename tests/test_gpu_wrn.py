@@ -142,7 +142,7 @@ def test_conv_building_blocks(B, H, C, Cout, ks, stride):
     assert float(dW[:, K:].abs().max()) == 0.0 if Kp > K else True
 
 
-@pytest.mark.parametrize("rows,C", [(96, 32), (1024, 128), (5000, 16)])
+@pytest.mark.parametrize("rows,C", [(96, 32), (1024, 128), (5000, 16), (65536, 32), (16384, 64), (300, 256), (70001, 4)])
 def test_batchnorm_leakyrelu(rows, C):
     """srhip_bn_fwd / srhip_bn_bwd against F.batch_norm + leaky_relu autograd: batch statistics, running update (unbiased variance,
     momentum 0.001), frozen update, eval mode, input gradient with a residual term, dgamma / dbeta."""
@@ -162,8 +162,9 @@ def test_batchnorm_leakyrelu(rows, C):
     rmd, rvd = d(rm0), d(rv0)
     mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     act, af = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV), torch.empty(rows, C, device=DEV)
-    ws = torch.zeros(512, dtype=torch.float64, device=DEV)
+    ws = torch.zeros(ops.bn_ws_doubles(), dtype=torch.float64, device=DEV)          # zeroed once; every launch leaves its counter at zero
     ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, True, True, rmd, rvd, mean, invstd, act, af, ws, rows, C)
+    assert int(ws[512:513].view(torch.int64)) == 0
     assert rel(af.cpu(), y.detach().numpy()) < 2e-6 and rel(act.float().cpu(), y.detach().numpy()) < 4e-3
     np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-6, atol=1e-7)
@@ -175,6 +176,12 @@ def test_batchnorm_leakyrelu(rows, C):
     rm1, rv1 = rmd.clone(), rvd.clone()
     ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, True, False, rmd, rvd, mean, invstd, act, af, ws, rows, C)
     assert torch.equal(rmd, rm1) and torch.equal(rvd, rv1) and rel(af.cpu(), y.detach().numpy()) < 2e-6
+    # fp64 sums rounded to float: the same statistics launch after launch; the workspace is left clean (accumulator copies and counter zero)
+    m0, i0, a0 = mean.clone(), invstd.clone(), af.clone()
+    for _ in range(3):
+        ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, True, False, rmd, rvd, mean, invstd, act, af, ws, rows, C)
+        assert torch.equal(mean, m0) and torch.equal(invstd, i0) and torch.equal(af, a0)
+    assert float(ws[512:].abs().max()) == 0.0
     ops.bn_fwd(xd, gd, bd, 1e-5, 0.1, 0.001, False, False, rmd, rvd, None, None, act, af, ws, rows, C)
     ye = F.leaky_relu(F.batch_norm(x, rm, rv, gam, bet, False, 0.001, 1e-5), 0.1)
     assert rel(af.cpu(), ye.numpy()) < 2e-6
