@@ -497,6 +497,27 @@ int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int
 int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int C, int ksize, int Kpad, void* stream);
 int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream);
 long long srhip_bn_ws_doubles(void);
+/* The same BasicBlock as ONE launch per convolution (csrc/wrn_conv.hip; wrn.py:41-60):
+ *   wrn_conv_bn : y fp32 [B*Ho*Wo, Cout] = conv_{k,stride,pad k/2}( f(xin) ) (+ resid), xin fp32 NHWC [B,H,W,Cin] read in place (implicit GEMM);
+ *                 f by in_mode: 0 = LeakyReLU(BatchNorm(x; in_mean, in_isd = invstd)), 1 = the same from running statistics (in_isd = running
+ *                 VAR, in_eps), 2 = identity (the raw-x path of wrn.py:50), 3 = LeakyReLU(BatchNorm(x)) with the batch statistics folded
+ *                 from in_acc (the accumulator the launch that produced xin filled).  pub_mean != NULL (with in_acc, any mode): workgroup
+ *                 (0,0) publishes mean / invstd of that BatchNorm (the backward reads them) and moves its running statistics when
+ *                 update_running (momentum; unbiased variance).  Wb = conv_weight_prep's bf16 [Cout, Kpad].  acc_out != NULL: per-channel
+ *                 sum / sum of squares of y are ADDED into it (srhip_bn_acc_doubles(Cout) doubles, zeroed by the caller before the forward)
+ *                 for the BatchNorm that reads y next.  Cin a power of two in [8,128]; Cout in {16, 32, 64} or a multiple of 64.
+ *   bn_stats    : the statistics of a tensor no wrn_conv_bn produced: mean / invstd / running update of x fp32 [rows, C] (ws as for bn_fwd).
+ *   bn_act      : act bf16 [rows, C] = f(x) by modes 0-2 -- the backward's im2col operand, recomputed instead of stored. */
+int srhip_wrn_conv_supported(int Cin, int Cout, int ksize);
+long long srhip_bn_acc_doubles(int C);
+int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* in_gamma,
+                      const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
+                      float* running_var, float momentum, int update_running, const void* Wb, const float* resid, float* y, int B, int H,
+                      int W, int Cin, int Cout, int ksize, int stride, int Kpad, double* acc_out, void* stream);
+int srhip_bn_stats(const float* x, float eps, float momentum, int update_running, float* running_mean, float* running_var, float* out_mean,
+                   float* out_invstd, double* ws, int rows, int C, void* stream);
+int srhip_bn_act(const float* x, const float* mean, const float* invstd_or_var, const float* gamma, const float* beta, float eps, float slope,
+                 int mode, void* act_bf16, int rows, int C, void* stream);
 int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
                  int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* act_bf16,
                  float* act_f32, double* ws, int rows, int C, void* stream);

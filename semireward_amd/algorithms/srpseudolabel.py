@@ -66,13 +66,13 @@ class SRPseudoLabel(SRConsistencyBase):
             # BatchNorm backbone (classic_cv, WRN): every model call of the reference is its own statistics group, so the calls stay
             # separate launches -- model(x_lb) moves the running statistics (:96), every model(x_ulb_w) runs under Bn_Controller.freeze_bn
             # (:100-110, :65-76).  Only the labelled forward and the LAST unlabelled forward carry a gradient.
-            lg_lb, ft_lb, ctx_lb = self.model.forward_features(x_lb.contiguous(), save=True, update_stats=True, tag="lb")
+            lg_lb, ft_lb, ctx_lb = self.model.forward_saved(x_lb.contiguous(), update_stats=True, tag="lb")
             lws, fws, ctx_u = [], [], None
             xu = x_ulb_w.contiguous()
             for k in range(P):
                 if k == K:
-                    lg, ft, ctx_u = self.model.forward_features(xu, save=True, update_stats=False, tag="ulb")
-                else:            # the K passes whose loss data_generator discards: frozen statistics, no state -> one HIP-graph replay each
+                    lg, ft, ctx_u = self.model.forward_saved(xu, update_stats=False, tag="ulb")
+                else:            # the K passes whose loss data_generator discards: frozen statistics, no state (every pass is a HIP-graph replay)
                     lg, ft = self.model.forward_frozen(xu, tag="ulb_inf")
                 lws.append(lg); fws.append(ft)
             logits, feats, ctx = torch.cat([lg_lb] + lws), torch.cat([ft_lb] + fws), (ctx_lb, ctx_u)

@@ -1,0 +1,321 @@
+// WideResNet BasicBlock convolution for gfx950 with the BatchNorm around it folded in (semilearn/nets/wrn/wrn.py:41-60):
+//
+//     y = conv_{k x k, stride}( LeakyReLU(BatchNorm(xin)) ) (+ resid),   and the column statistics of y for the BatchNorm that reads y next
+//
+// in ONE launch per convolution.  SRPseudoLabel forwards the same 64-image batch K + 1 >= 9 times per step (srpseudolabel.py:59-90); as
+// separate kernels a convolution was BN statistics (read y) -> BN apply (read y, write bf16 act) -> im2col (write 9 x act) -> GEMM (read
+// 9 x act): ~60 MB of traffic and four launches for a 4 MB activation.  Here:
+//   * implicit GEMM: the MFMA B operand (8 consecutive channels of one filter tap of one output pixel) is read straight from the fp32
+//     NHWC input -- two 16-byte loads --, normalised + activated in registers with exactly bn_apply_kernel's arithmetic and rounded to
+//     bf16 once; padding taps are zeros.  The nine taps of a pixel re-read the input from L1 / L2, not from a materialised col.
+//   * the A operand is the filter in the tap-major [Cout, Kpad] bf16 layout of conv_weight_prep, read from L1 / L2 (18-288 KB per layer).
+//   * a wave owns 16 output pixels x NT 16-channel tiles (v_mfma_f32_16x16x32_bf16; a lane ends up with 4 consecutive channels of one
+//     pixel = one 16-byte store) and walks pixel tiles with a grid stride (<= 512 workgroups); with few pixel tiles and a long K (the
+//     16x16 and 8x8 layers) two or four waves of a workgroup share a tile and take every 2nd / 4th k step (LDS reduce).
+//   * three k steps are requested ahead of the one being consumed: the loop is bound by the latency of L2 / fabric round trips.
+//   * epilogue: + resid, store, and per-channel sum / sum of squares of what was stored: lanes -> wave (shuffles, double from here on)
+//     -> workgroup (LDS) -> 16 accumulator copies of the NEXT BatchNorm (fp64 atomics, nobody waits for them).  The launch that reads y
+//     folds the copies in its prologue (mode 3), and its workgroup (0, 0) publishes mean / invstd (the backward reads them) and moves the
+//     running statistics.  (A fold by the producer's last workgroup -- arrival counter, re-read, store -- was 10-15 us of serial tail.)
+//     The caller zeroes the accumulators of all BatchNorms once per forward.
+// No LDS staging, no barrier in the main loop: the layers are small (1.2 GFLOP at most) and bound by load latency, which 16 waves per CU
+// of independent pixel tiles cover.
+#include <stdlib.h>
+
+#include "../../include/srhip.h"
+#include "common.h"
+#include "wrn_bn.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* xin;
+  const float* in_mean; const float* in_isd; const float* in_gamma; const float* in_beta;
+  const double* in_acc;        // mode 3 (and the publishing workgroup of any mode): accumulator copies [BN_COPIES][2 Cin] of the input BatchNorm
+  float in_eps, slope;
+  int in_mode;                 // 0: BN(mean, invstd) + LeakyReLU | 1: BN(running mean, running VAR, eps) + LeakyReLU | 2: raw input |
+                               // 3: BN(statistics folded from in_acc) + LeakyReLU
+  BnFinal pub;                 // pub.out_mean != NULL: workgroup (0, 0) publishes the folded statistics of the input BatchNorm
+  const bf16_t* Wb;
+  const float* resid;
+  float* y;
+  int H, W, Cin, log2Cin, Cout, ks, stride, Ho, Wo, Kp, npix, ntiles, in_rows;
+  double* acc_out;             // NULL: no statistics; else accumulator copies [BN_COPIES][2 Cout] of the BatchNorm that reads y
+};
+
+// what a lane requests for one 32-wide k step: its 8 input channels (raw fp32) and NT filter fragments
+template <int NT>
+struct StepRaw {
+  float4 v0, v1;
+  u32x4_t af[NT];
+  int c;                       // first of the lane's 8 channels; -1: padding / beyond K (B fragment = zeros)
+};
+
+template <int NT, int KS>
+__global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
+  __shared__ float prm[4][128];                       // mean, invstd, gamma, beta of the input BatchNorm
+  __shared__ double redw[4][2][NT * 16];
+  __shared__ double red2c[256];
+  __shared__ float kred[KS > 1 ? 4 : 1][NT][4][64];    // split K: the partial accumulators of the waves with k part != 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const bool publish = a.pub.out_mean != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  if (a.in_mode == 3 || publish) {
+    // the statistics of the input BatchNorm were left as BN_COPIES partial sums by the launch that produced xin (its epilogue only adds;
+    // a fold by ITS last workgroup cost 10-15 us of serial tail per launch): every workgroup folds them here, 16 independent L2 hits
+    for (int o = tid; o < 2 * a.Cin; o += 256) {
+      double u[BN_COPIES], t = 0.0;
+#pragma unroll
+      for (int q = 0; q < BN_COPIES; ++q) u[q] = a.in_acc[(size_t)q * 2 * a.Cin + o];
+#pragma unroll
+      for (int q = 0; q < BN_COPIES; ++q) t += u[q];
+      red2c[o] = t;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.Cin; c += 256) {                // bn_apply_kernel's mean / variance / invstd
+      const double m = red2c[c] / a.in_rows, v = red2c[a.Cin + c] / a.in_rows - m * m;
+      const float mu = (float)m, var = (float)(v > 0.0 ? v : 0.0);
+      if (a.in_mode == 3) { prm[0][c] = mu; prm[1][c] = 1.0f / sqrtf(var + a.in_eps); prm[2][c] = a.in_gamma[c]; prm[3][c] = a.in_beta[c]; }
+    }
+    if (publish) bn_finalize(red2c, a.Cin, a.in_rows, a.pub);
+  }
+  if (a.in_mode == 0 || a.in_mode == 1) {
+    for (int c = tid; c < a.Cin; c += 256) {
+      prm[0][c] = a.in_mean[c];
+      prm[1][c] = a.in_mode == 1 ? 1.0f / sqrtf(a.in_isd[c] + a.in_eps) : a.in_isd[c];
+      prm[2][c] = a.in_gamma[c];
+      prm[3][c] = a.in_beta[c];
+    }
+  }
+  __syncthreads();
+  const int co0 = blockIdx.y * NT * 16, K = a.ks * a.ks * a.Cin, pad = a.ks >> 1, nks = a.Kp >> 5, HoWo = a.Ho * a.Wo;
+  const bool stats = a.acc_out != nullptr;
+  // a lane adds ONE value per pixel tile it walks (<= 4 of them at the launch sizes below): fp32 here, double from the wave reduction on
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+  // KS > 1: KS waves of a workgroup share a pixel tile and take every KS-th k step (few pixel tiles, long K: the 16x16 and 8x8 layers run
+  // one wave per SIMD otherwise, each walking 18-36 dependent L2 round trips); a workgroup covers 4 / KS tiles per round
+  constexpr int TPW = 4 / KS;                              // tiles per workgroup round
+  const int kpart = wave % KS, tsub = wave / KS;
+  const int ks0 = kpart, ksstep = KS;
+  const bf16_t* wrow = a.Wb + (size_t)(co0 + l15) * a.Kp + 8 * lg;
+  const int rounds = (a.ntiles + gridDim.x * TPW - 1) / (gridDim.x * TPW);
+
+  for (int rnd = 0; rnd < rounds; ++rnd) {
+    const int pt = (rnd * gridDim.x + blockIdx.x) * TPW + tsub;
+    const int n = pt * 16 + l15;
+    const bool valid = pt < a.ntiles && n < a.npix;
+    const int nn = valid ? n : 0;
+    const int b = nn / HoWo, rr = nn - b * HoWo, yo = rr / a.Wo, xo = rr - yo * a.Wo;
+    const int y0 = yo * a.stride - pad, x0 = xo * a.stride - pad;
+    const float* base = a.xin + (size_t)b * a.H * a.W * a.Cin;
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto request = [&](int ksi) {
+      StepRaw<NT> q;
+      const int k = ksi * 32 + 8 * lg;
+      q.c = -1;
+      q.v0 = float4{0.f, 0.f, 0.f, 0.f}; q.v1 = q.v0;
+      if (valid && k < K) {
+        const int tap = k >> a.log2Cin, c = k & (a.Cin - 1);
+        const int dy = a.ks == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
+        const int yy = y0 + dy, xx = x0 + dx;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+          const float4* p = reinterpret_cast<const float4*>(base + ((size_t)yy * a.W + xx) * a.Cin + c);
+          q.v0 = p[0]; q.v1 = p[1];
+          q.c = c;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) q.af[t] = *reinterpret_cast<const u32x4_t*>(wrow + (size_t)16 * t * a.Kp + ksi * 32);
+      return q;
+    };
+    auto consume = [&](const StepRaw<NT>& q) {
+      u32x4_t bfrag = {0u, 0u, 0u, 0u};
+      if (q.c >= 0) {
+        float v[8] = {q.v0.x, q.v0.y, q.v0.z, q.v0.w, q.v1.x, q.v1.y, q.v1.z, q.v1.w};
+        if (a.in_mode != 2) {
+          const int c = q.c;
+          const float4 m0 = *reinterpret_cast<const float4*>(&prm[0][c]), m1 = *reinterpret_cast<const float4*>(&prm[0][c + 4]);
+          const float4 i0 = *reinterpret_cast<const float4*>(&prm[1][c]), i1 = *reinterpret_cast<const float4*>(&prm[1][c + 4]);
+          const float4 g0 = *reinterpret_cast<const float4*>(&prm[2][c]), g1 = *reinterpret_cast<const float4*>(&prm[2][c + 4]);
+          const float4 b0 = *reinterpret_cast<const float4*>(&prm[3][c]), b1 = *reinterpret_cast<const float4*>(&prm[3][c + 4]);
+          const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+          const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {                 // bn_apply_kernel's arithmetic, operation for operation
+            const float yv = g[e] * ((v[e] - mu[e]) * is[e]) + bt[e];
+            v[e] = yv > 0.f ? yv : a.slope * yv;
+          }
+        }
+        bfrag = u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, q.af[t]), __builtin_bit_cast(bf16x8_t, bfrag), acc[t], 0, 0, 0);
+    };
+    // three k steps requested ahead of the one being consumed: the loop is bound by load latency (L2 / fabric round trips: the input was
+    // written by the previous launch, mostly on other XCDs), not by bytes or MFMAs
+    if (ks0 < nks) {
+      StepRaw<NT> q0 = request(ks0), q1 = q0, q2 = q0;
+      if (ks0 + ksstep < nks) q1 = request(ks0 + ksstep);
+      if (ks0 + 2 * ksstep < nks) q2 = request(ks0 + 2 * ksstep);
+      for (int ksi = ks0; ksi < nks; ksi += ksstep) {
+        StepRaw<NT> q3 = q2;
+        if (ksi + 3 * ksstep < nks) q3 = request(ksi + 3 * ksstep);
+        consume(q0);
+        q0 = q1; q1 = q2; q2 = q3;
+      }
+    }
+    if (KS > 1) {
+      if (kpart != 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) kred[wave][t][r][lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (kpart == 0) {
+#pragma unroll
+        for (int p = 1; p < KS; ++p)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += kred[wave + p][t][r][lane];
+      }
+    }
+    // D[i][j]: i = output channel within the tile = 4 lg + r, j = pixel = l15
+    if (valid && kpart == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const size_t o = (size_t)n * a.Cout + co0 + 16 * t + 4 * lg;
+        f32x4_t out = acc[t];
+        if (a.resid) {
+          const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(a.resid + o);
+          out[0] += rs[0]; out[1] += rs[1]; out[2] += rs[2]; out[3] += rs[3];
+        }
+        *reinterpret_cast<f32x4_t*>(a.y + o) = out;
+        if (stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[t][r] += out[r]; s2[t][r] += out[r] * out[r]; }
+        }
+      }
+    }
+    if (KS > 1) __syncthreads();                          // kred is free again
+  }
+  if (!stats) return;
+  // ---- statistics: the 16 pixel lanes of a channel group -> lane l15 == 0 -> wave slot in LDS -> workgroup -> accumulator copy
+  // (waves with a k part != 0 stored nothing: their sums are zero)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float f1 = s1[t][r], f2 = s2[t][r];                    // 16 pixels x (<= 4 tiles) per channel in fp32, double from the wave slot on
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); }
+      if (l15 == 0) { redw[wave][0][16 * t + 4 * lg + r] = (double)f1; redw[wave][1][16 * t + 4 * lg + r] = (double)f2; }
+    }
+  __syncthreads();
+  double* accp = a.acc_out + (size_t)(blockIdx.x % BN_COPIES) * 2 * a.Cout;
+  for (int o = tid; o < 2 * NT * 16; o += 256) {
+    const int which = o / (NT * 16), ch = o % (NT * 16);
+    const double tsum = redw[0][which][ch] + redw[1][which][ch] + redw[2][which][ch] + redw[3][which][ch];
+    unsafeAtomicAdd(accp + which * a.Cout + co0 + ch, tsum);          // fire and forget: the next launch reads them
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ isd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float slope,
+                                                    int mode, bf16_t* __restrict__ act, size_t n4, int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over rows * C / 4
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  float o[4] = {v.x, v.y, v.z, v.w};
+  if (mode != 2) {
+    const int c = (int)((i * 4) % C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float is = mode == 1 ? 1.0f / sqrtf(isd[c + e] + eps) : isd[c + e];
+      const float yv = gamma[c + e] * ((o[e] - mean[c + e]) * is) + beta[c + e];
+      o[e] = yv > 0.f ? yv : slope * yv;
+    }
+  }
+  u32x2_t pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+  reinterpret_cast<u32x2_t*>(act)[i] = pk;
+}
+
+}  // namespace
+
+extern "C" int srhip_wrn_conv_supported(int Cin, int Cout, int ksize) {
+  return (ksize == 1 || ksize == 3) && Cin >= 8 && Cin <= 128 && (Cin & (Cin - 1)) == 0 && Cout <= 256 &&
+         (Cout == 16 || Cout == 32 || (Cout >= 64 && Cout % 64 == 0));
+}
+
+extern "C" long long srhip_bn_acc_doubles(int C) { return (long long)BN_COPIES * 2 * C; }
+
+extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc,
+                                 const float* in_gamma, const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd,
+                                 float* running_mean, float* running_var, float momentum, int update_running, const void* Wb,
+                                 const float* resid, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int Kpad,
+                                 double* acc_out, void* stream) {
+  if (!xin || !Wb || !y || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || !srhip_wrn_conv_supported(Cin, Cout, ksize) ||
+      Kpad < Cin * ksize * ksize || (Kpad % 32) || in_mode < 0 || in_mode > 3)
+    return SR_EINVAL;
+  if ((in_mode == 0 || in_mode == 1) && (!in_mean || !in_isd)) return SR_EINVAL;
+  if (in_mode != 2 && (!in_gamma || !in_beta)) return SR_EINVAL;
+  if ((in_mode == 3 || pub_mean) && !in_acc) return SR_EINVAL;
+  if (pub_mean && (!pub_invstd || (update_running && (!running_mean || !running_var)))) return SR_EINVAL;
+  ConvArgs a;
+  a.xin = xin; a.in_mean = in_mean; a.in_isd = in_isd; a.in_gamma = in_gamma; a.in_beta = in_beta; a.in_acc = in_acc;
+  a.in_eps = in_eps; a.slope = slope; a.in_mode = in_mode;
+  a.pub.out_mean = pub_mean; a.pub.out_invstd = pub_invstd; a.pub.running_mean = running_mean; a.pub.running_var = running_var;
+  a.pub.momentum = momentum; a.pub.update_running = update_running; a.pub.eps = in_eps;
+  a.Wb = (const bf16_t*)Wb; a.resid = resid; a.y = y;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.stride = stride; a.Kp = Kpad;
+  a.in_rows = B * H * W;
+  a.log2Cin = 0;
+  while ((1 << a.log2Cin) < Cin) ++a.log2Cin;
+  const int pad = ksize >> 1;
+  a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+  a.npix = B * a.Ho * a.Wo; a.ntiles = cdiv(a.npix, 16);
+  a.acc_out = acc_out;
+  const int NT = Cout >= 64 ? 4 : Cout / 16;                       // 16 -> 1, 32 -> 2, >= 64 -> 4
+  const int gy = Cout / (NT * 16), nks = Kpad / 32;
+  // <= 512 workgroups (tools/wrn_conv_bench.py: 1024 cost +2.6 us with the statistics prologue / epilogue per workgroup); the waves of a
+  // workgroup split K (2 or 4 ways) until the launch has ~2048 waves, as long as a wave keeps >= 4 k steps
+  static const int env_ks = getenv("SRHIP_CONV_KSPLIT") ? atoi(getenv("SRHIP_CONV_KSPLIT")) : 0;          // tuning: force 1 / 2 / 4
+  static const int env_maxwg = getenv("SRHIP_CONV_MAXWG") ? atoi(getenv("SRHIP_CONV_MAXWG")) : 512;
+  int KS = 1;
+  while (KS < 4 && (long)a.ntiles * gy * KS * 2 <= 2048 && nks / (KS * 2) >= 4) KS *= 2;
+  if (env_ks == 1 || env_ks == 2 || env_ks == 4) KS = env_ks;
+  int gx = cdiv(a.ntiles, 4 / KS);
+  if (gx > env_maxwg / gy) gx = env_maxwg / gy;
+  if (gx < 1) gx = 1;
+  hipStream_t s = (hipStream_t)stream;
+#define SR_CONV_LAUNCH(NT_)                                                                                          \
+  if (KS == 4) hipLaunchKernelGGL((wrn_conv_kernel<NT_, 4>), dim3(gx, gy), dim3(256), 0, s, a);                      \
+  else if (KS == 2) hipLaunchKernelGGL((wrn_conv_kernel<NT_, 2>), dim3(gx, gy), dim3(256), 0, s, a);                 \
+  else hipLaunchKernelGGL((wrn_conv_kernel<NT_, 1>), dim3(gx, gy), dim3(256), 0, s, a)
+  if (NT == 4) { SR_CONV_LAUNCH(4); }
+  else if (NT == 2) { SR_CONV_LAUNCH(2); }
+  else if (NT == 1) { SR_CONV_LAUNCH(1); }
+  else return SR_EINVAL;
+#undef SR_CONV_LAUNCH
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_act(const float* x, const float* mean, const float* invstd_or_var, const float* gamma, const float* beta, float eps,
+                            float slope, int mode, void* act_bf16, int rows, int C, void* stream) {
+  if (!x || !act_bf16 || rows <= 0 || C <= 0 || (C % 4) || mode < 0 || mode > 2) return SR_EINVAL;
+  if (mode != 2 && (!mean || !invstd_or_var || !gamma || !beta)) return SR_EINVAL;
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd_or_var, gamma, beta, eps, slope, mode,
+                     (bf16_t*)act_bf16, n4, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

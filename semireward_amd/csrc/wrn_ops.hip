@@ -5,6 +5,7 @@
 // throughput path: kernels are kept simple and HBM-bound.
 #include "../../include/srhip.h"
 #include "common.h"
+#include "wrn_bn.h"
 
 namespace {
 
@@ -113,58 +114,13 @@ __global__ void add_unpad_kernel(const float* __restrict__ src, float* __restric
 // ---- BatchNorm over the rows of x fp32 [rows, C] --------------------------------------------------------------------------------
 // column sums in double: ws[0..C) = sum, ws[C..2C) = sum of squares (forward) / sum dy', sum dy' * xhat (backward).
 // A workgroup covers rows_per_block rows; a thread owns V consecutive channels (V = 4: one 16-byte load per row) of every (256 / (C / V))-th
-// row, four rows requested before the first is used; the per-thread partials meet in LDS and the workgroup adds its 2C sums with hardware
-// fp64 atomics (global_atomic_add_f64) into copy (workgroup % BN_COPIES) of the accumulator -- one copy for everybody was 512 workgroups
-// queueing on four cache lines, 10 of the pass's 13 us.  The workgroup that arrives last (one integer atomic each) adds the copies into
-// ws[0..2C) for the apply launch and leaves copies and counter at ZERO: no memset launch per BatchNorm, the caller zeroes ws once.
-// (fp64 sums are order-dependent in the last bit of a double, 29 bits below the float the statistics are rounded to.)
-// ws layout (doubles): [0, 512) result | [512] counter (low 32 bits) | [520, 520 + BN_COPIES * 512) accumulator copies.
-constexpr int BN_COPIES = 16, BN_WS_COUNTER = 512, BN_WS_ACC = 520;
-
-// the tail every statistics producer shares: add this workgroup's 2C sums (red2c in LDS, [2C] doubles), and if it is the last one of the
-// launch, fold the copies.  Returns true in the last workgroup (all threads), with the totals in ws[0..2C) AND in red2c.
-__device__ __forceinline__ bool bn_accumulate_and_fold(double* __restrict__ ws, double* red2c, int C, unsigned n_workgroups, unsigned my_index,
-                                                       int* is_last_lds) {
-  double* acc = ws + BN_WS_ACC + (size_t)(my_index % BN_COPIES) * 512;
-  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) unsafeAtomicAdd(acc + o, red2c[o]);
-  // The adds above must be performed before the arrival is counted.  They are device-scope atomics (performed at the memory side, not held
-  // dirty in this XCD's L2), so waiting for their acknowledgement is enough: a workgroup-scope release is that s_waitcnt and nothing else.
-  // __threadfence() here is a device-scope release = buffer_wbl2, a walk over the XCD's 4 MB L2 (~1 us, serialised per XCD): 64 workgroups
-  // per XCD each paying for one made this pass 35 us instead of 5.  (MI355X_MICROARCH.md, inter-workgroup visibility: 8-byte device-scope
-  // atomics on both sides are a valid hand-off without fences.)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (explicit: the fence above may lower to nothing)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* counter = reinterpret_cast<unsigned*>(ws + BN_WS_COUNTER);
-    const unsigned seen = atomicAdd(counter, 1u);
-    *is_last_lds = seen == n_workgroups - 1;
-    if (seen == n_workgroups - 1) *counter = 0u;            // (everybody has arrived: nobody touches it again in this launch)
-  }
-  __syncthreads();
-  if (!*is_last_lds) return false;
-  // (acquire side: device-scope atomic loads below read at the memory side; nothing of this data is in a cache of this workgroup)
-  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
-    double u[BN_COPIES], t = 0.0;
-#pragma unroll
-    for (int q = 0; q < BN_COPIES; ++q) u[q] = __hip_atomic_load(ws + BN_WS_ACC + (size_t)q * 512 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int q = 0; q < BN_COPIES; ++q) {
-      t += u[q];
-      __hip_atomic_store(ws + BN_WS_ACC + (size_t)q * 512 + o, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ws[o] = t;
-    red2c[o] = t;
-  }
-  __syncthreads();
-  return true;
-}
-
+// row, four rows requested before the first is used; the per-thread partials meet in LDS and the workgroup adds its 2C sums into an
+// accumulator copy; the last workgroup folds the copies (wrn_bn.h) and, for srhip_bn_stats, derives mean / invstd / running statistics.
 template <bool BWD, int V>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dact, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float slope, double* __restrict__ ws, int rows, int C,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, const BnFinal fin) {
   __shared__ double red[2][256 * V];
   __shared__ double red2c[512];
   __shared__ int is_last;
@@ -225,7 +181,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     red2c[o] = t;
   }
   __syncthreads();
-  bn_accumulate_and_fold(ws, red2c, C, gridDim.x, blockIdx.x, &is_last);
+  double* acc = ws + BN_WS_ACC + (size_t)(blockIdx.x % BN_COPIES) * 512;
+  for (int o = threadIdx.x; o < 2 * C; o += 256) unsafeAtomicAdd(acc + o, red2c[o]);
+  if (bn_arrive_and_fold(ws, red2c, C, gridDim.x, blockIdx.x, &is_last)) bn_finalize(red2c, C, rows, fin);
 }
 
 // rows per workgroup of bn_reduce_kernel: a multiple of the rows one pass of the workgroup covers, ~512 workgroups, at most 1024 rows
@@ -420,6 +378,18 @@ extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int C, in
   return SR_OK;
 }
 
+static void launch_bn_stats(const float* x, double* ws, int rows, int C, const BnFinal& fin, hipStream_t s) {
+  if (C % 4 == 0) {
+    const int rpb = bn_rows_per_block(rows, C, 4);
+    hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
+                       ws, rows, C, rpb, fin);
+  } else {
+    const int rpb = bn_rows_per_block(rows, C, 1);
+    hipLaunchKernelGGL((bn_reduce_kernel<false, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
+                       ws, rows, C, rpb, fin);
+  }
+}
+
 extern "C" long long srhip_bn_ws_doubles(void) { return (long long)BN_WS_ACC + (long long)BN_COPIES * 512; }
 
 extern "C" int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
@@ -429,19 +399,23 @@ extern "C" int srhip_bn_fwd(const float* x, const float* gamma, const float* bet
   if (training && (!save_mean || !save_invstd || !ws)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (training) {
-    if (C % 4 == 0) {
-      const int rpb = bn_rows_per_block(rows, C, 4);
-      hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                         ws, rows, C, rpb);
-    } else {
-      const int rpb = bn_rows_per_block(rows, C, 1);
-      hipLaunchKernelGGL((bn_reduce_kernel<false, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                         ws, rows, C, rpb);
-    }
+    launch_bn_stats(x, ws, rows, C, BnFinal{}, s);
     SR_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, ws, gamma, beta, eps, slope, momentum, update_running,
                      running_mean, running_var, save_mean, save_invstd, !training, (bf16_t*)act_bf16, act_f32, rows, C);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_stats(const float* x, float eps, float momentum, int update_running, float* running_mean, float* running_var,
+                              float* out_mean, float* out_invstd, double* ws, int rows, int C, void* stream) {
+  if (!x || !out_mean || !out_invstd || !ws || rows <= 0 || C <= 0 || C > 256 || (256 % C)) return SR_EINVAL;
+  if (update_running && (!running_mean || !running_var)) return SR_EINVAL;
+  BnFinal fin;
+  fin.out_mean = out_mean; fin.out_invstd = out_invstd; fin.running_mean = running_mean; fin.running_var = running_var;
+  fin.momentum = momentum; fin.update_running = update_running; fin.eps = eps;
+  launch_bn_stats(x, ws, rows, C, fin, (hipStream_t)stream);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -455,11 +429,11 @@ extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save
   if (C % 4 == 0) {
     const int rpb = bn_rows_per_block(rows, C, 4);
     hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
-                       rows, C, rpb);
+                       rows, C, rpb, BnFinal{});
   } else {
     const int rpb = bn_rows_per_block(rows, C, 1);
     hipLaunchKernelGGL((bn_reduce_kernel<true, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
-                       rows, C, rpb);
+                       rows, C, rpb, BnFinal{});
   }
   SR_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, dact, ws, save_mean, save_invstd, gamma, beta,

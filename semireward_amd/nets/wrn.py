@@ -1,9 +1,12 @@
 """WideResNet on the HIP kernels (classic_cv backbone: ``wrn_28_2``), reference semilearn/nets/wrn/wrn.py.
 
-This is the CPU-reference PARITY configuration of BASELINE.json (configs[0]: CIFAR-100 WRN-28-2 PseudoLabel + SemiReward), not
-the throughput path.  Feature maps are NHWC = row-major [B*H*W, C]; a convolution is im2col (bf16) + srhip_gemm_nt, its weight
-gradient one problem of the grouped TN GEMM, its input gradient a GEMM with the transposed filter + col2im; BatchNorm + LeakyReLU
-are column-statistic kernels.  Parameter names / order, BatchNorm buffers and state_dict keys are the reference's.
+This is the CPU-reference PARITY configuration of BASELINE.json (configs[0]: CIFAR-100 WRN-28-2 PseudoLabel + SemiReward).  Feature maps
+are NHWC = row-major [B*H*W, C].  Forward: ONE launch per BasicBlock convolution (csrc/wrn_conv.hip): the convolution reads its fp32 input
+through the BatchNorm + LeakyReLU in front of it (implicit GEMM, no im2col, no separate normalisation pass) and its epilogue leaves mean /
+invstd / running statistics of the BatchNorm behind it -- SRPseudoLabel runs this forward K + 1 >= 9 times per step.  Backward (two of those
+forwards have one): the bf16 activation and its im2col are recomputed from the kept fp32 tensors; a filter gradient is one problem (K slices)
+of the grouped TN GEMM, an input gradient a GEMM with the transposed filter + col2im; BatchNorm backward is a statistics pass + an apply pass.
+Parameter names / order, BatchNorm buffers and state_dict keys are the reference's.
 
 BatchNorm semantics (wrn.py:32-38, core/utils/misc.py:105-129): every forward in training mode normalises with the statistics of
 ITS OWN batch, so -- unlike the ViT engine -- the passes of a step cannot be batched into one launch train; ``update_stats=False``
@@ -22,7 +25,7 @@ def _round_up(a, b):
 
 class WrnContext:
     """Activations of one ``save=True`` forward."""
-    __slots__ = ("B", "H", "W", "stem", "blocks", "final", "feat", "tag")
+    __slots__ = ("B", "H", "W", "stem", "blocks", "final", "feat", "tag", "graphed")
 
 
 class WideResNet:
@@ -75,6 +78,14 @@ class WideResNet:
                                        Wb=torch.zeros(cout, Kp, dtype=torch.bfloat16, device=self.device),
                                        WbT=torch.zeros(Kp, cout, dtype=torch.bfloat16, device=self.device))
         self.ws = torch.zeros(ops.bn_ws_doubles(), dtype=torch.float64, device=self.device)      # (zeroed once: srhip_bn_fwd keeps its counter at 0)
+        # per-BatchNorm statistics accumulators (16 copies x (sum | sum of squares)), filled by the convolution in front of the BatchNorm and
+        # folded by the one behind it; one arena so that a forward zeroes them with one launch
+        offs, o = {}, 0
+        for nme, c, _ in self.bn:
+            offs[nme] = (o, ops.bn_acc_doubles(c))
+            o += ops.bn_acc_doubles(c)
+        self.bn_acc_arena = torch.zeros(o, dtype=torch.float64, device=self.device)
+        self.bn_acc = {nme: self.bn_acc_arena[a:a + n] for nme, (a, n) in offs.items()}
         self.training = True
         self.couples_batch_rows = True      # BatchNorm: every forward call is its own statistics group (no cross-pass batching)
         self._buf_cache = {}
@@ -181,14 +192,48 @@ class WideResNet:
             self.buffers[name + ".num_batches_tracked"] += 1
         return act, af, (mean, invstd)
 
+    # ---- one launch per convolution (csrc/wrn_conv.hip) ------------------------------------------------------------------------------
+    def _stats_bufs(self, name, C, tag):
+        return (self._buf((tag, name, "mean"), (C,), torch.float32), self._buf((tag, name, "invstd"), (C,), torch.float32))
+
+    def _conv_bn(self, wname, xin, in_bn, in_st, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False):
+        """out = conv(LeakyReLU(BN_in(xin))) (+ resid) -- or conv(xin) when ``raw`` -- and, in training mode, the sums of ``out`` added into the
+        accumulator of ``next_bn``.  in_st: (mean, invstd) buffers already filled (the first BatchNorm: srhip_bn_stats) or None = fold them
+        from in_bn's accumulator; ``publish``: this launch also writes in_bn's (mean, invstd) for the backward and moves its running
+        statistics.  Returns in_bn's statistics buffers (None in eval mode)."""
+        c = self.convs[wname]
+        P = self.p
+        g, bt, eps = P(in_bn + ".weight"), P(in_bn + ".bias"), self.eps[in_bn]
+        acc_out = self.bn_acc[next_bn] if (next_bn is not None and train) else None
+        if not train:
+            stats, acc, mode, pub, st = (self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]), None, 1, None, None
+        elif in_st is not None:
+            stats, acc, mode, pub, st = in_st, None, 0, None, in_st
+        else:
+            stats, acc, mode = None, self.bn_acc[in_bn], 3
+            st = self._stats_bufs(in_bn, c["cin"], tag)
+            pub = st if publish else None
+        if raw:
+            mode = 2
+        ops.wrn_conv_bn(xin, mode, stats, acc, g, bt, eps, SLOPE, c["Wb"], resid, out, B, H, W, c["cin"], c["cout"], c["k"], stride, c["Kp"],
+                        publish=pub, running=(self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]) if pub else None,
+                        momentum=MOMENTUM, update_running=update, acc_out=acc_out)
+        if pub is not None and update:
+            self.buffers[in_bn + ".num_batches_tracked"] += 1
+        return st
+
     def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None):
         """img fp32 [B,3,H,W] (NCHW as the loaders deliver it).  Returns (logits [B,C], feat [B,F], ctx or None).
         ``update_stats=False`` = forward under Bn_Controller.freeze_bn.  ``tag`` names the activation buffer set (two saved graphs of
-        a step must not share buffers)."""
+        a step must not share buffers).
+        Launches: stem (layout + im2col + GEMM + statistics), then ONE per convolution -- each reads its input through the BatchNorm +
+        LeakyReLU in front of it and leaves the statistics of the BatchNorm behind it --, then the final BatchNorm, pooling, classifier."""
         assert img_index is None and droppath is None, "WideResNet has no DropPath and takes whole batches (BatchNorm couples the rows)"
         B, _, H, W = img.shape
         tag = tag or ("s" if save else "i")
         train = self.training
+        upd = bool(train and update_stats)
+        assert train or not save, "the backward needs a training-mode forward (batch statistics)"
         f32 = torch.float32
         a0 = self._buf((tag, "in"), (B, H, W, 3), torch.bfloat16)
         ops.nchw_to_nhwc_bf16(img.contiguous(), a0, B, 3, H, W)
@@ -199,31 +244,36 @@ class WideResNet:
             ctx = WrnContext()
             ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
         h, w = H, W
-        for p, cin, cout, stride, abr in self.blocks:
+        # statistics of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
+        first = self.blocks[0][0] + "bn1"
+        st = None
+        if train:
+            st = self._stats_bufs(first, self.channels[0], tag)
+            ops.bn_stats(out, self.eps[first], MOMENTUM, upd, self.buffers[first + ".running_mean"], self.buffers[first + ".running_var"],
+                         st[0], st[1], self.ws, B * h * w, self.channels[0])
+            if upd:
+                self.buffers[first + ".num_batches_tracked"] += 1
+        if train:
+            self.bn_acc_arena.zero_()                         # the accumulators of every BatchNorm of this forward: one fill launch
+        for bi, (p, cin, cout, stride, abr) in enumerate(self.blocks):
             equal = cin == cout
-            rows_in = B * h * w
-            o, _, st1 = self._bn_act(p + "bn1", out, rows_in, cin, tag, train, update_stats)
-            if equal or abr:
-                conv_in = o
-            else:                                             # wrn.py:50: conv1 takes the RAW x; bn1's output is unused (its statistics still move)
-                conv_in = self._buf((tag, p, "xraw"), (rows_in, cin), torch.bfloat16)
-                ops.cast_f32_bf16(out, conv_in, rows_in * cin)
+            raw = not (equal or abr)                          # wrn.py:50: conv1 / convShortcut take the RAW x; bn1's statistics still move
             ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
             rows_out = B * ho * wo
             c1 = self._buf((tag, p, "c1"), (rows_out, cout), f32)
-            col1, _, _ = self._conv(p + "conv1.weight", conv_in, B, h, w, stride, c1, tag)
-            o2, _, st2 = self._bn_act(p + "bn2", c1, rows_out, cout, tag, train, update_stats)
-            y = self._buf((tag, p, "y"), (rows_out, cout), f32)
-            colS = None
+            # conv1 reads x through bn1 (folding / publishing its statistics) and leaves the sums of its output for bn2
+            st1 = self._conv_bn(p + "conv1.weight", out, p + "bn1", st, raw, B, h, w, stride, c1, tag, train, upd, next_bn=p + "bn2", publish=True)
             if equal:
                 sc = out
             else:
                 sc = self._buf((tag, p, "sc"), (rows_out, cout), f32)
-                colS, _, _ = self._conv(p + "convShortcut.weight", conv_in, B, h, w, stride, sc, tag)
-            col2, _, _ = self._conv(p + "conv2.weight", o2, B, ho, wo, 1, y, tag, resid=sc)
+                self._conv_bn(p + "convShortcut.weight", out, p + "bn1", st, raw, B, h, w, stride, sc, tag, train, upd)
+            y = self._buf((tag, p, "y"), (rows_out, cout), f32)
+            nxt = self.blocks[bi + 1][0] + "bn1" if bi + 1 < len(self.blocks) else None
+            st2 = self._conv_bn(p + "conv2.weight", c1, p + "bn2", None, False, B, ho, wo, 1, y, tag, train, upd, resid=sc, next_bn=nxt, publish=True)
             if save:
-                ctx.blocks.append(dict(x=out, st1=st1, col1=col1, c1=c1, st2=st2, col2=col2, colS=colS, h=h, w=w, ho=ho, wo=wo))
-            out, h, w = y, ho, wo
+                ctx.blocks.append(dict(x=out, st1=st1, c1=c1, st2=st2, raw=raw, h=h, w=w, ho=ho, wo=wo))
+            out, h, w, st = y, ho, wo, None
         rows = B * h * w
         C3 = self.channels[3]
         _, af, stf = self._bn_act("bn1", out, rows, C3, tag, train, update_stats, want_f32=True)
@@ -235,35 +285,50 @@ class WideResNet:
             ctx.final, ctx.feat = dict(x=out, st=stf, h=h, w=w), feat
         return logits, feat, ctx
 
-    # ---- the frozen-statistics inference forward as a HIP graph ------------------------------------------------------------------------
-    # SRPseudoLabel's data_generator forwards the SAME unlabelled batch K = sr_decay() >= 8 times under Bn_Controller.freeze_bn
-    # (srpseudolabel.py:59-90) -- ~110 launches of a few microseconds each per forward at the classic_cv batch (64 images of 32x32), i.e. a
-    # forward bound by launch latency, not by the GPU.  It has no per-call host state (no DropPath, no statistics update): captured once
-    # per input shape, replayed per pass.  SR_WRN_GRAPH=0: eager launches.
-    graph_frozen = __import__("os").environ.get("SR_WRN_GRAPH", "1") != "0"
+    # ---- the passes of a step as HIP graphs (opt-in: SR_WRN_GRAPH=1) ------------------------------------------------------------------------
+    # SRPseudoLabel forwards the SAME unlabelled batch K + 1 >= 9 times per step (srpseudolabel.py:59-90) plus the labelled batch, and runs
+    # two backwards: ~35 launches per forward and ~250 per backward.  None of them has per-call host state (no DropPath; learning rate and
+    # momentum live in the optimizer launch; every workspace is a persistent buffer keyed by ``tag``), so each (kind, tag, shape) can be
+    # captured once and replayed: the first call runs eagerly (it builds the workspaces), the second is captured.  Measured on one MI355X at
+    # the classic_cv batch: 9.9 ms per step eager, 10.0 ms replayed -- the step is bound by the GPU, not by the host's enqueue rate -- so eager
+    # launches are the default and the replay path stays for hosts that are slower than that.
+    use_graphs = __import__("os").environ.get("SR_WRN_GRAPH", "0") != "0"
 
-    def forward_frozen(self, img, tag="ulb_inf"):
-        """forward_features(img, save=False, update_stats=False) -> (logits, feat); the returned tensors are the caller's own copies."""
-        key = (tag, tuple(img.shape), bool(self.training))
-        st = self.__dict__.setdefault("_frozen_graphs", {})
+    def _graphed(self, key, inputs, fn):
+        """fn(*inputs) with ``inputs`` device tensors -> whatever fn returns (tensors inside it are the graph's own static buffers)."""
+        st = self.__dict__.setdefault("_graphs", {})
         ent = st.get(key)
         if ent is None:
-            n = st.get(("seen",) + key, 0)
-            st[("seen",) + key] = n + 1
-            if not self.graph_frozen or n < 1 or not img.is_cuda or torch.cuda.is_current_stream_capturing():
-                lg, ft, _ = self.forward_features(img, save=False, update_stats=False, tag=tag)      # (first call: builds the workspaces)
-                return lg, ft
-            x_static = img.detach().clone()
+            n = st.get(("seen", key), 0)
+            st[("seen", key)] = n + 1
+            if (not self.use_graphs or n < 1 or not all(t.is_cuda for t in inputs) or torch.cuda.is_current_stream_capturing()):
+                return fn(*inputs), False
+            statics = [t.detach().clone() for t in inputs]
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), ops.stream_scope():
-                lg, ft, _ = self.forward_features(x_static, save=False, update_stats=False, tag=tag)
-            ent = st[key] = (g, x_static, lg, ft)
-        g, x_static, lg, ft = ent
-        if x_static.data_ptr() != img.data_ptr():
-            x_static.copy_(img, non_blocking=True)
+                out = fn(*statics)
+            ent = st[key] = (g, statics, out)
+        g, statics, out = ent
+        for s_, t in zip(statics, inputs):
+            if s_.data_ptr() != t.data_ptr():
+                s_.copy_(t, non_blocking=True)
         g.replay()
-        return lg.clone(), ft.clone()
+        return out, True
+
+    def forward_frozen(self, img, tag="ulb_inf"):
+        """forward_features(img, save=False, update_stats=False) -> (logits, feat); the returned tensors are the caller's own copies."""
+        (lg, ft, _), graphed = self._graphed(("frozen", tag, tuple(img.shape), bool(self.training)), [img],
+                                             lambda x: self.forward_features(x, save=False, update_stats=False, tag=tag))
+        return (lg.clone(), ft.clone()) if graphed else (lg, ft)
+
+    def forward_saved(self, img, update_stats, tag):
+        """forward_features(img, save=True, ...) -> (logits, feat, ctx) for a later backward(ctx, .); logits / feat are the caller's copies,
+        ctx keeps the graph's own buffers (the captured backward reads them)."""
+        (lg, ft, ctx), graphed = self._graphed(("saved", tag, tuple(img.shape), bool(update_stats), bool(self.training)), [img],
+                                               lambda x: self.forward_features(x, save=True, update_stats=update_stats, tag=tag))
+        ctx.graphed = graphed
+        return (lg.clone(), ft.clone(), ctx) if graphed else (lg, ft, ctx)
 
     def forward(self, x, only_fc=False, only_feat=False, **kw):
         assert not only_fc
@@ -275,6 +340,12 @@ class WideResNet:
     # ---- backward ---------------------------------------------------------------------------------------------------------------
     def backward(self, ctx, dlogits):
         """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] for a save=True forward."""
+        if getattr(ctx, "graphed", False):          # the forward's buffers are a graph's static buffers: the backward can be one too
+            self._graphed(("bwd", ctx.tag, tuple(dlogits.shape)), [dlogits.contiguous()], lambda d: self._backward(ctx, d))
+        else:
+            self._backward(ctx, dlogits)
+
+    def _backward(self, ctx, dlogits):
         B, tag = ctx.B, ctx.tag
         f32, bf16 = torch.float32, torch.bfloat16
         P, G = self.p, (lambda n: self.p(n, self.grad))
@@ -312,9 +383,30 @@ class WideResNet:
         dy = self._buf((tag, "dy.final"), (rows, C3), f32)
         ops.bn_bwd(dact, fin["x"], fin["st"][0], fin["st"][1], P("bn1.weight"), P("bn1.bias"), SLOPE, None, dy, G("bn1.weight"), G("bn1.bias"),
                    self.ws, rows, C3)
+        def col_of(name, src, bn, st, raw, rows_src, Hs, Ws, stride, act=None):
+            """The im2col operand of a convolution's filter gradient, recomputed from what the forward kept (its fp32 input and the statistics
+            of the BatchNorm in front of it) instead of stored by every forward: act bf16 = LeakyReLU(BN(src)) (or src), then im2col."""
+            c = self.convs[name]
+            if act is None:
+                act = self._buf((tag, bn, "act.bwd"), (rows_src, c["cin"]), bf16)
+                if raw:
+                    ops.bn_act(src, None, None, None, 0.0, SLOPE, 2, act, rows_src, c["cin"])
+                else:
+                    ops.bn_act(src, st, P(bn + ".weight"), P(bn + ".bias"), self.eps[bn], SLOPE, 0, act, rows_src, c["cin"])
+            k, pad = c["k"], c["k"] // 2
+            Ho, Wo = (Hs + 2 * pad - k) // stride + 1, (Ws + 2 * pad - k) // stride + 1
+            col = self._buf((tag, name, "col"), (B * Ho * Wo, c["Kp"]), bf16)
+            ops.im2col(act, col, B, Hs, Ws, c["cin"], k, stride, c["Kp"])
+            return col, act
+
         for (p, cin, cout, stride, abr), r in zip(reversed(self.blocks), reversed(ctx.blocks)):
             equal = cin == cout
             rows_out, rows_in = B * r["ho"] * r["wo"], B * r["h"] * r["w"]
+            col2, _ = col_of(p + "conv2.weight", r["c1"], p + "bn2", r["st2"], False, rows_out, r["ho"], r["wo"], 1)
+            col1, act1 = col_of(p + "conv1.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride)
+            r = dict(r, col2=col2, col1=col1)
+            if not equal:
+                r["colS"], _ = col_of(p + "convShortcut.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride, act=act1)
             do2 = conv_bwd(p + "conv2.weight", dy, rows_out, r["col2"], True, r["ho"], r["wo"], 1)
             dc1 = self._buf((tag, p, "dc1"), (rows_out, cout), f32)
             ops.bn_bwd(do2, r["c1"], r["st2"][0], r["st2"][1], P(p + "bn2.weight"), P(p + "bn2.bias"), SLOPE, None, dc1, G(p + "bn2.weight"),
@@ -334,7 +426,10 @@ class WideResNet:
             dy = dx
         conv_bwd("conv1.weight", dy, B * ctx.H * ctx.W, ctx.stem["col"], False, ctx.H, ctx.W, 1)
         # 32 x 288 .. 128 x 1152 outputs over 4096 .. 65536 pixels: slices of 2048 pixels fill the chip (filter gradients meet through fp32 atomics)
-        desc, npb, ntiles, flops, nbytes = ops.make_group_tn_desc(problems, self.device, split_k=2048)
+        dk = ("tn_desc", tag) + tuple(int(t.data_ptr()) for pr in problems for t in pr[:3])
+        if dk not in self._buf_cache:                  # (one host-to-device copy per buffer set, not per backward: the operands are persistent)
+            self._buf_cache[dk] = ops.make_group_tn_desc(problems, self.device, split_k=2048)
+        desc, npb, ntiles, flops, nbytes = self._buf_cache[dk]
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         for src, name in unpad:
             c = self.convs[name]

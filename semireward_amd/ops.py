@@ -658,6 +658,38 @@ def bn_ws_doubles():
     return int(lib().srhip_bn_ws_doubles())
 
 
+def wrn_conv_supported(Cin, Cout, ksize):
+    from ._lib import lib
+    return bool(lib().srhip_wrn_conv_supported(Cin, Cout, ksize))
+
+
+def bn_acc_doubles(C):
+    from ._lib import lib
+    return int(lib().srhip_bn_acc_doubles(C))
+
+
+def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope, Wb, resid, y, B, H, W, Cin, Cout, ksize, stride, Kpad,
+                publish=None, running=None, momentum=0.0, update_running=False, acc_out=None):
+    """y = conv(f(xin)) (+ resid).  in_mode 0: in_stats = (mean, invstd); 1: (running_mean, running_var); 2: raw; 3: statistics folded from
+    in_acc.  publish = (mean, invstd) buffers workgroup (0,0) fills from in_acc (+ running = (running_mean, running_var) moved when
+    update_running).  acc_out: accumulator of the BatchNorm that reads y next (sums of y are added)."""
+    im, ii = in_stats if in_stats is not None else (None, None)
+    pm, pi = publish if publish is not None else (None, None)
+    rm, rv = running if running is not None else (None, None)
+    _call("srhip_wrn_conv_bn", _p(xin), in_mode, _p(im), _p(ii), _p(in_acc), _p(in_gamma), _p(in_beta), in_eps, slope, _p(pm), _p(pi), _p(rm),
+          _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), _s())
+
+
+def bn_stats(x, eps, momentum, update_running, running_mean, running_var, out_mean, out_invstd, ws, rows, C):
+    _call("srhip_bn_stats", _p(x), eps, momentum, int(update_running), _p(running_mean), _p(running_var), _p(out_mean), _p(out_invstd), _p(ws),
+          rows, C, _s())
+
+
+def bn_act(x, stats, gamma, beta, eps, slope, mode, act, rows, C):
+    m, i = stats if stats is not None else (None, None)
+    _call("srhip_bn_act", _p(x), _p(m), _p(i), _p(gamma), _p(beta), eps, slope, mode, _p(act), rows, C, _s())
+
+
 def bn_fwd(x, gamma, beta, eps, slope, momentum, training, update_running, running_mean, running_var, save_mean, save_invstd, act_bf16,
            act_f32, ws, rows, C):
     _call("srhip_bn_fwd", _p(x), _p(gamma), _p(beta), eps, slope, momentum, int(training), int(update_running), _p(running_mean),
