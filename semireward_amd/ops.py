@@ -676,8 +676,17 @@ def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope
     im, ii = in_stats if in_stats is not None else (None, None)
     pm, pi = publish if publish is not None else (None, None)
     rm, rv = running if running is not None else (None, None)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _call("srhip_wrn_conv_bn", _p(xin), in_mode, _p(im), _p(ii), _p(in_acc), _p(in_gamma), _p(in_beta), in_eps, slope, _p(pm), _p(pi), _p(rm),
           _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), _s())
+    if _PROFILE is not None:
+        e1.record()
+        npix = y.shape[0]
+        # algorithmic work: the convolution's MACs; bytes: the fp32 input once, the fp32 output (+ residual) once, the filter once
+        _PROFILE.recs.append((e0, e1, 2.0 * npix * Cin * ksize * ksize * Cout, "wrn_conv_kernel",
+                              4.0 * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad))
 
 
 def bn_stats(x, eps, momentum, update_running, running_mean, running_var, out_mean, out_invstd, ws, rows, C):

@@ -34,7 +34,10 @@ def attn(N=257, H=6):
 def gemm():
     for (M, N, K, epi, name) in [(51400, 1152, 384, ops.EPI_BF16, "qkv"), (51400, 384, 384, ops.EPI_RESID_F32, "proj"),
                                  (51400, 1536, 384, ops.EPI_GELU_BF16, "fc1"), (51400, 384, 1536, ops.EPI_RESID_F32, "fc2"),
-                                 (51400, 1536, 384, ops.EPI_BF16, "fc1-nogelu"), (8192, 8192, 8192, ops.EPI_BF16, "big")]:
+                                 (51400, 1536, 384, ops.EPI_BF16, "fc1-nogelu"), (8192, 8192, 8192, ops.EPI_BF16, "big"),
+                                 (13952, 2304, 768, ops.EPI_BF16, "bert qkv"), (13952, 768, 768, ops.EPI_RESID_F32, "bert proj"),
+                                 (13952, 3072, 768, ops.EPI_GELU_BF16, "bert fc1"), (13952, 768, 3072, ops.EPI_RESID_F32, "bert fc2"),
+                                 (13952, 3072, 768, ops.EPI_BF16, "bert fc1-nogelu"), (4096, 4096, 4096, ops.EPI_BF16, "4k")]:
         A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
         Bm = (torch.randn(N, K, device=DEV) * 0.05).to(torch.bfloat16)
         bias = torch.randn(N, device=DEV)

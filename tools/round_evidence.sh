@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/round_evidence.sh <tag>   -> gpurun_out/<tag>_*: everything the round's profiles/ entries are copied from
 #   <tag>_bench_full.json            the driver-form bench line (python bench.py, default flags)
-#   <tag>_{headline,224,bu64,pre}.stats.txt + _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats of the four workloads
+#   <tag>_{headline,224,bu64,pre,wrn,bert,hubert}.stats.txt + _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats of the workloads
 #   <tag>_hbm_traffic.json           FETCH_SIZE / WRITE_SIZE passes of the headline (tools/traffic.sh)
 #   <tag>_pmc{1,2}.pmc.txt           SQ counters of the headline (tools/pmc.sh)
 tag=$1
@@ -12,6 +12,9 @@ bash tools/prof.sh ${tag}_headline $Q; grep -h "^{\"metric\"" gpurun_out/${tag}_
 bash tools/prof.sh ${tag}_224 $Q --img 224; grep -h "^{\"metric\"" gpurun_out/${tag}_224.log > gpurun_out/${tag}_224_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_bu64 $Q --bu 64 --steps 6 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_bu64.log > gpurun_out/${tag}_bu64_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_pre $Q --regime pre; grep -h "^{\"metric\"" gpurun_out/${tag}_pre.log > gpurun_out/${tag}_pre_bench_under_rocprof.json
+bash tools/prof.sh ${tag}_wrn $Q --net wrn --bu 64 --steps 8 --warmup 3; grep -h "^{\"metric\"" gpurun_out/${tag}_wrn.log > gpurun_out/${tag}_wrn_bench_under_rocprof.json
+bash tools/prof.sh ${tag}_bert $Q --net bert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_bert.log > gpurun_out/${tag}_bert_bench_under_rocprof.json
+bash tools/prof.sh ${tag}_hubert $Q --net hubert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_hubert.log > gpurun_out/${tag}_hubert_bench_under_rocprof.json
 bash tools/traffic.sh ${tag} --no-also --repeats 1
 P="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/pmc.sh ${tag}_pmc1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE" $P
