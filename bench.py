@@ -499,9 +499,27 @@ def worker(a):
         and not a.elide_unread_rows
     del head
     torch.cuda.empty_cache()
+    # The headline is measured.  What follows (secondary legs, the gradient-exchange A/B for N > 1) must never cost the line: if those phases
+    # do not finish within SR_BENCH_EXTRA_BUDGET seconds (a collective one rank never reaches does not raise, it waits), every rank's watchdog
+    # ends its process and rank 0 prints the line with what is complete.
+    import threading
+    budget = float(os.environ.get("SR_BENCH_EXTRA_BUDGET", "900"))
+    state = {"phase": "secondary legs", "done": False}
+
+    def _give_up():
+        if state["done"]:
+            return
+        if rank == 0:
+            out["truncated"] = "watchdog: phase '%s' did not finish within %.0f s after the headline; the headline fields are complete" % (
+                state["phase"], budget)
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    watchdog = threading.Timer(budget, _give_up)
+    watchdog.daemon = True
+    watchdog.start()
     if default_headline and not a.no_also:
         # the other workloads north_star names, short legs in the same process: fewer steps, one timed region each
-        also = []
+        also = out["also"] = []                          # (filled in place: a truncated line carries the legs that finished)
         # (BASELINE.json configs[3] and [4] -- the usb_nlp BERT-base and usb_audio Wav2Vec2-base + FreeMatch steps -- ride along with their own
         # metric names and fewer steps; a leg that fails is reported as such and never costs the line)
         legs = (("vit_s16_224", dict(img=224), max(4, a.steps // 2), True), ("scaled_batch_bu64", dict(bu=64), max(4, a.steps // 2), True),
@@ -530,12 +548,13 @@ def worker(a):
                 also.append({"leg": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
             del leg
             torch.cuda.empty_cache()
-        out["also"] = also
+    state["phase"] = "gradient-exchange A/B"
     if world > 1 and default_headline and not a.no_allreduce_ab:
         # A/B of the gradient exchange in the SAME run (decides the default once it has been timed on RCCL over xGMI): the headline above is
         # "off" = one all-reduce of the flat block after the backward; "on" = layer-group slices reduced on a communication stream under the
         # backward (SR_OVERLAP_ALLREDUCE, distributed.DataParallel.install_overlap); "on_bf16" = the same exchange in bf16 (never the default)
-        ab = {"off": {"ms_per_step": out["ms_per_step"], "value": out["value"], "allreduce_ms_per_step": out.get("allreduce_ms_per_step")}}
+        ab = out["overlap_allreduce"] = {"off": {"ms_per_step": out["ms_per_step"], "value": out["value"],
+                                                 "allreduce_ms_per_step": out.get("allreduce_ms_per_step")}}
         for tag, env in (("on", {"SR_OVERLAP_ALLREDUCE": "1"}), ("off_bf16", {"SR_ALLREDUCE_BF16": "1"})):
             leg, old_env = None, {k: os.environ.get(k) for k in env}
             try:
@@ -552,11 +571,15 @@ def worker(a):
                     os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             del leg
             torch.cuda.empty_cache()
-        out["overlap_allreduce"] = ab
+    state["phase"] = "cpu baseline"
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and default_headline:
             out["cpu_baseline"] = cpu_baseline(a.bl or a.bu, a.bu)
+        state["done"] = True
+        watchdog.cancel()
         print(json.dumps(out), flush=True)
+    state["done"] = True
+    watchdog.cancel()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -43,3 +43,15 @@ def test_same_command_under_torch_distributed_run():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     _check(lines[0])
+
+
+def test_watchdog_prints_the_headline_when_the_secondary_phases_do_not_finish():
+    """After the headline is measured nothing may cost the line: with a budget the secondary legs cannot meet, every rank's watchdog ends its
+    process and rank 0 prints the line with the headline fields complete (a collective that one rank never reaches does not raise)."""
+    env = dict(os.environ, SR_BENCH_EXTRA_BUDGET="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-roofline"], env=env,
+                       capture_output=True, text=True, timeout=420, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    o = json.loads(lines[0])
+    assert "truncated" in o and o["value"] > 0 and o["n_gpus"] == 1 and o["steps"] == 3 and o["ms_per_step"] > 0
