@@ -505,7 +505,8 @@ long long srhip_bn_ws_doubles(void);
  *                 (0,0) publishes mean / invstd of that BatchNorm (the backward reads them) and moves its running statistics when
  *                 update_running (momentum; unbiased variance).  Wb = conv_weight_prep's bf16 [Cout, Kpad].  acc_out != NULL: per-channel
  *                 sum / sum of squares of y are ADDED into it (srhip_bn_acc_doubles(Cout) doubles, zeroed by the caller before the forward)
- *                 for the BatchNorm that reads y next.  Cin a power of two in [8,128]; Cout in {16, 32, 64} or a multiple of 64.
+ *                 for the BatchNorm that reads y next.  stat_ranks: ranks whose sums in_acc holds (1, or the world size under SyncBatchNorm).
+ *                 Cin a power of two in [8,128]; Cout in {16, 32, 64} or a multiple of 64.
  *   bn_stats    : the statistics of a tensor no wrn_conv_bn produced: mean / invstd / running update of x fp32 [rows, C] (ws as for bn_fwd).
  *   bn_act      : act bf16 [rows, C] = f(x) by modes 0-2 -- the backward's im2col operand, recomputed instead of stored. */
 int srhip_wrn_conv_supported(int Cin, int Cout, int ksize);
@@ -513,11 +514,27 @@ long long srhip_bn_acc_doubles(int C);
 int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* in_gamma,
                       const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
                       float* running_var, float momentum, int update_running, const void* Wb, const float* resid, float* y, int B, int H,
-                      int W, int Cin, int Cout, int ksize, int stride, int Kpad, double* acc_out, void* stream);
+                      int W, int Cin, int Cout, int ksize, int stride, int Kpad, double* acc_out, int stat_ranks, void* stream);
 int srhip_bn_stats(const float* x, float eps, float momentum, int update_running, float* running_mean, float* running_var, float* out_mean,
                    float* out_invstd, double* ws, int rows, int C, void* stream);
 int srhip_bn_act(const float* x, const float* mean, const float* invstd_or_var, const float* gamma, const float* beta, float eps, float slope,
-                 int mode, void* act_bf16, int rows, int C, void* stream);
+                 int mode, void* act_bf16, float* act_f32, int rows, int C, void* stream);
+/* SyncBatchNorm (the reference converts the WideResNet's BatchNorms under DDP: core/utils/misc.py:55): the statistics are sums, so the ranks
+ * exchange the ACCUMULATOR between the launch that fills it and the launch that folds it (wrn_conv_bn: stat_ranks = world size scales the row
+ * count; the caller all-reduces acc in between), and the backward's two column sums between its reduce and apply halves:
+ *   bn_accumulate : sums of x fp32 [rows, C] ADDED into acc (srhip_bn_acc_doubles(C) doubles) -- the statistics of a tensor no wrn_conv_bn produced
+ *   bn_fold       : acc -> mean / invstd (+ running update with momentum, unbiased variance) and / or the 2C totals; rows_total = rows of all ranks
+ *   bn_bwd_reduce : the backward's sums (dy', dy' * xhat) of this rank into ws[0..2C) (ws as for bn_fwd)
+ *   bn_bwd_apply  : dx from `totals` over rows_total rows; d(gamma) / d(beta) += local_totals (NULL: totals) -- per-rank, as torch's
+ *                   batch_norm_backward_reduce / _elemt split.  srhip_bn_bwd = reduce + apply on one rank. */
+int srhip_bn_accumulate(const float* x, double* acc, int rows, int C, void* stream);
+int srhip_bn_fold(const double* acc, double rows_total, float eps, float momentum, int update_running, float* running_mean, float* running_var,
+                  float* out_mean, float* out_invstd, double* totals, int C, void* stream);
+int srhip_bn_bwd_reduce(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
+                        float slope, double* ws, int rows, int C, void* stream);
+int srhip_bn_bwd_apply(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
+                       float slope, const float* resid, float* dx, float* dgamma, float* dbeta, const double* totals, const double* local_totals,
+                       double rows_total, int rows, int C, void* stream);
 int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
                  int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* act_bf16,
                  float* act_f32, double* ws, int rows, int C, void* stream);

@@ -99,9 +99,13 @@ SIGNATURES = {
     "srhip_bn_ws_doubles": (ctypes.c_longlong, []),
     "srhip_wrn_conv_supported": (I, [I, I, I]),
     "srhip_bn_acc_doubles": (ctypes.c_longlong, [I]),
-    "srhip_wrn_conv_bn": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "srhip_wrn_conv_bn": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, I, I, P, I, P]),
     "srhip_bn_stats": (I, [P, F, F, I, P, P, P, P, P, I, I, P]),
-    "srhip_bn_act": (I, [P, P, P, P, P, F, F, I, P, I, I, P]),
+    "srhip_bn_act": (I, [P, P, P, P, P, F, F, I, P, P, I, I, P]),
+    "srhip_bn_accumulate": (I, [P, P, I, I, P]),
+    "srhip_bn_fold": (I, [P, Dbl, F, F, I, P, P, P, P, P, I, P]),
+    "srhip_bn_bwd_reduce": (I, [P, P, P, P, P, P, F, P, I, I, P]),
+    "srhip_bn_bwd_apply": (I, [P, P, P, P, P, P, F, P, P, P, P, P, P, Dbl, I, I, P]),
     "srhip_bn_fwd": (I, [P, P, P, F, F, F, I, I, P, P, P, P, P, P, P, I, I, P]),
     "srhip_bn_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, P, I, I, P]),
     "srhip_avgpool_fwd": (I, [P, P, I, I, I, P]),

@@ -98,6 +98,8 @@ class AlgorithmBase:
         self.dataset_dict = self.set_dataset()
         self.loader_dict = self.set_data_loader()
         self.model = self.set_model()
+        if getattr(self.model, "couples_batch_rows", False):
+            self.model.dp = self.dp          # BatchNorm backbone under data parallel = SyncBatchNorm, as the reference's send_model_cuda (misc.py:55)
         self.ema_model = self.set_ema_model()
         self.optimizer, self.scheduler = self.set_optimizer()
         self.ce_loss = CELoss()

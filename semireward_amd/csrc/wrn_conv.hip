@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
 
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ isd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float slope,
-                                                    int mode, bf16_t* __restrict__ act, size_t n4, int C) {
+                                                    int mode, bf16_t* __restrict__ act, float* __restrict__ act_f32, size_t n4, int C) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over rows * C / 4
   if (i >= n4) return;
   const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -244,8 +244,11 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
       o[e] = yv > 0.f ? yv : slope * yv;
     }
   }
-  u32x2_t pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-  reinterpret_cast<u32x2_t*>(act)[i] = pk;
+  if (act) {
+    u32x2_t pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    reinterpret_cast<u32x2_t*>(act)[i] = pk;
+  }
+  if (act_f32) reinterpret_cast<float4*>(act_f32)[i] = float4{o[0], o[1], o[2], o[3]};
 }
 
 }  // namespace
@@ -261,7 +264,7 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
                                  const float* in_gamma, const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd,
                                  float* running_mean, float* running_var, float momentum, int update_running, const void* Wb,
                                  const float* resid, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int Kpad,
-                                 double* acc_out, void* stream) {
+                                 double* acc_out, int stat_ranks, void* stream) {
   if (!xin || !Wb || !y || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || !srhip_wrn_conv_supported(Cin, Cout, ksize) ||
       Kpad < Cin * ksize * ksize || (Kpad % 32) || in_mode < 0 || in_mode > 3)
     return SR_EINVAL;
@@ -276,7 +279,7 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
   a.pub.momentum = momentum; a.pub.update_running = update_running; a.pub.eps = in_eps;
   a.Wb = (const bf16_t*)Wb; a.resid = resid; a.y = y;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.stride = stride; a.Kp = Kpad;
-  a.in_rows = B * H * W;
+  a.in_rows = B * H * W * (stat_ranks > 1 ? stat_ranks : 1);       // SyncBatchNorm: the accumulator holds every rank's sums
   a.log2Cin = 0;
   while ((1 << a.log2Cin) < Cin) ++a.log2Cin;
   const int pad = ksize >> 1;
@@ -310,12 +313,12 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
 }
 
 extern "C" int srhip_bn_act(const float* x, const float* mean, const float* invstd_or_var, const float* gamma, const float* beta, float eps,
-                            float slope, int mode, void* act_bf16, int rows, int C, void* stream) {
-  if (!x || !act_bf16 || rows <= 0 || C <= 0 || (C % 4) || mode < 0 || mode > 2) return SR_EINVAL;
+                            float slope, int mode, void* act_bf16, float* act_f32, int rows, int C, void* stream) {
+  if (!x || (!act_bf16 && !act_f32) || rows <= 0 || C <= 0 || (C % 4) || mode < 0 || mode > 2) return SR_EINVAL;
   if (mode != 2 && (!mean || !invstd_or_var || !gamma || !beta)) return SR_EINVAL;
   const size_t n4 = (size_t)rows * C / 4;
   hipLaunchKernelGGL(bn_act_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd_or_var, gamma, beta, eps, slope, mode,
-                     (bf16_t*)act_bf16, n4, C);
+                     (bf16_t*)act_bf16, act_f32, n4, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

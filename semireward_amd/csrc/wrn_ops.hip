@@ -120,7 +120,7 @@ template <bool BWD, int V>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dact, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float slope, double* __restrict__ ws, int rows, int C,
-                                                       int rows_per_block, const BnFinal fin) {
+                                                       int rows_per_block, const BnFinal fin, double* __restrict__ acc_only) {
   __shared__ double red[2][256 * V];
   __shared__ double red2c[512];
   __shared__ int is_last;
@@ -181,9 +181,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     red2c[o] = t;
   }
   __syncthreads();
+  if (acc_only) {              // the caller folds (after an all-reduce over the ranks, or in the prologue of the launch that reads x)
+    double* acc = acc_only + (size_t)(blockIdx.x % BN_COPIES) * 2 * C;
+    for (int o = threadIdx.x; o < 2 * C; o += 256) unsafeAtomicAdd(acc + o, red2c[o]);
+    return;
+  }
   double* acc = ws + BN_WS_ACC + (size_t)(blockIdx.x % BN_COPIES) * 512;
   for (int o = threadIdx.x; o < 2 * C; o += 256) unsafeAtomicAdd(acc + o, red2c[o]);
   if (bn_arrive_and_fold(ws, red2c, C, gridDim.x, blockIdx.x, &is_last)) bn_finalize(red2c, C, rows, fin);
+}
+
+// the copies of an accumulator [BN_COPIES][2C] -> totals (optional, 2C doubles) and mean / invstd / running statistics (one workgroup)
+__global__ __launch_bounds__(256) void bn_fold_kernel(const double* __restrict__ acc, double* __restrict__ totals, int rows, int C,
+                                                     const BnFinal fin) {
+  __shared__ double red2c[512];
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    double u[BN_COPIES], t = 0.0;
+#pragma unroll
+    for (int q = 0; q < BN_COPIES; ++q) u[q] = acc[(size_t)q * 2 * C + o];
+#pragma unroll
+    for (int q = 0; q < BN_COPIES; ++q) t += u[q];
+    red2c[o] = t;
+    if (totals) totals[o] = t;
+  }
+  __syncthreads();
+  bn_finalize(red2c, C, rows, fin);
 }
 
 // rows per workgroup of bn_reduce_kernel: a multiple of the rows one pass of the workgroup covers, ~512 workgroups, at most 1024 rows
@@ -232,17 +254,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                           const float* __restrict__ resid, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int rows, int C) {
+                                                          float* __restrict__ dbeta, int rows, int C, const double* __restrict__ wl,
+                                                          double rows_total) {
+  // ws: the sums over ALL rows the statistics were taken over (rows_total of them: this rank's, or every rank's under SyncBatchNorm);
+  // wl: this rank's own sums -- d(gamma), d(beta) are per-rank quantities (the data-parallel exchange averages them afterwards)
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)rows * C) return;
   const int c = (int)(i % C);
   const float mu = mean[c], is = invstd[c], g = gamma[c];
   const float xh = (x[i] - mu) * is, yv = g * xh + beta[c];
   const float dy = dact[i] * (yv > 0.f ? 1.0f : slope);
-  const float m1 = (float)(ws[c] / rows), m2 = (float)(ws[C + c] / rows);
+  const float m1 = (float)(ws[c] / rows_total), m2 = (float)(ws[C + c] / rows_total);
   const float v = g * is * (dy - m1 - xh * m2);
   dx[i] = resid ? resid[i] + v : v;
-  if (i < (size_t)C) { dbeta[c] += (float)ws[c]; dgamma[c] += (float)ws[C + c]; }
+  if (i < (size_t)C) { dbeta[c] += (float)wl[c]; dgamma[c] += (float)wl[C + c]; }
 }
 
 // feat[b][c] = mean over the HW2 pixels of act_f32[b][.][c];  backward: dact[b][p][c] = dfeat[b][c] / HW2
@@ -378,15 +403,15 @@ extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int C, in
   return SR_OK;
 }
 
-static void launch_bn_stats(const float* x, double* ws, int rows, int C, const BnFinal& fin, hipStream_t s) {
+static void launch_bn_stats(const float* x, double* ws, int rows, int C, const BnFinal& fin, hipStream_t s, double* acc_only = nullptr) {
   if (C % 4 == 0) {
     const int rpb = bn_rows_per_block(rows, C, 4);
     hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                       ws, rows, C, rpb, fin);
+                       ws, rows, C, rpb, fin, acc_only);
   } else {
     const int rpb = bn_rows_per_block(rows, C, 1);
     hipLaunchKernelGGL((bn_reduce_kernel<false, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                       ws, rows, C, rpb, fin);
+                       ws, rows, C, rpb, fin, acc_only);
   }
 }
 
@@ -420,26 +445,61 @@ extern "C" int srhip_bn_stats(const float* x, float eps, float momentum, int upd
   return SR_OK;
 }
 
-extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma,
-                            const float* beta, float slope, const float* resid, float* dx, float* dgamma, float* dbeta, double* ws, int rows,
-                            int C, void* stream) {
-  if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !ws || rows <= 0 || C <= 0 || C > 256 || (256 % C))
-    return SR_EINVAL;
+extern "C" int srhip_bn_accumulate(const float* x, double* acc, int rows, int C, void* stream) {
+  if (!x || !acc || rows <= 0 || C <= 0 || C > 256 || (256 % C)) return SR_EINVAL;
+  launch_bn_stats(x, nullptr, rows, C, BnFinal{}, (hipStream_t)stream, acc);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_fold(const double* acc, double rows_total, float eps, float momentum, int update_running, float* running_mean,
+                             float* running_var, float* out_mean, float* out_invstd, double* totals, int C, void* stream) {
+  if (!acc || rows_total < 1.0 || C <= 0 || C > 256 || (!out_mean && !totals) || (out_mean && !out_invstd)) return SR_EINVAL;
+  if (update_running && (!running_mean || !running_var)) return SR_EINVAL;
+  BnFinal fin;
+  fin.out_mean = out_mean; fin.out_invstd = out_invstd; fin.running_mean = running_mean; fin.running_var = running_var;
+  fin.momentum = momentum; fin.update_running = update_running; fin.eps = eps;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc, totals, (int)rows_total, C, fin);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_bwd_reduce(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma,
+                                   const float* beta, float slope, double* ws, int rows, int C, void* stream) {
+  if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !ws || rows <= 0 || C <= 0 || C > 256 || (256 % C)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (C % 4 == 0) {
     const int rpb = bn_rows_per_block(rows, C, 4);
     hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
-                       rows, C, rpb, BnFinal{});
+                       rows, C, rpb, BnFinal{}, nullptr);
   } else {
     const int rpb = bn_rows_per_block(rows, C, 1);
     hipLaunchKernelGGL((bn_reduce_kernel<true, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
-                       rows, C, rpb, BnFinal{});
+                       rows, C, rpb, BnFinal{}, nullptr);
   }
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, dact, ws, save_mean, save_invstd, gamma, beta,
-                     slope, resid, dx, dgamma, dbeta, rows, C);
+  return SR_OK;
+}
+
+extern "C" int srhip_bn_bwd_apply(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma,
+                                  const float* beta, float slope, const float* resid, float* dx, float* dgamma, float* dbeta,
+                                  const double* totals, const double* local_totals, double rows_total, int rows, int C, void* stream) {
+  if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !totals || rows <= 0 || C <= 0 ||
+      rows_total < rows)
+    return SR_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dact, totals, save_mean,
+                     save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, rows, C, local_totals ? local_totals : totals, rows_total);
   SR_CHECK_LAUNCH();
   return SR_OK;
+}
+
+extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma,
+                            const float* beta, float slope, const float* resid, float* dx, float* dgamma, float* dbeta, double* ws, int rows,
+                            int C, void* stream) {
+  const int rc = srhip_bn_bwd_reduce(dact, x, save_mean, save_invstd, gamma, beta, slope, ws, rows, C, stream);
+  if (rc != SR_OK) return rc;
+  return srhip_bn_bwd_apply(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, ws, nullptr, (double)rows, rows, C,
+                            stream);
 }
 
 extern "C" int srhip_avgpool_fwd(const float* act, float* feat, int B, int HW2, int C, void* stream) {

@@ -179,36 +179,36 @@ class WideResNet:
             ops.gemm_nt(ops.EPI_RESID_F32, col, c["Wb"], out, rows, c["cout"], c["Kp"], bias=bias, aux_in=resid, ldaux=c["cout"])
         return col, Ho, Wo
 
-    def _bn_act(self, name, x, rows, C, tag, train, update, want_f32=False):
-        """BatchNorm + LeakyReLU(0.1): returns (act bf16 [rows,C], act fp32 or None, (mean, invstd))."""
-        P = self.p
-        act = self._buf((tag, name, "act"), (rows, C), torch.bfloat16)
-        af = self._buf((tag, name, "actf"), (rows, C), torch.float32) if want_f32 else None
-        mean = self._buf((tag, name, "mean"), (C,), torch.float32)
-        invstd = self._buf((tag, name, "invstd"), (C,), torch.float32)
-        ops.bn_fwd(x, P(name + ".weight"), P(name + ".bias"), self.eps[name], SLOPE, MOMENTUM, train, update,
-                   self.buffers[name + ".running_mean"], self.buffers[name + ".running_var"], mean, invstd, act, af, self.ws, rows, C)
-        if train and update:
-            self.buffers[name + ".num_batches_tracked"] += 1
-        return act, af, (mean, invstd)
-
     # ---- one launch per convolution (csrc/wrn_conv.hip) ------------------------------------------------------------------------------
     def _stats_bufs(self, name, C, tag):
         return (self._buf((tag, name, "mean"), (C,), torch.float32), self._buf((tag, name, "invstd"), (C,), torch.float32))
 
-    def _conv_bn(self, wname, xin, in_bn, in_st, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False):
+    # SyncBatchNorm.  Under DDP the reference converts every BatchNorm of this backbone (core/utils/misc.py:55): in training mode the batch
+    # statistics are those of ALL ranks' rows.  Statistics are sums here, so the ranks exchange the accumulator of a BatchNorm between the
+    # launch that fills it and the launch that folds it, and the backward exchanges its two column sums between reduce and apply -- one small
+    # all-reduce per BatchNorm per pass, as torch's SyncBatchNorm does.  ``dp`` is set by the algorithm (core/algorithmbase.py).
+    dp = None
+
+    @property
+    def stat_ranks(self):
+        return self.dp.world_size if (self.dp is not None and self.dp.active) else 1
+
+    def _sync_acc(self, bn):
+        if self.stat_ranks > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.bn_acc[bn])
+
+    def _conv_bn(self, wname, xin, in_bn, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False):
         """out = conv(LeakyReLU(BN_in(xin))) (+ resid) -- or conv(xin) when ``raw`` -- and, in training mode, the sums of ``out`` added into the
-        accumulator of ``next_bn``.  in_st: (mean, invstd) buffers already filled (the first BatchNorm: srhip_bn_stats) or None = fold them
-        from in_bn's accumulator; ``publish``: this launch also writes in_bn's (mean, invstd) for the backward and moves its running
-        statistics.  Returns in_bn's statistics buffers (None in eval mode)."""
+        accumulator of ``next_bn`` (then exchanged between the ranks).  Training mode folds in_bn's statistics from its accumulator; ``publish``:
+        this launch also writes in_bn's (mean, invstd) for the backward and moves its running statistics.  Returns in_bn's statistics buffers
+        (None in eval mode)."""
         c = self.convs[wname]
         P = self.p
         g, bt, eps = P(in_bn + ".weight"), P(in_bn + ".bias"), self.eps[in_bn]
         acc_out = self.bn_acc[next_bn] if (next_bn is not None and train) else None
         if not train:
             stats, acc, mode, pub, st = (self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]), None, 1, None, None
-        elif in_st is not None:
-            stats, acc, mode, pub, st = in_st, None, 0, None, in_st
         else:
             stats, acc, mode = None, self.bn_acc[in_bn], 3
             st = self._stats_bufs(in_bn, c["cin"], tag)
@@ -217,9 +217,11 @@ class WideResNet:
             mode = 2
         ops.wrn_conv_bn(xin, mode, stats, acc, g, bt, eps, SLOPE, c["Wb"], resid, out, B, H, W, c["cin"], c["cout"], c["k"], stride, c["Kp"],
                         publish=pub, running=(self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]) if pub else None,
-                        momentum=MOMENTUM, update_running=update, acc_out=acc_out)
+                        momentum=MOMENTUM, update_running=update, acc_out=acc_out, stat_ranks=self.stat_ranks)
         if pub is not None and update:
             self.buffers[in_bn + ".num_batches_tracked"] += 1
+        if acc_out is not None:
+            self._sync_acc(next_bn)
         return st
 
     def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None):
@@ -244,17 +246,12 @@ class WideResNet:
             ctx = WrnContext()
             ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
         h, w = H, W
-        # statistics of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
-        first = self.blocks[0][0] + "bn1"
-        st = None
-        if train:
-            st = self._stats_bufs(first, self.channels[0], tag)
-            ops.bn_stats(out, self.eps[first], MOMENTUM, upd, self.buffers[first + ".running_mean"], self.buffers[first + ".running_var"],
-                         st[0], st[1], self.ws, B * h * w, self.channels[0])
-            if upd:
-                self.buffers[first + ".num_batches_tracked"] += 1
         if train:
             self.bn_acc_arena.zero_()                         # the accumulators of every BatchNorm of this forward: one fill launch
+            # sums of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
+            first = self.blocks[0][0] + "bn1"
+            ops.bn_accumulate(out, self.bn_acc[first], B * h * w, self.channels[0])
+            self._sync_acc(first)
         for bi, (p, cin, cout, stride, abr) in enumerate(self.blocks):
             equal = cin == cout
             raw = not (equal or abr)                          # wrn.py:50: conv1 / convShortcut take the RAW x; bn1's statistics still move
@@ -262,21 +259,33 @@ class WideResNet:
             rows_out = B * ho * wo
             c1 = self._buf((tag, p, "c1"), (rows_out, cout), f32)
             # conv1 reads x through bn1 (folding / publishing its statistics) and leaves the sums of its output for bn2
-            st1 = self._conv_bn(p + "conv1.weight", out, p + "bn1", st, raw, B, h, w, stride, c1, tag, train, upd, next_bn=p + "bn2", publish=True)
+            st1 = self._conv_bn(p + "conv1.weight", out, p + "bn1", raw, B, h, w, stride, c1, tag, train, upd, next_bn=p + "bn2", publish=True)
             if equal:
                 sc = out
             else:
                 sc = self._buf((tag, p, "sc"), (rows_out, cout), f32)
-                self._conv_bn(p + "convShortcut.weight", out, p + "bn1", st, raw, B, h, w, stride, sc, tag, train, upd)
+                self._conv_bn(p + "convShortcut.weight", out, p + "bn1", raw, B, h, w, stride, sc, tag, train, upd)
             y = self._buf((tag, p, "y"), (rows_out, cout), f32)
-            nxt = self.blocks[bi + 1][0] + "bn1" if bi + 1 < len(self.blocks) else None
-            st2 = self._conv_bn(p + "conv2.weight", c1, p + "bn2", None, False, B, ho, wo, 1, y, tag, train, upd, resid=sc, next_bn=nxt, publish=True)
+            nxt = self.blocks[bi + 1][0] + "bn1" if bi + 1 < len(self.blocks) else "bn1"        # (the last block feeds the final BatchNorm)
+            st2 = self._conv_bn(p + "conv2.weight", c1, p + "bn2", False, B, ho, wo, 1, y, tag, train, upd, resid=sc, next_bn=nxt, publish=True)
             if save:
                 ctx.blocks.append(dict(x=out, st1=st1, c1=c1, st2=st2, raw=raw, h=h, w=w, ho=ho, wo=wo))
-            out, h, w, st = y, ho, wo, None
+            out, h, w = y, ho, wo
         rows = B * h * w
         C3 = self.channels[3]
-        _, af, stf = self._bn_act("bn1", out, rows, C3, tag, train, update_stats, want_f32=True)
+        # final BatchNorm + LeakyReLU (fp32 for the pooling): fold the sums the last convolution left, then apply
+        af = self._buf((tag, "bn1", "actf"), (rows, C3), f32)
+        if train:
+            stf = self._stats_bufs("bn1", C3, tag)
+            ops.bn_fold(self.bn_acc["bn1"], rows * self.stat_ranks, self.eps["bn1"], MOMENTUM, upd, self.buffers["bn1.running_mean"],
+                        self.buffers["bn1.running_var"], stf[0], stf[1], None, C3)
+            if upd:
+                self.buffers["bn1.num_batches_tracked"] += 1
+            ops.bn_act(out, stf, self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE, 0, None, rows, C3, act_f32=af)
+        else:
+            stf = None
+            ops.bn_act(out, (self.buffers["bn1.running_mean"], self.buffers["bn1.running_var"]), self.p("bn1.weight"), self.p("bn1.bias"),
+                       self.eps["bn1"], SLOPE, 1, None, rows, C3, act_f32=af)
         feat = torch.empty(B, C3, dtype=f32, device=self.device)
         logits = torch.empty(B, self.num_classes, dtype=f32, device=self.device)
         ops.avgpool_fwd(af, feat, B, h * w, C3)
@@ -381,8 +390,22 @@ class WideResNet:
         dact = self._buf((tag, "dactf"), (rows, C3), f32)
         ops.avgpool_bwd(dfeat, dact, B, fin["h"] * fin["w"], C3)
         dy = self._buf((tag, "dy.final"), (rows, C3), f32)
-        ops.bn_bwd(dact, fin["x"], fin["st"][0], fin["st"][1], P("bn1.weight"), P("bn1.bias"), SLOPE, None, dy, G("bn1.weight"), G("bn1.bias"),
-                   self.ws, rows, C3)
+        ranks = self.stat_ranks
+
+        def bn_bwd(dact, x, st, bn, resid, dx, rows_, C_):
+            """BatchNorm + LeakyReLU backward: the two column sums (this rank's, then every rank's under SyncBatchNorm), then the apply pass."""
+            ops.bn_bwd_reduce(dact, x, st[0], st[1], P(bn + ".weight"), P(bn + ".bias"), SLOPE, self.ws, rows_, C_)
+            local = None
+            if ranks > 1:
+                import torch.distributed as dist
+                local = self._buf((tag, "bn.local_sums"), (512,), torch.float64)
+                local[:2 * C_].copy_(self.ws[:2 * C_])
+                dist.all_reduce(self.ws[:2 * C_])
+            ops.bn_bwd_apply(dact, x, st[0], st[1], P(bn + ".weight"), P(bn + ".bias"), SLOPE, resid, dx, G(bn + ".weight"), G(bn + ".bias"),
+                             self.ws, local, rows_ * ranks, rows_, C_)
+
+        bn_bwd(dact, fin["x"], fin["st"], "bn1", None, dy, rows, C3)
+
         def col_of(name, src, bn, st, raw, rows_src, Hs, Ws, stride, act=None):
             """The im2col operand of a convolution's filter gradient, recomputed from what the forward kept (its fp32 input and the statistics
             of the BatchNorm in front of it) instead of stored by every forward: act bf16 = LeakyReLU(BN(src)) (or src), then im2col."""
@@ -409,18 +432,15 @@ class WideResNet:
                 r["colS"], _ = col_of(p + "convShortcut.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride, act=act1)
             do2 = conv_bwd(p + "conv2.weight", dy, rows_out, r["col2"], True, r["ho"], r["wo"], 1)
             dc1 = self._buf((tag, p, "dc1"), (rows_out, cout), f32)
-            ops.bn_bwd(do2, r["c1"], r["st2"][0], r["st2"][1], P(p + "bn2.weight"), P(p + "bn2.bias"), SLOPE, None, dc1, G(p + "bn2.weight"),
-                       G(p + "bn2.bias"), self.ws, rows_out, cout)
+            bn_bwd(do2, r["c1"], r["st2"], p + "bn2", None, dc1, rows_out, cout)
             din = conv_bwd(p + "conv1.weight", dc1, rows_out, r["col1"], True, r["h"], r["w"], stride)
             dx = self._buf((tag, p, "dx"), (rows_in, cin), f32)
             if equal:
-                ops.bn_bwd(din, r["x"], r["st1"][0], r["st1"][1], P(p + "bn1.weight"), P(p + "bn1.bias"), SLOPE, dy, dx, G(p + "bn1.weight"),
-                           G(p + "bn1.bias"), self.ws, rows_in, cin)
+                bn_bwd(din, r["x"], r["st1"], p + "bn1", dy, dx, rows_in, cin)
             else:
                 conv_bwd(p + "convShortcut.weight", dy, rows_out, r["colS"], True, r["h"], r["w"], stride, din=din, accumulate=True)
                 if abr:
-                    ops.bn_bwd(din, r["x"], r["st1"][0], r["st1"][1], P(p + "bn1.weight"), P(p + "bn1.bias"), SLOPE, None, dx,
-                               G(p + "bn1.weight"), G(p + "bn1.bias"), self.ws, rows_in, cin)
+                    bn_bwd(din, r["x"], r["st1"], p + "bn1", None, dx, rows_in, cin)
                 else:
                     dx = din                                   # raw-x path; this bn1 feeds nothing (no gradient, as in the reference)
             dy = dx

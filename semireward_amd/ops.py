@@ -669,7 +669,7 @@ def bn_acc_doubles(C):
 
 
 def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope, Wb, resid, y, B, H, W, Cin, Cout, ksize, stride, Kpad,
-                publish=None, running=None, momentum=0.0, update_running=False, acc_out=None):
+                publish=None, running=None, momentum=0.0, update_running=False, acc_out=None, stat_ranks=1):
     """y = conv(f(xin)) (+ resid).  in_mode 0: in_stats = (mean, invstd); 1: (running_mean, running_var); 2: raw; 3: statistics folded from
     in_acc.  publish = (mean, invstd) buffers workgroup (0,0) fills from in_acc (+ running = (running_mean, running_var) moved when
     update_running).  acc_out: accumulator of the BatchNorm that reads y next (sums of y are added)."""
@@ -680,7 +680,7 @@ def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _call("srhip_wrn_conv_bn", _p(xin), in_mode, _p(im), _p(ii), _p(in_acc), _p(in_gamma), _p(in_beta), in_eps, slope, _p(pm), _p(pi), _p(rm),
-          _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), _s())
+          _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), stat_ranks, _s())
     if _PROFILE is not None:
         e1.record()
         npix = y.shape[0]
@@ -694,9 +694,27 @@ def bn_stats(x, eps, momentum, update_running, running_mean, running_var, out_me
           rows, C, _s())
 
 
-def bn_act(x, stats, gamma, beta, eps, slope, mode, act, rows, C):
+def bn_act(x, stats, gamma, beta, eps, slope, mode, act, rows, C, act_f32=None):
     m, i = stats if stats is not None else (None, None)
-    _call("srhip_bn_act", _p(x), _p(m), _p(i), _p(gamma), _p(beta), eps, slope, mode, _p(act), rows, C, _s())
+    _call("srhip_bn_act", _p(x), _p(m), _p(i), _p(gamma), _p(beta), eps, slope, mode, _p(act), _p(act_f32), rows, C, _s())
+
+
+def bn_accumulate(x, acc, rows, C):
+    _call("srhip_bn_accumulate", _p(x), _p(acc), rows, C, _s())
+
+
+def bn_fold(acc, rows_total, eps, momentum, update_running, running_mean, running_var, out_mean, out_invstd, totals, C):
+    _call("srhip_bn_fold", _p(acc), float(rows_total), eps, momentum, int(update_running), _p(running_mean), _p(running_var), _p(out_mean),
+          _p(out_invstd), _p(totals), C, _s())
+
+
+def bn_bwd_reduce(dact, x, save_mean, save_invstd, gamma, beta, slope, ws, rows, C):
+    _call("srhip_bn_bwd_reduce", _p(dact), _p(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta), slope, _p(ws), rows, C, _s())
+
+
+def bn_bwd_apply(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, totals, local_totals, rows_total, rows, C):
+    _call("srhip_bn_bwd_apply", _p(dact), _p(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta), slope, _p(resid), _p(dx), _p(dgamma),
+          _p(dbeta), _p(totals), _p(local_totals), float(rows_total), rows, C, _s())
 
 
 def bn_fwd(x, gamma, beta, eps, slope, momentum, training, update_running, running_mean, running_var, save_mean, save_invstd, act_bf16,

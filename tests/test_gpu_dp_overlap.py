@@ -40,6 +40,21 @@ def test_global_reward_threshold_through_the_engine_with_two_ranks():
     assert out.count("global_reward_threshold=True") == 2 and out.count("global_reward_threshold=False") == 2
 
 
+def test_wideresnet_under_data_parallel_is_syncbatchnorm():
+    """The reference converts the WideResNet's BatchNorms to SyncBatchNorm under DDP (core/utils/misc.py:55).  tools/dp_syncbn_check.py: two
+    ranks with half a batch each == one rank with the whole batch (logits, running statistics, the sum over ranks of the gradients), and the
+    same comparison fails by > 10x when the statistics stay per-rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "dp_syncbn_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and out.count("syncbn == whole batch: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_allreduce_streams_are_ordered_by_events_not_by_the_backend():
     """The all-reduce under the backward runs on a communication stream (distributed.DataParallel.install_overlap).  gloo's all_reduce
     synchronises the stream it is called on, so the two-rank tests cannot see a missing event; RCCL does not.  Here the collective is replaced by
