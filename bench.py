@@ -527,7 +527,10 @@ def worker(a):
                 ("classic_cv_wrn_28_2_srpseudolabel", dict(net="wrn", bu=64), max(4, a.steps // 2), True),
                 ("usb_nlp_bert_base_srsoftmatch", dict(net="bert"), max(3, a.steps // 5), True),
                 ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), True))
+        only = [t for t in os.environ.get("SR_BENCH_LEGS", "").split(",") if t]        # (debugging: run a subset of the secondary legs)
         for tag, kw, nsteps, roof in legs:
+            if only and tag not in only:
+                continue
             leg = None
             try:
                 leg = Leg(a, ctx, **kw)
