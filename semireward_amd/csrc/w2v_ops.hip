@@ -12,6 +12,8 @@
 // zero-padded staging copy [group][clip * Pp + frame][C / groups].
 // Layer 0 (1 input channel, k = 10) is a direct kernel: 20 flop per output, recomputed instead of stored (its pre-GroupNorm output would
 // be 26 MB per 4-second clip in fp32).
+#include <stdlib.h>
+
 #include "common.h"
 #include "srhip.h"
 
@@ -20,10 +22,11 @@ namespace {
 constexpr int TCH = 128;   // frames per workgroup of the layer-0 kernels
 constexpr int K0MAX = 16;
 
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_exact_grad(float v) {
-  return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
-}
+// nn.GELU() ("exact erf") and its derivative through the Abramowitz-Stegun erf of common.h (|err| <= 1.5e-7, one v_exp + one v_rcp, no
+// branches) -- the form the GEMM epilogues of the same encoder use; the OCML erff / expf pair was ~50 of the 80 instructions per output of the
+// layer-0 backward passes.
+__device__ __forceinline__ float gelu_exact(float v) { return gelu_erf(v); }
+__device__ __forceinline__ float gelu_exact_grad(float v) { return gelu_erf_grad(v); }
 
 // stage the waveform segment of TCH frames (stride s, k taps) of clip b into LDS
 __device__ __forceinline__ void stage_wave(float* seg, const float* wave, int S, int b, int t0, int k, int s) {
@@ -93,6 +96,100 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     if (MODE == 3) {
 #pragma unroll
       for (int j = 0; j < K0MAX; ++j) if (j < k) atomicAdd(dW0 + c * k + j, dw[j]);
+    }
+  }
+}
+
+// The same four passes for the shape every usb_audio config has (k = 10, stride 5), four frames per iteration.  In the generic kernel a thread
+// reads one waveform sample per multiply-add from LDS (ds_read_b32, every lane the same address): 10 LDS instructions per frame and channel,
+// 108 k of them per CU -- the LDS issue rate, not the arithmetic, bounded the statistics pass (380 us for 12 arithmetic instructions per
+// output).  Four consecutive frames read the 25 samples [5 t, 5 t + 25) as seven 16-byte LDS loads (t a multiple of 4: 80-byte steps) and keep
+// them in registers: 1.75 LDS instructions per frame instead of 10.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv0_k10s5_kernel(const float* __restrict__ wave, const float* __restrict__ W0, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, double* __restrict__ ws, double* __restrict__ ws2,
+                                                         bf16_t* __restrict__ out, const bf16_t* __restrict__ dY, float* __restrict__ dW0,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int S, int T0, int P0, int C,
+                                                         float eps, int nsub) {
+  constexpr int K = 10, ST = 5, FR = 4, MAXC = 2;                    // C <= 512: a thread owns channels threadIdx.x and threadIdx.x + 256
+  extern __shared__ __attribute__((aligned(16))) float seg[];
+  const int b = blockIdx.x, tlim = MODE == 1 ? P0 : T0;
+  float w[MAXC][K], mean[MAXC], rstd[MAXC], g[MAXC], be[MAXC], a1[MAXC], a2[MAXC];
+  float acc0[MAXC], acc1[MAXC], acc2[MAXC], acc3[MAXC], dw[MODE == 3 ? MAXC : 1][K];
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    acc0[q] = acc1[q] = acc2[q] = acc3[q] = 0.f;
+    mean[q] = rstd[q] = g[q] = be[q] = a1[q] = a2[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { w[q][j] = c < C ? W0[c * K + j] : 0.f; if (MODE == 3) dw[q][j] = 0.f; }
+    if (c < C && MODE >= 1) {
+      const double m = ws[((size_t)b * C + c) * 2] / T0, qq = ws[((size_t)b * C + c) * 2 + 1] / T0;
+      mean[q] = (float)m; rstd[q] = rsqrtf((float)(qq - m * m) + eps);
+      g[q] = gamma[c]; be[q] = beta[c];
+    }
+    if (c < C && MODE == 3) { a1[q] = (float)(ws2[((size_t)b * C + c) * 2] / T0); a2[q] = (float)(ws2[((size_t)b * C + c) * 2 + 1] / T0); }
+  }
+  // the reduction passes walk nsub segments per workgroup and add their sums once: the filter gradient alone was 13.8 M float atomics onto
+  // 5120 addresses (160 cache lines) -- at one atomic per clock and L2 channel that is 0.4 ms, twice the pass's arithmetic
+  for (int sub = 0; sub < nsub; ++sub) {
+    const int t0 = (blockIdx.y * nsub + sub) * TCH;
+    if (t0 >= tlim) break;                                  // (uniform over the workgroup)
+    if (sub) __syncthreads();                               // the previous segment's readers are done with seg
+    stage_wave(seg, wave, S, b, t0, K, ST);
+    __syncthreads();
+    const int tend = min(TCH, tlim - t0);
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+      const int c = threadIdx.x + 256 * q;
+      if (c < C) {
+        for (int tb = 0; tb < tend; tb += FR) {
+          float x[28];
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            const float4 v4 = *reinterpret_cast<const float4*>(seg + tb * ST + 4 * i);
+            x[4 * i] = v4.x; x[4 * i + 1] = v4.y; x[4 * i + 2] = v4.z; x[4 * i + 3] = v4.w;
+          }
+#pragma unroll
+          for (int f = 0; f < FR; ++f) {
+            const int tt = tb + f, t = t0 + tt;
+            if (tt >= tend) break;
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) v = fmaf(w[q][j], x[f * ST + j], v);        // (the generic kernel's order of the multiply-adds)
+            if (MODE == 0) { acc0[q] += v; acc1[q] += v * v; }
+            if (MODE == 1) {
+              const float y = t < T0 ? gelu_erf((v - mean[q]) * rstd[q] * g[q] + be[q]) : 0.f;
+              out[((size_t)b * P0 + t) * C + c] = f2bf(y);
+            }
+            if (MODE >= 2) {
+              const float xh = (v - mean[q]) * rstd[q], dgn = bf2f(dY[((size_t)b * P0 + t) * C + c]) * gelu_exact_grad(xh * g[q] + be[q]);
+              const float dxh = dgn * g[q];
+              if (MODE == 2) { acc0[q] += dxh; acc1[q] += dxh * xh; acc2[q] += dgn * xh; acc3[q] += dgn; }
+              if (MODE == 3) {
+                const float dc = rstd[q] * (dxh - a1[q] - xh * a2[q]);
+#pragma unroll
+                for (int j = 0; j < K; ++j) dw[q][j] = fmaf(dc, x[f * ST + j], dw[q][j]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // hardware fp atomics (global_atomic_add_f32 / _f64)
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    if (c >= C) continue;
+    if (MODE == 0) { unsafeAtomicAdd(&ws[((size_t)b * C + c) * 2], (double)acc0[q]); unsafeAtomicAdd(&ws[((size_t)b * C + c) * 2 + 1], (double)acc1[q]); }
+    if (MODE == 2) {
+      unsafeAtomicAdd(&ws2[((size_t)b * C + c) * 2], (double)acc0[q]); unsafeAtomicAdd(&ws2[((size_t)b * C + c) * 2 + 1], (double)acc1[q]);
+      unsafeAtomicAdd(dgamma + c, acc2[q]); unsafeAtomicAdd(dbeta + c, acc3[q]);
+    }
+    if (MODE == 3) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) unsafeAtomicAdd(dW0 + c * K + j, dw[q][j]);
     }
   }
 }
@@ -471,7 +568,21 @@ extern "C" int srhip_w2v_conv0(int mode, const float* wave, const float* W0, con
   hipStream_t s = (hipStream_t)stream;
 #define C0(MODE) hipLaunchKernelGGL(conv0_kernel<MODE>, grid, block, sm, s, wave, W0, gamma, beta, ws, ws2, (bf16_t*)out_bf16, (const bf16_t*)dY, dW0, \
                                     dgamma, dbeta, S, T0, P0, C, k, stride, eps)
-  if (mode == 0) C0(0); else if (mode == 1) C0(1); else if (mode == 2) C0(2); else C0(3);
+  static const bool generic_only = getenv("SRHIP_W2V_CONV0_GENERIC") != nullptr;            // tuning: the generic kernel for every shape
+  if (k == 10 && stride == 5 && !generic_only && C <= 512) {
+    static const int env_nsub = getenv("SRHIP_W2V_CONV0_NSUB") ? atoi(getenv("SRHIP_W2V_CONV0_NSUB")) : 0;
+    // segments per workgroup (measured per pass, 27 clips: statistics 139 / 154 / 172 us at 1 / 2 / 4, backward statistics 181 / 256 / 454,
+    // filter gradient 544 / 395 / 455): only the filter gradient, 10 atomics per channel and workgroup, gains from fewer workgroups
+    const int nsub = mode == 1 ? 1 : (env_nsub > 0 ? env_nsub : (mode == 3 ? 2 : 1));
+    const dim3 gridf(B, cdiv(mode == 1 ? P0 : T0, TCH * nsub));
+    const size_t smf = sm + 16 * sizeof(float);             // the last 16-byte read of a segment may reach 3 samples past it (never used)
+#define C0F(MODE) hipLaunchKernelGGL(conv0_k10s5_kernel<MODE>, gridf, block, smf, s, wave, W0, gamma, beta, ws, ws2, (bf16_t*)out_bf16, \
+                                     (const bf16_t*)dY, dW0, dgamma, dbeta, S, T0, P0, C, eps, nsub)
+    if (mode == 0) C0F(0); else if (mode == 1) C0F(1); else if (mode == 2) C0F(2); else C0F(3);
+#undef C0F
+  } else {
+    if (mode == 0) C0(0); else if (mode == 1) C0(1); else if (mode == 2) C0(2); else C0(3);
+  }
 #undef C0
   SR_CHECK_LAUNCH();
   return SR_OK;
