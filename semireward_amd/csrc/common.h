@@ -47,6 +47,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// all-reduce over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15) on the vector ALU: quad swaps, half-row mirror, row mirror -- four
+// full-rate adds instead of four ds_bpermute round trips (__shfl_xor)
+__device__ __forceinline__ float row16_sum(float v) {
+#define SR_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  SR_DPP_ADD(0xB1);      // quad_perm [1, 0, 3, 2]
+  SR_DPP_ADD(0x4E);      // quad_perm [2, 3, 0, 1]
+  SR_DPP_ADD(0x141);     // row_half_mirror
+  SR_DPP_ADD(0x140);     // row_mirror
+#undef SR_DPP_ADD
+  return v;
+}
+
 // all-reduce over the four 16-lane rows of a wave with the gfx950 row-swap instructions (instead of two ds_bpermute round trips):
 // permlane16_swap(a, b) = {a.r0 b.r0 a.r2 b.r2, a.r1 b.r1 a.r3 b.r3} (tools/pl_probe.hip), permlane32_swap(a, b) = {a.lo b.lo, a.hi b.hi}
 __device__ __forceinline__ float rows_sum4(float x) {

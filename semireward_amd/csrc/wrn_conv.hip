@@ -58,6 +58,62 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
   __shared__ double red2c[256];
   __shared__ float kred[KS > 1 ? 4 : 1][NT][4][64];    // split K: the partial accumulators of the waves with k part != 0
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int co0 = blockIdx.y * NT * 16, K = a.ks * a.ks * a.Cin, pad = a.ks >> 1, nks = a.Kp >> 5, HoWo = a.Ho * a.Wo;
+  const bool stats = a.acc_out != nullptr;
+  // a lane adds ONE value per pixel tile it walks (<= 4 of them at the launch sizes below): fp32 here, double from the wave reduction on
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+  // KS > 1: KS waves of a workgroup share a pixel tile and take every KS-th k step (few pixel tiles, long K: the 16x16 and 8x8 layers run
+  // one wave per SIMD otherwise, each walking 18-36 dependent L2 round trips); a workgroup covers 4 / KS tiles per round
+  constexpr int TPW = 4 / KS;                              // tiles per workgroup round
+  const int kpart = wave % KS, tsub = wave / KS;
+  const int ks0 = kpart, ksstep = KS;
+  const bf16_t* wrow = a.Wb + (size_t)(co0 + l15) * a.Kp + 8 * lg;
+  const int rounds = (a.ntiles + gridDim.x * TPW - 1) / (gridDim.x * TPW);
+
+  // ---- per-tile state (set by setup) and the request of one k step's operands
+  int n = 0, y0 = 0, x0 = 0;
+  bool valid = false;
+  const float* base = a.xin;
+  auto setup = [&](int rnd) {
+    const int pt = (rnd * gridDim.x + blockIdx.x) * TPW + tsub;
+    n = pt * 16 + l15;
+    valid = pt < a.ntiles && n < a.npix;
+    const int nn = valid ? n : 0;
+    const int b = nn / HoWo, rr = nn - b * HoWo, yo = rr / a.Wo, xo = rr - yo * a.Wo;
+    y0 = yo * a.stride - pad; x0 = xo * a.stride - pad;
+    base = a.xin + (size_t)b * a.H * a.W * a.Cin;
+  };
+  auto request = [&](int ksi) {
+    StepRaw<NT> q;
+    const int k = ksi * 32 + 8 * lg;
+    q.c = -1;
+    q.v0 = float4{0.f, 0.f, 0.f, 0.f}; q.v1 = q.v0;
+    if (valid && k < K) {
+      const int tap = k >> a.log2Cin, c = k & (a.Cin - 1);
+      const int dy = a.ks == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
+      const int yy = y0 + dy, xx = x0 + dx;
+      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+        const float4* p = reinterpret_cast<const float4*>(base + ((size_t)yy * a.W + xx) * a.Cin + c);
+        q.v0 = p[0]; q.v1 = p[1];
+        q.c = c;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) q.af[t] = *reinterpret_cast<const u32x4_t*>(wrow + (size_t)16 * t * a.Kp + ksi * 32);
+    return q;
+  };
+  // The first tile's first three k steps are requested BEFORE the statistics of the input BatchNorm are folded: they do not depend on them,
+  // and the fold is a round trip to the accumulator copies (+ two barriers) that every workgroup would otherwise sit out with nothing in flight.
+  StepRaw<NT> q0, q1, q2;
+  setup(0);
+  q0 = request(ks0 < nks ? ks0 : 0); q1 = q0; q2 = q0;
+  if (ks0 + ksstep < nks) q1 = request(ks0 + ksstep);
+  if (ks0 + 2 * ksstep < nks) q2 = request(ks0 + 2 * ksstep);
+
   const bool publish = a.pub.out_mean != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
   if (a.in_mode == 3 || publish) {
     // the statistics of the input BatchNorm were left as BN_COPIES partial sums by the launch that produced xin (its epilogue only adds;
@@ -87,53 +143,18 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();
-  const int co0 = blockIdx.y * NT * 16, K = a.ks * a.ks * a.Cin, pad = a.ks >> 1, nks = a.Kp >> 5, HoWo = a.Ho * a.Wo;
-  const bool stats = a.acc_out != nullptr;
-  // a lane adds ONE value per pixel tile it walks (<= 4 of them at the launch sizes below): fp32 here, double from the wave reduction on
-  float s1[NT][4], s2[NT][4];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
-  // KS > 1: KS waves of a workgroup share a pixel tile and take every KS-th k step (few pixel tiles, long K: the 16x16 and 8x8 layers run
-  // one wave per SIMD otherwise, each walking 18-36 dependent L2 round trips); a workgroup covers 4 / KS tiles per round
-  constexpr int TPW = 4 / KS;                              // tiles per workgroup round
-  const int kpart = wave % KS, tsub = wave / KS;
-  const int ks0 = kpart, ksstep = KS;
-  const bf16_t* wrow = a.Wb + (size_t)(co0 + l15) * a.Kp + 8 * lg;
-  const int rounds = (a.ntiles + gridDim.x * TPW - 1) / (gridDim.x * TPW);
 
   for (int rnd = 0; rnd < rounds; ++rnd) {
-    const int pt = (rnd * gridDim.x + blockIdx.x) * TPW + tsub;
-    const int n = pt * 16 + l15;
-    const bool valid = pt < a.ntiles && n < a.npix;
-    const int nn = valid ? n : 0;
-    const int b = nn / HoWo, rr = nn - b * HoWo, yo = rr / a.Wo, xo = rr - yo * a.Wo;
-    const int y0 = yo * a.stride - pad, x0 = xo * a.stride - pad;
-    const float* base = a.xin + (size_t)b * a.H * a.W * a.Cin;
+    if (rnd > 0) {
+      setup(rnd);
+      q0 = request(ks0 < nks ? ks0 : 0); q1 = q0; q2 = q0;
+      if (ks0 + ksstep < nks) q1 = request(ks0 + ksstep);
+      if (ks0 + 2 * ksstep < nks) q2 = request(ks0 + 2 * ksstep);
+    }
     f32x4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto request = [&](int ksi) {
-      StepRaw<NT> q;
-      const int k = ksi * 32 + 8 * lg;
-      q.c = -1;
-      q.v0 = float4{0.f, 0.f, 0.f, 0.f}; q.v1 = q.v0;
-      if (valid && k < K) {
-        const int tap = k >> a.log2Cin, c = k & (a.Cin - 1);
-        const int dy = a.ks == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
-        const int yy = y0 + dy, xx = x0 + dx;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-          const float4* p = reinterpret_cast<const float4*>(base + ((size_t)yy * a.W + xx) * a.Cin + c);
-          q.v0 = p[0]; q.v1 = p[1];
-          q.c = c;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) q.af[t] = *reinterpret_cast<const u32x4_t*>(wrow + (size_t)16 * t * a.Kp + ksi * 32);
-      return q;
-    };
     auto consume = [&](const StepRaw<NT>& q) {
       u32x4_t bfrag = {0u, 0u, 0u, 0u};
       if (q.c >= 0) {
@@ -158,18 +179,13 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
       for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, q.af[t]), __builtin_bit_cast(bf16x8_t, bfrag), acc[t], 0, 0, 0);
     };
-    // three k steps requested ahead of the one being consumed: the loop is bound by load latency (L2 / fabric round trips: the input was
-    // written by the previous launch, mostly on other XCDs), not by bytes or MFMAs
-    if (ks0 < nks) {
-      StepRaw<NT> q0 = request(ks0), q1 = q0, q2 = q0;
-      if (ks0 + ksstep < nks) q1 = request(ks0 + ksstep);
-      if (ks0 + 2 * ksstep < nks) q2 = request(ks0 + 2 * ksstep);
-      for (int ksi = ks0; ksi < nks; ksi += ksstep) {
-        StepRaw<NT> q3 = q2;
-        if (ksi + 3 * ksstep < nks) q3 = request(ksi + 3 * ksstep);
-        consume(q0);
-        q0 = q1; q1 = q2; q2 = q3;
-      }
+    // three k steps requested ahead of the one being consumed: the loop waits on L2 / fabric round trips (the input was written by the
+    // previous launch, mostly on other XCDs)
+    for (int ksi = ks0; ksi < nks; ksi += ksstep) {
+      StepRaw<NT> q3 = q2;
+      if (ksi + 3 * ksstep < nks) q3 = request(ksi + 3 * ksstep);
+      consume(q0);
+      q0 = q1; q1 = q2; q2 = q3;
     }
     if (KS > 1) {
       if (kpart != 0) {
@@ -215,8 +231,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float f1 = s1[t][r], f2 = s2[t][r];                    // 16 pixels x (<= 4 tiles) per channel in fp32, double from the wave slot on
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) { f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); }
+      f1 = row16_sum(f1); f2 = row16_sum(f2);              // (DPP: 256 ds_bpermute round trips per wave were ~2 us of this epilogue)
       if (l15 == 0) { redw[wave][0][16 * t + 4 * lg + r] = (double)f1; redw[wave][1][16 * t + 4 * lg + r] = (double)f2; }
     }
   __syncthreads();

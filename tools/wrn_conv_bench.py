@@ -46,6 +46,8 @@ for (B, H, Cin, Cout, ks, stride) in [(64, 32, 32, 32, 3, 1), (64, 32, 16, 32, 3
     t_stats = timeit(lambda: ops.wrn_conv_bn(x, 3, None, acc_in, gam, bet, 1e-5, 0.1, Wb, res, y, B, H, H, Cin, Cout, ks, stride, Kp,
                                              publish=(pm, pi), running=(rm[:Cin] if Cin <= Cout else None, rv[:Cin] if Cin <= Cout else None),
                                              momentum=0.001, update_running=False, acc_out=acc_out))
+    t_fold = timeit(lambda: ops.wrn_conv_bn(x, 3, None, acc_in, gam, bet, 1e-5, 0.1, Wb, res, y, B, H, H, Cin, Cout, ks, stride, Kp))
+    t_sums = timeit(lambda: ops.wrn_conv_bn(x, 0, (mean, invstd), None, gam, bet, 1e-5, 0.1, Wb, res, y, B, H, H, Cin, Cout, ks, stride, Kp, acc_out=acc_out))
     t_plain = timeit(lambda: ops.wrn_conv_bn(x, 0, (mean, invstd), None, gam, bet, 1e-5, 0.1, Wb, res, y, B, H, H, Cin, Cout, ks, stride, Kp))
     t_raw = timeit(lambda: ops.wrn_conv_bn(x, 2, None, None, None, None, 0.0, 0.1, Wb, None, y, B, H, H, Cin, Cout, ks, stride, Kp))
     act = torch.empty(rows_in, Cin, dtype=torch.bfloat16, device=DEV)
@@ -59,5 +61,5 @@ for (B, H, Cin, Cout, ks, stride) in [(64, 32, 32, 32, 3, 1), (64, 32, 16, 32, 3
         ops.gemm_nt(ops.EPI_RESID_F32, col, Wb, y, rows, Cout, Kp, aux_in=res, ldaux=Cout)
     t_chain = timeit(chain)
     flop = 2.0 * rows * K * Cout
-    print("B%d %dx%d Cin %3d Cout %3d k%d s%d: fold + sums %6.1f us | given stats, no sums %6.1f us | raw input %6.1f us | unfused chain %6.1f us | %5.1f TF/s, input %.1f MB"
-          % (B, H, H, Cin, Cout, ks, stride, t_stats, t_plain, t_raw, t_chain, flop / t_plain * 1e-6, rows_in * Cin * 4 / 1e6), flush=True)
+    print("B%d %dx%d Cin %3d Cout %3d k%d s%d: fold only %6.1f | sums only %6.1f | fold + sums %6.1f us | given stats, no sums %6.1f us | raw input %6.1f us | unfused chain %6.1f us | %5.1f TF/s, input %.1f MB"
+          % (B, H, H, Cin, Cout, ks, stride, t_fold, t_sums, t_stats, t_plain, t_raw, t_chain, flop / t_plain * 1e-6, rows_in * Cin * 4 / 1e6), flush=True)
