@@ -27,6 +27,7 @@ from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
 _PHASES = os.environ.get("SR_PHASES", "0") != "0"
+_SCORE_ON_SIDE = os.environ.get("SR_SCORE_ON_SIDE", "1") != "0"      # tuning switch: the max_reward scoring launch under the backward
 # Share of the inference images that run on the second stream (see _Plan).  SR_DEFER_FRACTION=<f> pins it; otherwise it is TUNED per
 # (batch, K, backbone) in the first steps of a regime (_DeferTuner) -- SR_DEFER_AUTOTUNE=0 falls back to the fixed _DEFER_SEED.
 _DEFER_SEED = 0.475           # measured optimum of ViT-S/2 at 8 / 8 / 8, K = 8 on one MI355X; the tuner's middle candidate
@@ -574,14 +575,33 @@ class SRConsistencyBase(AlgorithmBase):
             dl_all = (dl_lb, dl_s)
         # ---- backbone backward: only the rows with a non-zero upstream gradient (see module docstring)
         ph("losses")
+        fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
+        # :166-170 (the filter is a no-op, A.2): reward.mean() and the running maximum ride in ONE scoring launch of one workgroup (~55 us).  It
+        # reads the pass-0 weak features and the rewarder only, so it runs on the side stream UNDER the backward instead of behind it (behind it,
+        # it was 55 us of the step's serial tail: wgrad -> this -> AdamW); the step's stream waits for it before anything touches the rewarder
+        score_done = None
+        if it >= self.start_timing and it > 0:                                                    # :163
+            side = self._side_stream if (self.overlap_grad_rows and _SCORE_ON_SIDE and not torch.cuda.is_current_stream_capturing()) else None
+            fw0c = fw0.contiguous()
+            if side is None:
+                self.rewarder.score(fw0c, pl0, max_reward=self.max_reward)
+            else:
+                main = torch.cuda.current_stream()
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    with ops.stream_scope():
+                        self.rewarder.score(fw0c, pl0, max_reward=self.max_reward)
+                    score_done = torch.cuda.Event()
+                    score_done.record(side)
         self.model.backward(ctx, dl_buf if (two_blocks and len(dl_all) == 2) else torch.cat(dl_all))
+        if score_done is not None:
+            torch.cuda.current_stream().wait_event(score_done)
         ph("backward")
         # ---- rewarder / generator training (:154-208)
-        fx, fw0 = Fe[0, :nl], Fe[0, nl:nl + nu]
         if it > 0:
             if it >= self.start_timing:                                                           # :163
-                # :166-170 (the filter is a no-op, A.2): reward.mean() and the running maximum ride in the scoring launch
-                self.rewarder.score(fw0.contiguous(), pl0, max_reward=self.max_reward)
                 if it % self.N_k == 0 and it > self.start_timing:                                 # :173
                     self.max_reward.fill_(-float("inf"))                                            # (in place: the buffer of a captured step)
                     gen2 = self.generator.forward_with_labels(fw0.contiguous())[1]                # :177-178
