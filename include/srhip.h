@@ -496,6 +496,15 @@ int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksi
 int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int ksize, int stride, int Kpad, int accumulate, void* stream);
 int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int C, int ksize, int Kpad, void* stream);
 int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream);
+/* conv_weight_prep / add_unpad for every convolution of a network in ONE launch each: entry p covers [start_p, start_{p+1}) of a flat index
+ * space of `total` elements (prep: Cout * Kpad per entry, a = W fp32, b = Wb, c = WbT; unpad: Cout * C * kk per entry, a = dWpad, b = dW). */
+typedef struct srhip_conv_desc {
+  const void* a; void* b; void* c;
+  int Cout, C, kk, Kpad;
+  long long start;
+} srhip_conv_desc;                       /* 48 bytes */
+int srhip_conv_weight_prep_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream);
+int srhip_add_unpad_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream);
 long long srhip_bn_ws_doubles(void);
 /* The same BasicBlock as ONE launch per convolution (csrc/wrn_conv.hip; wrn.py:41-60):
  *   wrn_conv_bn : y fp32 [B*Ho*Wo, Cout] = conv_{k,stride,pad k/2}( f(xin) ) (+ resid), xin fp32 NHWC [B,H,W,Cin] read in place (implicit GEMM);
@@ -526,7 +535,8 @@ int srhip_bn_act(const float* x, const float* mean, const float* invstd_or_var, 
  *   bn_fold       : acc -> mean / invstd (+ running update with momentum, unbiased variance) and / or the 2C totals; rows_total = rows of all ranks
  *   bn_bwd_reduce : the backward's sums (dy', dy' * xhat) of this rank into ws[0..2C) (ws as for bn_fwd)
  *   bn_bwd_apply  : dx from `totals` over rows_total rows; d(gamma) / d(beta) += local_totals (NULL: totals) -- per-rank, as torch's
- *                   batch_norm_backward_reduce / _elemt split.  srhip_bn_bwd = reduce + apply on one rank. */
+ *                   batch_norm_backward_reduce / _elemt split; dx_bf16 (may be NULL): a bf16 copy of dx, the operand of the convolution
+ *                   backward that reads it next.  srhip_bn_bwd = reduce + apply on one rank. */
 int srhip_bn_accumulate(const float* x, double* acc, int rows, int C, void* stream);
 int srhip_bn_fold(const double* acc, double rows_total, float eps, float momentum, int update_running, float* running_mean, float* running_var,
                   float* out_mean, float* out_invstd, double* totals, int C, void* stream);
@@ -534,7 +544,7 @@ int srhip_bn_bwd_reduce(const float* dact, const float* x, const float* save_mea
                         float slope, double* ws, int rows, int C, void* stream);
 int srhip_bn_bwd_apply(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
                        float slope, const float* resid, float* dx, float* dgamma, float* dbeta, const double* totals, const double* local_totals,
-                       double rows_total, int rows, int C, void* stream);
+                       double rows_total, void* dx_bf16, int rows, int C, void* stream);
 int srhip_bn_fwd(const float* x, const float* gamma, const float* beta, float eps, float slope, float momentum, int training,
                  int update_running, float* running_mean, float* running_var, float* save_mean, float* save_invstd, void* act_bf16,
                  float* act_f32, double* ws, int rows, int C, void* stream);

@@ -96,6 +96,8 @@ SIGNATURES = {
     "srhip_col2im": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "srhip_conv_weight_prep": (I, [P, P, P, I, I, I, I, P]),
     "srhip_add_unpad": (I, [P, P, I, I, I, I, P]),
+    "srhip_conv_weight_prep_grouped": (I, [P, I, c_longlong, P]),
+    "srhip_add_unpad_grouped": (I, [P, I, c_longlong, P]),
     "srhip_bn_ws_doubles": (ctypes.c_longlong, []),
     "srhip_wrn_conv_supported": (I, [I, I, I]),
     "srhip_bn_acc_doubles": (ctypes.c_longlong, [I]),
@@ -105,7 +107,7 @@ SIGNATURES = {
     "srhip_bn_accumulate": (I, [P, P, I, I, P]),
     "srhip_bn_fold": (I, [P, Dbl, F, F, I, P, P, P, P, P, I, P]),
     "srhip_bn_bwd_reduce": (I, [P, P, P, P, P, P, F, P, I, I, P]),
-    "srhip_bn_bwd_apply": (I, [P, P, P, P, P, P, F, P, P, P, P, P, P, Dbl, I, I, P]),
+    "srhip_bn_bwd_apply": (I, [P, P, P, P, P, P, F, P, P, P, P, P, P, Dbl, P, I, I, P]),
     "srhip_bn_fwd": (I, [P, P, P, F, F, F, I, I, P, P, P, P, P, P, P, I, I, P]),
     "srhip_bn_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, P, I, I, P]),
     "srhip_avgpool_fwd": (I, [P, P, I, I, I, P]),

@@ -111,6 +111,29 @@ __global__ void add_unpad_kernel(const float* __restrict__ src, float* __restric
   dst[i] += src[(size_t)o * Kpad + t * C + c];
 }
 
+// The same two passes for ALL convolutions of a network in one launch each (28 launches of 3-4 us per step and direction were each a
+// dependent link of a latency-bound chain): entry p covers elements [start_p, start_{p+1}) of the flat index space.
+__global__ __launch_bounds__(256) void conv_weight_prep_grouped_kernel(const srhip_conv_desc* __restrict__ d, int n, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= d[mid].start) lo = mid; else hi = mid - 1; }
+  const srhip_conv_desc e = d[lo];
+  const int j = (int)(i - e.start), o = j / e.Kpad, k = j % e.Kpad, K = e.C * e.kk;
+  const bf16_t v = k < K ? f2bf(((const float*)e.a)[(size_t)o * K + (k % e.C) * e.kk + k / e.C]) : (bf16_t)0;
+  ((bf16_t*)e.b)[j] = v;
+  ((bf16_t*)e.c)[(size_t)k * e.Cout + o] = v;
+}
+__global__ __launch_bounds__(256) void add_unpad_grouped_kernel(const srhip_conv_desc* __restrict__ d, int n, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= d[mid].start) lo = mid; else hi = mid - 1; }
+  const srhip_conv_desc e = d[lo];
+  const int j = (int)(i - e.start), K = e.C * e.kk, o = j / K, q = j % K, c = q / e.kk, t = q % e.kk;
+  ((float*)e.b)[j] += ((const float*)e.a)[(size_t)o * e.Kpad + t * e.C + c];
+}
+
 // ---- BatchNorm over the rows of x fp32 [rows, C] --------------------------------------------------------------------------------
 // column sums in double: ws[0..C) = sum, ws[C..2C) = sum of squares (forward) / sum dy', sum dy' * xhat (backward).
 // A workgroup covers rows_per_block rows; a thread owns V consecutive channels (V = 4: one 16-byte load per row) of every (256 / (C / V))-th
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                           const float* __restrict__ resid, float* __restrict__ dx, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int rows, int C, const double* __restrict__ wl,
-                                                          double rows_total) {
+                                                          double rows_total, bf16_t* __restrict__ dx_bf16) {
   // ws: the sums over ALL rows the statistics were taken over (rows_total of them: this rank's, or every rank's under SyncBatchNorm);
   // wl: this rank's own sums -- d(gamma), d(beta) are per-rank quantities (the data-parallel exchange averages them afterwards)
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -266,7 +289,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float dy = dact[i] * (yv > 0.f ? 1.0f : slope);
   const float m1 = (float)(ws[c] / rows_total), m2 = (float)(ws[C + c] / rows_total);
   const float v = g * is * (dy - m1 - xh * m2);
-  dx[i] = resid ? resid[i] + v : v;
+  const float o = resid ? resid[i] + v : v;
+  dx[i] = o;
+  if (dx_bf16) dx_bf16[i] = f2bf(o);                 // the GEMM operand of the convolution backward that reads dx next (saves its cast launch)
   if (i < (size_t)C) { dbeta[c] += (float)wl[c]; dgamma[c] += (float)wl[C + c]; }
 }
 
@@ -396,6 +421,19 @@ extern "C" int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int 
   return SR_OK;
 }
 
+extern "C" int srhip_conv_weight_prep_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream) {
+  if (!desc_dev || n <= 0 || total <= 0) return SR_EINVAL;
+  LAUNCH1D(conv_weight_prep_grouped_kernel, total, desc_dev, n, total);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_add_unpad_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream) {
+  if (!desc_dev || n <= 0 || total <= 0) return SR_EINVAL;
+  LAUNCH1D(add_unpad_grouped_kernel, total, desc_dev, n, total);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
 extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream) {
   if (!src || !dst || Cout <= 0 || C <= 0 || ksize <= 0 || Kpad < C * ksize * ksize) return SR_EINVAL;
   LAUNCH1D(add_unpad_kernel, (long)Cout * C * ksize * ksize, src, dst, Cout, C, ksize * ksize, Kpad);
@@ -483,12 +521,14 @@ extern "C" int srhip_bn_bwd_reduce(const float* dact, const float* x, const floa
 
 extern "C" int srhip_bn_bwd_apply(const float* dact, const float* x, const float* save_mean, const float* save_invstd, const float* gamma,
                                   const float* beta, float slope, const float* resid, float* dx, float* dgamma, float* dbeta,
-                                  const double* totals, const double* local_totals, double rows_total, int rows, int C, void* stream) {
+                                  const double* totals, const double* local_totals, double rows_total, void* dx_bf16, int rows, int C,
+                                  void* stream) {
   if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !totals || rows <= 0 || C <= 0 ||
       rows_total < rows)
     return SR_EINVAL;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dact, totals, save_mean,
-                     save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, rows, C, local_totals ? local_totals : totals, rows_total);
+                     save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, rows, C, local_totals ? local_totals : totals, rows_total,
+                     (bf16_t*)dx_bf16);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -498,8 +538,8 @@ extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save
                             int C, void* stream) {
   const int rc = srhip_bn_bwd_reduce(dact, x, save_mean, save_invstd, gamma, beta, slope, ws, rows, C, stream);
   if (rc != SR_OK) return rc;
-  return srhip_bn_bwd_apply(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, ws, nullptr, (double)rows, rows, C,
-                            stream);
+  return srhip_bn_bwd_apply(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, ws, nullptr, (double)rows, nullptr,
+                            rows, C, stream);
 }
 
 extern "C" int srhip_avgpool_fwd(const float* act, float* feat, int B, int HW2, int C, void* stream) {

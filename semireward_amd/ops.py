@@ -649,6 +649,30 @@ def conv_weight_prep(Wf, Wb, WbT, Cout, C, ksize, Kpad):
     _call("srhip_conv_weight_prep", _p(Wf), _p(Wb), _p(WbT), Cout, C, ksize, Kpad, _s())
 
 
+CONV_DESC_DTYPE = [("a", "<u8"), ("b", "<u8"), ("c", "<u8"), ("Cout", "<i4"), ("C", "<i4"), ("kk", "<i4"), ("Kpad", "<i4"), ("start", "<i8")]
+
+
+def make_conv_desc(entries, device, per_entry):
+    """entries: (a, b, c or None, Cout, C, ksize, Kpad); per_entry(Cout, C, kk, Kpad) = elements of the flat index space an entry covers.
+    Returns (device table, n, total)."""
+    import numpy as np
+    arr = np.zeros(len(entries), dtype=CONV_DESC_DTYPE)
+    t = 0
+    for i, (a, b, c, Cout, C, ks, Kpad) in enumerate(entries):
+        arr[i] = (_p(a), _p(b), _p(c) or 0, Cout, C, ks * ks, Kpad, t)
+        t += per_entry(Cout, C, ks * ks, Kpad)
+    assert arr.itemsize == 48
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(entries), t
+
+
+def conv_weight_prep_grouped(desc, n, total):
+    _call("srhip_conv_weight_prep_grouped", _p(desc), n, total, _s())
+
+
+def add_unpad_grouped(desc, n, total):
+    _call("srhip_add_unpad_grouped", _p(desc), n, total, _s())
+
+
 def add_unpad(src, dst, Cout, C, ksize, Kpad):
     _call("srhip_add_unpad", _p(src), _p(dst), Cout, C, ksize, Kpad, _s())
 
@@ -712,9 +736,10 @@ def bn_bwd_reduce(dact, x, save_mean, save_invstd, gamma, beta, slope, ws, rows,
     _call("srhip_bn_bwd_reduce", _p(dact), _p(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta), slope, _p(ws), rows, C, _s())
 
 
-def bn_bwd_apply(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, totals, local_totals, rows_total, rows, C):
+def bn_bwd_apply(dact, x, save_mean, save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, totals, local_totals, rows_total, rows, C,
+                 dx_bf16=None):
     _call("srhip_bn_bwd_apply", _p(dact), _p(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta), slope, _p(resid), _p(dx), _p(dgamma),
-          _p(dbeta), _p(totals), _p(local_totals), float(rows_total), rows, C, _s())
+          _p(dbeta), _p(totals), _p(local_totals), float(rows_total), _p(dx_bf16), rows, C, _s())
 
 
 def bn_fwd(x, gamma, beta, eps, slope, momentum, training, update_running, running_mean, running_var, save_mean, save_invstd, act_bf16,
