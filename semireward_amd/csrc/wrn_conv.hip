@@ -266,7 +266,109 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
   if (act_f32) reinterpret_cast<float4*>(act_f32)[i] = float4{o[0], o[1], o[2], o[3]};
 }
 
+// The network's tail in one launch per image batch (wrn.py:119-126): final BatchNorm + LeakyReLU (statistics folded from the accumulator the
+// last convolution filled, or the running statistics), global average pooling, classifier.  One workgroup per image; workgroup 0 publishes the
+// BatchNorm's mean / invstd / running statistics.  (Four launches before: fold, apply, pool, classifier -- 32 us per forward.)
+struct HeadArgs {
+  const float* x; const float* in_mean; const float* in_isd; const double* in_acc; const float* gamma; const float* beta;
+  float eps, slope; int in_mode; BnFinal pub;
+  const float* Wc; const float* bc; float* feat; float* logits;
+  int HW2, C, K, in_rows;
+};
+__global__ __launch_bounds__(256) void wrn_head_kernel(const HeadArgs a) {
+  __shared__ double red2c[512];
+  __shared__ float prm[4][256];
+  __shared__ float part[256];
+  __shared__ float ft[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, C = a.C;
+  if (a.in_mode == 3) {
+    for (int o = tid; o < 2 * C; o += 256) {
+      double u[BN_COPIES], t = 0.0;
+#pragma unroll
+      for (int q = 0; q < BN_COPIES; ++q) u[q] = a.in_acc[(size_t)q * 2 * C + o];
+#pragma unroll
+      for (int q = 0; q < BN_COPIES; ++q) t += u[q];
+      red2c[o] = t;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const double m = red2c[c] / a.in_rows, v = red2c[C + c] / a.in_rows - m * m;
+      prm[0][c] = (float)m; prm[1][c] = 1.0f / sqrtf((float)(v > 0.0 ? v : 0.0) + a.eps); prm[2][c] = a.gamma[c]; prm[3][c] = a.beta[c];
+    }
+    if (b == 0) bn_finalize(red2c, C, a.in_rows, a.pub);
+  } else {
+    for (int c = tid; c < C; c += 256) {
+      prm[0][c] = a.in_mean[c];
+      prm[1][c] = a.in_mode == 1 ? 1.0f / sqrtf(a.in_isd[c] + a.eps) : a.in_isd[c];
+      prm[2][c] = a.gamma[c]; prm[3][c] = a.beta[c];
+    }
+  }
+  __syncthreads();
+  // pooled features: thread = (pixel group, channel); the groups' partial sums meet in LDS in group order
+  const int groups = 256 / C > 0 ? 256 / C : 1;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + tid % (groups > 1 ? C : 256), grp = groups > 1 ? tid / C : 0;
+    float s = 0.f;
+    if (c < C && grp < groups) {
+      const float mu = prm[0][c], is = prm[1][c], g = prm[2][c], bt = prm[3][c];
+      const float* xb = a.x + (size_t)b * a.HW2 * C + c;
+      int p = grp;
+      for (; p + 7 * groups < a.HW2; p += 8 * groups) {        // 8 loads in flight (a dependent chain of 32 round trips otherwise)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xb[(size_t)(p + u * groups) * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float yv = g * ((v[u] - mu) * is) + bt;                                     // bn_apply_kernel's arithmetic
+          s += yv > 0.f ? yv : a.slope * yv;
+        }
+      }
+      for (; p < a.HW2; p += groups) {
+        const float yv = g * ((xb[(size_t)p * C] - mu) * is) + bt;
+        s += yv > 0.f ? yv : a.slope * yv;
+      }
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      float t = 0.f;
+      for (int q = 0; q < groups; ++q) t += part[q * C + (groups > 1 ? c : tid)];
+      t /= a.HW2;
+      ft[c] = t;
+      a.feat[(size_t)b * C + c] = t;
+    }
+    __syncthreads();
+  }
+  // classifier: one wave per output, lanes along the features (fc_fwd_kernel's order of the sums)
+  for (int k = wave; k < a.K; k += 4) {
+    float s = 0.f;
+    for (int f = lane; f < C; f += 64) s += ft[f] * a.Wc[(size_t)k * C + f];
+    s = wave_sum(s);
+    if (lane == 0) a.logits[(size_t)b * a.K + k] = s + a.bc[k];
+  }
+}
+
 }  // namespace
+
+extern "C" int srhip_wrn_head(const float* x, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* gamma,
+                              const float* beta, float eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
+                              float* running_var, float momentum, int update_running, const float* Wc, const float* bc, float* feat,
+                              float* logits, int B, int HW2, int C, int K, int stat_ranks, void* stream) {
+  if (!x || !gamma || !beta || !Wc || !bc || !feat || !logits || B <= 0 || HW2 <= 0 || C <= 0 || C > 256 || K <= 0) return SR_EINVAL;
+  if (in_mode != 0 && in_mode != 1 && in_mode != 3) return SR_EINVAL;
+  if (in_mode == 3 ? !in_acc : (!in_mean || !in_isd)) return SR_EINVAL;
+  if (pub_mean && (in_mode != 3 || !pub_invstd || (update_running && (!running_mean || !running_var)))) return SR_EINVAL;
+  HeadArgs a;
+  a.x = x; a.in_mean = in_mean; a.in_isd = in_isd; a.in_acc = in_acc; a.gamma = gamma; a.beta = beta; a.eps = eps; a.slope = slope;
+  a.in_mode = in_mode;
+  a.pub.out_mean = pub_mean; a.pub.out_invstd = pub_invstd; a.pub.running_mean = running_mean; a.pub.running_var = running_var;
+  a.pub.momentum = momentum; a.pub.update_running = update_running; a.pub.eps = eps;
+  a.Wc = Wc; a.bc = bc; a.feat = feat; a.logits = logits; a.HW2 = HW2; a.C = C; a.K = K;
+  a.in_rows = B * HW2 * (stat_ranks > 1 ? stat_ranks : 1);
+  hipLaunchKernelGGL(wrn_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
 
 extern "C" int srhip_wrn_conv_supported(int Cin, int Cout, int ksize) {
   return (ksize == 1 || ksize == 3) && Cin >= 8 && Cin <= 128 && (Cin & (Cin - 1)) == 0 && Cout <= 256 &&

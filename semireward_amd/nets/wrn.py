@@ -65,7 +65,11 @@ class WideResNet:
         for nme, c, _ in self.bn:
             self.buffers[nme + ".running_mean"] = torch.zeros(c, dtype=f32, device=self.device)
             self.buffers[nme + ".running_var"] = torch.ones(c, dtype=f32, device=self.device)
-            self.buffers[nme + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=self.device)
+            self.buffers[nme + ".num_batches_tracked"] = None         # (views of one int64 block, below)
+        # every BatchNorm is visited exactly once by a forward, so the 25 counters move together: one block, one add per updating forward
+        self._nbt = torch.zeros(len(self.bn), dtype=torch.int64, device=self.device)
+        for i, (nme, _, _) in enumerate(self.bn):
+            self.buffers[nme + ".num_batches_tracked"] = self._nbt[i]
         self.eps = {nme: e for nme, _, e in self.bn}
         # bf16 GEMM operands of every convolution: W [Cout, Kpad] and W^T [Kpad, Cout]
         self.convs = {}
@@ -222,8 +226,6 @@ class WideResNet:
         ops.wrn_conv_bn(xin, mode, stats, acc, g, bt, eps, SLOPE, c["Wb"], resid, out, B, H, W, c["cin"], c["cout"], c["k"], stride, c["Kp"],
                         publish=pub, running=(self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]) if pub else None,
                         momentum=MOMENTUM, update_running=update, acc_out=acc_out, stat_ranks=self.stat_ranks)
-        if pub is not None and update:
-            self.buffers[in_bn + ".num_batches_tracked"] += 1
         if acc_out is not None:
             self._sync_acc(next_bn)
         return st
@@ -277,23 +279,21 @@ class WideResNet:
             out, h, w = y, ho, wo
         rows = B * h * w
         C3 = self.channels[3]
-        # final BatchNorm + LeakyReLU (fp32 for the pooling): fold the sums the last convolution left, then apply
-        af = self._buf((tag, "bn1", "actf"), (rows, C3), f32)
-        if train:
-            stf = self._stats_bufs("bn1", C3, tag)
-            ops.bn_fold(self.bn_acc["bn1"], rows * self.stat_ranks, self.eps["bn1"], MOMENTUM, upd, self.buffers["bn1.running_mean"],
-                        self.buffers["bn1.running_var"], stf[0], stf[1], None, C3)
-            if upd:
-                self.buffers["bn1.num_batches_tracked"] += 1
-            ops.bn_act(out, stf, self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE, 0, None, rows, C3, act_f32=af)
-        else:
-            stf = None
-            ops.bn_act(out, (self.buffers["bn1.running_mean"], self.buffers["bn1.running_var"]), self.p("bn1.weight"), self.p("bn1.bias"),
-                       self.eps["bn1"], SLOPE, 1, None, rows, C3, act_f32=af)
+        # final BatchNorm + LeakyReLU + average pooling + classifier: one launch (it folds the sums the last convolution left and publishes)
         feat = torch.empty(B, C3, dtype=f32, device=self.device)
         logits = torch.empty(B, self.num_classes, dtype=f32, device=self.device)
-        ops.avgpool_fwd(af, feat, B, h * w, C3)
-        ops.fc_fwd(feat, self.p("classifier.weight"), self.p("classifier.bias"), logits, B, C3, self.num_classes)
+        run = (self.buffers["bn1.running_mean"], self.buffers["bn1.running_var"])
+        if train:
+            stf = self._stats_bufs("bn1", C3, tag)
+            ops.wrn_head(out, 3, None, self.bn_acc["bn1"], self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE,
+                         self.p("classifier.weight"), self.p("classifier.bias"), feat, logits, B, h * w, C3, self.num_classes, publish=stf,
+                         running=run, momentum=MOMENTUM, update_running=upd, stat_ranks=self.stat_ranks)
+            if upd:
+                self._nbt += 1                                  # num_batches_tracked of all BatchNorms (each was visited once)
+        else:
+            stf = None
+            ops.wrn_head(out, 1, run, None, self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE, self.p("classifier.weight"),
+                         self.p("classifier.bias"), feat, logits, B, h * w, C3, self.num_classes)
         if save:
             ctx.final, ctx.feat = dict(x=out, st=stf, h=h, w=w), feat
         return logits, feat, ctx

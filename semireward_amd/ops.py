@@ -713,6 +713,15 @@ def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope
                               4.0 * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad))
 
 
+def wrn_head(x, in_mode, in_stats, in_acc, gamma, beta, eps, slope, Wc, bc, feat, logits, B, HW2, C, K, publish=None, running=None,
+             momentum=0.0, update_running=False, stat_ranks=1):
+    im, ii = in_stats if in_stats is not None else (None, None)
+    pm, pi = publish if publish is not None else (None, None)
+    rm, rv = running if running is not None else (None, None)
+    _call("srhip_wrn_head", _p(x), in_mode, _p(im), _p(ii), _p(in_acc), _p(gamma), _p(beta), eps, slope, _p(pm), _p(pi), _p(rm), _p(rv), momentum,
+          int(update_running), _p(Wc), _p(bc), _p(feat), _p(logits), B, HW2, C, K, stat_ranks, _s())
+
+
 def bn_stats(x, eps, momentum, update_running, running_mean, running_var, out_mean, out_invstd, ws, rows, C):
     _call("srhip_bn_stats", _p(x), eps, momentum, int(update_running), _p(running_mean), _p(running_var), _p(out_mean), _p(out_invstd), _p(ws),
           rows, C, _s())
