@@ -469,10 +469,21 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
 // Waves: 4 (m) x 2 (n); wave tile 64 x (16*NTW); NTW = 4 -> BN = 128, NTW = 8 -> BN = 256.
 constexpr int GBM = 256;
 
+// tile index -> (row tile, column tile) in bands of GROUP_M row tiles walked column-major: the 32 consecutive indices an XCD works on at a
+// time (xcd_remap) are then 8 x 4 tiles -- 8 A panels + 4 B panels per k step from HBM / MALL instead of 1 + 32 for a row of tiles
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_mn(int t, int ntm, int ntn, int& tm, int& tn) {
+  const int band = t / (GROUP_M * ntn), r = t - band * GROUP_M * ntn;
+  const int rows = min(GROUP_M, ntm - band * GROUP_M);
+  tm = band * GROUP_M + r % rows;
+  tn = r / rows;
+}
+
 // WN = waves along n (2: 8 waves, one workgroup per CU; 1: 4 waves with wave tile 64 x (16*NTW), TWO workgroups per CU whose
 // K-loop and epilogue phases drift apart and overlap).
 template <int EPI, int NTW, int WN>
 __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
+  const bool g_grouped = (g.debug & 64) == 0;          // SRHIP_DEBUG=64: row-major tile walk (tuning)
   constexpr int NWV = 4 * WN;                        // waves per workgroup (4 along m)
   constexpr int GBN = 16 * NTW * WN;
   constexpr int A_EL = GBM * BK, B_EL = GBN * BK, STG = A_EL + B_EL;
@@ -503,7 +514,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
   const bf16_t* pa[AI];
   const bf16_t* pb[BI];
   auto set_tile = [&](int t) {
-    const int m0 = (t / ntn) * GBM, n0 = (t % ntn) * GBN;
+    int tm_, tn_;
+    if (g_grouped) tile_mn(t, ntm, ntn, tm_, tn_); else { tm_ = t / ntn; tn_ = t % ntn; }
+    const int m0 = tm_ * GBM, n0 = tn_ * GBN;
 #pragma unroll
     for (int i = 0; i < AI; ++i) pa[i] = g.A + (size_t)min(m0 + ra[i], g.M - 1) * g.lda + sa[i];
 #pragma unroll
@@ -557,7 +570,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]),
                                                             acc[i][j], 0, 0, 0);
     if (++ck == nk) {
-      const int m0 = (ct / ntn) * GBM, n0 = (ct % ntn) * GBN;
+      int tm_, tn_;
+      if (g_grouped) tile_mn(ct, ntm, ntn, tm_, tn_); else { tm_ = ct / ntn; tn_ = ct % ntn; }
+      const int m0 = tm_ * GBM, n0 = tn_ * GBN;
       if ((EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16) && g.wide_store &&
           n0 + GBN <= g.N) {                      // (wave-uniform: full column tiles only; the ragged last one takes the plain path)
         bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
