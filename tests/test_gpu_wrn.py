@@ -461,3 +461,50 @@ def test_fused_conv_equals_the_unfused_chain(B, H, Cin, Cout, ks, stride, mode, 
     act2 = torch.empty_like(act)
     ops.bn_act(x, stats, gam if mode != 2 else None, bet if mode != 2 else None, 1e-5, 0.1, mode, act2, rows_in, Cin)
     assert torch.equal(act2.view(torch.int16), act.view(torch.int16))
+
+
+@pytest.mark.parametrize("B,HW2,C,K", [(64, 64, 128, 100), (5, 16, 64, 10), (3, 4, 256, 7), (2, 9, 32, 3)])
+def test_network_tail_in_one_launch(B, HW2, C, K):
+    """srhip_wrn_head (final BatchNorm + LeakyReLU + average pooling + classifier, statistics folded from the accumulator srhip_bn_accumulate
+    filled) against torch: batch statistics with the running update, then eval mode from the running statistics; srhip_bn_fold agrees with
+    srhip_bn_stats on the same tensor."""
+    import torch.nn.functional as F
+    rng = np.random.Generator(np.random.PCG64(B * 7 + C))
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(DEV).contiguous()   # noqa: E731
+    rows = B * HW2
+    x = T(rng.standard_normal((rows, C)) * 1.5 + 0.4)
+    gam, bet = T(1.0 + 0.1 * rng.standard_normal(C)), T(0.1 * rng.standard_normal(C))
+    rm0, rv0 = T(0.1 * rng.standard_normal(C)), T(1.0 + 0.2 * rng.random(C))
+    Wc, bc = T(rng.standard_normal((K, C)) / np.sqrt(C)), T(0.1 * rng.standard_normal(K))
+    # torch: [B, C, HW2] layout for batch_norm
+    xt = x.view(B, HW2, C).permute(0, 2, 1).contiguous()
+    rm, rv = rm0.clone(), rv0.clone()
+    yt = F.leaky_relu(F.batch_norm(xt, rm, rv, gam, bet, True, 0.001, 1e-3), 0.1)
+    feat_want = yt.mean(dim=2)
+    logits_want = feat_want @ Wc.t() + bc
+    acc = torch.zeros(ops.bn_acc_doubles(C), dtype=torch.float64, device=DEV)
+    ops.bn_accumulate(x, acc, rows, C)
+    feat, logits = torch.empty(B, C, device=DEV), torch.empty(B, K, device=DEV)
+    pm, pi = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rmd, rvd = rm0.clone(), rv0.clone()
+    ops.wrn_head(x, 3, None, acc, gam, bet, 1e-3, 0.1, Wc, bc, feat, logits, B, HW2, C, K, publish=(pm, pi), running=(rmd, rvd), momentum=0.001,
+                 update_running=True)
+    torch.cuda.synchronize()
+    assert rel(feat.cpu(), feat_want.cpu().numpy()) < 3e-6 and rel(logits.cpu(), logits_want.cpu().numpy()) < 5e-6
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # the published statistics == srhip_bn_fold == srhip_bn_stats of the same tensor
+    fm, fi = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    tot = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    ops.bn_fold(acc, rows, 1e-3, 0.0, False, None, None, fm, fi, tot, C)
+    ws = torch.zeros(ops.bn_ws_doubles(), dtype=torch.float64, device=DEV)
+    sm, si = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_stats(x, 1e-3, 0.0, False, None, None, sm, si, ws, rows, C)
+    assert torch.equal(fm, pm) and torch.equal(fi, pi)
+    np.testing.assert_allclose(fm.cpu().numpy(), sm.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(fi.cpu().numpy(), si.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(tot[:C].cpu().numpy(), x.double().sum(0).cpu().numpy(), rtol=1e-12)
+    # eval mode: running statistics
+    ye = F.leaky_relu(F.batch_norm(xt, rm, rv, gam, bet, False, 0.001, 1e-3), 0.1).mean(dim=2)
+    ops.wrn_head(x, 1, (rmd, rvd), None, gam, bet, 1e-3, 0.1, Wc, bc, feat, logits, B, HW2, C, K)
+    assert rel(feat.cpu(), ye.cpu().numpy()) < 3e-6 and rel(logits.cpu(), (ye @ Wc.t() + bc).cpu().numpy()) < 5e-6
