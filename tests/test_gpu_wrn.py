@@ -508,3 +508,33 @@ def test_network_tail_in_one_launch(B, HW2, C, K):
     ye = F.leaky_relu(F.batch_norm(xt, rm, rv, gam, bet, False, 0.001, 1e-3), 0.1).mean(dim=2)
     ops.wrn_head(x, 1, (rmd, rvd), None, gam, bet, 1e-3, 0.1, Wc, bc, feat, logits, B, HW2, C, K)
     assert rel(feat.cpu(), ye.cpu().numpy()) < 3e-6 and rel(logits.cpu(), (ye @ Wc.t() + bc).cpu().numpy()) < 5e-6
+
+
+def test_grouped_filter_prep_and_unpad_equal_the_single_launches():
+    """srhip_conv_weight_prep_grouped / srhip_add_unpad_grouped (every convolution of a network in one launch) against one
+    srhip_conv_weight_prep / srhip_add_unpad per convolution: bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    shapes = [(16, 3, 3), (32, 16, 3), (32, 16, 1), (64, 32, 3), (128, 128, 3)]
+    Wf, single, grouped, pads, g1, g2 = [], [], [], [], [], []
+    for Cout, C, ks in shapes:
+        K, Kp = C * ks * ks, (C * ks * ks + 31) // 32 * 32
+        w = torch.from_numpy(rng.standard_normal(Cout * K).astype(np.float32)).to(DEV)
+        Wf.append(w)
+        single.append((torch.zeros(Cout, Kp, dtype=torch.bfloat16, device=DEV), torch.zeros(Kp, Cout, dtype=torch.bfloat16, device=DEV)))
+        grouped.append((torch.full((Cout, Kp), 3.0, dtype=torch.bfloat16, device=DEV), torch.full((Kp, Cout), 3.0, dtype=torch.bfloat16, device=DEV)))
+        pads.append(torch.from_numpy(rng.standard_normal((Cout, Kp)).astype(np.float32)).to(DEV))
+        g0 = torch.from_numpy(rng.standard_normal(Cout * K).astype(np.float32)).to(DEV)
+        g1.append(g0.clone()); g2.append(g0.clone())
+    for (Cout, C, ks), w, (a, b), p_, g in zip(shapes, Wf, single, pads, g1):
+        Kp = a.shape[1]
+        ops.conv_weight_prep(w, a, b, Cout, C, ks, Kp)
+        ops.add_unpad(p_, g, Cout, C, ks, Kp)
+    d = ops.make_conv_desc([(w, a, b, Cout, C, ks, a.shape[1]) for (Cout, C, ks), w, (a, b) in zip(shapes, Wf, grouped)], DEV,
+                           lambda Cout, C, kk, Kpad: Cout * Kpad)
+    ops.conv_weight_prep_grouped(*d)
+    d2 = ops.make_conv_desc([(p_, g, None, Cout, C, ks, p_.shape[1]) for (Cout, C, ks), p_, g in zip(shapes, pads, g2)], DEV,
+                            lambda Cout, C, kk, Kpad: Cout * C * kk)
+    ops.add_unpad_grouped(*d2)
+    torch.cuda.synchronize()
+    for (a, b), (c, e), x, y in zip(single, grouped, g1, g2):
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16)) and torch.equal(b.view(torch.int16), e.view(torch.int16)) and torch.equal(x, y)
