@@ -505,6 +505,10 @@ typedef struct srhip_conv_desc {
 } srhip_conv_desc;                       /* 48 bytes */
 int srhip_conv_weight_prep_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream);
 int srhip_add_unpad_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream);
+/* conv_weight_flip_grouped : the filters of the INPUT-gradient convolutions (stride-1 3x3 layers): dX = srhip_wrn_conv_bn(dY, raw mode, W') with
+ * W' bf16 [Cin, Kpad], W'[ci][(8 - t) * Cout + co] = W[co][ci][t] -- the adjoint as one more implicit-GEMM launch instead of GEMM + col2im.
+ * Entry: a = W fp32 [Cout, C, 3, 3], b = W', kk = 9, Kpad = round32(9 * Cout); Cin * Kpad elements per entry. */
+int srhip_conv_weight_flip_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream);
 long long srhip_bn_ws_doubles(void);
 /* The same BasicBlock as ONE launch per convolution (csrc/wrn_conv.hip; wrn.py:41-60):
  *   wrn_conv_bn : y fp32 [B*Ho*Wo, Cout] = conv_{k,stride,pad k/2}( f(xin) ) (+ resid), xin fp32 NHWC [B,H,W,Cin] read in place (implicit GEMM);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "srhip_add_unpad": (I, [P, P, I, I, I, I, P]),
     "srhip_conv_weight_prep_grouped": (I, [P, I, c_longlong, P]),
     "srhip_add_unpad_grouped": (I, [P, I, c_longlong, P]),
+    "srhip_conv_weight_flip_grouped": (I, [P, I, c_longlong, P]),
     "srhip_bn_ws_doubles": (ctypes.c_longlong, []),
     "srhip_wrn_conv_supported": (I, [I, I, I]),
     "srhip_bn_acc_doubles": (ctypes.c_longlong, [I]),

@@ -124,6 +124,22 @@ __global__ __launch_bounds__(256) void conv_weight_prep_grouped_kernel(const srh
   ((bf16_t*)e.b)[j] = v;
   ((bf16_t*)e.c)[(size_t)k * e.Cout + o] = v;
 }
+// The filter of the INPUT-gradient convolution of a stride-1 3x3 layer: dX = conv(dY, W') with W'[ci][(8 - t) * Cout + co] = W[co][ci][t]
+// (taps rotated by 180 degrees, channels swapped), bf16, K axis padded to Kpad = round32(9 * Cout); e.C = Cin, e.Cout = Cout, e.kk = 9.
+__global__ __launch_bounds__(256) void conv_weight_flip_grouped_kernel(const srhip_conv_desc* __restrict__ d, int n, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= d[mid].start) lo = mid; else hi = mid - 1; }
+  const srhip_conv_desc e = d[lo];
+  const int j = (int)(i - e.start), ci = j / e.Kpad, k = j % e.Kpad, K = e.Cout * e.kk;
+  bf16_t v = 0;
+  if (k < K) {
+    const int tf = k / e.Cout, co = k % e.Cout, t = e.kk - 1 - tf;
+    v = f2bf(((const float*)e.a)[((size_t)co * e.C + ci) * e.kk + t]);
+  }
+  ((bf16_t*)e.b)[j] = v;
+}
 __global__ __launch_bounds__(256) void add_unpad_grouped_kernel(const srhip_conv_desc* __restrict__ d, int n, long long total) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -424,6 +440,12 @@ extern "C" int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int 
 extern "C" int srhip_conv_weight_prep_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream) {
   if (!desc_dev || n <= 0 || total <= 0) return SR_EINVAL;
   LAUNCH1D(conv_weight_prep_grouped_kernel, total, desc_dev, n, total);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+extern "C" int srhip_conv_weight_flip_grouped(const srhip_conv_desc* desc_dev, int n, long long total, void* stream) {
+  if (!desc_dev || n <= 0 || total <= 0) return SR_EINVAL;
+  LAUNCH1D(conv_weight_flip_grouped_kernel, total, desc_dev, n, total);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

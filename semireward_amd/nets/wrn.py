@@ -17,6 +17,7 @@ import torch
 from .. import ops
 
 MOMENTUM, SLOPE = 0.001, 0.1
+_FUSED_DX = __import__("os").environ.get("SR_WRN_FUSED_DX", "1") != "0"      # tuning switch: input gradients of stride-1 3x3 layers as convolutions
 
 
 def _round_up(a, b):
@@ -91,6 +92,10 @@ class WideResNet:
         self.bn_acc_arena = torch.zeros(o, dtype=torch.float64, device=self.device)
         self.bn_acc = {nme: self.bn_acc_arena[a:a + n] for nme, (a, n) in offs.items()}
         self._prep_desc = None
+        self._flip_desc = None
+        self.conv_stride = {"conv1.weight": 1}
+        for p_, _, _, st_, _ in self.blocks:
+            self.conv_stride.update({p_ + "conv1.weight": st_, p_ + "conv2.weight": 1, p_ + "convShortcut.weight": st_})
         self.training = True
         self.couples_batch_rows = True      # BatchNorm: every forward call is its own statistics group (no cross-pass batching)
         self._buf_cache = {}
@@ -150,6 +155,16 @@ class WideResNet:
             self._prep_desc = ops.make_conv_desc([(self.p(n), c["Wb"], c["WbT"], c["cout"], c["cin"], c["k"], c["Kp"]) for n, c in self.convs.items()],
                                                  self.device, lambda Cout, C, kk, Kpad: Cout * Kpad)
         ops.conv_weight_prep_grouped(*self._prep_desc)
+        if self._flip_desc is None:        # stride-1 3x3 layers: the input gradient is one more implicit-GEMM convolution (filter rotated / transposed)
+            ent = []
+            for n, c in self.convs.items():
+                if c["k"] == 3 and self.conv_stride.get(n, 1) == 1 and ops.wrn_conv_supported(c["cout"], c["cin"], 3):
+                    c["Kp2"] = _round_up(9 * c["cout"], 32)
+                    c["Wfl"] = torch.zeros(c["cin"], c["Kp2"], dtype=torch.bfloat16, device=self.device)
+                    ent.append((self.p(n), c["Wfl"], None, c["cout"], c["cin"], 3, c["Kp2"]))
+            self._flip_desc = ops.make_conv_desc(ent, self.device, lambda Cout, C, kk, Kpad: C * Kpad) if ent else ()
+        if self._flip_desc:
+            ops.conv_weight_flip_grouped(*self._flip_desc)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -394,6 +409,12 @@ class WideResNet:
             problems.append((dyb, col, dst, G("conv1.bias") if name == "conv1.weight" else None, c["cout"], c["Kp"], rows_out))
             if not need_dx:
                 return None
+            if "Wfl" in c and stride == 1 and not accumulate and _FUSED_DX:
+                # dX = conv(dY, W'): the adjoint of a stride-1 3x3 convolution is one implicit-GEMM launch (raw fp32 dY in, bf16 on load)
+                if din is None:
+                    din = self._buf((tag, name, "din"), (B * Hin * Win, c["cin"]), f32)
+                ops.wrn_conv_bn(dy, 2, None, None, None, None, 0.0, SLOPE, c["Wfl"], None, din, B, Hin, Win, c["cout"], c["cin"], 3, 1, c["Kp2"])
+                return din
             dcol = self._buf((tag, name, "dcol"), (rows_out, c["Kp"]), f32)
             ops.gemm_nt(ops.EPI_F32, dyb, c["WbT"], dcol, rows_out, c["Kp"], c["cout"])
             if din is None:

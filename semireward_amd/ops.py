@@ -669,6 +669,10 @@ def conv_weight_prep_grouped(desc, n, total):
     _call("srhip_conv_weight_prep_grouped", _p(desc), n, total, _s())
 
 
+def conv_weight_flip_grouped(desc, n, total):
+    _call("srhip_conv_weight_flip_grouped", _p(desc), n, total, _s())
+
+
 def add_unpad_grouped(desc, n, total):
     _call("srhip_add_unpad_grouped", _p(desc), n, total, _s())
 
