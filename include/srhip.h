@@ -493,6 +493,10 @@ int srhip_augment(const unsigned char* src, int n_src, int H0, int W0, int B, in
  *                       {int64 end, float weight_decay, float pad} per parameter; optional EMA shadow; first_step: buf = d. */
 int srhip_nchw_to_nhwc_bf16(const float* img, void* out, int B, int C, int H, int W, void* stream);
 int srhip_im2col(const void* act, void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream);
+/* im2col_bn : col = im2col(bf16(f(x))) from the fp32 tensor in front of the BatchNorm, f = LeakyReLU(BatchNorm(x; mean, invstd)) (mode 0) or
+ * identity (mode 2) -- the filter-gradient operand of the backward without a materialised activation.  C % 8 == 0, C <= 256. */
+int srhip_im2col_bn(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int mode,
+                    void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream);
 int srhip_col2im(const float* dcol, float* dact, int B, int H, int W, int C, int ksize, int stride, int Kpad, int accumulate, void* stream);
 int srhip_conv_weight_prep(const float* Wf, void* Wb, void* WbT, int Cout, int C, int ksize, int Kpad, void* stream);
 int srhip_add_unpad(const float* src, float* dst, int Cout, int C, int ksize, int Kpad, void* stream);

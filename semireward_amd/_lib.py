@@ -93,6 +93,7 @@ SIGNATURES = {
     "srhip_clip_grad_coef": (I, [P, L, F, F, P, P, P]),
     "srhip_nchw_to_nhwc_bf16": (I, [P, P, I, I, I, I, P]),
     "srhip_im2col": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "srhip_im2col_bn": (I, [P, P, P, P, P, F, I, P, I, I, I, I, I, I, I, P]),
     "srhip_col2im": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "srhip_conv_weight_prep": (I, [P, P, P, I, I, I, I, P]),
     "srhip_add_unpad": (I, [P, P, I, I, I, I, P]),

@@ -49,6 +49,44 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// The same col straight from the fp32 tensor in FRONT of the BatchNorm: col = im2col(bf16(LeakyReLU(BN(x)))) (mode 0: mean / invstd; mode 2:
+// bf16(x)), bn_apply_kernel's arithmetic per element -- the backward's filter-gradient operand without materialising the activation first
+// (a bn_act launch + 12 MB per convolution).  C % 8 == 0, C <= 256.
+__global__ __launch_bounds__(256) void im2col_bn_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ isd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float slope, int mode,
+                                                       bf16_t* __restrict__ col, int H, int W, int C, int ks, int stride, int Ho, int Wo,
+                                                       int Kpad, size_t total) {
+  __shared__ float prm[4][256];
+  if (mode != 2) {
+    for (int c = threadIdx.x; c < C; c += 256) { prm[0][c] = mean[c]; prm[1][c] = isd[c]; prm[2][c] = gamma[c]; prm[3][c] = beta[c]; }
+    __syncthreads();
+  }
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over rows * (Kpad / 8)
+  if (idx >= total) return;
+  const int kv = Kpad / 8;
+  const size_t row = idx / kv;
+  const int k = (int)(idx % kv) * 8, K = C * ks * ks, pad = ks >> 1;
+  const int b = (int)(row / (Ho * Wo)), r = (int)(row % (Ho * Wo)), yo = r / Wo, xo = r % Wo;
+  u32x4_t o = {0u, 0u, 0u, 0u};
+  if (k < K) {
+    const int t = k / C, c = k % C, y = yo * stride + t / ks - pad, xx = xo * stride + t % ks - pad;
+    if (y >= 0 && y < H && xx >= 0 && xx < W) {
+      const float4* p = reinterpret_cast<const float4*>(x + (((size_t)b * H + y) * W + xx) * C + c);
+      const float4 v0 = p[0], v1 = p[1];
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (mode != 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yv = prm[2][c + e] * ((v[e] - prm[0][c + e]) * prm[1][c + e]) + prm[3][c + e];
+          v[e] = yv > 0.f ? yv : slope * yv;
+        }
+      }
+      o = u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    }
+  }
+  *reinterpret_cast<u32x4_t*>(col + row * Kpad + k) = o;
+}
+
 // dact[b][y][x][c] (=|+=) sum over the (<= k*k) output positions that read this input pixel of dcol[(b,yo,xo)][(i*k + j) * C + c];
 // a thread owns V channels of one input pixel (V = 4: 16-byte loads of dcol, consecutive threads consecutive channels)
 template <int V>
@@ -408,6 +446,20 @@ extern "C" int srhip_im2col(const void* act, void* col, int B, int H, int W, int
     hipLaunchKernelGGL(im2col_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
                        ksize, stride, Ho, Wo, Kpad, total);
   }
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int srhip_im2col_bn(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                               int mode, void* col, int B, int H, int W, int C, int ksize, int stride, int Kpad, void* stream) {
+  if (!x || !col || B <= 0 || (ksize != 1 && ksize != 3) || stride <= 0 || Kpad < C * ksize * ksize || (Kpad % 32) || (C % 8) || C > 256 ||
+      (mode != 0 && mode != 2))
+    return SR_EINVAL;
+  if (mode == 0 && (!mean || !invstd || !gamma || !beta)) return SR_EINVAL;
+  const int pad = ksize >> 1, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  const size_t total = (size_t)B * Ho * Wo * (Kpad / 8);
+  hipLaunchKernelGGL(im2col_bn_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, slope, mode,
+                     (bf16_t*)col, H, W, C, ksize, stride, Ho, Wo, Kpad, total);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -448,30 +448,27 @@ class WideResNet:
 
         bn_bwd(dact, fin["x"], fin["st"], "bn1", None, dy, rows, C3)
 
-        def col_of(name, src, bn, st, raw, rows_src, Hs, Ws, stride, act=None):
-            """The im2col operand of a convolution's filter gradient, recomputed from what the forward kept (its fp32 input and the statistics
-            of the BatchNorm in front of it) instead of stored by every forward: act bf16 = LeakyReLU(BN(src)) (or src), then im2col."""
+        def col_of(name, src, bn, st, raw, rows_src, Hs, Ws, stride):
+            """The im2col operand of a convolution's filter gradient, recomputed from what the forward kept (its fp32 input and the statistics of
+            the BatchNorm in front of it) instead of stored by every forward: one launch, BatchNorm + LeakyReLU applied on load."""
             c = self.convs[name]
-            if act is None:
-                act = self._buf((tag, bn, "act.bwd"), (rows_src, c["cin"]), bf16)
-                if raw:
-                    ops.bn_act(src, None, None, None, 0.0, SLOPE, 2, act, rows_src, c["cin"])
-                else:
-                    ops.bn_act(src, st, P(bn + ".weight"), P(bn + ".bias"), self.eps[bn], SLOPE, 0, act, rows_src, c["cin"])
             k, pad = c["k"], c["k"] // 2
             Ho, Wo = (Hs + 2 * pad - k) // stride + 1, (Ws + 2 * pad - k) // stride + 1
             col = self._buf((tag, name, "col"), (B * Ho * Wo, c["Kp"]), bf16)
-            ops.im2col(act, col, B, Hs, Ws, c["cin"], k, stride, c["Kp"])
-            return col, act
+            if raw:
+                ops.im2col_bn(src, None, None, None, SLOPE, 2, col, B, Hs, Ws, c["cin"], k, stride, c["Kp"])
+            else:
+                ops.im2col_bn(src, st, P(bn + ".weight"), P(bn + ".bias"), SLOPE, 0, col, B, Hs, Ws, c["cin"], k, stride, c["Kp"])
+            return col
 
         for (p, cin, cout, stride, abr), r in zip(reversed(self.blocks), reversed(ctx.blocks)):
             equal = cin == cout
             rows_out, rows_in = B * r["ho"] * r["wo"], B * r["h"] * r["w"]
-            col2, _ = col_of(p + "conv2.weight", r["c1"], p + "bn2", r["st2"], False, rows_out, r["ho"], r["wo"], 1)
-            col1, act1 = col_of(p + "conv1.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride)
+            col2 = col_of(p + "conv2.weight", r["c1"], p + "bn2", r["st2"], False, rows_out, r["ho"], r["wo"], 1)
+            col1 = col_of(p + "conv1.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride)
             r = dict(r, col2=col2, col1=col1)
             if not equal:
-                r["colS"], _ = col_of(p + "convShortcut.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride, act=act1)
+                r["colS"] = col_of(p + "convShortcut.weight", r["x"], p + "bn1", r["st1"], r["raw"], rows_in, r["h"], r["w"], stride)
             do2 = conv_bwd(p + "conv2.weight", dy, rows_out, r["col2"], True, r["ho"], r["wo"], 1)
             dc1 = self._buf((tag, p, "dc1"), (rows_out, cout), f32)
             bn_bwd(do2, r["c1"], r["st2"], p + "bn2", None, dc1, rows_out, cout)

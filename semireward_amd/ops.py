@@ -641,6 +641,11 @@ def im2col(act, col, B, H, W, C, ksize, stride, Kpad):
     _call("srhip_im2col", _p(act), _p(col), B, H, W, C, ksize, stride, Kpad, _s())
 
 
+def im2col_bn(x, stats, gamma, beta, slope, mode, col, B, H, W, C, ksize, stride, Kpad):
+    m, i = stats if stats is not None else (None, None)
+    _call("srhip_im2col_bn", _p(x), _p(m), _p(i), _p(gamma), _p(beta), slope, mode, _p(col), B, H, W, C, ksize, stride, Kpad, _s())
+
+
 def col2im(dcol, dact, B, H, W, C, ksize, stride, Kpad, accumulate=False):
     _call("srhip_col2im", _p(dcol), _p(dact), B, H, W, C, ksize, stride, Kpad, int(accumulate), _s())
 

@@ -538,3 +538,27 @@ def test_grouped_filter_prep_and_unpad_equal_the_single_launches():
     torch.cuda.synchronize()
     for (a, b), (c, e), x, y in zip(single, grouped, g1, g2):
         assert torch.equal(a.view(torch.int16), c.view(torch.int16)) and torch.equal(b.view(torch.int16), e.view(torch.int16)) and torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,H,C,ks,stride,mode", [(3, 8, 32, 3, 1, 0), (2, 8, 16, 3, 2, 0), (2, 8, 64, 1, 2, 2), (4, 4, 128, 3, 1, 2), (64, 32, 32, 3, 1, 0)])
+def test_im2col_with_batchnorm_on_load_equals_act_then_im2col(B, H, C, ks, stride, mode):
+    """srhip_im2col_bn (the backward's filter-gradient operand straight from the fp32 tensor in front of the BatchNorm) == srhip_bn_act followed
+    by srhip_im2col, bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(B + C + ks))
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(DEV).contiguous()   # noqa: E731
+    rows = B * H * H
+    x = T(rng.standard_normal((rows, C)) * 1.4 + 0.1)
+    gam, bet = T(1.0 + 0.1 * rng.standard_normal(C)), T(0.1 * rng.standard_normal(C))
+    mean, isd = T(0.1 * rng.standard_normal(C)), T(1.0 + 0.2 * rng.random(C))
+    Kp = (C * ks * ks + 31) // 32 * 32
+    pad = ks // 2
+    Ho = (H + 2 * pad - ks) // stride + 1
+    act = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    st = (mean, isd) if mode == 0 else None
+    ops.bn_act(x, st, gam if mode == 0 else None, bet if mode == 0 else None, 1e-5, 0.1, mode, act, rows, C)
+    want = torch.empty(B * Ho * Ho, Kp, dtype=torch.bfloat16, device=DEV)
+    ops.im2col(act, want, B, H, H, C, ks, stride, Kp)
+    got = torch.full((B * Ho * Ho, Kp), 5.0, dtype=torch.bfloat16, device=DEV)
+    ops.im2col_bn(x, st, gam if mode == 0 else None, bet if mode == 0 else None, 0.1, mode, got, B, H, H, C, ks, stride, Kp)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
