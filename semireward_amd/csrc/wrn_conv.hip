@@ -339,12 +339,28 @@ __global__ __launch_bounds__(256) void wrn_head_kernel(const HeadArgs a) {
     }
     __syncthreads();
   }
-  // classifier: one wave per output, lanes along the features (fc_fwd_kernel's order of the sums)
-  for (int k = wave; k < a.K; k += 4) {
-    float s = 0.f;
-    for (int f = lane; f < C; f += 64) s += ft[f] * a.Wc[(size_t)k * C + f];
-    s = wave_sum(s);
-    if (lane == 0) a.logits[(size_t)b * a.K + k] = s + a.bc[k];
+  // classifier: one wave per output, lanes along the features (fc_fwd_kernel's order of the sums); the filter rows of 8 outputs are requested
+  // before the first is used (a dependent L2 round trip per output otherwise: 25 of them per wave)
+  const int nf = (C + 63) / 64;                     // features per lane (<= 4)
+  for (int k0 = wave; k0 < a.K; k0 += 32) {
+    float w[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + 4 * u, f = lane + 64 * q;
+        w[u][q] = (k < a.K && q < nf && f < C) ? a.Wc[(size_t)k * C + f] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 4 * u;
+      if (k >= a.K) break;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (q < nf) s += ft[(lane + 64 * q) < C ? lane + 64 * q : 0] * w[u][q];
+      s = rows_sum4(row16_sum(s));                 // DPP + row swaps instead of six ds_bpermute round trips
+      if (lane == 0) a.logits[(size_t)b * a.K + k] = s + a.bc[k];
+    }
   }
 }
 
