@@ -12,6 +12,8 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libsrhip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-value"]
+if os.environ.get("SRHIP_EXTRA_FLAGS"):          # A/B builds on the GPU box (e.g. -DSRHIP_SHFL_REDUCE); never set for the shipped library
+    FLAGS += os.environ["SRHIP_EXTRA_FLAGS"].split()
 if os.environ.get("SRHIP_TUNING_BUILD"):          # extra diagnostic kernel variants (tools/microbench.py); never shipped
     FLAGS.append("-DSRHIP_TUNING")
 
