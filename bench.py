@@ -249,37 +249,49 @@ class Leg:
             self.workload = ("SRFlexMatch ViT-S/2@32 CIFAR-100 shapes, flexmatch_cifar100_200_0.yaml, " if img == 32 else
                              "SRFlexMatch ViT-S/16@224 (vit_small_patch16_224) 224x224x3 batches, 100 classes, ")
         elif net == "wrn":
-            # BASELINE.json configs[0]: config/classic_cv/pseudolabel/pseudolabel_cifar100_400_0.yaml + the SR keys (SURVEY Appendix C:
-            # feature_dim 128): WRN-28-2, batch 64 / uratio 1, SGD-Nesterov lr 0.03 momentum 0.9 wd 1e-3, ema_m 0.999, 2^20 iterations
+            # BASELINE.json configs[0]: configs/classic_cv_srpseudolabel_cifar100_400_wrn_28_2.yaml (authored: the reference's classic_cv pseudolabel
+            # yaml + the SR keys) through the yaml loader: WRN-28-2, batch 64 / uratio 1, SGD-Nesterov lr 0.03 wd 1e-3, ema_m 0.999
+            from semireward_amd import config as srconfig
             from semireward_amd.nets import wrn
             self.alg_name = "srpseudolabel"
-            cfg = dict(NS, algorithm="srpseudolabel", num_train_iter=1048576, ema_m=0.999, optim="SGD", lr=0.03, momentum=0.9, weight_decay=1e-3,
-                       layer_decay=1.0, num_warmup_iter=0, feature_dim=128, unsup_warm_up=0.4)
-            m = get_algorithm(argparse.Namespace(**common, **cfg), wrn.wrn_28_2)          # reference init (wrn.py:108-117), seed 0
+            ya = srconfig.get_config(os.path.join(ROOT, "configs", "classic_cv_srpseudolabel_cifar100_400_wrn_28_2.yaml"),
+                                     overrides=dict(common, ulb_dest_len=50000, num_warmup_iter=0))
+            assert ya.net == "wrn_28_2" and ya.algorithm == "srpseudolabel" and ya.batch_size == 64 and ya.num_classes == 100
+            m = get_algorithm(ya, wrn.wrn_28_2)          # reference init (wrn.py:108-117), seed 0
             m.dp.broadcast_params(m.model, m.rewarder, m.generator)
             b = synth.synth_batch(100 + rank, self.bl, bu, 32, 100, 50000)
             self.batch = m.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
-            start = 200001                                               # sr_decay(): max(8, 1 + 2^20 / it) = 8
+            start = 200001                                               # > start_timing (100000); sr_decay(): max(8, 1 + 2^20 / it) = 8
             self.metric, self.unit = "unlabeled images/sec/node (PseudoLabel+SR, WRN-28-2 CIFAR-100)", "unlabeled images/s"
-            self.workload = "SRPseudoLabel WRN-28-2@32 CIFAR-100 shapes, classic_cv pseudolabel_cifar100_400_0.yaml + SR keys, SGD, "
+            self.workload = "SRPseudoLabel WRN-28-2@32 CIFAR-100 shapes, configs/classic_cv_srpseudolabel_cifar100_400_wrn_28_2.yaml, SGD, "
         else:
-            # usb_nlp / usb_audio SR yamls (config/SemiReward/usb_nlp/softmatch/softmatch_ag_news_40_0.yaml, usb_audio/{softmatch,freematch}/
-            # *_urbansound8k_100_0.yaml): batch 8 / uratio 1, use_cat False, AdamW lr 5e-5 wd 5e-4, num_train_iter 102400, start_timing 10000
+            # BASELINE.json configs[3] / [4] through their authored yamls (configs/usb_nlp_srsoftmatch_aclImdb_20_bert_base.yaml: IMDB, 2 classes;
+            # configs/usb_audio_srfreematch_urbansound8k_100_wave2vecv2_base.yaml); the HuBERT leg (not a BASELINE config; the net every usb_audio SR
+            # yaml of the reference names) keeps the keys of config/SemiReward/usb_audio/softmatch/softmatch_urbansound8k_100_0.yaml as a dict
+            from semireward_amd import config as srconfig
+            ypath = None
             if net == "bert":
                 from semireward_amd.nets import bert
-                builder, C, ld = bert.bert_base_uncased, 4, 0.65
+                builder, ypath = bert.bert_base_uncased, "usb_nlp_srsoftmatch_aclImdb_20_bert_base.yaml"
             elif net == "hubert":
                 from semireward_amd.nets import hubert
                 builder, C, ld = hubert.hubert_base, 10, 0.75
             else:
                 from semireward_amd.nets import wave2vec
-                builder, C, ld = wave2vec.wave2vecv2_base, 10, 0.75
-            self.alg_name = ("srfreematch" if net == "wave2vec" else "srsoftmatch") if alg == "auto" else alg
-            extra = dict(dist_align=True, dist_uniform=True, ema_p=0.999, n_sigma=2, per_class=False) if self.alg_name == "srsoftmatch" else \
-                dict(ema_p=0.999, use_quantile=False, clip_thresh=False, ent_loss_ratio=0.001) if self.alg_name == "srfreematch" else {}
-            cfg = dict(NS, algorithm=self.alg_name, num_classes=C, num_train_iter=102400, start_timing=10000, lr=5e-5, layer_decay=ld,
-                       use_cat=False, feature_dim=768, **extra)
-            args = argparse.Namespace(**common, **cfg)
+                builder, ypath = wave2vec.wave2vecv2_base, "usb_audio_srfreematch_urbansound8k_100_wave2vecv2_base.yaml"
+            if ypath is not None and alg == "auto":
+                args = srconfig.get_config(os.path.join(ROOT, "configs", ypath), overrides=common)
+                self.alg_name, C = args.algorithm, args.num_classes
+                self.config_file = "configs/" + ypath
+            else:
+                if ypath is not None:
+                    C, ld = (2, 0.75) if net == "bert" else (10, 0.75)
+                self.alg_name = "srsoftmatch" if alg == "auto" else alg
+                extra = dict(dist_align=True, dist_uniform=True, ema_p=0.999, n_sigma=2, per_class=False) if self.alg_name == "srsoftmatch" else \
+                    dict(ema_p=0.999, use_quantile=False, clip_thresh=False, ent_loss_ratio=0.001) if self.alg_name == "srfreematch" else {}
+                cfg = dict(NS, algorithm=self.alg_name, num_classes=C, num_train_iter=102400, start_timing=10000, lr=5e-5, layer_decay=ld,
+                           use_cat=False, feature_dim=768, **extra)
+                args = argparse.Namespace(**common, **cfg)
             m = get_algorithm(args, builder)                              # random init (no network for the checkpoint)
             m.dp.broadcast_params(m.model, m.rewarder, m.generator)
             g = torch.Generator().manual_seed(100 + rank)
@@ -288,14 +300,15 @@ class Leg:
                                 "attention_mask": torch.ones(n, a.seq_len, dtype=torch.int64)}          # full-length rows
                 self.metric = "unlabeled sequences/sec/node (%s, BERT-base, L=%d)" % (self.alg_name, a.seq_len)
                 self.unit = "unlabeled sequences/s"
-                self.workload = "%s bert_base_uncased, [B, %d] token batches, usb_nlp SR yaml shapes, use_cat False, " % (self.alg_name, a.seq_len)
+                self.workload = "%s bert_base_uncased, [B, %d] token batches, %d classes (%s), use_cat False, " % (
+                    self.alg_name, a.seq_len, C, getattr(self, "config_file", "usb_nlp SR yaml shapes"))
             else:
                 mk = lambda n: torch.randn(n, a.samples, generator=g)   # noqa: E731
                 nm = "HuBERT-base" if net == "hubert" else "Wav2Vec2-base"
                 self.metric = "unlabeled clips/sec/node (%s, %s, %d samples)" % (self.alg_name, nm, a.samples)
                 self.unit = "unlabeled clips/s"
-                self.workload = "%s %s, [B, %d] waveforms, usb_audio SR yaml shapes, use_cat False, " % (
-                    self.alg_name, "hubert_base" if net == "hubert" else "wave2vecv2_base", a.samples)
+                self.workload = "%s %s, [B, %d] waveforms, %d classes (%s), use_cat False, " % (
+                    self.alg_name, "hubert_base" if net == "hubert" else "wave2vecv2_base", a.samples, C, getattr(self, "config_file", "usb_audio SR yaml shapes"))
             kw = dict(x_lb=mk(self.bl), y_lb=torch.randint(0, C, (self.bl,), generator=g), x_ulb_w=mk(bu), x_ulb_s=mk(bu))
             self.batch = m.process_batch(**kw)
             start = 90001                                                 # sr_decay(): max(8, 1 + 102400 / it) = 8
@@ -472,7 +485,13 @@ def worker(a):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsrhip has no CPU path)")
     ndev = torch.cuda.device_count()
-    backend = os.environ.get("SR_DIST_BACKEND", "nccl" if ndev >= world else "gloo")     # "nccl" is RCCL on ROCm
+    backend = os.environ.get("SR_DIST_BACKEND", "nccl")                                  # "nccl" is RCCL on ROCm
+    if backend == "nccl" and ndev < world:
+        # never a silent fall-back: N ranks over fewer devices would print a "scaling" line measured through host memory (a mis-set
+        # HIP_VISIBLE_DEVICES on a real 8-GPU node).  The functional check with ranks sharing devices has to be asked for.
+        raise SystemExit("bench.py: --gpus %d but only %d visible device(s).  One rank per GPU over RCCL needs %d devices (check HIP_VISIBLE_DEVICES / "
+                         "ROCR_VISIBLE_DEVICES); for a functional check of the multi-rank path with ranks sharing devices set SR_DIST_BACKEND=gloo "
+                         "explicitly (its line is labelled as such and is not a scaling measurement)." % (world, ndev, world))
     ctx = {"world": world, "rank": rank, "local": local % max(ndev, 1), "rccl_ranks": 0, "ndev_used": min(ndev, world), "backend_note": None}
     torch.cuda.set_device(ctx["local"])
     if world > 1:
@@ -547,8 +566,14 @@ def worker(a):
                 if tag.startswith("classic_cv") and rank == 0 and world == 1 and not a.no_cpu_baseline:
                     keep["cpu_baseline"] = cpu_baseline_wrn(64, 64)       # the configuration BASELINE.json labels "CPU reference"
                 also.append(keep)
+                # the driver keeps `config` whole and drops keys it does not know: the legs' numbers ride there as well, compact
+                out["config"].setdefault("legs", {})[tag] = {
+                    "metric": keep["metric"], "value": keep["value"], "unit": keep["unit"], "ms_per_step": keep["ms_per_step"],
+                    "workload": keep["workload"], "roofline_frac": keep.get("roofline", {}).get("frac"),
+                    "roofline_bound": keep.get("roofline", {}).get("bound"), "roofline_kernel": keep.get("roofline", {}).get("kernel")}
             except Exception as e:                       # noqa: BLE001
                 also.append({"leg": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+                out["config"].setdefault("legs", {})[tag] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             del leg
             torch.cuda.empty_cache()
     state["phase"] = "gradient-exchange A/B"
@@ -558,15 +583,18 @@ def worker(a):
         # backward (SR_OVERLAP_ALLREDUCE, distributed.DataParallel.install_overlap); "on_bf16" = the same exchange in bf16 (never the default)
         ab = out["overlap_allreduce"] = {"off": {"ms_per_step": out["ms_per_step"], "value": out["value"],
                                                  "allreduce_ms_per_step": out.get("allreduce_ms_per_step")}}
-        for tag, env in (("on", {"SR_OVERLAP_ALLREDUCE": "1"}), ("off_bf16", {"SR_ALLREDUCE_BF16": "1"})):
+        for tag, env in (("on", {"SR_OVERLAP_ALLREDUCE": "1"}), ("off_bf16", {"SR_ALLREDUCE_BF16": "1"}), ("rs_ag", {"SR_GRAD_EXCHANGE": "rs_ag"}),
+                         ("rs_ag_on", {"SR_GRAD_EXCHANGE": "rs_ag", "SR_OVERLAP_ALLREDUCE": "1"})):
             leg, old_env = None, {k: os.environ.get(k) for k in env}
             try:
                 os.environ.update(env)
                 leg = Leg(a, ctx, net=a.net, img=a.img, bu=a.bu, bl=a.bl, regime=a.regime, alg=a.alg)
                 o = leg.run(max(4, a.steps // 2), 2, 3, roofline=False)
                 ab[tag] = {"ms_per_step": o["ms_per_step"], "value": o["value"], "allreduce_ms_per_step": o.get("allreduce_ms_per_step"),
-                           "note": "allreduce_ms_per_step = what is left exposed behind the backward (event pair around all_reduce_grads)"
-                           if tag == "on" else "gradient block exchanged as bf16 (a rounded sum: NOT the reference's fp32 DDP buckets)"}
+                           "note": {"on": "allreduce_ms_per_step = what is left exposed behind the backward (event pair around all_reduce_grads)",
+                                    "off_bf16": "gradient block exchanged as bf16 (a rounded sum: NOT the reference's fp32 DDP buckets)",
+                                    "rs_ag": "reduce-scatter + all-gather of the flat fp32 block instead of one all-reduce (SR_GRAD_EXCHANGE=rs_ag)",
+                                    "rs_ag_on": "reduce-scatter + all-gather per layer-group slice under the backward"}[tag]}
             except Exception as e:                       # noqa: BLE001
                 ab[tag] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             finally:
@@ -574,6 +602,17 @@ def worker(a):
                     os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             del leg
             torch.cuda.empty_cache()
+    if "overlap_allreduce" in out:
+        # which exchange the measurements of THIS run favour (fp32 only: the bf16 exchange changes results); the default in distributed.py stays
+        # the single all-reduce until a run on RCCL says otherwise -- on gloo / shared devices this field says nothing about xGMI
+        ab = out["overlap_allreduce"]
+        timed = {k: v["ms_per_step"] for k, v in ab.items() if k != "off_bf16" and isinstance(v, dict) and v.get("ms_per_step")}
+        if timed:
+            best = min(timed, key=timed.get)
+            ab["fastest_fp32"] = {"leg": best, "ms_per_step": timed[best], "vs_off": timed[best] / timed["off"] if timed.get("off") else None,
+                                  "env": {"off": {}, "on": {"SR_OVERLAP_ALLREDUCE": "1"}, "rs_ag": {"SR_GRAD_EXCHANGE": "rs_ag"},
+                                          "rs_ag_on": {"SR_GRAD_EXCHANGE": "rs_ag", "SR_OVERLAP_ALLREDUCE": "1"}}[best],
+                                  "measured_on": ctx["backend_note"]}
     state["phase"] = "cpu baseline"
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and default_headline:

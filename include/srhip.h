@@ -145,22 +145,6 @@ int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao, const voi
                          const float* b2, const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma,
                          const float* next_beta, int M, int D, int Hd, void* stream);
 
-/* srhip_mlp_fused_proj with the workgroup split into PRODUCER waves (fc1 + GELU) and CONSUMER waves (projection, fc2, both LayerNorms,
- * epilogue) on 32x32x16 MFMAs (csrc/mlp_ps.hip) -- same formula, same rounding points, same arguments except that the three weights arrive as
- * ONE packed image: the 1 KiB MFMA fragments of Wp (vit.py:105), fc1 and fc2 (vit.py:69-75) in the order the kernel's LDS ring consumes them
- * (srhip_mlp_ps_pack: Wp bf16 [D, D], W1 bf16 [Hd, D], W2 bf16 [D, Hd] -> packed, srhip_mlp_ps_pack_bytes(D, Hd) bytes; repack after
- * every parameter update).  D == 384, Hd % 64 == 0, Hd <= 1536, M * D * 2 < 2^31.  This is the launch the inference rows of a training step
- * take (nets/vit.py); srhip_mlp_fused_proj stays for comparison and for the gradient-row variant of srhip_mlp_fused. */
-long long srhip_mlp_ps_pack_bytes(int D, int Hd);
-int srhip_mlp_ps_pack(const void* Wp, const void* W1, const void* W2, void* packed, int D, int Hd, void* stream);
-/* all blocks of a backbone in ONE launch: offsets int64 [n_blocks, 3] (device) = element offsets of (proj.weight, fc1.weight, fc2.weight) of
- * every block inside the bf16 copy of the flat parameter block (16-byte aligned); packed [n_blocks * srhip_mlp_ps_pack_bytes] */
-int srhip_mlp_ps_pack_blocks(const void* flat_bf16, const long long* offsets, int n_blocks, void* packed, int D, int Hd, void* stream);
-int srhip_mlp_ps_proj(const float* x, float* x_out, const void* ao, const void* packed, const float* bp, const float* row_scale1,
-                      int ao_scaled, const float* ln_gamma, const float* ln_beta, float eps, const float* b1, const float* b2,
-                      const float* row_scale2, int rows_per_sample, void* ln_next, const float* next_gamma, const float* next_beta,
-                      int M, int D, int Hd, void* stream);
-
 /* Fused qkv projection + attention of a ViT block for rows without a backward: ao = softmax(q k^T * scale) v with [q | k | v] = xn Wqkv^T +
  * bqkv -- Attention.forward up to the output projection (semilearn/nets/vit/vit.py:93-104) on the norm1 output (:163) in ONE launch, one
  * workgroup per image; replaces srhip_gemm_nt(qkv) + srhip_attn_fwd for inference rows (the [M, 3D] qkv activation never reaches HBM).

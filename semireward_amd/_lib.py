@@ -37,10 +37,6 @@ SIGNATURES = {
     "srhip_adamw_flat_dyn": (I, [P, P, P, P, P, P, P, I, P, P, P, F, F, F, Dbl, F, P, I, P]),
     "srhip_adam_flat_dyn": (I, [P, P, P, P, L, F, F, F, F, P, P]),
     "srhip_droppath_fill_cols_dyn": (I, [P, P, P, I, I, I, P, c_ulonglong, P]),
-    "srhip_mlp_ps_pack_bytes": (c_longlong, [I, I]),
-    "srhip_mlp_ps_pack": (I, [P, P, P, P, I, I, P]),
-    "srhip_mlp_ps_pack_blocks": (I, [P, P, I, P, I, I, P]),
-    "srhip_mlp_ps_proj": (I, [P, P, P, P, P, P, I, P, P, F, P, P, P, I, P, P, P, I, I, I, P]),
     "srhip_patch_embed_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "srhip_patch_embed_bwd_ws_floats": (L, [I, I, I, I, I]),

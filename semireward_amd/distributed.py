@@ -9,6 +9,10 @@ one packed all-reduce of (sum reward per pass, n) per step, ``reward_means``).  
 reference's DDP (srflexmatch/utils.py:24-35 recounts the rank's own ``selected_label``).  And (SR_ALLREDUCE_BF16=1) the gradient block exchanged as bf16 --
 half the xGMI ring time of the one large all-reduce (42.9 instead of 85.7 MB for ViT-S), at the price of a gradient sum rounded to 8 bits
 of mantissa per hop, which DDP's fp32 buckets do not do: opt-in, never the default.
+``SR_GRAD_EXCHANGE=rs_ag`` (opt-in until it has been timed on RCCL) runs the same exchange as reduce-scatter + all-gather on the flat block: every
+rank reduces one contiguous 1/world shard (in place, 256-byte aligned) and the shards are gathered back -- the two halves of an all-reduce as
+separate collectives, which on xGMI's all-to-all mesh (7 links per GPU) can go direct between every pair of GPUs instead of
+around a ring bound by ONE link; `bench.py --gpus N` times it beside the single all-reduce (`overlap_allreduce.rs_ag`).
 """
 import os
 
@@ -22,7 +26,28 @@ class DataParallel:
         self.global_reward_threshold = global_reward_threshold
         self.comm_events = None      # bench.py: list that receives a HIP-event pair around the gradient all-reduce of every step
         self.bf16_grads = os.environ.get("SR_ALLREDUCE_BF16", "0") != "0"
+        self.exchange = os.environ.get("SR_GRAD_EXCHANGE", "allreduce")       # "allreduce" | "rs_ag"
+        if self.exchange not in ("allreduce", "rs_ag"):
+            raise ValueError("SR_GRAD_EXCHANGE must be 'allreduce' or 'rs_ag', not %r" % (self.exchange,))
         self._g16 = None
+
+    SHARD_ALIGN = 64                 # elements: shards of the reduce-scatter start on 256-byte boundaries
+
+    def _sum_over_ranks(self, t):
+        """Sum of a contiguous 1-D slice of a flat block over the ranks, in place: ONE all-reduce, or (rs_ag) reduce-scatter into this rank's
+        shard + all-gather of the shards, with the < world * SHARD_ALIGN elements that do not divide evenly all-reduced behind them."""
+        if self.exchange != "rs_ag" or t.dim() != 1 or not t.is_contiguous():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        w, n = self.world_size, t.numel()
+        chunk = (n // (w * self.SHARD_ALIGN)) * self.SHARD_ALIGN
+        main = chunk * w
+        if chunk:
+            shard = t[self.rank * chunk:(self.rank + 1) * chunk]
+            dist.reduce_scatter_tensor(shard, t[:main], op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(t[:main], shard)
+        if main < n:
+            dist.all_reduce(t[main:], op=dist.ReduceOp.SUM)
 
     @property
     def active(self):
@@ -46,7 +71,7 @@ class DataParallel:
         ready.record(main)                                   # every gradient of [lo, hi) is final on the compute stream here
         self._comm.wait_event(ready)
         with torch.cuda.stream(self._comm):
-            dist.all_reduce(self._model.grad[lo:hi], op=dist.ReduceOp.SUM)
+            self._sum_over_ranks(self._model.grad[lo:hi])
         self._done.append((lo, hi))
 
     def all_reduce_grads(self, model):
@@ -73,10 +98,10 @@ class DataParallel:
                     ops.cast_f32_bf16(g, self._g16, g.numel())
                 else:
                     self._g16.copy_(g)
-                dist.all_reduce(self._g16, op=dist.ReduceOp.SUM)
+                self._sum_over_ranks(self._g16)
                 g.copy_(self._g16)
                 return
-            dist.all_reduce(model.grad, op=dist.ReduceOp.SUM)
+            self._sum_over_ranks(model.grad)
             return
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
@@ -86,7 +111,7 @@ class DataParallel:
             pos = 0
             for lo, hi in done + [(model.grad.numel(), model.grad.numel())]:
                 if lo > pos:
-                    dist.all_reduce(model.grad[pos:lo], op=dist.ReduceOp.SUM)
+                    self._sum_over_ranks(model.grad[pos:lo])
                 pos = max(pos, hi)
             fin = torch.cuda.Event()
             fin.record(self._comm)

@@ -64,11 +64,6 @@ _FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
 _FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
 _FUSED_PROJ = os.environ.get("SRHIP_FUSED_PROJ", "1") != "0"        # attention projection + residual inside the fused MLP launch
 _FUSED_NEXT_LN = os.environ.get("SRHIP_FUSED_NEXT_LN", "1") != "0"  # ... which then also writes the next block's norm1 output
-# that launch as producer / consumer waves on 32x32x16 MFMAs fed from a packed weight image (csrc/mlp_ps.hip).  Opt-in (SRHIP_MLP_PS=1): correct and
-# pinned by the same tests, but measured 12 % SLOWER than the 8 x 16-row kernel at the launch sizes of a step (127 vs 111 us for 105 images on
-# the same box; profiles/r03_mlp_ps_*: half the fragment reads and MFMA issue slots, but the producer waves idle through projection / LayerNorm /
-# epilogue and the consumer waves wait for the producer's GELU inside the MLP loop -- 41 % of the wave cycles are parked at barriers)
-_MLP_PS = os.environ.get("SRHIP_MLP_PS", "0") != "0"
 # the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
 # pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
 _FUSED_MLP_MIN_ROWS = int(os.environ.get("SRHIP_FUSED_MLP_MIN_ROWS", "16384"))
@@ -116,13 +111,6 @@ class VisionTransformer:
                 n = "blocks.%d.%s" % (i, w)
                 r, c = self.offsets[n][1]
                 self.wT[n] = torch.zeros(c, r, dtype=torch.bfloat16, device=self.device)
-        # packed (proj | fc1 | fc2) fragment streams of every block for srhip_mlp_ps_proj (inference rows), refreshed with the bf16 operands
-        self.mlp_pk = None
-        if _MLP_PS and ops.mlp_ps_supported(cfg.embed_dim, cfg.hidden) and self.device.type == "cuda":
-            nb = ops.mlp_ps_pack_bytes(cfg.embed_dim, cfg.hidden)
-            self.mlp_pk = torch.empty(cfg.depth, nb, dtype=torch.uint8, device=self.device)
-            self._pk_offs = torch.tensor([[self.offsets["blocks.%d.%s" % (i, w)][0] for w in ("attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")]
-                                          for i in range(cfg.depth)], dtype=torch.int64, device=self.device)
         self.dp_probs = torch.linspace(0, cfg.drop_path_rate, cfg.depth).to(self.device)    # vit.py:247-249
         self.training = True
         self._ws = {}
@@ -175,13 +163,7 @@ class VisionTransformer:
     def refresh_operands(self):
         """bf16 operand copy of the whole block + transposed GEMM weights (after any parameter change)."""
         ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
-        self.refresh_packed()
         self.refresh_transposed()
-
-    def refresh_packed(self):
-        """The fragment streams of srhip_mlp_ps_proj follow the bf16 operand copy (one launch for all blocks; after every parameter update)."""
-        if self.mlp_pk is not None:
-            ops.mlp_ps_pack_blocks(self.flat_bf16, self._pk_offs, self.cfg.depth, self.mlp_pk, self.cfg.embed_dim, self.cfg.hidden)
 
     lazy_transposed = os.environ.get("SR_LAZY_WT", "1") != "0"   # the optimizer only marks the transposed weight copies stale (ensure_transposed)
 
@@ -337,12 +319,6 @@ class VisionTransformer:
                 # block's norm1 output (the operand of its fused qkv + attention launch) when there is a next block
                 nb = "blocks.%d." % (i + 1)
                 ln_ready = _FUSED_NEXT_LN and i + 1 < cfg.depth
-                if _MLP_PS and self.mlp_pk is not None:
-                    ops.mlp_ps_proj(x, ao, self.mlp_pk[i], P(b + "attn.proj.bias"), s1, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps,
-                                    P(b + "mlp.fc1.bias"), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd,
-                                    ln_next=ln if ln_ready else None, next_gamma=P(nb + "norm1.weight") if ln_ready else None,
-                                    next_beta=P(nb + "norm1.bias") if ln_ready else None, ao_scaled=ao_scaled)
-                    continue
                 ops.mlp_fused_proj(x, ao, P(b + "attn.proj.weight", wb), P(b + "attn.proj.bias"), s1, P(b + "norm2.weight"),
                                    P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb), P(b + "mlp.fc1.bias"),
                                    P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd,

@@ -82,6 +82,16 @@ class WideResNet:
                 self.convs[nme] = dict(cout=cout, cin=cin, k=k, K=K, Kp=Kp,
                                        Wb=torch.zeros(cout, Kp, dtype=torch.bfloat16, device=self.device),
                                        WbT=torch.zeros(Kp, cout, dtype=torch.bfloat16, device=self.device))
+        # Every block convolution runs as srhip_wrn_conv_bn and the tail as srhip_wrn_head (no generic fall-back chain): refuse at construction,
+        # with the reason, the widths those launches are not built for (e.g. widen_factor 4: block3 has Cin = 256; the reference's wrn_28_8 /
+        # wrn_var_37_2, which no config/SemiReward yaml names) instead of failing with SR_EINVAL in the middle of a forward.
+        bad = ["%s [Cout %d, Cin %d, %dx%d]" % (nme, c["cout"], c["cin"], c["k"], c["k"]) for nme, c in self.convs.items()
+               if nme != "conv1.weight" and not ops.wrn_conv_supported(c["cin"], c["cout"], c["k"])]
+        if bad or ch[3] > 256:
+            raise NotImplementedError(
+                "WideResNet(depth=%d, widen_factor=%d): the fused convolution launches (csrc/wrn_conv.hip) take Cin a power of two in 8..128 and "
+                "Cout in {16, 32, 64 k <= 256}, the tail launch (wrn_head_kernel) at most 256 channels; not supported here: %s" % (
+                    depth, widen_factor, ", ".join(bad) or "final width %d" % ch[3]))
         self.ws = torch.zeros(ops.bn_ws_doubles(), dtype=torch.float64, device=self.device)      # (zeroed once: srhip_bn_fwd keeps its counter at 0)
         # per-BatchNorm statistics accumulators (16 copies x (sum | sum of squares)), filled by the convolution in front of the BatchNorm and
         # folded by the one behind it; one arena so that a forward zeroes them with one launch

@@ -322,45 +322,6 @@ def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, 
     _call("srhip_mlp_fused_proj", *args, _s())
 
 
-def mlp_ps_pack_bytes(D, Hd):
-    n = int(_lib.lib().srhip_mlp_ps_pack_bytes(D, Hd))
-    if n <= 0:
-        raise RuntimeError("srhip_mlp_ps_pack_bytes: unsupported shape D=%d Hd=%d" % (D, Hd))
-    return n
-
-
-def mlp_ps_supported(D, Hd):
-    return D == 384 and Hd % 64 == 0 and 128 <= Hd <= 1536
-
-
-def mlp_ps_pack(Wp, W1, W2, packed, D, Hd):
-    """The three bf16 weights of a block's (proj, fc1, fc2) as the fragment stream srhip_mlp_ps_proj consumes (uint8 [mlp_ps_pack_bytes])."""
-    _call("srhip_mlp_ps_pack", _p(Wp), _p(W1), _p(W2), _p(packed), D, Hd, _s())
-
-
-def mlp_ps_pack_blocks(flat_bf16, offsets, n_blocks, packed, D, Hd):
-    """Every block's (proj, fc1, fc2) weights from the bf16 copy of the flat parameter block into packed [n_blocks, mlp_ps_pack_bytes]: one launch."""
-    _call("srhip_mlp_ps_pack_blocks", _p(flat_bf16), _p(offsets), n_blocks, _p(packed), D, Hd, _s())
-
-
-def mlp_ps_proj(x, ao, packed, bp, row_scale1, gamma, beta, eps, b1, b2, row_scale2, rows_per_sample, M, D, Hd, x_out=None,
-                ln_next=None, next_gamma=None, next_beta=None, ao_scaled=False):
-    """mlp_fused_proj on the producer / consumer kernel (csrc/mlp_ps.hip): same result contract, weights as one packed image."""
-    args = (_p(x), _p(x_out if x_out is not None else x), _p(ao), _p(packed), _p(bp), _p(row_scale1), int(bool(ao_scaled)), _p(gamma), _p(beta),
-            eps, _p(b1), _p(b2), _p(row_scale2), rows_per_sample, _p(ln_next), _p(next_gamma), _p(next_beta), M, D, Hd)
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_mlp_ps_proj", *args, _s())
-        e1.record()
-        # algorithmic: fc1 + fc2 + proj products; bytes: x in, x out (fp32; x1 never leaves the accumulators), ao in (bf16), [next norm1
-        # output out (bf16)], the weights once
-        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_ps_kernel<0>",
-                              8.0 * M * D + 2.0 * M * D + (2.0 * M * D if ln_next is not None else 0.0) + 4.0 * D * Hd + 2.0 * D * D))
-        return
-    _call("srhip_mlp_ps_proj", *args, _s())
-
-
 def gelu_eval(x, y_erf, y_poly):
     _call("srhip_gelu_eval", _p(x), _p(y_erf), _p(y_poly), x.numel(), _s())
 

@@ -139,8 +139,6 @@ class FusedAdamW:
                        self.table.shape[0], self.lr_t, self.wd_t, self.lr_factor(), self.step_count, self.betas[0],
                        self.betas[1], self.eps, ema_m=ema_m, grad_scale=grad_scale, zero_grad=True, clip_coef=coef,
                        dyn=sc.adamw_ptr if sc is not None else None)
-        if hasattr(self.model, "refresh_packed"):
-            self.model.refresh_packed()          # fragment streams of the producer / consumer MLP launch (one launch for all blocks)
         if getattr(self.model, "lazy_transposed", False):
             self.model._wT_stale = True          # refreshed off the critical path (model.ensure_transposed)
         else:

@@ -280,3 +280,42 @@ def test_step_plan_partitions_every_column_for_every_deferred_share():
                 assert len(r) <= int(f * (len(i) + len(r))) + 1
             sizes.add(len(r))
         assert (len(sizes) > 2) == (N > 100)          # tiny backbones: nothing to tune (everything rides in the read launch)
+
+
+def test_wide_resnet_refuses_unsupported_widths_at_construction():
+    """Every block convolution runs as srhip_wrn_conv_bn (no generic chain behind it): a width the launch is not built for is an error with the
+    reason when the model is BUILT (the reference's wrn_28_8 / widen_factor 4: Cin = 256), not SR_EINVAL in the middle of a forward."""
+    from semireward_amd.nets import wrn
+    with pytest.raises(NotImplementedError, match="Cin 256"):
+        wrn.WideResNet(num_classes=10, depth=10, widen_factor=4, device="cpu")
+    m = wrn.WideResNet(num_classes=10, depth=10, widen_factor=2, device="cpu")       # wrn_tiny_test / wrn_28_2 widths
+    assert m.convs["block3.layer.0.conv2.weight"]["cin"] == 128
+
+
+def test_bench_headline_keys_are_the_reference_yaml():
+    """bench.py:NS (the headline configuration) against the namespace the reference's get_config() produces for
+    config/SemiReward/usb_cv/flexmatch/flexmatch_cifar100_200_0.yaml (tests/golden/sr_configs.json); the three BASELINE configurations without a
+    reference yaml load from configs/*.yaml through the same loader."""
+    import glob
+    import json
+    import bench
+    from semireward_amd import config
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "sr_configs.json")))["configs"]["usb_cv/flexmatch/flexmatch_cifar100_200_0.yaml"]
+    for k, v in bench.NS.items():
+        if k == "ulb_dest_len":           # not a yaml key: train.py sets it to len(unlabeled set) at run time (50 000 = CIFAR-100's training set)
+            assert v == 50000
+            continue
+        assert ref[k] == v, (k, ref[k], v)
+    assert ref["net"] == "vit_small_patch2_32" and ref["batch_size"] == 8 and ref["uratio"] == 1
+    files = sorted(glob.glob(os.path.join(ROOT, "configs", "*.yaml")))
+    assert len(files) == 3
+    seen = {}
+    for f in files:
+        a = config.get_config(f)
+        seen[a.algorithm] = a
+        for k in ("start_timing", "feature_dim", "sr_lr", "N_k", "sr_ema", "sr_ema_m"):      # the SR keys every config/SemiReward yaml carries
+            assert hasattr(a, k), (f, k)
+        assert isinstance(a.lr, float) and a.amp is False
+    assert seen["srpseudolabel"].net == "wrn_28_2" and seen["srpseudolabel"].feature_dim == 128 and seen["srpseudolabel"].num_classes == 100
+    assert seen["srsoftmatch"].net == "bert_base_uncased" and seen["srsoftmatch"].num_classes == 2 and seen["srsoftmatch"].dataset == "aclImdb"
+    assert seen["srfreematch"].net == "wave2vecv2_base" and seen["srfreematch"].num_classes == 10 and seen["srfreematch"].ema_p == 0.999

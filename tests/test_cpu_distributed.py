@@ -88,6 +88,55 @@ def test_data_parallel_world2_gloo():
     assert sorted(res) == [(0, True, True), (1, True, True)]
 
 
+def _rs_ag_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semireward_amd.distributed import DataParallel
+    ok = True
+    # block sizes: one that divides into aligned shards with a tail (the ViT-S block: 21 436 900 elements on 8 ranks leaves a tail too), one
+    # smaller than world * SHARD_ALIGN (everything goes through the tail all-reduce), one exactly divisible
+    for n in (3 * 64 * 5 + 37, 100, 3 * 64 * 2):
+        rng = np.random.Generator(np.random.PCG64(100 + n))
+        blocks = torch.from_numpy(rng.standard_normal((world, n)).astype(np.float32))
+        want = blocks.double().sum(0)
+        for bf16 in (False, True):
+            dp = DataParallel(world, rank)
+            dp.exchange, dp.bf16_grads = "rs_ag", bf16
+            m = _Flat(n)
+            m.grad = blocks[rank].clone()
+            dp.all_reduce_grads(m)
+            ref = DataParallel(world, rank)
+            ref.bf16_grads = bf16
+            m2 = _Flat(n)
+            m2.grad = blocks[rank].clone()
+            ref.all_reduce_grads(m2)
+            tol = dict(rtol=3e-2, atol=3e-2) if bf16 else dict(rtol=1e-6, atol=1e-6)
+            ok = ok and torch.allclose(m.grad.double(), want, **tol) and torch.allclose(m.grad, m2.grad, **tol)
+            # every rank holds the same block afterwards (bit for bit: the shards are gathered, not re-summed)
+            g0 = m.grad.clone()
+            dist.broadcast(g0, src=0)
+            ok = ok and torch.equal(g0, m.grad)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce():
+    """SR_GRAD_EXCHANGE=rs_ag (distributed.DataParallel._sum_over_ranks): in-place reduce-scatter into aligned shards + all-gather + tail
+    all-reduce == the single all-reduce of the flat gradient block, on 3 ranks (uneven division), fp32 and the opt-in bf16 exchange."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rs_ag_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True), (2, True)]
+
+
 def test_local_mode_is_reference_semantics():
     from semireward_amd.distributed import DataParallel
     dp = DataParallel(1, 0)

@@ -1,7 +1,9 @@
 """bench.py starts its own ranks (the reference's train.py:344 mp.spawn): the plain driver command ``python bench.py --gpus 2 ...`` must print
-one valid JSON line with n_gpus == 2.  On a one-GPU box the two ranks share the device and the collectives run over gloo (bench.py picks
-that backend when there are fewer devices than ranks) -- a functional proof of the multi-rank path, not a scaling measurement; the same
-command under torch.distributed.run (how the driver launches N > 1) must give the same line shape."""
+one valid JSON line with n_gpus == 2.  On a one-GPU box the ranks share the device and the collectives run over gloo -- which has to be ASKED
+for (SR_DIST_BACKEND=gloo): with fewer visible devices than ranks the default backend (RCCL, one rank per GPU) refuses to start instead of
+printing a "scaling" line measured through host memory.  A functional proof of the multi-rank path, not a scaling measurement; the same
+command under torch.distributed.run (how the driver launches N > 1) must give the same line shape; 8 ranks (the node size BASELINE.json
+names) complete the headline, the deferred-share tuner's rank agreement and the gradient-exchange A/B legs."""
 import json
 import os
 import socket
@@ -26,17 +28,47 @@ def _check(line):
 
 def test_plain_command_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SR_DIST_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
-    _check(lines[0])
+    o = _check(lines[0])
+    assert o["rccl_ranks"] == 0 and "gloo" in o["config"]["backend"] and "not a scaling measurement" in o["config"]["backend"]
+
+
+def test_fewer_devices_than_ranks_is_an_error_unless_gloo_is_asked_for():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer devices than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SR_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.stdout[-2000:], r.stderr[-2000:])
+    assert "SR_DIST_BACKEND=gloo" in r.stderr and "visible device" in r.stderr
+
+
+def test_eight_ranks_complete_the_headline_the_tuner_and_the_exchange_legs():
+    """`python bench.py --gpus 8` as the driver's scaling run starts it, 8 gloo ranks on this box's device(s): every rank's deferred-share tuner
+    takes the same decisions (a disagreement hangs the gradient all-reduce), the off / on / bf16 / reduce-scatter legs of the gradient exchange
+    all report, and the line is complete (no watchdog truncation)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-also",
+                        "--no-roofline"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 8 and o["config"]["parallelism"] == "dp8" and o["value"] > 0 and "truncated" not in o
+    ab = o["overlap_allreduce"]
+    for tag in ("off", "on", "off_bf16", "rs_ag"):
+        assert "error" not in ab[tag] and ab[tag]["ms_per_step"] > 0, (tag, ab[tag])
+    assert o["config"]["step_schedule"]["tuned"] in (True, False)
 
 
 def test_same_command_under_torch_distributed_run():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SR_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py")] + ARGS, env=env, capture_output=True, text=True,
                        timeout=420, cwd=ROOT)

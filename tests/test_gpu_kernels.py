@@ -172,30 +172,13 @@ def attn_ref(qkv, B, N, H, scale):
     return (a @ v).transpose(1, 2).reshape(B * N, H * 64), torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)
 
 
-def _mlp_ps_as_fused_proj(x, ao, Wp, bp, rs1, g, b, eps, W1, b1, W2, b2, rs2, rows_per_sample, M, D, Hd, **kw):
-    """ops.mlp_fused_proj's signature on the producer / consumer kernel: packs (Wp, W1, W2) into the fragment stream and calls srhip_mlp_ps_proj."""
-    packed = torch.empty(ops.mlp_ps_pack_bytes(D, Hd), dtype=torch.uint8, device=DEV)
-    ops.mlp_ps_pack(Wp, W1, W2, packed, D, Hd)
-    if rs1 is not None and not kw.get("ao_scaled", False):
-        # this launch takes the DropPath factor of the attention branch ON ao only (ao_scaled, as srhip_attn_block_fused out_scale writes it);
-        # an unscaled ao with a factor is an argument error -- scale it here the way the 8 x 16-row kernel does internally (a second rounding)
-        with pytest.raises(RuntimeError):
-            ops.mlp_ps_proj(x, ao, packed, bp, rs1, g, b, eps, b1, b2, rs2, rows_per_sample, M, D, Hd, **kw)
-        ao = bf(rs1.repeat_interleave(rows_per_sample)[:M, None] * ao.float())
-        kw = dict(kw, ao_scaled=True)
-    ops.mlp_ps_proj(x, ao, packed, bp, rs1, g, b, eps, b1, b2, rs2, rows_per_sample, M, D, Hd, **kw)
-
-
-@pytest.mark.parametrize("impl", ["rows16", "producer_consumer"])
 @pytest.mark.parametrize("M,rows_per_sample", [(128, 0), (257 * 3, 257), (1000, 0), (257 * 40 + 5, 257), (257 * 127, 257), (257 * 300, 257)])
-def test_mlp_fused_proj(M, rows_per_sample, impl, monkeypatch):
+def test_mlp_fused_proj(M, rows_per_sample):
     """Attention projection + first residual + LN2 + fc1 + GELU + fc2 + second residual in ONE launch (srhip_mlp_fused_proj, vit.py:105-106,
-    :163-165; impl = producer_consumer: srhip_mlp_ps_proj, the launch the training step uses) against (a) the fp32 torch formula on the
+    :163-165) against (a) the fp32 torch formula on the
     bf16-rounded operands and (b) the two launches it replaces (srhip_gemm_nt with the residual epilogue + srhip_mlp_fused), incl. per-sample
     DropPath scales on both branches and in-place operation.  (257 * 300 rows = 603 tiles: workgroups that loop over several tiles.)"""
     D, Hd = 384, 1536
-    if impl == "producer_consumer":
-        monkeypatch.setattr(ops, "mlp_fused_proj", _mlp_ps_as_fused_proj)
     x0 = rnd(M, D, seed=1)
     x0[:, 7] += 3.0
     ao32 = rnd(M, D, seed=11, scale=0.7)

@@ -72,29 +72,20 @@ def test_vit_matches_reference_golden(golden, tag, monkeypatch):
         # golden logits, in eval mode and with the injected DropPath table (factors 0 and 1 / keep_prob live in every block after the first)
         monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1024)
         attn, lnf = _Calls(monkeypatch, "attn_block_fused"), _Calls(monkeypatch, "layernorm_fwd")
-        # the default launch (8 waves x 16 rows, srhip_mlp_fused_proj) and the opt-in producer / consumer launch (SRHIP_MLP_PS=1, srhip_mlp_ps_proj)
-        for ps, entry in ((False, "mlp_fused_proj"), (True, "mlp_ps_proj")):
-            monkeypatch.setattr(vit, "_MLP_PS", ps)
-            if ps and model.mlp_pk is None:          # what the constructor does under SRHIP_MLP_PS=1
-                model.mlp_pk = torch.empty(cfg.depth, ops.mlp_ps_pack_bytes(cfg.embed_dim, cfg.hidden), dtype=torch.uint8, device=DEV)
-                model._pk_offs = torch.tensor([[model.offsets["blocks.%d.%s" % (i, w)][0] for w in ("attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")]
-                                               for i in range(cfg.depth)], dtype=torch.int64, device=DEV)
-                model.refresh_packed()
-            fused = _Calls(monkeypatch, entry)
-            a0, l0 = attn.n, lnf.n
-            lg5, ft5, _ = model.forward_features(x, None, None, save=False)
-            assert fused.n == cfg.depth and attn.n - a0 == cfg.depth and lnf.n - l0 == 1, (fused.n, attn.n, lnf.n)    # ln_next hand-off: ONE norm1 launch
-            assert rel(lg5.cpu(), g[f"{tag}/eval_logits"]) < LOGIT_REL_L2 and rel(ft5.cpu(), g[f"{tag}/eval_feat"]) < LOGIT_REL_L2
-            lg6, ft6, _ = model.forward_features(x, None, dp, save=False)
-            assert fused.n == 2 * cfg.depth and lnf.n - l0 == 2
-            assert float(dp.min()) == 0.0 and float(dp.max()) > 1.0                                       # dropped and re-scaled rows both present
-            assert rel(lg6.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft6.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
-            assert rel(lg6.cpu(), lg2.cpu().numpy()) < 6e-3 and rel(ft6.cpu(), ft2.cpu().numpy()) < 6e-3  # ... and against the rows with a backward
-            # rows permuted through img_index: the fused chain gives the permuted rows bit for bit (rows are independent)
-            permf = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(DEV)
-            lg7, _, _ = model.forward_features(x, permf.to(torch.int32), dp[:, :, permf].contiguous(), save=False)
-            assert torch.equal(lg7, lg6[permf])
-        monkeypatch.setattr(vit, "_MLP_PS", False)
+        fused = _Calls(monkeypatch, "mlp_fused_proj")
+        a0, l0 = attn.n, lnf.n
+        lg5, ft5, _ = model.forward_features(x, None, None, save=False)
+        assert fused.n == cfg.depth and attn.n - a0 == cfg.depth and lnf.n - l0 == 1, (fused.n, attn.n, lnf.n)    # ln_next hand-off: ONE norm1 launch
+        assert rel(lg5.cpu(), g[f"{tag}/eval_logits"]) < LOGIT_REL_L2 and rel(ft5.cpu(), g[f"{tag}/eval_feat"]) < LOGIT_REL_L2
+        lg6, ft6, _ = model.forward_features(x, None, dp, save=False)
+        assert fused.n == 2 * cfg.depth and lnf.n - l0 == 2
+        assert float(dp.min()) == 0.0 and float(dp.max()) > 1.0                                       # dropped and re-scaled rows both present
+        assert rel(lg6.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft6.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
+        assert rel(lg6.cpu(), lg2.cpu().numpy()) < 6e-3 and rel(ft6.cpu(), ft2.cpu().numpy()) < 6e-3  # ... and against the rows with a backward
+        # rows permuted through img_index: the fused chain gives the permuted rows bit for bit (rows are independent)
+        permf = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(DEV)
+        lg7, _, _ = model.forward_features(x, permf.to(torch.int32), dp[:, :, permf].contiguous(), save=False)
+        assert torch.equal(lg7, lg6[permf])
         monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1 << 30)       # the rest of the test: the small-launch kernels again
     assert rel(lg2.cpu(), g[f"{tag}/train_logits"]) < LOGIT_REL_L2 and rel(ft2.cpu(), g[f"{tag}/train_feat"]) < LOGIT_REL_L2
     # gather path: rows permuted through img_index give permuted outputs

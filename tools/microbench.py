@@ -152,50 +152,6 @@ def mlp_proj():
         print("proj+mlp B=%3d: two launches %7.1f us | fused %7.1f us %6.1f TF/s | (mlp alone %7.1f us)" % (B, t0, t1, fl / t1 / 1e6, t2), flush=True)
 
 
-def mlp_ps():
-    """srhip_mlp_fused_proj (8 waves x 16 rows) against srhip_mlp_ps_proj (producer / consumer waves, 32x32x16 MFMAs) with the next block's
-    norm1 fused, launch sizes of a step.  SRHIP_TUNING_BUILD: knock-outs of the new kernel (SRHIP_PS_DEBUG) + its phase stamps."""
-    import ctypes
-    D, Hd, N = 384, 1536, 257
-    tuning = hasattr(ops._lib.lib(), "srhip_mlp_ps_debug")
-    for B in (95, 105, 200, 1000):
-        M = B * N
-        x = torch.randn(M, D, device=DEV)
-        ao = torch.randn(M, D, device=DEV).to(torch.bfloat16)
-        Wp = (torch.randn(D, D, device=DEV) * 0.05).to(torch.bfloat16)
-        bp = torch.randn(D, device=DEV) * 0.1
-        g, b = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
-        W1 = (torch.randn(Hd, D, device=DEV) * 0.05).to(torch.bfloat16)
-        W2 = (torch.randn(D, Hd, device=DEV) * 0.02).to(torch.bfloat16)
-        b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(D, device=DEV) * 0.1
-        ln = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
-        pk = torch.empty(ops.mlp_ps_pack_bytes(D, Hd), dtype=torch.uint8, device=DEV)
-        tp = timeit(lambda: ops.mlp_ps_pack(Wp, W1, W2, pk, D, Hd), reps=10)
-        fl = 4.0 * M * D * Hd + 2.0 * M * D * D
-        t1 = timeit(lambda: ops.mlp_fused_proj(x, ao, Wp, bp, None, g, b, 1e-6, W1, b1, W2, b2, None, 0, M, D, Hd, ln_next=ln, next_gamma=g, next_beta=b), reps=10)
-        x.normal_()
-        t2 = timeit(lambda: ops.mlp_ps_proj(x, ao, pk, bp, None, g, b, 1e-6, b1, b2, None, 0, M, D, Hd, ln_next=ln, next_gamma=g, next_beta=b), reps=10)
-        x.normal_()
-        print("proj+mlp+ln B=%4d (%4d tiles): rows16 %7.1f us %6.1f TF/s | producer/consumer %7.1f us %6.1f TF/s | pack %5.1f us" % (
-            B, (M + 127) // 128, t1, fl / t1 / 1e6, t2, fl / t2 / 1e6, tp), flush=True)
-        if tuning and B in (105, 200):
-            import numpy as np
-            for dbg in (0, 1, 2, 8, 9, 10, 14, 15):
-                os.environ["SRHIP_PS_DEBUG"] = str(dbg)
-                t = timeit(lambda: ops.mlp_ps_proj(x, ao, pk, bp, None, g, b, 1e-6, b1, b2, None, 0, M, D, Hd, ln_next=ln, next_gamma=g, next_beta=b), reps=6)
-                torch.cuda.synchronize()
-                nb = min((M + 127) // 128, 256)
-                buf = (ctypes.c_longlong * (8 * nb))()
-                ops._lib.lib().srhip_mlp_ps_debug(ctypes.cast(buf, ctypes.c_void_p), 8 * nb)
-                st = np.frombuffer(buf, dtype=np.int64).reshape(nb, 8).astype(np.float64)
-                d = lambda i, k: float(np.median(st[:, k] - st[:, i])) / 100.0     # wall_clock64: 100 MHz
-                span = (st[:, 3].max() - st[:, 0].min()) / 100.0
-                x.normal_()
-                print("    debug=%2d (1 no GELU, 2 no DMA, 4 no reads, 8 no MFMA): %7.1f us | stamps (median over WGs, consumer wave): start %.1f | proj %.1f | LN %.1f | "
-                      "MLP %.1f | epilogue %.1f | total %.1f | first start -> last end %.1f" % (dbg, t, d(0, 1), d(1, 4), d(4, 5), d(5, 2), d(2, 3), d(0, 3), span), flush=True)
-            os.environ.pop("SRHIP_PS_DEBUG", None)
-
-
 def attn_block_alone():
     """srhip_attn_block_fused alone at the launch sizes of a step: A/B of SRHIP_ATTN_SPREAD (run the process once per setting)."""
     D, H = 384, 6
