@@ -100,3 +100,30 @@ def test_device_prefetcher_roundtrip():
     for a, b in zip(batches, got):
         assert b["x_lb"].is_cuda and torch.equal(b["x_lb"].cpu(), a["x_lb"]) and torch.equal(b["y_lb"].cpu(), a["y_lb"])
         assert torch.equal(b["x_ulb_w"]["input_ids"].cpu(), a["x_ulb_w"]["input_ids"])
+
+
+def test_whole_transforms_against_the_reference_chain(golden):
+    """srhip_augment against tests/golden/augment_tv.npz: the reference's transform_weak / transform_strong executed as torchvision's PIL op
+    sequence + the reference's RandAugment class + torch's ToTensor / Normalize (oracle/gen_golden.py:gen_augment_tv) -- bytes of the strong
+    view and fp32 tensors of both views, exact, with the fixture's draws."""
+    g = golden("augment_tv")
+    mean, std = tuple(float(v) for v in g["meta/mean"]), tuple(float(v) for v in g["meta/std"])
+    cases = {}
+    for n in range(int(g["meta/n"])):
+        seed, S, kind, pad, i, j, flip = [int(v) for v in g[f"case/{n}/meta"]]
+        cases.setdefault((S, pad), []).append((n, seed, kind, i, j, flip))
+    assert set(cases) == {(32, 4), (96, 12)}
+    for (S, pad), cs in cases.items():
+        aug = GpuAugment(S, pad, mean, std, n_ops=3, device=DEV, seed=1)
+        imgs = [synth_image(seed, S, S, kind) for _, seed, kind, _, _, _ in cs]
+        d = dict(i=np.array([c[3] for c in cs]), j=np.array([c[4] for c in cs]), flip=np.array([bool(c[5]) for c in cs]))
+        out, _ = _run(aug, imgs, d, False)
+        for t, c in enumerate(cs):
+            assert np.array_equal(out[t], g[f"case/{c[0]}/weak"]), ("weak", c[0])
+        d.update(ops=np.stack([g[f"case/{c[0]}/ops"] for c in cs]), vals=np.stack([g[f"case/{c[0]}/vals"] for c in cs]),
+                 cut_v=np.array([g[f"case/{c[0]}/cut"][0] for c in cs]), ux=np.array([g[f"case/{c[0]}/cut"][1] for c in cs]),
+                 uy=np.array([g[f"case/{c[0]}/cut"][2] for c in cs]))
+        out, u8 = _run(aug, imgs, d, True)
+        for t, c in enumerate(cs):
+            assert np.array_equal(u8[t], g[f"case/{c[0]}/strong_u8"]), ("strong bytes", c[0])
+            assert np.array_equal(out[t], g[f"case/{c[0]}/strong"]), ("strong", c[0])

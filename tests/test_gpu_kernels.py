@@ -420,7 +420,7 @@ def test_glue_kernels():
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["c10_w", "c100_w", "c10_nw", "c100_b256"])
+@pytest.mark.parametrize("tag", ["c10_w", "c100_w", "c10_nw", "c100_b256", "c100_rej", "c100_rej_nw"])
 def test_flexmatch_score_filter_bit_exact(golden, tag):
     """Golden probabilities from the reference -> masks / classwise_acc / selected_label must be bit-identical."""
     g = golden("hooks")

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import semireward_ref as S        # noqa: E402
 from oracle import vit_ref as V               # noqa: E402
-from oracle.gen_golden import TRACE, TRACE_FIX   # noqa: E402
+from oracle.gen_golden import TRACE, TRACE_C100, TRACE_FIX   # noqa: E402
 from semireward_amd.algorithms import get_algorithm   # noqa: E402
 from semireward_amd.nets import vit           # noqa: E402
 from semireward_amd.utils import synth        # noqa: E402
@@ -35,10 +35,21 @@ def rel(a, b):
 from oracle.gen_golden import TRACE_FREE, TRACE_SOFT   # noqa: E402
 
 
-@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX), ("srfreematch_trace", TRACE_FREE),
-                                     ("srsoftmatch_trace", TRACE_SOFT)])
+def samp_of(arr, gs):
+    return np.asarray(arr, np.float32).ravel()[::int(gs["stride"])]
+
+
+@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srflexmatch_c100_trace", TRACE_C100), ("srfixmatch_trace", TRACE_FIX),
+                                     ("srfreematch_trace", TRACE_FREE), ("srsoftmatch_trace", TRACE_SOFT)])
 def test_sr_train_step_trace(golden, name, tr):
+    """train_step + ParamUpdateHook on the HIP engine against traces of the REFERENCE's own train_step.  The two srflexmatch traces (10 and
+    100 classes) are non-degenerate by construction (oracle/gen_golden.py: labels are selected, rows are rejected, classwise_acc and the convex
+    threshold are non-zero, mask2 takes both values; tests/test_oracle_golden.py asserts it on the fixture), and no max-prob the reference
+    thresholds is closer than tr['min_margin'] to its threshold -- so a bf16-operand backbone has to reproduce EVERY mask, selected label and
+    classwise_acc bit of every pass of all 12 iterations."""
+    from oracle.gen_golden import trace_vit_params
     g = golden(name)
+    flex = tr["algorithm"] == "srflexmatch"
     fix = tr["algorithm"] in ("srfixmatch", "srfreematch", "srsoftmatch")
     free = tr["algorithm"] == "srfreematch"
     soft = tr["algorithm"] == "srsoftmatch"
@@ -47,12 +58,15 @@ def test_sr_train_step_trace(golden, name, tr):
     extra = dict(ema_p=tr["ema_p"], use_quantile=tr["use_quantile"], clip_thresh=tr["clip_thresh"], ent_loss_ratio=tr["ent_loss_ratio"]) if free else {}
     if soft:
         extra = dict(ema_p=tr["ema_p"], n_sigma=tr["n_sigma"], dist_uniform=tr["dist_uniform"], dist_align=True, per_class=False)
-    alg = get_algorithm(make_args(algorithm=tr["algorithm"], p_cutoff=tr["p_cutoff"], **extra), vit.vit_tiny_test)
+    alg = get_algorithm(make_args(algorithm=tr["algorithm"], p_cutoff=tr["p_cutoff"], num_classes=C, ulb_dest_len=tr["ulb_dest_len"],
+                                  lr=tr.get("lr", 5e-4), **extra), vit.vit_tiny_test)
     T = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
-    alg.model.load_state_dict(T(synth.synth_params(V.param_shapes(cfg), seed)))
+    P0 = trace_vit_params(cfg, seed, tr.get("head_gain", 1.0), tr.get("hot_classes", 0), tr.get("cold_scale", 0.25))
+    alg.model.load_state_dict(T(P0))
     alg.rewarder.load_state_dict(T(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), seed + 1)))
     alg.generator.load_state_dict(T(synth.synth_params(S.generator_shapes(cfg.embed_dim), seed + 2)))
-    flips = 0
+    names = [nme for nme, _ in alg.model.named_parameters()]
+    flips, worst_dev, grad_rels, sign_stats = 0, 0.0, [], []
     for n, it in enumerate(tr["its"]):
         p = f"it{it}"
         alg.it = it
@@ -63,9 +77,19 @@ def test_sr_train_step_trace(golden, name, tr):
                                for k in range(K + 1)]
         alg.trace = {}
         before = alg.rewarder.flat.clone()
+        pbefore = {nme: v.detach().clone() for nme, v in alg.model.named_parameters()}
         out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))   # idx_ulb dropped for srfixmatch
         alg.out_dict, alg.log_dict = out, log
         assert alg.optimizer.lr_factor() == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        # ---- the step's combined backward (supervised rows of pass 0 + the mask * mask2-weighted strong rows of the LAST pass, through the engine's
+        # hand-written backward) against the reference's autograd gradients of the same step, BEFORE the optimizer consumes them
+        if flex:
+            num = den = 0.0
+            for nme, gv in alg.model.named_grads():
+                gs = g.samp(f"{p}/grad/{nme}")
+                a = samp_of(gv.cpu().numpy(), gs).astype(np.float64)
+                num += float(((a - gs["sample"]) ** 2).sum()); den += float((gs["sample"].astype(np.float64) ** 2).sum())
+            grad_rels.append((num / max(den, 1e-30)) ** 0.5)
         alg.call_hook("after_train_step")
         assert alg.trace["K"] == K
         masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
@@ -75,14 +99,44 @@ def test_sr_train_step_trace(golden, name, tr):
             assert float(log["train/util_ratio"]) == pytest.approx(float(g[f"{p}/log/util_ratio"]), abs=4e-2)
         else:
             flips += int((masks != want).sum())
+        if flex:
+            # what the hook thresholds: the engine's max-probs stay inside the fixture's margin of the reference's, so every comparison
+            # (>= p_cutoff * acc / (2 - acc): mask; >= p_cutoff: select) has the reference's outcome
+            mpv = alg.trace["max_probs"].cpu().numpy().reshape(want.shape)
+            dev = float(np.abs(mpv - g[f"{p}/mask_probs"]).max())
+            worst_dev = max(worst_dev, dev)
+            assert dev < tr["min_margin"], (p, dev)
+            assert np.array_equal(alg.trace["pseudo"].cpu().numpy().reshape(want.shape), g[f"{p}/pseudo_label"]), p
+            assert np.array_equal(masks, want), p
+            if K:
+                r = alg.trace["reward"].cpu().numpy().reshape(K, Bu)
+                np.testing.assert_allclose(r, g[f"{p}/reward"], rtol=0, atol=5e-3)
+                # mask2 = reward >= mean(reward) of the pass (:100-101): identical wherever the reference's reward is clear of its mean
+                clear = np.abs(g[f"{p}/reward"] - g[f"{p}/reward"].mean(axis=1, keepdims=True)) > 1e-2
+                m2 = alg.trace["mask2"].cpu().numpy().reshape(K, Bu)
+                assert clear.mean() > 0.5 and np.array_equal(m2[clear], g[f"{p}/mask2"][clear]), p
         for k_ in ("sup_loss", "unsup_loss", "total_loss"):
             assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
         # AdamW moves every weight by ~lr per step whatever |g| is, so bf16-operand gradient noise turns into a
-        # slowly growing parameter gap vs the fp32 trajectory: tolerance = 2e-2 + 1.5e-2 per full-lr step taken
-        ftol = 2e-2 + 1.5e-2 * sum(1 for j in tr["its"][:n] if j >= tr["num_warmup_iter"])
+        # slowly growing parameter gap vs the fp32 trajectory: tolerance = 2e-2 + 1.5e-2 per full-lr (5e-4) step taken
+        ftol = 2e-2 + 1.5e-2 * (tr.get("lr", 5e-4) / 5e-4) * sum(1 for j in tr["its"][:n] if j >= tr["num_warmup_iter"])
         for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
             assert rel(out["feat"][k_].cpu(), g[f"{p}/feat/{k_}"]) < ftol, (p, k_)
         assert int(not torch.equal(before, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"]), p
+        # ---- direction of the AdamW update: the engine's parameter change of this step against the reference's (its parameters after this
+        # iteration minus after the previous one -- the reference's optimizer only steps at the trace's iterations), on the sampled elements whose
+        # reference gradient is above the noise floor of a bf16-operand backward (>= 10 % of the tensor's rms gradient)
+        if flex and float(g[f"{p}/lr_factor"]) > 0.0:
+            agree = tot = 0
+            for nme, v in alg.model.named_parameters():
+                gs, gg = g.samp(f"{p}/param/{nme}"), g.samp(f"{p}/grad/{nme}")
+                prev = samp_of(P0[nme], gs) if n == 0 else g.samp(f"it{tr['its'][n - 1]}/param/{nme}")["sample"]
+                d_ref = gs["sample"].astype(np.float64) - prev.astype(np.float64)
+                d_eng = samp_of((v.detach() - pbefore[nme]).cpu().numpy(), gs).astype(np.float64)
+                gr = gg["sample"].astype(np.float64)
+                keep = (np.abs(gr) >= 0.1 * np.sqrt((gr ** 2).mean() + 1e-30)) & (d_ref != 0.0)
+                agree += int((np.sign(d_eng[keep]) == np.sign(d_ref[keep])).sum()); tot += int(keep.sum())
+            sign_stats.append((it, agree, tot))
         if soft:
             sm, da = alg.hooks_dict["MaskingHook"], alg.hooks_dict["DistAlignHook"]
             assert float(sm.prob_max_mu_t) == pytest.approx(float(g[f"{p}/mu"]), rel=2e-2)
@@ -102,15 +156,27 @@ def test_sr_train_step_trace(golden, name, tr):
             assert np.array_equal(nz, g[f"{p}/sel_idx"]) and np.array_equal(sel[nz], g[f"{p}/sel_val"]), p
             acc = alg.hooks_dict["MaskingHook"].classwise_acc.cpu().numpy()
             assert np.array_equal(acc.view(np.uint32), g[f"{p}/accs"][-1].view(np.uint32)), p
-    # bf16 logits vs the fp32 reference may flip a row that sits on a threshold; on this trace none does
+    # bf16 logits vs the fp32 reference may flip a row that sits on a threshold; on these traces none does
     assert flips == 0, flips
-    # backbone parameters after 8 AdamW steps (bf16-operand gradients) stay close to the fp32 reference trajectory
-    worst = 0.0
-    for nme, v in alg.model.named_parameters():
-        gs = g.samp(f"it{tr['its'][-1]}/param/{nme}")
-        a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
-        worst = max(worst, float(np.abs(a - gs["sample"]).max()))
-    assert worst < 4e-3, worst      # <= a handful of lr-sized (5e-4) steps
+    if flex:
+        print("\n%s: worst |max-prob - reference| %.2e (margin %.1e); grad rel-L2 per iteration %s; update-sign agreement %s" % (
+            name, worst_dev, tr["min_margin"], ["%.3f" % r for r in grad_rels], ["%d: %d/%d" % t for t in sign_stats]))
+        # the fixture is not degenerate for the engine either: rejections, selections and a non-zero table through train_step
+        allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
+        h = alg.hooks_dict["MaskingHook"]
+        assert 0.2 < allm.mean() < 0.9 and int((h.selected_label != -1).sum()) > 0 and float(h.classwise_acc.max()) > 0
+        # gradients: rel-L2 over the sampled elements of all parameters, every iteration (pre-SR steps: K = 0; SR steps: loss of the LAST pass)
+        assert max(grad_rels[:2]) < 6e-2 and max(grad_rels) < 8e-2, grad_rels
+        ag, tt = sum(t[1] for t in sign_stats), sum(t[2] for t in sign_stats)
+        assert tt > 2000 and ag >= 0.99 * tt, (ag, tt, sign_stats)
+    else:
+        # backbone parameters after the trace's AdamW steps (bf16-operand gradients) stay close to the fp32 reference trajectory
+        worst = 0.0
+        for nme, v in alg.model.named_parameters():
+            gs = g.samp(f"it{tr['its'][-1]}/param/{nme}")
+            a = v.reshape(-1).cpu().numpy()[::gs["stride"]]
+            worst = max(worst, float(np.abs(a - gs["sample"]).max()))
+        assert worst < 4e-3, worst      # <= a handful of lr-sized (5e-4) steps
 
 
 def test_train_loop_and_checkpoint(tmp_path):
@@ -222,13 +288,35 @@ def test_full_size_step_properties():
     from oracle import hooks_ref as H
     NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
                num_warmup_iter=5120)
+    # A random-init backbone with the stock classifier never reaches p_cutoff = 0.95 at 100 classes (weak-row max-probs 0.03-0.1) and an empty
+    # selected_label table keeps every threshold at 0: all masks would be 1 and the table untouched.  So the step starts from a MID-TRAINING hook
+    # state (46 000 of the 50 000 entries selected, the class counts skewed towards the classes this backbone predicts, so their classwise_acc
+    # -- and the convex threshold 0.95 acc / (2 - acc) -- is high; the batch's own entries unselected) and a classifier loud enough (x 24) that
+    # the weak rows' max-probs straddle 0.95 (0.4 .. 1.0 on the CPU oracle): rows are selected, rows are rejected, the table changes.
+    HEAD_GAIN = 24.0
+    P0 = synth.synth_params(V.param_shapes(V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)), 0)
+    P0["head.weight"] = P0["head.weight"] * np.float32(HEAD_GAIN)
+    rs = np.random.Generator(np.random.PCG64(77))
+    w = np.ones(100); w[[97, 11, 45, 20, 84, 90, 26, 52, 35]] = [60, 55, 50, 40, 35, 30, 25, 20, 15]
+    sel0 = rs.choice(100, size=50000, p=w / w.sum()).astype(np.int64)
+    sel0[rs.permutation(50000)[:4000]] = -1
+    b = synth.synth_batch(100, 8, 8, 32, 100, 50000)
+    sel0[b["idx_ulb"]] = -1
+    st0 = H.FlexMatchState(50000, 100, True)
+    st0.selected_label[:] = sel0
+    st0.update()                                   # classwise_acc as the previous step's last masking call left it (utils.py:61)
+    assert st0.classwise_acc.max() == 1.0 and (st0.classwise_acc > 0.3).sum() >= 6
+
     def make():
         alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
-        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+        assert [n for n, _ in alg.model.names_shapes] == list(P0)
+        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in P0.items()})
+        h = alg.hooks_dict["MaskingHook"]
+        h.selected_label = torch.from_numpy(sel0)                       # (the setter recounts the histogram, as load_model does)
+        h.classwise_acc = torch.from_numpy(st0.classwise_acc.copy()).to(DEV)
         alg.it = 30000
         alg.optimizer.sched_step = alg.it
         return alg
-    b = synth.synth_batch(100, 8, 8, 32, 100, 50000)
     cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
     dps = [torch.from_numpy(synth.synth_droppath(900 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
     runs = []
@@ -244,16 +332,30 @@ def test_full_size_step_properties():
     assert K == 8 and tr["logits"].shape[:2] == (9, 24)
     # --- integer work against the oracle on the engine's own numbers
     st = H.FlexMatchState(50000, C, True)
+    st.selected_label[:] = sel0
+    st.classwise_acc[:] = st0.classwise_acc
     mp, mi = tr["max_probs"].cpu().numpy().reshape(9, nu), tr["pseudo"].cpu().numpy().reshape(9, nu)
     idx = b["idx_ulb"]
+    thr_at_reject, allmask = [], []
     for k in range(9):
         probs = np.zeros((nu, C), np.float32)
         probs[np.arange(nu), mi[k]] = mp[k]                      # masking only looks at (max, argmax) of each row
+        acc_k = st.classwise_acc[mi[k]].copy()
         want = st.masking(probs, idx, 0.95)
         assert np.array_equal(tr["masks"][k].cpu().numpy(), want), k
+        thr_at_reject += list((np.float32(0.95) * (acc_k / (np.float32(2.0) - acc_k)))[want == 0.0])
+        allmask.append(want)
     h = alg.hooks_dict["MaskingHook"]
     assert np.array_equal(h.selected_label.cpu().numpy(), st.selected_label)
     assert np.array_equal(h.classwise_acc.cpu().numpy().view(np.uint32), st.classwise_acc.view(np.uint32))
+    # ... and that work was not trivial: rows above and below 0.95, rejected rows (against a non-zero convex threshold), accepted rows, entries
+    # of the batch newly selected in the 50 000-entry table and a class histogram that moved
+    allmask = np.stack(allmask)
+    assert mp.min() < 0.9 and mp.max() > 0.95, (mp.min(), mp.max())
+    assert 0.0 < allmask.mean() < 1.0 and len(thr_at_reject) >= 3 and min(thr_at_reject) > 0.05, (allmask.mean(), thr_at_reject)
+    assert (st.selected_label[idx] != -1).any() and (sel0[idx] == -1).all()
+    assert not np.array_equal(st.classwise_acc, st0.classwise_acc)
+    assert 0.0 < float(log["train/util_ratio"]) <= 1.0
     r = tr["reward"].cpu().numpy().reshape(K, nu)
     assert np.array_equal(tr["mask2"].cpu().numpy().reshape(K, nu), (r >= r.mean(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32))
     assert 0.0 <= r.min() and r.max() <= 1.0
@@ -264,7 +366,7 @@ def test_full_size_step_properties():
     # and the same DropPath draws: pass 0 (labelled rows = gradient rows with activations kept; weak rows = the 105-image launch that is read;
     # strong rows = read or deferred launch, both the production fused chain attn_block -> mlp_fused_proj + ln_next) and the last pass
     # (strong rows = gradient rows).  One 24-image CPU forward of ViT-S/2 takes a few seconds.
-    Pt = {k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()}
+    Pt = {k: torch.from_numpy(v) for k, v in P0.items()}
     x24 = torch.from_numpy(np.concatenate([b["x_lb"], b["x_ulb_w"], b["x_ulb_s"]]))
     plan = alg._plans[(8, 8, 8, True, False)]
     assert plan.inf_cols.numel() * 257 >= vit._FUSED_MLP_MIN_ROWS and plan.rest_cols.numel() * 257 >= vit._FUSED_MLP_MIN_ROWS   # fused launches

@@ -10,7 +10,7 @@ from oracle import optim_ref as O
 from oracle import semireward_ref as S
 from oracle import srflexmatch_ref as SF
 from oracle import vit_ref as V
-from oracle.gen_golden import TRACE, TRACE_FIX
+from oracle.gen_golden import TRACE, TRACE_C100, TRACE_FIX
 from semireward_amd.utils import synth
 
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
@@ -60,7 +60,7 @@ def test_rewarder_generator(golden, tag):
             check_samp(rp[k].numpy(), g.samp(f"{tag}/after{step}/{k}"), 1e-5, 2e-5, k)
 
 
-@pytest.mark.parametrize("tag", ["c10_w", "c100_w", "c10_nw", "c100_b256"])
+@pytest.mark.parametrize("tag", ["c10_w", "c100_w", "c10_nw", "c100_b256", "c100_rej", "c100_rej_nw"])
 def test_flexmatch_hook_bit_exact(golden, tag):
     g = golden("hooks")
     C, U, Bu, steps, warm, seed = [int(v) for v in g[f"{tag}/meta"]]
@@ -74,8 +74,10 @@ def test_flexmatch_hook_bit_exact(golden, tag):
         assert np.array_equal(H.fixed_threshold_mask(probs, 0.95), g[f"{tag}/fixed_mask"][t])
     nz = np.nonzero(st.selected_label != -1)[0]
     assert np.array_equal(nz, g[f"{tag}/sel_idx"]) and np.array_equal(st.selected_label[nz], g[f"{tag}/sel_val"])
-    if tag.startswith("c10_"):     # the small-U fixtures exercise both mask outcomes
+    if tag.startswith("c10_") or tag.startswith("c100_rej"):     # these fixtures exercise both mask outcomes (c100_rej*: at the headline class count)
         assert g[f"{tag}/mask"].min() == 0.0 and g[f"{tag}/mask"].max() == 1.0
+    if tag.startswith("c100_rej"):
+        assert 0.2 < g[f"{tag}/mask"].mean() < 0.9 and g[f"{tag}/classwise_acc"][-1].max() == 1.0
 
 
 @pytest.mark.parametrize("tag", ["b8_c100", "b64_c10", "b256_c100"])
@@ -147,22 +149,23 @@ def k_bias_rows(cfg):
     return lambda idx: (idx >= D) & (idx < 2 * D)
 
 
-@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srfixmatch_trace", TRACE_FIX)])
+@pytest.mark.parametrize("name,tr", [("srflexmatch_trace", TRACE), ("srflexmatch_c100_trace", TRACE_C100), ("srfixmatch_trace", TRACE_FIX)])
 def test_sr_train_step_trace(golden, name, tr):
     """Whole-step control flow (SURVEY A.1-A.7, A.5 boundary iterations) against the reference traces
-    (SRFlexMatch: srflexmatch.py:107-217; SRFixMatch: srfixmatch/fixmatch.py:96-205)."""
+    (SRFlexMatch: srflexmatch.py:107-217, at 10 and at 100 classes; SRFixMatch: srfixmatch/fixmatch.py:96-205)."""
+    from oracle.gen_golden import trace_vit_params
     g = golden(name)
     fix = tr["algorithm"] == "srfixmatch"
     C, Bl, Bu, seed = tr["C"], tr["Bl"], tr["Bu"], tr["seed"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_TINY_TEST)
     Fd = cfg.embed_dim
     orc = SF.SRFlexMatchOracle(
-        cfg, TP(synth.synth_params(V.param_shapes(cfg), seed)),
+        cfg, TP(trace_vit_params(cfg, seed, tr.get("head_gain", 1.0), tr.get("hot_classes", 0), tr.get("cold_scale", 0.25))),
         TP(synth.synth_params(S.rewarder_shapes(Fd, C), seed + 1)),
         TP(synth.synth_params(S.generator_shapes(Fd), seed + 2)),
         num_train_iter=tr["num_train_iter"], start_timing=tr["start_timing"], N_k=tr["N_k"],
         ulb_dest_len=tr["ulb_dest_len"], num_warmup_iter=tr["num_warmup_iter"], p_cutoff=tr["p_cutoff"],
-        algorithm=tr["algorithm"])
+        algorithm=tr["algorithm"], lr=tr.get("lr", 5e-4))
     for n, it in enumerate(tr["its"]):
         p = f"it{it}"
         orc.it = it
@@ -176,6 +179,11 @@ def test_sr_train_step_trace(golden, name, tr):
         if not fix:
             accs = np.stack([q["classwise_acc"] for q in t["passes"]])
             assert np.array_equal(accs.view(np.uint32), g[f"{p}/accs"].view(np.uint32)), p
+            # per pass: the pseudo labels the hooks and the rewarder saw, the rewards of the K scoring calls (:99) and the mask2 the loss received (:100-102)
+            assert np.array_equal(np.stack([q["pseudo_label"].numpy() for q in t["passes"]]), g[f"{p}/pseudo_label"]), p
+            if K:
+                np.testing.assert_allclose(np.stack([q["reward"].numpy().reshape(-1) for q in t["passes"][1:]]), g[f"{p}/reward"], rtol=2e-5, atol=2e-6)
+                assert np.array_equal(np.stack([q["mask2"].numpy() for q in t["passes"][1:]]), g[f"{p}/mask2"]), p
         for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
             assert t[k_] == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=2e-5, abs=2e-6), (p, k_)
         assert t["lr_factor"] == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12), p
@@ -193,9 +201,24 @@ def test_sr_train_step_trace(golden, name, tr):
         if not fix:
             nz = np.nonzero(orc.hook.selected_label != -1)[0]
             assert np.array_equal(nz, g[f"{p}/sel_idx"]) and np.array_equal(orc.hook.selected_label[nz], g[f"{p}/sel_val"])
+    allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
     if fix:      # fixture exercises both mask outcomes
-        allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
         assert 0.05 < allm.mean() < 0.95
+    else:
+        # the FlexMatch fixtures are NOT degenerate: rows are rejected (mask 0) in several iterations, labels are selected from the third
+        # iteration on, classwise_acc is non-zero, the convex threshold p_cutoff * acc / (2 - acc) is non-zero where it rejects, mask2 has both
+        # values, and no max-prob the reference thresholds sits closer than tr['min_margin'] to the threshold it is compared with
+        assert 0.2 < allm.mean() < 0.9
+        third = tr["its"][2]
+        assert len(g[f"it{third}/sel_idx"]) > 0 and g[f"it{third}/accs"].max() > 0
+        assert sum(1 for it in tr["its"] if g[f"it{it}/masks"].min() == 0.0) >= 4
+        m2 = np.concatenate([g[f"it{it}/mask2"].ravel() for it in tr["its"] if int(g[f"it{it}/K"])])
+        assert 0.1 < m2.mean() < 0.9
+        margin = min(min(float(np.abs(g[f"it{it}/mask_probs"] - g[f"it{it}/mask_thr"]).min()), float(np.abs(g[f"it{it}/mask_probs"] - tr["p_cutoff"]).min()))
+                     for it in tr["its"])
+        assert margin >= tr["min_margin"], margin
+        rej = [float(g[f"it{it}/mask_thr"][g[f"it{it}/masks"] == 0.0].min()) for it in tr["its"] if g[f"it{it}/masks"].min() == 0.0]
+        assert min(rej) > 0.0
 
 
 def test_sr_decay_schedule():
@@ -567,3 +590,29 @@ def test_augment_oracle_matches_reference(golden):
             x = A.apply_op(int(o), x, float(v))
         cv, ux, uy = [float(v) for v in g[f"chain/{t}/cut"]]
         assert np.array_equal(A.cutout(x, cv, ux, uy), g[f"chain/{t}/out"]), t
+
+
+def test_augment_oracle_matches_the_whole_reference_transforms(golden):
+    """transform_weak / transform_strong (cv_datasets/cifar.py:34-49) end to end: tests/golden/augment_tv.npz was produced by the op sequence of
+    torchvision's PIL branch on Pillow images (np.pad 'reflect' -> Image.crop -> Image.transpose), the REFERENCE's RandAugment(3, 5) class and
+    torch's ToTensor / Normalize arithmetic (oracle/gen_golden.py:gen_augment_tv says which call stands for which transform; torchvision itself
+    is absent from the build container).  The numpy oracle reproduces bytes and fp32 tensors exactly."""
+    from oracle import augment_ref as A
+    from oracle.gen_golden import synth_image
+    g = golden("augment_tv")
+    mean, std = tuple(float(v) for v in g["meta/mean"]), tuple(float(v) for v in g["meta/std"])
+    flips = 0
+    for n in range(int(g["meta/n"])):
+        seed, S, kind, pad, i, j, flip = [int(v) for v in g[f"case/{n}/meta"]]
+        assert pad == int(S * (1 - 0.875))
+        flips += flip
+        src = synth_image(seed, S, S, kind)
+        assert np.array_equal(A.weak(src, pad, S, i, j, bool(flip), mean, std), g[f"case/{n}/weak"]), n
+        cv, ux, uy = [float(v) for v in g[f"case/{n}/cut"]]
+        x = A.crop_flip(src, pad, S, i, j, bool(flip))
+        for o, v in zip(g[f"case/{n}/ops"], g[f"case/{n}/vals"]):
+            x = A.apply_op(int(o), x, float(v))
+        assert np.array_equal(A.cutout(x, cv, ux, uy), g[f"case/{n}/strong_u8"]), n
+        assert np.array_equal(A.strong(src, pad, S, i, j, bool(flip), g[f"case/{n}/ops"], g[f"case/{n}/vals"], cv, ux, uy, mean, std),
+                              g[f"case/{n}/strong"]), n
+    assert 0 < flips < int(g["meta/n"])
