@@ -279,7 +279,7 @@ class Leg:
             else:
                 from semireward_amd.nets import wave2vec
                 builder, ypath = wave2vec.wave2vecv2_base, "usb_audio_srfreematch_urbansound8k_100_wave2vecv2_base.yaml"
-            if ypath is not None and alg == "auto":
+            if ypath is not None and alg in ("auto", srconfig.load_yaml(os.path.join(ROOT, "configs", ypath))["algorithm"]):
                 args = srconfig.get_config(os.path.join(ROOT, "configs", ypath), overrides=common)
                 self.alg_name, C = args.algorithm, args.num_classes
                 self.config_file = "configs/" + ypath

@@ -743,12 +743,14 @@ _TRACE_BASE = dict(num_train_iter=2000, start_timing=100, N_k=10, ulb_dest_len=2
 # through train_step itself: a louder classifier (`head_gain`, as in the BERT / Wav2Vec2 traces) spreads the max-probs, the cut-off sits inside
 # their range, and a table about the size of the indices the trace touches lets classwise_acc (count / max count incl. the unselected, utils.py:30-36)
 # grow.  seed / p_cutoff were swept with `python -m oracle.gen_golden --search trace` (largest distance of any max-prob from either threshold it
-# is compared with); gen_trace asserts the non-degeneracy it was chosen for.
+# is compared with), then the best candidates were run on the HIP engine (tools/trace_diag.py): the chosen ones keep every engine max-prob closer to
+# the reference's than that max-prob is to its nearer threshold (smallest slack 6.5e-3 / 5.5e-3), so every decision is the reference's by a margin,
+# not by luck; gen_trace asserts the non-degeneracy they were chosen for.
 TRACE = dict(_TRACE_BASE, Bu=8, ulb_dest_len=16, head_gain=4.0, p_cutoff=0.8, seed=119, its=[0, 1, 2, 3, 4, 5, 99, 100, 101, 110, 300, 301], lr=2e-5,
              min_margin=8e-3)
 # C = 100 (the headline class count): 100 random classifier rows spread the argmax over so many classes that no class count grows; `hot_classes`
 # keeps the first 5 classifier rows at full gain and scales the rest by `cold_scale`, so predictions concentrate as they do in a trained model
-TRACE_C100 = dict(TRACE, C=100, head_gain=12.0, hot_classes=5, cold_scale=0.1, p_cutoff=0.7, seed=235, min_margin=1.5e-2)
+TRACE_C100 = dict(TRACE, C=100, head_gain=12.0, hot_classes=5, cold_scale=0.1, p_cutoff=0.8, seed=182, min_margin=1.3e-2)
 # srfixmatch: a fixed threshold of 0.95 would mask every row of a random-init 10-class model; 0.16 exercises both outcomes
 TRACE_FIX = dict(_TRACE_BASE, its=[0, 1, 99, 100, 101, 110], seed=91, p_cutoff=0.16, algorithm="srfixmatch")
 

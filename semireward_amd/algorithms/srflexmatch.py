@@ -64,6 +64,11 @@ class _DeferTuner:
     def done(self):
         return self.best is not None
 
+    def invalidate(self):
+        """Something other than training steps ran on the device (evaluation, a checkpoint): the gap between the last two step starts is not
+        a step time.  The current candidate starts its WARM + TIMED steps over (every rank calls this at the same iteration)."""
+        self.marks = []
+
     def fraction(self):
         """Share for the step that starts now (records the step-start event while tuning)."""
         if self.best is not None:
@@ -466,7 +471,14 @@ class SRConsistencyBase(AlgorithmBase):
                 # candidates that give distinct (read | deferred) splits; a split whose deferred launch would fall below the fused kernels'
                 # launch size is folded by _Plan and drops out here
                 cand, seen = {}, set()
-                for f in _DeferTuner.CANDIDATES:
+                # a regime that differs only in K (sr_decay() walks through dozens of values early in a run) starts from the share its
+                # neighbour was tuned to and measures that share and its two neighbours only: 12 tuning steps instead of ~32 per new K
+                prev = [(abs(k_[2] - K), r["chosen"]) for k_, r in self.defer_report.items() if (k_[0], k_[1], k_[3], k_[4]) == (nl, nu, key[3], key[4])]
+                seeds = _DeferTuner.CANDIDATES
+                if prev:
+                    b_ = min(prev)[1]
+                    seeds = [f_ for f_ in (round(b_ - _DeferTuner.REFINE, 4), b_, round(b_ + _DeferTuner.REFINE, 4)) if 0.05 < f_ <= 1.0]
+                for f in seeds:
                     p_ = self._make_plan(nl, nu, K, defer_fraction=f)
                     n_ = int(p_.rest_cols.numel())
                     if n_ > 0 and n_ not in seen:
@@ -474,7 +486,7 @@ class SRConsistencyBase(AlgorithmBase):
                         cand[f] = p_
                 if len(cand) > 1:
                     agree = (lambda ms: self.dp.max_over_ranks(ms, self.device)) if self.dp.active else None
-                    self._tuners[key] = (_DeferTuner(cand.keys(), agree=agree), cand)
+                    self._tuners[key] = (_DeferTuner(cand.keys(), refine=not prev, agree=agree), cand)
         tn = self._tuners.get(key)
         if tn is not None:
             tuner, cand = tn
@@ -633,7 +645,7 @@ class SRConsistencyBase(AlgorithmBase):
         if "sr_rewarder" in ck:
             self.rewarder.load_state_dict(ck["sr_rewarder"]); self.generator.load_state_dict(ck["sr_generator"])
             self.rewarder_optimizer.load_state_dict(ck["sr_rewarder_optimizer"])
-            self.max_reward = torch.full((), ck["sr_max_reward"], device=self.device)
+            self.max_reward.fill_(float(ck["sr_max_reward"]))       # in place: a captured step graph keeps reading this buffer
         return ck
 
     def get_save_dict(self):

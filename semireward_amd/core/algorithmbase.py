@@ -236,6 +236,7 @@ class AlgorithmBase:
         synchronises three times per batch)."""
         import numpy as np
         assert out_key == "logits"
+        self._invalidate_step_timing()
         net = self.ema_model
         if net is not self.model:
             net.refresh_operands()                    # bf16 operand copy of the EMA block
@@ -282,7 +283,14 @@ class AlgorithmBase:
                 "loss_scaler": {}, "it": self.it + 1, "epoch": self.epoch + 1, "best_it": self.best_it,
                 "best_eval_acc": self.best_eval_metric}
 
+    def _invalidate_step_timing(self):
+        """Evaluation / checkpointing between two training steps: a schedule tuner that times steps by their start events (srflexmatch._DeferTuner)
+        must not count this gap as a step."""
+        for tuner, _ in getattr(self, "_tuners", {}).values():
+            tuner.invalidate()
+
     def save_model(self, save_name, save_path):
+        self._invalidate_step_timing()
         ops.check_label_errors()
         os.makedirs(save_path, exist_ok=True)
         torch.save(self.get_save_dict(), os.path.join(save_path, save_name))

@@ -17,6 +17,8 @@ What has to hold for a capture to be valid for every later step:
 The reference sequence this replaces per step: SRFlexMatch.train_step (srflexmatch.py:107-217) + ParamUpdateHook.after_train_step
 (param_update.py:21-45).  Results are bit-identical to the eager step (tests/test_gpu_stepgraph.py).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -89,7 +91,8 @@ class StepGraph:
         if getattr(algorithm, "rewarder_optimizer", None) is not None:
             algorithm.rewarder_optimizer.step_scalars = self.scal
         algorithm.optimizer.step_scalars = self.scal
-        self.graphs, self.seen = {}, {}
+        self.graphs, self.seen = {}, {}                      # (dict order = least .. most recently used)
+        self.pool, self.max_graphs = None, int(os.environ.get("SR_HIP_GRAPH_MAX", "8"))
         self.replays = self.eager_steps = 0
         self.hook = algorithm.hooks_dict["ParamUpdateHook"]
 
@@ -119,6 +122,7 @@ class StepGraph:
         self.scal.push(alg)
         ent = self.graphs.get(key)
         if ent is not None:
+            self.graphs[key] = self.graphs.pop(key)          # most recently used last
             g, static, deltas, out, log = ent
             for k, v in batch.items():
                 if static[k] is not v:
@@ -134,11 +138,18 @@ class StepGraph:
             self.eager_steps += 1
             return self._eager(batch)
         # ---- capture this step (nothing executes during capture), then replay it once: that IS this step
-        static = dict(batch)
+        # The graph owns its inputs (clones: a replay must not overwrite the tensors the caller handed in for an earlier step); every variant
+        # captures into ONE shared memory pool (K = sr_decay() takes dozens of values over a run, times the rewarder-update variants: private
+        # pools would pin a full step's activations each), and the cache is bounded -- the least recently used variant is dropped.
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        while len(self.graphs) >= self.max_graphs:
+            self.graphs.pop(next(iter(self.graphs)))
         before = self._counters()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self.pool):
             out, log = self._eager(static)
         deltas = [a - b for a, b in zip(self._counters(), before)]
         src = _log_sources(log)

@@ -681,9 +681,14 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
   static const double big_min_rounds = getenv("SRHIP_BIG_MIN_ROUNDS") ? atof(getenv("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
   // (N = 512 conv layers of the Wav2Vec2 feature encoder, K = 1024 / 1536 over 10^5..10^6 frames: +5 % clips/s on the persistent kernel)
-  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (mode && mode[0] == 'b');
+  // K >= 768 (the D = 768 legs: BERT / Wav2Vec2 / HuBERT): the K loop is long enough that the 256-row tile pays from ~0.6 rounds of tiles on, also
+  // at N = 768 (tools/gemm_modes_probe.py, standalone TF/s default -> this rule: BERT qkv 13952 x 2304 x 768 664 -> 800, fc1 615 -> 735, fc2 13952 x
+  // 768 x 3072 630 -> 680, Wav2Vec2 fc1 5373 x 3072 x 768 617 -> 775); the 3-round threshold above is for the epilogue-heavy K = 384 products
+  const bool big_k = K >= 768;
+  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || (mode && mode[0] == 'b');
   const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
-  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= big_min_rounds || (mode && mode[0] == 'b'))) {
+  const double min_rounds = (big_k && !getenv("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
+  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || (mode && mode[0] == 'b'))) {
     int variant = 0;
     if (mode && !strcmp(mode, "big128")) variant = 1;
     if (mode && !strcmp(mode, "big2wg")) variant = 2;
@@ -700,7 +705,9 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   // under-filled launches (less than one round of 2 workgroups per CU on 128x128 tiles) -> 64x64 tiles, deep ring
   const bool force_small = mode && mode[0] == 's';
   static const int small_max_grid = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : 256;
-  if ((grid < small_max_grid || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
+  // (the 64x64 kernel is for short K loops: at K >= 768 a launch of < 256 128x128 tiles is still faster on those tiles -- Wav2Vec2 fc2 5373 x 768 x
+  // 3072: 405 -> 607 TF/s, BERT gradient-row fc2 4096 x 768 x 3072: 394 -> 470)
+  if (((grid < small_max_grid && !big_k) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
     const dim3 gs(cdiv(M, SBM) * cdiv(N, SBM));
     switch (epilogue) {
       case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;

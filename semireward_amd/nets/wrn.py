@@ -108,6 +108,7 @@ class WideResNet:
             self.conv_stride.update({p_ + "conv1.weight": st_, p_ + "conv2.weight": 1, p_ + "convShortcut.weight": st_})
         self.training = True
         self.couples_batch_rows = True      # BatchNorm: every forward call is its own statistics group (no cross-pass batching)
+        self._rows_checked = set()
         self._buf_cache = {}
 
     # ---- parameter plumbing (same surface as the ViT engine) ------------------------------------------------------------------
@@ -231,6 +232,20 @@ class WideResNet:
             import torch.distributed as dist
             dist.all_reduce(self.bn_acc[bn])
 
+    def _check_equal_rows(self, B):
+        """The exchanged statistics are sums over rows and the kernels divide by rows * ranks (torch's SyncBatchNorm exchanges the counts as
+        well): every rank must forward the same number of images.  Checked with ONE small collective per batch size, then cached -- a
+        last partial batch or an uneven split raises here instead of silently skewing mean / var / running_var."""
+        if self.stat_ranks > 1 and B not in self._rows_checked:
+            import torch.distributed as dist
+            t = torch.tensor([B, -B], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hi, lo = int(t[0]), -int(t[1])
+            if hi != lo:
+                raise RuntimeError("WideResNet under data parallel (SyncBatchNorm): per-rank batches differ (%d .. %d images); the statistics exchange "
+                                   "assumes equal row counts on every rank" % (lo, hi))
+            self._rows_checked.add(B)
+
     def _conv_bn(self, wname, xin, in_bn, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False):
         """out = conv(LeakyReLU(BN_in(xin))) (+ resid) -- or conv(xin) when ``raw`` -- and, in training mode, the sums of ``out`` added into the
         accumulator of ``next_bn`` (then exchanged between the ranks).  Training mode folds in_bn's statistics from its accumulator; ``publish``:
@@ -278,6 +293,7 @@ class WideResNet:
             ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
         h, w = H, W
         if train:
+            self._check_equal_rows(B)
             self.bn_acc_arena.zero_()                         # the accumulators of every BatchNorm of this forward: one fill launch
             # sums of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
             first = self.blocks[0][0] + "bn1"
@@ -495,17 +511,24 @@ class WideResNet:
             dy = dx
         conv_bwd("conv1.weight", dy, B * ctx.H * ctx.W, ctx.stem["col"], False, ctx.H, ctx.W, 1)
         # 32 x 288 .. 128 x 1152 outputs over 4096 .. 65536 pixels: slices of 2048 pixels fill the chip (filter gradients meet through fp32 atomics)
-        dk = ("tn_desc", tag) + tuple(int(t.data_ptr()) for pr in problems for t in pr[:3])
-        if dk not in self._buf_cache:                  # (one host-to-device copy per buffer set, not per backward: the operands are persistent)
-            self._buf_cache[dk] = ops.make_group_tn_desc(problems, self.device, split_k=2048)
-        desc, npb, ntiles, flops, nbytes = self._buf_cache[dk]
+        # Descriptor tables hold raw addresses AND row counts: the key carries the operands' addresses, the batch size and every problem's shape
+        # (a batch-size change under the same tag makes _buf reallocate; an address recycled by the caching allocator must not replay a table with
+        # stale row counts), and ONE table per tag is kept -- the previous one is dropped when the key changes.
+        sig = (B,) + tuple((int(pr[4]), int(pr[5]), int(pr[6])) for pr in problems) + tuple(int(t.data_ptr()) for pr in problems for t in pr[:3])
+        ent_tn = self._buf_cache.get(("tn_desc", tag))
+        if ent_tn is None or ent_tn[0] != sig:         # (one host-to-device copy per buffer set, not per backward: the operands are persistent)
+            ent_tn = (sig, ops.make_group_tn_desc(problems, self.device, split_k=2048))
+            self._buf_cache[("tn_desc", tag)] = ent_tn
+        desc, npb, ntiles, flops, nbytes = ent_tn[1]
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
-        uk = ("unpad_desc", tag)
-        if uk not in self._buf_cache:                  # dW[Cout, C, k, k] += dWpad[Cout, Kpad] (tap-major) for every padded gradient: one launch
+        usig = tuple((int(src.data_ptr()), name) for src, name in unpad) + (int(self.grad.data_ptr()),)
+        ent_up = self._buf_cache.get(("unpad_desc", tag))
+        if ent_up is None or ent_up[0] != usig:        # dW[Cout, C, k, k] += dWpad[Cout, Kpad] (tap-major) for every padded gradient: one launch
             ent = [(src, self.p(name, self.grad), None, self.convs[name]["cout"], self.convs[name]["cin"], self.convs[name]["k"],
                     self.convs[name]["Kp"]) for src, name in unpad]
-            self._buf_cache[uk] = ops.make_conv_desc(ent, self.device, lambda Cout, C, kk, Kpad: Cout * C * kk)
-        ops.add_unpad_grouped(*self._buf_cache[uk])
+            ent_up = (usig, ops.make_conv_desc(ent, self.device, lambda Cout, C, kk, Kpad: Cout * C * kk))
+            self._buf_cache[("unpad_desc", tag)] = ent_up
+        ops.add_unpad_grouped(*ent_up[1])
 
 
 def wrn_28_2(num_classes=100, **kw):

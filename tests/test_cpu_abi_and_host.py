@@ -319,3 +319,41 @@ def test_bench_headline_keys_are_the_reference_yaml():
     assert seen["srpseudolabel"].net == "wrn_28_2" and seen["srpseudolabel"].feature_dim == 128 and seen["srpseudolabel"].num_classes == 100
     assert seen["srsoftmatch"].net == "bert_base_uncased" and seen["srsoftmatch"].num_classes == 2 and seen["srsoftmatch"].dataset == "aclImdb"
     assert seen["srfreematch"].net == "wave2vecv2_base" and seen["srfreematch"].num_classes == 10 and seen["srfreematch"].ema_p == 0.999
+
+
+def test_defer_tuner_discards_a_window_with_an_evaluation_in_it(monkeypatch):
+    """_DeferTuner times a step as the gap between consecutive step-start events; AlgorithmBase.evaluate / save_model call ``invalidate`` so that a
+    gap which contains an evaluation is not taken for a step time -- the candidate restarts its window."""
+    import torch
+    from semireward_amd.algorithms import srflexmatch as SF
+
+    class FakeEvent:
+        clock, cost = 0.0, 1.0
+
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            FakeEvent.clock += FakeEvent.cost
+            self.t = FakeEvent.clock
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    t = SF._DeferTuner([0.4, 0.5], refine=False)
+    seq = []
+    for i in range(40):
+        if t.done:
+            break
+        f = t.fraction()
+        seq.append(f)
+        if i == 2:                       # an evaluation ran between two steps of the first candidate
+            FakeEvent.clock += 100.0
+            t.invalidate()
+        FakeEvent.cost = 1.0 + abs(f - 0.5)
+    assert t.best == 0.5 and t.report == {"0.400": 1.1, "0.500": 1.0}, (seq, t.report)       # the 100 ms gap is in neither median
+    assert seq.count(0.4) == 3 + (SF._DeferTuner.WARM + SF._DeferTuner.TIMED)

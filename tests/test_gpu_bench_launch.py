@@ -61,7 +61,7 @@ def test_eight_ranks_complete_the_headline_the_tuner_and_the_exchange_legs():
     ab = o["overlap_allreduce"]
     for tag in ("off", "on", "off_bf16", "rs_ag"):
         assert "error" not in ab[tag] and ab[tag]["ms_per_step"] > 0, (tag, ab[tag])
-    assert o["config"]["step_schedule"]["tuned"] in (True, False)
+    assert 0.0 < o["config"]["step_schedule"]["deferred_share"] <= 1.0          # every rank's tuner finished with the same choice (else: a hang)
 
 
 def test_same_command_under_torch_distributed_run():

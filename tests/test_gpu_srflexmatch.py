@@ -45,8 +45,9 @@ def test_sr_train_step_trace(golden, name, tr):
     """train_step + ParamUpdateHook on the HIP engine against traces of the REFERENCE's own train_step.  The two srflexmatch traces (10 and
     100 classes) are non-degenerate by construction (oracle/gen_golden.py: labels are selected, rows are rejected, classwise_acc and the convex
     threshold are non-zero, mask2 takes both values; tests/test_oracle_golden.py asserts it on the fixture), and no max-prob the reference
-    thresholds is closer than tr['min_margin'] to its threshold -- so a bf16-operand backbone has to reproduce EVERY mask, selected label and
-    classwise_acc bit of every pass of all 12 iterations."""
+    thresholds is closer than tr['min_margin'] to its threshold, while the engine's max-probs stay closer to the reference's than that (per row:
+    deviation < distance to the nearer threshold; candidates were screened on the engine with tools/trace_diag.py) -- so a bf16-operand
+    backbone has to reproduce EVERY mask, selected label and classwise_acc bit of every pass of all 12 iterations."""
     from oracle.gen_golden import trace_vit_params
     g = golden(name)
     flex = tr["algorithm"] == "srflexmatch"
@@ -66,7 +67,7 @@ def test_sr_train_step_trace(golden, name, tr):
     alg.rewarder.load_state_dict(T(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), seed + 1)))
     alg.generator.load_state_dict(T(synth.synth_params(S.generator_shapes(cfg.embed_dim), seed + 2)))
     names = [nme for nme, _ in alg.model.named_parameters()]
-    flips, worst_dev, grad_rels, sign_stats = 0, 0.0, [], []
+    flips, worst_dev, min_slack, grad_rels, sign_stats, m2_clear = 0, 0.0, 1.0, [], [], [0, 0]
     for n, it in enumerate(tr["its"]):
         p = f"it{it}"
         alg.it = it
@@ -103,18 +104,27 @@ def test_sr_train_step_trace(golden, name, tr):
             # what the hook thresholds: the engine's max-probs stay inside the fixture's margin of the reference's, so every comparison
             # (>= p_cutoff * acc / (2 - acc): mask; >= p_cutoff: select) has the reference's outcome
             mpv = alg.trace["max_probs"].cpu().numpy().reshape(want.shape)
-            dev = float(np.abs(mpv - g[f"{p}/mask_probs"]).max())
-            worst_dev = max(worst_dev, dev)
-            assert dev < tr["min_margin"], (p, dev)
+            refp = g[f"{p}/mask_probs"]
+            devs = np.abs(mpv - refp)
+            margin = np.minimum(np.abs(refp - g[f"{p}/mask_thr"]), np.abs(refp - tr["p_cutoff"]))      # to the nearer of the two thresholds, per row
+            worst_dev, min_slack = max(worst_dev, float(devs.max())), min(min_slack, float((margin - devs).min()))
+            assert float(margin.min()) >= tr["min_margin"] and float(devs.max()) < 5e-2, (p, float(margin.min()), float(devs.max()))
+            assert (devs < margin).all(), (p, float((margin - devs).min()))      # every decision is the reference's with room to spare
             assert np.array_equal(alg.trace["pseudo"].cpu().numpy().reshape(want.shape), g[f"{p}/pseudo_label"]), p
             assert np.array_equal(masks, want), p
             if K:
                 r = alg.trace["reward"].cpu().numpy().reshape(K, Bu)
                 np.testing.assert_allclose(r, g[f"{p}/reward"], rtol=0, atol=5e-3)
-                # mask2 = reward >= mean(reward) of the pass (:100-101): identical wherever the reference's reward is clear of its mean
-                clear = np.abs(g[f"{p}/reward"] - g[f"{p}/reward"].mean(axis=1, keepdims=True)) > 1e-2
+                # mask2 = reward >= mean(reward) of the pass (:100-101).  The rewards of a pass sit within a few 1e-2 of their mean (the
+                # rewarder's softmax couples the batch), so: identical wherever the reference's reward is further from its pass mean than
+                # twice the largest reward deviation of that pass (the mean moves by at most that deviation), and exactly consistent with
+                # the engine's own rewards everywhere
+                rg = g[f"{p}/reward"]
+                clear = np.abs(rg - rg.mean(axis=1, keepdims=True)) > 2.0 * np.abs(r - rg).max(axis=1, keepdims=True) + 1e-6
                 m2 = alg.trace["mask2"].cpu().numpy().reshape(K, Bu)
-                assert clear.mean() > 0.5 and np.array_equal(m2[clear], g[f"{p}/mask2"][clear]), p
+                assert np.array_equal(m2[clear], g[f"{p}/mask2"][clear]), p
+                assert np.array_equal(m2, (r >= r.mean(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32)), p
+                m2_clear[0] += int(clear.sum()); m2_clear[1] += clear.size
         for k_ in ("sup_loss", "unsup_loss", "total_loss"):
             assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
         # AdamW moves every weight by ~lr per step whatever |g| is, so bf16-operand gradient noise turns into a
@@ -159,16 +169,18 @@ def test_sr_train_step_trace(golden, name, tr):
     # bf16 logits vs the fp32 reference may flip a row that sits on a threshold; on these traces none does
     assert flips == 0, flips
     if flex:
-        print("\n%s: worst |max-prob - reference| %.2e (margin %.1e); grad rel-L2 per iteration %s; update-sign agreement %s" % (
-            name, worst_dev, tr["min_margin"], ["%.3f" % r for r in grad_rels], ["%d: %d/%d" % t for t in sign_stats]))
+        print("\n%s: worst |max-prob - reference| %.2e, smallest (margin - deviation) %.2e (fixture margin %.1e); grad rel-L2 per iteration %s; update-sign agreement %s; mask2 rows compared with the reference %d / %d" % (
+            name, worst_dev, min_slack, tr["min_margin"], ["%.3f" % r for r in grad_rels], ["%d: %d/%d" % t for t in sign_stats], m2_clear[0], m2_clear[1]))
         # the fixture is not degenerate for the engine either: rejections, selections and a non-zero table through train_step
         allm = np.concatenate([g[f"it{it}/masks"].ravel() for it in tr["its"]])
         h = alg.hooks_dict["MaskingHook"]
         assert 0.2 < allm.mean() < 0.9 and int((h.selected_label != -1).sum()) > 0 and float(h.classwise_acc.max()) > 0
         # gradients: rel-L2 over the sampled elements of all parameters, every iteration (pre-SR steps: K = 0; SR steps: loss of the LAST pass)
-        assert max(grad_rels[:2]) < 6e-2 and max(grad_rels) < 8e-2, grad_rels
+        # (measured on MI355X: 0.005 .. 0.010 in every iteration of both traces; the model-level bound of tests/test_gpu_vit.py is 6e-2)
+        assert max(grad_rels) < 2.5e-2, grad_rels
         ag, tt = sum(t[1] for t in sign_stats), sum(t[2] for t in sign_stats)
         assert tt > 2000 and ag >= 0.99 * tt, (ag, tt, sign_stats)
+        assert m2_clear[0] > 0.5 * m2_clear[1], m2_clear          # most (pass, row) mask2 decisions were compared with the reference's
     else:
         # backbone parameters after the trace's AdamW steps (bf16-operand gradients) stay close to the fp32 reference trajectory
         worst = 0.0
