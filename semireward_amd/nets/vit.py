@@ -120,8 +120,15 @@ class VisionTransformer:
 
     # ---- parameter plumbing ---------------------------------------------------------------------
     def p(self, name, buf=None):
-        o, s = self.offsets[name]
-        return (self.flat if buf is None else buf)[o:o + int(torch.Size(s).numel())]
+        """Flat view of parameter ``name`` inside ``buf`` (default: the parameter block).  Cached per (name, buffer): building a slice view costs
+        ~3 us of host time and a step asks for ~500 of them -- more than half of the step's enqueue time before the cache."""
+        b = self.flat if buf is None else buf
+        pv = self.__dict__.setdefault("_pviews", {})
+        ent = pv.get((name, id(b)))
+        if ent is None:
+            o, s = self.offsets[name]
+            ent = pv[(name, id(b))] = (b, b[o:o + int(torch.Size(s).numel())])     # (holds ``b``: its id stays unique)
+        return ent[1]
 
     def view(self, name, buf=None):
         return self.p(name, buf).view(self.offsets[name][1])
@@ -237,7 +244,9 @@ class VisionTransformer:
         ctx.xmid, ctx.ln1, ctx.ln2 = mk((M, D), f32), mk((M, D), bf16), mk((M, D), bf16)
         ctx.qkv, ctx.ao, ctx.pre = mk((M, 3 * D), bf16), mk((M, D), bf16), mk((M, Hd), bf16)
         ctx.h = mk((M, Hd), bf16)                # GELU output: the X operand of dW_fc2
-        ctx.lse, ctx.st1, ctx.st2 = mk((B, H, N), f32), mk((2, M), f32), mk((2, M), f32)
+        ctx.lse = mk((B, H, N), f32)
+        ctx.st1 = [(t[0], t[1]) for t in mk((2, M), f32)]            # (mean, rstd) rows as ready views: indexing costs host time per launch
+        ctx.st2 = [(t[0], t[1]) for t in mk((2, M), f32)]
         ctx.xhat = torch.empty(B, D, dtype=f32, device=self.device)
         ctx.rstd = torch.empty(B, dtype=f32, device=self.device)
         self._ws[key] = ctx
@@ -282,11 +291,12 @@ class VisionTransformer:
             ops.gemm_nt(ops.EPI_F32, col, P("patch_embed.proj.weight", wb), tok, B * Np, D, Kp)
             ops.patch_assemble(tok, P("patch_embed.proj.bias"), P("cls_token"), P("pos_embed"), x, B, Np, D)
         scale = 64 ** -0.5
+        dst0, dst1 = (droppath.stride(0), droppath.stride(1)) if droppath is not None else (0, 0)      # (a column range of the step's table: strided rows)
         ln_ready = False           # the previous block's fused launch already wrote this block's norm1 output
         for i in range(cfg.depth):
             b = "blocks.%d." % i
-            s1 = droppath[i, 0] if droppath is not None else None
-            s2 = droppath[i, 1] if droppath is not None else None
+            s1 = ops.RawRows(droppath, i * dst0) if droppath is not None else None            # droppath[i, 0], droppath[i, 1] without building views
+            s2 = ops.RawRows(droppath, i * dst0 + dst1) if droppath is not None else None
             if save:
                 ln, qkv, ao = ctx.ln1[i], ctx.qkv[i], ctx.ao[i]
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
@@ -527,11 +537,12 @@ class VisionTransformer:
         lnp = T["ln_part"]
         cb = self.grad_ready_cb            # data parallel only: called with the flat-block range of every finished layer group
         gdone = {g["lo_layer"]: g for g in T["groups"]} if cb is not None else {}
-        ops.cast_scale_rows(dx, dp[cfg.depth - 1, 1] if dp is not None else None, N, T["layers"][cfg.depth - 1]["g2"], M, D)
+        dpr = (lambda i_, j_: ops.RawRows(dp, i_ * dp.stride(0) + j_ * dp.stride(1))) if dp is not None else (lambda i_, j_: None)   # dp[i, j] as a raw pointer
+        ops.cast_scale_rows(dx, dpr(cfg.depth - 1, 1), N, T["layers"][cfg.depth - 1]["g2"], M, D)
         for i in reversed(range(cfg.depth)):
             b = "blocks.%d." % i
             Ti = T["layers"][i]
-            s1 = dp[i, 0] if dp is not None else None
+            s1 = dpr(i, 0)
             # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))));  g2 = bf16(s2 * dx) came from the previous LayerNorm backward
             ops.gemm_nt(ops.EPI_DGELU_BF16, Ti["g2"], self.wT[b + "mlp.fc2.weight"], Ti["dpre"], M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
             ops.gemm_nt(ops.EPI_BF16, Ti["dpre"], self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
@@ -542,7 +553,7 @@ class VisionTransformer:
             ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], Ti["dqkv"], delta, B, N, H, scale)
             ops.gemm_nt(ops.EPI_BF16, Ti["dqkv"], self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
             ops.layernorm_bwd_part(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, lnp[2 * i], LN_REP,
-                                   T["layers"][i - 1]["g2"] if i > 0 else None, dp[i - 1, 1] if dp is not None and i > 0 else None, N, M, D)
+                                   T["layers"][i - 1]["g2"] if i > 0 else None, dpr(i - 1, 1) if i > 0 else None, N, M, D)
             g = gdone.get(i)
             if g is not None:               # layers [i, g.hi_layer) are finished: their weight / bias / LayerNorm gradients, then the hand-over
                 desc, npb, ntiles, flops, nbytes = g["desc"]

@@ -28,6 +28,25 @@ def _p_fast(t):
 _p = _p_checked if _CHECK_ARGS else _p_fast
 
 
+class RawRows:
+    """Element ``off`` (in elements from ``base.data_ptr()``; rows of a strided view are fine, the last dimension must be dense) .. of a device
+    tensor as a bare pointer argument (a per-sample scale row of a [depth, 2, B] table, ...): what
+    ``t[i, j]`` would hand to a launch without building a tensor view (~2 us of host time each, ~100 of them per step).  Holds the base tensor."""
+    __slots__ = ("base", "ptr")
+    is_cuda = True
+
+    def __init__(self, base, off):
+        if _CHECK_ARGS:
+            assert base.is_cuda and base.stride(-1) == 1 and off >= 0
+        self.base, self.ptr = base, base.data_ptr() + off * base.element_size()
+
+    def data_ptr(self):
+        return self.ptr
+
+    def is_contiguous(self):
+        return True
+
+
 _STREAM = None
 
 
