@@ -707,7 +707,9 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   static const int small_max_grid = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : 256;
   // (the 64x64 kernel is for short K loops: at K >= 768 a launch of < 256 128x128 tiles is still faster on those tiles -- Wav2Vec2 fc2 5373 x 768 x
   // 3072: 405 -> 607 TF/s, BERT gradient-row fc2 4096 x 768 x 3072: 394 -> 470)
-  if (((grid < small_max_grid && !big_k) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
+  // ... but only for the D = 768 widths: the ViT-S gradient-row products with a long K (fc2 4112 x 384 x 1536, the dX products with K = 1152 / 1536)
+  // have N = 384 = 3 column tiles of 128 -- 99 workgroups -- and take 2.5 x as long there (12.8 -> 31 us, measured in the step)
+  if (((grid < small_max_grid && !(big_k && N >= 768)) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
     const dim3 gs(cdiv(M, SBM) * cdiv(N, SBM));
     switch (epilogue) {
       case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;
