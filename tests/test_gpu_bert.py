@@ -293,11 +293,15 @@ def test_full_size_step_properties_bert():
     import argparse
     from oracle import hooks_ref as H
     from semireward_amd.algorithms import get_algorithm
-    C, L, nl, nu = 4, 512, 8, 8
-    args = dict(algorithm="srsoftmatch", num_classes=C, num_train_iter=102400, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False, amp=False,
-                optim="AdamW", lr=5e-5, weight_decay=5e-4, layer_decay=0.65, num_warmup_iter=5120, T=0.5, hard_label=True, ema_p=0.999, n_sigma=2,
-                dist_uniform=True, dist_align=True, per_class=False, ulb_dest_len=50000, N_k=10, start_timing=10000, feature_dim=768, sr_lr=5e-4,
-                sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    # the configuration itself comes from the authored yaml of BASELINE configs[3] (IMDB: 2 classes; configs/README.md) through the yaml loader
+    import os
+    from semireward_amd import config as srconfig
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = srconfig.get_config(os.path.join(root, "configs", "usb_nlp_srsoftmatch_aclImdb_20_bert_base.yaml"),
+                            overrides=dict(gpu=0, rank=0, world_size=1, distributed=False, ulb_dest_len=50000))
+    assert a.algorithm == "srsoftmatch" and a.net == "bert_base_uncased" and a.num_classes == 2 and a.use_cat is False and a.batch_size == 8
+    args = vars(a)
+    C, L, nl, nu = a.num_classes, a.max_length, a.batch_size, a.batch_size * a.uratio
     g = torch.Generator().manual_seed(5)
     def tok(n, full):
         lens = torch.full((n,), L) if full else torch.randint(L // 2, L + 1, (n,), generator=g)

@@ -235,11 +235,15 @@ def test_full_size_step_properties_wave2vec_freematch():
     import argparse
     from oracle import hooks_ref as H
     from semireward_amd.algorithms import get_algorithm
-    C, S, nl, nu = 10, 64000, 8, 8
-    args = dict(algorithm="srfreematch", num_classes=C, num_train_iter=102400, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=False, amp=False,
-                optim="AdamW", lr=5e-5, weight_decay=5e-4, layer_decay=0.75, num_warmup_iter=5120, T=0.5, hard_label=True, ema_p=0.999,
-                use_quantile=False, clip_thresh=False, ent_loss_ratio=0.001, p_cutoff=0.95, thresh_warmup=True, ulb_dest_len=50000, N_k=10,
-                start_timing=10000, feature_dim=768, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
+    # the configuration comes from the authored yaml of BASELINE configs[4] (configs/README.md) through the yaml loader
+    import os
+    from semireward_amd import config as srconfig
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = srconfig.get_config(os.path.join(root, "configs", "usb_audio_srfreematch_urbansound8k_100_wave2vecv2_base.yaml"),
+                            overrides=dict(gpu=0, rank=0, world_size=1, distributed=False, ulb_dest_len=50000))
+    assert a.algorithm == "srfreematch" and a.net == "wave2vecv2_base" and a.num_classes == 10 and a.use_cat is False and a.ema_p == 0.999
+    args = vars(a)
+    C, S, nl, nu = a.num_classes, int(a.max_length_seconds * a.sample_rate), a.batch_size, a.batch_size * a.uratio
     g = torch.Generator().manual_seed(16)
     batch = dict(x_lb=torch.randn(nl, S, generator=g), y_lb=torch.randint(0, C, (nl,), generator=g), x_ulb_w=torch.randn(nu, S, generator=g),
                  x_ulb_s=torch.randn(nu, S, generator=g))

@@ -289,11 +289,13 @@ def test_full_size_step_properties_wrn():
     params = synth_wrn_params(wcfg, 5)
 
     def make(p_cutoff):
-        args = argparse.Namespace(
-            algorithm="srpseudolabel", num_classes=C, num_train_iter=1048576, epoch=1, ema_m=0.999, ulb_loss_ratio=1.0, use_cat=True, amp=False,
-            optim="SGD", lr=0.03, momentum=0.9, weight_decay=1e-3, layer_decay=1.0, num_warmup_iter=0, p_cutoff=p_cutoff, unsup_warm_up=0.4,
-            N_k=10, start_timing=20000, feature_dim=Fd, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False,
-            T=0.5, hard_label=True)
+        # the authored yaml of BASELINE configs[0] (configs/README.md) through the yaml loader; only the cut-off is the test's
+        import os
+        from semireward_amd import config as srconfig
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        args = srconfig.get_config(os.path.join(root, "configs", "classic_cv_srpseudolabel_cifar100_400_wrn_28_2.yaml"),
+                                   overrides=dict(gpu=0, rank=0, world_size=1, distributed=False, p_cutoff=p_cutoff))
+        assert (args.algorithm, args.net, args.num_classes, args.batch_size, args.feature_dim, args.optim) == ("srpseudolabel", "wrn_28_2", C, Bl, Fd, "SGD")
         alg = get_algorithm(args, wrn.wrn_28_2)
         sd = {k: torch.from_numpy(v) for k, v in params.items()}
         alg.model.load_state_dict(sd)
