@@ -589,6 +589,9 @@ def worker(a):
             try:
                 os.environ.update(env)
                 leg = Leg(a, ctx, net=a.net, img=a.img, bu=a.bu, bl=a.bl, regime=a.regime, alg=a.alg)
+                # same step schedule as the headline leg (its tuned deferred share): the legs differ in the gradient exchange only, and none
+                # of them spends ~30 tuning steps (each with a blocking rank agreement) before its timed region
+                leg.alg.defer_share = out["config"].get("step_schedule", {}).get("deferred_share")
                 o = leg.run(max(4, a.steps // 2), 2, 3, roofline=False)
                 ab[tag] = {"ms_per_step": o["ms_per_step"], "value": o["value"], "allreduce_ms_per_step": o.get("allreduce_ms_per_step"),
                            "note": {"on": "allreduce_ms_per_step = what is left exposed behind the backward (event pair around all_reduce_grads)",

@@ -215,6 +215,7 @@ class SRConsistencyBase(AlgorithmBase):
             self.dp.install_overlap(self.model)
         self._plans = {}
         self._tuners = {}                      # plan key -> (_DeferTuner, {share: _Plan}) while the deferred share of that regime is being tuned
+        self.defer_share = None                # a share handed in (e.g. the one an earlier leg of a bench was tuned to): no tuning steps
         self.defer_report = {}                 # plan key -> what the tuner measured and chose
         self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
         # gradient-row forward on a second HIP stream (SR_OVERLAP_GRAD_ROWS=0 serialises it behind the inference forward)
@@ -466,8 +467,8 @@ class SRConsistencyBase(AlgorithmBase):
         if key not in self._plans:
             if self.elide_unread_rows and not getattr(self.model, "rows_independent", False):
                 raise ValueError("elide_unread_rows needs a backbone without batch statistics (ViT / BERT / Wav2Vec2 engines)")
-            self._plans[key] = self._make_plan(nl, nu, K)
-            if _DEFER_AUTOTUNE and self.defer_unread_rows and self._plans[key].rest_cols.numel() > 0:
+            self._plans[key] = self._make_plan(nl, nu, K, defer_fraction=self.defer_share)
+            if _DEFER_AUTOTUNE and self.defer_share is None and self.defer_unread_rows and self._plans[key].rest_cols.numel() > 0:
                 # candidates that give distinct (read | deferred) splits; a split whose deferred launch would fall below the fused kernels'
                 # launch size is folded by _Plan and drops out here
                 cand, seen = {}, set()

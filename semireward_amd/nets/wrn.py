@@ -116,6 +116,9 @@ class WideResNet:
         """Flat view of parameter ``name`` inside ``buf`` (default: the parameter block).  Cached per (name, buffer): building a slice view costs
         ~3 us of host time and a step asks for ~500 of them -- more than half of the step's enqueue time before the cache."""
         b = self.flat if buf is None else buf
+        if not (b is self.flat or b is self.grad or b is getattr(self, "flat_bf16", None)):
+            o, s = self.offsets[name]                     # some other block (optimizer state, a test's copy): no entry is kept for it
+            return b[o:o + int(torch.Size(s).numel())]
         pv = self.__dict__.setdefault("_pviews", {})
         ent = pv.get((name, id(b)))
         if ent is None:
