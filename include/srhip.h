@@ -38,6 +38,16 @@ enum {
 int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_scale, int rows_per_sample, const void* aux_in, void* aux_out,
                   int ldaux, float alpha, float beta, void* stream);
+/* The tile kernel srhip_gemm_nt picks for a product (host logic only, no launch): the 128 x 128 LDS-DMA ring kernel, the 64 x 64 deep-ring kernel
+ * for launches that would leave most CUs idle, or the persistent 256-row kernel.  Exported so that a test can pin the decision per shape family
+ * (the nn.Linear products of vit.py:93-98,105,69-75 at ViT-S width and of the HF encoders behind bert.py:34 / wave2vecv2.py:44 at D = 768). */
+#define SRHIP_GEMM_PLAN_TILE128 0
+#define SRHIP_GEMM_PLAN_SMALL64 1
+#define SRHIP_GEMM_PLAN_BIG256 2
+#define SRHIP_GEMM_PLAN_BIG128 3
+#define SRHIP_GEMM_PLAN_BIG2WG 4
+int srhip_gemm_nt_plan(int epilogue, int M, int N, int K, float beta);
+
 
 /* SRHIP_EPI_RESID_F32 with nn.Dropout on the branch: C(f32)[M,N] = resid (f32, ldresid; NULL: C) + dropout(acc + bias) -- the
  * ``LayerNorm(x + dropout(dense(.)))`` of BertSelfOutput / BertOutput (reached from semilearn/nets/bert/bert.py:34) before the LayerNorm.

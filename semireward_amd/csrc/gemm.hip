@@ -639,6 +639,56 @@ static void launch_big(const GemmArgs& g, int variant, hipStream_t s) {
 
 }  // namespace
 
+// Which kernel a product goes to (the decision of srhip_gemm_nt, also exported as srhip_gemm_nt_plan so that a test can pin it: a rule written for
+// one family of shapes has caught another before -- DESIGN 6f).  Returns SRHIP_GEMM_PLAN_*; *splits = K splits of the 128 x 128 kernel.
+static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_out) {
+  const int grid = cdiv(M, BM) * cdiv(N, BN);
+  // split-K: weight-gradient products (small M x N, long K = tokens) would otherwise fill a few dozen of the 256 CUs.
+  // Only the accumulating fp32 epilogue (beta == 1) can be split; ~512 workgroups are targeted.
+  int splits = 1;
+  const int nkt = K / BK;
+  if (epilogue == SRHIP_EPI_F32 && beta == 1.0f && grid < 128 && nkt >= 16) splits = min(min(cdiv(256, grid), nkt / 8), 32);
+  splits = cdiv(nkt, cdiv(nkt, splits));
+  if (splits_out) *splits_out = splits;
+  // large problems go to the persistent 256-row kernel (tuning switches: SRHIP_GEMM=tile|big128|big256)
+  static const char* mode = getenv("SRHIP_GEMM");
+  const bool force_tile = mode && mode[0] == 't';
+  // measured (tools/microbench.py, M = 51400): N >= 1024 -> 256x256 persistent kernel wins (fc1 152 -> 144 us, 8192^3
+  // 775 -> 1064 TF); N = 384 products are epilogue/HBM bound and slightly better on the 128x128 kernel (2 WGs/CU).
+  // The persistent kernel runs 256 workgroups over 256x256 tiles: below ~3 full rounds of tiles its round quantisation costs more than the
+  // larger tile saves (the split launches of a training step: 32 639 x 1152 = 640 tiles = 2.5 -> 3 rounds; on the 128x128 kernel 2313 tiles
+  // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
+  static const double big_min_rounds = getenv("SRHIP_BIG_MIN_ROUNDS") ? atof(getenv("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
+  // (N = 512 conv layers of the Wav2Vec2 feature encoder, K = 1024 / 1536 over 10^5..10^6 frames: +5 % clips/s on the persistent kernel)
+  // K >= 768 (the D = 768 legs: BERT / Wav2Vec2 / HuBERT): the K loop is long enough that the 256-row tile pays from ~0.6 rounds of tiles on, also
+  // at N = 768 (tools/gemm_modes_probe.py, standalone TF/s default -> this rule: BERT qkv 13952 x 2304 x 768 664 -> 800, fc1 615 -> 735, fc2 13952 x
+  // 768 x 3072 630 -> 680, Wav2Vec2 fc1 5373 x 3072 x 768 617 -> 775); the 3-round threshold above is for the epilogue-heavy K = 384 products
+  const bool big_k = K >= 768;
+  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || (mode && mode[0] == 'b');
+  const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
+  const double min_rounds = (big_k && !getenv("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
+  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || (mode && mode[0] == 'b'))) {
+    if (mode && !strcmp(mode, "big128")) return SRHIP_GEMM_PLAN_BIG128;
+    if (mode && !strcmp(mode, "big2wg")) return SRHIP_GEMM_PLAN_BIG2WG;
+    return SRHIP_GEMM_PLAN_BIG256;
+  }
+  // under-filled launches (less than one round of 2 workgroups per CU on 128x128 tiles) -> 64x64 tiles, deep ring
+  // (the 64x64 kernel is for short K loops: at K >= 768 a launch of < 256 128x128 tiles is still faster on those tiles -- Wav2Vec2 fc2 5373 x 768 x
+  // 3072: 405 -> 607 TF/s, BERT gradient-row fc2 4096 x 768 x 3072: 394 -> 470)
+  // ... but only for the D = 768 widths: the ViT-S gradient-row products with a long K (fc2 4112 x 384 x 1536, the dX products with K = 1152 / 1536)
+  // have N = 384 = 3 column tiles of 128 -- 99 workgroups -- and take 2.5 x as long there (12.8 -> 31 us, measured in the step)
+  const bool force_small = mode && mode[0] == 's';
+  static const int small_max_grid = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : 256;
+  if (((grid < small_max_grid && !(big_k && N >= 768)) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32)
+    return SRHIP_GEMM_PLAN_SMALL64;
+  return SRHIP_GEMM_PLAN_TILE128;
+}
+
+extern "C" int srhip_gemm_nt_plan(int epilogue, int M, int N, int K, float beta) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK)) return SR_EINVAL;
+  return gemm_plan(epilogue, M, N, K, beta, nullptr);
+}
+
 static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                         int M, int N, int K, const float* bias, const float* row_scale, int rows_per_sample,
                         const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, uint32_t drop_key, uint32_t drop_thresh,
@@ -661,37 +711,13 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
                  (N % 128) == 0 && (ldc % 8) == 0 && (epilogue != SRHIP_EPI_GELU_BF16 || !aux_out || (ldaux % 4) == 0);
   const int grid = cdiv(M, BM) * cdiv(N, BN);
   hipStream_t s = (hipStream_t)stream;
-  // split-K: weight-gradient products (small M x N, long K = tokens) would otherwise fill a few dozen of the 256 CUs.
-  // Only the accumulating fp32 epilogue (beta == 1) can be split; ~512 workgroups are targeted.
   int splits = 1;
+  const int plan = gemm_plan(epilogue, M, N, K, beta, &splits);
   const int nkt = K / BK;
-  if (epilogue == SRHIP_EPI_F32 && beta == 1.0f && grid < 128 && nkt >= 16) {
-    splits = min(min(cdiv(256, grid), nkt / 8), 32);
-  }
   g.ksplit_tiles = cdiv(nkt, splits);
-  splits = cdiv(nkt, g.ksplit_tiles);
   const dim3 grid3(grid, splits);
-  // large problems go to the persistent 256-row kernel (tuning switches: SRHIP_GEMM=tile|big128|big256)
-  static const char* mode = getenv("SRHIP_GEMM");
-  const bool force_tile = mode && mode[0] == 't';
-  // measured (tools/microbench.py, M = 51400): N >= 1024 -> 256x256 persistent kernel wins (fc1 152 -> 144 us, 8192^3
-  // 775 -> 1064 TF); N = 384 products are epilogue/HBM bound and slightly better on the 128x128 kernel (2 WGs/CU).
-  // The persistent kernel runs 256 workgroups over 256x256 tiles: below ~3 full rounds of tiles its round quantisation costs more than the
-  // larger tile saves (the split launches of a training step: 32 639 x 1152 = 640 tiles = 2.5 -> 3 rounds; on the 128x128 kernel 2313 tiles
-  // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
-  static const double big_min_rounds = getenv("SRHIP_BIG_MIN_ROUNDS") ? atof(getenv("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
-  // (N = 512 conv layers of the Wav2Vec2 feature encoder, K = 1024 / 1536 over 10^5..10^6 frames: +5 % clips/s on the persistent kernel)
-  // K >= 768 (the D = 768 legs: BERT / Wav2Vec2 / HuBERT): the K loop is long enough that the 256-row tile pays from ~0.6 rounds of tiles on, also
-  // at N = 768 (tools/gemm_modes_probe.py, standalone TF/s default -> this rule: BERT qkv 13952 x 2304 x 768 664 -> 800, fc1 615 -> 735, fc2 13952 x
-  // 768 x 3072 630 -> 680, Wav2Vec2 fc1 5373 x 3072 x 768 617 -> 775); the 3-round threshold above is for the epilogue-heavy K = 384 products
-  const bool big_k = K >= 768;
-  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || (mode && mode[0] == 'b');
-  const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
-  const double min_rounds = (big_k && !getenv("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
-  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || (mode && mode[0] == 'b'))) {
-    int variant = 0;
-    if (mode && !strcmp(mode, "big128")) variant = 1;
-    if (mode && !strcmp(mode, "big2wg")) variant = 2;
+  if (plan == SRHIP_GEMM_PLAN_BIG256 || plan == SRHIP_GEMM_PLAN_BIG128 || plan == SRHIP_GEMM_PLAN_BIG2WG) {
+    const int variant = plan == SRHIP_GEMM_PLAN_BIG256 ? 0 : (plan == SRHIP_GEMM_PLAN_BIG128 ? 1 : 2);
     switch (epilogue) {
       case SRHIP_EPI_BF16: launch_big<SRHIP_EPI_BF16>(g, variant, s); break;
       case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, variant, s); break;
@@ -702,14 +728,7 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
     SR_CHECK_LAUNCH();
     return SR_OK;
   }
-  // under-filled launches (less than one round of 2 workgroups per CU on 128x128 tiles) -> 64x64 tiles, deep ring
-  const bool force_small = mode && mode[0] == 's';
-  static const int small_max_grid = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : 256;
-  // (the 64x64 kernel is for short K loops: at K >= 768 a launch of < 256 128x128 tiles is still faster on those tiles -- Wav2Vec2 fc2 5373 x 768 x
-  // 3072: 405 -> 607 TF/s, BERT gradient-row fc2 4096 x 768 x 3072: 394 -> 470)
-  // ... but only for the D = 768 widths: the ViT-S gradient-row products with a long K (fc2 4112 x 384 x 1536, the dX products with K = 1152 / 1536)
-  // have N = 384 = 3 column tiles of 128 -- 99 workgroups -- and take 2.5 x as long there (12.8 -> 31 us, measured in the step)
-  if (((grid < small_max_grid && !(big_k && N >= 768)) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32) {
+  if (plan == SRHIP_GEMM_PLAN_SMALL64) {
     const dim3 gs(cdiv(M, SBM) * cdiv(N, SBM));
     switch (epilogue) {
       case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;

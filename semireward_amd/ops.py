@@ -169,6 +169,17 @@ def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, r
           rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
 
 
+GEMM_PLAN_NAMES = {0: "tile128", 1: "small64", 2: "big256", 3: "big128", 4: "big2wg"}
+
+
+def gemm_nt_plan(epi, M, N, K, beta=0.0):
+    """Which tile kernel srhip_gemm_nt picks for this product (host logic, no launch; srhip_gemm_nt_plan)."""
+    rc = int(_lib.lib().srhip_gemm_nt_plan(epi, M, N, K, beta))
+    if rc < 0:
+        _lib.check(rc, "srhip_gemm_nt_plan")
+    return GEMM_PLAN_NAMES[rc]
+
+
 GROUP_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
                     ("ldb", "<i4"), ("ldc", "<i4"), ("tile_start", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"), ("pad2", "<i4")]
 

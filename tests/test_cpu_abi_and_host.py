@@ -357,3 +357,33 @@ def test_defer_tuner_discards_a_window_with_an_evaluation_in_it(monkeypatch):
         FakeEvent.cost = 1.0 + abs(f - 0.5)
     assert t.best == 0.5 and t.report == {"0.400": 1.1, "0.500": 1.0}, (seq, t.report)       # the 100 ms gap is in neither median
     assert seq.count(0.4) == 3 + (SF._DeferTuner.WARM + SF._DeferTuner.TIMED)
+
+
+def test_gemm_tile_dispatch_is_pinned_per_shape_family(monkeypatch):
+    """srhip_gemm_nt_plan (host logic of srhip_gemm_nt, no launch): which tile kernel every product family of the legs goes to.  A dispatch rule
+    written for the D = 768 legs once caught the ViT-S gradient-row products as well (99 workgroups of 128 x 128 instead of 390 of 64 x 64:
+    12.8 -> 31 us per launch, found only in the round's rocprofv3 stats) -- this table makes such a change visible on the CPU."""
+    from semireward_amd import ops
+    for v in ("SRHIP_GEMM", "SRHIP_BIG_MIN_ROUNDS", "SRHIP_SMALL_MAX_GRID"):
+        assert v not in os.environ, "tuning switch set: the table below is the default dispatch"
+    want = {
+        # ViT-S (D = 384), the 16 gradient images of a step (4112 rows): latency-bound launches -> 64 x 64 tiles wherever 128 x 128 would not fill the chip
+        ("vit grad fc2 / proj fwd", ops.EPI_RESID_F32, 4112, 384, 1536): "small64", ("vit grad proj", ops.EPI_RESID_F32, 4112, 384, 384): "small64",
+        ("vit grad fc1^T dX", ops.EPI_BF16, 4112, 384, 1536): "small64", ("vit grad qkv^T dX", ops.EPI_BF16, 4112, 384, 1152): "small64",
+        ("vit grad fc1", ops.EPI_GELU_BF16, 4112, 1536, 384): "tile128", ("vit grad fc2^T dGELU", ops.EPI_DGELU_BF16, 4112, 1536, 384): "tile128",
+        ("vit grad qkv", ops.EPI_BF16, 4112, 1152, 384): "tile128", ("vit 257th-token rows", ops.EPI_BF16, 105, 1152, 384): "small64",
+        # ViT-S inference launches when the fused kernels are off: persistent kernel from 3 rounds of 256 x 256 tiles on
+        ("vit qkv 200 images", ops.EPI_BF16, 51400, 1152, 384): "big256", ("vit qkv 127 images", ops.EPI_BF16, 32639, 1152, 384): "tile128",
+        ("vit proj 200 images", ops.EPI_RESID_F32, 51400, 384, 384): "tile128",
+        # D = 768 (BERT / Wav2Vec2 / HuBERT): persistent kernel from 0.6 rounds on, 128 x 128 (not 64 x 64) below
+        ("bert qkv", ops.EPI_BF16, 13952, 2304, 768): "big256", ("bert proj", ops.EPI_RESID_F32, 13952, 768, 768): "big256",
+        ("bert fc1", ops.EPI_GELU_BF16, 13952, 3072, 768): "big256", ("bert fc2", ops.EPI_RESID_F32, 13952, 768, 3072): "big256",
+        ("bert grad fc2", ops.EPI_RESID_F32, 4096, 768, 3072): "tile128", ("bert grad fc1", ops.EPI_GELU_BF16, 4096, 3072, 768): "big256",
+        ("w2v fc1", ops.EPI_GELU_BF16, 5373, 3072, 768): "big256", ("w2v fc2", ops.EPI_RESID_F32, 5373, 768, 3072): "tile128",
+        # fp32-accumulating products (weight gradients outside the grouped launch) never leave the 128 x 128 kernel (split-K lives there)
+        ("dW small", ops.EPI_F32, 384, 1536, 4160): "tile128",
+    }
+    got = {k: ops.gemm_nt_plan(k[1], k[2], k[3], k[4], beta=1.0 if k[1] == ops.EPI_F32 else 0.0) for k in want}
+    assert got == want, {k[0]: (got[k], want[k]) for k in want if got[k] != want[k]}
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt_plan(ops.EPI_BF16, 128, 128, 100)          # K % 32 != 0, as srhip_gemm_nt refuses it
