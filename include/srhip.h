@@ -47,6 +47,11 @@ int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, 
 #define SRHIP_GEMM_PLAN_BIG128 3
 #define SRHIP_GEMM_PLAN_BIG2WG 4
 int srhip_gemm_nt_plan(int epilogue, int M, int N, int K, float beta);
+/* Launches of fewer than n 128 x 128 tiles go to the 64 x 64 deep-ring kernel (default 256 = one round of the chip; K >= 768 products at N >= 768
+ * excepted).  The small tiles are the latency choice for a chain of dependent launches that has the chip to itself; a training step whose
+ * row-streaming inference launches own most CUs meanwhile sets a low n (fewer, fatter workgroups).  n < 0: query only.  Returns the previous value.
+ * Process-wide (one process per GPU, train.py:344), not thread-safe. */
+int srhip_gemm_small_max_grid(int n);
 
 
 /* SRHIP_EPI_RESID_F32 with nn.Dropout on the branch: C(f32)[M,N] = resid (f32, ldresid; NULL: C) + dropout(acc + bias) -- the

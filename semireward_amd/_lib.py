@@ -20,6 +20,7 @@ P, I, F, L, Dbl, U = c_void_p, c_int, c_float, c_long, c_double, c_uint
 SIGNATURES = {
     "srhip_gemm_nt": (I, [I, P, I, P, I, P, I, I, I, I, P, P, I, P, P, I, F, F, P]),
     "srhip_gemm_nt_plan": (I, [I, I, I, I, F]),
+    "srhip_gemm_small_max_grid": (I, [I]),
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_gemm_tn_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_attn_fwd": (I, [P, P, P, I, I, I, F, P]),

@@ -535,6 +535,9 @@ class SRConsistencyBase(AlgorithmBase):
             nl, nu = y_lb.shape[0], x_ulb_w.shape[0]
             imgs = torch.cat((x_lb, x_ulb_w, x_ulb_s)).contiguous()                              # :113
         K = self.sr_decay() if it > self.start_timing else 0                                     # :147, :75
+        # tile choice of the small GEMMs of the gradient rows: with K > 0 the inference launches of the K passes own most CUs while they run
+        # (fewer, fatter workgroups win: 4.86 vs 4.95 ms per step); with K = 0 the chain has the chip to itself (64 x 64 tiles: 3.21 vs 3.57 ms)
+        ops.gemm_small_max_grid(ops.GEMM_SMALL_CONTENDED if (K > 0 and self.defer_unread_rows) else ops.GEMM_SMALL_ALONE)
         ph = self._phase_mark if _PHASES else (lambda name: None)
         ph("start")
         L, Fe, ctx = self._forward_passes(imgs, nl, nu, K)

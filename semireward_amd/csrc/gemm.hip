@@ -639,6 +639,8 @@ static void launch_big(const GemmArgs& g, int variant, hipStream_t s) {
 
 }  // namespace
 
+static int g_small_max_grid = 256;      // srhip_gemm_small_max_grid (one process per GPU, one launching thread: a plain int)
+
 // Which kernel a product goes to (the decision of srhip_gemm_nt, also exported as srhip_gemm_nt_plan so that a test can pin it: a rule written for
 // one family of shapes has caught another before -- DESIGN 6f).  Returns SRHIP_GEMM_PLAN_*; *splits = K splits of the 128 x 128 kernel.
 static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_out) {
@@ -678,10 +680,21 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   // ... but only for the D = 768 widths: the ViT-S gradient-row products with a long K (fc2 4112 x 384 x 1536, the dX products with K = 1152 / 1536)
   // have N = 384 = 3 column tiles of 128 -- 99 workgroups -- and take 2.5 x as long there (12.8 -> 31 us, measured in the step)
   const bool force_small = mode && mode[0] == 's';
-  static const int small_max_grid = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : 256;
+  // The threshold is a run-time setting (srhip_gemm_small_max_grid): 64 x 64 tiles are the LATENCY choice -- 390 instead of 99 workgroups for a
+  // 4112 x 384 product, 12.8 instead of 31 us with the chip to itself (the K = 0 regime: 3.21 vs 3.57 ms per step) -- but while the row-streaming
+  // launches of the deferred rows own most CUs, fewer and fatter workgroups win (K = 8 headline: 4.86 vs 4.95 ms, ViT-S/16@224 4.07 vs 4.13;
+  // DESIGN 6f), so the step sets it per regime.  SRHIP_SMALL_MAX_GRID pins it for tuning.
+  static const int small_env = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : -1;
+  const int small_max_grid = small_env >= 0 ? small_env : g_small_max_grid;
   if (((grid < small_max_grid && !(big_k && N >= 768)) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32)
     return SRHIP_GEMM_PLAN_SMALL64;
   return SRHIP_GEMM_PLAN_TILE128;
+}
+
+extern "C" int srhip_gemm_small_max_grid(int n) {
+  const int prev = g_small_max_grid;
+  if (n >= 0) g_small_max_grid = n;
+  return prev;
 }
 
 extern "C" int srhip_gemm_nt_plan(int epilogue, int M, int N, int K, float beta) {

@@ -180,6 +180,18 @@ def gemm_nt_plan(epi, M, N, K, beta=0.0):
     return GEMM_PLAN_NAMES[rc]
 
 
+GEMM_SMALL_ALONE, GEMM_SMALL_CONTENDED = 256, 40      # srhip_gemm_small_max_grid: chain alone on the chip / beside the deferred rows' launches
+_small_max_grid = None
+
+
+def gemm_small_max_grid(n):
+    """Run-time threshold of the 64 x 64-tile kernel (srhip_gemm_small_max_grid); cached so that a step sets it with no call when unchanged."""
+    global _small_max_grid
+    if n != _small_max_grid:
+        _lib.lib().srhip_gemm_small_max_grid(int(n))
+        _small_max_grid = n
+
+
 GROUP_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
                     ("ldb", "<i4"), ("ldc", "<i4"), ("tile_start", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"), ("pad2", "<i4")]
 

@@ -387,3 +387,13 @@ def test_gemm_tile_dispatch_is_pinned_per_shape_family(monkeypatch):
     assert got == want, {k[0]: (got[k], want[k]) for k in want if got[k] != want[k]}
     with pytest.raises(RuntimeError):
         ops.gemm_nt_plan(ops.EPI_BF16, 128, 128, 100)          # K % 32 != 0, as srhip_gemm_nt refuses it
+    # the run-time threshold a step with K > 0 sets (srhip_gemm_small_max_grid): the gradient-row products move to 128 x 128 tiles, the tiny
+    # 257th-token launch keeps its 64 x 64 tiles, nothing else moves; back at the default the table above holds again
+    ops.gemm_small_max_grid(ops.GEMM_SMALL_CONTENDED)
+    try:
+        moved = {k[0] for k in want if ops.gemm_nt_plan(k[1], k[2], k[3], k[4], beta=1.0 if k[1] == ops.EPI_F32 else 0.0) != want[k]}
+        assert moved == {"vit grad fc2 / proj fwd", "vit grad proj", "vit grad fc1^T dX", "vit grad qkv^T dX"}, moved
+        assert ops.gemm_nt_plan(ops.EPI_RESID_F32, 4112, 384, 1536) == "tile128"
+    finally:
+        ops.gemm_small_max_grid(ops.GEMM_SMALL_ALONE)
+    assert {k: ops.gemm_nt_plan(k[1], k[2], k[3], k[4], beta=1.0 if k[1] == ops.EPI_F32 else 0.0) for k in want} == want
