@@ -470,6 +470,20 @@ class Leg:
                      "ridge_flop_per_byte": ridge, "tflops": fl / (ms * 1e-3) / 1e12, "ms_per_step_in_kernel": ms / prof_steps,
                      "measured_over": "%d instrumented steps run right after the timed regions (same process, same inputs)" % prof_steps,
                      "all_gemm_kernels": {"tflops": tfl / (tms * 1e-3) / 1e12, "launches": tn, "ms_per_step": tms / prof_steps}})
+        # the other instrumented kernels of the step, same measurement (event pairs minus the calibrated pair overhead), each against the roof
+        # that bounds it: the row-streaming attention launch, the GEMMs of the gradient rows, the grouped weight-gradient launch
+        others = []
+        for kn, (kfl, kms_raw, kn_l, kbytes) in sorted(pk.items(), key=lambda kv: -kv[1][1]):
+            if kn == name or kn_l == 0 or kbytes <= 0:
+                continue
+            kms = max(kms_raw - kn_l * ovh_ms, 0.5 * kms_raw)
+            if kfl / kbytes < ridge:
+                a_, pk_, un_, bd_ = kbytes / (kms * 1e-3) / 1e9, HBM_PEAK_TBS * 1e3, "GB/s", "hbm"
+            else:
+                a_, pk_, un_, bd_ = kfl / (kms * 1e-3) / 1e12, MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            others.append({"kernel": kn, "bound": bd_, "achieved": a_, "peak": pk_, "unit": un_, "frac": a_ / pk_, "launches": kn_l,
+                           "avg_launch_us": 1e3 * kms / kn_l, "ms_per_step_in_kernel": kms / prof_steps})
+        roof["other_kernels"] = others[:6]
         return roof
 
 

@@ -101,13 +101,14 @@ class _GemmProfile:
     def __init__(self):
         self.recs = []          # (event0, event1, flops, kernel name)
 
+    _KERNEL = {"tile128": "gemm_nt_kernel<%d>", "small64": "gemm_small_kernel<%d>", "big256": "gemm_big_kernel<%d, 8, 2>",
+               "big128": "gemm_big_kernel<%d, 4, 2>", "big2wg": "gemm_big_kernel<%d, 8, 1>"}
+
     @classmethod
     def kernel_name(cls, epi, M, N, K):
-        if epi != EPI_F32 and (N >= 1024 or (N >= 512 and K >= 1024 and M >= 65536)) and M >= 1024 and (-(-M // 256)) * (-(-N // 256)) >= 3 * 256:
-            return "gemm_big_kernel<%d, 8, 2>" % epi
-        if epi != EPI_F32 and -(-M // 128) * -(-N // 128) < 256:
-            return "gemm_small_kernel<%d>" % epi
-        return "gemm_nt_kernel<%d>" % epi
+        """The device kernel srhip_gemm_nt launches for this product: asked of the library itself (srhip_gemm_nt_plan, incl. the run-time
+        small-tile threshold the step has set), not mirrored here."""
+        return cls._KERNEL[gemm_nt_plan(epi, M, N, K, 1.0 if epi == EPI_F32 else 0.0)] % epi
 
     @staticmethod
     def gemm_bytes(epi, M, N, K, aux_in, aux_out, beta):
