@@ -571,14 +571,14 @@ int srhip_fc_bwd(const float* dlogits, const float* feat, const float* Wc, float
 int srhip_sgd_flat(float* p, float* g, float* buf, float* ema, const void* chunk_table, int nchunks, long long n, float lr, float momentum,
                    float grad_scale, const float* clip_coef, double ema_m, int first_step, int zero_grad, void* stream);
 
-/* HIP stream confined to a subset of the compute units (hipExtStreamCreateWithCUMask) -- the step's second stream: the workgroups of the
- * row-streaming inference kernels own a CU each for ~100 us, and launched where they may land on every CU they make each small launch of
- * the critical chain wait for one of them to retire (the reference has one CUDA stream: semilearn/core/algorithmbase.py train loop).
- * cu_mask: bit i = compute unit i in the driver's numbering, `words` 32-bit words; *stream_out receives a hipStream_t. */
-int srhip_stream_create_cu_mask(const unsigned* cu_mask, int words, void** stream_out);
-int srhip_stream_destroy(void* stream);
-/* Diagnostic: n one-wave workgroups spinning spin_ticks of the 100 MHz clock; out[2 i] = XCD, out[2 i + 1] = HW_ID register of workgroup i. */
-int srhip_cu_probe(int* out, int n, int spin_ticks, void* stream);
+/* Kernel-execution timing for the benchmark's roofline object (no counterpart in the reference, which times whole iterations:
+ * semilearn/core/hooks/timer.py).  While enabled, every launch of this library is issued with a (start, stop) event pair bound to the
+ * dispatch itself, so srhip_prof_elapsed_ms returns what `rocprofv3 --kernel-trace` reports for the same launches: execution time
+ * without dispatch latency or event packets.  Entry points are numbered in launch order since the last srhip_prof_enable(1).
+ * These three calls are host-side only (no stream argument); srhip_prof_elapsed_ms needs a synchronised device. */
+int srhip_prof_enable(int on);                                   /* returns the number of launches recorded so far */
+int srhip_prof_count(void);
+int srhip_prof_elapsed_ms(int first, int last, float* ms_sum);   /* HOST pointer: sum over the launches [first, last) */
 
 #ifdef __cplusplus
 }

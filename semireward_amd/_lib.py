@@ -82,9 +82,9 @@ SIGNATURES = {
     "srhip_sr_target": (I, [P, P, P, I, I, P]),
     "srhip_label_error": (I, [P, I, P]),
     "srhip_index_error": (I, [P, I, P]),
-    "srhip_stream_create_cu_mask": (I, [P, I, P]),
-    "srhip_stream_destroy": (I, [P]),
-    "srhip_cu_probe": (I, [P, I, I, P]),
+    "srhip_prof_enable": (I, [I]),
+    "srhip_prof_count": (I, []),
+    "srhip_prof_elapsed_ms": (I, [I, I, P]),
     "srhip_adam_flat": (I, [P, P, P, P, L, F, F, F, F, I, P]),
     "srhip_adamw_flat": (I, [P, P, P, P, P, P, P, I, P, P, F, F, F, F, I, Dbl, F, P, I, P]),
     "srhip_clip_grad_ws_floats": (I, []),

@@ -27,12 +27,12 @@ from .semireward import FlatAdam, Generator, Rewarder, cosine_target, label_dim
 from .utils import SSL_Argument, str2bool
 
 _PHASES = os.environ.get("SR_PHASES", "0") != "0"
-_SCORE_ON_SIDE = os.environ.get("SR_SCORE_ON_SIDE", "1") != "0"      # tuning switch: the max_reward scoring launch under the backward
+_SCORE_ON_SIDE = True         # the max_reward scoring launch runs on the side stream under the backward (DESIGN: -55 us of serial tail)
 # Share of the inference images that run on the second stream (see _Plan).  SR_DEFER_FRACTION=<f> pins it; otherwise it is TUNED per
-# (batch, K, backbone) in the first steps of a regime (_DeferTuner) -- SR_DEFER_AUTOTUNE=0 falls back to the fixed _DEFER_SEED.
-_DEFER_SEED = 0.475           # measured optimum of ViT-S/2 at 8 / 8 / 8, K = 8 on one MI355X (DESIGN 6b); the tuner's middle candidate
+# (batch, K, backbone) in the first steps of a regime (_DeferTuner).
+_DEFER_SEED = 0.475           # measured optimum of ViT-S/2 at 8 / 8 / 8, K = 8 on one MI355X; the tuner's middle candidate
 _DEFER_FIXED = float(os.environ["SR_DEFER_FRACTION"]) if "SR_DEFER_FRACTION" in os.environ else None
-_DEFER_AUTOTUNE = os.environ.get("SR_DEFER_AUTOTUNE", "1") != "0" and _DEFER_FIXED is None
+_DEFER_AUTOTUNE = _DEFER_FIXED is None
 _DEFER_FRACTION = _DEFER_FIXED if _DEFER_FIXED is not None else _DEFER_SEED
 
 
@@ -96,28 +96,6 @@ class _DeferTuner:
         return self.cur
 
 
-class _OwnStreamScope:
-    """Run a step on ``stream`` (ordered after the caller's current stream on entry, the caller's stream ordered after it on exit)."""
-
-    def __init__(self, stream):
-        self.stream = stream
-
-    def __enter__(self):
-        self.outer = torch.cuda.current_stream()
-        self.stream.wait_stream(self.outer)
-        self.ctx = torch.cuda.stream(self.stream)
-        self.ctx.__enter__()
-        self.pin = ops.stream_scope()
-        self.pin.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        self.pin.__exit__(*a)
-        self.ctx.__exit__(*a)
-        self.outer.wait_stream(self.stream)
-        return False
-
-
 class _Plan:
     """Row bookkeeping of one step: every column is one (pass, image) row of the batched forward; ``grad_cols`` are the
     rows whose logits enter the loss (they are run with activations kept), all other rows run in inference mode."""
@@ -165,7 +143,6 @@ class _Plan:
         self.inf_img = t([cols_img[c] for c in inf_cols], torch.int32)
         self.rest_img = t([cols_img[c] for c in rest_cols], torch.int32)
         self.ncols = len(cols_img)
-        self.mixed_cols = self.mixed_img = None      # gradient columns first (forward_mixed), built on first use
 
     @classmethod
     def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False, rows_per_col=None,
@@ -219,18 +196,11 @@ class SRConsistencyBase(AlgorithmBase):
         self.defer_report = {}                 # plan key -> what the tuner measured and chose
         self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
         # gradient-row forward on a second HIP stream (SR_OVERLAP_GRAD_ROWS=0 serialises it behind the inference forward)
-        self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", os.environ.get("SR_OVERLAP_GRAD_ROWS", "1") != "0")) \
-            and torch.cuda.is_available()
+        # (args.overlap_grad_rows = False / args.defer_unread_rows = False: the serial schedule, one stream -- tests and A/B runs)
+        self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", True)) and torch.cuda.is_available()
         self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
-        # the rows nothing reads: optionally on a stream of their own that is confined to SR_REST_CUS compute units (ops.masked_stream)
-        rest_cus = int(os.environ.get("SR_REST_CUS", "0"))
-        self._rest_stream = ops.masked_stream(rest_cus, self.device) if (self.overlap_grad_rows and rest_cus > 0) else None
-        self._rest_after_grad = os.environ.get("SR_REST_AFTER_GRAD", "1") != "0"
-        # hipExtStreamCreateWithCUMask only makes BLOCKING streams (they synchronise with the NULL stream, torch's default current stream):
-        # with one in play the step itself runs on a non-blocking stream of its own, joined to the caller's stream at both ends
-        self._main_stream = torch.cuda.Stream(device=self.device) if self._rest_stream is not None else None
         # rows nothing downstream reads (see _Plan) go behind the gradient rows on the second stream; the step end waits for them
-        self.defer_unread_rows = self.overlap_grad_rows and os.environ.get("SR_DEFER_UNREAD_ROWS", "1") != "0"
+        self.defer_unread_rows = self.overlap_grad_rows and bool(getattr(args, "defer_unread_rows", True))
         # opt-in: do not compute the rows nothing reads (see _Plan.cat_passes); never on by default -- the reference computes them
         self.elide_unread_rows = bool(getattr(args, "elide_unread_rows", os.environ.get("SR_ELIDE_UNREAD_ROWS", "0") != "0"))
         self._rest_done = None
@@ -277,37 +247,6 @@ class SRConsistencyBase(AlgorithmBase):
         scatter = getattr(m, "scatter_outputs", False)
         logits = torch.empty(pl.ncols, C, dtype=torch.float32, device=self.device)
         feats = torch.empty(pl.ncols, D, dtype=torch.float32, device=self.device)
-        if _vit.MIXED_FWD and m.supports_mixed(pl.ncols):
-            # ONE forward over all (pass, image) columns, gradient columns first: every row takes the big inference launches and the
-            # backward operands of the leading rows are kept by the kernels themselves (nets/vit.py forward_mixed; opt-in, see there).
-            if pl.mixed_cols is None:
-                pl.mixed_cols = torch.cat((pl.grad_cols, pl.inf_cols))
-                pl.mixed_img = torch.cat((pl.grad_img, pl.inf_img)).contiguous()
-            nr_ = pl.rest_cols.numel()
-            side_ = self._side_stream if (self.overlap_grad_rows and nr_) else None
-            dp_mixed, dp_rest_ = sel(pl.mixed_cols, 0), (sel(pl.rest_cols, ng_ + ni_) if nr_ else None)
-            if side_ is not None:                     # the unread rows: second stream, from the start of the step (see below)
-                ready_ = torch.cuda.Event()
-                ready_.record(torch.cuda.current_stream())
-            lg, ft, ctx = m.forward_mixed(imgs, pl.mixed_img, dp_mixed, pl.grad_cols.numel())
-            logits.index_copy_(0, pl.mixed_cols, lg)
-            feats.index_copy_(0, pl.mixed_cols, ft)
-            if nr_ and side_ is None:
-                lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest_, save=False, buftag="r")
-                logits.index_copy_(0, pl.rest_cols, lg_r)
-                feats.index_copy_(0, pl.rest_cols, ft_r)
-            elif nr_:
-                side_.wait_event(ready_)
-                for t_ in (logits, feats, dp_rest_, imgs):
-                    if torch.is_tensor(t_) and not capturing:
-                        t_.record_stream(side_)
-                with torch.cuda.stream(side_), ops.stream_scope():
-                    lg_r, ft_r, _ = m.forward_features(imgs, pl.rest_img, dp_rest_, save=False, buftag="r")
-                    logits.index_copy_(0, pl.rest_cols, lg_r)
-                    feats.index_copy_(0, pl.rest_cols, ft_r)
-                    self._rest_done = torch.cuda.Event()
-                    self._rest_done.record(side_)
-            return logits, feats, ctx
         # The gradient-carrying rows (16 of 216 images at the reference batch) run on a SECOND HIP stream: their launches are
         # 100-400 workgroups of latency-bound work (14-28 us each, 1.6 ms per step back to back) that fit beside the tails of
         # the 200-image inference launches.  Both forwards only read the parameters; they write disjoint workspaces.
@@ -351,14 +290,7 @@ class SRConsistencyBase(AlgorithmBase):
                                                      **(dict(out=(logits, feats, pl.grad_cols)) if scatter else {}))
                 grad_done = torch.cuda.Event()
                 grad_done.record(side)
-            rs = self._rest_stream if self._rest_stream is not None else side
-            if nr and rs is not side:
-                rs.wait_event(grad_done if self._rest_after_grad else ready)
-                for t_ in (logits, feats, dp_rest, imgs, getattr(imgs, "ids", None), getattr(imgs, "key_len", None),
-                           getattr(imgs, "seq_len", None)):
-                    if torch.is_tensor(t_) and not capturing:
-                        t_.record_stream(rs)
-            with torch.cuda.stream(rs), ops.stream_scope():
+            with torch.cuda.stream(side), ops.stream_scope():
                 if nr:
                     # Rows whose outputs nothing reads before the step ends (strong / labelled rows of the passes whose loss the
                     # reference discards): 60 % of the forward work, off the critical path.  The masks, losses and the latency-bound
@@ -370,7 +302,7 @@ class SRConsistencyBase(AlgorithmBase):
                         logits.index_copy_(0, pl.rest_cols, lg_r)
                         feats.index_copy_(0, pl.rest_cols, ft_r)
                     self._rest_done = torch.cuda.Event()
-                    self._rest_done.record(rs)
+                    self._rest_done.record(side)
             # The gradient rows are joined LATER (_join_grad): masks, pseudo labels and reward scores only read the weak rows of the launch
             # above, so that chain (~0.3 ms of tiny sequential launches) runs while the second stream still works on the gradient rows.
             self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, None if scatter else pl.grad_cols)
@@ -398,12 +330,7 @@ class SRConsistencyBase(AlgorithmBase):
             feats.index_copy_(0, cols, ft_g)
 
     def _step_scope(self):
-        # (tried and measured on MI355X, both without gain: running the step on a high-priority stream -- the hardware offers two levels and
-        # a small launch still waits for a 100-us workgroup of the other stream to retire -- and confining the second stream to a CU subset
-        # with hipExtStreamCreateWithCUMask, which slows the full-chip launches by more than it speeds the small ones up)
-        if self._rest_stream is None:
-            return ops.stream_scope()
-        return _OwnStreamScope(self._main_stream)
+        return ops.stream_scope()
 
     def _phase_mark(self, name):
         """Tuning aid (SR_PHASES=1): GPU timestamps (events on the step's stream) + host timestamps of the phases of train_step."""

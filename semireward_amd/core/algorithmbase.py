@@ -185,6 +185,14 @@ class AlgorithmBase:
     def train_step(self, *a, **k):
         raise NotImplementedError
 
+    def _check_device_flags(self):
+        """The error conditions the kernels record on the device instead of raising mid-stream, read where the host may wait: an out-of-range
+        label / idx_ulb (IndexError at the offending call in the reference), unequal per-rank batches under SyncBatchNorm (nets/wrn.py)."""
+        ops.check_label_errors()
+        chk = getattr(self.model, "check_equal_rows", None)
+        if chk is not None:
+            chk()
+
     # ---- outer loop (algorithmbase.py:346-375) -------------------------------------------------------
     def train(self, batches=None):
         self.model.train()
@@ -205,9 +213,9 @@ class AlgorithmBase:
                 # out-of-range label / idx_ulb (IndexError at the offending call in the reference): the device flag is read at the logging
                 # cadence, where the log scalars synchronise anyway -- bad data stops training within num_log_iter steps, not at the epoch end
                 if self.num_log_iter and self.it % self.num_log_iter == 0:
-                    ops.check_label_errors()
+                    self._check_device_flags()
             self.call_hook("after_train_epoch")
-            ops.check_label_errors()        # IndexError of nn.Embedding / F.one_hot in the reference; the device flag is read where the host may wait
+            self._check_device_flags()
         self.call_hook("after_run")
 
     # ---- evaluation (algorithmbase.py:377-457) ----------------------------------------------------------------
@@ -291,7 +299,7 @@ class AlgorithmBase:
 
     def save_model(self, save_name, save_path):
         self._invalidate_step_timing()
-        ops.check_label_errors()
+        self._check_device_flags()
         os.makedirs(save_path, exist_ok=True)
         torch.save(self.get_save_dict(), os.path.join(save_path, save_name))
 

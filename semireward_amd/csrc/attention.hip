@@ -562,7 +562,7 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, int H,
     const size_t sm = (size_t)NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
     auto kern = attn_fwd_kernel<NKT, VAR>;
     if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, av);
+    SR_LAUNCH(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, av);
     SR_CHECK_LAUNCH();
     return SR_OK;
   });
@@ -587,9 +587,9 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
     // rows share the chip -- every split re-stages K / V / Q / dO; alone on the chip (K = 0 regime) split 3 wins by 1 %)
     int split = 1;
     while (B * H * split * 2 < 128 && split * BWD_NW < nt16) ++split;
-    static const char* force = getenv("SRHIP_ATTN_BWD_SPLIT");
+    static const char* force = SR_TUNE_ENV("SRHIP_ATTN_BWD_SPLIT");
     if (force && atoi(force) > 0) split = atoi(force);
-    hipLaunchKernelGGL(kern, dim3(B * H, split, 2), dim3(BWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
+    SR_LAUNCH(kern, dim3(B * H, split, 2), dim3(BWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)d_out, lse, (bf16_t*)dqkv, delta_ws, N, H, scale, av);
     SR_CHECK_LAUNCH();
     return SR_OK;

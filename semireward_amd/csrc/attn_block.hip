@@ -434,8 +434,8 @@ int launch(const AbArgs& a, hipStream_t s) {
   // head groups per image: as many (1, 2, 3 or 6) as keep the launch within one workgroup per CU (SRHIP_AB_SPLIT overrides)
   int split = 1;
   for (int c : {2, 3, 6}) if (a.B * c <= 256) split = c;
-  if (const char* e = getenv("SRHIP_AB_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 3 || v == 6) split = v; }
-  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(512), smem, s, a);
+  if (const char* e = SR_TUNE_ENV("SRHIP_AB_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 3 || v == 6) split = v; }
+  SR_LAUNCH(kern, dim3(a.B, split), dim3(512), smem, s, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -455,7 +455,7 @@ extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, con
   a.scale = scale; a.B = B; a.osc = out_scale;
   hipStream_t s = (hipStream_t)stream;
 #ifdef SRHIP_TUNING
-  switch (getenv("SRHIP_AB_DEBUG") ? atoi(getenv("SRHIP_AB_DEBUG")) : 0) {
+  switch (SR_TUNE_ENV("SRHIP_AB_DEBUG") ? atoi(SR_TUNE_ENV("SRHIP_AB_DEBUG")) : 0) {
     case 1: return N == 257 ? launch<257, 1>(a, s) : launch<197, 1>(a, s);
     case 2: return N == 257 ? launch<257, 2>(a, s) : launch<197, 2>(a, s);
     case 3: return N == 257 ? launch<257, 3>(a, s) : launch<197, 3>(a, s);
@@ -468,7 +468,7 @@ extern "C" int srhip_attn_block_fused(const void* xn_bf16, const void* Wqkv, con
   }
 #endif
   // (A/B on one box: 41.5 -> 40.8 us per 105 images at N = 197, no difference at N = 257 -- unlike the fused MLP launch, where it is 5 %)
-  static const int spread = getenv("SRHIP_ATTN_SPREAD") ? atoi(getenv("SRHIP_ATTN_SPREAD")) : 1;
+  static const int spread = SR_TUNE_ENV("SRHIP_ATTN_SPREAD") ? atoi(SR_TUNE_ENV("SRHIP_ATTN_SPREAD")) : 1;
   if (spread) return N == 257 ? launch<257, 32>(a, s) : launch<197, 32>(a, s);
   return N == 257 ? launch<257>(a, s) : launch<197>(a, s);
 }

@@ -207,7 +207,7 @@ extern "C" int srhip_augment(const unsigned char* src, int n_src, int H0, int W0
   if (!src || !ip || !dp || !scratch || !out || !mean3 || !std3 || B <= 0 || S <= 1 || S > MAXS || pad < 0 || pad >= H0 || pad >= W0 || n_src <= 0)
     return SR_EINVAL;
   if (H0 + 2 * pad < S || W0 + 2 * pad < S) return SR_EINVAL;
-  hipLaunchKernelGGL(augment_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, src, H0, W0, S, pad, ip, dp, scratch, out, out_u8, mean3[0],
+  SR_LAUNCH(augment_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, src, H0, W0, S, pad, ip, dp, scratch, out, out_u8, mean3[0],
                      mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   SR_CHECK_LAUNCH();
   return SR_OK;

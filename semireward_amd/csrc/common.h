@@ -1,7 +1,11 @@
 // Shared device helpers for libsrhip (gfx950 / CDNA4 only: wave = 64, MFMA 16x16x32 bf16).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+
+#include <tuple>
+#include <utility>
 
 #define SR_OK 0
 #define SR_EINVAL (-1)
@@ -141,3 +145,36 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Tuning switches (tile splits, knock-outs, schedule variants for tools/microbench.py and the A/B scripts) exist in the tuning build only
+// (SRHIP_TUNING_BUILD=1 -> -DSRHIP_TUNING).  The shipped library reads two environment variables, both test hooks: SRHIP_GEMM (pins the GEMM
+// tile kernel so that tests/test_gpu_kernels.py reaches every kernel with every epilogue) and SRHIP_FLEXMATCH_GENERAL (the global-memory
+// FlexMatch path that tables too large for LDS take).
+#ifdef SRHIP_TUNING
+#include <stdlib.h>
+#define SR_TUNE_ENV(name) getenv(name)
+#else
+#define SR_TUNE_ENV(name) ((const char*)nullptr)
+#endif
+
+// Every launch of the library: the plain launch, or -- while bench.py's roofline pass has profiling on (prof.hip) -- the same launch with a
+// (start, stop) event pair bound to the dispatch, whose elapsed time is the kernel's own execution time.
+extern bool g_sr_prof_on;
+bool sr_prof_take(hipEvent_t* es, hipEvent_t* ee);
+template <typename... P, size_t... I, typename... A>
+static inline void sr_launch_timed_(void (*kern)(P...), std::index_sequence<I...>, dim3 g, dim3 b, unsigned sm, hipStream_t s, hipEvent_t es,
+                                    hipEvent_t ee, A&&... a) {
+  std::tuple<P...> params{static_cast<P>(a)...};          // the arguments converted to the kernel's parameter types
+  void* ptrs[] = {(void*)&std::get<I>(params)...};
+  (void)hipExtLaunchKernel((const void*)kern, g, b, ptrs, sm, s, es, ee, 0);
+}
+template <typename... P, typename... A>
+static inline void sr_launch_timed(void (*kern)(P...), dim3 g, dim3 b, unsigned sm, hipStream_t s, hipEvent_t es, hipEvent_t ee, A&&... a) {
+  sr_launch_timed_(kern, std::index_sequence_for<P...>{}, g, b, sm, s, es, ee, static_cast<A&&>(a)...);
+}
+#define SR_LAUNCH(kern, grid, block, sm, stream, ...)                                                                \
+  do {                                                                                                              \
+    hipEvent_t es__, ee__;                                                                                          \
+    if (g_sr_prof_on && sr_prof_take(&es__, &ee__)) sr_launch_timed(kern, grid, block, sm, stream, es__, ee__, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, sm, stream, __VA_ARGS__);                                            \
+  } while (0)

@@ -316,7 +316,7 @@ extern "C" int srhip_embed_ln_fwd(const long long* ids, int ld_ids, const int* s
   if (!ids || !word || !pos || !type0 || !x || !x_bf16 || B <= 0 || L <= 0 || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
   hipStream_t s = (hipStream_t)stream;
-#define CALL(NV) hipLaunchKernelGGL(embed_ln_fwd_kernel<NV>, dim3(cdiv((long)B * L, 4)), dim3(256), 0, s, ids, ld_ids, seq_index, word, pos, type0, \
+#define CALL(NV) SR_LAUNCH(embed_ln_fwd_kernel<NV>, dim3(cdiv((long)B * L, 4)), dim3(256), 0, s, ids, ld_ids, seq_index, word, pos, type0, \
                                     gamma, beta, eps, x, (bf16_t*)x_bf16, mean, rstd, B, L, dr)
   DISPATCH_NV(D, CALL)
 #undef CALL
@@ -331,7 +331,7 @@ extern "C" int srhip_embed_ln_bwd(const float* dy, const long long* ids, int ld_
   if (!dy || !ids || !mean || !rstd || !dword || !dpos || !dtype0 || !dgamma || !dbeta || B <= 0 || L <= 0) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
   hipStream_t s = (hipStream_t)stream;
-#define CALL(NV) hipLaunchKernelGGL(embed_ln_bwd_kernel<NV>, dim3(cdiv((long)B * L, 32)), dim3(256), 0, s, dy, ids, ld_ids, seq_index, word, pos, \
+#define CALL(NV) SR_LAUNCH(embed_ln_bwd_kernel<NV>, dim3(cdiv((long)B * L, 32)), dim3(256), 0, s, dy, ids, ld_ids, seq_index, word, pos, \
                                     type0, mean, rstd, gamma, dword, dpos, dtype0, dgamma, dbeta, B, L, pad_id, dr)
   DISPATCH_NV(D, CALL)
 #undef CALL
@@ -343,7 +343,7 @@ extern "C" int srhip_postln_fwd(const float* y, const float* gamma, const float*
                                 float* rstd, int M, int D, void* stream) {
   if (!y || !x || !x_bf16 || M <= 0 || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-#define CALL(NV) hipLaunchKernelGGL(postln_fwd_kernel<NV>, dim3(cdiv(M, 8)), dim3(256), 0, s, y, gamma, beta, eps, x, (bf16_t*)x_bf16, mean, rstd, M)
+#define CALL(NV) SR_LAUNCH(postln_fwd_kernel<NV>, dim3(cdiv(M, 8)), dim3(256), 0, s, y, gamma, beta, eps, x, (bf16_t*)x_bf16, mean, rstd, M)
   DISPATCH_NV(D, CALL)
 #undef CALL
   SR_CHECK_LAUNCH();
@@ -359,9 +359,9 @@ static int postln_bwd_impl(const float* dy, const float* y, const float* mean, c
   const bool small = M < 16384;       // few rows: 8 instead of 32 per workgroup (see ln_bwd_kernel)
 #define CALL(NV)                                                                                                                                    \
   do {                                                                                                                                              \
-    if (small) hipLaunchKernelGGL((postln_bwd_kernel<NV, 2>), dim3(cdiv(M, 8)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16,     \
+    if (small) SR_LAUNCH((postln_bwd_kernel<NV, 2>), dim3(cdiv(M, 8)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16,     \
                                   dgamma, dbeta, M, dr, part, n_rep);                                                                               \
-    else hipLaunchKernelGGL((postln_bwd_kernel<NV, 8>), dim3(cdiv(M, 32)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16, dgamma, \
+    else SR_LAUNCH((postln_bwd_kernel<NV, 8>), dim3(cdiv(M, 32)), dim3(256), 0, s, dy, y, mean, rstd, gamma, dx, (bf16_t*)dx_bf16, dgamma, \
                             dbeta, M, dr, part, n_rep);                                                                                             \
   } while (0)
   DISPATCH_NV(D, CALL)
@@ -386,7 +386,7 @@ extern "C" int srhip_meanpool_fwd(const float* x, float* feat, const int* seq_le
                                   float drop_scale, void* stream) {
   if (!x || !feat || B <= 0 || L <= 0 || D % 64 || (long)B * L * D >= (1L << 32)) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_thresh ? drop_scale : 1.0f};
-  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, D / 64), dim3(256), 0, (hipStream_t)stream, x, feat, seq_len, L, D, dr);
+  SR_LAUNCH(meanpool_fwd_kernel, dim3(B, D / 64), dim3(256), 0, (hipStream_t)stream, x, feat, seq_len, L, D, dr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -395,20 +395,20 @@ extern "C" int srhip_meanpool_bwd(const float* dfeat, float* dx, const int* seq_
   const long n = (long)B * L * D;
   if (!dfeat || !dx || B <= 0 || L <= 0 || D <= 0 || n >= (1L << 32)) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_thresh ? drop_scale : 1.0f};
-  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, dx, seq_len, L, D, n, dr);
+  SR_LAUNCH(meanpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, dx, seq_len, L, D, n, dr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
 extern "C" int srhip_gelu_f32(const float* pre, float* out, long n, void* stream) {
   if (!pre || !out || n <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(gelu_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pre, out, n);
+  SR_LAUNCH(gelu_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pre, out, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 extern "C" int srhip_gelu_bwd_f32(const float* dout, const float* pre, float* dpre, long n, void* stream) {
   if (!dout || !pre || !dpre || n <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, pre, dpre, n);
+  SR_LAUNCH(gelu_bwd_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, pre, dpre, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -416,14 +416,14 @@ extern "C" int srhip_gelu_bwd_f32(const float* dout, const float* pre, float* dp
 extern "C" int srhip_dropout_cast(const float* x, void* out_bf16, long n, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream) {
   if (!x || !out_bf16 || n <= 0 || (n & 1) || n >= (1L << 32)) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
-  hipLaunchKernelGGL(dropout_cast_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out_bf16, n, dr);
+  SR_LAUNCH(dropout_cast_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out_bf16, n, dr);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
 extern "C" int srhip_mask_lengths(const long long* mask, int ld, int* klen, int B, int L, void* stream) {
   if (!mask || !klen || B <= 0 || L <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(mask_len_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, ld, klen, L);
+  SR_LAUNCH(mask_len_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, ld, klen, L);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

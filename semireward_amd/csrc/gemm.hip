@@ -626,7 +626,7 @@ static void launch_big_t(const GemmArgs& g, int grid_cap, hipStream_t s) {
   const int tiles = cdiv(g.M, GBM) * cdiv(g.N, GBN);
   auto kern = gemm_big_kernel<EPI, NTW, WN>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(kern, dim3(min(tiles, grid_cap)), dim3(256 * WN), sm, s, g);
+  SR_LAUNCH(kern, dim3(min(tiles, grid_cap)), dim3(256 * WN), sm, s, g);
 }
 
 // variant: 0 = 256x256 / 8 waves / 1 WG per CU, 1 = 256x128 / 8 waves, 2 = 256x128 / 4 waves / 2 WGs per CU
@@ -660,7 +660,7 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   // The persistent kernel runs 256 workgroups over 256x256 tiles: below ~3 full rounds of tiles its round quantisation costs more than the
   // larger tile saves (the split launches of a training step: 32 639 x 1152 = 640 tiles = 2.5 -> 3 rounds; on the 128x128 kernel 2313 tiles
   // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
-  static const double big_min_rounds = getenv("SRHIP_BIG_MIN_ROUNDS") ? atof(getenv("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
+  static const double big_min_rounds = SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS") ? atof(SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
   // (N = 512 conv layers of the Wav2Vec2 feature encoder, K = 1024 / 1536 over 10^5..10^6 frames: +5 % clips/s on the persistent kernel)
   // K >= 768 (the D = 768 legs: BERT / Wav2Vec2 / HuBERT): the K loop is long enough that the 256-row tile pays from ~0.6 rounds of tiles on, also
   // at N = 768 (tools/gemm_modes_probe.py, standalone TF/s default -> this rule: BERT qkv 13952 x 2304 x 768 664 -> 800, fc1 615 -> 735, fc2 13952 x
@@ -668,7 +668,7 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   const bool big_k = K >= 768;
   const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || (mode && mode[0] == 'b');
   const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
-  const double min_rounds = (big_k && !getenv("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
+  const double min_rounds = (big_k && !SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
   if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || (mode && mode[0] == 'b'))) {
     if (mode && !strcmp(mode, "big128")) return SRHIP_GEMM_PLAN_BIG128;
     if (mode && !strcmp(mode, "big2wg")) return SRHIP_GEMM_PLAN_BIG2WG;
@@ -684,7 +684,7 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   // 4112 x 384 product, 12.8 instead of 31 us with the chip to itself (the K = 0 regime: 3.21 vs 3.57 ms per step) -- but while the row-streaming
   // launches of the deferred rows own most CUs, fewer and fatter workgroups win (K = 8 headline: 4.86 vs 4.95 ms, ViT-S/16@224 4.07 vs 4.13;
   // DESIGN 6f), so the step sets it per regime.  SRHIP_SMALL_MAX_GRID pins it for tuning.
-  static const int small_env = getenv("SRHIP_SMALL_MAX_GRID") ? atoi(getenv("SRHIP_SMALL_MAX_GRID")) : -1;
+  static const int small_env = SR_TUNE_ENV("SRHIP_SMALL_MAX_GRID") ? atoi(SR_TUNE_ENV("SRHIP_SMALL_MAX_GRID")) : -1;
   const int small_max_grid = small_env >= 0 ? small_env : g_small_max_grid;
   if (((grid < small_max_grid && !(big_k && N >= 768)) || force_small) && !force_tile && splits == 1 && epilogue != SRHIP_EPI_F32)
     return SRHIP_GEMM_PLAN_SMALL64;
@@ -716,9 +716,9 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; g.alpha = alpha; g.beta = beta;
   g.drop_key = drop_key; g.drop_thresh = drop_thresh; g.drop_scale = drop_scale;
-  static const int dbg = getenv("SRHIP_DEBUG") ? atoi(getenv("SRHIP_DEBUG")) : 0;
+  static const int dbg = SR_TUNE_ENV("SRHIP_DEBUG") ? atoi(SR_TUNE_ENV("SRHIP_DEBUG")) : 0;
   g.debug = dbg;
-  static const bool no_wide = getenv("SRHIP_NO_WIDE_STORE") != nullptr;
+  static const bool no_wide = SR_TUNE_ENV("SRHIP_NO_WIDE_STORE") != nullptr;
   // (N % 128 == 0: no ragged column tile in the 128- and 64-column kernels; the persistent kernel checks its own last tile)
   g.wide_store = (epilogue == SRHIP_EPI_BF16 || epilogue == SRHIP_EPI_GELU_BF16 || epilogue == SRHIP_EPI_DGELU_BF16) && !no_wide && !(dbg & 1) &&
                  (N % 128) == 0 && (ldc % 8) == 0 && (epilogue != SRHIP_EPI_GELU_BF16 || !aux_out || (ldaux % 4) == 0);
@@ -744,21 +744,21 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   if (plan == SRHIP_GEMM_PLAN_SMALL64) {
     const dim3 gs(cdiv(M, SBM) * cdiv(N, SBM));
     switch (epilogue) {
-      case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;
-      case SRHIP_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_GELU_BF16>, gs, dim3(256), 0, s, g); break;
-      case SRHIP_EPI_RESID_F32: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_RESID_F32>, gs, dim3(256), 0, s, g); break;
-      case SRHIP_EPI_DGELU_BF16: hipLaunchKernelGGL(gemm_small_kernel<SRHIP_EPI_DGELU_BF16>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_BF16: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_GELU_BF16: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_GELU_BF16>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_RESID_F32: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_RESID_F32>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_DGELU_BF16: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_DGELU_BF16>, gs, dim3(256), 0, s, g); break;
       default: return SR_EINVAL;
     }
     SR_CHECK_LAUNCH();
     return SR_OK;
   }
   switch (epilogue) {
-    case SRHIP_EPI_BF16: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_BF16>, grid3, dim3(256), 0, s, g); break;
-    case SRHIP_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_GELU_BF16>, grid3, dim3(256), 0, s, g); break;
-    case SRHIP_EPI_RESID_F32: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_RESID_F32>, grid3, dim3(256), 0, s, g); break;
-    case SRHIP_EPI_DGELU_BF16: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_DGELU_BF16>, grid3, dim3(256), 0, s, g); break;
-    case SRHIP_EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<SRHIP_EPI_F32>, grid3, dim3(256), 0, s, g); break;
+    case SRHIP_EPI_BF16: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_BF16>, grid3, dim3(256), 0, s, g); break;
+    case SRHIP_EPI_GELU_BF16: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_GELU_BF16>, grid3, dim3(256), 0, s, g); break;
+    case SRHIP_EPI_RESID_F32: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_RESID_F32>, grid3, dim3(256), 0, s, g); break;
+    case SRHIP_EPI_DGELU_BF16: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_DGELU_BF16>, grid3, dim3(256), 0, s, g); break;
+    case SRHIP_EPI_F32: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_F32>, grid3, dim3(256), 0, s, g); break;
     default: return SR_EINVAL;
   }
   SR_CHECK_LAUNCH();
@@ -797,7 +797,7 @@ extern "C" int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B
 extern "C" int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
                                          void* stream) {
   if (!desc_dev || n_problems <= 0 || n_problems > 4096 || total_tiles <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(gemm_grouped_f32_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_problems, alpha, beta);
+  SR_LAUNCH(gemm_grouped_f32_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_problems, alpha, beta);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip
 extern "C" int srhip_gemm_tn_grouped_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha,
                                          float beta, void* stream) {
   if (!desc_dev || n_problems <= 0 || n_problems > 4096 || total_tiles <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(gemm_tn_grouped_f32_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_problems, alpha,
+  SR_LAUNCH(gemm_tn_grouped_f32_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_problems, alpha,
                      beta);
   SR_CHECK_LAUNCH();
   return SR_OK;

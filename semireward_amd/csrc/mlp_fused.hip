@@ -599,7 +599,7 @@ extern "C" int srhip_mlp_debug(long long* out_host, int n) {
 // epilogue), y_poly = gelu_poly2 (the transcendental-free form inside srhip_mlp_fused_proj) -- so that a test can pin the distance between them.
 extern "C" int srhip_gelu_eval(const float* x, float* y_erf, float* y_poly, int n, void* stream) {
   if (!x || !y_erf || !y_poly || n <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(gelu_eval_kernel, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, y_erf, y_poly, n);
+  SR_LAUNCH(gelu_eval_kernel, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, y_erf, y_poly, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -624,7 +624,7 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
   const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
   void (*kern)(MlpArgs) = mlp_fused_kernel<384, 0, 4>;
 #ifdef SRHIP_TUNING
-  switch (getenv("SRHIP_MLP_DEBUG") ? atoi(getenv("SRHIP_MLP_DEBUG")) : 0) {
+  switch (SR_TUNE_ENV("SRHIP_MLP_DEBUG") ? atoi(SR_TUNE_ENV("SRHIP_MLP_DEBUG")) : 0) {
     case 1: kern = mlp_fused_kernel<384, 1, 4>; break;
     case 2: kern = mlp_fused_kernel<384, 2, 4>; break;
     case 3: kern = mlp_fused_kernel<384, 3, 4>; break;
@@ -638,7 +638,7 @@ extern "C" int srhip_mlp_fused(const float* x, float* x_out, const float* ln_gam
 #endif
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int ntiles = cdiv(M, FBM);
-  hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
+  SR_LAUNCH(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -668,11 +668,11 @@ extern "C" int srhip_mlp_fused_proj(const float* x, float* x_out, const void* ao
   const size_t smem = (size_t)NS * TILE_EL * sizeof(bf16_t) + (size_t)(Hd + 6 * D) * sizeof(float);
   // SRHIP_MLP_SPREAD=0: all GS refills of a group right behind its barrier (the round-2 schedule; A/B on one box: 104 -> 99.5 us per 105-image
   // launch, 1547 -> 1574 img/s on the step)
-  static const int spread = getenv("SRHIP_MLP_SPREAD") ? atoi(getenv("SRHIP_MLP_SPREAD")) : 1;
+  static const int spread = SR_TUNE_ENV("SRHIP_MLP_SPREAD") ? atoi(SR_TUNE_ENV("SRHIP_MLP_SPREAD")) : 1;
   void (*kern)(MlpArgs) = spread ? mlp_fused_kernel<384, 0, 4, true, 1> : mlp_fused_kernel<384, 0, 4, true, 0>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int ntiles = cdiv(M, FBM);
-  hipLaunchKernelGGL(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
+  SR_LAUNCH(kern, dim3(min(ntiles, 256)), dim3(512), smem, (hipStream_t)stream, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

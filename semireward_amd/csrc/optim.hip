@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 extern "C" int srhip_clip_grad_ws_floats(void) { return CLIP_WG; }
 extern "C" int srhip_clip_grad_coef(const float* g, long long n, float pre_scale, float max_norm, float* ws, float* coef_out, void* stream) {
   if (!g || n <= 0 || !ws || !coef_out || !(max_norm > 0.f)) return SR_EINVAL;
-  hipLaunchKernelGGL(sumsq_part_kernel, dim3(CLIP_WG), dim3(256), 0, (hipStream_t)stream, g, (size_t)n, ws);
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, pre_scale, max_norm, coef_out);
+  SR_LAUNCH(sumsq_part_kernel, dim3(CLIP_WG), dim3(256), 0, (hipStream_t)stream, g, (size_t)n, ws);
+  SR_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, pre_scale, max_norm, coef_out);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -88,7 +88,7 @@ extern "C" int srhip_adamw_flat(float* p, float* g, float* m, float* v, void* p_
   if (n_chunks <= 0 || step <= 0) return SR_EINVAL;
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adamw_flat_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, ema,
+  SR_LAUNCH(adamw_flat_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, ema,
                      (const int4*)chunk_table, lr_t, wd_t, lr_factor, beta1, beta2, eps, bc1, bc2s, (float)ema_m, (float)(1.0 - ema_m), grad_scale, clip_coef, zero_grad,
                      (const float*)nullptr);
   SR_CHECK_LAUNCH();
@@ -108,7 +108,7 @@ extern "C" int srhip_adamw_flat_dyn(float* p, float* g, float* m, float* v, void
                                     int n_chunks, const float* lr_t, const float* wd_t, const float* dyn, float beta1, float beta2,
                                     float eps, double ema_m, float grad_scale, const float* clip_coef, int zero_grad, void* stream) {
   if (n_chunks <= 0 || !dyn) return SR_EINVAL;
-  hipLaunchKernelGGL(adamw_flat_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, ema,
+  SR_LAUNCH(adamw_flat_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, ema,
                      (const int4*)chunk_table, lr_t, wd_t, 0.f, beta1, beta2, eps, 1.f, 1.f, (float)ema_m, (float)(1.0 - ema_m), grad_scale, clip_coef, zero_grad, dyn);
   SR_CHECK_LAUNCH();
   return SR_OK;

@@ -517,7 +517,7 @@ extern "C" long srhip_rewarder_t_floats(int F) { return RewTOff(F).total; }
 extern "C" long srhip_generator_t_floats(int F) { return GenTOff(F).total; }
 
 static void launch_tr(const float* W, float* WT, int J, int K, hipStream_t s) {
-  hipLaunchKernelGGL(transpose_small_kernel, dim3(cdiv((long)J * K, 256)), dim3(256), 0, s, W, WT, J, K);
+  SR_LAUNCH(transpose_small_kernel, dim3(cdiv((long)J * K, 256)), dim3(256), 0, s, W, WT, J, K);
 }
 
 extern "C" int srhip_rewarder_prepare(const float* params, float* params_t, int F, int L, void* stream) {
@@ -559,18 +559,18 @@ extern "C" int srhip_rewarder_fwd_strided(const float* params, const float* para
   if (max_reward_inout && (G != 1 || B > RT)) return SR_EINVAL;            // the running maximum rides in the one-launch form only
   hipStream_t s = (hipStream_t)stream;
   const size_t sm1 = ((size_t)F * RT + E * RT + 256 * RT) * sizeof(float);
-  static const bool two = getenv("SRHIP_REWARDER_TWO_LAUNCHES") != nullptr;
+  static const bool two = SR_TUNE_ENV("SRHIP_REWARDER_TWO_LAUNCHES") != nullptr;
   if (B <= RT && (!two || max_reward_inout)) {
     const size_t smf = sm1 > SCORE_LDS_FLOATS * sizeof(float) ? sm1 : SCORE_LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(rew_fused_kernel, dim3(1, G), dim3(256), smf, s, params, params_t, feats, labels, ws, reward, G, B, F, L, save_for_bwd,
+    SR_LAUNCH(rew_fused_kernel, dim3(1, G), dim3(256), smf, s, params, params_t, feats, labels, ws, reward, G, B, F, L, save_for_bwd,
                        feat_group_stride, max_reward_inout);
     SR_CHECK_LAUNCH();
     return SR_OK;
   }
-  hipLaunchKernelGGL(rew_embed_kernel, dim3(cdiv(B, RT), G), dim3(256), sm1, s, params, params_t, feats, labels, ws, G, B, F, L, save_for_bwd,
+  SR_LAUNCH(rew_embed_kernel, dim3(cdiv(B, RT), G), dim3(256), sm1, s, params, params_t, feats, labels, ws, G, B, F, L, save_for_bwd,
                      feat_group_stride);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rew_score_kernel, dim3(cdiv(B, RT), G), dim3(256), 0, s, params, params_t, ws, reward, G, B, F, L, save_for_bwd);
+  SR_LAUNCH(rew_score_kernel, dim3(cdiv(B, RT), G), dim3(256), 0, s, params, params_t, ws, reward, G, B, F, L, save_for_bwd);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -583,18 +583,18 @@ extern "C" int srhip_rewarder_bwd(const float* params, const float* feats, const
   const RewWs w(1, B);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(grads + o.Emb, 0, (size_t)L * E * sizeof(float), s) != hipSuccess) return SR_ELAUNCH;
-  hipLaunchKernelGGL(rew_bwd_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, params, ws, target, losses, B, F, L);
+  SR_LAUNCH(rew_bwd_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, params, ws, target, losses, B, F, L);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rew_bwd_ctx_kernel, dim3(1), dim3(128), 0, s, params, ws, grads, target, losses, B, F, L);
+  SR_LAUNCH(rew_bwd_ctx_kernel, dim3(1), dim3(128), 0, s, params, ws, grads, target, losses, B, F, L);
   SR_CHECK_LAUNCH();
   // weight gradients of the per-row head
-  hipLaunchKernelGGL(small_dw_kernel, dim3(1), dim3(64), 0, s, ws + w.dlogit, 1, ws + w.f1, 64, grads + o.w4, grads + o.b4, B, 64);
-  hipLaunchKernelGGL(small_dw_kernel, dim3(64), dim3(128), 0, s, ws + w.df1, 64, ws + w.m2, E, grads + o.W3, grads + o.b3, B, E);
-  hipLaunchKernelGGL(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dm2, E, ws + w.m1, 256, grads + o.W2, grads + o.b2, B, 256);
-  hipLaunchKernelGGL(small_dw_kernel, dim3(256), dim3(128), 0, s, ws + w.dm1, 256, ws + w.u, E, grads + o.W1, grads + o.b1, B, E);
+  SR_LAUNCH(small_dw_kernel, dim3(1), dim3(64), 0, s, ws + w.dlogit, 1, ws + w.f1, 64, grads + o.w4, grads + o.b4, B, 64);
+  SR_LAUNCH(small_dw_kernel, dim3(64), dim3(128), 0, s, ws + w.df1, 64, ws + w.m2, E, grads + o.W3, grads + o.b3, B, E);
+  SR_LAUNCH(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dm2, E, ws + w.m1, 256, grads + o.W2, grads + o.b2, B, 256);
+  SR_LAUNCH(small_dw_kernel, dim3(256), dim3(128), 0, s, ws + w.dm1, 256, ws + w.u, E, grads + o.W1, grads + o.b1, B, E);
   // feature_fc: d(pre) of the B feature rows sits in dz rows [0,B); label rows [B,2B) feed the embedding
-  hipLaunchKernelGGL(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dz, E, feats, F, grads + o.Wf, grads + o.bf, B, F);
-  hipLaunchKernelGGL(rew_emb_scatter_kernel, dim3(B), dim3(E), 0, s, ws + w.dz + (size_t)B * E, labels, grads + o.Emb, L);
+  SR_LAUNCH(small_dw_kernel, dim3(E), dim3(256), 0, s, ws + w.dz, E, feats, F, grads + o.Wf, grads + o.bf, B, F);
+  SR_LAUNCH(rew_emb_scatter_kernel, dim3(B), dim3(E), 0, s, ws + w.dz + (size_t)B * E, labels, grads + o.Emb, L);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -603,7 +603,7 @@ extern "C" int srhip_generator_fwd(const float* params, const float* params_t, c
                                    int F, void* stream) {
   if (B <= 0 || F <= 0 || F > 1024 || !params_t) return SR_EINVAL;
   const size_t sm = ((size_t)F * RT + (256 + 128 + 64 + 256) * RT) * sizeof(float);
-  hipLaunchKernelGGL(generator_kernel, dim3(cdiv(B, RT)), dim3(256), sm, (hipStream_t)stream, params, params_t, x, out, label, B, F);
+  SR_LAUNCH(generator_kernel, dim3(cdiv(B, RT)), dim3(256), sm, (hipStream_t)stream, params, params_t, x, out, label, B, F);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -623,7 +623,7 @@ extern "C" int srhip_label_error(int* bits_out, int reset, void* stream) {
 
 extern "C" int srhip_sr_target(const long long* gen, const long long* ref, float* target, int B, int num_classes, void* stream) {
   if (B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(sr_target_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, gen, ref, target, B, num_classes);
+  SR_LAUNCH(sr_target_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, gen, ref, target, B, num_classes);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -633,7 +633,7 @@ extern "C" int srhip_adam_flat(float* p, const float* g, float* m, float* v, lon
   if (n <= 0 || step <= 0) return SR_EINVAL;
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, bc1, bc2s,
+  SR_LAUNCH(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, bc1, bc2s,
                      (const float*)nullptr);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -641,7 +641,7 @@ extern "C" int srhip_adam_flat(float* p, const float* g, float* m, float* v, lon
 extern "C" int srhip_adam_flat_dyn(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                                    const float* dyn, void* stream) {
   if (n <= 0 || !dyn) return SR_EINVAL;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, 1.f, 1.f, dyn);
+  SR_LAUNCH(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (int)n, lr, beta1, beta2, eps, 1.f, 1.f, dyn);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void freematch_entropy_kernel(const float* __r
 extern "C" int srhip_row_max(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B,
                              int C, void* stream) {
   if (B <= 0 || C <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C, 0,
+  SR_LAUNCH(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C, 0,
                      0LL);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -499,7 +499,7 @@ extern "C" int srhip_row_max(const float* in, int in_is_probs, float* probs_out,
 extern "C" int srhip_row_max_strided(const float* in, int in_is_probs, float* probs_out, float* max_probs, long long* max_idx, int B, int C,
                                      int rows_per_group, long long group_stride, void* stream) {
   if (B <= 0 || C <= 0 || rows_per_group <= 0 || group_stride < (long long)rows_per_group * C) return SR_EINVAL;
-  hipLaunchKernelGGL(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C,
+  SR_LAUNCH(row_max_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, in, in_is_probs, probs_out, max_probs, max_idx, B, C,
                      rows_per_group, group_stride);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -522,10 +522,10 @@ extern "C" int srhip_flexmatch_mask_passes(const float* max_probs, const long lo
   if (lds_path && smem > 48 * 1024)
     lds_path = hipFuncSetAttribute((const void*)flexmatch_mask_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
   if (lds_path) {
-    hipLaunchKernelGGL(flexmatch_mask_lds_kernel, dim3(1), dim3(256), smem, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
+    SR_LAUNCH(flexmatch_mask_lds_kernel, dim3(1), dim3(256), smem, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
                        selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
   } else {
-    hipLaunchKernelGGL(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
+    SR_LAUNCH(flexmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, max_probs, max_idx, idx_ulb, p_cutoff,
                        selected_label, hist, classwise_acc, mask, B, C, ulb_dest_len, thresh_warmup, n_pass);
   }
   SR_CHECK_LAUNCH();
@@ -548,14 +548,14 @@ extern "C" int srhip_flexmatch_rebuild_hist(const long long* selected_label, int
   if (ulb_dest_len <= 0 || C <= 0) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(hist, 0, (size_t)(C + 1) * sizeof(int), s) != hipSuccess) return SR_ELAUNCH;
-  hipLaunchKernelGGL(flexmatch_hist_kernel, dim3(cdiv(ulb_dest_len, 256)), dim3(256), 0, s, selected_label, hist, ulb_dest_len, C);
+  SR_LAUNCH(flexmatch_hist_kernel, dim3(cdiv(ulb_dest_len, 256)), dim3(256), 0, s, selected_label, hist, ulb_dest_len, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
 extern "C" int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* mask, int B, void* stream) {
   if (B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(fixed_mask_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, max_probs, p_cutoff, mask, B);
+  SR_LAUNCH(fixed_mask_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, max_probs, p_cutoff, mask, B);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -563,7 +563,7 @@ extern "C" int srhip_fixed_mask(const float* max_probs, float p_cutoff, float* m
 extern "C" int srhip_reward_mask2(const float* reward, float* mask2, float* mean_out, const float* mean_in, int groups, int B,
                                   void* stream) {
   if (groups <= 0 || B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(reward_mask2_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, reward, mask2, mean_out, mean_in, B);
+  SR_LAUNCH(reward_mask2_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, reward, mask2, mean_out, mean_in, B);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -571,7 +571,7 @@ extern "C" int srhip_reward_mask2(const float* reward, float* mask2, float* mean
 extern "C" int srhip_masked_ce(const float* logits, const long long* targets, const float* mask, const float* mask2,
                                float grad_scale, float* loss_out, float* dlogits, int B, int C, void* stream) {
   if (B <= 0 || C <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(masked_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, mask, mask2, grad_scale,
+  SR_LAUNCH(masked_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, mask, mask2, grad_scale,
                      loss_out, dlogits, B, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void softmatch_mask_kernel(const float* __rest
 
 extern "C" int srhip_freematch_stats(const float* probs, const long long* max_idx, float* colsum, float* hist, int B, int C, void* stream) {
   if (B <= 0 || C <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(freematch_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, probs, max_idx, colsum, hist, B, C);
+  SR_LAUNCH(freematch_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, probs, max_idx, colsum, hist, B, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -674,7 +674,7 @@ extern "C" int srhip_freematch_update(const float* maxp_all, int n_all, const fl
                                       const long long* max_idx, float* time_p, float* p_model, float* label_hist, float* mask, int B,
                                       int C, float momentum, float one_minus_momentum, int use_quantile, int clip_thresh, void* stream) {
   if (B <= 0 || C <= 0 || n_all <= 0 || n_all > 1024) return SR_EINVAL;
-  hipLaunchKernelGGL(freematch_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, maxp_all, n_all, colsum, hist, max_probs, max_idx,
+  SR_LAUNCH(freematch_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, maxp_all, n_all, colsum, hist, max_probs, max_idx,
                      time_p, p_model, label_hist, mask, B, C, momentum, one_minus_momentum, use_quantile, clip_thresh);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -684,7 +684,7 @@ extern "C" int srhip_freematch_entropy(const float* logits, const float* mask, c
                                        float grad_scale, float* loss_out, float* dlogits, float* ws, int B, int C, int accumulate,
                                        void* stream) {
   if (B <= 0 || B > 1024 || C <= 0 || C > 2048) return SR_EINVAL;
-  hipLaunchKernelGGL(freematch_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, mask, p_model, label_hist, grad_scale,
+  SR_LAUNCH(freematch_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, mask, p_model, label_hist, grad_scale,
                      loss_out, dlogits, ws, B, C, accumulate);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -695,7 +695,7 @@ extern "C" int srhip_distalign(const float* probs, const float* colsum_ulb, int 
                                int B, int C, void* stream) {
   if (!probs || !colsum_ulb || !p_model || !p_target || !inited || !aligned || !max_probs || !max_idx) return SR_EINVAL;
   if (B <= 0 || C <= 0 || n_ulb <= 0 || (colsum_lb && n_lb <= 0)) return SR_EINVAL;
-  hipLaunchKernelGGL(distalign_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, colsum_ulb, n_ulb, colsum_lb, n_lb, p_model,
+  SR_LAUNCH(distalign_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, colsum_ulb, n_ulb, colsum_lb, n_lb, p_model,
                      p_target, inited, (float)momentum, (float)(1.0 - momentum), aligned, max_probs, max_idx, B, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -704,7 +704,7 @@ extern "C" int srhip_distalign(const float* probs, const float* colsum_ulb, int 
 extern "C" int srhip_softmatch_mask(const float* maxp_all, int n_all, const float* max_probs, float* mu_var, double momentum, int n_sigma,
                                     float* mask, int B, void* stream) {
   if (!maxp_all || !max_probs || !mu_var || !mask || n_all <= 0 || B <= 0 || n_sigma <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(softmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, maxp_all, n_all, max_probs, mu_var, momentum, n_sigma,
+  SR_LAUNCH(softmatch_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, maxp_all, n_all, max_probs, mu_var, momentum, n_sigma,
                      mask, B);
   SR_CHECK_LAUNCH();
   return SR_OK;

@@ -578,10 +578,10 @@ extern "C" int srhip_layernorm_fwd(const float* x, const float* gamma, const flo
   if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768) || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(M, 8)), block(256);
-  if (D == 128) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
-  else if (D == 512) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
-  else if (D == 384) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
-  else hipLaunchKernelGGL(ln_fwd_kernel<6>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  if (D == 128) SR_LAUNCH(ln_fwd_kernel<1>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  else if (D == 512) SR_LAUNCH(ln_fwd_kernel<4>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  else if (D == 384) SR_LAUNCH(ln_fwd_kernel<3>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
+  else SR_LAUNCH(ln_fwd_kernel<6>, grid, block, 0, s, x, gamma, beta, eps, (bf16_t*)out, mean, rstd, M);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -591,15 +591,15 @@ static int layernorm_bwd_impl(const void* dy, const float* x, const float* mean,
                               float* part = nullptr, int n_rep = 0) {
   if (M <= 0 || (D != 128 && D != 384 && D != 512 && D != 768) || (row_scale && rows_per_sample <= 0)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  static const int rpw_env = getenv("SRHIP_LNB_RPW") ? atoi(getenv("SRHIP_LNB_RPW")) : 0;
+  static const int rpw_env = SR_TUNE_ENV("SRHIP_LNB_RPW") ? atoi(SR_TUNE_ENV("SRHIP_LNB_RPW")) : 0;
   const bool small = rpw_env ? rpw_env == 2 : M < 16384;
   dim3 grid(cdiv(M, small ? 8 : 32)), block(256);
   const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
 #define LNB(NV)                                                                                                                                   \
   do {                                                                                                                                            \
-    if (small) hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M,        \
+    if (small) SR_LAUNCH((ln_bwd_kernel<NV, 2>), grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M,        \
                                   (bf16_t*)out_bf16, row_scale, rps, part, n_rep);                                                                             \
-    else hipLaunchKernelGGL((ln_bwd_kernel<NV, 8>), grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M,              \
+    else SR_LAUNCH((ln_bwd_kernel<NV, 8>), grid, block, 0, s, (const bf16_t*)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, M,              \
                             (bf16_t*)out_bf16, row_scale, rps, part, n_rep);                                                                                   \
   } while (0)
   if (D == 128) LNB(1); else if (D == 512) LNB(4); else if (D == 384) LNB(3); else LNB(6);
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const srhip_ln_redu
 }  // namespace
 extern "C" int srhip_ln_grad_reduce(const srhip_ln_reduce_desc* desc_dev, float* part, int n_ln, int n_rep, int D, void* stream) {
   if (!desc_dev || !part || n_ln <= 0 || n_rep <= 0 || D <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3(cdiv(2 * D, 256), n_ln), dim3(256), 0, (hipStream_t)stream, desc_dev, part, n_rep, D);
+  SR_LAUNCH(ln_grad_reduce_kernel, dim3(cdiv(2 * D, 256), n_ln), dim3(256), 0, (hipStream_t)stream, desc_dev, part, n_rep, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -649,7 +649,7 @@ extern "C" int srhip_patch_embed_fwd(const float* img, const int* img_index, con
                                      const float* pos, float* x, int B, int C, int HW, int ps, int D, void* stream) {
   if (B <= 0 || HW % ps || D % 64 || D > 1024 || C * ps * ps > 64) return SR_EINVAL;
   const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps;
-  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(cdiv(N, PE_TOK), B), dim3(D), PE_TOK * K * sizeof(float), (hipStream_t)stream,
+  SR_LAUNCH(patch_embed_fwd_kernel, dim3(cdiv(N, PE_TOK), B), dim3(D), PE_TOK * K * sizeof(float), (hipStream_t)stream,
                      img, img_index, Wp, bp, cls, pos, x, C, HW, ps, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -660,9 +660,9 @@ extern "C" int srhip_patch_embed_bwd(const float* dx, const float* img, const in
   if (B <= 0 || HW % ps || D % 64 || D > 1024 || C * ps * ps > 64) return SR_EINVAL;
   const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(patch_embed_bwd_pos_kernel, dim3(N), dim3(D), 0, s, dx, dpos, dcls, B, N, D);
+  SR_LAUNCH(patch_embed_bwd_pos_kernel, dim3(N), dim3(D), 0, s, dx, dpos, dcls, B, N, D);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(patch_embed_bwd_w_kernel, dim3(cdiv(N - 1, PE_TOK_BWD), B), dim3(D), PE_TOK_BWD * K * sizeof(float), s, dx, img,
+  SR_LAUNCH(patch_embed_bwd_w_kernel, dim3(cdiv(N - 1, PE_TOK_BWD), B), dim3(D), PE_TOK_BWD * K * sizeof(float), s, dx, img,
                      img_index, dWp, dbp, C, HW, ps, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -678,11 +678,11 @@ extern "C" int srhip_patch_embed_bwd_ws(const float* dx, const float* img, const
   if (B <= 0 || HW % ps || D % 64 || D > 1024 || C * ps * ps > 64 || !ws) return SR_EINVAL;
   const int gw = HW / ps, N = gw * gw + 1, K = C * ps * ps, nch = cdiv(N - 1, PE_TOK);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(patch_embed_bwd_pos_kernel, dim3(N), dim3(D), 0, s, dx, dpos, dcls, B, N, D);
+  SR_LAUNCH(patch_embed_bwd_pos_kernel, dim3(N), dim3(D), 0, s, dx, dpos, dcls, B, N, D);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(patch_embed_bwd_part_kernel, dim3(nch, B), dim3(D), PE_TOK * K * sizeof(float), s, dx, img, img_index, ws, C, HW, ps, D);
+  SR_LAUNCH(patch_embed_bwd_part_kernel, dim3(nch, B), dim3(D), PE_TOK * K * sizeof(float), s, dx, img, img_index, ws, C, HW, ps, D);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(patch_embed_bwd_fold_kernel, dim3(cdiv((K + 1) * D, 256)), dim3(256), 0, s, ws, dWp, dbp, nch * B, K, D);
+  SR_LAUNCH(patch_embed_bwd_fold_kernel, dim3(cdiv((K + 1) * D, 256)), dim3(256), 0, s, ws, dWp, dbp, nch * B, K, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -698,7 +698,7 @@ extern "C" int srhip_cls_head_fwd_scatter(const float* x, const float* gamma, co
   if (B <= 0 || D > 1024 || C <= 0) return SR_EINVAL;
   if ((!feat || !logits) && (!feat_all || !logits_all)) return SR_EINVAL;       // some complete (feat, logits) destination
   if ((feat_all || logits_all) && !out_rows) return SR_EINVAL;
-  hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(B, C >= 32 ? 4 : 1), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream, x, gamma, beta, eps,
+  SR_LAUNCH(cls_head_fwd_kernel, dim3(B, C >= 32 ? 4 : 1), dim3(256), (D + 4) * sizeof(float), (hipStream_t)stream, x, gamma, beta, eps,
                      Wh, bh, feat, logits, xhat, rstd, feat_all, logits_all, out_rows, N, D, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -709,10 +709,10 @@ extern "C" int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const f
                                   float* dbeta, int B, int N, int D, int C, void* stream) {
   if (B <= 0 || D > 1024 || C <= 0) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(cls_head_bwd_x_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, dlogits, Wh, gamma, xhat, rstd, dx,
+  SR_LAUNCH(cls_head_bwd_x_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, dlogits, Wh, gamma, xhat, rstd, dx,
                      dgamma, dbeta, N, D, C);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, s, dlogits, feat, dWh, dbh, B, D, C);
+  SR_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, s, dlogits, feat, dWh, dbh, B, D, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -721,7 +721,7 @@ extern "C" int srhip_cast_scale_rows(const float* x, const float* scale, int row
                                      void* stream) {
   if (M <= 0 || D % 8 || (scale && rows_per_sample <= 0)) return SR_EINVAL;
   const size_t n8 = (size_t)M * D / 8;
-  hipLaunchKernelGGL(cast_scale_rows_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
+  SR_LAUNCH(cast_scale_rows_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
                      rows_per_sample > 0 ? rows_per_sample : 1, (bf16_t*)out, n8, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -734,11 +734,11 @@ extern "C" int srhip_transpose_to_bf16(const void* in, int in_is_f32, int ld_in,
   hipStream_t s = (hipStream_t)stream;
   if (in_is_f32) {
     if (apply_gelu) return SR_EINVAL;
-    hipLaunchKernelGGL((transpose_kernel<float, false>), grid, block, 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
+    SR_LAUNCH((transpose_kernel<float, false>), grid, block, 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
   } else if (apply_gelu) {
-    hipLaunchKernelGGL((transpose_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
+    SR_LAUNCH((transpose_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
   } else {
-    hipLaunchKernelGGL((transpose_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
+    SR_LAUNCH((transpose_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, Mp, colsum);
   }
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -746,14 +746,14 @@ extern "C" int srhip_transpose_to_bf16(const void* in, int in_is_f32, int ld_in,
 
 extern "C" int srhip_cast_f32_bf16(const float* x, void* out, long n, void* stream) {
   if (n <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, (size_t)n);
+  SR_LAUNCH(cast_f32_bf16_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, (size_t)n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
 extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, int B, unsigned long long seed, void* stream) {
   if (depth <= 0 || B <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
+  SR_LAUNCH(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * B, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
                      (const long long*)nullptr, B, (const unsigned long long*)nullptr);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -761,7 +761,7 @@ extern "C" int srhip_droppath_fill(float* out, const float* probs, int depth, in
 extern "C" int srhip_droppath_fill_cols(float* out, const float* probs, const long long* cols, int depth, int B, int n_cols,
                                         unsigned long long seed, void* stream) {
   if (depth <= 0 || B <= 0 || n_cols <= 0 || !cols) return SR_EINVAL;
-  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
+  SR_LAUNCH(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed,
                      cols, n_cols, (const unsigned long long*)nullptr);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -770,7 +770,7 @@ extern "C" int srhip_droppath_fill_cols(float* out, const float* probs, const lo
 extern "C" int srhip_droppath_fill_cols_dyn(float* out, const float* probs, const long long* cols, int depth, int B, int n_cols,
                                             const unsigned long long* seed_dev, unsigned long long seed_offset, void* stream) {
   if (depth <= 0 || B <= 0 || n_cols <= 0 || !seed_dev) return SR_EINVAL;
-  hipLaunchKernelGGL(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed_offset,
+  SR_LAUNCH(droppath_fill_kernel, dim3(cdiv((long)depth * 2 * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out, probs, depth, B, seed_offset,
                      cols, cols ? n_cols : B, seed_dev);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -778,7 +778,7 @@ extern "C" int srhip_droppath_fill_cols_dyn(float* out, const float* probs, cons
 
 extern "C" int srhip_transpose_batched(const srhip_transpose_desc* desc_dev, int n, int total_tiles, void* stream) {
   if (!desc_dev || n <= 0 || total_tiles <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n);
+  SR_LAUNCH(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -786,7 +786,7 @@ extern "C" int srhip_transpose_batched(const srhip_transpose_desc* desc_dev, int
 extern "C" int srhip_patch_im2col(const float* img, const int* img_index, void* out, int B, int C, int HW, int ps, void* stream) {
   if (!img || !out || B <= 0 || C <= 0 || ps <= 0 || (ps & 1) || HW % ps) return SR_EINVAL;
   const int gw = HW / ps;
-  hipLaunchKernelGGL(patch_im2col_kernel, dim3(gw * gw, B), dim3(256), 0, (hipStream_t)stream, img, img_index, (bf16_t*)out, C, HW, ps);
+  SR_LAUNCH(patch_im2col_kernel, dim3(gw * gw, B), dim3(256), 0, (hipStream_t)stream, img, img_index, (bf16_t*)out, C, HW, ps);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -794,7 +794,7 @@ extern "C" int srhip_patch_im2col(const float* img, const int* img_index, void* 
 extern "C" int srhip_patch_assemble(const float* tok, const float* bp, const float* cls, const float* pos, float* x, int B, int Np,
                                     int D, void* stream) {
   if (!tok || !bp || !cls || !pos || !x || B <= 0 || Np <= 0 || D <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(patch_assemble_kernel, dim3(Np + 1, B), dim3(D < 256 ? 64 : 256), 0, (hipStream_t)stream, tok, bp, cls, pos, x, Np, D);
+  SR_LAUNCH(patch_assemble_kernel, dim3(Np + 1, B), dim3(D < 256 ? 64 : 256), 0, (hipStream_t)stream, tok, bp, cls, pos, x, Np, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -803,9 +803,9 @@ extern "C" int srhip_patch_grad_operands(const float* dx, void* dx_tok_bf16, flo
                                          void* stream) {
   if (!dx || !dx_tok_bf16 || !dpos || !dcls || B <= 0 || Np <= 0 || D <= 0 || (D & 1) || D > 1024) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(patch_embed_bwd_pos_kernel, dim3(Np + 1), dim3(D), 0, s, dx, dpos, dcls, B, Np + 1, D);
+  SR_LAUNCH(patch_embed_bwd_pos_kernel, dim3(Np + 1), dim3(D), 0, s, dx, dpos, dcls, B, Np + 1, D);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(patch_gather_grad_kernel, dim3(Np, B), dim3(D < 512 ? 64 : 256), 0, s, dx, (bf16_t*)dx_tok_bf16, Np, D);
+  SR_LAUNCH(patch_gather_grad_kernel, dim3(Np, B), dim3(D < 512 ? 64 : 256), 0, s, dx, (bf16_t*)dx_tok_bf16, Np, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

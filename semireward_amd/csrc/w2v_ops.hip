@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void featln_bwd_kernel(const bf16_t* __restric
 
 }  // namespace
 
-#define W2V_LAUNCH1D(kern, n, ...) hipLaunchKernelGGL(kern, dim3(cdiv((n), 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+#define W2V_LAUNCH1D(kern, n, ...) SR_LAUNCH(kern, dim3(cdiv((n), 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" int srhip_w2v_conv0(int mode, const float* wave, const float* W0, const float* gamma, const float* beta, double* ws, double* ws2,
                                void* out_bf16, const void* dY, float* dW0, float* dgamma, float* dbeta, int B, int S, int T0, int P0, int C, int k,
@@ -566,17 +566,17 @@ extern "C" int srhip_w2v_conv0(int mode, const float* wave, const float* W0, con
   const dim3 grid(B, cdiv(mode == 1 ? P0 : T0, TCH)), block(256);
   const size_t sm = (size_t)(stride * (TCH - 1) + k) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define C0(MODE) hipLaunchKernelGGL(conv0_kernel<MODE>, grid, block, sm, s, wave, W0, gamma, beta, ws, ws2, (bf16_t*)out_bf16, (const bf16_t*)dY, dW0, \
+#define C0(MODE) SR_LAUNCH(conv0_kernel<MODE>, grid, block, sm, s, wave, W0, gamma, beta, ws, ws2, (bf16_t*)out_bf16, (const bf16_t*)dY, dW0, \
                                     dgamma, dbeta, S, T0, P0, C, k, stride, eps)
-  static const bool generic_only = getenv("SRHIP_W2V_CONV0_GENERIC") != nullptr;            // tuning: the generic kernel for every shape
+  static const bool generic_only = SR_TUNE_ENV("SRHIP_W2V_CONV0_GENERIC") != nullptr;            // tuning: the generic kernel for every shape
   if (k == 10 && stride == 5 && !generic_only && C <= 512) {
-    static const int env_nsub = getenv("SRHIP_W2V_CONV0_NSUB") ? atoi(getenv("SRHIP_W2V_CONV0_NSUB")) : 0;
+    static const int env_nsub = SR_TUNE_ENV("SRHIP_W2V_CONV0_NSUB") ? atoi(SR_TUNE_ENV("SRHIP_W2V_CONV0_NSUB")) : 0;
     // segments per workgroup (measured per pass, 27 clips: statistics 139 / 154 / 172 us at 1 / 2 / 4, backward statistics 181 / 256 / 454,
     // filter gradient 544 / 395 / 455): only the filter gradient, 10 atomics per channel and workgroup, gains from fewer workgroups
     const int nsub = mode == 1 ? 1 : (env_nsub > 0 ? env_nsub : (mode == 3 ? 2 : 1));
     const dim3 gridf(B, cdiv(mode == 1 ? P0 : T0, TCH * nsub));
     const size_t smf = sm + 16 * sizeof(float);             // the last 16-byte read of a segment may reach 3 samples past it (never used)
-#define C0F(MODE) hipLaunchKernelGGL(conv0_k10s5_kernel<MODE>, gridf, block, smf, s, wave, W0, gamma, beta, ws, ws2, (bf16_t*)out_bf16, \
+#define C0F(MODE) SR_LAUNCH(conv0_k10s5_kernel<MODE>, gridf, block, smf, s, wave, W0, gamma, beta, ws, ws2, (bf16_t*)out_bf16, \
                                      (const bf16_t*)dY, dW0, dgamma, dbeta, S, T0, P0, C, eps, nsub)
     if (mode == 0) C0F(0); else if (mode == 1) C0F(1); else if (mode == 2) C0F(2); else C0F(3);
 #undef C0F
@@ -617,7 +617,7 @@ extern "C" int srhip_w2v_spec_mask_fwd(float* x, const unsigned char* mask, cons
 extern "C" int srhip_w2v_spec_mask_bwd(float* dx, const float* add, const unsigned char* mask, float* dembed, int B, int T, int P, int Padd, int D,
                                        void* stream) {
   if (!dx || B <= 0 || D % 64 || (mask && !dembed)) return SR_EINVAL;
-  hipLaunchKernelGGL(spec_mask_bwd_kernel, dim3(D / 64, B), dim3(256), 0, (hipStream_t)stream, dx, add, mask, dembed, T, P, Padd, D);
+  SR_LAUNCH(spec_mask_bwd_kernel, dim3(D / 64, B), dim3(256), 0, (hipStream_t)stream, dx, add, mask, dembed, T, P, Padd, D);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -632,7 +632,7 @@ extern "C" int srhip_w2v_pos_stage(const float* src, void* out, int B, int T, in
 extern "C" int srhip_w2v_weightnorm_prep(const float* v, const float* g, float* norms, void* Wf, void* Wb, int D, int groups, int k, void* stream) {
   if (!v || !g || !norms || !Wf || !Wb || D % groups) return SR_EINVAL;
   const int cg = D / groups;
-  hipLaunchKernelGGL(wn_norm_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, v, norms, D * cg, k);
+  SR_LAUNCH(wn_norm_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, v, norms, D * cg, k);
   SR_CHECK_LAUNCH();
   W2V_LAUNCH1D(wn_prep_kernel, (long)D * cg * k, v, g, norms, (bf16_t*)Wf, (bf16_t*)Wb, D, cg, k);
   SR_CHECK_LAUNCH();
@@ -641,7 +641,7 @@ extern "C" int srhip_w2v_weightnorm_prep(const float* v, const float* g, float* 
 extern "C" int srhip_w2v_weightnorm_bwd(const float* dWf, const float* v, const float* g, const float* norms, float* dv, float* dg, int D, int groups,
                                         int k, void* stream) {
   if (!dWf || !v || !g || !norms || !dv || !dg || D % groups) return SR_EINVAL;
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, dWf, v, g, norms, dv, dg, D, D / groups, k);
+  SR_LAUNCH(wn_bwd_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, dWf, v, g, norms, dv, dg, D, D / groups, k);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -658,7 +658,7 @@ extern "C" int srhip_w2v_pos_finish_fwd(const float* x, const float* conv, const
   if (!x || !conv || !x0 || !x0_bf16 || B <= 0 || T <= 0 || P < T || Pp < T) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
   const int M = B * P;
-#define CALL(NV) hipLaunchKernelGGL(pos_finish_fwd_kernel<NV>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, conv, conv_bias, gamma, beta, eps, \
+#define CALL(NV) SR_LAUNCH(pos_finish_fwd_kernel<NV>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, conv, conv_bias, gamma, beta, eps, \
                                     x0, (bf16_t*)x0_bf16, ysave, mean, rstd, T, P, Pp, M, dr)
   W2V_NV(D, CALL)
 #undef CALL
@@ -671,7 +671,7 @@ extern "C" int srhip_w2v_pos_finish_bwd(float* dx0, const float* ysave, const fl
   if (!dx0 || !ysave || !conv || !mean || !rstd || !dconv || !dgamma || !dbeta || B <= 0) return SR_EINVAL;
   const Drop dr{drop_key, drop_thresh, drop_scale};
   const int M = B * P;
-#define CALL(NV) hipLaunchKernelGGL(pos_finish_bwd_kernel<NV>, dim3(cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream, dx0, ysave, conv, conv_bias, mean, \
+#define CALL(NV) SR_LAUNCH(pos_finish_bwd_kernel<NV>, dim3(cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream, dx0, ysave, conv, conv_bias, mean, \
                                     rstd, gamma, dconv, dgamma, dbeta, T, P, Pp, M, dr)
   W2V_NV(D, CALL)
 #undef CALL
@@ -690,7 +690,7 @@ extern "C" int srhip_w2v_featln_fwd(const void* x, const float* gamma, const flo
                                     int P, int C, void* stream) {
   if (!x || !out || B <= 0 || T <= 0 || P < T || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
   const int M = B * P;
-#define CALL(NV) hipLaunchKernelGGL(featln_fwd_kernel<NV>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, eps, \
+#define CALL(NV) SR_LAUNCH(featln_fwd_kernel<NV>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, eps, \
                                     (bf16_t*)out, mean, rstd, T, P, M)
   W2V_NVC(C, CALL)
 #undef CALL
@@ -701,7 +701,7 @@ extern "C" int srhip_w2v_featln_bwd(const void* dy, const void* x, const void* p
                                     float* dgamma, float* dbeta, int B, int T, int P, int C, void* stream) {
   if (!dy || !x || !pre || !mean || !rstd || !dpre || !dgamma || !dbeta || B <= 0 || T <= 0 || P < T) return SR_EINVAL;
   const int M = B * P;
-#define CALL(NV) hipLaunchKernelGGL(featln_bwd_kernel<NV>, dim3(cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, \
+#define CALL(NV) SR_LAUNCH(featln_bwd_kernel<NV>, dim3(cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, \
                                     (const bf16_t*)pre, mean, rstd, gamma, (bf16_t*)dpre, dgamma, dbeta, T, P, M)
   W2V_NVC(C, CALL)
 #undef CALL

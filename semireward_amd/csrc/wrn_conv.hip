@@ -381,7 +381,7 @@ extern "C" int srhip_wrn_head(const float* x, int in_mode, const float* in_mean,
   a.pub.momentum = momentum; a.pub.update_running = update_running; a.pub.eps = eps;
   a.Wc = Wc; a.bc = bc; a.feat = feat; a.logits = logits; a.HW2 = HW2; a.C = C; a.K = K;
   a.in_rows = B * HW2 * (stat_ranks > 1 ? stat_ranks : 1);
-  hipLaunchKernelGGL(wrn_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  SR_LAUNCH(wrn_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -423,8 +423,8 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
   const int gy = Cout / (NT * 16), nks = Kpad / 32;
   // <= 512 workgroups (tools/wrn_conv_bench.py: 1024 cost +2.6 us with the statistics prologue / epilogue per workgroup); the waves of a
   // workgroup split K (2 or 4 ways) until the launch has ~2048 waves, as long as a wave keeps >= 4 k steps
-  static const int env_ks = getenv("SRHIP_CONV_KSPLIT") ? atoi(getenv("SRHIP_CONV_KSPLIT")) : 0;          // tuning: force 1 / 2 / 4
-  static const int env_maxwg = getenv("SRHIP_CONV_MAXWG") ? atoi(getenv("SRHIP_CONV_MAXWG")) : 512;
+  static const int env_ks = SR_TUNE_ENV("SRHIP_CONV_KSPLIT") ? atoi(SR_TUNE_ENV("SRHIP_CONV_KSPLIT")) : 0;          // tuning: force 1 / 2 / 4
+  static const int env_maxwg = SR_TUNE_ENV("SRHIP_CONV_MAXWG") ? atoi(SR_TUNE_ENV("SRHIP_CONV_MAXWG")) : 512;
   int KS = 1;
   while (KS < 4 && (long)a.ntiles * gy * KS * 2 <= 2048 && nks / (KS * 2) >= 4) KS *= 2;
   if (env_ks == 1 || env_ks == 2 || env_ks == 4) KS = env_ks;
@@ -433,9 +433,9 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
   if (gx < 1) gx = 1;
   hipStream_t s = (hipStream_t)stream;
 #define SR_CONV_LAUNCH(NT_)                                                                                          \
-  if (KS == 4) hipLaunchKernelGGL((wrn_conv_kernel<NT_, 4>), dim3(gx, gy), dim3(256), 0, s, a);                      \
-  else if (KS == 2) hipLaunchKernelGGL((wrn_conv_kernel<NT_, 2>), dim3(gx, gy), dim3(256), 0, s, a);                 \
-  else hipLaunchKernelGGL((wrn_conv_kernel<NT_, 1>), dim3(gx, gy), dim3(256), 0, s, a)
+  if (KS == 4) SR_LAUNCH((wrn_conv_kernel<NT_, 4>), dim3(gx, gy), dim3(256), 0, s, a);                      \
+  else if (KS == 2) SR_LAUNCH((wrn_conv_kernel<NT_, 2>), dim3(gx, gy), dim3(256), 0, s, a);                 \
+  else SR_LAUNCH((wrn_conv_kernel<NT_, 1>), dim3(gx, gy), dim3(256), 0, s, a)
   if (NT == 4) { SR_CONV_LAUNCH(4); }
   else if (NT == 2) { SR_CONV_LAUNCH(2); }
   else if (NT == 1) { SR_CONV_LAUNCH(1); }
@@ -450,7 +450,7 @@ extern "C" int srhip_bn_act(const float* x, const float* mean, const float* invs
   if (!x || (!act_bf16 && !act_f32) || rows <= 0 || C <= 0 || (C % 4) || mode < 0 || mode > 2) return SR_EINVAL;
   if (mode != 2 && (!mean || !invstd_or_var || !gamma || !beta)) return SR_EINVAL;
   const size_t n4 = (size_t)rows * C / 4;
-  hipLaunchKernelGGL(bn_act_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd_or_var, gamma, beta, eps, slope, mode,
+  SR_LAUNCH(bn_act_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd_or_var, gamma, beta, eps, slope, mode,
                      (bf16_t*)act_bf16, act_f32, n4, C);
   SR_CHECK_LAUNCH();
   return SR_OK;

@@ -423,12 +423,12 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, fl
 
 }  // namespace
 
-#define LAUNCH1D(kern, n, ...) hipLaunchKernelGGL(kern, dim3(cdiv((long)(n), 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+#define LAUNCH1D(kern, n, ...) SR_LAUNCH(kern, dim3(cdiv((long)(n), 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" int srhip_nchw_to_nhwc_bf16(const float* img, void* out, int B, int C, int H, int W, void* stream) {
   if (!img || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return SR_EINVAL;
   const long n = (long)B * C * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, C, H * W, (size_t)n);
+  SR_LAUNCH(nchw_to_nhwc_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, C, H * W, (size_t)n);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -439,11 +439,11 @@ extern "C" int srhip_im2col(const void* act, void* col, int B, int H, int W, int
   const size_t rows = (size_t)B * Ho * Wo;
   if (C % 8 == 0) {
     const size_t total = rows * (Kpad / 8);
-    hipLaunchKernelGGL(im2col_kernel<8>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
+    SR_LAUNCH(im2col_kernel<8>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
                        ksize, stride, Ho, Wo, Kpad, total);
   } else {
     const size_t total = rows * Kpad;
-    hipLaunchKernelGGL(im2col_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
+    SR_LAUNCH(im2col_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, (bf16_t*)col, H, W, C,
                        ksize, stride, Ho, Wo, Kpad, total);
   }
   SR_CHECK_LAUNCH();
@@ -458,7 +458,7 @@ extern "C" int srhip_im2col_bn(const float* x, const float* mean, const float* i
   if (mode == 0 && (!mean || !invstd || !gamma || !beta)) return SR_EINVAL;
   const int pad = ksize >> 1, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
   const size_t total = (size_t)B * Ho * Wo * (Kpad / 8);
-  hipLaunchKernelGGL(im2col_bn_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, slope, mode,
+  SR_LAUNCH(im2col_bn_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, slope, mode,
                      (bf16_t*)col, H, W, C, ksize, stride, Ho, Wo, Kpad, total);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -471,11 +471,11 @@ extern "C" int srhip_col2im(const float* dcol, float* dact, int B, int H, int W,
   const size_t pix = (size_t)B * H * W;
   if (C % 4 == 0 && Kpad % 4 == 0) {
     const size_t total = pix * (C / 4);
-    hipLaunchKernelGGL(col2im_kernel<4>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho, Wo,
+    SR_LAUNCH(col2im_kernel<4>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho, Wo,
                        Kpad, accumulate, total);
   } else {
     const size_t total = pix * C;
-    hipLaunchKernelGGL(col2im_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho, Wo,
+    SR_LAUNCH(col2im_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, dact, H, W, C, ksize, stride, Ho, Wo,
                        Kpad, accumulate, total);
   }
   SR_CHECK_LAUNCH();
@@ -518,11 +518,11 @@ extern "C" int srhip_add_unpad(const float* src, float* dst, int Cout, int C, in
 static void launch_bn_stats(const float* x, double* ws, int rows, int C, const BnFinal& fin, hipStream_t s, double* acc_only = nullptr) {
   if (C % 4 == 0) {
     const int rpb = bn_rows_per_block(rows, C, 4);
-    hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
+    SR_LAUNCH((bn_reduce_kernel<false, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
                        ws, rows, C, rpb, fin, acc_only);
   } else {
     const int rpb = bn_rows_per_block(rows, C, 1);
-    hipLaunchKernelGGL((bn_reduce_kernel<false, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
+    SR_LAUNCH((bn_reduce_kernel<false, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
                        ws, rows, C, rpb, fin, acc_only);
   }
 }
@@ -539,7 +539,7 @@ extern "C" int srhip_bn_fwd(const float* x, const float* gamma, const float* bet
     launch_bn_stats(x, ws, rows, C, BnFinal{}, s);
     SR_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, ws, gamma, beta, eps, slope, momentum, update_running,
+  SR_LAUNCH(bn_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, s, x, ws, gamma, beta, eps, slope, momentum, update_running,
                      running_mean, running_var, save_mean, save_invstd, !training, (bf16_t*)act_bf16, act_f32, rows, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -571,7 +571,7 @@ extern "C" int srhip_bn_fold(const double* acc, double rows_total, float eps, fl
   BnFinal fin;
   fin.out_mean = out_mean; fin.out_invstd = out_invstd; fin.running_mean = running_mean; fin.running_var = running_var;
   fin.momentum = momentum; fin.update_running = update_running; fin.eps = eps;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc, totals, (int)rows_total, C, fin);
+  SR_LAUNCH(bn_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc, totals, (int)rows_total, C, fin);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -582,11 +582,11 @@ extern "C" int srhip_bn_bwd_reduce(const float* dact, const float* x, const floa
   hipStream_t s = (hipStream_t)stream;
   if (C % 4 == 0) {
     const int rpb = bn_rows_per_block(rows, C, 4);
-    hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
+    SR_LAUNCH((bn_reduce_kernel<true, 4>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
                        rows, C, rpb, BnFinal{}, nullptr);
   } else {
     const int rpb = bn_rows_per_block(rows, C, 1);
-    hipLaunchKernelGGL((bn_reduce_kernel<true, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
+    SR_LAUNCH((bn_reduce_kernel<true, 1>), dim3(cdiv(rows, rpb)), dim3(256), 0, s, x, dact, save_mean, save_invstd, gamma, beta, slope, ws,
                        rows, C, rpb, BnFinal{}, nullptr);
   }
   SR_CHECK_LAUNCH();
@@ -600,7 +600,7 @@ extern "C" int srhip_bn_bwd_apply(const float* dact, const float* x, const float
   if (!dact || !x || !save_mean || !save_invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !totals || rows <= 0 || C <= 0 ||
       rows_total < rows)
     return SR_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dact, totals, save_mean,
+  SR_LAUNCH(bn_bwd_apply_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dact, totals, save_mean,
                      save_invstd, gamma, beta, slope, resid, dx, dgamma, dbeta, rows, C, local_totals ? local_totals : totals, rows_total,
                      (bf16_t*)dx_bf16);
   SR_CHECK_LAUNCH();
@@ -618,29 +618,29 @@ extern "C" int srhip_bn_bwd(const float* dact, const float* x, const float* save
 
 extern "C" int srhip_avgpool_fwd(const float* act, float* feat, int B, int HW2, int C, void* stream) {
   if (!act || !feat || B <= 0 || HW2 <= 0 || C <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, act, feat, HW2, C);
+  SR_LAUNCH(avgpool_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, act, feat, HW2, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 extern "C" int srhip_avgpool_bwd(const float* dfeat, float* dact, int B, int HW2, int C, void* stream) {
   if (!dfeat || !dact || B <= 0 || HW2 <= 0 || C <= 0 || ((long)B * HW2 * C) % 64) return SR_EINVAL;
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((long)B * HW2 * C / 64), dim3(64), 0, (hipStream_t)stream, dfeat, dact, HW2, C);
+  SR_LAUNCH(avgpool_bwd_kernel, dim3((long)B * HW2 * C / 64), dim3(64), 0, (hipStream_t)stream, dfeat, dact, HW2, C);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 
 extern "C" int srhip_fc_fwd(const float* feat, const float* Wc, const float* bc, float* logits, int B, int F, int K, void* stream) {
   if (!feat || !Wc || !bc || !logits || B <= 0 || F <= 0 || K <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(fc_fwd_kernel, dim3(B, cdiv(K, 4)), dim3(256), 0, (hipStream_t)stream, feat, Wc, bc, logits, F, K);
+  SR_LAUNCH(fc_fwd_kernel, dim3(B, cdiv(K, 4)), dim3(256), 0, (hipStream_t)stream, feat, Wc, bc, logits, F, K);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 extern "C" int srhip_fc_bwd(const float* dlogits, const float* feat, const float* Wc, float* dfeat, float* dWc, float* dbc, int B, int F, int K,
                             void* stream) {
   if (!dlogits || !feat || !Wc || !dfeat || !dWc || !dbc || B <= 0 || F <= 0 || K <= 0) return SR_EINVAL;
-  hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(B, cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, dlogits, Wc, dfeat, F, K);
+  SR_LAUNCH(fc_bwd_x_kernel, dim3(B, cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, dlogits, Wc, dfeat, F, K);
   SR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, dlogits, feat, dWc, dbc, B, F, K);
+  SR_LAUNCH(fc_bwd_w_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, dlogits, feat, dWc, dbc, B, F, K);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

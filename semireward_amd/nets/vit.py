@@ -15,8 +15,6 @@ Data layout in HBM (B images, N tokens, D channels, M = B*N rows):
   weights                   bf16 [out, in]   (+ transposed bf16 copies for the dX products)
 """
 import math
-import os
-import types
 
 import torch
 
@@ -60,16 +58,14 @@ def param_names_shapes(cfg):
 
 DW_GROUPS = 3              # layer groups of the weight-gradient launch when a grad_ready_cb is installed (data parallel)
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.layernorm_bwd_part)
-_FUSED_MLP = os.environ.get("SRHIP_FUSED_MLP", "1") != "0"
-_FUSED_ATTN = os.environ.get("SRHIP_FUSED_ATTN", "1") != "0"
-_FUSED_PROJ = os.environ.get("SRHIP_FUSED_PROJ", "1") != "0"        # attention projection + residual inside the fused MLP launch
-_FUSED_NEXT_LN = os.environ.get("SRHIP_FUSED_NEXT_LN", "1") != "0"  # ... which then also writes the next block's norm1 output
+# Which launches the rows without a backward take (module constants: the tests flip them to compare the fused chain with the launches it replaces)
+_FUSED_MLP = True          # LN2 + fc1 + GELU + fc2 + residual as one launch
+_FUSED_ATTN = True         # qkv Linear + attention as one launch
+_FUSED_PROJ = True         # attention projection + residual inside the fused MLP launch
+_FUSED_NEXT_LN = True      # ... which then also writes the next block's norm1 output
 # the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
 # pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
-_FUSED_MLP_MIN_ROWS = int(os.environ.get("SRHIP_FUSED_MLP_MIN_ROWS", "16384"))
-# gradient + inference images in ONE forward (forward_mixed).  Opt-in: at the reference batch the 16 extra images push the qkv GEMM
-# from 4 to 5 rounds of 256x256 tiles (89 -> 106 us) and the two-stream schedule hides the small launches anyway: 8.52 vs 8.10 ms/step.
-MIXED_FWD = os.environ.get("SRHIP_MIXED_FWD", "0") != "0"
+_FUSED_MLP_MIN_ROWS = 16384
 
 
 def _round_up(a, b):
@@ -175,7 +171,7 @@ class VisionTransformer:
         ops.cast_f32_bf16(self.flat, self.flat_bf16, self.numel)
         self.refresh_transposed()
 
-    lazy_transposed = os.environ.get("SR_LAZY_WT", "1") != "0"   # the optimizer only marks the transposed weight copies stale (ensure_transposed)
+    lazy_transposed = True   # the optimizer only marks the transposed weight copies stale (ensure_transposed)
 
     def ensure_transposed(self):
         """The transposed bf16 weight copies are operands of the BACKWARD only (dX products).  After an optimizer step they are refreshed
@@ -365,101 +361,6 @@ class VisionTransformer:
             ctx.feat = feat
         ops.cls_head_fwd(x, P("norm.weight"), P("norm.bias"), cfg.eps, P("head.weight"), P("head.bias"), feat, logits,
                          ctx.xhat if save else None, ctx.rstd if save else None, B, N, D, C)
-        return logits, feat, ctx
-
-    # ---- mixed forward: gradient images first, everything in ONE pass ----------------------------------------------
-    def supports_mixed(self, B):
-        cfg = self.cfg
-        return cfg.embed_dim == 384 and cfg.hidden % 128 == 0 and cfg.hidden <= 4096 and B * cfg.num_tokens >= 1024
-
-    def _mixed_arenas(self, B, Bg):
-        """Activation arenas of a mixed batch (Bg gradient images FIRST, then B - Bg inference images).  Layer i writes its
-        [M, w] activation at row offset i * Mg of an arena of depth * Mg + M rows (Mg = Bg * N): its leading Mg rows (the
-        gradient images) are never touched again, its inference rows are overwritten by the later layers -- the backward
-        reads [Mg, w] slices, nothing is copied, and the memory is (depth * Mg + M) rows instead of depth * M."""
-        key = ("mixed", B, Bg)
-        if key in self._ws:
-            return self._ws[key]
-        cfg = self.cfg
-        D, N, H, Hd, L = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.depth
-        M, Mg = B * N, Bg * N
-        f32, bf16, dev = torch.float32, torch.bfloat16, self.device
-        A = types.SimpleNamespace()
-        A.X = torch.empty((L + 1) * Mg + M, D, dtype=f32, device=dev)         # block inputs x_0 .. x_L
-        A.XM = torch.empty(L * Mg + M, D, dtype=f32, device=dev)              # residual stream after the attention branch
-        A.LN1 = torch.empty(L * Mg + M, D, dtype=bf16, device=dev)
-        A.QKV = torch.empty(L * Mg + M, 3 * D, dtype=bf16, device=dev)
-        A.AO = torch.empty(L * Mg + M, D, dtype=bf16, device=dev)
-        A.ST1 = torch.empty(L, 2, M, dtype=f32, device=dev)
-        A.LSE = torch.empty(L, B, H, N, dtype=f32, device=dev)
-        A.LN2 = torch.empty(L, Mg, D, dtype=bf16, device=dev)                 # written by the fused MLP kernel for the gradient rows
-        A.PRE = torch.empty(L, Mg, Hd, dtype=bf16, device=dev)
-        A.Hh = torch.empty(L, Mg, Hd, dtype=bf16, device=dev)
-        A.ST2 = torch.empty(L, 2, Mg, dtype=f32, device=dev)
-        A.xhat = torch.empty(B, D, dtype=f32, device=dev)
-        A.rstd = torch.empty(B, dtype=f32, device=dev)
-        win = lambda T, i, rows=M: T[i * Mg:i * Mg + rows]   # noqa: E731
-        ctx = FwdContext()
-        ctx.xs = [win(A.X, i, Mg) for i in range(L + 1)]
-        ctx.xmid = [win(A.XM, i, Mg) for i in range(L)]
-        ctx.ln1 = [win(A.LN1, i, Mg) for i in range(L)]
-        ctx.qkv = [win(A.QKV, i, Mg) for i in range(L)]
-        ctx.ao = [win(A.AO, i, Mg) for i in range(L)]
-        ctx.ln2, ctx.pre, ctx.h = [A.LN2[i] for i in range(L)], [A.PRE[i] for i in range(L)], [A.Hh[i] for i in range(L)]
-        ctx.st1 = [(A.ST1[i, 0, :Mg], A.ST1[i, 1, :Mg]) for i in range(L)]
-        ctx.st2 = [(A.ST2[i, 0], A.ST2[i, 1]) for i in range(L)]
-        ctx.lse = [A.LSE[i, :Bg] for i in range(L)]
-        ctx.xhat, ctx.rstd = A.xhat[:Bg], A.rstd[:Bg]
-        A.ctx, A.win = ctx, win
-        self._ws[key] = A
-        return A
-
-    def forward_mixed(self, img, img_index, droppath, n_grad):
-        """ONE forward over B = len(img_index) images of which the first ``n_grad`` carry a gradient: the reference's (1 + K)
-        passes of a training step as a single launch train (216 images at the reference batch).  All rows take the inference
-        kernels (fused LN2 + MLP, big GEMM tiles); the backward operands of the leading rows are kept in the arenas.
-        Returns (logits [B,C], feat [B,D], ctx) with ``ctx`` as from forward_features(save=True) for the first n_grad images."""
-        cfg = self.cfg
-        D, N, H, Hd, C, L = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes, cfg.depth
-        B, Bg = int(img_index.numel()), int(n_grad)
-        M, Mg = B * N, Bg * N
-        A = self._mixed_arenas(B, Bg)
-        ctx, win = A.ctx, A.win
-        ctx.B, ctx.img, ctx.img_index = Bg, img, img_index[:Bg].contiguous()
-        ctx.dp = droppath[:, :, :Bg].contiguous() if droppath is not None else None
-        wb, P = self.flat_bf16, self.p
-        x = win(A.X, 0)
-        Kp = cfg.in_chans * cfg.patch_size ** 2
-        if Kp <= 64:
-            ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),
-                                P("pos_embed"), x, B, cfg.in_chans, cfg.img_size, cfg.patch_size, D)
-        else:
-            Np = N - 1
-            col = self._buf("mcol", (B * Np, Kp), torch.bfloat16)
-            tok = self._buf("mtok", (B * Np, D), torch.float32)
-            ops.patch_im2col(img, img_index, col, B, cfg.in_chans, cfg.img_size, cfg.patch_size)
-            ops.gemm_nt(ops.EPI_F32, col, P("patch_embed.proj.weight", wb), tok, B * Np, D, Kp)
-            ops.patch_assemble(tok, P("patch_embed.proj.bias"), P("cls_token"), P("pos_embed"), x, B, Np, D)
-        scale = 64 ** -0.5
-        for i in range(L):
-            b = "blocks.%d." % i
-            s1 = droppath[i, 0] if droppath is not None else None
-            s2 = droppath[i, 1] if droppath is not None else None
-            ln, qkv, ao, xm, xn = win(A.LN1, i), win(A.QKV, i), win(A.AO, i), win(A.XM, i), win(A.X, i + 1)
-            ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, A.ST1[i, 0], A.ST1[i, 1], M, D)
-            ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
-            ops.attn_fwd(qkv, ao, A.LSE[i], B, N, H, scale)
-            ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), xm, M, D, D, bias=P(b + "attn.proj.bias"),
-                        row_scale=s1, rows_per_sample=N, aux_in=x, ldaux=D)
-            ops.mlp_fused(xm, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb), P(b + "mlp.fc1.bias"),
-                          P(b + "mlp.fc2.weight", wb), P(b + "mlp.fc2.bias"), s2, N, M, D, Hd, x_out=xn,
-                          save=(Mg, A.LN2[i], A.PRE[i], A.Hh[i], A.ST2[i, 0], A.ST2[i, 1]))
-            x = xn
-        feat = torch.empty(B, D, dtype=torch.float32, device=self.device)
-        logits = torch.empty(B, C, dtype=torch.float32, device=self.device)
-        ops.cls_head_fwd(x, P("norm.weight"), P("norm.bias"), cfg.eps, P("head.weight"), P("head.bias"), feat, logits, A.xhat, A.rstd,
-                         B, N, D, C)
-        ctx.feat = feat[:Bg]
         return logits, feat, ctx
 
     def forward(self, x, only_fc=False, only_feat=False, **kw):

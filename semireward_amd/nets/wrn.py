@@ -17,7 +17,7 @@ import torch
 from .. import ops
 
 MOMENTUM, SLOPE = 0.001, 0.1
-_FUSED_DX = __import__("os").environ.get("SR_WRN_FUSED_DX", "1") != "0"      # tuning switch: input gradients of stride-1 3x3 layers as convolutions
+_FUSED_DX = True      # input gradients of the stride-1 3x3 layers as implicit-GEMM convolutions with the rotated / transposed filter
 
 
 def _round_up(a, b):
@@ -26,7 +26,7 @@ def _round_up(a, b):
 
 class WrnContext:
     """Activations of one ``save=True`` forward."""
-    __slots__ = ("B", "H", "W", "stem", "blocks", "final", "feat", "tag", "graphed")
+    __slots__ = ("B", "H", "W", "stem", "blocks", "final", "feat", "tag")
 
 
 class WideResNet:
@@ -95,12 +95,19 @@ class WideResNet:
         self.ws = torch.zeros(ops.bn_ws_doubles(), dtype=torch.float64, device=self.device)      # (zeroed once: srhip_bn_fwd keeps its counter at 0)
         # per-BatchNorm statistics accumulators (16 copies x (sum | sum of squares)), filled by the convolution in front of the BatchNorm and
         # folded by the one behind it; one arena so that a forward zeroes them with one launch
+        # Data parallel: two more doubles ride behind the FIRST accumulator a forward exchanges -- (rows, ranks * rows^2) of this rank -- so the
+        # per-rank row counts are compared by the all-reduce that is issued anyway (_sync_acc / check_equal_rows): no collective of its own.
         offs, o = {}, 0
+        first = self.blocks[0][0] + "bn1"
         for nme, c, _ in self.bn:
             offs[nme] = (o, ops.bn_acc_doubles(c))
-            o += ops.bn_acc_doubles(c)
+            o += ops.bn_acc_doubles(c) + (2 if nme == first else 0)
         self.bn_acc_arena = torch.zeros(o, dtype=torch.float64, device=self.device)
         self.bn_acc = {nme: self.bn_acc_arena[a:a + n] for nme, (a, n) in offs.items()}
+        a_, n_ = offs[first]
+        self._acc_first_with_rows = self.bn_acc_arena[a_:a_ + n_ + 2]
+        self._rows_cell = self.bn_acc_arena[a_ + n_:a_ + n_ + 2]
+        self._rows_const, self._rows_dev, self._rows_tmp = {}, None, None
         self._prep_desc = None
         self._flip_desc = None
         self.conv_stride = {"conv1.weight": 1}
@@ -108,7 +115,6 @@ class WideResNet:
             self.conv_stride.update({p_ + "conv1.weight": st_, p_ + "conv2.weight": 1, p_ + "convShortcut.weight": st_})
         self.training = True
         self.couples_batch_rows = True      # BatchNorm: every forward call is its own statistics group (no cross-pass batching)
-        self._rows_checked = set()
         self._buf_cache = {}
 
     # ---- parameter plumbing (same surface as the ViT engine) ------------------------------------------------------------------
@@ -242,19 +248,35 @@ class WideResNet:
             import torch.distributed as dist
             dist.all_reduce(self.bn_acc[bn])
 
-    def _check_equal_rows(self, B):
-        """The exchanged statistics are sums over rows and the kernels divide by rows * ranks (torch's SyncBatchNorm exchanges the counts as
-        well): every rank must forward the same number of images.  Checked with ONE small collective per batch size, then cached -- a
-        last partial batch or an uneven split raises here instead of silently skewing mean / var / running_var."""
-        if self.stat_ranks > 1 and B not in self._rows_checked:
-            import torch.distributed as dist
-            t = torch.tensor([B, -B], dtype=torch.int64, device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            hi, lo = int(t[0]), -int(t[1])
-            if hi != lo:
-                raise RuntimeError("WideResNet under data parallel (SyncBatchNorm): per-rank batches differ (%d .. %d images); the statistics exchange "
-                                   "assumes equal row counts on every rank" % (lo, hi))
-            self._rows_checked.add(B)
+    def _sync_first_acc(self, B):
+        """The exchange of the first accumulator of a training forward, with this rank's row count riding along.  The statistics are sums over
+        rows and the kernels divide by rows * ranks (torch's SyncBatchNorm exchanges the counts as well), so every rank must forward the same
+        number of images.  EVERY rank enters the SAME collective in EVERY training forward -- whether the counts agree is decided from its
+        result ON THE DEVICE (sum B and ranks * sum B^2: equal rows <=> ranks * sum B^2 == (sum B)^2), accumulated into a flag the host
+        reads where it may wait (check_equal_rows: AlgorithmBase.train at the logging cadence and before a checkpoint; every forward in the
+        test suite).  A rank-local decision to enter a collective of its own (a per-batch-size cache) would pair that collective with another
+        rank's next statistics exchange when the counts DO differ -- a hang instead of the error."""
+        import torch.distributed as dist
+        R = self.stat_ranks
+        c = self._rows_const.get((B, R))
+        if c is None:
+            c = self._rows_const[(B, R)] = torch.tensor([float(B), float(R) * B * B], dtype=torch.float64, device=self.device)
+            if self._rows_dev is None:
+                self._rows_dev = torch.zeros((), dtype=torch.float64, device=self.device)
+                self._rows_tmp = torch.zeros((), dtype=torch.float64, device=self.device)
+        self._rows_cell.copy_(c)
+        dist.all_reduce(self._acc_first_with_rows)
+        torch.addcmul(self._rows_cell[1], self._rows_cell[0], self._rows_cell[0], value=-1.0, out=self._rows_tmp)      # R sum B^2 - (sum B)^2 >= 0
+        torch.maximum(self._rows_dev, self._rows_tmp, out=self._rows_dev)
+        if ops._CHECK_ARGS and not torch.cuda.is_current_stream_capturing():
+            self.check_equal_rows()
+
+    def check_equal_rows(self):
+        """Raises if any training forward since the last call saw different per-rank batch sizes (synchronises: one scalar read)."""
+        if self._rows_dev is not None and float(self._rows_dev) > 0.5:
+            self._rows_dev.zero_()
+            raise RuntimeError("WideResNet under data parallel (SyncBatchNorm): the per-rank batches of a training forward differed; the statistics "
+                               "exchange assumes equal row counts on every rank (a last partial batch or an uneven split)")
 
     def _conv_bn(self, wname, xin, in_bn, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False):
         """out = conv(LeakyReLU(BN_in(xin))) (+ resid) -- or conv(xin) when ``raw`` -- and, in training mode, the sums of ``out`` added into the
@@ -303,12 +325,12 @@ class WideResNet:
             ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
         h, w = H, W
         if train:
-            self._check_equal_rows(B)
             self.bn_acc_arena.zero_()                         # the accumulators of every BatchNorm of this forward: one fill launch
             # sums of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
             first = self.blocks[0][0] + "bn1"
             ops.bn_accumulate(out, self.bn_acc[first], B * h * w, self.channels[0])
-            self._sync_acc(first)
+            if self.stat_ranks > 1:
+                self._sync_first_acc(B)                       # (+ the row counts of the ranks, compared on the device)
         for bi, (p, cin, cout, stride, abr) in enumerate(self.blocks):
             equal = cin == cout
             raw = not (equal or abr)                          # wrn.py:50: conv1 / convShortcut take the RAW x; bn1's statistics still move
@@ -349,50 +371,15 @@ class WideResNet:
             ctx.final, ctx.feat = dict(x=out, st=stf, h=h, w=w), feat
         return logits, feat, ctx
 
-    # ---- the passes of a step as HIP graphs (opt-in: SR_WRN_GRAPH=1) ------------------------------------------------------------------------
-    # SRPseudoLabel forwards the SAME unlabelled batch K + 1 >= 9 times per step (srpseudolabel.py:59-90) plus the labelled batch, and runs
-    # two backwards: ~35 launches per forward and ~250 per backward.  None of them has per-call host state (no DropPath; learning rate and
-    # momentum live in the optimizer launch; every workspace is a persistent buffer keyed by ``tag``), so each (kind, tag, shape) can be
-    # captured once and replayed: the first call runs eagerly (it builds the workspaces), the second is captured.  Measured on one MI355X at
-    # the classic_cv batch: 9.9 ms per step eager, 10.0 ms replayed -- the step is bound by the GPU, not by the host's enqueue rate -- so eager
-    # launches are the default and the replay path stays for hosts that are slower than that.
-    use_graphs = __import__("os").environ.get("SR_WRN_GRAPH", "0") != "0"
-
-    def _graphed(self, key, inputs, fn):
-        """fn(*inputs) with ``inputs`` device tensors -> whatever fn returns (tensors inside it are the graph's own static buffers)."""
-        st = self.__dict__.setdefault("_graphs", {})
-        ent = st.get(key)
-        if ent is None:
-            n = st.get(("seen", key), 0)
-            st[("seen", key)] = n + 1
-            if (not self.use_graphs or n < 1 or not all(t.is_cuda for t in inputs) or torch.cuda.is_current_stream_capturing()):
-                return fn(*inputs), False
-            statics = [t.detach().clone() for t in inputs]
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), ops.stream_scope():
-                out = fn(*statics)
-            ent = st[key] = (g, statics, out)
-        g, statics, out = ent
-        for s_, t in zip(statics, inputs):
-            if s_.data_ptr() != t.data_ptr():
-                s_.copy_(t, non_blocking=True)
-        g.replay()
-        return out, True
-
+    # ---- the two kinds of pass of an SRPseudoLabel step (srpseudolabel.py:59-90) ---------------------------------------------------------------
     def forward_frozen(self, img, tag="ulb_inf"):
-        """forward_features(img, save=False, update_stats=False) -> (logits, feat); the returned tensors are the caller's own copies."""
-        (lg, ft, _), graphed = self._graphed(("frozen", tag, tuple(img.shape), bool(self.training)), [img],
-                                             lambda x: self.forward_features(x, save=False, update_stats=False, tag=tag))
-        return (lg.clone(), ft.clone()) if graphed else (lg, ft)
+        """A data_generator pass: forward_features(img, save=False, update_stats=False) -> (logits, feat)."""
+        lg, ft, _ = self.forward_features(img, save=False, update_stats=False, tag=tag)
+        return lg, ft
 
     def forward_saved(self, img, update_stats, tag):
-        """forward_features(img, save=True, ...) -> (logits, feat, ctx) for a later backward(ctx, .); logits / feat are the caller's copies,
-        ctx keeps the graph's own buffers (the captured backward reads them)."""
-        (lg, ft, ctx), graphed = self._graphed(("saved", tag, tuple(img.shape), bool(update_stats), bool(self.training)), [img],
-                                               lambda x: self.forward_features(x, save=True, update_stats=update_stats, tag=tag))
-        ctx.graphed = graphed
-        return (lg.clone(), ft.clone(), ctx) if graphed else (lg, ft, ctx)
+        """forward_features(img, save=True, ...) -> (logits, feat, ctx) for a later backward(ctx, .)."""
+        return self.forward_features(img, save=True, update_stats=update_stats, tag=tag)
 
     def forward(self, x, only_fc=False, only_feat=False, **kw):
         assert not only_fc
@@ -404,12 +391,6 @@ class WideResNet:
     # ---- backward ---------------------------------------------------------------------------------------------------------------
     def backward(self, ctx, dlogits):
         """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] for a save=True forward."""
-        if getattr(ctx, "graphed", False):          # the forward's buffers are a graph's static buffers: the backward can be one too
-            self._graphed(("bwd", ctx.tag, tuple(dlogits.shape)), [dlogits.contiguous()], lambda d: self._backward(ctx, d))
-        else:
-            self._backward(ctx, dlogits)
-
-    def _backward(self, ctx, dlogits):
         B, tag = ctx.B, ctx.tag
         f32, bf16 = torch.float32, torch.bfloat16
         P, G = self.p, (lambda n: self.p(n, self.grad))

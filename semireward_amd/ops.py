@@ -54,17 +54,6 @@ def _s():
     return _STREAM if _STREAM is not None else torch.cuda.current_stream().cuda_stream
 
 
-def masked_stream(n_cus, device=None):
-    """A HIP stream whose launches may only use the first ``n_cus`` compute units of the driver's numbering (MI355X: bit i of the mask is a CU
-    of XCD i % 8, so 192 = 24 CUs of every XCD), wrapped for torch.cuda.stream().  The stream lives as long as the process."""
-    import ctypes
-    words = (max(n_cus, 1) + 31) // 32
-    mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if 32 * (w + 1) <= n_cus else ((1 << (n_cus - 32 * w)) - 1)) for w in range(words)])
-    out = ctypes.c_void_p()
-    _call("srhip_stream_create_cu_mask", ctypes.cast(mask, ctypes.c_void_p), words, ctypes.cast(ctypes.byref(out), ctypes.c_void_p))
-    return torch.cuda.ExternalStream(out.value, device=device)
-
-
 class stream_scope:
     """Pin the hipStream_t for a burst of launches (torch.cuda.current_stream() costs ~2.5 us per call, 40 % of the host
     time of a training step).  Use as a context manager around code that does not switch streams."""
@@ -94,12 +83,25 @@ def _call(name, *args):
 
 # ---- optional live profiling of the dominant kernel (bench.py roofline object) -------------------
 class _GemmProfile:
-    """HIP events (torch.cuda.Event on the launch stream) around every GEMM launch, keyed by the device kernel the C
-    dispatcher picks (mirrors srhip_gemm_nt: persistent 256x256 kernel for wide-N large products, else 128x128 tiles)."""
+    """Timing of every instrumented launch, keyed by the device kernel the C dispatcher picks.  Two clocks per launch:
+      * the library's own dispatch-bound event pair (srhip_prof_*, csrc/prof.hip): the kernel's EXECUTION time, the quantity rocprofv3
+        --kernel-trace reports -- this is what the roofline object uses;
+      * a torch.cuda.Event pair recorded on the launch stream around the call: execution + dispatch latency + the event packets
+        (reported beside it as ``avg_launch_us_event_pair``, never used for a roofline fraction)."""
     EPI = {0: "bf16", 1: "gelu_bf16", 2: "resid_f32", 3: "dgelu_bf16", 4: "f32"}
 
     def __init__(self):
-        self.recs = []          # (event0, event1, flops, kernel name)
+        self.recs = []          # (event0, event1, flops, kernel name, algorithmic bytes, first launch index, last launch index)
+        _lib.lib().srhip_prof_enable(1)
+
+    def timed(self, name, args, flops, kernel, nbytes):
+        """One instrumented C call (it may issue helper launches besides its main kernel: all of them are summed)."""
+        i0 = _lib.lib().srhip_prof_count()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call(name, *args)
+        e1.record()
+        self.recs.append((e0, e1, flops, kernel, nbytes, i0, _lib.lib().srhip_prof_count()))
 
     _KERNEL = {"tile128": "gemm_nt_kernel<%d>", "small64": "gemm_small_kernel<%d>", "big256": "gemm_big_kernel<%d, 8, 2>",
                "big128": "gemm_big_kernel<%d, 4, 2>", "big2wg": "gemm_big_kernel<%d, 8, 1>"}
@@ -127,12 +129,15 @@ class _GemmProfile:
         return b
 
     def per_kernel(self):
+        import ctypes
         torch.cuda.synchronize()
         out = {}
-        for a, b, f, name, nbytes in self.recs:
-            d = out.setdefault(name, [0.0, 0.0, 0, 0.0])
-            d[0] += f; d[1] += a.elapsed_time(b); d[2] += 1; d[3] += nbytes
-        return out           # name -> [flops, ms, launches, algorithmic bytes]
+        ms = ctypes.c_float()
+        for a, b, f, name, nbytes, i0, i1 in self.recs:
+            _call("srhip_prof_elapsed_ms", i0, i1, ctypes.cast(ctypes.byref(ms), ctypes.c_void_p))
+            d = out.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
+            d[0] += f; d[1] += ms.value; d[2] += 1; d[3] += nbytes; d[4] += a.elapsed_time(b)
+        return out           # name -> [flops, kernel-execution ms, launches, algorithmic bytes, event-pair ms]
 
     def totals(self):
         pk = self.per_kernel()
@@ -151,6 +156,7 @@ def enable_gemm_profile():
 def disable_gemm_profile():
     global _PROFILE
     _PROFILE = None
+    _lib.lib().srhip_prof_enable(0)
 
 
 # ---- dense ------------------------------------------------------------------------------------
@@ -158,13 +164,9 @@ def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, r
             aux_in=None, aux_out=None, ldaux=0, alpha=1.0, beta=0.0):
     """C[M,N] (+)= A[M,K] . B[N,K]^T  (bf16 operands; see srhip_gemm_nt)."""
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
-              rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
-        e1.record()
-        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K),
-                              _GemmProfile.gemm_bytes(epi, M, N, K, aux_in, aux_out, beta)))
+        _PROFILE.timed("srhip_gemm_nt", (epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
+              rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s(),), 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K),
+                              _GemmProfile.gemm_bytes(epi, M, N, K, aux_in, aux_out, beta))
         return
     _call("srhip_gemm_nt", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), ldc or N, M, N, K, _p(bias), _p(row_scale),
           rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
@@ -214,11 +216,7 @@ def make_group_desc(problems, device):
 
 def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
-        e1.record()
-        _PROFILE.recs.append((e0, e1, flops, "gemm_grouped_f32_kernel", nbytes))
+        _PROFILE.timed("srhip_gemm_nt_grouped_f32", (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, "gemm_grouped_f32_kernel", nbytes)
         return
     _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
@@ -259,11 +257,7 @@ def make_group_tn_desc(problems, device, split_k=0):
 def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
     """C_p = alpha * A_p^T . B_p + beta * C_p (+ dbias_p += colsum A_p) for all problems in one launch."""
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_gemm_tn_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
-        e1.record()
-        _PROFILE.recs.append((e0, e1, flops, "gemm_tn_grouped_f32_kernel", nbytes))
+        _PROFILE.timed("srhip_gemm_tn_grouped_f32", (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, "gemm_tn_grouped_f32_kernel", nbytes)
         return
     _call("srhip_gemm_tn_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
@@ -281,23 +275,27 @@ def attn_block_fused(xn, Wqkv, bqkv, out, B, N, D, H, scale, qkv_extra=None, out
         # rows 256, 256 + N, ... of xn: a strided A operand (lda = N * D), no gather
         gemm_nt(EPI_BF16, xn[256:], Wqkv, qkv_extra, B, 3 * D, D, lda=N * D, bias=bqkv)
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), _p(out_scale), B, N, D, H, scale, _s())
-        e1.record()
         M = B * N
         # algorithmic work: the qkv product + QK^T + PV; bytes: xn bf16 in, bf16 out, the weights once
-        _PROFILE.recs.append((e0, e1, 2.0 * M * 3 * D * D + 4.0 * B * H * N * N * 64, "attn_block_kernel<%d>" % N,
-                              2.0 * M * D + 2.0 * M * D + 2.0 * 3 * D * D))
+        _PROFILE.timed("srhip_attn_block_fused", (_p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), _p(out_scale), B, N, D, H, scale, _s(),), 2.0 * M * 3 * D * D + 4.0 * B * H * N * N * 64, "attn_block_kernel<%d>" % N,
+                              2.0 * M * D + 2.0 * M * D + 2.0 * 3 * D * D)
         return
     _call("srhip_attn_block_fused", _p(xn), _p(Wqkv), _p(bqkv), _p(qkv_extra), _p(out), _p(out_scale), B, N, D, H, scale, _s())
 
 
 def attn_fwd(qkv, out, lse, B, N, H, scale):
+    if _PROFILE is not None:        # flops: QK^T + PV; bytes: qkv in, out
+        _PROFILE.timed("srhip_attn_fwd", (_p(qkv), _p(out), _p(lse), B, N, H, scale, _s()), 4.0 * B * H * N * N * 64, "attn_fwd_kernel",
+                       2.0 * B * N * 4 * H * 64)
+        return
     _call("srhip_attn_fwd", _p(qkv), _p(out), _p(lse), B, N, H, scale, _s())
 
 
 def attn_bwd(qkv, out, d_out, lse, dqkv, delta_ws, B, N, H, scale):
+    if _PROFILE is not None:        # flops: 5 N x N x 64 products per head (S, dP, dQ, dK, dV); bytes: qkv, out, d_out in, dqkv out
+        _PROFILE.timed("srhip_attn_bwd", (_p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), _p(delta_ws), B, N, H, scale, _s()),
+                       10.0 * B * H * N * N * 64, "attn_bwd (dq + dkv kernels)", 2.0 * B * N * 8 * H * 64)
+        return
     _call("srhip_attn_bwd", _p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), _p(delta_ws), B, N, H, scale, _s())
 
 
@@ -312,6 +310,10 @@ def layernorm_bwd_cast(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, out_bf16, ro
 
 def layernorm_bwd_part(dy, x, mean, rstd, gamma, dx, part, n_rep, out_bf16, row_scale, rows_per_sample, M, D):
     """layernorm_bwd(_cast) with dgamma / dbeta added into copy (workgroup % n_rep) of part fp32 [n_rep, 2, D]; see ln_grad_reduce."""
+    if _PROFILE is not None:        # bytes: dy (bf16) + x (fp32) in, dx fp32 read + written, bf16 copy out
+        _PROFILE.timed("srhip_layernorm_bwd_part", (_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(part), n_rep, _p(out_bf16),
+                                                    _p(row_scale), rows_per_sample, M, D, _s()), 0.0, "ln_bwd_kernel", 16.0 * M * D)
+        return
     _call("srhip_layernorm_bwd_part", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(part), n_rep, _p(out_bf16), _p(row_scale),
           rows_per_sample, M, D, _s())
 
@@ -334,12 +336,8 @@ def mlp_fused(x, gamma, beta, eps, W1, b1, W2, b2, row_scale, rows_per_sample, M
     args = (_p(x), _p(x_out if x_out is not None else x), _p(gamma), _p(beta), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(row_scale),
             rows_per_sample, rows, _p(ln2), _p(pre), _p(h), _p(mean), _p(rstd), M, D, Hd)
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_mlp_fused", *args, _s())
-        e1.record()
-        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd, "mlp_fused_kernel<384, 0, 4>",
-                              8.0 * M * D + 4.0 * D * Hd + rows * (2.0 * D + 4.0 * Hd)))
+        _PROFILE.timed("srhip_mlp_fused", (*args, _s(),), 4.0 * M * D * Hd, "mlp_fused_kernel<384, 0, 4>",
+                              8.0 * M * D + 4.0 * D * Hd + rows * (2.0 * D + 4.0 * Hd))
         return
     _call("srhip_mlp_fused", *args, _s())
 
@@ -353,14 +351,10 @@ def mlp_fused_proj(x, ao, Wp, bp, row_scale1, gamma, beta, eps, W1, b1, W2, b2, 
             _p(W1), _p(b1),
             _p(W2), _p(b2), _p(row_scale2), rows_per_sample, _p(ln_next), _p(next_gamma), _p(next_beta), M, D, Hd)
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_mlp_fused_proj", *args, _s())
-        e1.record()
         # algorithmic: fc1 + fc2 + proj products; bytes: x in, x out (fp32; x1 never leaves the accumulators), ao in (bf16), [next norm1
         # output out (bf16)], the weights once
-        _PROFILE.recs.append((e0, e1, 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_fused_kernel<384, 0, 4, true, 1>",
-                              8.0 * M * D + 2.0 * M * D + (2.0 * M * D if ln_next is not None else 0.0) + 4.0 * D * Hd + 2.0 * D * D))
+        _PROFILE.timed("srhip_mlp_fused_proj", (*args, _s(),), 4.0 * M * D * Hd + 2.0 * M * D * D, "mlp_fused_kernel<384, 0, 4, true, 1>",
+                              8.0 * M * D + 2.0 * M * D + (2.0 * M * D if ln_next is not None else 0.0) + 4.0 * D * Hd + 2.0 * D * D)
         return
     _call("srhip_mlp_fused_proj", *args, _s())
 
@@ -713,17 +707,15 @@ def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope
     im, ii = in_stats if in_stats is not None else (None, None)
     pm, pi = publish if publish is not None else (None, None)
     rm, rv = running if running is not None else (None, None)
+    args = (_p(xin), in_mode, _p(im), _p(ii), _p(in_acc), _p(in_gamma), _p(in_beta), in_eps, slope, _p(pm), _p(pi), _p(rm),
+            _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), stat_ranks, _s())
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _call("srhip_wrn_conv_bn", _p(xin), in_mode, _p(im), _p(ii), _p(in_acc), _p(in_gamma), _p(in_beta), in_eps, slope, _p(pm), _p(pi), _p(rm),
-          _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), stat_ranks, _s())
-    if _PROFILE is not None:
-        e1.record()
         npix = y.shape[0]
         # algorithmic work: the convolution's MACs; bytes: the fp32 input once, the fp32 output (+ residual) once, the filter once
-        _PROFILE.recs.append((e0, e1, 2.0 * npix * Cin * ksize * ksize * Cout, "wrn_conv_kernel",
-                              4.0 * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad))
+        _PROFILE.timed("srhip_wrn_conv_bn", args, 2.0 * npix * Cin * ksize * ksize * Cout, "wrn_conv_kernel",
+                       4.0 * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad)
+        return
+    _call("srhip_wrn_conv_bn", *args)
 
 
 def wrn_head(x, in_mode, in_stats, in_acc, gamma, beta, eps, slope, Wc, bc, feat, logits, B, HW2, C, K, publish=None, running=None,
@@ -829,12 +821,8 @@ def _d(drop):
 def gemm_nt_resid_dropout(A, B, C, M, N, K, bias, resid, drop, lda=None, ldb=None):
     """C(f32)[M,N] = resid (or C) + dropout(A . B^T + bias)."""
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_gemm_nt_resid_dropout", _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s())
-        e1.record()
-        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(EPI_RESID_F32, M, N, K),
-                              _GemmProfile.gemm_bytes(EPI_RESID_F32, M, N, K, resid, None, 0.0)))
+        _PROFILE.timed("srhip_gemm_nt_resid_dropout", (_p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s(),), 2.0 * M * N * K, _GemmProfile.kernel_name(EPI_RESID_F32, M, N, K),
+                              _GemmProfile.gemm_bytes(EPI_RESID_F32, M, N, K, resid, None, 0.0))
         return
     _call("srhip_gemm_nt_resid_dropout", _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s())
 
@@ -896,11 +884,7 @@ def mask_lengths(mask, key_len, B, L):
 def gemm_nt_dropout(epi, A, B, C, M, N, K, drop, *, lda=None, ldb=None, bias=None, aux_in=None, aux_out=None, ldaux=0):
     """gemm_nt with dropout in the GELU / DGELU / RESID epilogue (ldc == N)."""
     if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _call("srhip_gemm_nt_dropout", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(aux_in), _p(aux_out), ldaux, *_d(drop), _s())
-        e1.record()
-        _PROFILE.recs.append((e0, e1, 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K), _GemmProfile.gemm_bytes(epi, M, N, K, aux_in, aux_out, 0.0)))
+        _PROFILE.timed("srhip_gemm_nt_dropout", (epi, _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(aux_in), _p(aux_out), ldaux, *_d(drop), _s(),), 2.0 * M * N * K, _GemmProfile.kernel_name(epi, M, N, K), _GemmProfile.gemm_bytes(epi, M, N, K, aux_in, aux_out, 0.0))
         return
     _call("srhip_gemm_nt_dropout", epi, _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(aux_in), _p(aux_out), ldaux, *_d(drop), _s())
 

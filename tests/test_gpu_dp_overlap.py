@@ -43,7 +43,7 @@ def test_global_reward_threshold_through_the_engine_with_two_ranks():
 def test_wideresnet_under_data_parallel_is_syncbatchnorm():
     """The reference converts the WideResNet's BatchNorms to SyncBatchNorm under DDP (core/utils/misc.py:55).  tools/dp_syncbn_check.py: two
     ranks with half a batch each == one rank with the whole batch (logits, running statistics, the sum over ranks of the gradients), and the
-    same comparison fails by > 10x when the statistics stay per-rank."""
+    same comparison fails by > 10x when the statistics stay per-rank; unequal per-rank batches raise on EVERY rank (no rank-local collective)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -53,6 +53,7 @@ def test_wideresnet_under_data_parallel_is_syncbatchnorm():
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and out.count("syncbn == whole batch: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
+    assert out.count("unequal per-rank batches raise on every rank: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_allreduce_streams_are_ordered_by_events_not_by_the_backend():

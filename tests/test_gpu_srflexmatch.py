@@ -453,83 +453,28 @@ def test_elide_unread_rows_changes_no_result():
     assert torch.equal(h0.selected_label, h1.selected_label) and torch.equal(h0.classwise_acc, h1.classwise_acc)
 
 
-def test_deferred_rows_on_a_cu_masked_stream_change_no_result(monkeypatch):
-    """Opt-in ``SR_REST_CUS`` (srhip_stream_create_cu_mask): the rows nothing reads run on a stream confined to 192 compute units while the step
-    itself moves to a non-blocking stream of its own (CU-masked streams are blocking streams).  Same kernels, same launches: every logit,
-    mask, loss and the hook state are bit-identical to the default schedule; and the mask really confines the stream (srhip_cu_probe)."""
-    from semireward_amd import ops
-    st = ops.masked_stream(192, DEV)
-    probe = torch.zeros(2048, 2, dtype=torch.int32, device=DEV)
-    torch.cuda.synchronize()
-    ops._call("srhip_cu_probe", probe.data_ptr(), 2048, 500, st.cuda_stream)
-    torch.cuda.synchronize()
-    pr = probe.cpu().numpy()
-    units = {(int(x), (int(h) >> 8) & 15, (int(h) >> 12) & 1, (int(h) >> 13) & 7) for x, h in pr}
-    assert len({u[0] for u in units}) == 8 and len(units) <= 192              # every XCD, at most 24 CUs of each
-    NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
-               num_warmup_iter=5120)
-    b = synth.synth_batch(103, 8, 8, 32, 100, 50000)
-    cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
-    dps = [torch.from_numpy(synth.synth_droppath(900 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
-    res = []
-    for cus in ("0", "192"):
-        monkeypatch.setenv("SR_REST_CUS", cus)
-        alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
-        assert (alg._rest_stream is not None) == (cus != "0")
-        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
-        alg.it = 30000
-        alg.optimizer.sched_step = alg.it
-        alg.inject_droppath = dps
-        alg.trace = {}
-        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
-        alg.call_hook("after_train_step")
-        torch.cuda.synchronize()
-        res.append((alg, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}))
-    (a0, l0, t0), (a1, l1, t1) = res
-    assert t0["K"] == 8 and t1["K"] == 8
-    assert torch.equal(t0["logits"], t1["logits"]) and torch.equal(t0["feats"], t1["feats"])
-    assert all(torch.equal(x, y) for x, y in zip(t0["masks"], t1["masks"])) and torch.equal(t0["reward"], t1["reward"])
-    for k_ in ("sup_loss", "unsup_loss", "total_loss", "util_ratio"):
-        assert float(l0["train/" + k_]) == float(l1["train/" + k_]), k_
-    h0, h1 = a0.hooks_dict["MaskingHook"], a1.hooks_dict["MaskingHook"]
-    assert torch.equal(h0.selected_label, h1.selected_label) and torch.equal(h0.classwise_acc, h1.classwise_acc)
-
-
-def test_mixed_forward_computes_every_row(monkeypatch):
-    """Opt-in ``SRHIP_MIXED_FWD`` (gradient rows inside the inference launches): every (pass, image) row must still be computed -- the rows
-    nothing reads included (they were once dropped by accident) -- and the inference rows must equal those of the default schedule."""
+def test_every_pass_image_row_is_computed(monkeypatch):
+    """Every (pass, image) row of the reference's 1 + K forwards is computed -- the rows nothing reads included (the deferred launch train on
+    the second stream; they were once dropped by accident): the step's logits table is finite everywhere and the unread rows hold what a direct
+    forward of those (pass, image) columns gives, bit for bit."""
     NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
                num_warmup_iter=5120)
     b = synth.synth_batch(103, 8, 8, 32, 100, 50000)
     cfg = V.VitCfg(num_classes=100, **V.VIT_SMALL_P2_32)
     dps = [torch.from_numpy(synth.synth_droppath(500 + k, V.drop_path_probs(cfg), 24)) for k in range(9)]
-    traces = []
-    monkeypatch.setattr(vit, "_FUSED_ATTN", False)     # the mixed forward keeps qkv for its gradient rows: same (unfused) attention kernels on both sides
-    monkeypatch.setattr(vit, "_FUSED_PROJ", False)     # ... and the residual stream after the projection
     monkeypatch.setattr(vit, "_FUSED_MLP_MIN_ROWS", 1024)   # the direct 8-image forwards below on the kernels of the big launches
-    for mixed in (False, True):
-        monkeypatch.setattr(vit, "MIXED_FWD", mixed)
-        alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
-        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
-        alg.it = 30000
-        alg.optimizer.sched_step = alg.it
-        alg.inject_droppath = dps
-        alg.trace = {}
-        alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
-        torch.cuda.synchronize()
-        assert (not mixed) or alg.model.supports_mixed(216)
-        traces.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()})
-    t0, t1 = traces
-    K, nl, nu = t0["K"], 8, 8
-    L0, L1 = t0["logits"], t1["logits"]
-    assert torch.isfinite(L1).all() and L1.shape == L0.shape == (K + 1, 24, 100)
-    grad_rows = torch.zeros(K + 1, 24, dtype=torch.bool)
-    grad_rows[0, :nl] = True
-    grad_rows[K, nl + nu:] = True
-    assert torch.equal(L0[~grad_rows], L1[~grad_rows])               # 200 inference rows (read AND unread): same kernels, same bits
-    assert float((L0[grad_rows] - L1[grad_rows]).abs().max()) < 5e-2      # gradient rows: fused vs unfused MLP launches, bf16 round-off
-    assert all(torch.equal(a, c) for a, c in zip(t0["masks"], t1["masks"]))
-    # ... and the unread rows hold what a direct forward of those (pass, image) columns gives: strong rows of pass 3, labelled rows of pass 5
+    alg = get_algorithm(make_args(**NSa), vit.vit_small_patch2_32)
+    alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+    alg.it = 30000
+    alg.optimizer.sched_step = alg.it
+    alg.inject_droppath = dps
+    alg.trace = {}
+    alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+    torch.cuda.synchronize()
+    K, nl, nu = alg.trace["K"], 8, 8
+    L0 = alg.trace["logits"].clone()
+    assert torch.isfinite(L0).all() and L0.shape == (K + 1, 24, 100)
+    # the unread rows: strong rows of pass 3, labelled rows of pass 5
     pb = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
     imgs = torch.cat((pb["x_lb"], pb["x_ulb_w"], pb["x_ulb_s"])).contiguous()
     for k, rows in ((3, list(range(nl + nu, 24))), (5, list(range(nl)))):

@@ -141,44 +141,3 @@ def test_vit_backward_matches_oracle_fp32_on_bf16_weights():
             assert rel(gr.cpu().numpy()[:D], ref[:D]) < 4e-2 and rel(gr.cpu().numpy()[2 * D:], ref[2 * D:]) < 4e-2, n
         else:
             assert rel(gr.cpu().numpy(), ref) < 4e-2, (n, rel(gr.cpu().numpy(), ref))
-
-
-def test_forward_mixed_matches_separate_forwards(monkeypatch):
-    """forward_mixed (gradient images first, one launch train, backward operands kept by the inference kernels) against the two
-    separate forwards it replaces: same logits / features for every image, and the same backbone gradients.  (The mixed forward keeps
-    qkv / the projection residual for its gradient rows, so it runs the separate qkv GEMM, attention and proj kernels: compared here against the same.)"""
-    from semireward_amd.nets import vit as _v
-    monkeypatch.setattr(_v, "_FUSED_ATTN", False)
-    monkeypatch.setattr(_v, "_FUSED_PROJ", False)
-    monkeypatch.setattr(_v, "_FUSED_MLP_MIN_ROWS", 1024)     # the 19-image inference forward on the fused MLP kernel, as inside the mixed launch
-    torch.manual_seed(0)
-    model, cfg = build("small_p2_32")
-    assert model.supports_mixed(24)
-    P = synth.synth_params(V.param_shapes(cfg), 5)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
-    rng = np.random.Generator(np.random.PCG64(6))
-    B, Bg, C = 24, 5, cfg.num_classes
-    x = torch.from_numpy(rng.standard_normal((B, 3, cfg.img_size, cfg.img_size)).astype(np.float32)).to(DEV)
-    idx = torch.from_numpy(rng.permutation(B).astype(np.int32)).to(DEV)
-    dp = torch.from_numpy(synth.synth_droppath(7, V.drop_path_probs(cfg), B)).to(DEV)
-    dl = torch.from_numpy((rng.standard_normal((Bg, C)) * 1e-2).astype(np.float32)).to(DEV)
-    # reference path: gradient images with save=True, the rest without
-    lg_g, ft_g, ctx = model.forward_features(x, idx[:Bg].contiguous(), dp[:, :, :Bg].contiguous(), save=True)
-    lg_i, ft_i, _ = model.forward_features(x, idx[Bg:].contiguous(), dp[:, :, Bg:].contiguous(), save=False)
-    model.zero_grad()
-    model.backward(ctx, dl)
-    g_ref = model.grad.clone()
-    # mixed path
-    lg, ft, ctx2 = model.forward_mixed(x, idx, dp, Bg)
-    model.zero_grad()
-    model.backward(ctx2, dl)
-    torch.cuda.synchronize()
-    assert rel(lg[:Bg].cpu(), lg_g.cpu().numpy()) < 4e-3 and rel(ft[:Bg].cpu(), ft_g.cpu().numpy()) < 4e-3     # fused MLP vs unfused
-    assert rel(lg[Bg:].cpu(), lg_i.cpu().numpy()) < 1e-5 and rel(ft[Bg:].cpu(), ft_i.cpu().numpy()) < 1e-5     # same kernels
-    assert rel(model.grad.cpu(), g_ref.cpu().numpy()) < 2e-2
-    worst = 0.0
-    for (n, ga), (_, gb) in zip(model.named_grads(), [(n, model.view(n, g_ref)) for n, _ in model.names_shapes]):
-        if n.endswith("attn.qkv.bias"):
-            continue
-        worst = max(worst, rel(ga.cpu(), gb.cpu().numpy()))
-    assert worst < 6e-2, worst

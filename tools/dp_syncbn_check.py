@@ -60,5 +60,19 @@ ok = e_lg < 2e-3 and e_ft < 2e-3 and e_g < 5e-3 and e_rs < 1e-5 and nbt and e_lo
 print("rank %d: logits %.2e feat %.2e grad(sum over ranks) %.2e running stats %.2e | per-rank statistics would give %.2e | syncbn == whole batch: %s"
       % (rank, e_lg, e_ft, e_g, e_rs, e_loc, ok), flush=True)
 assert ok
+# unequal per-rank batches (a last partial batch): every rank enters the same collectives (the row counts ride on the first statistics exchange of
+# the forward) and EVERY rank gets the error -- neither a hang nor silently skewed statistics.  One rank sees a batch size it has used before, the
+# other a new one: the case a per-batch-size cache of a separate check would turn into mismatched collectives.
+bad = x[:4 if rank == 0 else 3].contiguous()
+try:
+    part.forward_features(bad, save=False, update_stats=False, tag="bad")      # (SRHIP_CHECK_ARGS=1, the test suite: raised inside the forward)
+    part.check_equal_rows()
+    caught = False
+except RuntimeError as e:
+    caught = "per-rank batches" in str(e)
+part.forward_features(x[sl].contiguous(), save=False, update_stats=False, tag="part2")      # equal again: the flag was cleared, no error
+part.check_equal_rows()
+print("rank %d: unequal per-rank batches raise on every rank: %s" % (rank, caught), flush=True)
+assert caught
 dist.barrier()
 dist.destroy_process_group()

@@ -2,6 +2,7 @@
 # usage (GPU box): tools/round_evidence.sh <tag>   -> gpurun_out/<tag>_*: everything the round's profiles/ entries are copied from
 #   <tag>_bench_full.json            the driver-form bench line (python bench.py, default flags)
 #   <tag>_{headline,224,bu64,pre,wrn,bert,hubert}.stats.txt + _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats of the workloads
+#   <tag>_roofline_vs_rocprof.txt   the bench line's live per-launch time of the dominant kernel against the rocprofv3 average (must agree within 3 %)
 #   <tag>_hbm_traffic.json           FETCH_SIZE / WRITE_SIZE passes of the headline (tools/traffic.sh)
 #   <tag>_pmc{1,2}.pmc.txt           SQ counters of the headline (tools/pmc.sh)
 tag=$1
@@ -9,6 +10,9 @@ cd $GRAFT_REPO_ROOT
 python bench.py 2> gpurun_out/${tag}_bench_full.err | tail -1 > gpurun_out/${tag}_bench_full.json
 Q="--steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/prof.sh ${tag}_headline $Q; grep -h "^{\"metric\"" gpurun_out/${tag}_headline.log > gpurun_out/${tag}_headline_bench_under_rocprof.json
+python tools/check_roofline_vs_rocprof.py gpurun_out/${tag}_bench_full.json gpurun_out/${tag}_headline.stats.txt > gpurun_out/${tag}_roofline_vs_rocprof.txt 2>&1 \
+  || echo "ROOFLINE CHECK FAILED (see gpurun_out/${tag}_roofline_vs_rocprof.txt)"
+cat gpurun_out/${tag}_roofline_vs_rocprof.txt
 bash tools/prof.sh ${tag}_224 $Q --img 224; grep -h "^{\"metric\"" gpurun_out/${tag}_224.log > gpurun_out/${tag}_224_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_bu64 $Q --bu 64 --steps 6 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_bu64.log > gpurun_out/${tag}_bu64_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_pre $Q --regime pre; grep -h "^{\"metric\"" gpurun_out/${tag}_pre.log > gpurun_out/${tag}_pre_bench_under_rocprof.json
