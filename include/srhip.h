@@ -207,7 +207,9 @@ int srhip_cls_head_fwd(const float* x, const float* gamma, const float* beta, fl
 int srhip_cls_head_fwd_scatter(const float* x, const float* gamma, const float* beta, float eps, const float* Wh, const float* bh,
                                float* feat, float* logits, float* xhat, float* rstd, float* feat_all, float* logits_all,
                                const long long* out_rows, int B, int N, int D, int C, void* stream);
-/* dx[b,0,:] = ...(rows other than the cls row are left untouched: zero dx first); dWh/dbh/dgamma/dbeta += */
+/* dx[b,0,:] = ...(rows other than the cls row are left untouched: zero dx first); dWh/dbh/dgamma/dbeta +=.
+ * dx == NULL: only the head weight / bias gradients (they sum over ALL images of the backward); dWh == NULL: only dx and the final-norm affine
+ * gradients (atomic adds) of the B images handed in -- the two halves of a backward whose images are back-propagated in separate row chains. */
 int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const float* gamma, const float* feat, const float* xhat,
                        const float* rstd, float* dx, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int N,
                        int D, int C, void* stream);

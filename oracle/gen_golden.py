@@ -24,6 +24,7 @@ from oracle import vit_ref as V  # noqa: E402
 from oracle import wrn_ref as W  # noqa: E402
 from oracle import bert_ref as BR  # noqa: E402
 from oracle import w2v2_ref as WR  # noqa: E402
+from oracle import hooks_ref as H  # noqa: E402
 from semireward_amd.utils import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -1536,7 +1537,136 @@ def search_trace(which, n=40):
         print("margin %.4f seed %d p_cutoff %.2f head_gain %.1f mask_mean %.3f" % (m, seed, pc, gn, mm))
 
 
-GENS = dict(sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
+
+# ---- the north-star configuration at FULL size through the reference's own train_step (BASELINE.json configs[1]) -------------------------------
+# ViT-S/2 on 32 x 32, 100 classes, batch 8 / 8 / 8, ulb_dest_len 50 000, the hyper-parameters of config/SemiReward/usb_cv/flexmatch/
+# flexmatch_cifar100_200_0.yaml.  Two independent single steps from the SAME state: it = 1000 (<= start_timing: K = 0, stage-1 rewarder update)
+# and it = 30000 (K = sr_decay() = 8 extra passes).  A random-init backbone with the stock classifier never reaches p_cutoff = 0.95 at 100
+# classes and an empty table keeps every threshold at 0, so -- exactly as tests/test_gpu_srflexmatch.py::test_full_size_step_properties sets its
+# engine up -- the step starts from a mid-training hook table (46 000 of 50 000 entries selected, skewed class counts) and a classifier x 24.
+# Several batches are run through the REFERENCE and the one whose thresholded max-probs keep the largest distance from their thresholds is
+# stored (a bf16-operand backbone must reproduce every mask: the GPU test asserts deviation < margin per row).
+FULL = dict(num_train_iter=204800, start_timing=20000, N_k=10, ulb_dest_len=50000, C=100, Bl=8, Bu=8, num_warmup_iter=5120, p_cutoff=0.95,
+            algorithm="srflexmatch", head_gain=24.0, lr=5e-4, its=[1000, 30000], batch_seeds=list(range(100, 124)), seed=0)
+
+
+def full_hook_state(batch_idx):
+    """The mid-training FlexMatch table of test_full_size_step_properties: (selected_label int64 [50000], classwise_acc float32 [100])."""
+    rs = np.random.Generator(np.random.PCG64(77))
+    w = np.ones(100); w[[97, 11, 45, 20, 84, 90, 26, 52, 35]] = [60, 55, 50, 40, 35, 30, 25, 20, 15]
+    sel0 = rs.choice(100, size=50000, p=w / w.sum()).astype(np.int64)
+    sel0[rs.permutation(50000)[:4000]] = -1
+    sel0[batch_idx] = -1
+    st0 = H.FlexMatchState(50000, 100, True)
+    st0.selected_label[:] = sel0
+    st0.update()
+    return sel0, st0.classwise_acc.copy()
+
+
+def run_full_step(tr, it, bseed):
+    """ONE reference train_step + backward at full size from the fixed state.  Returns (fixture dict with keys relative to the step, margin)."""
+    C, Bl, Bu = tr["C"], tr["Bl"], tr["Bu"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_SMALL_P2_32)
+    Fd = cfg.embed_dim
+    vp = trace_vit_params(cfg, tr["seed"], tr["head_gain"])
+    model = build_ref_vit(V.VIT_SMALL_P2_32, C, vp)
+    model.train()
+    alg = build_headless_srflexmatch(model, C, Fd, tr)
+    load_module_params(alg.rewarder, synth.synth_params(S.rewarder_shapes(Fd, C), tr["seed"] + 1))
+    load_module_params(alg.generator, synth.synth_params(S.generator_shapes(Fd), tr["seed"] + 2))
+    b = synth.synth_batch(bseed, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+    sel0, acc0 = full_hook_state(b["idx_ulb"])
+    mh = alg.hooks_dict["MaskingHook"]
+    mh.selected_label = torch.from_numpy(sel0.copy())
+    mh.classwise_acc = torch.from_numpy(acc0.copy())
+    for _ in range(it):
+        alg.scheduler.step()                    # LambdaLR position of iteration `it`
+    alg.it = it
+    K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
+    dps = [synth.synth_droppath(900 + 16 * (bseed % 64) + k, V.drop_path_probs(cfg), Bl + 2 * Bu) for k in range(K + 1)]
+    alg.model = _PassModel(model, dps)
+    rec = dict(mask=[], acc=[], probs=[], thr=[], pl=[], reward=[], rlabel=[], mask2=[])
+    orig = mh.masking
+
+    def wrapped(algorithm, *a, **k):
+        mp, mi = k["logits_x_ulb"].detach().max(dim=-1)
+        acc = mh.classwise_acc[mi]
+        rec["probs"].append(mp.numpy().copy()); rec["pl"].append(mi.numpy().copy())
+        rec["thr"].append((algorithm.p_cutoff * (acc / (2.0 - acc))).numpy().copy())
+        m = orig(algorithm, *a, **k)
+        rec["mask"].append(m.numpy().copy()); rec["acc"].append(mh.classwise_acc.numpy().copy())
+        return m
+    mh.masking = wrapped
+    rfwd, closs = alg.rewarder.forward, alg.consistency_loss
+
+    def rew_wrapped(feats, labels):
+        r = rfwd(feats, labels)
+        if not alg.rewarder.training:
+            rec["reward"].append(r.detach().numpy().reshape(-1).copy()); rec["rlabel"].append(labels.detach().numpy().copy())
+        return r
+
+    def closs_wrapped(*a, **k):
+        if k.get("mask2") is not None:
+            rec["mask2"].append(k["mask2"].detach().numpy().copy())
+        return closs(*a, **k)
+    alg.rewarder.forward, alg.consistency_loss = rew_wrapped, closs_wrapped
+    rbefore = {k_: v.detach().clone() for k_, v in alg.rewarder.named_parameters()}
+    o, log = alg.train_step(T(b["x_lb"]), T(b["y_lb"]), T(b["idx_ulb"]), T(b["x_ulb_w"]), T(b["x_ulb_s"]))
+    mh.masking = orig
+    del alg.rewarder.forward
+    alg.consistency_loss = closs
+    assert alg.model.calls == K + 1
+    o["loss"].backward()                       # ParamUpdateHook.after_train_step (param_update.py:33)
+    out = {}
+    for nme, prm in model.named_parameters():
+        flat(f"grad/{nme}", samp(prm.grad.numpy(), 256), out)
+    out["lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / tr["lr"])
+    for k_, v in log.items():
+        out[f"log/{k_.split('/')[-1]}"] = np.float64(v)
+    out["K"], out["bseed"], out["dp_seed0"] = np.int64(K), np.int64(bseed), np.int64(900 + 16 * (bseed % 64))
+    out["masks"], out["accs"] = np.stack(rec["mask"]), np.stack(rec["acc"])
+    out["mask_probs"], out["mask_thr"], out["pseudo_label"] = np.stack(rec["probs"]), np.stack(rec["thr"]), np.stack(rec["pl"])
+    margin = min(float(np.abs(out["mask_probs"] - out["mask_thr"]).min()), float(np.abs(out["mask_probs"] - tr["p_cutoff"]).min()))
+    if K:
+        assert len(rec["mask2"]) == K and len(rec["reward"]) >= K
+        out["reward"], out["mask2"] = np.stack(rec["reward"][:K]), np.stack(rec["mask2"])
+        assert all(np.array_equal(rec["rlabel"][k], rec["pl"][k + 1]) for k in range(K))
+    for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+        out[f"feat/{k_}"] = o["feat"][k_].detach().numpy()
+    out["rewarder_updated"] = np.int64(any(not torch.equal(rbefore[k_], v.detach()) for k_, v in alg.rewarder.named_parameters()))
+    for k_, v in alg.rewarder.named_parameters():
+        flat(f"rewarder/{k_}", samp(v.detach().numpy(), 64), out)
+    out["sel_after_batch"] = mh.selected_label.numpy()[b["idx_ulb"]].copy()          # the only table entries a step can touch
+    out["n_selected_after"] = np.int64(int((mh.selected_label.numpy() != -1).sum()))
+    out["max_reward"] = np.float64(float(alg.max_reward))
+    return out, margin
+
+
+def gen_trace_full():
+    tr = FULL
+    best = None
+    for bseed in tr["batch_seeds"]:
+        cand, ms = {}, []
+        for it in tr["its"]:
+            o, m = run_full_step(tr, it, bseed)
+            cand[it] = o
+            ms.append(m)
+            print("full trace: batch seed %d it %d K %d  mask mean %.2f  margin %.4f  losses %.4f / %.4f" % (
+                bseed, it, int(o["K"]), float(o["masks"].mean()), m, float(o["log/sup_loss"]), float(o["log/unsup_loss"])), flush=True)
+        sr = cand[tr["its"][-1]]
+        ok = 0.0 < float(sr["masks"].mean()) < 1.0 and 0.0 < float(sr["mask2"].mean()) < 1.0        # rows selected AND rejected by both filters
+        if ok and (best is None or min(ms) > best[0]):
+            best = (min(ms), bseed, cand)
+    assert best is not None, "no candidate batch with rows selected and rejected"
+    print("full trace: keeping batch seed %d (margin %.4f)" % (best[1], best[0]))
+    out = {}
+    for it, o in best[2].items():
+        flat(f"it{it}", o, out)
+    out["meta/its"], out["meta/margin"], out["meta/bseed"] = np.array(tr["its"], dtype=np.int64), np.float64(best[0]), np.int64(best[1])
+    np.savez_compressed(os.path.join(OUT, "srflexmatch_full_trace.npz"), **out)
+
+
+GENS = dict(trace_full=gen_trace_full, sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_c100=gen_trace_c100, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
             bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment, vit_b16_96=gen_vit_b16_96, augment_tv=gen_augment_tv)

@@ -414,7 +414,14 @@ class SRConsistencyBase(AlgorithmBase):
                         cand[f] = p_
                 if len(cand) > 1:
                     agree = (lambda ms: self.dp.max_over_ranks(ms, self.device)) if self.dp.active else None
+                    # a regime abandoned mid-tuning (K or the batch shape moved on before its windows finished) will not come back to finish:
+                    # its tuner and candidate plans go (they would keep StepGraph in eager mode and hold device tensors for the rest of the run)
+                    for k_ in [k_ for k_ in self._tuners if k_ != key]:
+                        del self._tuners[k_]
                     self._tuners[key] = (_DeferTuner(cand.keys(), refine=not prev, agree=agree), cand)
+                elif prev:
+                    # the neighbour's candidates collapse to one split at this size: that split, not the untuned rule
+                    self._plans[key] = self._make_plan(nl, nu, K, defer_fraction=min(prev)[1])
         tn = self._tuners.get(key)
         if tn is not None:
             tuner, cand = tn
@@ -464,6 +471,8 @@ class SRConsistencyBase(AlgorithmBase):
         K = self.sr_decay() if it > self.start_timing else 0                                     # :147, :75
         # tile choice of the small GEMMs of the gradient rows: with K > 0 the inference launches of the K passes own most CUs while they run
         # (fewer, fatter workgroups win: 4.86 vs 4.95 ms per step); with K = 0 the chain has the chip to itself (64 x 64 tiles: 3.21 vs 3.57 ms)
+        # (process-wide library setting: restored when the step returns -- train_step's wrapper -- so that evaluate(), the EMA forward and
+        # anything else that runs between steps picks its tiles independently of which step ran last)
         ops.gemm_small_max_grid(ops.GEMM_SMALL_CONTENDED if (K > 0 and self.defer_unread_rows) else ops.GEMM_SMALL_ALONE)
         ph = self._phase_mark if _PHASES else (lambda name: None)
         ph("start")
@@ -613,7 +622,10 @@ class SRFlexMatch(SRConsistencyBase):
 
     def train_step(self, x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s):
         with self._step_scope():
-            return self._train_step(x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s)
+            try:
+                return self._train_step(x_lb, y_lb, idx_ulb, x_ulb_w, x_ulb_s)
+            finally:
+                ops.gemm_small_max_grid(ops.GEMM_SMALL_ALONE)
 
     def get_save_dict(self):
         d = super().get_save_dict()
@@ -663,7 +675,10 @@ class SRFixMatch(SRConsistencyBase):
 
     def train_step(self, x_lb, y_lb, x_ulb_w, x_ulb_s):
         with self._step_scope():
-            return self._train_step(x_lb, y_lb, None, x_ulb_w, x_ulb_s)
+            try:
+                return self._train_step(x_lb, y_lb, None, x_ulb_w, x_ulb_s)
+            finally:
+                ops.gemm_small_max_grid(ops.GEMM_SMALL_ALONE)
 
     @staticmethod
     def get_argument():

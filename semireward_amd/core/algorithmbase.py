@@ -7,7 +7,9 @@ Kept identical: constructor signature ``(args, net_builder, tb_log=None, logger=
 Different by design: the backbone backward is fused into ``train_step`` (``out_dict['loss']`` is a
 detached scalar and ``model.grad`` is already populated), the optimizer + scheduler are one fused object, the EMA
 model is an alias when ``ema_m == 0``, and log scalars are fetched lazily (no per-step host sync).
-Datasets / loaders are out of scope (CPU input pipeline): ``train()`` consumes any iterable of (data_lb, data_ulb).
+Datasets / loaders are the reference's own (CPU input pipeline): ``set_dataset`` / ``set_data_loader`` call ITS ``get_dataset`` /
+``get_data_loader`` when semilearn is importable (or take ready dicts from ``args``); ``train()`` then zips ``loader_dict['train_lb'/'train_ulb']``
+as the reference does, or consumes any iterable of (data_lb, data_ulb) handed in.
 """
 import os
 from collections import OrderedDict
@@ -20,6 +22,7 @@ from ..distributed import DataParallel
 from ..optim import FusedAdamW, FusedSGD
 from .criterions import CELoss, ConsistencyLoss
 from .hooks import EMAHook, Hook, ParamUpdateHook, TimerHook, get_priority
+from .utils import reference_data_functions
 
 
 class DeferredScalar:
@@ -87,7 +90,9 @@ class AlgorithmBase:
         self.rank = g("rank", 0)
         self.distributed = g("distributed", False)
         self.world_size = g("world_size", 1)
-        self.device = torch.device("cuda", self.gpu if isinstance(self.gpu, int) else torch.cuda.current_device())
+        # (without a GPU only the host-side wiring of this class can be exercised -- tests/test_cpu_driver_contract.py; every op raises)
+        self.device = torch.device("cuda", self.gpu if isinstance(self.gpu, int) else torch.cuda.current_device()) \
+            if torch.cuda.is_available() else torch.device("cpu")
         self.dp = DataParallel(self.world_size, self.rank, global_reward_threshold=g("global_reward_threshold", False))
         self.it = 0
         self.epoch = 0
@@ -114,10 +119,49 @@ class AlgorithmBase:
 
     # ---- construction ---------------------------------------------------------------------------
     def set_dataset(self):
-        return None          # CPU input pipeline is out of scope; batches come from the caller
+        """algorithmbase.py:140-166.  The datasets are the reference's own (CPU input pipeline): built by ITS ``get_dataset``
+        when ``semilearn`` is importable (or by the functions handed in as ``args.data_functions = (get_dataset, get_data_loader)``), with the
+        reference's rank-0-first barriers and its ``ulb_dest_len`` / ``lb_dest_len`` side effects on ``args``.  ``args.dataset_dict``: a ready
+        dict is taken as is.  Otherwise None -- ``train(batches=...)`` or a ``loader_dict`` assigned by the caller feeds the loop."""
+        a = self.args
+        ready = getattr(a, "dataset_dict", None)
+        get_dataset = (getattr(a, "data_functions", None) or reference_data_functions())[0]
+        if ready is None and (get_dataset is None or getattr(a, "dataset", None) is None):
+            return None
+        if ready is None:
+            if self.rank != 0 and self.distributed:
+                torch.distributed.barrier()
+            ready = get_dataset(a, self.algorithm, a.dataset, a.num_labels, a.num_classes, getattr(a, "data_dir", "./data"),
+                                getattr(a, "include_lb_to_ulb", True))
+        if ready is None:
+            return None
+        a.ulb_dest_len = len(ready["train_ulb"]) if ready.get("train_ulb") is not None else 0
+        a.lb_dest_len = len(ready["train_lb"])
+        self.print_fn("unlabeled data number: {}, labeled data number {}".format(a.ulb_dest_len, a.lb_dest_len))
+        if self.rank == 0 and self.distributed and getattr(a, "dataset_dict", None) is None:
+            torch.distributed.barrier()
+        return ready
 
     def set_data_loader(self):
-        return None
+        """algorithmbase.py:185-228: train_lb / train_ulb / eval (/ test) loaders from ``dataset_dict`` through the reference's
+        ``get_data_loader`` with the reference's arguments; ``args.loader_dict`` (ready loaders) when there is no dataset_dict."""
+        a = self.args
+        if self.dataset_dict is None:
+            return getattr(a, "loader_dict", None)
+        get_data_loader = (getattr(a, "data_functions", None) or reference_data_functions())[1]
+        if get_data_loader is None:
+            raise RuntimeError("a dataset_dict was given but no get_data_loader: install semilearn or pass args.data_functions")
+        self.print_fn("Create train and test data loaders")
+        nw = getattr(a, "num_workers", 1)
+        train = dict(data_sampler=getattr(a, "train_sampler", "RandomSampler"), num_iters=self.num_train_iter, num_epochs=self.epochs,
+                     distributed=self.distributed)
+        ld = {"train_lb": get_data_loader(a, self.dataset_dict["train_lb"], a.batch_size, num_workers=nw, **train),
+              "train_ulb": get_data_loader(a, self.dataset_dict["train_ulb"], a.batch_size * a.uratio, num_workers=2 * nw, **train)}
+        for k in ("eval", "test"):                       # evaluation: no sampler, keep the last partial batch
+            if self.dataset_dict.get(k) is not None:
+                ld[k] = get_data_loader(a, self.dataset_dict[k], a.eval_batch_size, data_sampler=None, num_workers=nw, drop_last=False)
+        self.print_fn(f"[!] data loader keys: {ld.keys()}")
+        return ld
 
     def set_model(self):
         model = self.net_builder(num_classes=self.num_classes, device=self.device)

@@ -13,7 +13,10 @@ What has to hold for a capture to be valid for every later step:
   * state the step mutates lives in persistent device buffers updated in place (FlexMatch table / histogram, rewarder parameters and moments,
     ``max_reward``); Python-side counters the captured code advances (optimizer step, scheduler step, DropPath draw counter, rewarder-Adam step)
     are advanced by the same amounts at every replay;
-  * inputs are copied into the static batch tensors of the capture (no copy when the caller hands over the very same tensors every step).
+  * inputs are copied into the static batch tensors of the capture (the graph owns clones of the first batch: one device-to-device copy per
+    batch tensor and replay);
+  * the out / log dictionaries a replay returns read the graph's own buffers: valid until the next step() (all variants share one memory
+    pool, so a later replay of ANOTHER variant may reuse them) -- read log scalars before stepping again, as LoggingHook does.
 The reference sequence this replaces per step: SRFlexMatch.train_step (srflexmatch.py:107-217) + ParamUpdateHook.after_train_step
 (param_update.py:21-45).  Results are bit-identical to the eager step (tests/test_gpu_stepgraph.py).
 """
@@ -80,6 +83,7 @@ class StepGraph:
     """``step(**batch)`` == ``train_step(**batch)`` + ``ParamUpdateHook.after_train_step`` of the algorithm, eagerly for the first ``warm`` steps of
     a variant (and while the step schedule is still being tuned), from then on as a captured HIP graph."""
 
+    MAX_GRAPHS = 8           # captured variants kept (least recently used one dropped beyond that)
     COUNTERS = (("optimizer", "step_count"), ("optimizer", "sched_step"), ("model", "_rng_calls"), ("rewarder_optimizer", "steps"))
 
     def __init__(self, algorithm, warm=2):
@@ -92,7 +96,7 @@ class StepGraph:
             algorithm.rewarder_optimizer.step_scalars = self.scal
         algorithm.optimizer.step_scalars = self.scal
         self.graphs, self.seen = {}, {}                      # (dict order = least .. most recently used)
-        self.pool, self.max_graphs = None, int(os.environ.get("SR_HIP_GRAPH_MAX", "8"))
+        self.pool, self.max_graphs = None, max(1, self.MAX_GRAPHS)
         self.replays = self.eager_steps = 0
         self.hook = algorithm.hooks_dict["ParamUpdateHook"]
 

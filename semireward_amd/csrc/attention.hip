@@ -532,13 +532,298 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The LDS-resident backward (N <= 288: every instantiation of the ViT / Wav2Vec2 shapes), two tiles per wave.
+//
+// Why.  A backward workgroup is a chain of dependent steps per tile -- ds_read -> MFMA -> v_exp / scale -> pack -> MFMA -- walked by two
+// waves per SIMD (the four 37-KB images of a role leave room for ONE workgroup per CU): in-kernel stamps put an iteration of that
+// chain at ~1100 clocks for 128 clocks of MFMA issue.  The workgroup owns its CU outright, so its CU time is what the gradient rows'
+// backward costs the step while the deferred inference rows fill the other CUs (bench.py other_kernels: 58 us per launch beside them,
+// 31 us alone -- three rounds of 192 whole-CU workgroups on the ~64 CUs left).  The registers a second resident workgroup would need are
+// free (129 of 256 in use), so each wave carries TWO independent tiles through the chain at once: twice the instruction-level
+// parallelism under every latency, every K / V (dQ role) or Q / dO (dK / dV role) fragment read from LDS once for both tiles, and the
+// wave that owns the odd 17th tile of N = 257 needs two rounds instead of three.  delta = rowsum(dO * O) is computed once per workgroup
+// in the staging phase (both roles), so a tile's operands are only its q / dO fragments.
+template <int NKT, bool VAR>
+__device__ __forceinline__ void attn_bwd_dq_pair(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+                                                 const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
+                                                 bf16_t* __restrict__ dqkv, float* __restrict__ delta, int N, int H, float scale, AttnVar av) {
+  constexpr int NP = NKT * 16, TP = vt_pitch(NP);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][64]  chunk-swizzled (stage_rows_swz)
+  bf16_t* Vs = Ks + NP * HD;                          // [NP][64]
+  bf16_t* Kt = Vs + NP * HD;                          // [64][TP]  key-permuted + chunk-swizzled (stage_transposed_perm)
+  float* lse_s = reinterpret_cast<float*>(Kt + 64 * TP);   // [NP]  (* log2e; +inf for padded queries)
+  float* dl_s = lse_s + NP;                                // [NP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int kc_ = g ^ ((l15 >> 1) & 7);
+  const int kof0 = l15 * HD + (kc_ << 3), kof1 = l15 * HD + ((kc_ ^ 4) << 3);
+  const int vof = l15 * TP + ((g ^ swz4(l15)) << 3);
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+  const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
+  const float sc2 = scale * LOG2E;
+  const int nqt = (N + 15) >> 4;
+  const int qstride = BWD_NW * gridDim.y, qfirst = blockIdx.y * BWD_NW + wave;
+  const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
+  // the q / dO fragments of a tile pair (rows clamped: a tile past the end is computed on row N - 1 and never stored)
+  s16x8_t nq[2][2], nd[2][2];
+  auto fetch = [&](int qa) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int qc = min((qa + x * qstride) * 16 + l15, N - 1);
+      const bf16_t* qp = base + (size_t)qc * ld + g * 8;
+      const bf16_t* dop = dobase + (size_t)qc * D + g * 8;
+      nq[x][0] = ld16(qp); nq[x][1] = ld16(qp + 32);
+      nd[x][0] = ld16(dop); nd[x][1] = ld16(dop + 32);
+    }
+  };
+  fetch(qfirst);
+  stage_rows_swz<NP, BWD_NT>(Ks, base + D, ld, N, tid);
+  stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
+  stage_transposed_perm<NP, BWD_NT>(Kt, base + D, ld, N, tid);
+  for (int i = tid; i < NP; i += BWD_NT) {
+    float dl = 0.f;
+    if (i < N) {
+      const bf16_t* dop = dobase + (size_t)i * D;
+      const bf16_t* op = o_fwd + ((size_t)b * N + i) * D + h * HD;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const s16x8_t a = ld16(dop + c * 8), o8 = ld16(op + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)a[j]) * bf2f((bf16_t)o8[j]);
+      }
+      if (blockIdx.y == 0) delta[((size_t)b * H + h) * N + i] = dl;
+    }
+    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : INFINITY;
+    dl_s[i] = dl;
+  }
+  __syncthreads();
+  DBG_T(1);
+  for (int qa = qfirst; qa < nqt; qa += 2 * qstride) {
+    s16x8_t q0[2], q1[2], do0[2], do1[2];
+    float lse2[2], dl[2];
+    int q[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      q0[x] = nq[x][0]; q1[x] = nq[x][1]; do0[x] = nd[x][0]; do1[x] = nd[x][1];
+      q[x] = (qa + x * qstride) * 16 + l15;
+      const int qs = min(q[x], NP - 1);
+      lse2[x] = lse_s[qs]; dl[x] = dl_s[qs];
+    }
+    if (qa + 2 * qstride < nqt) fetch(qa + 2 * qstride);      // the next pair's operands travel under this pair's MFMAs
+    f32x4_t dq[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u = 0; u < NKT / 2; ++u) {
+      float ds[2][2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int t = 2 * u + e;
+        const s16x8_t ka = ld16(Ks + t * 16 * HD + kof0), kb = ld16(Ks + t * 16 * HD + kof1);
+        const s16x8_t va = ld16(Vs + t * 16 * HD + kof0), vb = ld16(Vs + t * 16 * HD + kof1);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = mfma16(ka, q0[x], s);
+          s = mfma16(kb, q1[x], s);
+          dp = mfma16(va, do0[x], dp);
+          dp = mfma16(vb, do1[x], dp);
+          if (VAR) {
+            const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)min(q[x], N - 1)) * (uint32_t)N + (uint32_t)(g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = t * 16 + g * 4 + r;
+              const float p = key < klen ? fast_exp2(s[r] * sc2 - lse2[x]) : 0.f;
+              float dpv = dp[r];
+              if (av.drop_thresh) dpv = drop_keep(rowbase + t * 16 + r, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
+              ds[x][e][r] = p * (dpv - dl[x]) * scale;
+            }
+          } else if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = t * 16 + g * 4 + r;
+              const float p = key < N ? fast_exp2(s[r] * sc2 - lse2[x]) : 0.f;
+              ds[x][e][r] = p * (dp[r] - dl[x]) * scale;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[x][e][r] = fast_exp2(s[r] * sc2 - lse2[x]) * (dp[r] - dl[x]) * scale;
+          }
+        }
+      }
+      const s16x8_t dsa = pack8(ds[0][0], ds[0][1]), dsb = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const s16x8_t kt = ld16(Kt + dt * 16 * TP + 32 * u + vof);
+        dq[0][dt] = mfma16(kt, dsa, dq[0][dt]);
+        dq[1][dt] = mfma16(kt, dsb, dq[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      if (q[x] < N) {
+        bf16_t* dqp = dqkv + ((size_t)b * N + q[x]) * ld + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 v = {pack_bf2(dq[x][dt][0], dq[x][dt][1]), pack_bf2(dq[x][dt][2], dq[x][dt][3])};
+          *reinterpret_cast<uint2*>(dqp + dt * 16) = v;
+        }
+      }
+    }
+  }
+}
+
+// dK / dV role of the same: each wave owns 16-key tiles, two at a time, and walks the query-tile pairs; S[q][key], dP[q][key] with the KEY
+// on l15 ->  dV^T[d][key] += dO^T[d][q] . P[q][key],  dK^T[d][key] += Q^T[d][q] . dS[q][key].
+template <int NKT, bool VAR>
+__device__ __forceinline__ void attn_bwd_dkv_pair(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+                                                  const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
+                                                  bf16_t* __restrict__ dqkv, int N, int H, float scale, AttnVar av) {
+  constexpr int NP = NKT * 16, TP = vt_pitch(NP);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem_raw);   // [64][TP]  query-permuted + chunk-swizzled (stage_transposed_perm)
+  bf16_t* dOt = Qt + 64 * TP;                         // [64][TP]
+  bf16_t* Qs = dOt + 64 * TP;                         // [NP][64]  chunk-swizzled rows (stage_rows_swz): the a-operands of S and dP
+  bf16_t* dOs = Qs + NP * HD;                         // [NP][64]
+  float* lse_s = reinterpret_cast<float*>(dOs + NP * HD);   // [NP]  (already * log2e)
+  float* dl_s = lse_s + NP;                                 // [NP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+  const bf16_t* dobase = d_out + (size_t)b * N * D + h * HD;
+  const int kstride = BWD_NW * gridDim.y, kfirst = blockIdx.y * BWD_NW + wave;
+  // the k / v fragments of the wave's first tile pair are requested before the staging traffic (keys clamped like the queries above)
+  s16x8_t kf[2][2], vf[2][2];
+  auto kfetch = [&](int ka) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int kc = min((ka + x * kstride) * 16 + l15, N - 1);
+      const bf16_t* kp = base + D + (size_t)kc * ld + g * 8;
+      const bf16_t* vp = base + 2 * D + (size_t)kc * ld + g * 8;
+      kf[x][0] = ld16(kp); kf[x][1] = ld16(kp + 32); vf[x][0] = ld16(vp); vf[x][1] = ld16(vp + 32);
+    }
+  };
+  kfetch(kfirst);
+  stage_transposed_perm<NP, BWD_NT>(Qt, base, ld, N, tid);
+  stage_transposed_perm<NP, BWD_NT>(dOt, dobase, D, N, tid);
+  stage_rows_swz<NP, BWD_NT>(Qs, base, ld, N, tid);
+  stage_rows_swz<NP, BWD_NT>(dOs, dobase, D, N, tid);
+  const int kc_ = g ^ ((l15 >> 1) & 7);
+  const int kof0 = l15 * HD + (kc_ << 3), kof1 = l15 * HD + ((kc_ ^ 4) << 3);
+  const int vof = (threadIdx.x & 15) * TP + (((threadIdx.x >> 4 & 3) ^ swz4(threadIdx.x & 15)) << 3);
+  for (int i = tid; i < NP; i += BWD_NT) {
+    lse_s[i] = i < N ? lse[((size_t)b * H + h) * N + i] * LOG2E : INFINITY;
+    float dl = 0.f;
+    if (i < N) {
+      const bf16_t* dop = dobase + (size_t)i * D;
+      const bf16_t* op = o_fwd + ((size_t)b * N + i) * D + h * HD;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const s16x8_t a = ld16(dop + c * 8), o8 = ld16(op + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)a[j]) * bf2f((bf16_t)o8[j]);
+      }
+    }
+    dl_s[i] = dl;
+  }
+  __syncthreads();
+  DBG_T(1);
+  const float sc2 = scale * LOG2E;
+  const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
+  for (int ka = kfirst; ka * 16 < N; ka += 2 * kstride) {
+    int key[2];
+    s16x8_t k0[2], k1[2], v0[2], v1[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { key[x] = (ka + x * kstride) * 16 + l15; k0[x] = kf[x][0]; k1[x] = kf[x][1]; v0[x] = vf[x][0]; v1[x] = vf[x][1]; }
+    if ((ka + 2 * kstride) * 16 < N) kfetch(ka + 2 * kstride);
+    f32x4_t dv[2][4], dk[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dv[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dk[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int u = 0; u < NKT / 2; ++u) {
+      float pp[2][2][4], ds[2][2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ro = (2 * u + e) * 16 * HD;
+        const s16x8_t cq0 = ld16(Qs + ro + kof0), cq1 = ld16(Qs + ro + kof1), cd0 = ld16(dOs + ro + kof0), cd1 = ld16(dOs + ro + kof1);
+        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + (2 * u + e) * 16 + g * 4);      // result rows = queries 4 g .. 4 g + 3 of the tile
+        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dl_s + (2 * u + e) * 16 + g * 4);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = mfma16(cq0, k0[x], s);            // a-operand rows = queries, b-operand cols = keys
+          s = mfma16(cq1, k1[x], s);
+          dp = mfma16(cd0, v0[x], dp);
+          dp = mfma16(cd1, v1[x], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // padded queries: lse_s = +inf -> p = 0 exactly.  Padded KEY columns (this lane's key >= N) may hold anything: a column
+            // of P / dS only feeds the dK / dV rows of that key, which are never stored.
+            float p = fast_exp2(s[r] * sc2 - l4[r]);
+            float pk = p, dpv = dp[r];
+            if (VAR) {                              // masked keys (rows [klen, N) ARE stored: padded positions have dK = dV = 0)
+              const int qq = (2 * u + e) * 16 + g * 4 + r;
+              p = key[x] < klen ? p : 0.f;
+              pk = p;
+              if (av.drop_thresh) {
+                const bool keep = drop_keep(((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qq) * (uint32_t)N + (uint32_t)min(key[x], N - 1), av.drop_key,
+                                            av.drop_thresh);
+                pk = keep ? p * av.drop_scale : 0.f;
+                dpv = keep ? dpv * av.drop_scale : 0.f;
+              }
+            }
+            pp[x][e][r] = pk;
+            ds[x][e][r] = p * (dpv - d4[r]) * scale;
+          }
+        }
+      }
+      const s16x8_t pba = pack8(pp[0][0], pp[0][1]), pbb = pack8(pp[1][0], pp[1][1]);
+      const s16x8_t dsa = pack8(ds[0][0], ds[0][1]), dsb = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int off = dt * 16 * TP + 32 * u + vof;
+        const s16x8_t dot = ld16(dOt + off), qt = ld16(Qt + off);
+        dv[0][dt] = mfma16(dot, pba, dv[0][dt]);
+        dk[0][dt] = mfma16(qt, dsa, dk[0][dt]);
+        dv[1][dt] = mfma16(dot, pbb, dv[1][dt]);
+        dk[1][dt] = mfma16(qt, dsb, dk[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      if (key[x] < N) {
+        bf16_t* dkp = dqkv + ((size_t)b * N + key[x]) * ld + D + h * HD + g * 4;
+        bf16_t* dvp = dkp + D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 a = {pack_bf2(dk[x][dt][0], dk[x][dt][1]), pack_bf2(dk[x][dt][2], dk[x][dt][3])};
+          uint2 c = {pack_bf2(dv[x][dt][0], dv[x][dt][1]), pack_bf2(dv[x][dt][2], dv[x][dt][3])};
+          *reinterpret_cast<uint2*>(dkp + dt * 16) = a;
+          *reinterpret_cast<uint2*>(dvp + dt * 16) = c;
+        }
+      }
+    }
+  }
+}
+
 template <int NKT, bool VAR, bool VG>
 __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                       const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                       bf16_t* __restrict__ dqkv, float* __restrict__ delta, int N, int H, float scale, AttnVar av) {
   DBG_T(0);
-  if (blockIdx.z == 0) attn_bwd_dq_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
-  else attn_bwd_dkv_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
+  if constexpr (!VG) {                     // K, V, Q, dO images in LDS: two tiles per wave
+    if (blockIdx.z == 0) attn_bwd_dq_pair<NKT, VAR>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
+    else attn_bwd_dkv_pair<NKT, VAR>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
+  } else {                                 // N > 288: the V / (q, dO) row fragments come from L2
+    if (blockIdx.z == 0) attn_bwd_dq_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
+    else attn_bwd_dkv_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
+  }
   __syncthreads();
   DBG_T(2);
 }
@@ -575,7 +860,7 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
     constexpr bool VG = NKT > 18;           // K + V + K^T images exceed the LDS: V fragments from L2
-    const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
+    const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2 + (VG ? 0 : (size_t)2 * NP * 4);
     const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (VG ? 0 : (size_t)2 * NP * HD * 2) + (size_t)2 * NP * 4;
     if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;
     auto kern = attn_bwd_kernel<NKT, VAR, VG>;

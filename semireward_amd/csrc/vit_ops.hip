@@ -707,13 +707,17 @@ extern "C" int srhip_cls_head_fwd_scatter(const float* x, const float* gamma, co
 extern "C" int srhip_cls_head_bwd(const float* dlogits, const float* Wh, const float* gamma, const float* feat,
                                   const float* xhat, const float* rstd, float* dx, float* dWh, float* dbh, float* dgamma,
                                   float* dbeta, int B, int N, int D, int C, void* stream) {
-  if (B <= 0 || D > 1024 || C <= 0) return SR_EINVAL;
+  if (B <= 0 || D > 1024 || C <= 0 || (!dx && !dWh)) return SR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  SR_LAUNCH(cls_head_bwd_x_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, dlogits, Wh, gamma, xhat, rstd, dx,
-                     dgamma, dbeta, N, D, C);
-  SR_CHECK_LAUNCH();
-  SR_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, s, dlogits, feat, dWh, dbh, B, D, C);
-  SR_CHECK_LAUNCH();
+  if (dx) {               // per-image half: dx of the cls rows, final-norm affine gradients (atomic adds)
+    SR_LAUNCH(cls_head_bwd_x_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, dlogits, Wh, gamma, xhat, rstd, dx,
+                       dgamma, dbeta, N, D, C);
+    SR_CHECK_LAUNCH();
+  }
+  if (dWh) {              // the half that sums over all images: head weight / bias gradients (plain +=: one launch per backward)
+    SR_LAUNCH(cls_head_bwd_w_kernel, dim3(C), dim3(256), 0, s, dlogits, feat, dWh, dbh, B, D, C);
+    SR_CHECK_LAUNCH();
+  }
   return SR_OK;
 }
 

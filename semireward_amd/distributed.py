@@ -39,15 +39,25 @@ class DataParallel:
         if self.exchange != "rs_ag" or t.dim() != 1 or not t.is_contiguous():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return
-        w, n = self.world_size, t.numel()
+        # shard boundaries on ABSOLUTE 256-byte boundaries of the flat block: a slice that starts off such a boundary (a layer group of the
+        # overlapped exchange) sends its first < SHARD_ALIGN elements with the tail
+        w = self.world_size
+        head = (-t.storage_offset()) % self.SHARD_ALIGN
+        if head >= t.numel():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        body = t[head:]
+        n = body.numel()
         chunk = (n // (w * self.SHARD_ALIGN)) * self.SHARD_ALIGN
         main = chunk * w
         if chunk:
-            shard = t[self.rank * chunk:(self.rank + 1) * chunk]
-            dist.reduce_scatter_tensor(shard, t[:main], op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(t[:main], shard)
+            shard = body[self.rank * chunk:(self.rank + 1) * chunk]
+            dist.reduce_scatter_tensor(shard, body[:main], op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(body[:main], shard)
         if main < n:
-            dist.all_reduce(t[main:], op=dist.ReduceOp.SUM)
+            dist.all_reduce(body[main:], op=dist.ReduceOp.SUM)
+        if head:
+            dist.all_reduce(t[:head], op=dist.ReduceOp.SUM)
 
     @property
     def active(self):

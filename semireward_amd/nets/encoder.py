@@ -18,12 +18,13 @@ LayerDrop (Wav2Vec2, train mode): ``skip[i]`` leaves layer i out of forward and 
 import torch
 
 from .. import ops
+from .surface import ModuleSurface
 
 SITE_PROBS, SITE_ATTN_OUT, SITE_FFN_OUT, SITE_ACT = 0, 1, 2, 3
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.postln_bwd_part)
 
 
-class PostLNEncoderMixin:
+class PostLNEncoderMixin(ModuleSurface):
     # ---- packed q|k|v views (the three tensors are adjacent in the flat block) ---------------------------------
     def packed_qkv(self, i, buf=None):
         D = self.cfg.hidden

@@ -15,10 +15,12 @@ Data layout in HBM (B images, N tokens, D channels, M = B*N rows):
   weights                   bf16 [out, in]   (+ transposed bf16 copies for the dX products)
 """
 import math
+import types
 
 import torch
 
 from .. import ops
+from .surface import ModuleSurface
 
 
 class VitConfig:
@@ -78,7 +80,7 @@ class FwdContext:
                  "feat", "xhat", "rstd")
 
 
-class VisionTransformer:
+class VisionTransformer(ModuleSurface):
     GEMM_WEIGHTS = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
     rows_independent = True       # LayerNorm only: a row's outputs do not depend on which other rows share the launch
     scatter_outputs = True        # forward_features(out=...) writes logits / features at the caller's row numbers (no index_copy_)
@@ -421,52 +423,102 @@ class VisionTransformer:
 
     def backward(self, ctx, dlogits):
         """Accumulates d(loss)/d(params) into ``self.grad`` given dlogits fp32 [B, C] for a save=True forward."""
+        self.backward_rows(ctx, dlogits, 0, ctx.B)
+        self.backward_finish(ctx, dlogits)
+
+    def _bwd_views(self, ctx, T, b0, b1):
+        """Per-layer operands of the dX chain restricted to the images [b0, b1) (built once per range: a view costs ~3 us of host time)."""
+        key = ("bwdviews", id(ctx), b0, b1)
+        v = self._ws.get(key)
+        if v is not None:
+            return v
         cfg = self.cfg
-        D, N, H, Hd, C = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes
+        D, N, H = cfg.embed_dim, cfg.num_tokens, cfg.num_heads
         B = ctx.B
         M = B * N
         f32, bf16 = torch.float32, torch.bfloat16
-        P, G, wb = self.p, (lambda n: self.p(n, self.grad)), self.flat_bf16
+        whole = b0 == 0 and b1 == B
+        r = (lambda t: t) if whole else (lambda t: t[b0 * N:b1 * N])            # rows of a [M, .] buffer
+        im = (lambda t: t) if whole else (lambda t: t[b0:b1])                   # images of a [B, ..] buffer
+        v = types.SimpleNamespace()
+        v.dx, v.dln, v.dao = r(self._buf("b_dx", (M, D), f32)), r(self._buf("b_dln", (M, D), bf16)), r(self._buf("b_dao", (M, D), bf16))
+        v.delta = im(self._buf("b_delta", (B, H, N), f32))
+        v.feat, v.xhat, v.rstd = im(ctx.feat), im(ctx.xhat), im(ctx.rstd)
+        v.layers = []
+        for i in range(cfg.depth):
+            Ti = T["layers"][i]
+            v.layers.append(types.SimpleNamespace(
+                g2=r(Ti["g2"]), dpre=r(Ti["dpre"]), g1=r(Ti["g1"]), dqkv=r(Ti["dqkv"]), pre=r(ctx.pre[i]), xmid=r(ctx.xmid[i]), xs=r(ctx.xs[i]),
+                st1=(r(ctx.st1[i][0]), r(ctx.st1[i][1])), st2=(r(ctx.st2[i][0]), r(ctx.st2[i][1])), qkv=r(ctx.qkv[i]), ao=r(ctx.ao[i]),
+                lse=im(ctx.lse[i])))
+        self._ws[key] = v
+        return v
+
+    def backward_rows(self, ctx, dlogits, b0, b1):
+        """The input-gradient chain (head -> blocks 11 .. 0) of the images [b0, b1) of a save=True forward: every operand is a row range, rows of
+        different images never meet before the weight-gradient products, so disjoint ranges may run on different streams at different times
+        (the labelled rows' chain under the inference forward, the strong rows' chain after the masks: srflexmatch._train_step).  ``dlogits``
+        is the whole [B, C] buffer; only its rows [b0, b1) are read.  LayerNorm / final-norm affine gradients are added with atomics into the
+        partial copies; everything that sums over ALL rows -- weight, bias, head and patch-embedding gradients -- is backward_finish."""
+        cfg = self.cfg
+        D, N, H, Hd, C = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes
+        nb = b1 - b0
+        M = nb * N
+        P = self.p
+        G = lambda n: self.p(n, self.grad)   # noqa: E731
         self.ensure_transposed()
-        dx = self._buf("b_dx", (M, D), f32)
-        dx.zero_()
-        ops.cls_head_bwd(dlogits, P("head.weight"), P("norm.weight"), ctx.feat, ctx.xhat, ctx.rstd, dx, G("head.weight"),
-                         G("head.bias"), G("norm.weight"), G("norm.bias"), B, N, D, C)
-        dln = self._buf("b_dln", (M, D), bf16)
-        dao = self._buf("b_dao", (M, D), bf16)
-        delta = self._buf("b_delta", (B, H, N), f32)
-        T = self._bwd_plan(M, ctx)
+        T = self._bwd_plan(ctx.B * N, ctx)
+        v = self._bwd_views(ctx, T, b0, b1)
+        dl = dlogits if (b0 == 0 and b1 == ctx.B) else dlogits[b0:b1]
+        v.dx.zero_()
+        ops.cls_head_bwd(dl, P("head.weight"), P("norm.weight"), None, v.xhat, v.rstd, v.dx, None, None, G("norm.weight"), G("norm.bias"),
+                         nb, N, D, C)
         scale = 64 ** -0.5
         dp = ctx.dp
         lnp = T["ln_part"]
-        cb = self.grad_ready_cb            # data parallel only: called with the flat-block range of every finished layer group
+        cb = self.grad_ready_cb if (b0 == 0 and b1 == ctx.B) else None          # data parallel overlap: whole-batch chains only
         gdone = {g["lo_layer"]: g for g in T["groups"]} if cb is not None else {}
-        dpr = (lambda i_, j_: ops.RawRows(dp, i_ * dp.stride(0) + j_ * dp.stride(1))) if dp is not None else (lambda i_, j_: None)   # dp[i, j] as a raw pointer
-        ops.cast_scale_rows(dx, dpr(cfg.depth - 1, 1), N, T["layers"][cfg.depth - 1]["g2"], M, D)
+        # dp[i, j, b0:] as a raw pointer (the DropPath factors of this range's images)
+        dpr = (lambda i_, j_: ops.RawRows(dp, i_ * dp.stride(0) + j_ * dp.stride(1) + b0)) if dp is not None else (lambda i_, j_: None)
+        L = v.layers
+        ops.cast_scale_rows(v.dx, dpr(cfg.depth - 1, 1), N, L[cfg.depth - 1].g2, M, D)
         for i in reversed(range(cfg.depth)):
             b = "blocks.%d." % i
-            Ti = T["layers"][i]
+            Li = L[i]
             s1 = dpr(i, 0)
             # ---- MLP branch: x_out = x_mid + s2 * fc2(gelu(fc1(ln2(x_mid))));  g2 = bf16(s2 * dx) came from the previous LayerNorm backward
-            ops.gemm_nt(ops.EPI_DGELU_BF16, Ti["g2"], self.wT[b + "mlp.fc2.weight"], Ti["dpre"], M, Hd, D, aux_in=ctx.pre[i], ldaux=Hd)
-            ops.gemm_nt(ops.EPI_BF16, Ti["dpre"], self.wT[b + "mlp.fc1.weight"], dln, M, D, Hd)
-            ops.layernorm_bwd_part(dln, ctx.xmid[i], ctx.st2[i][0], ctx.st2[i][1], P(b + "norm2.weight"), dx, lnp[2 * i + 1], LN_REP,
-                                   Ti["g1"], s1, N, M, D)
+            ops.gemm_nt(ops.EPI_DGELU_BF16, Li.g2, self.wT[b + "mlp.fc2.weight"], Li.dpre, M, Hd, D, aux_in=Li.pre, ldaux=Hd)
+            ops.gemm_nt(ops.EPI_BF16, Li.dpre, self.wT[b + "mlp.fc1.weight"], v.dln, M, D, Hd)
+            ops.layernorm_bwd_part(v.dln, Li.xmid, Li.st2[0], Li.st2[1], P(b + "norm2.weight"), v.dx, lnp[2 * i + 1], LN_REP,
+                                   Li.g1, s1, N, M, D)
             # ---- attention branch: x_mid = x_in + s1 * proj(attn(qkv(ln1(x_in))))
-            ops.gemm_nt(ops.EPI_BF16, Ti["g1"], self.wT[b + "attn.proj.weight"], dao, M, D, D)
-            ops.attn_bwd(ctx.qkv[i], ctx.ao[i], dao, ctx.lse[i], Ti["dqkv"], delta, B, N, H, scale)
-            ops.gemm_nt(ops.EPI_BF16, Ti["dqkv"], self.wT[b + "attn.qkv.weight"], dln, M, D, 3 * D)
-            ops.layernorm_bwd_part(dln, ctx.xs[i], ctx.st1[i][0], ctx.st1[i][1], P(b + "norm1.weight"), dx, lnp[2 * i], LN_REP,
-                                   T["layers"][i - 1]["g2"] if i > 0 else None, dpr(i - 1, 1) if i > 0 else None, N, M, D)
+            ops.gemm_nt(ops.EPI_BF16, Li.g1, self.wT[b + "attn.proj.weight"], v.dao, M, D, D)
+            ops.attn_bwd(Li.qkv, Li.ao, v.dao, Li.lse, Li.dqkv, v.delta, nb, N, H, scale)
+            ops.gemm_nt(ops.EPI_BF16, Li.dqkv, self.wT[b + "attn.qkv.weight"], v.dln, M, D, 3 * D)
+            ops.layernorm_bwd_part(v.dln, Li.xs, Li.st1[0], Li.st1[1], P(b + "norm1.weight"), v.dx, lnp[2 * i], LN_REP,
+                                   L[i - 1].g2 if i > 0 else None, dpr(i - 1, 1) if i > 0 else None, N, M, D)
             g = gdone.get(i)
             if g is not None:               # layers [i, g.hi_layer) are finished: their weight / bias / LayerNorm gradients, then the hand-over
                 desc, npb, ntiles, flops, nbytes = g["desc"]
                 ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
                 ops.ln_grad_reduce(g["ln_desc"], lnp[2 * g["lo_layer"]:2 * g["hi_layer"]], 2 * (g["hi_layer"] - g["lo_layer"]), LN_REP, D)
                 cb(*g["flat"])
-        if cb is None:
-            ops.ln_grad_reduce(T["ln_desc"], lnp, 2 * cfg.depth, LN_REP, D)
-            # all 4 * depth weight (and bias) gradients: dW += dY^T X, db += colsum dY
+
+    def backward_finish(self, ctx, dlogits):
+        """Everything of the backward that sums over ALL rows, after the chain(s) of backward_rows have covered every image: head weight / bias
+        gradients, the LayerNorm partial copies folded into the gradient block, all 4 * depth weight (and bias) gradients in ONE grouped
+        launch (dW += dY^T X, db += colsum dY), the patch embedding."""
+        cfg = self.cfg
+        D, N, C = cfg.embed_dim, cfg.num_tokens, cfg.num_classes
+        B = ctx.B
+        M = B * N
+        f32, bf16 = torch.float32, torch.bfloat16
+        G = lambda n: self.p(n, self.grad)   # noqa: E731
+        T = self._bwd_plan(M, ctx)
+        dx = self._buf("b_dx", (M, D), f32)
+        ops.cls_head_bwd(dlogits, None, None, ctx.feat, None, None, None, G("head.weight"), G("head.bias"), None, None, B, N, D, C)
+        if self.grad_ready_cb is None:
+            ops.ln_grad_reduce(T["ln_desc"], T["ln_part"], 2 * cfg.depth, LN_REP, D)
             desc, npb, ntiles, flops, nbytes = T["desc"]
             ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
         Kp = cfg.in_chans * cfg.patch_size ** 2

@@ -15,6 +15,7 @@ is Bn_Controller.freeze_bn ... unfreeze_bn (running statistics untouched).
 import torch
 
 from .. import ops
+from .surface import ModuleSurface
 
 MOMENTUM, SLOPE = 0.001, 0.1
 _FUSED_DX = True      # input gradients of the stride-1 3x3 layers as implicit-GEMM convolutions with the rotated / transposed filter
@@ -29,7 +30,7 @@ class WrnContext:
     __slots__ = ("B", "H", "W", "stem", "blocks", "final", "feat", "tag")
 
 
-class WideResNet:
+class WideResNet(ModuleSurface):
     def __init__(self, num_classes, depth=28, widen_factor=2, first_stride=1, device="cuda", **kw):
         assert (depth - 4) % 6 == 0
         self.num_classes, self.depth, self.widen, self.first_stride = num_classes, depth, widen_factor, first_stride

@@ -409,6 +409,92 @@ def test_full_size_step_properties():
     assert rel(g2.cpu(), (2.0 * g1).cpu().numpy()) < 2e-3        # bf16 rounding of the scaled output gradients is not exactly linear
 
 
+def test_full_size_reference_trace(golden):
+    """BASELINE.json configs[1] at FULL size against the REFERENCE's own train_step (tests/golden/srflexmatch_full_trace.npz, oracle/gen_golden.py
+    gen_trace_full: ViT-S/2, 100 classes, 8 / 8 / 8, ulb_dest_len 50 000, the yaml's hyper-parameters; two single steps from the same mid-training
+    state -- it = 1000: K = 0 and the stage-1 rewarder update, it = 30000: K = 8).  Reference-side values for everything the step decides or
+    returns: per pass the max-probs / thresholds / pseudo labels / masks the hook saw, the K reward vectors and mask2, the three losses, the
+    sampled step gradients of every parameter tensor, the features, the table entries of the batch after the step.  Masks, pseudo labels and
+    the table are bit-exact (asserted per row: the engine's max-prob deviates from the reference's by less than that row's distance to its
+    nearer threshold); rewards 5e-3; losses 6e-2 relative; gradients 2.5e-2 rel-L2."""
+    from oracle.gen_golden import FULL, full_hook_state, trace_vit_params
+    g = golden("srflexmatch_full_trace")
+    tr = FULL
+    C, Bl, Bu = tr["C"], tr["Bl"], tr["Bu"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_SMALL_P2_32)
+    T_ = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
+    P0 = trace_vit_params(cfg, tr["seed"], tr["head_gain"])
+    bseed = int(g["meta/bseed"])
+    b = synth.synth_batch(bseed, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+    sel0, acc0 = full_hook_state(b["idx_ulb"])
+    for it in [int(i) for i in g["meta/its"]]:
+        p = f"it{it}"
+        K = int(g[f"{p}/K"])
+        alg = get_algorithm(make_args(algorithm="srflexmatch", num_classes=C, num_train_iter=tr["num_train_iter"], ulb_dest_len=tr["ulb_dest_len"],
+                                      start_timing=tr["start_timing"], feature_dim=cfg.embed_dim, num_warmup_iter=tr["num_warmup_iter"],
+                                      p_cutoff=tr["p_cutoff"], N_k=tr["N_k"], lr=tr["lr"]), vit.vit_small_patch2_32)
+        alg.model.load_state_dict(T_(P0))
+        alg.rewarder.load_state_dict(T_(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), tr["seed"] + 1)))
+        alg.generator.load_state_dict(T_(synth.synth_params(S.generator_shapes(cfg.embed_dim), tr["seed"] + 2)))
+        h = alg.hooks_dict["MaskingHook"]
+        h.selected_label = torch.from_numpy(sel0.copy())
+        h.classwise_acc = torch.from_numpy(acc0.copy()).to(DEV)
+        alg.it = it
+        alg.optimizer.sched_step = it
+        alg.inject_droppath = [torch.from_numpy(synth.synth_droppath(int(g[f"{p}/dp_seed0"]) + k, V.drop_path_probs(cfg), Bl + 2 * Bu))
+                               for k in range(K + 1)]
+        alg.trace = {}
+        rbefore = alg.rewarder.flat.clone()
+        out, log = alg.train_step(**alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()}))
+        torch.cuda.synchronize()
+        assert alg.trace["K"] == K and alg.optimizer.lr_factor() == pytest.approx(float(g[f"{p}/lr_factor"]), rel=1e-9, abs=1e-12)
+        # ---- the score filter: every pass's decisions are the reference's, with room
+        want = g[f"{p}/masks"]
+        masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
+        mpv = alg.trace["max_probs"].cpu().numpy().reshape(want.shape)
+        refp = g[f"{p}/mask_probs"]
+        devs = np.abs(mpv - refp)
+        margin = np.minimum(np.abs(refp - g[f"{p}/mask_thr"]), np.abs(refp - tr["p_cutoff"]))
+        assert float(devs.max()) < 5e-2 and (devs < margin).all(), (p, float(devs.max()), float((margin - devs).min()))
+        assert np.array_equal(alg.trace["pseudo"].cpu().numpy().reshape(want.shape), g[f"{p}/pseudo_label"]), p
+        assert np.array_equal(masks, want), p
+        assert 0.0 < want.mean() < 1.0                                     # rows selected and rows rejected at full size
+        assert np.array_equal(h.selected_label.cpu().numpy()[b["idx_ulb"]], g[f"{p}/sel_after_batch"])
+        assert int((h.selected_label != -1).sum()) == int(g[f"{p}/n_selected_after"])
+        assert np.array_equal(h.classwise_acc.cpu().numpy().view(np.uint32), g[f"{p}/accs"][-1].view(np.uint32))
+        if K:
+            r = alg.trace["reward"].cpu().numpy().reshape(K, Bu)
+            rg = g[f"{p}/reward"]
+            np.testing.assert_allclose(r, rg, rtol=0, atol=5e-3)
+            clear = np.abs(rg - rg.mean(axis=1, keepdims=True)) > 2.0 * np.abs(r - rg).max(axis=1, keepdims=True) + 1e-6
+            m2 = alg.trace["mask2"].cpu().numpy().reshape(K, Bu)
+            assert clear.mean() > 0.7 and np.array_equal(m2[clear], g[f"{p}/mask2"][clear]), (p, float(clear.mean()))
+            assert np.array_equal(m2, (r >= r.mean(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32)), p
+        # ---- losses, features, the step gradient (before the optimizer consumes it), the rewarder update
+        for k_ in ("sup_loss", "unsup_loss", "total_loss"):
+            assert float(log["train/" + k_]) == pytest.approx(float(g[f"{p}/log/{k_}"]), rel=6e-2, abs=5e-3), (p, k_)
+        assert float(log["train/util_ratio"]) == pytest.approx(float(g[f"{p}/log/util_ratio"]), abs=1e-6)
+        for k_ in ("x_lb", "x_ulb_w", "x_ulb_s"):
+            assert rel(out["feat"][k_].cpu().numpy(), g[f"{p}/feat/{k_}"]) < 2e-2, (p, k_)
+        num = den = 0.0
+        worst = (0.0, None)
+        for nme, gv in alg.model.named_grads():
+            gs = g.samp(f"{p}/grad/{nme}")
+            a = samp_of(gv.cpu().numpy(), gs).astype(np.float64)
+            e2, n2 = float(((a - gs["sample"]) ** 2).sum()), float((gs["sample"].astype(np.float64) ** 2).sum())
+            num += e2; den += n2
+            if n2 > 0 and not nme.endswith("attn.qkv.bias") and nme != "cls_token":       # (K third of the qkv bias: analytic gradient 0, see DESIGN)
+                worst = max(worst, ((e2 / n2) ** 0.5, nme))
+        assert (num / den) ** 0.5 < 2.5e-2, (p, (num / den) ** 0.5)
+        assert worst[0] < 8e-2, (p, worst)
+        alg.out_dict, alg.log_dict = out, log
+        alg.call_hook("after_train_step")
+        assert int(not torch.equal(rbefore, alg.rewarder.flat)) == int(g[f"{p}/rewarder_updated"])
+        for k_, v in alg.rewarder.named_parameters():
+            gs = g.samp(f"{p}/rewarder/{k_}")
+            np.testing.assert_allclose(samp_of(v.detach().cpu().numpy(), gs), gs["sample"], rtol=0, atol=2e-3, err_msg=p + k_)
+
+
 def test_elide_unread_rows_changes_no_result():
     """Opt-in ``elide_unread_rows`` (never the default): the (pass, image) rows nothing reads are not computed.  Rows are independent in the
     ViT engine, so every mask, every logit that IS read, the losses and the updated parameters must equal those of the full step."""
