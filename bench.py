@@ -65,8 +65,12 @@ def parse_args(argv=None):
                     help="NOT the reference's work (never the default, flagged in config): skip the (pass, image) rows whose outputs nothing reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-allreduce-ab", action="store_true", help="N > 1: skip the overlap off / on / bf16 legs of the gradient exchange")
+    ap.add_argument("--no-allreduce-ab", action="store_true", help="N > 1: skip the pinned legs of the gradient exchange (allreduce / overlap / rs_ag ...)")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary legs (224x224, scaled batch, K = 0 regime, BERT, Wav2Vec2)")
+    ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs (default: all of them)")
+    ap.add_argument("--extra-budget", type=float, default=900.0,
+                    help="seconds the phases AFTER the headline (secondary legs, gradient-exchange legs, CPU baseline) may take before the line is "
+                         "printed with what is complete")
     return ap.parse_args(argv)
 
 
@@ -318,14 +322,36 @@ class Leg:
         m.optimizer.sched_step = m.it
         m.model.train()
         self.alg = m
-        # HIP-graph replay of the step (SR_HIP_GRAPH=0: eager launches): algorithms whose step keeps no Python-side state, single rank
-        self.graph = None
-        # Opt-in (SR_HIP_GRAPH=1): measured on one MI355X the replayed step is NOT faster -- 5.32 vs 5.23 ms in the K = 8 regime, 3.18 vs 3.19 ms at
-        # K = 0: the step is bound by the GPU (dependent small launches, total CU time), not by the 2.5 ms of host enqueue, which runs ahead of it
-        if os.environ.get("SR_HIP_GRAPH", "0") != "0" and getattr(m, "graph_safe", False) and world == 1 and net == "vit":
-            from semireward_amd.core.stepgraph import StepGraph
-            self.graph = StepGraph(m, warm=1)
+        # HIP-graph replay of the step (core/stepgraph.py; algorithms whose step keeps no Python-side state, single rank).  SR_HIP_GRAPH = auto
+        # (default): decided from a measurement in run() -- replay when the host needs more than HOST_BOUND of a step's time to enqueue it (a
+        # slow or oversubscribed host); on one MI355X with its own host the step is GPU-bound (1.9 ms of enqueue per 4.9 ms step, replay
+        # 5.32 vs 5.23 ms eager) and eager launches stay.  1 / 0 force it.
+        self.graph, self.graph_mode = None, os.environ.get("SR_HIP_GRAPH", "auto")
+        self.graph_ok = getattr(m, "graph_safe", False) and world == 1 and net == "vit"
+        if self.graph_mode not in ("auto", "0") and self.graph_ok:
+            self._enable_graph()
         self.workload += "steady SR regime" if regime == "sr" else "pre-start_timing regime"
+
+    HOST_BOUND = 0.85
+
+    def _enable_graph(self):
+        from semireward_amd.core.stepgraph import StepGraph
+        self.graph = StepGraph(self.alg, warm=1)
+
+    def host_enqueue_ms(self, steps=6):
+        """Host time to ENQUEUE a step (perf_counter around step() with the device drained before and nothing waited for inside) and the step's
+        device time (events), over ``steps`` steps.  Returns (host ms per step, device ms per step)."""
+        import torch
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        host = 1e3 * (time.perf_counter() - t0) / steps
+        e1.record()
+        e1.synchronize()
+        return host, e0.elapsed_time(e1) / steps
 
     def step(self):
         m = self.alg
@@ -367,10 +393,17 @@ class Leg:
         m = self.alg
         # set-up, untimed like building the model: the start-up autotune of the step schedule (share of the inference rows on the second
         # stream, srflexmatch._DeferTuner) runs its candidates as real training steps; the W warm-up and the K timed steps follow it
+        # (data parallel: the gradient exchange is selected first -- distributed.ExchangeTuner -- then the step schedule)
         tune_steps = 0
-        while getattr(m, "_tuners", None) is not None and (tune_steps == 0 or m._tuners) and tune_steps < 64:
+        tuning = lambda: (not m.dp.settled) or bool(getattr(m, "_tuners", None)) or bool(getattr(m, "_untuned", None))   # noqa: E731
+        while (getattr(m, "_tuners", None) is not None or not m.dp.settled) and (tune_steps == 0 or tuning()) and tune_steps < 96:
             self.step()
             tune_steps += 1
+        # host-boundness of the step, every rank its own: enqueue time against device time of the same steps
+        host_ms, dev_ms = self.host_enqueue_ms()
+        host_bound = host_ms > self.HOST_BOUND * dev_ms
+        if self.graph is None and self.graph_mode == "auto" and self.graph_ok and host_bound:
+            self._enable_graph()
         # ... and the capture of the step's HIP graphs: every variant that occurs in the steady regime (with / without the SemiReward update of
         # every N_k-th step) is run eagerly once and captured at its next occurrence
         cap_steps = 0
@@ -380,7 +413,9 @@ class Leg:
         for _ in range(warmup):
             self.step()
         m.dp.comm_events = [] if world > 1 else None          # event pairs around the gradient all-reduce of every timed step
+        syncs0 = m.dp.agreement_syncs
         dts = [self.timed(steps) for _ in range(repeats)]
+        syncs_timed = m.dp.agreement_syncs - syncs0
         ar_ms = None
         if world > 1:
             torch.cuda.synchronize()
@@ -413,11 +448,30 @@ class Leg:
                                     "autotune_ms_per_step_by_share": rep[-1]["ms_per_step"], "autotune_steps": tune_steps}
         out["config"]["launch"] = ("HIP graph replay of train_step + optimizer (%d variants captured; %d replays, %d eager steps incl. tuning / capture)" % (
             len(self.graph.graphs), self.graph.replays, self.graph.eager_steps)) if self.graph is not None else "eager launches"
+        # host enqueue time of a step per rank (8 feeder processes share one host on a node) and whether the step is host-bound there
+        hosts = [host_ms]
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.zeros(world, dtype=torch.float64, device="cuda")
+            t[self.ctx["rank"]] = host_ms
+            dist.all_reduce(t)
+            hosts = [float(x) for x in t.cpu()]
+        out["host_enqueue_ms_per_step"] = {"per_rank": [round(h, 4) for h in hosts], "max": max(hosts), "device_ms_per_step_this_rank": dev_ms,
+                                           "host_bound": bool(max(hosts) > self.HOST_BOUND * dev_ms),
+                                           "measured_over": "6 steps after the schedule tuning, device drained before, nothing waited for inside"}
+        out["config"]["host_enqueue_ms_per_step_max"] = max(hosts)
+        out["config"]["hip_graph"] = "%s -> %s" % (self.graph_mode, "replay" if self.graph is not None else "eager")
         if world > 1:
             out["config"]["backend"] = self.ctx["backend_note"]
             out["rccl_ranks"] = self.ctx["rccl_ranks"]
             out["devices"] = self.ctx["ndev_used"]
             out["allreduce_ms_per_step"] = ar_ms
+            # which gradient exchange ran: chosen at start-up from measurements on this backend (or pinned by SR_GRAD_EXCHANGE); rank agreements
+            # (blocking) happen while the schedules are tuned -- none inside the timed regions
+            out["grad_exchange"] = dict(m.dp.exchange_report or {}, running=m.dp.exchange)
+            out["config"]["grad_exchange"] = m.dp.exchange
+            out["rank_agreement_syncs"] = {"during_tuning": syncs0 + (m.dp.exchange_report or {}).get("agreement_syncs", 0),
+                                           "in_timed_regions": syncs_timed}
         if roofline:
             # roofline pass: the SAME steps again, in this process, with HIP events (on the launch stream) around every GEMM-class launch.
             # Kept out of the timed regions because 2 x 145 event records per step cost ~0.9 ms of host time.  Every rank runs the pass
@@ -522,10 +576,10 @@ def worker(a):
     del head
     torch.cuda.empty_cache()
     # The headline is measured.  What follows (secondary legs, the gradient-exchange A/B for N > 1) must never cost the line: if those phases
-    # do not finish within SR_BENCH_EXTRA_BUDGET seconds (a collective one rank never reaches does not raise, it waits), every rank's watchdog
+    # do not finish within --extra-budget seconds (a collective one rank never reaches does not raise, it waits), every rank's watchdog
     # ends its process and rank 0 prints the line with what is complete.
     import threading
-    budget = float(os.environ.get("SR_BENCH_EXTRA_BUDGET", "900"))
+    budget = float(a.extra_budget)
     state = {"phase": "secondary legs", "done": False}
 
     def _give_up():
@@ -549,7 +603,7 @@ def worker(a):
                 ("classic_cv_wrn_28_2_srpseudolabel", dict(net="wrn", bu=64), max(4, a.steps // 2), True),
                 ("usb_nlp_bert_base_srsoftmatch", dict(net="bert"), max(3, a.steps // 5), True),
                 ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), True))
-        only = [t for t in os.environ.get("SR_BENCH_LEGS", "").split(",") if t]        # (debugging: run a subset of the secondary legs)
+        only = [t for t in a.legs.split(",") if t]        # (--legs: a subset of the secondary legs)
         for tag, kw, nsteps, roof in legs:
             if only and tag not in only:
                 continue
@@ -582,13 +636,13 @@ def worker(a):
             torch.cuda.empty_cache()
     state["phase"] = "gradient-exchange A/B"
     if world > 1 and default_headline and not a.no_allreduce_ab:
-        # A/B of the gradient exchange in the SAME run (decides the default once it has been timed on RCCL over xGMI): the headline above is
-        # "off" = one all-reduce of the flat block after the backward; "on" = layer-group slices reduced on a communication stream under the
-        # backward (SR_OVERLAP_ALLREDUCE, distributed.DataParallel.install_overlap); "on_bf16" = the same exchange in bf16 (never the default)
-        ab = out["overlap_allreduce"] = {"off": {"ms_per_step": out["ms_per_step"], "value": out["value"],
-                                                 "allreduce_ms_per_step": out.get("allreduce_ms_per_step")}}
-        for tag, env in (("on", {"SR_OVERLAP_ALLREDUCE": "1"}), ("off_bf16", {"SR_ALLREDUCE_BF16": "1"}), ("rs_ag", {"SR_GRAD_EXCHANGE": "rs_ag"}),
-                         ("rs_ag_on", {"SR_GRAD_EXCHANGE": "rs_ag", "SR_OVERLAP_ALLREDUCE": "1"})):
+        # Every gradient exchange pinned once in the SAME run, beside the headline's start-up selection (distributed.ExchangeTuner): the evidence
+        # table for the first run on RCCL over xGMI
+        ab = out["grad_exchange_legs"] = {"headline": {"exchange": out["config"].get("grad_exchange"), "ms_per_step": out["ms_per_step"],
+                                                       "value": out["value"], "allreduce_ms_per_step": out.get("allreduce_ms_per_step")}}
+        for tag, env in (("allreduce", {"SR_GRAD_EXCHANGE": "allreduce"}), ("overlap", {"SR_GRAD_EXCHANGE": "overlap"}),
+                         ("allreduce_bf16", {"SR_GRAD_EXCHANGE": "allreduce_bf16"}), ("rs_ag", {"SR_GRAD_EXCHANGE": "rs_ag"}),
+                         ("rs_ag_overlap", {"SR_GRAD_EXCHANGE": "rs_ag_overlap"})):
             leg, old_env = None, {k: os.environ.get(k) for k in env}
             try:
                 os.environ.update(env)
@@ -596,12 +650,14 @@ def worker(a):
                 # same step schedule as the headline leg (its tuned deferred share): the legs differ in the gradient exchange only, and none
                 # of them spends ~30 tuning steps (each with a blocking rank agreement) before its timed region
                 leg.alg.defer_share = out["config"].get("deferred_share")
+                leg.graph_mode = "0"
                 o = leg.run(max(4, a.steps // 2), 2, 3, roofline=False)
                 ab[tag] = {"ms_per_step": o["ms_per_step"], "value": o["value"], "allreduce_ms_per_step": o.get("allreduce_ms_per_step"),
-                           "note": {"on": "allreduce_ms_per_step = what is left exposed behind the backward (event pair around all_reduce_grads)",
-                                    "off_bf16": "gradient block exchanged as bf16 (a rounded sum: NOT the reference's fp32 DDP buckets)",
-                                    "rs_ag": "reduce-scatter + all-gather of the flat fp32 block instead of one all-reduce (SR_GRAD_EXCHANGE=rs_ag)",
-                                    "rs_ag_on": "reduce-scatter + all-gather per layer-group slice under the backward"}[tag]}
+                           "note": {"allreduce": "one all-reduce of the flat fp32 block after the backward",
+                                    "overlap": "allreduce_ms_per_step = what is left exposed behind the backward (event pair around all_reduce_grads)",
+                                    "allreduce_bf16": "gradient block exchanged as bf16 (a rounded sum: NOT the reference's fp32 DDP buckets)",
+                                    "rs_ag": "reduce-scatter + all-gather of the flat fp32 block instead of one all-reduce",
+                                    "rs_ag_overlap": "reduce-scatter + all-gather per layer-group slice under the backward"}[tag]}
             except Exception as e:                       # noqa: BLE001
                 ab[tag] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             finally:
@@ -609,17 +665,13 @@ def worker(a):
                     os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             del leg
             torch.cuda.empty_cache()
-    if "overlap_allreduce" in out:
-        # which exchange the measurements of THIS run favour (fp32 only: the bf16 exchange changes results); the default in distributed.py stays
-        # the single all-reduce until a run on RCCL says otherwise -- on gloo / shared devices this field says nothing about xGMI
-        ab = out["overlap_allreduce"]
-        timed = {k: v["ms_per_step"] for k, v in ab.items() if k != "off_bf16" and isinstance(v, dict) and v.get("ms_per_step")}
+    if "grad_exchange_legs" in out:
+        # the pinned legs beside the start-up selection of the headline: on gloo / shared devices they say nothing about xGMI
+        ab = out["grad_exchange_legs"]
+        timed = {k: v["ms_per_step"] for k, v in ab.items() if k not in ("headline", "allreduce_bf16") and isinstance(v, dict) and v.get("ms_per_step")}
         if timed:
             best = min(timed, key=timed.get)
-            ab["fastest_fp32"] = {"leg": best, "ms_per_step": timed[best], "vs_off": timed[best] / timed["off"] if timed.get("off") else None,
-                                  "env": {"off": {}, "on": {"SR_OVERLAP_ALLREDUCE": "1"}, "rs_ag": {"SR_GRAD_EXCHANGE": "rs_ag"},
-                                          "rs_ag_on": {"SR_GRAD_EXCHANGE": "rs_ag", "SR_OVERLAP_ALLREDUCE": "1"}}[best],
-                                  "measured_on": ctx["backend_note"]}
+            ab["fastest_fp32"] = {"leg": best, "ms_per_step": timed[best], "measured_on": ctx["backend_note"]}
     state["phase"] = "cpu baseline"
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and default_headline:

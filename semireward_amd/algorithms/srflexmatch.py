@@ -185,17 +185,16 @@ class SRConsistencyBase(AlgorithmBase):
         self.generator_optimizer = None       # generator grads are None in the reference -> its Adam step is a no-op (A.1)
         self.max_reward = torch.full((), -float("inf"), device=self.device)
         self.dp.broadcast_params(self.model, self.rewarder, self.generator)
-        # Opt-in (SR_OVERLAP_ALLREDUCE=1; data parallel + ViT engine): gradient slices are all-reduced under the backward.  The logic is verified
-        # with two gloo ranks on one GPU (tests/test_gpu_dp_overlap.py); it stays off by default until it has been timed on RCCL over xGMI --
-        # this round only had single-GPU boxes, and the proven path is the single all-reduce after the backward.
-        if os.environ.get("SR_OVERLAP_ALLREDUCE", "0") != "0":
-            self.dp.install_overlap(self.model)
+        # data parallel: which gradient exchange runs (one all-reduce / reduce-scatter + all-gather, after or under the backward) is measured on
+        # the live backend in the first steps and agreed between the ranks (distributed.ExchangeTuner; SR_GRAD_EXCHANGE pins it)
+        self.dp.attach(self.model)
         self._plans = {}
+        self._untuned = set()                  # plan keys created while the exchange selection was still measuring steps: tuned once it has settled
         self._tuners = {}                      # plan key -> (_DeferTuner, {share: _Plan}) while the deferred share of that regime is being tuned
         self.defer_share = None                # a share handed in (e.g. the one an earlier leg of a bench was tuned to): no tuning steps
         self.defer_report = {}                 # plan key -> what the tuner measured and chose
         self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
-        # gradient-row forward on a second HIP stream (SR_OVERLAP_GRAD_ROWS=0 serialises it behind the inference forward)
+        # gradient-row forward on a second HIP stream
         # (args.overlap_grad_rows = False / args.defer_unread_rows = False: the serial schedule, one stream -- tests and A/B runs)
         self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", True)) and torch.cuda.is_available()
         self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
@@ -391,11 +390,16 @@ class SRConsistencyBase(AlgorithmBase):
 
     def _forward_passes(self, imgs, nl, nu, K):
         key = (nl, nu, K, bool(self.use_cat), self.elide_unread_rows)
+        if key in self._untuned and self.dp.settled:
+            self._untuned.discard(key)
+            del self._plans[key]
         if key not in self._plans:
             if self.elide_unread_rows and not getattr(self.model, "rows_independent", False):
                 raise ValueError("elide_unread_rows needs a backbone without batch statistics (ViT / BERT / Wav2Vec2 engines)")
             self._plans[key] = self._make_plan(nl, nu, K, defer_fraction=self.defer_share)
-            if _DEFER_AUTOTUNE and self.defer_share is None and self.defer_unread_rows and self._plans[key].rest_cols.numel() > 0:
+            if not self.dp.settled:
+                self._untuned.add(key)               # (two tuners varying the step at once would time each other)
+            elif _DEFER_AUTOTUNE and self.defer_share is None and self.defer_unread_rows and self._plans[key].rest_cols.numel() > 0:
                 # candidates that give distinct (read | deferred) splits; a split whose deferred launch would fall below the fused kernels'
                 # launch size is folded by _Plan and drops out here
                 cand, seen = {}, set()

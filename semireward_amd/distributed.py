@@ -1,42 +1,168 @@
 """Data-parallel plumbing: one process per GPU, torch.distributed 'nccl' (= RCCL over xGMI) or 'gloo' (CPU tests).
 
 Reference: plain DDP (semilearn/core/utils/misc.py:55-58) -> bucketed gradient all-reduce, per-rank hook state.
-Here parameters/gradients are ONE flat fp32 block, so the gradient exchange is a single large all-reduce
-(85.7 MB for ViT-S) issued right after the hand-written backward -- the "few, large collectives" shape that suits
-xGMI's point-to-point links -- and the 1/world scaling is folded into the AdamW launch (grad_scale).
-Optional extension named in BASELINE.json (off by default = reference parity): a global reward threshold (``global_reward_threshold``:
-one packed all-reduce of (sum reward per pass, n) per step, ``reward_means``).  The FlexMatch class histogram stays per rank, as under the
-reference's DDP (srflexmatch/utils.py:24-35 recounts the rank's own ``selected_label``).  And (SR_ALLREDUCE_BF16=1) the gradient block exchanged as bf16 --
-half the xGMI ring time of the one large all-reduce (42.9 instead of 85.7 MB for ViT-S), at the price of a gradient sum rounded to 8 bits
-of mantissa per hop, which DDP's fp32 buckets do not do: opt-in, never the default.
-``SR_GRAD_EXCHANGE=rs_ag`` (opt-in until it has been timed on RCCL) runs the same exchange as reduce-scatter + all-gather on the flat block: every
-rank reduces one contiguous 1/world shard (in place, 256-byte aligned) and the shards are gathered back -- the two halves of an all-reduce as
-separate collectives, which on xGMI's all-to-all mesh (7 links per GPU) can go direct between every pair of GPUs instead of
-around a ring bound by ONE link; `bench.py --gpus N` times it beside the single all-reduce (`overlap_allreduce.rs_ag`).
+Here parameters / gradients are ONE flat fp32 block (85.7 MB for ViT-S), so the gradient exchange is few, large collectives -- the shape that
+suits xGMI's point-to-point links -- and the 1 / world scaling is folded into the AdamW launch (grad_scale).
+
+Which exchange (``SR_GRAD_EXCHANGE``, default ``auto``):
+  allreduce      one all-reduce of the flat block after the backward;
+  rs_ag          the same as reduce-scatter + all-gather: every rank reduces one contiguous 1 / world shard in place (256-byte aligned) and the
+                 shards are gathered back -- the two halves of an all-reduce as separate collectives, which on xGMI's all-to-all mesh (7 links per
+                 GPU) can go direct between every pair of GPUs instead of around a ring bound by ONE link;
+  overlap        the backward finishes its weight gradients in layer groups, last layers first, and each finished contiguous range of the block
+                 is reduced on a communication stream while the backward of the earlier layers continues (install_overlap);
+  rs_ag_overlap  both;
+  allreduce_bf16 the block exchanged as bf16 (half the bytes; a gradient sum rounded to 8 bits of mantissa per hop, which DDP's fp32 buckets do
+                 not do): explicit opt-in only, never chosen by ``auto``;
+  auto           MEASURED at start-up on the live backend, agreed between the ranks (ExchangeTuner): no environment variable is needed for
+                 the first run on a node whose interconnect nobody has timed yet.
+Optional extension named in BASELINE.json (off by default = reference parity): a global reward threshold (``global_reward_threshold``: one packed
+all-reduce of (sum reward per pass, n) per step, ``reward_means``).  The FlexMatch class histogram stays per rank, as under the reference's DDP
+(srflexmatch/utils.py:24-35 recounts the rank's own ``selected_label``).
 """
 import os
 
 import torch
 import torch.distributed as dist
 
+EXCHANGES = ("allreduce", "rs_ag", "overlap", "rs_ag_overlap")           # what ``auto`` chooses between
+_EXPLICIT = EXCHANGES + ("allreduce_bf16", "auto")
+
+
+class ExchangeTuner:
+    """Start-up selection of the gradient exchange, driven by DataParallel.all_reduce_grads (called once per step):
+      step 0      both collective forms -- one all-reduce, reduce-scatter + all-gather -- are timed on a scratch block of the gradient's size
+                  (1 warm + 3 timed launches each, HIP events; nothing touches the real gradient), the ranks agree on the maximum over the
+                  ranks of each median (ONE small blocking all-reduce) and keep the faster form;
+      then        WARM + TIMED steps with the exchange after the backward, WARM + TIMED steps with it under the backward (when the backbone
+                  reports finished layer groups), step time = HIP events at consecutive exchange calls, again agreed as the maximum over
+                  the ranks (one blocking read per phase) -- the faster schedule is kept.
+    Every rank takes every decision from the SAME agreed numbers at the SAME step, so the ranks never issue different collectives.  While it
+    runs ``settled`` is False and the algorithm's own step-schedule tuner waits (two tuners varying the step at once would time each other)."""
+    WARM, TIMED, COLL_TIMED = 1, 3, 3
+
+    def __init__(self, dp):
+        self.dp = dp
+        self.phase = 0                 # 0: collective forms; 1: exchange after the backward; 2: under the backward; 3: done
+        self.marks = []
+        self.report = {}
+        self.syncs = 0
+
+    def _agree(self, values, device):
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.syncs += 1
+        return [float(x) for x in t.cpu()]
+
+    def _time_collectives(self, grad):
+        dp = self.dp
+        scratch = torch.zeros_like(grad)
+        cuda = grad.is_cuda
+        out = []
+        for form in ("allreduce", "rs_ag"):
+            dp.collective = form
+            ts = []
+            for i in range(1 + self.COLL_TIMED):
+                if cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); dp._sum_over_ranks(scratch); e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                else:
+                    import time
+                    t0 = time.perf_counter(); dp._sum_over_ranks(scratch); ts.append(1e3 * (time.perf_counter() - t0))
+            out.append(sorted(ts[1:])[len(ts[1:]) // 2])
+        return out
+
+    def _mark(self, device):
+        if device.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        else:
+            import time
+            e = time.perf_counter()
+        self.marks.append(e)
+
+    def _median_step_ms(self):
+        m = self.marks
+        if not isinstance(m[0], float):
+            m[-1].synchronize()
+            gaps = [m[j].elapsed_time(m[j + 1]) for j in range(self.WARM, len(m) - 1)]
+        else:
+            gaps = [1e3 * (m[j + 1] - m[j]) for j in range(self.WARM, len(m) - 1)]
+        return sorted(gaps)[len(gaps) // 2]
+
+    def step(self, model):
+        """Called at the top of every all_reduce_grads while tuning.  Sets dp.collective / overlap for the exchange that follows."""
+        dp, grad = self.dp, model.grad
+        if self.phase == 0:
+            ms = self._agree(self._time_collectives(grad), grad.device)
+            dp.collective = "allreduce" if ms[0] <= ms[1] else "rs_ag"
+            self.report["collective_ms"] = {"allreduce": round(ms[0], 4), "rs_ag": round(ms[1], 4)}
+            self.phase, self.marks = 1, []
+            if not dp.can_overlap(model):                   # nothing to compare a schedule with: done after one step
+                self._finish(False, model)
+            return
+        self._mark(grad.device)
+        if len(self.marks) < self.WARM + self.TIMED + 1:
+            return
+        ms = self._agree([self._median_step_ms()], grad.device)[0]
+        if self.phase == 1:
+            self.report["step_ms_exchange_after_backward"] = round(ms, 4)
+            self._after = ms
+            dp.install_overlap(model)                       # from the next backward on the layer groups are reduced under it
+            self.phase, self.marks = 2, []
+        else:
+            self.report["step_ms_exchange_under_backward"] = round(ms, 4)
+            self._finish(ms < self._after, model)
+
+    def _finish(self, overlap, model):
+        dp = self.dp
+        if not overlap:
+            dp.uninstall_overlap(model)
+        dp.exchange = ("rs_ag" if dp.collective == "rs_ag" else "allreduce") if not overlap else ("rs_ag_overlap" if dp.collective == "rs_ag" else "overlap")
+        self.report["chosen"] = dp.exchange
+        self.phase = 3
+        dp.tuner = None
+        dp.exchange_report = dict(self.report, agreement_syncs=self.syncs)
+
 
 class DataParallel:
-    def __init__(self, world_size=1, rank=0, global_reward_threshold=False):
+    def __init__(self, world_size=1, rank=0, global_reward_threshold=False, exchange=None):
         self.world_size, self.rank = world_size, rank
         self.global_reward_threshold = global_reward_threshold
         self.comm_events = None      # bench.py: list that receives a HIP-event pair around the gradient all-reduce of every step
-        self.bf16_grads = os.environ.get("SR_ALLREDUCE_BF16", "0") != "0"
-        self.exchange = os.environ.get("SR_GRAD_EXCHANGE", "allreduce")       # "allreduce" | "rs_ag"
-        if self.exchange not in ("allreduce", "rs_ag"):
-            raise ValueError("SR_GRAD_EXCHANGE must be 'allreduce' or 'rs_ag', not %r" % (self.exchange,))
+        req = exchange if exchange is not None else os.environ.get("SR_GRAD_EXCHANGE", "auto")
+        if req not in _EXPLICIT:
+            raise ValueError("SR_GRAD_EXCHANGE must be one of %s, not %r" % (", ".join(_EXPLICIT), req))
+        self.requested = req
+        self.bf16_grads = req == "allreduce_bf16"
+        self.exchange = "allreduce" if req in ("auto", "allreduce_bf16") else req           # what runs now (auto: until the tuner has decided)
+        self.collective = "rs_ag" if self.exchange.startswith("rs_ag") else "allreduce"
+        self.tuner = ExchangeTuner(self) if req == "auto" else None
+        self.exchange_report = None if req == "auto" else {"chosen": req, "requested": True}
+        self.agreement_syncs = 0     # blocking rank agreements so far (bench.py shows that none happens inside a timed region)
         self._g16 = None
+
+    @property
+    def settled(self):
+        """False while the start-up selection of the gradient exchange is still measuring steps (the algorithm's schedule tuner waits for it)."""
+        return not (self.active and self.tuner is not None)
+
+    def attach(self, model):
+        """Called once by the algorithm with its backbone: an explicitly requested overlapped exchange is installed here."""
+        if self.active and self.exchange.endswith("overlap"):
+            self.install_overlap(model)
+
+    def can_overlap(self, model):
+        return torch.cuda.is_available() and hasattr(model, "grad_ready_cb") and getattr(model.grad, "is_cuda", False)
 
     SHARD_ALIGN = 64                 # elements: shards of the reduce-scatter start on 256-byte boundaries
 
     def _sum_over_ranks(self, t):
         """Sum of a contiguous 1-D slice of a flat block over the ranks, in place: ONE all-reduce, or (rs_ag) reduce-scatter into this rank's
         shard + all-gather of the shards, with the < world * SHARD_ALIGN elements that do not divide evenly all-reduced behind them."""
-        if self.exchange != "rs_ag" or t.dim() != 1 or not t.is_contiguous():
+        if self.collective != "rs_ag" or t.dim() != 1 or not t.is_contiguous():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return
         # shard boundaries on ABSOLUTE 256-byte boundaries of the flat block: a slice that starts off such a boundary (a layer group of the
@@ -68,12 +194,18 @@ class DataParallel:
     # gradient block; each range is all-reduced on a communication stream while the backward of the earlier layers continues (xGMI ring time
     # of the 86 MB block is otherwise serial with the step).  all_reduce_grads then reduces what was not reported and joins the stream.
     def install_overlap(self, model):
-        if not (self.active and torch.cuda.is_available() and hasattr(model, "grad_ready_cb")):
+        if not (self.active and self.can_overlap(model)):
             return False
-        self._comm = torch.cuda.Stream(device=model.grad.device)
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=model.grad.device)
         self._done, self._model = [], model
         model.grad_ready_cb = self._reduce_range
         return True
+
+    def uninstall_overlap(self, model):
+        if getattr(model, "grad_ready_cb", None) is not None:
+            model.grad_ready_cb = None
+        self._done, self._model = [], None
 
     def _reduce_range(self, lo, hi):
         main = torch.cuda.current_stream()
@@ -87,6 +219,8 @@ class DataParallel:
     def all_reduce_grads(self, model):
         if not self.active:
             return
+        if self.tuner is not None:
+            self.tuner.step(model)
         if self.comm_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -139,6 +273,7 @@ class DataParallel:
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.agreement_syncs += 1
         return float(t)
 
     def broadcast_params(self, *modules):

@@ -52,8 +52,7 @@ def _worker(rank, world, port, q):
     H.ce_loss_mean(X @ w2.t(), Y).backward()
     ok_grad = torch.allclose(got, w2.grad.reshape(-1), rtol=1e-5, atol=1e-7)
     # (2b) opt-in bf16 exchange of the gradient block: the same sum to bf16 precision (every rank rounds its block, the sum is rounded)
-    dp16 = DataParallel(world, rank)
-    dp16.bf16_grads = True
+    dp16 = DataParallel(world, rank, exchange="allreduce_bf16")
     m.grad = w.grad.reshape(-1).clone()
     dp16.all_reduce_grads(m)
     ok_grad = ok_grad and m.grad.dtype == torch.float32 and torch.allclose(m.grad / world, w2.grad.reshape(-1), rtol=2e-2, atol=1e-4)
@@ -88,6 +87,45 @@ def test_data_parallel_world2_gloo():
     assert sorted(res) == [(0, True, True), (1, True, True)]
 
 
+def _auto_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semireward_amd.distributed import EXCHANGES, DataParallel
+    dp = DataParallel(world, rank)                     # SR_GRAD_EXCHANGE unset: auto
+    assert dp.requested == "auto" and not dp.settled
+    n = 3 * 64 * 40 + 17
+    rng = np.random.Generator(np.random.PCG64(9))
+    blocks = torch.from_numpy(rng.standard_normal((world, n)).astype(np.float32))
+    m = _Flat(n)
+    ok = True
+    for step in range(3):
+        m.grad = blocks[rank].clone() * (step + 1)
+        dp.all_reduce_grads(m)                          # step 0 times both collective forms on a scratch block first; the gradient is summed ONCE
+        ok = ok and torch.allclose(m.grad.double(), blocks.double().sum(0) * (step + 1), rtol=1e-6, atol=1e-6)
+    rep = dp.exchange_report
+    # a host-memory block cannot be reduced under a backward: the selection is over after the collective forms
+    ok = ok and dp.settled and rep["chosen"] in EXCHANGES and not rep["chosen"].endswith("overlap") and set(rep["collective_ms"]) == {"allreduce", "rs_ag"}
+    q.put((rank, bool(ok), rep["chosen"], rep["agreement_syncs"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_is_selected_at_start_up_and_agreed_between_the_ranks():
+    """SR_GRAD_EXCHANGE=auto (the default): the first exchange call times one all-reduce against reduce-scatter + all-gather on a scratch block,
+    the ranks agree on the maxima over the ranks (one blocking all-reduce) and ALL keep the same form; the gradients are summed exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_auto_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res) and len({r[2] for r in res}) == 1 and all(r[3] == 1 for r in res), res
+
+
 def _rs_ag_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -100,13 +138,12 @@ def _rs_ag_worker(rank, world, port, q):
         blocks = torch.from_numpy(rng.standard_normal((world, n)).astype(np.float32))
         want = blocks.double().sum(0)
         for bf16 in (False, True):
-            dp = DataParallel(world, rank)
-            dp.exchange, dp.bf16_grads = "rs_ag", bf16
+            dp = DataParallel(world, rank, exchange="rs_ag")
+            dp.bf16_grads = bf16
             m = _Flat(n)
             m.grad = blocks[rank].clone()
             dp.all_reduce_grads(m)
-            ref = DataParallel(world, rank)
-            ref.bf16_grads = bf16
+            ref = DataParallel(world, rank, exchange="allreduce_bf16" if bf16 else "allreduce")
             m2 = _Flat(n)
             m2.grad = blocks[rank].clone()
             ref.all_reduce_grads(m2)
@@ -122,7 +159,7 @@ def _rs_ag_worker(rank, world, port, q):
 
 
 def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce():
-    """SR_GRAD_EXCHANGE=rs_ag (distributed.DataParallel._sum_over_ranks): in-place reduce-scatter into aligned shards + all-gather + tail
+    """exchange 'rs_ag' (SR_GRAD_EXCHANGE=rs_ag; distributed.DataParallel._sum_over_ranks): in-place reduce-scatter into aligned shards + all-gather + tail
     all-reduce == the single all-reduce of the flat gradient block, on 3 ranks (uneven division), fp32 and the opt-in bf16 exchange."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -22,7 +22,8 @@ def _check(line):
     assert o["n_gpus"] == 2 and o["steps"] == 2 and o["value"] > 0 and o["config"]["parallelism"] == "dp2"
     assert (o["config"]["bl"], o["config"]["bu_w"], o["config"]["bu_s"]) == (8, 8, 8) and o["scaling"] == "weak"
     assert o["allreduce_ms_per_step"] is not None and o["allreduce_ms_per_step"] > 0
-    assert ("rccl_ranks" in o) and ("backend" in o["config"])
+    assert ("rccl_ranks" in o) and ("backend" in o["config"]) and o["config"]["grad_exchange"] in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap")
+    assert len(o["host_enqueue_ms_per_step"]["per_rank"]) == 2
     return o
 
 
@@ -58,9 +59,19 @@ def test_eight_ranks_complete_the_headline_the_tuner_and_the_exchange_legs():
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     o = json.loads(lines[0])
     assert o["n_gpus"] == 8 and o["config"]["parallelism"] == "dp8" and o["value"] > 0 and "truncated" not in o
-    ab = o["overlap_allreduce"]
-    for tag in ("off", "on", "off_bf16", "rs_ag"):
+    ab = o["grad_exchange_legs"]
+    for tag in ("allreduce", "overlap", "allreduce_bf16", "rs_ag", "rs_ag_overlap"):
         assert "error" not in ab[tag] and ab[tag]["ms_per_step"] > 0, (tag, ab[tag])
+    # the headline's exchange was selected at start-up from measurements on this backend and agreed between the ranks; its rank agreements
+    # (blocking) all happen while the schedules are tuned, none inside a timed region
+    from semireward_amd.distributed import EXCHANGES
+    ge = o["grad_exchange"]
+    assert ge["chosen"] in EXCHANGES and ge["running"] == ge["chosen"] == o["config"]["grad_exchange"]
+    assert set(ge["collective_ms"]) == {"allreduce", "rs_ag"} and "step_ms_exchange_after_backward" in ge and "step_ms_exchange_under_backward" in ge
+    assert o["rank_agreement_syncs"]["in_timed_regions"] == 0 and o["rank_agreement_syncs"]["during_tuning"] >= 3
+    # every rank reports the host time it needs to enqueue a step (8 feeder processes on one host)
+    he = o["host_enqueue_ms_per_step"]
+    assert len(he["per_rank"]) == 8 and min(he["per_rank"]) > 0 and he["max"] == max(he["per_rank"]) and isinstance(he["host_bound"], bool)
     assert 0.0 < o["config"]["deferred_share"] <= 1.0          # every rank's tuner finished with the same choice (else: a hang)
 
 
@@ -80,8 +91,9 @@ def test_same_command_under_torch_distributed_run():
 def test_watchdog_prints_the_headline_when_the_secondary_phases_do_not_finish():
     """After the headline is measured nothing may cost the line: with a budget the secondary legs cannot meet, every rank's watchdog ends its
     process and rank 0 prints the line with the headline fields complete (a collective that one rank never reaches does not raise)."""
-    env = dict(os.environ, SR_BENCH_EXTRA_BUDGET="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-roofline"], env=env,
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-roofline",
+                        "--extra-budget", "1"], env=env,
                        capture_output=True, text=True, timeout=420, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])

@@ -616,3 +616,42 @@ def test_augment_oracle_matches_the_whole_reference_transforms(golden):
         assert np.array_equal(A.strong(src, pad, S, i, j, bool(flip), g[f"case/{n}/ops"], g[f"case/{n}/vals"], cv, ux, uy, mean, std),
                               g[f"case/{n}/strong"]), n
     assert 0 < flips < int(g["meta/n"])
+
+
+def test_full_size_trace_filter_decisions(golden):
+    """tests/golden/srflexmatch_full_trace.npz (the reference's own train_step at BASELINE.json configs[1] size: ViT-S/2, 100 classes, 8 / 8 / 8,
+    50 000-entry table, K = 0 and K = 8): the numpy FlexMatch hook replays every pass's decision from the max-probs / pseudo labels the REFERENCE
+    hook saw -- masks, classwise_acc and the table entries of the batch bit for bit, from the mid-training state the fixture was generated from --
+    and the reward filter is mask2 = reward >= mean(reward) per pass.  The fixture is non-trivial (rows selected AND rejected by both filters)
+    and keeps the margin it was chosen for (the GPU test needs every engine max-prob closer to the reference's than to its threshold)."""
+    from oracle.gen_golden import FULL, full_hook_state
+    g = golden("srflexmatch_full_trace")
+    b = synth.synth_batch(int(g["meta/bseed"]), FULL["Bl"], FULL["Bu"], 32, FULL["C"], FULL["ulb_dest_len"])
+    assert float(g["meta/margin"]) >= 1.3e-2
+    for it in [int(i) for i in g["meta/its"]]:
+        p = f"it{it}"
+        K = int(g[f"{p}/K"])
+        assert K == (0 if it <= FULL["start_timing"] else 8)
+        sel0, acc0 = full_hook_state(b["idx_ulb"])
+        st = H.FlexMatchState(FULL["ulb_dest_len"], FULL["C"], True)
+        st.selected_label[:] = sel0
+        st.classwise_acc[:] = acc0
+        mp, mi = g[f"{p}/mask_probs"], g[f"{p}/pseudo_label"]
+        margin = np.minimum(np.abs(mp - g[f"{p}/mask_thr"]), np.abs(mp - FULL["p_cutoff"]))
+        assert float(margin.min()) >= float(g["meta/margin"]) - 1e-9
+        for k in range(K + 1):
+            probs = np.zeros((FULL["Bu"], FULL["C"]), np.float32)
+            probs[np.arange(FULL["Bu"]), mi[k]] = mp[k]                    # masking only looks at (max, argmax) of each row
+            thr = np.float32(FULL["p_cutoff"]) * (st.classwise_acc[mi[k]] / (np.float32(2.0) - st.classwise_acc[mi[k]]))
+            assert np.array_equal(thr.view(np.uint32), g[f"{p}/mask_thr"][k].view(np.uint32)), (p, k)
+            want = st.masking(probs, b["idx_ulb"], FULL["p_cutoff"])
+            assert np.array_equal(want, g[f"{p}/masks"][k]), (p, k)
+            assert np.array_equal(st.classwise_acc.view(np.uint32), g[f"{p}/accs"][k].view(np.uint32)), (p, k)
+        assert np.array_equal(st.selected_label[b["idx_ulb"]], g[f"{p}/sel_after_batch"])
+        assert int((st.selected_label != -1).sum()) == int(g[f"{p}/n_selected_after"])
+        assert 0.0 < g[f"{p}/masks"].mean() < 1.0
+        if K:
+            r = g[f"{p}/reward"]
+            assert np.array_equal(g[f"{p}/mask2"], (r >= r.mean(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32))
+            assert 0.0 < g[f"{p}/mask2"].mean() < 1.0
+        assert float(g[f"{p}/log/util_ratio"]) == pytest.approx(float(g[f"{p}/masks"][0].mean()), abs=1e-7)

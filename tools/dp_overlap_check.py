@@ -15,7 +15,7 @@ torch.cuda.set_device(0)
 dist.init_process_group(os.environ.get("SR_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
 res = []
 for overlap in ("1", "0"):
-    os.environ["SR_OVERLAP_ALLREDUCE"] = overlap
+    os.environ["SR_GRAD_EXCHANGE"] = "overlap" if overlap == "1" else "allreduce"
     args = argparse.Namespace(gpu=0, rank=rank, world_size=world, distributed=True, infer_chunk=0, **bench.NS)
     alg = get_algorithm(args, vit.vit_small_patch2_32)
     alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})

@@ -12,6 +12,12 @@ with open("$GRAFT_REPO_ROOT/gpurun_out/$tag.stats.txt","w") as f:
     for n,cl,t,a,p in rows[:70]:
         f.write("%-100s %6d %10.0f %9.1f %6.2f\n"%(n[:100],cl,t,a,p))
     f.write("TOTAL_US %.0f\n"%sum(r[2] for r in rows))
+# every dispatch's duration of the ten kernels with the most time, in dispatch order (tools/check_roofline_vs_rocprof.py compares the bench line's
+# live per-launch time with the profiler's average over THE SAME launches -- the last N of the process, the roofline pass)
+import json
+top=[r[0] for r in rows[:10]]
+dur={n:[d/1e3 for (d,) in c.execute("select (end-start) from kernels where name=? order by start",(n,))] for n in top}
+json.dump(dur,open("$GRAFT_REPO_ROOT/gpurun_out/$tag.durations.json","w"))
 cols=[r[1] for r in c.execute("pragma table_info(kernels)")]
 with open("$GRAFT_REPO_ROOT/gpurun_out/$tag.dispatch.txt","w") as f:
     f.write(" ".join(cols)+"\n")

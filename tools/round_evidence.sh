@@ -10,8 +10,13 @@ cd $GRAFT_REPO_ROOT
 python bench.py 2> gpurun_out/${tag}_bench_full.err | tail -1 > gpurun_out/${tag}_bench_full.json
 Q="--steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/prof.sh ${tag}_headline $Q; grep -h "^{\"metric\"" gpurun_out/${tag}_headline.log > gpurun_out/${tag}_headline_bench_under_rocprof.json
-python tools/check_roofline_vs_rocprof.py gpurun_out/${tag}_bench_full.json gpurun_out/${tag}_headline.stats.txt > gpurun_out/${tag}_roofline_vs_rocprof.txt 2>&1 \
-  || echo "ROOFLINE CHECK FAILED (see gpurun_out/${tag}_roofline_vs_rocprof.txt)"
+# the roofline pass under the profiler: the SAME launches timed by bench.py (dispatch-bound events) and by rocprofv3 must agree within 3 %
+bash tools/prof.sh ${tag}_roofcheck --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-also
+grep -h "^{\"metric\"" gpurun_out/${tag}_roofcheck.log > gpurun_out/${tag}_roofcheck_bench_under_rocprof.json
+python tools/check_roofline_vs_rocprof.py gpurun_out/${tag}_roofcheck_bench_under_rocprof.json gpurun_out/${tag}_roofcheck.stats.txt gpurun_out/${tag}_roofcheck.durations.json \
+  > gpurun_out/${tag}_roofline_vs_rocprof.txt 2>&1 || echo "ROOFLINE CHECK FAILED (see gpurun_out/${tag}_roofline_vs_rocprof.txt)"
+echo "--- the unprofiled driver-form line against the profile of the plain run (different processes: the profiler slows the step) ---" >> gpurun_out/${tag}_roofline_vs_rocprof.txt
+python tools/check_roofline_vs_rocprof.py gpurun_out/${tag}_bench_full.json gpurun_out/${tag}_headline.stats.txt 0.10 >> gpurun_out/${tag}_roofline_vs_rocprof.txt 2>&1
 cat gpurun_out/${tag}_roofline_vs_rocprof.txt
 bash tools/prof.sh ${tag}_224 $Q --img 224; grep -h "^{\"metric\"" gpurun_out/${tag}_224.log > gpurun_out/${tag}_224_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_bu64 $Q --bu 64 --steps 6 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_bu64.log > gpurun_out/${tag}_bu64_bench_under_rocprof.json
@@ -23,5 +28,5 @@ bash tools/traffic.sh ${tag} --no-also --repeats 1
 P="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/pmc.sh ${tag}_pmc1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE" $P
 bash tools/pmc.sh ${tag}_pmc2 "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" $P
-rm -f gpurun_out/${tag}_*.dispatch.txt
+rm -f gpurun_out/${tag}_*.dispatch.txt gpurun_out/${tag}_[a-z0-9]*.durations.json.bak; for f in gpurun_out/${tag}_*.durations.json; do case $f in *roofcheck*) ;; *) rm -f $f;; esac; done
 ls -la gpurun_out | grep ${tag}
