@@ -60,7 +60,6 @@ def parse_args(argv=None):
                     help="auto: srflexmatch (vit), srsoftmatch (bert, hubert), srfreematch (wave2vec = BASELINE.json configs[4])")
     ap.add_argument("--samples", type=int, default=64000, help="waveform length (usb_audio: 4 s at 16 kHz)")
     ap.add_argument("--seq-len", type=int, default=512)
-    ap.add_argument("--infer-chunk", type=int, default=0)
     ap.add_argument("--elide-unread-rows", action="store_true",
                     help="NOT the reference's work (never the default, flagged in config): skip the (pass, image) rows whose outputs nothing reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,7 +235,7 @@ class Leg:
         from semireward_amd.utils import synth
         self.a, self.ctx, self.net, self.img, self.bu, self.bl, self.regime = a, ctx, net, img, bu, bl or bu, regime
         world, rank, local = ctx["world"], ctx["rank"], ctx["local"]
-        common = dict(gpu=local, rank=rank, world_size=world, distributed=world > 1, infer_chunk=a.infer_chunk)
+        common = dict(gpu=local, rank=rank, world_size=world, distributed=world > 1)
         self.elide = elide
         if net == "vit":
             from semireward_amd.nets import vit

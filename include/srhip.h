@@ -533,12 +533,26 @@ int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_mean, const
                       const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
                       float* running_var, float momentum, int update_running, const void* Wb, const float* resid, float* y, int B, int H,
                       int W, int Cin, int Cout, int ksize, int stride, int Kpad, double* acc_out, int stat_ranks, void* stream);
+/* The same launch for `passes` independent forwards of B images each (pass-major tensors: xin [passes, B, H, W, Cin], y / resid [passes,
+ * B*Ho*Wo, Cout], in_acc / acc_out [passes, srhip_bn_acc_doubles(C)], pub_mean / pub_invstd [passes, Cin]): every pass is its own BatchNorm
+ * statistics group, exactly as separate model() calls are -- the K + 1 forwards of x_ulb_w per step of SRPseudoLabel.data_generator under
+ * Bn_Controller.freeze_bn (semilearn/algorithms/srpseudolabel/srpseudolabel.py:59-90) share one launch per convolution instead of K + 1.
+ * in_mode 2 or 3 only (handed-in statistics would be one group's); update_running moves the running statistics from pass 0 only. */
+int srhip_wrn_conv_bn_passes(const float* xin, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* in_gamma,
+                             const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
+                             float* running_var, float momentum, int update_running, const void* Wb, const float* resid, float* y, int B, int H,
+                             int W, int Cin, int Cout, int ksize, int stride, int Kpad, double* acc_out, int stat_ranks, int passes, void* stream);
 /* wrn_head : the network's tail (wrn.py:119-126) in one launch: feat [B, C] = mean over the HW2 pixels of LeakyReLU(BatchNorm(x)), logits [B, K] =
  * feat Wc^T + bc; in_mode 0 / 1 / 3 and the publishing arguments as for wrn_conv_bn (workgroup 0 publishes).  C <= 256. */
 int srhip_wrn_head(const float* x, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* gamma,
                    const float* beta, float eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean, float* running_var,
                    float momentum, int update_running, const float* Wc, const float* bc, float* feat, float* logits, int B, int HW2, int C,
                    int K, int stat_ranks, void* stream);
+/* ... and for `passes` forwards of B images (x [passes * B, HW2, C]; in_acc / published statistics per pass; in_mode 3). */
+int srhip_wrn_head_passes(const float* x, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* gamma,
+                   const float* beta, float eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean, float* running_var,
+                   float momentum, int update_running, const float* Wc, const float* bc, float* feat, float* logits, int B, int HW2, int C,
+                   int K, int stat_ranks, int passes, void* stream);
 int srhip_bn_stats(const float* x, float eps, float momentum, int update_running, float* running_mean, float* running_var, float* out_mean,
                    float* out_invstd, double* ws, int rows, int C, void* stream);
 int srhip_bn_act(const float* x, const float* mean, const float* invstd_or_var, const float* gamma, const float* beta, float eps, float slope,

@@ -103,6 +103,8 @@ SIGNATURES = {
     "srhip_bn_acc_doubles": (ctypes.c_longlong, [I]),
     "srhip_wrn_conv_bn": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, I, I, P, I, P]),
     "srhip_wrn_head": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, P, I, I, I, I, I, P]),
+    "srhip_wrn_conv_bn_passes": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, I, I, P, I, I, P]),
+    "srhip_wrn_head_passes": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, P, I, I, I, I, I, I, P]),
     "srhip_bn_stats": (I, [P, F, F, I, P, P, P, P, P, I, I, P]),
     "srhip_bn_act": (I, [P, P, P, P, P, F, F, I, P, P, I, I, P]),
     "srhip_bn_accumulate": (I, [P, P, I, I, P]),

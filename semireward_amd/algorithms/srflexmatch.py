@@ -193,7 +193,6 @@ class SRConsistencyBase(AlgorithmBase):
         self._tuners = {}                      # plan key -> (_DeferTuner, {share: _Plan}) while the deferred share of that regime is being tuned
         self.defer_share = None                # a share handed in (e.g. the one an earlier leg of a bench was tuned to): no tuning steps
         self.defer_report = {}                 # plan key -> what the tuner measured and chose
-        self.infer_chunk = getattr(args, "infer_chunk", 0)     # images per inference launch-train (0 = all at once)
         # gradient-row forward on a second HIP stream
         # (args.overlap_grad_rows = False / args.defer_unread_rows = False: the serial schedule, one stream -- tests and A/B runs)
         self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", True)) and torch.cuda.is_available()
@@ -257,8 +256,7 @@ class SRConsistencyBase(AlgorithmBase):
         side = self._side_stream if self.overlap_grad_rows else None
         dp_grad = sel(pl.grad_cols, 0)
         ni, nr = pl.inf_cols.numel(), pl.rest_cols.numel()
-        step = self.infer_chunk if self.infer_chunk > 0 else max(ni, 1)
-        chunks = [(pl.inf_cols[s:s + step], pl.inf_img[s:s + step].contiguous(), ng_ + s) for s in range(0, ni, step)]
+        chunks = [(pl.inf_cols, pl.inf_img, ng_)] if ni else []
         if side is None and nr:
             chunks.append((pl.rest_cols, pl.rest_img, ng_ + ni))
         dps = [sel(cols, a) for cols, _, a in chunks]

@@ -18,6 +18,9 @@ from .srflexmatch import SRConsistencyBase, _Plan
 from .utils import SSL_Argument, str2bool
 
 
+_SHARE_PASS_LAUNCHES = True      # BatchNorm backbone: the K + 1 forwards of x_ulb_w share their launches (module constant: tests flip it)
+
+
 @ALGORITHMS.register("srpseudolabel")
 class SRPseudoLabel(SRConsistencyBase):
     def _init_thresholds(self, args):
@@ -66,16 +69,17 @@ class SRPseudoLabel(SRConsistencyBase):
             # BatchNorm backbone (classic_cv, WRN): every model call of the reference is its own statistics group, so the calls stay
             # separate launches -- model(x_lb) moves the running statistics (:96), every model(x_ulb_w) runs under Bn_Controller.freeze_bn
             # (:100-110, :65-76).  Only the labelled forward and the LAST unlabelled forward carry a gradient.
+            # The K + 1 forwards of x_ulb_w (K data_generator passes + the one whose loss is kept) are K + 1 statistics groups over the same
+            # batch: they share ONE launch per convolution (WideResNet.forward_passes; 28 launches instead of 28 (K + 1), each large enough
+            # to amortise its statistics prologue / epilogue); every pass is computed, the last one keeps its activations for the backward.
             lg_lb, ft_lb, ctx_lb = self.model.forward_saved(x_lb.contiguous(), update_stats=True, tag="lb")
-            lws, fws, ctx_u = [], [], None
-            xu = x_ulb_w.contiguous()
-            for k in range(P):
-                if k == K:
-                    lg, ft, ctx_u = self.model.forward_saved(xu, update_stats=False, tag="ulb")
-                else:            # the K passes whose loss data_generator discards: frozen statistics, no state (every pass is a HIP-graph replay)
-                    lg, ft = self.model.forward_frozen(xu, tag="ulb_inf")
-                lws.append(lg); fws.append(ft)
-            logits, feats, ctx = torch.cat([lg_lb] + lws), torch.cat([ft_lb] + fws), (ctx_lb, ctx_u)
+            if _SHARE_PASS_LAUNCHES:
+                lg_u, ft_u, ctx_u = self.model.forward_passes(x_ulb_w.contiguous(), P, tag="ulb")
+            else:                # one launch train per pass (the comparison the tests / A-B runs flip to)
+                outs = [self.model.forward_frozen(x_ulb_w.contiguous(), tag="ulb_inf") for _ in range(K)]
+                lg_k, ft_k, ctx_u = self.model.forward_saved(x_ulb_w.contiguous(), update_stats=False, tag="ulb")
+                lg_u, ft_u = torch.cat([o[0] for o in outs] + [lg_k]), torch.cat([o[1] for o in outs] + [ft_k])
+            logits, feats, ctx = torch.cat((lg_lb, lg_u)), torch.cat((ft_lb, ft_u)), (ctx_lb, ctx_u)
         else:
             logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
             self._join_grad()

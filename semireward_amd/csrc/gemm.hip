@@ -468,6 +468,13 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
 // prefetch cursor running PDG steps ahead of the MFMA cursor across tile boundaries.
 // Waves: 4 (m) x 2 (n); wave tile 64 x (16*NTW); NTW = 4 -> BN = 128, NTW = 8 -> BN = 256.
 constexpr int GBM = 256;
+// LDS-DMA ring depth of the persistent kernel (stages of (256 + BN) x 32 bf16).  256 x 256: 4 stages = 128 KB.  A fifth stage (the whole 160 KB of
+// a CU's LDS, a third more bytes in flight) was measured neutral on every shape of the legs (profiles/r05_gemm_ring_depth.txt: 13952 x 3072 x 768
+// 748 vs 749 TF/s, 8192^3 1136 vs 1152): the K loop is not waiting for operand arrival at this depth.
+#ifndef SRHIP_BIG_NSTG
+#define SRHIP_BIG_NSTG 4
+#endif
+constexpr int big_stages(int ntw, int wn) { return wn == 1 ? 3 : (ntw == 4 ? 5 : SRHIP_BIG_NSTG); }
 
 // tile index -> (row tile, column tile) in bands of GROUP_M row tiles walked column-major: the 32 consecutive indices an XCD works on at a
 // time (xcd_remap) are then 8 x 4 tiles -- 8 A panels + 4 B panels per k step from HBM / MALL instead of 1 + 32 for a row of tiles
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
   constexpr int NWV = 4 * WN;                        // waves per workgroup (4 along m)
   constexpr int GBN = 16 * NTW * WN;
   constexpr int A_EL = GBM * BK, B_EL = GBN * BK, STG = A_EL + B_EL;
-  constexpr int NSTG = (WN == 1) ? 3 : ((NTW == 4) ? 5 : 4), PDG = NSTG - 1;
+  constexpr int NSTG = big_stages(NTW, WN), PDG = NSTG - 1;
   constexpr int AI = 16 / NWV, BI = (GBN / 16) / NWV; // LDS-DMA instructions (16 rows each) per wave for the A / B sub-tile
   constexpr int NI = AI + BI;
   extern __shared__ __attribute__((aligned(16))) bf16_t gsm[];
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
 template <int EPI, int NTW, int WN>
 static void launch_big_t(const GemmArgs& g, int grid_cap, hipStream_t s) {
   constexpr int GBN = 16 * NTW * WN;
-  constexpr int NSTG = (WN == 1) ? 3 : ((NTW == 4) ? 5 : 4);
+  constexpr int NSTG = big_stages(NTW, WN);
   constexpr size_t sm = (size_t)NSTG * (GBM + GBN) * BK * sizeof(bf16_t);
   const int tiles = cdiv(g.M, GBM) * cdiv(g.N, GBN);
   auto kern = gemm_big_kernel<EPI, NTW, WN>;

@@ -41,6 +41,12 @@ struct ConvArgs {
   float* y;
   int H, W, Cin, log2Cin, Cout, ks, stride, Ho, Wo, Kp, npix, ntiles, in_rows;
   double* acc_out;             // NULL: no statistics; else accumulator copies [BN_COPIES][2 Cout] of the BatchNorm that reads y
+  // blockIdx.z = PASS: gridDim.z independent forwards (each its own BatchNorm statistics group, as separate model() calls are in the
+  // reference: srpseudolabel.py:59-90 forwards x_ulb_w K + 1 times) share the launch.  Pass-major tensors: xin / y / resid advance by one
+  // batch, the accumulators and the published statistics by one BatchNorm's worth; npix, ntiles, in_rows are PER PASS.
+  long in_ps, out_ps;          // floats per pass of xin, of y / resid
+  // wrn_conv_tile_kernel: one workgroup = one TH x TW block of output pixels of one image (TH * TW = 64 * PG)
+  int TW, TH, IW, IH, tiles_x, tiles_y;
 };
 
 // what a lane requests for one 32-wide k step: its 8 input channels (raw fp32) and NT filter fragments
@@ -60,6 +66,16 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int co0 = blockIdx.y * NT * 16, K = a.ks * a.ks * a.Cin, pad = a.ks >> 1, nks = a.Kp >> 5, HoWo = a.Ho * a.Wo;
   const bool stats = a.acc_out != nullptr;
+  // this workgroup's pass
+  const int ps = blockIdx.z;
+  const float* const xin_p = a.xin + (size_t)ps * a.in_ps;
+  float* const y_p = a.y + (size_t)ps * a.out_ps;
+  const float* const resid_p = a.resid ? a.resid + (size_t)ps * a.out_ps : nullptr;
+  const double* const in_acc_p = a.in_acc ? a.in_acc + (size_t)ps * BN_COPIES * 2 * a.Cin : nullptr;
+  double* const acc_out_p = a.acc_out ? a.acc_out + (size_t)ps * BN_COPIES * 2 * a.Cout : nullptr;
+  BnFinal pub_p = a.pub;
+  if (pub_p.out_mean) { pub_p.out_mean += (size_t)ps * a.Cin; pub_p.out_invstd += (size_t)ps * a.Cin; }
+  pub_p.update_running = a.pub.update_running && ps == 0;      // (one statistics group moves the running statistics: the caller's first)
   // a lane adds ONE value per pixel tile it walks (<= 4 of them at the launch sizes below): fp32 here, double from the wave reduction on
   float s1[NT][4], s2[NT][4];
 #pragma unroll
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
   // ---- per-tile state (set by setup) and the request of one k step's operands
   int n = 0, y0 = 0, x0 = 0;
   bool valid = false;
-  const float* base = a.xin;
+  const float* base = xin_p;
   auto setup = [&](int rnd) {
     const int pt = (rnd * gridDim.x + blockIdx.x) * TPW + tsub;
     n = pt * 16 + l15;
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
     const int nn = valid ? n : 0;
     const int b = nn / HoWo, rr = nn - b * HoWo, yo = rr / a.Wo, xo = rr - yo * a.Wo;
     y0 = yo * a.stride - pad; x0 = xo * a.stride - pad;
-    base = a.xin + (size_t)b * a.H * a.W * a.Cin;
+    base = xin_p + (size_t)b * a.H * a.W * a.Cin;
   };
   auto request = [&](int ksi) {
     StepRaw<NT> q;
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
     for (int o = tid; o < 2 * a.Cin; o += 256) {
       double u[BN_COPIES], t = 0.0;
 #pragma unroll
-      for (int q = 0; q < BN_COPIES; ++q) u[q] = a.in_acc[(size_t)q * 2 * a.Cin + o];
+      for (int q = 0; q < BN_COPIES; ++q) u[q] = in_acc_p[(size_t)q * 2 * a.Cin + o];
 #pragma unroll
       for (int q = 0; q < BN_COPIES; ++q) t += u[q];
       red2c[o] = t;
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
       const float mu = (float)m, var = (float)(v > 0.0 ? v : 0.0);
       if (a.in_mode == 3) { prm[0][c] = mu; prm[1][c] = 1.0f / sqrtf(var + a.in_eps); prm[2][c] = a.in_gamma[c]; prm[3][c] = a.in_beta[c]; }
     }
-    if (publish) bn_finalize(red2c, a.Cin, a.in_rows, a.pub);
+    if (publish) bn_finalize(red2c, a.Cin, a.in_rows, pub_p);
   }
   if (a.in_mode == 0 || a.in_mode == 1) {
     for (int c = tid; c < a.Cin; c += 256) {
@@ -210,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
       for (int t = 0; t < NT; ++t) {
         const size_t o = (size_t)n * a.Cout + co0 + 16 * t + 4 * lg;
         f32x4_t out = acc[t];
-        if (a.resid) {
-          const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(a.resid + o);
+        if (resid_p) {
+          const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(resid_p + o);
           out[0] += rs[0]; out[1] += rs[1]; out[2] += rs[2]; out[3] += rs[3];
         }
-        *reinterpret_cast<f32x4_t*>(a.y + o) = out;
+        *reinterpret_cast<f32x4_t*>(y_p + o) = out;
         if (stats) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s1[t][r] += out[r]; s2[t][r] += out[r] * out[r]; }
@@ -235,11 +251,206 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
       if (l15 == 0) { redw[wave][0][16 * t + 4 * lg + r] = (double)f1; redw[wave][1][16 * t + 4 * lg + r] = (double)f2; }
     }
   __syncthreads();
-  double* accp = a.acc_out + (size_t)(blockIdx.x % BN_COPIES) * 2 * a.Cout;
+  double* accp = acc_out_p + (size_t)(blockIdx.x % BN_COPIES) * 2 * a.Cout;
   for (int o = tid; o < 2 * NT * 16; o += 256) {
     const int which = o / (NT * 16), ch = o % (NT * 16);
     const double tsum = redw[0][which][ch] + redw[1][which][ch] + redw[2][which][ch] + redw[3][which][ch];
     unsafeAtomicAdd(accp + which * a.Cout + co0 + ch, tsum);          // fire and forget: the next launch reads them
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same convolution with the INPUT TILE IN LDS (layers whose output rows are >= 16 pixels wide: 20 of the 28 convolutions of WRN-28-2).
+//
+// wrn_conv_kernel above asks L2 for every operand of every k step: per 16-pixel tile and k step NT filter fragments + the pixel's 8 channels
+// of one tap -- 5 loads for 4 MFMAs, the same input value fetched (and normalised) once per tap, nine times in all.  bench.py's roofline
+// pass put it at 0.09 of the HBM roof (70 TFLOP/s) whether a launch carried one pass or nine: not launch overhead, the operand path.
+// Here a workgroup owns a TH x TW block of output pixels (128 or 256) of one image:
+//   * the (TH s + k - s) x (TW s + k - s) input block is read ONCE, normalised + activated ONCE with bn_apply_kernel's arithmetic, rounded to
+//     bf16 and kept in LDS ([pixel][Cin + 8]: the 16-byte pad makes the pixel pitch an odd number of 16-byte bank groups); out-of-image
+//     pixels are the zeros of the convolution's padding;
+//   * B fragments (8 channels of one tap of one pixel) are ds_read_b128s; a filter fragment from L2 (three k steps ahead) feeds PG MFMAs
+//     -- the PG 16-pixel groups a wave owns -- instead of one;
+//   * k order, accumulation order and the epilogue (residual, store, statistics of the output into the next BatchNorm's accumulator
+//     copies) are wrn_conv_kernel's, so the two kernels agree to the last bit on the layers both can run.
+template <int NT, int PG>
+__global__ __launch_bounds__(256, 2) void wrn_conv_tile_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t tin[];          // [IH * IW][Cin + 8]
+  __shared__ float prm[4][128];
+  __shared__ double redw[4][2][NT * 16];
+  __shared__ double red2c[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int co0 = blockIdx.y * NT * 16, K = a.ks * a.ks * a.Cin, pad = a.ks >> 1, nks = a.Kp >> 5;
+  const bool stats = a.acc_out != nullptr;
+  const int ps = blockIdx.z;
+  const float* const xin_p = a.xin + (size_t)ps * a.in_ps;
+  float* const y_p = a.y + (size_t)ps * a.out_ps;
+  const float* const resid_p = a.resid ? a.resid + (size_t)ps * a.out_ps : nullptr;
+  const double* const in_acc_p = a.in_acc ? a.in_acc + (size_t)ps * BN_COPIES * 2 * a.Cin : nullptr;
+  double* const acc_out_p = a.acc_out ? a.acc_out + (size_t)ps * BN_COPIES * 2 * a.Cout : nullptr;
+  BnFinal pub_p = a.pub;
+  if (pub_p.out_mean) { pub_p.out_mean += (size_t)ps * a.Cin; pub_p.out_invstd += (size_t)ps * a.Cin; }
+  pub_p.update_running = a.pub.update_running && ps == 0;
+  // block -> (image, tile row, tile column)
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x / tpi, tr = (blockIdx.x - b * tpi) / a.tiles_x, tc = blockIdx.x - b * tpi - tr * a.tiles_x;
+  const int oy0 = tr * a.TH, ox0 = tc * a.TW;
+  const int iy0 = oy0 * a.stride - pad, ix0 = ox0 * a.stride - pad;
+  const int PP = a.Cin + 8;                                             // LDS pixel pitch (elements)
+
+  // filter fragments of the first three k steps: requested before anything else (they depend on nothing)
+  const bf16_t* wrow = a.Wb + (size_t)(co0 + l15) * a.Kp + 8 * lg;
+  struct WF { u32x4_t af[NT]; };
+  auto wreq = [&](int ksi) {
+    WF q;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) q.af[t] = *reinterpret_cast<const u32x4_t*>(wrow + (size_t)16 * t * a.Kp + ksi * 32);
+    return q;
+  };
+  WF w0 = wreq(0), w1 = w0, w2 = w0;
+  if (1 < nks) w1 = wreq(1);
+  if (2 < nks) w2 = wreq(2);
+
+  const bool publish = a.pub.out_mean != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  if (a.in_mode == 3 || publish) {
+    for (int o = tid; o < 2 * a.Cin; o += 256) {
+      double u[BN_COPIES], t = 0.0;
+#pragma unroll
+      for (int q = 0; q < BN_COPIES; ++q) u[q] = in_acc_p[(size_t)q * 2 * a.Cin + o];
+#pragma unroll
+      for (int q = 0; q < BN_COPIES; ++q) t += u[q];
+      red2c[o] = t;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.Cin; c += 256) {                // bn_apply_kernel's mean / variance / invstd
+      const double m = red2c[c] / a.in_rows, v = red2c[a.Cin + c] / a.in_rows - m * m;
+      const float mu = (float)m, var = (float)(v > 0.0 ? v : 0.0);
+      if (a.in_mode == 3) { prm[0][c] = mu; prm[1][c] = 1.0f / sqrtf(var + a.in_eps); prm[2][c] = a.in_gamma[c]; prm[3][c] = a.in_beta[c]; }
+    }
+    if (publish) bn_finalize(red2c, a.Cin, a.in_rows, pub_p);
+  }
+  if (a.in_mode == 0 || a.in_mode == 1) {
+    for (int c = tid; c < a.Cin; c += 256) {
+      prm[0][c] = a.in_mean[c];
+      prm[1][c] = a.in_mode == 1 ? 1.0f / sqrtf(a.in_isd[c] + a.in_eps) : a.in_isd[c];
+      prm[2][c] = a.in_gamma[c];
+      prm[3][c] = a.in_beta[c];
+    }
+  }
+  __syncthreads();
+
+  // ---- the input block: fp32 NHWC -> BatchNorm + LeakyReLU -> bf16 -> LDS (4 channels per thread and step)
+  {
+    const int c4n = a.Cin >> 2, total = a.IH * a.IW * c4n;
+    const float* img = xin_p + (size_t)b * a.H * a.W * a.Cin;
+    for (int e0 = tid; e0 < total; e0 += 4 * 256) {
+      float4 v[4];
+      int pix[4], cc[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                          // four requests in flight per thread
+        const int e = e0 + u * 256;
+        pix[u] = e / c4n; cc[u] = (e - pix[u] * c4n) << 2;
+        const int iy = pix[u] / a.IW, ix = pix[u] - iy * a.IW, yy = iy0 + iy, xx = ix0 + ix;
+        in[u] = e < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        v[u] = float4{0.f, 0.f, 0.f, 0.f};
+        if (in[u]) v[u] = *reinterpret_cast<const float4*>(img + ((size_t)yy * a.W + xx) * a.Cin + cc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (e0 + u * 256 >= total) break;
+        float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        if (in[u] && a.in_mode != 2) {
+          const int c = cc[u];
+          const float4 m0 = *reinterpret_cast<const float4*>(&prm[0][c]), i0 = *reinterpret_cast<const float4*>(&prm[1][c]);
+          const float4 g0 = *reinterpret_cast<const float4*>(&prm[2][c]), b0 = *reinterpret_cast<const float4*>(&prm[3][c]);
+          const float mu[4] = {m0.x, m0.y, m0.z, m0.w}, is[4] = {i0.x, i0.y, i0.z, i0.w};
+          const float g[4] = {g0.x, g0.y, g0.z, g0.w}, bt[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                      // bn_apply_kernel's arithmetic, operation for operation
+            const float yv = g[q] * ((o[q] - mu[q]) * is[q]) + bt[q];
+            o[q] = yv > 0.f ? yv : a.slope * yv;
+          }
+        }
+        const u32x2_t pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};      // (padding pixels: zeros)
+        *reinterpret_cast<u32x2_t*>(tin + (size_t)pix[u] * PP + cc[u]) = pk;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop: the wave's PG pixel groups x NT channel tiles
+  int pb[PG];                                               // LDS element offset of the pixel's tap (0, 0)
+  int n_out[PG];
+#pragma unroll
+  for (int gi = 0; gi < PG; ++gi) {
+    const int p = (wave * PG + gi) * 16 + l15, ty = p / a.TW, tx = p - ty * a.TW;
+    pb[gi] = ((ty * a.stride) * a.IW + tx * a.stride) * PP;
+    n_out[gi] = (b * a.Ho + oy0 + ty) * a.Wo + ox0 + tx;
+  }
+  f32x4_t acc[PG][NT];
+#pragma unroll
+  for (int gi = 0; gi < PG; ++gi)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[gi][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int ksi = 0; ksi < nks; ++ksi) {
+    WF w3 = w2;
+    if (ksi + 3 < nks) w3 = wreq(ksi + 3);
+    const int k = ksi * 32 + 8 * lg;
+    int toff = -1;
+    if (k < K) {
+      const int tap = k >> a.log2Cin, c = k & (a.Cin - 1);
+      const int dy = a.ks == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
+      toff = (dy * a.IW + dx) * PP + c;
+    }
+#pragma unroll
+    for (int gi = 0; gi < PG; ++gi) {
+      u32x4_t bfrag = {0u, 0u, 0u, 0u};
+      if (toff >= 0) bfrag = *reinterpret_cast<const u32x4_t*>(tin + pb[gi] + toff);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[gi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w0.af[t]), __builtin_bit_cast(bf16x8_t, bfrag),
+                                                             acc[gi][t], 0, 0, 0);
+    }
+    w0 = w1; w1 = w2; w2 = w3;
+  }
+  // ---- epilogue: D[i][j]: i = output channel within the tile = 4 lg + r, j = pixel = l15
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+#pragma unroll
+  for (int gi = 0; gi < PG; ++gi) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const size_t o = (size_t)n_out[gi] * a.Cout + co0 + 16 * t + 4 * lg;
+      f32x4_t out = acc[gi][t];
+      if (resid_p) {
+        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(resid_p + o);
+        out[0] += rs[0]; out[1] += rs[1]; out[2] += rs[2]; out[3] += rs[3];
+      }
+      *reinterpret_cast<f32x4_t*>(y_p + o) = out;
+      if (stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[t][r] += out[r]; s2[t][r] += out[r] * out[r]; }
+      }
+    }
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float f1 = row16_sum(s1[t][r]), f2 = row16_sum(s2[t][r]);
+      if (l15 == 0) { redw[wave][0][16 * t + 4 * lg + r] = (double)f1; redw[wave][1][16 * t + 4 * lg + r] = (double)f2; }
+    }
+  __syncthreads();
+  double* accp = acc_out_p + (size_t)(blockIdx.x % BN_COPIES) * 2 * a.Cout;
+  for (int o = tid; o < 2 * NT * 16; o += 256) {
+    const int which = o / (NT * 16), ch = o % (NT * 16);
+    const double tsum = redw[0][which][ch] + redw[1][which][ch] + redw[2][which][ch] + redw[3][which][ch];
+    unsafeAtomicAdd(accp + which * a.Cout + co0 + ch, tsum);
   }
 }
 
@@ -274,6 +485,7 @@ struct HeadArgs {
   float eps, slope; int in_mode; BnFinal pub;
   const float* Wc; const float* bc; float* feat; float* logits;
   int HW2, C, K, in_rows;
+  int Bp;                      // images per pass (blockIdx.x / Bp = the pass: its own accumulator, its own published statistics)
 };
 __global__ __launch_bounds__(256) void wrn_head_kernel(const HeadArgs a) {
   __shared__ double red2c[512];
@@ -281,11 +493,13 @@ __global__ __launch_bounds__(256) void wrn_head_kernel(const HeadArgs a) {
   __shared__ float part[256];
   __shared__ float ft[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, C = a.C;
+  const int ps = b / a.Bp;
   if (a.in_mode == 3) {
+    const double* in_acc_p = a.in_acc + (size_t)ps * BN_COPIES * 2 * C;
     for (int o = tid; o < 2 * C; o += 256) {
       double u[BN_COPIES], t = 0.0;
 #pragma unroll
-      for (int q = 0; q < BN_COPIES; ++q) u[q] = a.in_acc[(size_t)q * 2 * C + o];
+      for (int q = 0; q < BN_COPIES; ++q) u[q] = in_acc_p[(size_t)q * 2 * C + o];
 #pragma unroll
       for (int q = 0; q < BN_COPIES; ++q) t += u[q];
       red2c[o] = t;
@@ -295,7 +509,12 @@ __global__ __launch_bounds__(256) void wrn_head_kernel(const HeadArgs a) {
       const double m = red2c[c] / a.in_rows, v = red2c[C + c] / a.in_rows - m * m;
       prm[0][c] = (float)m; prm[1][c] = 1.0f / sqrtf((float)(v > 0.0 ? v : 0.0) + a.eps); prm[2][c] = a.gamma[c]; prm[3][c] = a.beta[c];
     }
-    if (b == 0) bn_finalize(red2c, C, a.in_rows, a.pub);
+    if (b % a.Bp == 0) {
+      BnFinal pub_p = a.pub;
+      if (pub_p.out_mean) { pub_p.out_mean += (size_t)ps * C; pub_p.out_invstd += (size_t)ps * C; }
+      pub_p.update_running = a.pub.update_running && ps == 0;
+      bn_finalize(red2c, C, a.in_rows, pub_p);
+    }
   } else {
     for (int c = tid; c < C; c += 256) {
       prm[0][c] = a.in_mean[c];
@@ -370,7 +589,16 @@ extern "C" int srhip_wrn_head(const float* x, int in_mode, const float* in_mean,
                               const float* beta, float eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
                               float* running_var, float momentum, int update_running, const float* Wc, const float* bc, float* feat,
                               float* logits, int B, int HW2, int C, int K, int stat_ranks, void* stream) {
-  if (!x || !gamma || !beta || !Wc || !bc || !feat || !logits || B <= 0 || HW2 <= 0 || C <= 0 || C > 256 || K <= 0) return SR_EINVAL;
+  return srhip_wrn_head_passes(x, in_mode, in_mean, in_isd, in_acc, gamma, beta, eps, slope, pub_mean, pub_invstd, running_mean, running_var, momentum,
+                               update_running, Wc, bc, feat, logits, B, HW2, C, K, stat_ranks, 1, stream);
+}
+
+extern "C" int srhip_wrn_head_passes(const float* x, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* gamma,
+                                     const float* beta, float eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,
+                                     float* running_var, float momentum, int update_running, const float* Wc, const float* bc, float* feat,
+                                     float* logits, int B, int HW2, int C, int K, int stat_ranks, int passes, void* stream) {
+  if (!x || !gamma || !beta || !Wc || !bc || !feat || !logits || B <= 0 || HW2 <= 0 || C <= 0 || C > 256 || K <= 0 || passes <= 0) return SR_EINVAL;
+  if (passes > 1 && in_mode != 3) return SR_EINVAL;                // passes = statistics groups: batch statistics only
   if (in_mode != 0 && in_mode != 1 && in_mode != 3) return SR_EINVAL;
   if (in_mode == 3 ? !in_acc : (!in_mean || !in_isd)) return SR_EINVAL;
   if (pub_mean && (in_mode != 3 || !pub_invstd || (update_running && (!running_mean || !running_var)))) return SR_EINVAL;
@@ -381,7 +609,8 @@ extern "C" int srhip_wrn_head(const float* x, int in_mode, const float* in_mean,
   a.pub.momentum = momentum; a.pub.update_running = update_running; a.pub.eps = eps;
   a.Wc = Wc; a.bc = bc; a.feat = feat; a.logits = logits; a.HW2 = HW2; a.C = C; a.K = K;
   a.in_rows = B * HW2 * (stat_ranks > 1 ? stat_ranks : 1);
-  SR_LAUNCH(wrn_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  a.Bp = B;
+  SR_LAUNCH(wrn_head_kernel, dim3(B * passes), dim3(256), 0, (hipStream_t)stream, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -398,9 +627,20 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
                                  float* running_mean, float* running_var, float momentum, int update_running, const void* Wb,
                                  const float* resid, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int Kpad,
                                  double* acc_out, int stat_ranks, void* stream) {
+  return srhip_wrn_conv_bn_passes(xin, in_mode, in_mean, in_isd, in_acc, in_gamma, in_beta, in_eps, slope, pub_mean, pub_invstd, running_mean,
+                                  running_var, momentum, update_running, Wb, resid, y, B, H, W, Cin, Cout, ksize, stride, Kpad, acc_out, stat_ranks, 1,
+                                  stream);
+}
+
+extern "C" int srhip_wrn_conv_bn_passes(const float* xin, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc,
+                                        const float* in_gamma, const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd,
+                                        float* running_mean, float* running_var, float momentum, int update_running, const void* Wb,
+                                        const float* resid, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int Kpad,
+                                        double* acc_out, int stat_ranks, int passes, void* stream) {
   if (!xin || !Wb || !y || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || !srhip_wrn_conv_supported(Cin, Cout, ksize) ||
-      Kpad < Cin * ksize * ksize || (Kpad % 32) || in_mode < 0 || in_mode > 3)
+      Kpad < Cin * ksize * ksize || (Kpad % 32) || in_mode < 0 || in_mode > 3 || passes <= 0 || passes > 64)
     return SR_EINVAL;
+  if (passes > 1 && (in_mode == 0 || in_mode == 1)) return SR_EINVAL;     // statistics handed in are one group's: passes fold their own (3) or read raw (2)
   if ((in_mode == 0 || in_mode == 1) && (!in_mean || !in_isd)) return SR_EINVAL;
   if (in_mode != 2 && (!in_gamma || !in_beta)) return SR_EINVAL;
   if ((in_mode == 3 || pub_mean) && !in_acc) return SR_EINVAL;
@@ -419,23 +659,60 @@ extern "C" int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_
   a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
   a.npix = B * a.Ho * a.Wo; a.ntiles = cdiv(a.npix, 16);
   a.acc_out = acc_out;
+  a.in_ps = (long)B * H * W * Cin; a.out_ps = (long)a.npix * Cout;
   const int NT = Cout >= 64 ? 4 : Cout / 16;                       // 16 -> 1, 32 -> 2, >= 64 -> 4
   const int gy = Cout / (NT * 16), nks = Kpad / 32;
+  hipStream_t s = (hipStream_t)stream;
+  // layers with >= 16 output pixels per row and whole 128 / 256-pixel blocks: the input block in LDS (wrn_conv_tile_kernel)
+  static const bool no_tile = SR_TUNE_ENV("SRHIP_CONV_NO_TILE") != nullptr;
+  if (!no_tile && a.Wo >= 16 && (a.Wo % 16) == 0 && NT >= 2 && Cin % 4 == 0) {
+    const int TW = (a.Wo % 32) == 0 ? 32 : 16;
+    // 128 pixels per workgroup (PG = 2); 256 (PG = 4: every filter fragment feeds four MFMAs) when the launch still has >= 4 workgroups per
+    // CU and the input block stays within 64 KB (two workgroups per CU)
+    auto geom = [&](int PG_) {
+      a.TW = TW; a.TH = 64 * PG_ / TW; a.IW = (TW - 1) * stride + ksize; a.IH = (a.TH - 1) * stride + ksize;
+      a.tiles_x = a.Wo / TW; a.tiles_y = a.Ho / a.TH;
+      return (size_t)a.IH * a.IW * (Cin + 8) * sizeof(bf16_t);
+    };
+    int PG = 4;
+    size_t smem = geom(4);
+    if ((long)B * passes * a.Ho * a.Wo / 256 * gy < 1024 || a.Ho % a.TH != 0 || smem > 64 * 1024) { PG = 2; smem = geom(2); }
+    if (a.Ho % a.TH == 0) {
+      if (smem <= 64 * 1024) {
+        const dim3 grid(B * a.tiles_x * a.tiles_y, gy, passes);
+#define SR_TILE_LAUNCH(NT_, PG_)                                                                                           \
+        do {                                                                                                              \
+          auto kern = wrn_conv_tile_kernel<NT_, PG_>;                                                                     \
+          if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+          SR_LAUNCH(kern, grid, dim3(256), smem, s, a);                                                                   \
+        } while (0)
+        if (NT == 4 && PG == 4) SR_TILE_LAUNCH(4, 4);
+        else if (NT == 4) SR_TILE_LAUNCH(4, 2);
+        else if (PG == 4) SR_TILE_LAUNCH(2, 4);
+        else SR_TILE_LAUNCH(2, 2);
+#undef SR_TILE_LAUNCH
+        SR_CHECK_LAUNCH();
+        return SR_OK;
+      }
+    }
+  }
   // <= 512 workgroups (tools/wrn_conv_bench.py: 1024 cost +2.6 us with the statistics prologue / epilogue per workgroup); the waves of a
   // workgroup split K (2 or 4 ways) until the launch has ~2048 waves, as long as a wave keeps >= 4 k steps
   static const int env_ks = SR_TUNE_ENV("SRHIP_CONV_KSPLIT") ? atoi(SR_TUNE_ENV("SRHIP_CONV_KSPLIT")) : 0;          // tuning: force 1 / 2 / 4
   static const int env_maxwg = SR_TUNE_ENV("SRHIP_CONV_MAXWG") ? atoi(SR_TUNE_ENV("SRHIP_CONV_MAXWG")) : 512;
   int KS = 1;
-  while (KS < 4 && (long)a.ntiles * gy * KS * 2 <= 2048 && nks / (KS * 2) >= 4) KS *= 2;
+  while (KS < 4 && (long)a.ntiles * passes * gy * KS * 2 <= 2048 && nks / (KS * 2) >= 4) KS *= 2;
   if (env_ks == 1 || env_ks == 2 || env_ks == 4) KS = env_ks;
+  // workgroups per pass: the launch as a whole stays at <= env_maxwg workgroups (two rounds of the chip) however many passes share it --
+  // every workgroup pays the statistics prologue / epilogue once and then walks more pixel tiles
   int gx = cdiv(a.ntiles, 4 / KS);
-  if (gx > env_maxwg / gy) gx = env_maxwg / gy;
+  const int cap = env_maxwg * (passes > 1 ? 2 : 1) / (gy * passes);
+  if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
-  hipStream_t s = (hipStream_t)stream;
 #define SR_CONV_LAUNCH(NT_)                                                                                          \
-  if (KS == 4) SR_LAUNCH((wrn_conv_kernel<NT_, 4>), dim3(gx, gy), dim3(256), 0, s, a);                      \
-  else if (KS == 2) SR_LAUNCH((wrn_conv_kernel<NT_, 2>), dim3(gx, gy), dim3(256), 0, s, a);                 \
-  else SR_LAUNCH((wrn_conv_kernel<NT_, 1>), dim3(gx, gy), dim3(256), 0, s, a)
+  if (KS == 4) SR_LAUNCH((wrn_conv_kernel<NT_, 4>), dim3(gx, gy, passes), dim3(256), 0, s, a);                      \
+  else if (KS == 2) SR_LAUNCH((wrn_conv_kernel<NT_, 2>), dim3(gx, gy, passes), dim3(256), 0, s, a);                 \
+  else SR_LAUNCH((wrn_conv_kernel<NT_, 1>), dim3(gx, gy, passes), dim3(256), 0, s, a)
   if (NT == 4) { SR_CONV_LAUNCH(4); }
   else if (NT == 2) { SR_CONV_LAUNCH(2); }
   else if (NT == 1) { SR_CONV_LAUNCH(1); }

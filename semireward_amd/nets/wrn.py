@@ -231,8 +231,9 @@ class WideResNet(ModuleSurface):
         return col, Ho, Wo
 
     # ---- one launch per convolution (csrc/wrn_conv.hip) ------------------------------------------------------------------------------
-    def _stats_bufs(self, name, C, tag):
-        return (self._buf((tag, name, "mean"), (C,), torch.float32), self._buf((tag, name, "invstd"), (C,), torch.float32))
+    def _stats_bufs(self, name, C, tag, passes=1):
+        shape = (C,) if passes == 1 else (passes, C)
+        return (self._buf((tag, name, "mean"), shape, torch.float32), self._buf((tag, name, "invstd"), shape, torch.float32))
 
     # SyncBatchNorm.  Under DDP the reference converts every BatchNorm of this backbone (core/utils/misc.py:55): in training mode the batch
     # statistics are those of ALL ranks' rows.  Statistics are sums here, so the ranks exchange the accumulator of a BatchNorm between the
@@ -244,10 +245,25 @@ class WideResNet(ModuleSurface):
     def stat_ranks(self):
         return self.dp.world_size if (self.dp is not None and self.dp.active) else 1
 
-    def _sync_acc(self, bn):
+    def _sync_acc(self, bn, acc=None):
         if self.stat_ranks > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.bn_acc[bn])
+            dist.all_reduce((acc or self.bn_acc)[bn])
+
+    def _pass_acc(self, passes):
+        """Statistics accumulators of ``passes`` forwards that share their launches (forward_features(passes=...)): per BatchNorm a contiguous
+        [passes, srhip_bn_acc_doubles(C)] block (the layout srhip_wrn_conv_bn_passes indexes by blockIdx.z), all in one arena that a forward
+        zeroes with one fill launch.  Returns (arena, {name: [passes, n] view})."""
+        key = ("pass_acc", passes)
+        if key not in self._buf_cache:
+            sizes = [(nme, ops.bn_acc_doubles(c)) for nme, c, _ in self.bn]
+            arena = torch.zeros(passes * sum(n for _, n in sizes), dtype=torch.float64, device=self.device)
+            views, o = {}, 0
+            for nme, n in sizes:
+                views[nme] = arena[o:o + passes * n].view(passes, n)
+                o += passes * n
+            self._buf_cache[key] = (arena, views)
+        return self._buf_cache[key]
 
     def _sync_first_acc(self, B):
         """The exchange of the first accumulator of a training forward, with this rank's row count riding along.  The statistics are sums over
@@ -279,7 +295,8 @@ class WideResNet(ModuleSurface):
             raise RuntimeError("WideResNet under data parallel (SyncBatchNorm): the per-rank batches of a training forward differed; the statistics "
                                "exchange assumes equal row counts on every rank (a last partial batch or an uneven split)")
 
-    def _conv_bn(self, wname, xin, in_bn, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False):
+    def _conv_bn(self, wname, xin, in_bn, raw, B, H, W, stride, out, tag, train, update, resid=None, next_bn=None, publish=False, passes=1,
+                 accs=None):
         """out = conv(LeakyReLU(BN_in(xin))) (+ resid) -- or conv(xin) when ``raw`` -- and, in training mode, the sums of ``out`` added into the
         accumulator of ``next_bn`` (then exchanged between the ranks).  Training mode folds in_bn's statistics from its accumulator; ``publish``:
         this launch also writes in_bn's (mean, invstd) for the backward and moves its running statistics.  Returns in_bn's statistics buffers
@@ -287,81 +304,106 @@ class WideResNet(ModuleSurface):
         c = self.convs[wname]
         P = self.p
         g, bt, eps = P(in_bn + ".weight"), P(in_bn + ".bias"), self.eps[in_bn]
-        acc_out = self.bn_acc[next_bn] if (next_bn is not None and train) else None
+        accs = accs if accs is not None else self.bn_acc
+        acc_out = accs[next_bn] if (next_bn is not None and train) else None
         if not train:
             stats, acc, mode, pub, st = (self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]), None, 1, None, None
         else:
-            stats, acc, mode = None, self.bn_acc[in_bn], 3
-            st = self._stats_bufs(in_bn, c["cin"], tag)
+            stats, acc, mode = None, accs[in_bn], 3
+            st = self._stats_bufs(in_bn, c["cin"], tag, passes)
             pub = st if publish else None
         if raw:
             mode = 2
         ops.wrn_conv_bn(xin, mode, stats, acc, g, bt, eps, SLOPE, c["Wb"], resid, out, B, H, W, c["cin"], c["cout"], c["k"], stride, c["Kp"],
                         publish=pub, running=(self.buffers[in_bn + ".running_mean"], self.buffers[in_bn + ".running_var"]) if pub else None,
-                        momentum=MOMENTUM, update_running=update, acc_out=acc_out, stat_ranks=self.stat_ranks)
+                        momentum=MOMENTUM, update_running=update, acc_out=acc_out, stat_ranks=self.stat_ranks, passes=passes)
         if acc_out is not None:
-            self._sync_acc(next_bn)
+            self._sync_acc(next_bn, accs)
         return st
 
-    def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None):
+    def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None, passes=1):
         """img fp32 [B,3,H,W] (NCHW as the loaders deliver it).  Returns (logits [B,C], feat [B,F], ctx or None).
         ``update_stats=False`` = forward under Bn_Controller.freeze_bn.  ``tag`` names the activation buffer set (two saved graphs of
         a step must not share buffers).
         Launches: stem (layout + im2col + GEMM + statistics), then ONE per convolution -- each reads its input through the BatchNorm +
-        LeakyReLU in front of it and leaves the statistics of the BatchNorm behind it --, then the final BatchNorm, pooling, classifier."""
+        LeakyReLU in front of it and leaves the statistics of the BatchNorm behind it --, then the final BatchNorm, pooling, classifier.
+        ``passes`` = G > 1: G forwards of the SAME batch under frozen running statistics share every launch behind the stem (pass-major
+        activations [G * rows, C]; each pass is its own BatchNorm statistics group, as G separate model() calls are in the reference:
+        srpseudolabel.py:59-90 forwards x_ulb_w K + 1 times per step).  Returns logits [G * B, C], feat [G * B, F] in pass order;
+        ``save`` keeps the LAST pass for a backward."""
         assert img_index is None and droppath is None, "WideResNet has no DropPath and takes whole batches (BatchNorm couples the rows)"
         B, _, H, W = img.shape
+        G = int(passes)
         tag = tag or ("s" if save else "i")
         train = self.training
         upd = bool(train and update_stats)
         assert train or not save, "the backward needs a training-mode forward (batch statistics)"
+        assert G == 1 or (train and not upd), "passes > 1: batch statistics per pass, running statistics frozen (Bn_Controller.freeze_bn)"
         f32 = torch.float32
+        last = (lambda t, rows: t) if G == 1 else (lambda t, rows: t[(G - 1) * rows:])      # the pass a save=True forward keeps
         a0 = self._buf((tag, "in"), (B, H, W, 3), torch.bfloat16)
-        ops.nchw_to_nhwc_bf16(img.contiguous(), a0, B, 3, H, W)
-        out = self._buf((tag, "stem.out"), (B * H * W, self.channels[0]), f32)
-        col0, _, _ = self._conv("conv1.weight", a0, B, H, W, 1, out, tag, bias=self.p("conv1.bias"))
+        out = self._buf((tag, "stem.out"), (G * B * H * W, self.channels[0]), f32)
+        col0 = None
+        for g_ in range(G):                                   # the stem convolution of every pass (layout + im2col + GEMM: three small launches)
+            ops.nchw_to_nhwc_bf16(img.contiguous(), a0, B, 3, H, W)
+            col0, _, _ = self._conv("conv1.weight", a0, B, H, W, 1, out[g_ * B * H * W:(g_ + 1) * B * H * W], tag, bias=self.p("conv1.bias"))
         ctx = None
         if save:
             ctx = WrnContext()
             ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
         h, w = H, W
+        accs = None
         if train:
-            self.bn_acc_arena.zero_()                         # the accumulators of every BatchNorm of this forward: one fill launch
+            # the accumulators of every BatchNorm of this forward: one fill launch
+            if G == 1:
+                self.bn_acc_arena.zero_()
+                accs = self.bn_acc
+            else:
+                arena, accs = self._pass_acc(G)
+                arena.zero_()
             # sums of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
             first = self.blocks[0][0] + "bn1"
-            ops.bn_accumulate(out, self.bn_acc[first], B * h * w, self.channels[0])
+            for g_ in range(G):
+                ops.bn_accumulate(out[g_ * B * h * w:(g_ + 1) * B * h * w], accs[first] if G == 1 else accs[first][g_], B * h * w, self.channels[0])
             if self.stat_ranks > 1:
-                self._sync_first_acc(B)                       # (+ the row counts of the ranks, compared on the device)
+                if G == 1:
+                    self._sync_first_acc(B)                   # (+ the row counts of the ranks, compared on the device)
+                else:
+                    self._sync_acc(first, accs)
         for bi, (p, cin, cout, stride, abr) in enumerate(self.blocks):
             equal = cin == cout
             raw = not (equal or abr)                          # wrn.py:50: conv1 / convShortcut take the RAW x; bn1's statistics still move
             ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
             rows_out = B * ho * wo
-            c1 = self._buf((tag, p, "c1"), (rows_out, cout), f32)
+            c1 = self._buf((tag, p, "c1"), (G * rows_out, cout), f32)
+            kw = dict(passes=G, accs=accs)
             # conv1 reads x through bn1 (folding / publishing its statistics) and leaves the sums of its output for bn2
-            st1 = self._conv_bn(p + "conv1.weight", out, p + "bn1", raw, B, h, w, stride, c1, tag, train, upd, next_bn=p + "bn2", publish=True)
+            st1 = self._conv_bn(p + "conv1.weight", out, p + "bn1", raw, B, h, w, stride, c1, tag, train, upd, next_bn=p + "bn2", publish=True, **kw)
             if equal:
                 sc = out
             else:
-                sc = self._buf((tag, p, "sc"), (rows_out, cout), f32)
-                self._conv_bn(p + "convShortcut.weight", out, p + "bn1", raw, B, h, w, stride, sc, tag, train, upd)
-            y = self._buf((tag, p, "y"), (rows_out, cout), f32)
+                sc = self._buf((tag, p, "sc"), (G * rows_out, cout), f32)
+                self._conv_bn(p + "convShortcut.weight", out, p + "bn1", raw, B, h, w, stride, sc, tag, train, upd, **kw)
+            y = self._buf((tag, p, "y"), (G * rows_out, cout), f32)
             nxt = self.blocks[bi + 1][0] + "bn1" if bi + 1 < len(self.blocks) else "bn1"        # (the last block feeds the final BatchNorm)
-            st2 = self._conv_bn(p + "conv2.weight", c1, p + "bn2", False, B, ho, wo, 1, y, tag, train, upd, resid=sc, next_bn=nxt, publish=True)
+            st2 = self._conv_bn(p + "conv2.weight", c1, p + "bn2", False, B, ho, wo, 1, y, tag, train, upd, resid=sc, next_bn=nxt, publish=True, **kw)
             if save:
-                ctx.blocks.append(dict(x=out, st1=st1, c1=c1, st2=st2, raw=raw, h=h, w=w, ho=ho, wo=wo))
+                pick = (lambda st: st) if G == 1 else (lambda st: (st[0][G - 1], st[1][G - 1]))
+                ctx.blocks.append(dict(x=last(out, B * h * w), st1=pick(st1), c1=last(c1, rows_out), st2=pick(st2), raw=raw, h=h, w=w, ho=ho, wo=wo))
             out, h, w = y, ho, wo
         rows = B * h * w
         C3 = self.channels[3]
         # final BatchNorm + LeakyReLU + average pooling + classifier: one launch (it folds the sums the last convolution left and publishes)
-        feat = torch.empty(B, C3, dtype=f32, device=self.device)
-        logits = torch.empty(B, self.num_classes, dtype=f32, device=self.device)
+        feat = torch.empty(G * B, C3, dtype=f32, device=self.device)
+        logits = torch.empty(G * B, self.num_classes, dtype=f32, device=self.device)
         run = (self.buffers["bn1.running_mean"], self.buffers["bn1.running_var"])
         if train:
-            stf = self._stats_bufs("bn1", C3, tag)
-            ops.wrn_head(out, 3, None, self.bn_acc["bn1"], self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE,
+            stf = self._stats_bufs("bn1", C3, tag, G)
+            ops.wrn_head(out, 3, None, accs["bn1"], self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE,
                          self.p("classifier.weight"), self.p("classifier.bias"), feat, logits, B, h * w, C3, self.num_classes, publish=stf,
-                         running=run, momentum=MOMENTUM, update_running=upd, stat_ranks=self.stat_ranks)
+                         running=run, momentum=MOMENTUM, update_running=upd, stat_ranks=self.stat_ranks, passes=G)
+            if G > 1:
+                stf = (stf[0][G - 1], stf[1][G - 1])
             if upd:
                 self._nbt += 1                                  # num_batches_tracked of all BatchNorms (each was visited once)
         else:
@@ -369,7 +411,7 @@ class WideResNet(ModuleSurface):
             ops.wrn_head(out, 1, run, None, self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE, self.p("classifier.weight"),
                          self.p("classifier.bias"), feat, logits, B, h * w, C3, self.num_classes)
         if save:
-            ctx.final, ctx.feat = dict(x=out, st=stf, h=h, w=w), feat
+            ctx.final, ctx.feat = dict(x=last(out, rows), st=stf, h=h, w=w), feat[(G - 1) * B:]
         return logits, feat, ctx
 
     # ---- the two kinds of pass of an SRPseudoLabel step (srpseudolabel.py:59-90) ---------------------------------------------------------------
@@ -381,6 +423,11 @@ class WideResNet(ModuleSurface):
     def forward_saved(self, img, update_stats, tag):
         """forward_features(img, save=True, ...) -> (logits, feat, ctx) for a later backward(ctx, .)."""
         return self.forward_features(img, save=True, update_stats=update_stats, tag=tag)
+
+    def forward_passes(self, img, passes, tag="ulb"):
+        """The K + 1 forwards of one batch under frozen running statistics (data_generator's K passes + the pass the unsupervised loss
+        back-propagates through, srpseudolabel.py:59-90, :104-110) with shared launches: (logits [passes * B, C], feat, ctx of the LAST pass)."""
+        return self.forward_features(img, save=True, update_stats=False, tag=tag, passes=passes)
 
     def forward(self, x, only_fc=False, only_feat=False, **kw):
         assert not only_fc

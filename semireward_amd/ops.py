@@ -700,31 +700,33 @@ def bn_acc_doubles(C):
 
 
 def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope, Wb, resid, y, B, H, W, Cin, Cout, ksize, stride, Kpad,
-                publish=None, running=None, momentum=0.0, update_running=False, acc_out=None, stat_ranks=1):
+                publish=None, running=None, momentum=0.0, update_running=False, acc_out=None, stat_ranks=1, passes=1):
     """y = conv(f(xin)) (+ resid).  in_mode 0: in_stats = (mean, invstd); 1: (running_mean, running_var); 2: raw; 3: statistics folded from
     in_acc.  publish = (mean, invstd) buffers workgroup (0,0) fills from in_acc (+ running = (running_mean, running_var) moved when
     update_running).  acc_out: accumulator of the BatchNorm that reads y next (sums of y are added)."""
     im, ii = in_stats if in_stats is not None else (None, None)
     pm, pi = publish if publish is not None else (None, None)
     rm, rv = running if running is not None else (None, None)
+    """passes > 1: that many independent forwards of B images each in the one launch (pass-major tensors, see srhip_wrn_conv_bn_passes)."""
     args = (_p(xin), in_mode, _p(im), _p(ii), _p(in_acc), _p(in_gamma), _p(in_beta), in_eps, slope, _p(pm), _p(pi), _p(rm),
-            _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), stat_ranks, _s())
+            _p(rv), momentum, int(update_running), _p(Wb), _p(resid), _p(y), B, H, W, Cin, Cout, ksize, stride, Kpad, _p(acc_out), stat_ranks,
+            int(passes), _s())
     if _PROFILE is not None:
-        npix = y.shape[0]
+        npix = y.shape[0]                   # (all passes)
         # algorithmic work: the convolution's MACs; bytes: the fp32 input once, the fp32 output (+ residual) once, the filter once
-        _PROFILE.timed("srhip_wrn_conv_bn", args, 2.0 * npix * Cin * ksize * ksize * Cout, "wrn_conv_kernel",
-                       4.0 * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad)
+        _PROFILE.timed("srhip_wrn_conv_bn_passes", args, 2.0 * npix * Cin * ksize * ksize * Cout, "wrn_conv_kernel",
+                       4.0 * passes * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad)
         return
-    _call("srhip_wrn_conv_bn", *args)
+    _call("srhip_wrn_conv_bn_passes", *args)
 
 
 def wrn_head(x, in_mode, in_stats, in_acc, gamma, beta, eps, slope, Wc, bc, feat, logits, B, HW2, C, K, publish=None, running=None,
-             momentum=0.0, update_running=False, stat_ranks=1):
+             momentum=0.0, update_running=False, stat_ranks=1, passes=1):
     im, ii = in_stats if in_stats is not None else (None, None)
     pm, pi = publish if publish is not None else (None, None)
     rm, rv = running if running is not None else (None, None)
-    _call("srhip_wrn_head", _p(x), in_mode, _p(im), _p(ii), _p(in_acc), _p(gamma), _p(beta), eps, slope, _p(pm), _p(pi), _p(rm), _p(rv), momentum,
-          int(update_running), _p(Wc), _p(bc), _p(feat), _p(logits), B, HW2, C, K, stat_ranks, _s())
+    _call("srhip_wrn_head_passes", _p(x), in_mode, _p(im), _p(ii), _p(in_acc), _p(gamma), _p(beta), eps, slope, _p(pm), _p(pi), _p(rm), _p(rv), momentum,
+          int(update_running), _p(Wc), _p(bc), _p(feat), _p(logits), B, HW2, C, K, stat_ranks, int(passes), _s())
 
 
 def bn_stats(x, eps, momentum, update_running, running_mean, running_var, out_mean, out_invstd, ws, rows, C):

@@ -71,7 +71,7 @@ def test_eight_ranks_complete_the_headline_the_tuner_and_the_exchange_legs():
     assert o["rank_agreement_syncs"]["in_timed_regions"] == 0 and o["rank_agreement_syncs"]["during_tuning"] >= 3
     # every rank reports the host time it needs to enqueue a step (8 feeder processes on one host)
     he = o["host_enqueue_ms_per_step"]
-    assert len(he["per_rank"]) == 8 and min(he["per_rank"]) > 0 and he["max"] == max(he["per_rank"]) and isinstance(he["host_bound"], bool)
+    assert len(he["per_rank"]) == 8 and min(he["per_rank"]) > 0 and abs(he["max"] - max(he["per_rank"])) < 1e-3 and isinstance(he["host_bound"], bool)
     assert 0.0 < o["config"]["deferred_share"] <= 1.0          # every rank's tuner finished with the same choice (else: a hang)
 
 

@@ -75,7 +75,7 @@ def test_allreduce_streams_are_ordered_by_events_not_by_the_backend():
     n = 1 << 20
     model = type("M", (), {})()
     model.grad, model.grad_ready_cb = torch.zeros(n, device=dev), None
-    dp = FakeDP(world_size=2, rank=0)
+    dp = FakeDP(world_size=2, rank=0, exchange="overlap")        # pinned: the start-up selection would time collectives on a scratch block first
     assert dp.install_overlap(model) and model.grad_ready_cb is not None
     seen, calls = [], []
     spin = int(1e8)                                        # ~50 ms at 2 GHz

@@ -310,18 +310,16 @@ def test_full_size_step_properties_wrn():
         alg = make(p_cutoff)
         calls = []
         ff = alg.model.forward_features
-        alg.model.forward_features = lambda *a, **k: (calls.append(k.get("update_stats", True)), ff(*a, **k))[1]
-        fz = alg.model.forward_frozen
-        alg.model.forward_frozen = lambda *a, **k: (calls.append("frozen"), fz(*a, **k))[1]
+        alg.model.forward_features = lambda *a, **k: (calls.append((k.get("update_stats", True), k.get("passes", 1))), ff(*a, **k))[1]
         alg.trace = {}
         out, log = alg.train_step(**alg.process_batch(**batch))
         torch.cuda.synchronize()
         return alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}, calls
     alg, out, log, tr, calls = run(0.95)
     K = tr["K"]
-    # model(x_lb) moves the statistics; K frozen inference passes of model(x_ulb_w) and the saved frozen pass the backward belongs to
-    assert K == 8 and calls[0] is True and calls.count("frozen") == K and calls.count(True) == 1
-    assert calls[-1] is False and calls.count(False) == K + 1
+    # model(x_lb) moves the statistics; the K + 1 forwards of model(x_ulb_w) under frozen running statistics -- K data_generator passes and the
+    # pass the backward belongs to -- are K + 1 statistics groups sharing their launches (WideResNet.forward_passes)
+    assert K == 8 and calls == [(True, 1), (False, K + 1)]
     mp = tr["max_probs"].cpu().numpy().reshape(K + 1, Bu)
     mi = tr["pseudo"].cpu().numpy().reshape(K + 1, Bu)
     assert all(float(m.sum()) == 0.0 for m in tr["masks"]) and mp.max() < 0.95      # random-init model: nothing reaches 0.95
@@ -373,7 +371,11 @@ def test_full_size_step_properties_wrn():
 
 @pytest.mark.parametrize("B,H,Cin,Cout,ks,stride,mode,resid", [
     (3, 8, 16, 32, 3, 1, 0, False), (2, 8, 32, 32, 3, 1, 0, True), (2, 8, 32, 64, 3, 2, 2, False), (2, 8, 32, 64, 1, 2, 2, False),
-    (4, 4, 128, 128, 3, 1, 0, True), (2, 8, 64, 128, 3, 2, 1, False), (5, 6, 16, 16, 3, 1, 0, True), (64, 32, 32, 32, 3, 1, 0, True)])
+    (4, 4, 128, 128, 3, 1, 0, True), (2, 8, 64, 128, 3, 2, 1, False), (5, 6, 16, 16, 3, 1, 0, True), (64, 32, 32, 32, 3, 1, 0, True),
+    # the layers that take the LDS-tiled kernel (output rows >= 16 pixels): every (Cin, Cout, stride, kernel size, input mode) of WRN-28-2's
+    # 32 x 32 and 16 x 16 stages, with enough images that both block sizes (128 / 256 pixels per workgroup) occur
+    (3, 32, 16, 32, 3, 1, 0, False), (3, 32, 16, 32, 1, 1, 2, False), (5, 32, 32, 64, 3, 2, 0, False), (5, 32, 32, 64, 1, 2, 2, False),
+    (6, 16, 64, 64, 3, 1, 0, True), (6, 16, 64, 64, 3, 1, 1, True), (300, 16, 64, 64, 3, 1, 0, True), (40, 32, 32, 32, 3, 1, 2, False)])
 def test_fused_conv_equals_the_unfused_chain(B, H, Cin, Cout, ks, stride, mode, resid):
     """srhip_wrn_conv_bn (statistics of the input BatchNorm folded from its accumulator, BatchNorm + LeakyReLU on load, implicit GEMM, residual,
     sums of the output into the next accumulator) against the chain it replaces -- srhip_bn_fwd -> srhip_im2col -> srhip_gemm_nt -> srhip_bn_fwd
@@ -462,6 +464,39 @@ def test_fused_conv_equals_the_unfused_chain(B, H, Cin, Cout, ks, stride, mode, 
     act2 = torch.empty_like(act)
     ops.bn_act(x, stats, gam if mode != 2 else None, bet if mode != 2 else None, 1e-5, 0.1, mode, act2, rows_in, Cin)
     assert torch.equal(act2.view(torch.int16), act.view(torch.int16))
+
+
+def test_passes_sharing_their_launches_equal_separate_forwards():
+    """WideResNet.forward_passes (srhip_wrn_conv_bn_passes / srhip_wrn_head_passes: G forwards of one batch, each its own BatchNorm statistics
+    group, one launch per convolution) against G separate forward_features calls under frozen running statistics: logits and features of every
+    pass bit for bit (the statistics are fp64 sums rounded to float: order-independent), the kept activations / statistics of the last pass
+    equal to a saved single forward's, and the backward from them gives the same gradients.  Running statistics do not move."""
+    torch.manual_seed(0)
+    m = wrn.WideResNet(num_classes=10, depth=10, widen_factor=2, first_stride=1, device=DEV)
+    m.init_weights(seed=3)
+    m.refresh_operands()
+    m.train()
+    rng = np.random.Generator(np.random.PCG64(21))
+    x = torch.from_numpy(rng.standard_normal((6, 3, 16, 16)).astype(np.float32)).to(DEV)
+    dl = torch.from_numpy((rng.standard_normal((6, 10)) * 0.1).astype(np.float32)).to(DEV)
+    run0 = {k: v.clone() for k, v in m.buffers.items()}
+    G = 3
+    lg, ft, ctx = m.forward_passes(x, G, tag="ulb")
+    m.zero_grad(); m.backward(ctx, dl); g_group = m.grad.clone()
+    singles = [m.forward_features(x, save=False, update_stats=False, tag="one%d" % i) for i in range(G)]
+    lg1, ft1, ctx1 = m.forward_features(x, save=True, update_stats=False, tag="saved")
+    m.zero_grad(); m.backward(ctx1, dl); g_single = m.grad.clone()
+    torch.cuda.synchronize()
+    assert lg.shape == (G * 6, 10) and ft.shape[0] == G * 6
+    for i, (l1, f1, _) in enumerate(singles):
+        assert torch.equal(lg[i * 6:(i + 1) * 6], l1) and torch.equal(ft[i * 6:(i + 1) * 6], f1), i
+    assert torch.equal(lg[(G - 1) * 6:], lg1) and torch.equal(ctx.feat, ctx1.feat)
+    for a, b in zip(ctx.blocks, ctx1.blocks):
+        assert torch.equal(a["x"], b["x"]) and torch.equal(a["c1"], b["c1"])
+        assert all(torch.equal(u, v) for u, v in zip(a["st1"], b["st1"])) and all(torch.equal(u, v) for u, v in zip(a["st2"], b["st2"]))
+    assert torch.equal(ctx.final["x"], ctx1.final["x"]) and all(torch.equal(u, v) for u, v in zip(ctx.final["st"], ctx1.final["st"]))
+    assert float((g_group - g_single).abs().max()) <= 1e-6 * float(g_single.abs().max())          # (fp32 atomics of the filter gradients: unordered sums)
+    assert all(torch.equal(run0[k], m.buffers[k]) for k in run0)                                    # frozen: no running statistic moved
 
 
 @pytest.mark.parametrize("B,HW2,C,K", [(64, 64, 128, 100), (5, 16, 64, 10), (3, 4, 256, 7), (2, 9, 32, 3)])

@@ -627,7 +627,7 @@ def test_full_size_trace_filter_decisions(golden):
     from oracle.gen_golden import FULL, full_hook_state
     g = golden("srflexmatch_full_trace")
     b = synth.synth_batch(int(g["meta/bseed"]), FULL["Bl"], FULL["Bu"], 32, FULL["C"], FULL["ulb_dest_len"])
-    assert float(g["meta/margin"]) >= 1.3e-2
+    assert float(g["meta/margin"]) >= 1.0          # "slack": every row's room / the deviation expected of a bf16-operand backbone there (gen_golden.run_full_step)
     for it in [int(i) for i in g["meta/its"]]:
         p = f"it{it}"
         K = int(g[f"{p}/K"])
@@ -637,8 +637,8 @@ def test_full_size_trace_filter_decisions(golden):
         st.selected_label[:] = sel0
         st.classwise_acc[:] = acc0
         mp, mi = g[f"{p}/mask_probs"], g[f"{p}/pseudo_label"]
-        margin = np.minimum(np.abs(mp - g[f"{p}/mask_thr"]), np.abs(mp - FULL["p_cutoff"]))
-        assert float(margin.min()) >= float(g["meta/margin"]) - 1e-9
+        room = np.minimum(np.minimum(np.abs(mp - g[f"{p}/mask_thr"]), np.abs(mp - FULL["p_cutoff"])), g[f"{p}/label_gap"])
+        assert float((room / (0.3 * mp * (1.0 - mp) + 2e-3)).min()) >= float(g["meta/margin"]) - 1e-6
         for k in range(K + 1):
             probs = np.zeros((FULL["Bu"], FULL["C"]), np.float32)
             probs[np.arange(FULL["Bu"]), mi[k]] = mp[k]                    # masking only looks at (max, argmax) of each row

@@ -19,7 +19,7 @@ dist.init_process_group(os.environ.get("SR_DIST_BACKEND", "gloo"), rank=rank, wo
 NSt = dict(bench.NS, num_classes=10, ulb_dest_len=256, feature_dim=128, num_train_iter=2000, start_timing=100, num_warmup_iter=0)
 out = {}
 for flag in (True, False):
-    args = argparse.Namespace(gpu=0, rank=rank, world_size=world, distributed=True, infer_chunk=0, global_reward_threshold=flag, **NSt)
+    args = argparse.Namespace(gpu=0, rank=rank, world_size=world, distributed=True, global_reward_threshold=flag, **NSt)
     alg = get_algorithm(args, vit.vit_tiny_test)
     alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
     alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)

@@ -16,7 +16,7 @@ dist.init_process_group(os.environ.get("SR_DIST_BACKEND", "gloo"), rank=rank, wo
 res = []
 for overlap in ("1", "0"):
     os.environ["SR_GRAD_EXCHANGE"] = "overlap" if overlap == "1" else "allreduce"
-    args = argparse.Namespace(gpu=0, rank=rank, world_size=world, distributed=True, infer_chunk=0, **bench.NS)
+    args = argparse.Namespace(gpu=0, rank=rank, world_size=world, distributed=True, **bench.NS)
     alg = get_algorithm(args, vit.vit_small_patch2_32)
     alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
     alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)

@@ -7,7 +7,7 @@ from semireward_amd.algorithms import get_algorithm
 from semireward_amd.nets import vit
 from semireward_amd.utils import synth
 
-args = argparse.Namespace(gpu=0, rank=0, world_size=1, distributed=False, infer_chunk=0, **bench.NS)
+args = argparse.Namespace(gpu=0, rank=0, world_size=1, distributed=False, **bench.NS)
 alg = get_algorithm(args, vit.vit_small_patch2_32)
 alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
 b = synth.synth_batch(100, 8, 8, 32, 100, 50000)
