@@ -47,6 +47,7 @@ struct ConvArgs {
   long in_ps, out_ps;          // floats per pass of xin, of y / resid
   // wrn_conv_tile_kernel: one workgroup = one TH x TW block of output pixels of one image (TH * TW = 64 * PG)
   int TW, TH, IW, IH, tiles_x, tiles_y;
+  int ipw;                     // images per workgroup (> 1 only when a whole image is one TH x TW block: the 8 x 8 stage takes two)
 };
 
 // what a lane requests for one 32-wide k step: its 8 input channels (raw fp32) and NT filter fragments
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The same convolution with the INPUT TILE IN LDS (layers whose output rows are >= 16 pixels wide: 20 of the 28 convolutions of WRN-28-2).
+// The same convolution with the INPUT TILE IN LDS (output rows of >= 16 pixels in 128 / 256-pixel blocks; 8 x 8 outputs one image per workgroup).
 //
 // wrn_conv_kernel above asks L2 for every operand of every k step: per 16-pixel tile and k step NT filter fragments + the pixel's 8 channels
 // of one tap -- 5 loads for 4 MFMAs, the same input value fetched (and normalised) once per tap, nine times in all.  bench.py's roofline
@@ -293,7 +294,9 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_tile_kernel(const ConvArgs a)
   pub_p.update_running = a.pub.update_running && ps == 0;
   // block -> (image, tile row, tile column)
   const int tpi = a.tiles_x * a.tiles_y;
-  const int b = blockIdx.x / tpi, tr = (blockIdx.x - b * tpi) / a.tiles_x, tc = blockIdx.x - b * tpi - tr * a.tiles_x;
+  const int bq = blockIdx.x / tpi, tr = (blockIdx.x - bq * tpi) / a.tiles_x, tc = blockIdx.x - bq * tpi - tr * a.tiles_x;
+  const int b = bq * a.ipw;                                              // first image of the workgroup
+  const int blk_px = a.TH * a.TW, blk_in = a.IH * a.IW;
   const int oy0 = tr * a.TH, ox0 = tc * a.TW;
   const int iy0 = oy0 * a.stride - pad, ix0 = ox0 * a.stride - pad;
   const int PP = a.Cin + 8;                                             // LDS pixel pitch (elements)
@@ -341,8 +344,8 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_tile_kernel(const ConvArgs a)
 
   // ---- the input block: fp32 NHWC -> BatchNorm + LeakyReLU -> bf16 -> LDS (4 channels per thread and step)
   {
-    const int c4n = a.Cin >> 2, total = a.IH * a.IW * c4n;
-    const float* img = xin_p + (size_t)b * a.H * a.W * a.Cin;
+    const int c4n = a.Cin >> 2, total = a.ipw * blk_in * c4n;
+    const float* img0 = xin_p + (size_t)b * a.H * a.W * a.Cin;
     for (int e0 = tid; e0 < total; e0 += 4 * 256) {
       float4 v[4];
       int pix[4], cc[4];
@@ -351,10 +354,11 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_tile_kernel(const ConvArgs a)
       for (int u = 0; u < 4; ++u) {                          // four requests in flight per thread
         const int e = e0 + u * 256;
         pix[u] = e / c4n; cc[u] = (e - pix[u] * c4n) << 2;
-        const int iy = pix[u] / a.IW, ix = pix[u] - iy * a.IW, yy = iy0 + iy, xx = ix0 + ix;
+        const int il = pix[u] / blk_in, pr = pix[u] - il * blk_in;
+        const int iy = pr / a.IW, ix = pr - iy * a.IW, yy = iy0 + iy, xx = ix0 + ix;
         in[u] = e < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
         v[u] = float4{0.f, 0.f, 0.f, 0.f};
-        if (in[u]) v[u] = *reinterpret_cast<const float4*>(img + ((size_t)yy * a.W + xx) * a.Cin + cc[u]);
+        if (in[u]) v[u] = *reinterpret_cast<const float4*>(img0 + ((size_t)(il * a.H + yy) * a.W + xx) * a.Cin + cc[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -384,9 +388,9 @@ __global__ __launch_bounds__(256, 2) void wrn_conv_tile_kernel(const ConvArgs a)
   int n_out[PG];
 #pragma unroll
   for (int gi = 0; gi < PG; ++gi) {
-    const int p = (wave * PG + gi) * 16 + l15, ty = p / a.TW, tx = p - ty * a.TW;
-    pb[gi] = ((ty * a.stride) * a.IW + tx * a.stride) * PP;
-    n_out[gi] = (b * a.Ho + oy0 + ty) * a.Wo + ox0 + tx;
+    const int p = (wave * PG + gi) * 16 + l15, il = p / blk_px, q = p - il * blk_px, ty = q / a.TW, tx = q - ty * a.TW;
+    pb[gi] = (il * blk_in + (ty * a.stride) * a.IW + tx * a.stride) * PP;
+    n_out[gi] = ((b + il) * a.Ho + oy0 + ty) * a.Wo + ox0 + tx;
   }
   f32x4_t acc[PG][NT];
 #pragma unroll
@@ -665,28 +669,35 @@ extern "C" int srhip_wrn_conv_bn_passes(const float* xin, int in_mode, const flo
   hipStream_t s = (hipStream_t)stream;
   // layers with >= 16 output pixels per row and whole 128 / 256-pixel blocks: the input block in LDS (wrn_conv_tile_kernel)
   static const bool no_tile = SR_TUNE_ENV("SRHIP_CONV_NO_TILE") != nullptr;
-  if (!no_tile && a.Wo >= 16 && (a.Wo % 16) == 0 && NT >= 2 && Cin % 4 == 0) {
-    const int TW = (a.Wo % 32) == 0 ? 32 : 16;
+  if (!no_tile && ((a.Wo >= 16 && (a.Wo % 16) == 0) || (a.Wo == 8 && a.Ho == 8)) && NT >= 2 && Cin % 4 == 0) {
+    const int TW = (a.Wo % 32) == 0 ? 32 : (a.Wo == 8 ? 8 : 16);
     // 128 pixels per workgroup (PG = 2); 256 (PG = 4: every filter fragment feeds four MFMAs) when the launch still has >= 4 workgroups per
     // CU and the input block stays within 64 KB (two workgroups per CU)
     auto geom = [&](int PG_) {
-      a.TW = TW; a.TH = 64 * PG_ / TW; a.IW = (TW - 1) * stride + ksize; a.IH = (a.TH - 1) * stride + ksize;
+      a.ipw = a.Wo == 8 ? PG_ : 1;
+      a.TW = TW; a.TH = 64 * PG_ / (TW * a.ipw); a.IW = (TW - 1) * stride + ksize; a.IH = (a.TH - 1) * stride + ksize;
       a.tiles_x = a.Wo / TW; a.tiles_y = a.Ho / a.TH;
-      return (size_t)a.IH * a.IW * (Cin + 8) * sizeof(bf16_t);
+      return (size_t)a.ipw * a.IH * a.IW * (Cin + 8) * sizeof(bf16_t);
     };
     int PG = 4;
     size_t smem = geom(4);
     if ((long)B * passes * a.Ho * a.Wo / 256 * gy < 1024 || a.Ho % a.TH != 0 || smem > 64 * 1024) { PG = 2; smem = geom(2); }
+    if (a.Wo == 8) {                                                 // the 8 x 8 stage: whole images, two per workgroup when the batch is even
+      PG = (B % 2 == 0) ? 2 : 1;
+      smem = geom(PG);
+    }
     if (a.Ho % a.TH == 0) {
       if (smem <= 64 * 1024) {
-        const dim3 grid(B * a.tiles_x * a.tiles_y, gy, passes);
+        const dim3 grid(B / a.ipw * a.tiles_x * a.tiles_y, gy, passes);
 #define SR_TILE_LAUNCH(NT_, PG_)                                                                                           \
         do {                                                                                                              \
           auto kern = wrn_conv_tile_kernel<NT_, PG_>;                                                                     \
           if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
           SR_LAUNCH(kern, grid, dim3(256), smem, s, a);                                                                   \
         } while (0)
-        if (NT == 4 && PG == 4) SR_TILE_LAUNCH(4, 4);
+        if (PG == 1 && NT == 4) SR_TILE_LAUNCH(4, 1);
+        else if (PG == 1) SR_TILE_LAUNCH(2, 1);
+        else if (NT == 4 && PG == 4) SR_TILE_LAUNCH(4, 4);
         else if (NT == 4) SR_TILE_LAUNCH(4, 2);
         else if (PG == 4) SR_TILE_LAUNCH(2, 4);
         else SR_TILE_LAUNCH(2, 2);

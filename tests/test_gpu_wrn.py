@@ -375,7 +375,8 @@ def test_full_size_step_properties_wrn():
     # the layers that take the LDS-tiled kernel (output rows >= 16 pixels): every (Cin, Cout, stride, kernel size, input mode) of WRN-28-2's
     # 32 x 32 and 16 x 16 stages, with enough images that both block sizes (128 / 256 pixels per workgroup) occur
     (3, 32, 16, 32, 3, 1, 0, False), (3, 32, 16, 32, 1, 1, 2, False), (5, 32, 32, 64, 3, 2, 0, False), (5, 32, 32, 64, 1, 2, 2, False),
-    (6, 16, 64, 64, 3, 1, 0, True), (6, 16, 64, 64, 3, 1, 1, True), (300, 16, 64, 64, 3, 1, 0, True), (40, 32, 32, 32, 3, 1, 2, False)])
+    (6, 16, 64, 64, 3, 1, 0, True), (6, 16, 64, 64, 3, 1, 1, True), (300, 16, 64, 64, 3, 1, 0, True), (40, 32, 32, 32, 3, 1, 2, False),
+    (7, 8, 128, 128, 3, 1, 0, True), (8, 8, 128, 128, 3, 1, 0, True), (7, 16, 64, 128, 3, 2, 0, False), (6, 16, 64, 128, 3, 2, 0, False), (7, 16, 64, 128, 1, 2, 2, False)])
 def test_fused_conv_equals_the_unfused_chain(B, H, Cin, Cout, ks, stride, mode, resid):
     """srhip_wrn_conv_bn (statistics of the input BatchNorm folded from its accumulator, BatchNorm + LeakyReLU on load, implicit GEMM, residual,
     sums of the output into the next accumulator) against the chain it replaces -- srhip_bn_fwd -> srhip_im2col -> srhip_gemm_nt -> srhip_bn_fwd

