@@ -38,7 +38,7 @@ NS = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, epoch
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (the 5 PF headline is 2:1 sparse)
 HBM_PEAK_TBS = 8.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 measured with a float4 copy)
 START_IT = 30000                          # it >= 25601 -> sr_decay() == 8 (88 % of the reference run)
-TRAFFIC_JSON = os.path.join("profiles", "r04_hbm_traffic.json")     # PMC passes of this same command (tools/traffic.sh), static
+TRAFFIC_JSON = os.path.join("profiles", "r05_hbm_traffic.json")     # PMC passes of this same command (tools/traffic.sh), static
 
 
 def parse_args(argv=None):
@@ -476,9 +476,11 @@ class Leg:
             # Kept out of the timed regions because 2 x 145 event records per step cost ~0.9 ms of host time.  Every rank runs the pass
             # (the steps contain collectives); rank 0 reports.
             prof = ops.enable_gemm_profile()
+            replay, self.graph = self.graph, None          # (the pass instruments single launches: eager steps, also when the leg replays a graph)
             for _ in range(steps):
                 self.step()
             torch.cuda.synchronize()
+            self.graph = replay
             ops.disable_gemm_profile()
             if self.ctx["rank"] == 0:
                 out["roofline"] = self.roofline(prof, steps)

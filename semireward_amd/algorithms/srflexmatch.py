@@ -287,6 +287,8 @@ class SRConsistencyBase(AlgorithmBase):
                                                      **(dict(out=(logits, feats, pl.grad_cols)) if scatter else {}))
                 grad_done = torch.cuda.Event()
                 grad_done.record(side)
+                if _PHASES:
+                    self._phase_mark("side:grad_rows_forwarded")
             with torch.cuda.stream(side), ops.stream_scope():
                 if nr:
                     # Rows whose outputs nothing reads before the step ends (strong / labelled rows of the passes whose loss the
@@ -300,6 +302,8 @@ class SRConsistencyBase(AlgorithmBase):
                         feats.index_copy_(0, pl.rest_cols, ft_r)
                     self._rest_done = torch.cuda.Event()
                     self._rest_done.record(side)
+                    if _PHASES:
+                        self._phase_mark("side:deferred_rows_done")
             # The gradient rows are joined LATER (_join_grad): masks, pseudo labels and reward scores only read the weak rows of the launch
             # above, so that chain (~0.3 ms of tiny sequential launches) runs while the second stream still works on the gradient rows.
             self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, None if scatter else pl.grad_cols)

@@ -470,7 +470,9 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
 constexpr int GBM = 256;
 // LDS-DMA ring depth of the persistent kernel (stages of (256 + BN) x 32 bf16).  256 x 256: 4 stages = 128 KB.  A fifth stage (the whole 160 KB of
 // a CU's LDS, a third more bytes in flight) was measured neutral on every shape of the legs (profiles/r05_gemm_ring_depth.txt: 13952 x 3072 x 768
-// 748 vs 749 TF/s, 8192^3 1136 vs 1152): the K loop is not waiting for operand arrival at this depth.
+// 748 vs 749 TF/s, 8192^3 1136 vs 1152): the K loop is not waiting for operand arrival at this depth.  Nor for the refill's issue: the two waves
+// of a SIMD taking refill and MFMAs in opposite order (one blocked in its LDS-DMA instructions while the other multiplies) was neutral too
+// (profiles/r05_gemm_stagger.txt).
 #ifndef SRHIP_BIG_NSTG
 #define SRHIP_BIG_NSTG 4
 #endif

@@ -1,7 +1,8 @@
 // Kernel-execution timing of single launches for bench.py's roofline object.  While profiling is on, every launch of the library goes through
-// hipExtLaunchKernel with a (start, stop) event pair bound to THAT dispatch: hipEventElapsedTime of the pair is the dispatch's own begin -> end
-// interval (the completion signal's timestamps), i.e. the quantity `rocprofv3 --kernel-trace --stats` reports per kernel -- no dispatch latency,
-// no event packets, nothing to calibrate away.  (semilearn has no counterpart: it times whole iterations with two CUDA events and a
+// hipExtLaunchKernel with a (start, stop) event pair bound to THAT dispatch: the stop event carries the kernel's own end timestamp, the start
+// event is a marker directly in front of the dispatch, so the pair spans the kernel's execution plus the 3-4 us between marker and first wave
+// (measured against rocprofv3's durations of the same launches in one process: +4 %, profiles/r05_roofline_vs_rocprof.txt).  That is 8 us closer
+// to the kernel than an event pair recorded around the host call, needs no calibration, and errs on the conservative side only.  (semilearn has no counterpart: it times whole iterations with two CUDA events and a
 // synchronisation, semilearn/core/hooks/timer.py.)
 #include <hip/hip_runtime.h>
 

@@ -685,6 +685,7 @@ extern "C" int srhip_wrn_conv_bn_passes(const float* xin, int in_mode, const flo
     if (a.Wo == 8) {                                                 // the 8 x 8 stage: whole images, two per workgroup when the batch is even
       PG = (B % 2 == 0) ? 2 : 1;
       smem = geom(PG);
+      if (smem > 64 * 1024 && PG == 2) { PG = 1; smem = geom(1); }   // (the stride-2 layer into this stage: 17 x 17 input pixels per image)
     }
     if (a.Ho % a.TH == 0) {
       if (smem <= 64 * 1024) {

@@ -1,7 +1,9 @@
 """usage: check_roofline_vs_rocprof.py <bench line json> <rocprofv3 stats txt (tools/prof.sh)> [<durations json (tools/prof.sh)>] [tolerance, default 0.03]
 The roofline object of bench.py times the dominant kernel with start / stop events bound to each dispatch (csrc/prof.hip).  When the bench line and
 the profile come from the SAME process (bench.py run under rocprofv3 with its roofline pass on) the profiler's durations of the same launches -- the
-last ``roofline.launches`` dispatches of that kernel in the process -- must agree with it: that is the check (exit 1 beyond the tolerance).  The
+last ``roofline.launches`` dispatches of that kernel in the process -- must agree with it: that is the check (exit 1 outside [-3 %, +6 %]).
+The live figure may only err HIGH: the start event of hipExtLaunchKernel is a marker in front of the dispatch, so the pair also spans the 3-4 us
+between that marker and the kernel's first wave -- roofline.frac is conservative by that much, never optimistic.  The
 average over ALL launches of the process (the --stats line: tuning steps with other launch sizes included) and, for a line from a separate
 unprofiled run, the profiler's slow-down of the whole step (rocprofv3 serialises part of the two-stream overlap: ~6.2 vs 4.9 ms per step) are
 printed beside it so that nobody compares unlike populations."""
@@ -38,9 +40,10 @@ if durs is not None:
     if len(same) == rf["launches"]:
         avg_same = sum(same) / len(same)
         dev = rf["avg_launch_us"] / avg_same - 1.0
-        print("  rocprofv3, the SAME %d launches (the last ones of the process): %.2f us per launch -> frac %.4f; live measurement deviates by %+.2f %% (tolerance %.0f %%)"
-              % (len(same), avg_same, work / (avg_same * 1e-6) / unit / rf["peak"], 100 * dev, 100 * tol))
-        ok = ok and abs(dev) <= tol
+        print("  rocprofv3, the SAME %d launches (the last ones of the process): %.2f us per launch -> frac %.4f; live measurement deviates by %+.2f %% "
+              "(accepted: -%.0f %% .. +%.0f %%; the live pair includes the dispatch gap in front of the kernel)"
+              % (len(same), avg_same, work / (avg_same * 1e-6) / unit / rf["peak"], 100 * dev, 100 * tol, 200 * tol))
+        ok = ok and -tol <= dev <= 2 * tol
     else:
         print("  (durations file has %d launches of the kernel, the roofline pass %d: not the same process?)" % (len(same), rf["launches"]))
         ok = False

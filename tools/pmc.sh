@@ -2,6 +2,7 @@
 # usage: tools/pmc.sh <tag> "<counters>" <python args...>   -> gpurun_out/<tag>.pmc.txt (per-kernel averages)
 tag=$1; shift; ctr=$1; shift
 cd /tmp && export TMPDIR=/tmp
+export SR_HIP_GRAPH=0          # eager launches, as in the driver's run (see tools/prof.sh)
 rocprofv3 --pmc $ctr -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o r -- python "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
 python - <<PY
 import sqlite3,glob,collections

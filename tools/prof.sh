@@ -2,6 +2,8 @@
 # usage: tools_prof.sh <tag> [bench args]   (runs on the GPU box; writes gpurun_out/<tag>.stats.txt)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
+# (the profiler multiplies the host's enqueue time: SR_HIP_GRAPH=auto would switch the step to graph replay under it; profile the eager launches the driver's run makes)
+export SR_HIP_GRAPH=0
 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o r -- python $GRAFT_REPO_ROOT/bench.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
 python - <<PY
 import sqlite3,glob

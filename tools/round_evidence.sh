@@ -7,6 +7,9 @@
 #   <tag>_pmc{1,2}.pmc.txt           SQ counters of the headline (tools/pmc.sh)
 tag=$1
 cd $GRAFT_REPO_ROOT
+# HBM traffic first: the bench line reads profiles/<tag>_hbm_traffic.json (static, labelled as such) for roofline.traffic
+bash tools/traffic.sh ${tag} --no-also --repeats 1
+cp gpurun_out/${tag}_hbm_traffic.json profiles/${tag}_hbm_traffic.json
 python bench.py 2> gpurun_out/${tag}_bench_full.err | tail -1 > gpurun_out/${tag}_bench_full.json
 Q="--steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/prof.sh ${tag}_headline $Q; grep -h "^{\"metric\"" gpurun_out/${tag}_headline.log > gpurun_out/${tag}_headline_bench_under_rocprof.json
@@ -24,7 +27,6 @@ bash tools/prof.sh ${tag}_pre $Q --regime pre; grep -h "^{\"metric\"" gpurun_out
 bash tools/prof.sh ${tag}_wrn $Q --net wrn --bu 64 --steps 8 --warmup 3; grep -h "^{\"metric\"" gpurun_out/${tag}_wrn.log > gpurun_out/${tag}_wrn_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_bert $Q --net bert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_bert.log > gpurun_out/${tag}_bert_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_hubert $Q --net hubert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_hubert.log > gpurun_out/${tag}_hubert_bench_under_rocprof.json
-bash tools/traffic.sh ${tag} --no-also --repeats 1
 P="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/pmc.sh ${tag}_pmc1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE" $P
 bash tools/pmc.sh ${tag}_pmc2 "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" $P

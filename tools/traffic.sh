@@ -4,6 +4,7 @@
 # FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), FETCH_SIZE doubled on gfx950, WRITE_SIZE as reported.
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
+export SR_HIP_GRAPH=0          # eager launches, as in the driver's run (see tools/prof.sh)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_$c -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/${tag}_$c.log 2>&1
 done
