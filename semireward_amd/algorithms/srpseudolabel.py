@@ -72,14 +72,20 @@ class SRPseudoLabel(SRConsistencyBase):
             # The K + 1 forwards of x_ulb_w (K data_generator passes + the one whose loss is kept) are K + 1 statistics groups over the same
             # batch: they share ONE launch per convolution (WideResNet.forward_passes; 28 launches instead of 28 (K + 1), each large enough
             # to amortise its statistics prologue / epilogue); every pass is computed, the last one keeps its activations for the backward.
-            lg_lb, ft_lb, ctx_lb = self.model.forward_saved(x_lb.contiguous(), update_stats=True, tag="lb")
-            if _SHARE_PASS_LAUNCHES:
-                lg_u, ft_u, ctx_u = self.model.forward_passes(x_ulb_w.contiguous(), P, tag="ulb")
-            else:                # one launch train per pass (the comparison the tests / A-B runs flip to)
-                outs = [self.model.forward_frozen(x_ulb_w.contiguous(), tag="ulb_inf") for _ in range(K)]
-                lg_k, ft_k, ctx_u = self.model.forward_saved(x_ulb_w.contiguous(), update_stats=False, tag="ulb")
-                lg_u, ft_u = torch.cat([o[0] for o in outs] + [lg_k]), torch.cat([o[1] for o in outs] + [ft_k])
-            logits, feats, ctx = torch.cat((lg_lb, lg_u)), torch.cat((ft_lb, ft_u)), (ctx_lb, ctx_u)
+            xl, xu = x_lb.contiguous(), x_ulb_w.contiguous()
+            if _SHARE_PASS_LAUNCHES and tuple(xl.shape) == tuple(xu.shape):
+                # ... and model(x_lb) (:96, the call that moves the running statistics) rides along as statistics group 0 when the two
+                # batches have one shape (uratio 1, every classic_cv SR setting)
+                logits, feats, ctx = self.model.forward_passes(xu, P, tag="ulb", first_img=xl)
+            else:
+                lg_lb, ft_lb, ctx_lb = self.model.forward_saved(xl, update_stats=True, tag="lb")
+                if _SHARE_PASS_LAUNCHES:
+                    lg_u, ft_u, ctx_u = self.model.forward_passes(xu, P, tag="ulb")
+                else:            # one launch train per pass (the comparison the tests / A-B runs flip to)
+                    outs = [self.model.forward_frozen(xu, tag="ulb_inf") for _ in range(K)]
+                    lg_k, ft_k, ctx_u = self.model.forward_saved(xu, update_stats=False, tag="ulb")
+                    lg_u, ft_u = torch.cat([o[0] for o in outs] + [lg_k]), torch.cat([o[1] for o in outs] + [ft_k])
+                logits, feats, ctx = torch.cat((lg_lb, lg_u)), torch.cat((ft_lb, ft_u)), (ctx_lb, ctx_u)
         else:
             logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
             self._join_grad()

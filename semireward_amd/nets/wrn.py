@@ -321,7 +321,7 @@ class WideResNet(ModuleSurface):
             self._sync_acc(next_bn, accs)
         return st
 
-    def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None, passes=1):
+    def forward_features(self, img, img_index=None, droppath=None, save=False, update_stats=True, tag=None, B=None, passes=1, first_img=None):
         """img fp32 [B,3,H,W] (NCHW as the loaders deliver it).  Returns (logits [B,C], feat [B,F], ctx or None).
         ``update_stats=False`` = forward under Bn_Controller.freeze_bn.  ``tag`` names the activation buffer set (two saved graphs of
         a step must not share buffers).
@@ -330,7 +330,9 @@ class WideResNet(ModuleSurface):
         ``passes`` = G > 1: G forwards of the SAME batch under frozen running statistics share every launch behind the stem (pass-major
         activations [G * rows, C]; each pass is its own BatchNorm statistics group, as G separate model() calls are in the reference:
         srpseudolabel.py:59-90 forwards x_ulb_w K + 1 times per step).  Returns logits [G * B, C], feat [G * B, F] in pass order;
-        ``save`` keeps the LAST pass for a backward."""
+        ``save`` keeps the LAST pass for a backward.  ``first_img`` (same shape as img): pass 0 forwards THAT batch instead -- the labelled
+        batch of the step, the one model() call that moves the running statistics (``update_stats`` then applies to pass 0 alone, which is
+        what the kernels implement) -- and ``save`` keeps it as well: ctx = (ctx of pass 0, ctx of the last pass)."""
         assert img_index is None and droppath is None, "WideResNet has no DropPath and takes whole batches (BatchNorm couples the rows)"
         B, _, H, W = img.shape
         G = int(passes)
@@ -338,19 +340,27 @@ class WideResNet(ModuleSurface):
         train = self.training
         upd = bool(train and update_stats)
         assert train or not save, "the backward needs a training-mode forward (batch statistics)"
-        assert G == 1 or (train and not upd), "passes > 1: batch statistics per pass, running statistics frozen (Bn_Controller.freeze_bn)"
+        assert G == 1 or (train and (not upd or first_img is not None)), \
+            "passes > 1: batch statistics per pass; only a first_img pass may move the running statistics (the others run under Bn_Controller.freeze_bn)"
+        assert first_img is None or (G > 1 and tuple(first_img.shape) == tuple(img.shape))
         f32 = torch.float32
         last = (lambda t, rows: t) if G == 1 else (lambda t, rows: t[(G - 1) * rows:])      # the pass a save=True forward keeps
         a0 = self._buf((tag, "in"), (B, H, W, 3), torch.bfloat16)
         out = self._buf((tag, "stem.out"), (G * B * H * W, self.channels[0]), f32)
-        col0 = None
+        col0 = colf = None
         for g_ in range(G):                                   # the stem convolution of every pass (layout + im2col + GEMM: three small launches)
-            ops.nchw_to_nhwc_bf16(img.contiguous(), a0, B, 3, H, W)
-            col0, _, _ = self._conv("conv1.weight", a0, B, H, W, 1, out[g_ * B * H * W:(g_ + 1) * B * H * W], tag, bias=self.p("conv1.bias"))
-        ctx = None
+            src, stag = (first_img, tag + ":first") if (g_ == 0 and first_img is not None) else (img, tag)      # (pass 0's col is a backward operand of its own)
+            ops.nchw_to_nhwc_bf16(src.contiguous(), a0, B, 3, H, W)
+            col0, _, _ = self._conv("conv1.weight", a0, B, H, W, 1, out[g_ * B * H * W:(g_ + 1) * B * H * W], stag, bias=self.p("conv1.bias"))
+            if g_ == 0:
+                colf = col0
+        ctx = ctx_f = None
         if save:
             ctx = WrnContext()
             ctx.B, ctx.H, ctx.W, ctx.tag, ctx.stem, ctx.blocks = B, H, W, tag, dict(col=col0), []
+            if first_img is not None:
+                ctx_f = WrnContext()
+                ctx_f.B, ctx_f.H, ctx_f.W, ctx_f.tag, ctx_f.stem, ctx_f.blocks = B, H, W, tag + ":first", dict(col=colf), []
         h, w = H, W
         accs = None
         if train:
@@ -390,6 +400,9 @@ class WideResNet(ModuleSurface):
             if save:
                 pick = (lambda st: st) if G == 1 else (lambda st: (st[0][G - 1], st[1][G - 1]))
                 ctx.blocks.append(dict(x=last(out, B * h * w), st1=pick(st1), c1=last(c1, rows_out), st2=pick(st2), raw=raw, h=h, w=w, ho=ho, wo=wo))
+                if ctx_f is not None:
+                    ctx_f.blocks.append(dict(x=out[:B * h * w], st1=(st1[0][0], st1[1][0]), c1=c1[:rows_out], st2=(st2[0][0], st2[1][0]), raw=raw,
+                                             h=h, w=w, ho=ho, wo=wo))
             out, h, w = y, ho, wo
         rows = B * h * w
         C3 = self.channels[3]
@@ -402,6 +415,7 @@ class WideResNet(ModuleSurface):
             ops.wrn_head(out, 3, None, accs["bn1"], self.p("bn1.weight"), self.p("bn1.bias"), self.eps["bn1"], SLOPE,
                          self.p("classifier.weight"), self.p("classifier.bias"), feat, logits, B, h * w, C3, self.num_classes, publish=stf,
                          running=run, momentum=MOMENTUM, update_running=upd, stat_ranks=self.stat_ranks, passes=G)
+            stf_first = (stf[0][0], stf[1][0]) if G > 1 else None
             if G > 1:
                 stf = (stf[0][G - 1], stf[1][G - 1])
             if upd:
@@ -412,6 +426,9 @@ class WideResNet(ModuleSurface):
                          self.p("classifier.bias"), feat, logits, B, h * w, C3, self.num_classes)
         if save:
             ctx.final, ctx.feat = dict(x=last(out, rows), st=stf, h=h, w=w), feat[(G - 1) * B:]
+            if ctx_f is not None:
+                ctx_f.final, ctx_f.feat = dict(x=out[:rows], st=stf_first, h=h, w=w), feat[:B]
+                return logits, feat, (ctx_f, ctx)
         return logits, feat, ctx
 
     # ---- the two kinds of pass of an SRPseudoLabel step (srpseudolabel.py:59-90) ---------------------------------------------------------------
@@ -424,9 +441,13 @@ class WideResNet(ModuleSurface):
         """forward_features(img, save=True, ...) -> (logits, feat, ctx) for a later backward(ctx, .)."""
         return self.forward_features(img, save=True, update_stats=update_stats, tag=tag)
 
-    def forward_passes(self, img, passes, tag="ulb"):
+    def forward_passes(self, img, passes, tag="ulb", first_img=None):
         """The K + 1 forwards of one batch under frozen running statistics (data_generator's K passes + the pass the unsupervised loss
-        back-propagates through, srpseudolabel.py:59-90, :104-110) with shared launches: (logits [passes * B, C], feat, ctx of the LAST pass)."""
+        back-propagates through, srpseudolabel.py:59-90, :104-110) with shared launches: (logits [passes * B, C], feat, ctx of the LAST pass).
+        ``first_img``: the labelled batch's forward (the call that moves the running statistics, :96) rides in the same launches as pass 0 of
+        passes + 1: (logits [(passes + 1) * B, C], feat, (ctx of the labelled pass, ctx of the last pass))."""
+        if first_img is not None:
+            return self.forward_features(img, save=True, update_stats=True, tag=tag, passes=passes + 1, first_img=first_img)
         return self.forward_features(img, save=True, update_stats=False, tag=tag, passes=passes)
 
     def forward(self, x, only_fc=False, only_feat=False, **kw):

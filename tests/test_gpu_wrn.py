@@ -317,9 +317,9 @@ def test_full_size_step_properties_wrn():
         return alg, out, log, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in alg.trace.items()}, calls
     alg, out, log, tr, calls = run(0.95)
     K = tr["K"]
-    # model(x_lb) moves the statistics; the K + 1 forwards of model(x_ulb_w) under frozen running statistics -- K data_generator passes and the
-    # pass the backward belongs to -- are K + 1 statistics groups sharing their launches (WideResNet.forward_passes)
-    assert K == 8 and calls == [(True, 1), (False, K + 1)]
+    # model(x_lb) (moves the running statistics) and the K + 1 forwards of model(x_ulb_w) under frozen running statistics -- K data_generator
+    # passes and the pass the backward belongs to -- are K + 2 statistics groups sharing their launches (WideResNet.forward_passes)
+    assert K == 8 and calls == [(True, K + 2)]
     mp = tr["max_probs"].cpu().numpy().reshape(K + 1, Bu)
     mi = tr["pseudo"].cpu().numpy().reshape(K + 1, Bu)
     assert all(float(m.sum()) == 0.0 for m in tr["masks"]) and mp.max() < 0.95      # random-init model: nothing reaches 0.95
@@ -498,6 +498,21 @@ def test_passes_sharing_their_launches_equal_separate_forwards():
     assert torch.equal(ctx.final["x"], ctx1.final["x"]) and all(torch.equal(u, v) for u, v in zip(ctx.final["st"], ctx1.final["st"]))
     assert float((g_group - g_single).abs().max()) <= 1e-6 * float(g_single.abs().max())          # (fp32 atomics of the filter gradients: unordered sums)
     assert all(torch.equal(run0[k], m.buffers[k]) for k in run0)                                    # frozen: no running statistic moved
+    # ... with the labelled batch as pass 0 (the one call that moves the running statistics): == forward_saved(x_lb, update_stats=True) followed
+    # by the frozen passes, running statistics and num_batches_tracked included
+    xl = torch.from_numpy(rng.standard_normal((6, 3, 16, 16)).astype(np.float32)).to(DEV)
+    import copy
+    m2 = wrn.WideResNet(num_classes=10, depth=10, widen_factor=2, first_stride=1, device=DEV)
+    m2.load_state_dict(m.state_dict()); m2.train()
+    lga, fta, (cf, cl) = m.forward_passes(x, G, tag="ulb", first_img=xl)
+    m.zero_grad(); m.backward(cf, dl); m.backward(cl, dl); ga = m.grad.clone()
+    lgl, ftl, cl2 = m2.forward_features(xl, save=True, update_stats=True, tag="lb")
+    lgu, ftu, cu2 = m2.forward_passes(x, G, tag="ulb")
+    m2.zero_grad(); m2.backward(cl2, dl); m2.backward(cu2, dl); gb = m2.grad.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(lga, torch.cat((lgl, lgu))) and torch.equal(fta, torch.cat((ftl, ftu)))
+    assert all(torch.equal(m.buffers[k], m2.buffers[k]) for k in m.buffers) and not all(torch.equal(run0[k], m.buffers[k]) for k in run0)
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
 
 
 @pytest.mark.parametrize("B,HW2,C,K", [(64, 64, 128, 100), (5, 16, 64, 10), (3, 4, 256, 7), (2, 9, 32, 3)])
