@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "srhip.h"
 
@@ -170,8 +173,10 @@ __device__ __forceinline__ void store_quad_pair(bf16_t* C, int ldc, int m, bool 
 #ifdef SRHIP_TUNING
 __device__ long long srhip_gemm_dbg[4 * 8192];
 #define GDBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) srhip_gemm_dbg[4 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#define PDBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) srhip_gemm_dbg[16 * blockIdx.x + (i)] = wall_clock64(); } while (0)
 #else
 #define GDBG_T(i) do { } while (0)
+#define PDBG_T(i) do { } while (0)
 #endif
 // One 128x128 output tile, K-tiles [kt0, kt1).  smem: NS * STAGE elements (the kernel's ONE __shared__ object: a second
 // one makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline).
@@ -638,6 +643,296 @@ static void launch_big_t(const GemmArgs& g, int grid_cap, hipStream_t s) {
   SR_LAUNCH(kern, dim3(min(tiles, grid_cap)), dim3(256 * WN), sm, s, g);
 }
 
+// =================================================================================================
+// 256 x 256 x 64 kernel, two wave groups half a phase apart (K % 64 == 0; operands < 2 GiB so that buffer addressing reaches them).
+//
+// The persistent kernel above runs all eight waves in lockstep: barrier, refill, 12 fragment reads, 32 MFMAs -- both waves of a SIMD read
+// together and multiply together, and the matrix pipe idles through every read phase (1070-1130 TF/s at 8192^3 against the vendor library's
+// 1510-1600).  Here the waves are 2 (m) x 4 (n) with a 128 x 64 wave tile, and the row groups wr = 0 / 1 -- one wave of each on every SIMD --
+// alternate: between two consecutive workgroup barriers one group issues its fragment reads and LDS-DMA refills while the other runs 16 MFMAs
+// (one 64 x 32 quadrant of its tile over a 64-deep K-tile), then they swap.  A K-tile is four such phases per group:
+//     p0: read A0 (8 fragments) + B0 (4)   q(0,0)        p1: read B1 (4)   q(0,1)        p2: read A1 (8)   q(1,1)        p3: --   q(1,0) (B0 kept)
+// LDS: a ring of NSLOT 16-KiB half-tiles [128 rows][64 k] (A0 / A1 = the rows every wave multiplies in its upper / lower quadrants, B0 / B1
+// likewise for columns), refilled one per phase in the fixed order  q = 4 s + {A0, B0, B1, A1}  of K-tile s, slot q % NSLOT.  Phase k = 4 s + p
+// issues q = k + NSLOT - 2: its slot held q - NSLOT = k - 2, last read in phase k - 2 or k - 3 -- two phases back at least, the write-after-read
+// distance two staggered groups need -- and then waits until at most NSLOT - 4 half-tiles are in flight, i.e. q <= k + 2 has landed: what phase
+// k + 1 reads, one barrier later.  The walk over output tiles is persistent: the refill cursor runs across tile boundaries, so the first
+// K-tiles of the next output tile land during the epilogue.
+// Stores count in vmcnt like loads, so a counted wait behind an epilogue would drain the stores: every output tile ends with vmcnt(0) BEFORE its
+// stores (the half-tiles ahead have had a phase or more to land) and the first NSLOT - 4 phases of the next tile wait for nothing.
+// Both groups take their epilogue between the same two barriers (the stagger is closed at the end of a tile and reopened at the start of the
+// next: one extra barrier each), otherwise each group's stores would hold the other one at a barrier in turn.
+// 16-byte chunks of a 128-byte LDS row are permuted by (row >> 1) & 7 (on the source address, LDS-DMA writes lane-linear): the 16 lanes of a
+// ds_read_b128 service group (8 rows at chunk c, 8 at c ^ 1) then fall on 16 distinct 16-byte bank groups.
+constexpr int PBK = 64;
+constexpr int PH_EL = 128 * PBK;          // one half-tile
+
+template <int EPI, int NSLOT>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g) {
+  constexpr int LEAD = NSLOT - 2;         // phase k issues half-tile k + LEAD
+  constexpr int INFL = 2 * (LEAD - 2);    // LDS-DMA instructions that may stay in flight behind a phase's wait
+  static_assert(NSLOT == 8 || NSLOT == 10, "ring");
+  extern __shared__ __attribute__((aligned(16))) bf16_t psm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int ntn = (g.N + 255) / 256, ntm = (g.M + 255) / 256, ntiles = ntm * ntn;
+  const int nk = g.K / PBK;
+  const int first = xcd_remap(blockIdx.x, gridDim.x);
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
+
+  // ---- producer: a wave-instruction moves one 1-KiB piece = 8 rows x 128 B; every wave owns pieces wave and wave + 8 of each half-tile
+  const int prho = wave * 8 + (lane >> 3);                      // row of the lane inside the half-tile (piece 1: + 64)
+  const int pch = ((lane & 7) ^ ((prho >> 1) & 7)) * 8;         // logical chunk the lane's physical slot holds
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, (int)(((size_t)(g.M - 1) * g.lda + g.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.B), 0, (int)(((size_t)(g.N - 1) * g.ldb + g.K) * 2), 0x00020000);
+  constexpr int OOB = 0x7ffffff0;                               // past num_records: the load moves nothing and still counts in vmcnt
+  // refill cursor: K-tile (c_tile, c_kt) whose half-tiles are being issued, byte offsets of the lane's two pieces per kind, next ring slot
+  int c_tile = first, c_kt = 0, c_slot = 0;
+  int va[2][2], vb[2][2];                                       // [half][piece]
+  auto set_cur = [&]() {
+    if (c_tile >= ntiles) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { va[i >> 1][i & 1] = OOB; vb[i >> 1][i & 1] = OOB; }
+      return;
+    }
+    int tm_, tn_;
+    tile_mn(c_tile, ntm, ntn, tm_, tn_);
+    const int m0 = tm_ * 256, n0 = tn_ * 256;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        va[h][i] = (min(m0 + i * 128 + h * 64 + prho, g.M - 1) * g.lda + pch) * 2;
+        vb[h][i] = (min(n0 + ((prho >> 5) + 2 * i) * 64 + h * 32 + (prho & 31), g.N - 1) * g.ldb + pch) * 2;
+      }
+  };
+  auto issue = [&](auto kc) __attribute__((always_inline)) {      // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+    constexpr int kind = decltype(kc)::value;
+    bf16_t* dst = psm + c_slot * PH_EL + wave * 512;
+    const int ko = c_kt * (PBK * 2);
+    const int (&vo)[2] = kind == 0 ? va[0] : (kind == 3 ? va[1] : (kind == 1 ? vb[0] : vb[1]));
+    const __amdgpu_buffer_rsrc_t& rs = (kind == 0 || kind == 3) ? rsa : rsb;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo[0], ko, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + 8 * 512), 16, vo[1], ko, 0, 0);
+    c_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
+    if constexpr (kind == 3) {
+      if (++c_kt == nk) { c_kt = 0; c_tile += gridDim.x; set_cur(); }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  set_cur();
+  issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
+  issue(I0{}); issue(I1{});
+  if constexpr (LEAD == 8) { issue(I2{}); issue(I3{}); }
+
+  // ---- consumer fragment offsets (elements) inside a half-tile: row l15 of a 16-row tile, k-step ks
+  int foA[2], foB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((4 * ks + lg) ^ (l15 >> 1)) << 3;
+    foA[ks] = (wr * 64 + l15) * PBK + ch;
+    foB[ks] = (wc * 32 + l15) * PBK + ch;
+  }
+  f32x4_t acc[4][8];                     // [column tile nt][row tile mt] of the wave's 128 x 64
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  s16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+
+  auto rd = [&](const bf16_t* p) __attribute__((always_inline)) { return *reinterpret_cast<const s16x8_t*>(p); };
+  // 16 MFMAs of quadrant (h, j): acc[2 j + nt][4 h + mt] += B fragment (nt, ks) x A fragment (mt, ks)
+  auto quadrant = [&](auto hc, auto jc, s16x8_t (&fb)[2][2]) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value, j = decltype(jc)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[2 * j + nt][4 * h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb[nt][ks]), __builtin_bit_cast(bf16x8_t, fa[mt][ks]),
+                                                                                acc[2 * j + nt][4 * h + mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define PP_SYNC(wait_)                                                   \
+  if (wait_) wait_vm<INFL>();                                            \
+  __builtin_amdgcn_s_barrier();                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+  __builtin_amdgcn_sched_barrier(0);
+#define PP_END()                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                     \
+  __builtin_amdgcn_s_barrier();                                          \
+  __builtin_amdgcn_sched_barrier(0);
+  int r_base = 0;                        // ring slot of A0 of the K-tile being multiplied
+  // kt = K-tile inside the output tile: phases 4 kt + p < LEAD - 2 follow the vmcnt(0) of the previous epilogue (or of the prologue)
+  auto ktile = [&](int kt) __attribute__((always_inline)) {
+    const bool w01 = 4 * kt >= LEAD - 2 - 1, w23 = 4 * kt + 2 >= LEAD - 2;          // LEAD 6: kt >= 1 both; LEAD 8: p0/p1 kt >= 2, p2/p3 kt >= 1
+    const bool w0 = 4 * kt >= LEAD - 2, w1 = 4 * kt + 1 >= LEAD - 2, w2 = w23, w3 = 4 * kt + 3 >= LEAD - 2;
+    (void)w01;
+    int sl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int v = r_base + c; sl[c] = (NSLOT == 8 || v < NSLOT ? v : v - NSLOT) * PH_EL; }
+    // ---- p0
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb0[nt][ks] = rd(psm + sl[1] + foB[ks] + nt * 16 * PBK);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rd(psm + sl[0] + foA[ks] + mt * 16 * PBK);
+    issue(std::integral_constant<int, (LEAD + 0) & 3>{});
+    PP_SYNC(w0)
+    quadrant(I0{}, I0{}, fb0);
+    PP_END()
+    // ---- p1
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb1[nt][ks] = rd(psm + sl[2] + foB[ks] + nt * 16 * PBK);
+    issue(std::integral_constant<int, (LEAD + 1) & 3>{});
+    PP_SYNC(w1)
+    quadrant(I0{}, I1{}, fb1);
+    PP_END()
+    // ---- p2
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rd(psm + sl[3] + foA[ks] + mt * 16 * PBK);
+    issue(std::integral_constant<int, (LEAD + 2) & 3>{});
+    PP_SYNC(w2)
+    quadrant(I1{}, I1{}, fb1);
+    PP_END()
+    // ---- p3
+    issue(std::integral_constant<int, (LEAD + 3) & 3>{});
+    PP_SYNC(w3)
+    quadrant(I1{}, I0{}, fb0);
+    PP_END()
+    r_base = r_base + 4 >= NSLOT ? r_base + 4 - NSLOT : r_base + 4;
+  };
+
+  PDBG_T(12);
+  WAIT_VM(0);
+  __builtin_amdgcn_s_barrier();
+  PDBG_T(13);
+  int ct = first;
+  constexpr bool BF16_OUT = EPI == SRHIP_EPI_BF16 || EPI == SRHIP_EPI_GELU_BF16 || EPI == SRHIP_EPI_DGELU_BF16;
+  for (int t = 0; t < my_tiles; ++t, ct += gridDim.x) {
+    PDBG_T(min(t, 1) * 6 + 0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // the lower row group runs one barrier behind
+    for (int kt = 0; kt < nk; ++kt) ktile(kt);
+    PDBG_T(min(t, 1) * 6 + 1);
+    // ---- epilogue: lane holds C[m][n .. n + 3], m = row l15 of row tile mt, n = 4 lg of column tile nt
+    int tm_, tn_;
+    tile_mn(ct, ntm, ntn, tm_, tn_);
+    const int m0 = tm_ * 256 + wr * 128, n0 = tn_ * 256 + wc * 64;
+    // what the epilogue reads first is requested ahead of the closing barrier and the vmcnt(0): the fragment registers are free by now
+    f32x4_t bq[4];
+    if (g.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bq[i] = *reinterpret_cast<const f32x4_t*>(g.bias + min(n0 + i * 16 + lg * 4, g.N - 4));
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    WAIT_VM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    PDBG_T(min(t, 1) * 6 + 2);
+    if (BF16_OUT && g.wide_store && tn_ * 256 + 256 <= g.N) {
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int mr = m0 + mt * 16 + l15, m = min(mr, g.M - 1);
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+          u32x2_t q[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = 2 * np + e;
+            float v[4] = {acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]};
+            acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            q[e] = epi_quad_bf16<EPI>(g, m, n0 + i * 16 + lg * 4, v, mr < g.M, &bq[i]);
+          }
+          store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + np * 32, lg, q[0], q[1]);
+        }
+      }
+    } else if (EPI == SRHIP_EPI_RESID_F32) {
+      // x += rs * (acc + bias): the 16 residual quads of four row tiles are requested together (in place C is read and written through the same
+      // pointer, so left to itself every load waits for the store before it) -- two exposed round trips per tile instead of 32
+      const float* src = g.aux_in ? reinterpret_cast<const float*>(g.aux_in) : reinterpret_cast<const float*>(g.C);
+      const int lds_ = g.aux_in ? g.ldaux : g.ldc;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4_t res[4][4];
+#pragma unroll
+        for (int mq = 0; mq < 4; ++mq) {
+          const int m = min(m0 + (4 * hh + mq) * 16 + l15, g.M - 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) res[mq][i] = *reinterpret_cast<const f32x4_t*>(src + (size_t)m * lds_ + min(n0 + i * 16 + lg * 4, g.N - 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mq = 0; mq < 4; ++mq) {
+          const int mt = 4 * hh + mq, m = m0 + mt * 16 + l15;
+          float rs = 1.0f;
+          if (g.row_scale && m < g.M) rs = g.row_scale[m / g.rows_per_sample];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int n = n0 + i * 16 + lg * 4;
+            float v[4] = {acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]};
+            acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (g.bias) { v[0] += bq[i][0]; v[1] += bq[i][1]; v[2] += bq[i][2]; v[3] += bq[i][3]; }
+            if (g.drop_thresh) {
+              const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+            }
+            f32x4_t x = res[mq][i];
+            x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
+            if (m < g.M && n < g.N) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = x;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + mt * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = n0 + i * 16 + lg * 4;
+          float v[4] = {acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]};
+          acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (m < g.M && n < g.N) epi_store<EPI>(g, m, n, v, 1.0f, false);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PDBG_T(min(t, 1) * 6 + 3);
+  }
+#undef PP_SYNC
+#undef PP_END
+}
+
+template <int EPI, int NSLOT>
+static void launch_pp_t(const GemmArgs& g, hipStream_t s) {
+  constexpr size_t sm = (size_t)NSLOT * PH_EL * sizeof(bf16_t);
+  const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
+  auto kern = gemm_pp_kernel<EPI, NSLOT>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  SR_LAUNCH(kern, dim3(min(tiles, 256)), dim3(512), sm, s, g);
+}
+template <int EPI>
+static void launch_pp(const GemmArgs& g, hipStream_t s) {
+  static const char* mode = getenv("SRHIP_GEMM");
+  if (mode && !strcmp(mode, "big256r8")) launch_pp_t<EPI, 8>(g, s); else launch_pp_t<EPI, 10>(g, s);
+}
+
 // variant: 0 = 256x256 / 8 waves / 1 WG per CU, 1 = 256x128 / 8 waves, 2 = 256x128 / 4 waves / 2 WGs per CU
 template <int EPI>
 static void launch_big(const GemmArgs& g, int variant, hipStream_t s) {
@@ -675,10 +970,11 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   // at N = 768 (tools/gemm_modes_probe.py, standalone TF/s default -> this rule: BERT qkv 13952 x 2304 x 768 664 -> 800, fc1 615 -> 735, fc2 13952 x
   // 768 x 3072 630 -> 680, Wav2Vec2 fc1 5373 x 3072 x 768 617 -> 775); the 3-round threshold above is for the epilogue-heavy K = 384 products
   const bool big_k = K >= 768;
-  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || (mode && mode[0] == 'b');
+  const bool force_big = mode && mode[0] == 'b' && strcmp(mode, "bigold") != 0;        // "bigold": the lockstep kernel where the plan says 256 x 256, nothing forced
+  const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || force_big;
   const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
   const double min_rounds = (big_k && !SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
-  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || (mode && mode[0] == 'b'))) {
+  if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || force_big)) {
     if (mode && !strcmp(mode, "big128")) return SRHIP_GEMM_PLAN_BIG128;
     if (mode && !strcmp(mode, "big2wg")) return SRHIP_GEMM_PLAN_BIG2WG;
     return SRHIP_GEMM_PLAN_BIG256;
@@ -740,6 +1036,21 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   const dim3 grid3(grid, splits);
   if (plan == SRHIP_GEMM_PLAN_BIG256 || plan == SRHIP_GEMM_PLAN_BIG128 || plan == SRHIP_GEMM_PLAN_BIG2WG) {
     const int variant = plan == SRHIP_GEMM_PLAN_BIG256 ? 0 : (plan == SRHIP_GEMM_PLAN_BIG128 ? 1 : 2);
+    // 256 x 256 tiles: the two-wave-group kernel whenever its K-tile pairs and 31-bit buffer offsets fit (SRHIP_GEMM=bigold pins the lockstep one)
+    static const char* mode = getenv("SRHIP_GEMM");
+    const bool pp_ok = (K % PBK) == 0 && ((size_t)(M - 1) * lda + K) * 2 < (1ull << 31) && ((size_t)(N - 1) * ldb + K) * 2 < (1ull << 31) &&
+                       !(mode && !strncmp(mode, "bigold", 6));
+    if (variant == 0 && pp_ok) {
+      switch (epilogue) {
+        case SRHIP_EPI_BF16: launch_pp<SRHIP_EPI_BF16>(g, s); break;
+        case SRHIP_EPI_GELU_BF16: launch_pp<SRHIP_EPI_GELU_BF16>(g, s); break;
+        case SRHIP_EPI_RESID_F32: launch_pp<SRHIP_EPI_RESID_F32>(g, s); break;
+        case SRHIP_EPI_DGELU_BF16: launch_pp<SRHIP_EPI_DGELU_BF16>(g, s); break;
+        default: return SR_EINVAL;
+      }
+      SR_CHECK_LAUNCH();
+      return SR_OK;
+    }
     switch (epilogue) {
       case SRHIP_EPI_BF16: launch_big<SRHIP_EPI_BF16>(g, variant, s); break;
       case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, variant, s); break;

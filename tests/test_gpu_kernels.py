@@ -38,7 +38,8 @@ def gelu(x):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(16, 128, 64), (300, 256, 128), (24 * 257, 1152, 384), (4112, 384, 1536), (384, 1536, 4160), (130, 4, 64),
                                    (70001, 1152, 384),         # persistent 256x256 kernel, ragged last column tile and row
-                                   (2061, 768, 3072), (2300, 3072, 768)])   # D = 768 legs (BERT / Wav2Vec2 MLP products)
+                                   (2061, 768, 3072), (2300, 3072, 768),    # D = 768 legs (BERT / Wav2Vec2 MLP products)
+                                   (13952, 768, 768), (9001, 2304, 1536)])  # two-wave-group 256 x 256 x 64 kernel, ragged last row tile
 def test_gemm_epilogues(M, N, K):
     A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.1))
     bias = rnd(N, seed=3)
