@@ -662,6 +662,8 @@ static void launch_big_t(const GemmArgs& g, int grid_cap, hipStream_t s) {
 // stores (the half-tiles ahead have had a phase or more to land) and the first NSLOT - 4 phases of the next tile wait for nothing.
 // Both groups take their epilogue between the same two barriers (the stagger is closed at the end of a tile and reopened at the start of the
 // next: one extra barrier each), otherwise each group's stores would hold the other one at a barrier in turn.
+// (A stream-K walk of this kernel -- equal K-tile ranges per workgroup, fp32 slabs + flags for the shared tiles -- was built and measured: the
+// 256-KiB slab round trip costs a workgroup 20-30 us, more than the idle CUs of a partial last round; profiles/r05_gemm_stream_k.txt.)
 // 16-byte chunks of a 128-byte LDS row are permuted by (row >> 1) & 7 (on the source address, LDS-DMA writes lane-linear): the 16 lanes of a
 // ds_read_b128 service group (8 rows at chunk c, 8 at c ^ 1) then fall on 16 distinct 16-byte bank groups.
 constexpr int PBK = 64;
@@ -966,14 +968,14 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   // over 512 slots; measured 1029 -> 1065 img/s).  SRHIP_BIG_MIN_ROUNDS overrides the threshold for tuning.
   static const double big_min_rounds = SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS") ? atof(SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS")) : 3.0;
   // (N = 512 conv layers of the Wav2Vec2 feature encoder, K = 1024 / 1536 over 10^5..10^6 frames: +5 % clips/s on the persistent kernel)
-  // K >= 768 (the D = 768 legs: BERT / Wav2Vec2 / HuBERT): the K loop is long enough that the 256-row tile pays from ~0.6 rounds of tiles on, also
+  // K >= 768 (the D = 768 legs: BERT / Wav2Vec2 / HuBERT): the K loop is long enough that the 256-row tile pays from ~0.5 rounds of tiles on (12288 x 768 x 3072, 0.56 rounds: 98 -> 76 us, tools/gemm_dispatch_probe.py), also
   // at N = 768 (tools/gemm_modes_probe.py, standalone TF/s default -> this rule: BERT qkv 13952 x 2304 x 768 664 -> 800, fc1 615 -> 735, fc2 13952 x
   // 768 x 3072 630 -> 680, Wav2Vec2 fc1 5373 x 3072 x 768 617 -> 775); the 3-round threshold above is for the epilogue-heavy K = 384 products
   const bool big_k = K >= 768;
   const bool force_big = mode && mode[0] == 'b' && strcmp(mode, "bigold") != 0;        // "bigold": the lockstep kernel where the plan says 256 x 256, nothing forced
   const bool want_big = N >= 1024 || (N >= 512 && K >= 1024 && M >= 65536) || (big_k && N >= 768 && M >= 8192) || force_big;
   const double big_rounds = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0;
-  const double min_rounds = (big_k && !SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS")) ? 0.6 : big_min_rounds;
+  const double min_rounds = (big_k && !SR_TUNE_ENV("SRHIP_BIG_MIN_ROUNDS")) ? 0.5 : big_min_rounds;
   if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || force_big)) {
     if (mode && !strcmp(mode, "big128")) return SRHIP_GEMM_PLAN_BIG128;
     if (mode && !strcmp(mode, "big2wg")) return SRHIP_GEMM_PLAN_BIG2WG;
