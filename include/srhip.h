@@ -39,13 +39,14 @@ int srhip_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, 
                   const float* bias, const float* row_scale, int rows_per_sample, const void* aux_in, void* aux_out,
                   int ldaux, float alpha, float beta, void* stream);
 /* The tile kernel srhip_gemm_nt picks for a product (host logic only, no launch): the 128 x 128 LDS-DMA ring kernel, the 64 x 64 deep-ring kernel
- * for launches that would leave most CUs idle, or the persistent 256-row kernel.  Exported so that a test can pin the decision per shape family
+ * for launches that would leave most CUs idle, or one of the persistent 256-row kernels.  Exported so that a test can pin the decision per shape family
  * (the nn.Linear products of vit.py:93-98,105,69-75 at ViT-S width and of the HF encoders behind bert.py:34 / wave2vecv2.py:44 at D = 768). */
 #define SRHIP_GEMM_PLAN_TILE128 0
 #define SRHIP_GEMM_PLAN_SMALL64 1
 #define SRHIP_GEMM_PLAN_BIG256 2
 #define SRHIP_GEMM_PLAN_BIG128 3
 #define SRHIP_GEMM_PLAN_BIG2WG 4
+#define SRHIP_GEMM_PLAN_PP256 5      /* 256 x 256 x 64 tiles, two wave groups half a phase apart (K % 64 == 0, operands < 2 GiB); else BIG256 = its lockstep predecessor */
 int srhip_gemm_nt_plan(int epilogue, int M, int N, int K, float beta);
 /* Launches of fewer than n 128 x 128 tiles go to the 64 x 64 deep-ring kernel (default 256 = one round of the chip; K >= 768 products at N >= 768
  * excepted).  The small tiles are the latency choice for a chain of dependent launches that has the chip to itself; a training step whose

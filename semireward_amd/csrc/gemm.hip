@@ -979,7 +979,10 @@ static int gemm_plan(int epilogue, int M, int N, int K, float beta, int* splits_
   if (!force_tile && want_big && epilogue != SRHIP_EPI_F32 && M >= 4 * GBM && (big_rounds >= min_rounds || force_big)) {
     if (mode && !strcmp(mode, "big128")) return SRHIP_GEMM_PLAN_BIG128;
     if (mode && !strcmp(mode, "big2wg")) return SRHIP_GEMM_PLAN_BIG2WG;
-    return SRHIP_GEMM_PLAN_BIG256;
+    // the two-wave-group kernel whenever its 64-deep K-tiles and 31-bit buffer offsets fit (contiguous operands assumed here; the launch
+    // re-checks with the real leading dimensions).  SRHIP_GEMM=bigold pins the lockstep kernel
+    const bool pp = (K % 64) == 0 && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K * 2 < (1ull << 31) && !(mode && !strncmp(mode, "bigold", 6));
+    return pp ? SRHIP_GEMM_PLAN_PP256 : SRHIP_GEMM_PLAN_BIG256;
   }
   // under-filled launches (less than one round of 2 workgroups per CU on 128x128 tiles) -> 64x64 tiles, deep ring
   // (the 64x64 kernel is for short K loops: at K >= 768 a launch of < 256 128x128 tiles is still faster on those tiles -- Wav2Vec2 fc2 5373 x 768 x
@@ -1036,12 +1039,10 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   const int nkt = K / BK;
   g.ksplit_tiles = cdiv(nkt, splits);
   const dim3 grid3(grid, splits);
-  if (plan == SRHIP_GEMM_PLAN_BIG256 || plan == SRHIP_GEMM_PLAN_BIG128 || plan == SRHIP_GEMM_PLAN_BIG2WG) {
-    const int variant = plan == SRHIP_GEMM_PLAN_BIG256 ? 0 : (plan == SRHIP_GEMM_PLAN_BIG128 ? 1 : 2);
-    // 256 x 256 tiles: the two-wave-group kernel whenever its K-tile pairs and 31-bit buffer offsets fit (SRHIP_GEMM=bigold pins the lockstep one)
-    static const char* mode = getenv("SRHIP_GEMM");
-    const bool pp_ok = (K % PBK) == 0 && ((size_t)(M - 1) * lda + K) * 2 < (1ull << 31) && ((size_t)(N - 1) * ldb + K) * 2 < (1ull << 31) &&
-                       !(mode && !strncmp(mode, "bigold", 6));
+  if (plan == SRHIP_GEMM_PLAN_PP256 || plan == SRHIP_GEMM_PLAN_BIG256 || plan == SRHIP_GEMM_PLAN_BIG128 || plan == SRHIP_GEMM_PLAN_BIG2WG) {
+    const int variant = (plan == SRHIP_GEMM_PLAN_BIG256 || plan == SRHIP_GEMM_PLAN_PP256) ? 0 : (plan == SRHIP_GEMM_PLAN_BIG128 ? 1 : 2);
+    // 256 x 256 tiles: the two-wave-group kernel unless the real leading dimensions push an operand past 2 GiB
+    const bool pp_ok = plan == SRHIP_GEMM_PLAN_PP256 && ((size_t)(M - 1) * lda + K) * 2 < (1ull << 31) && ((size_t)(N - 1) * ldb + K) * 2 < (1ull << 31);
     if (variant == 0 && pp_ok) {
       switch (epilogue) {
         case SRHIP_EPI_BF16: launch_pp<SRHIP_EPI_BF16>(g, s); break;

@@ -104,7 +104,7 @@ class _GemmProfile:
         self.recs.append((e0, e1, flops, kernel, nbytes, i0, _lib.lib().srhip_prof_count()))
 
     _KERNEL = {"tile128": "gemm_nt_kernel<%d>", "small64": "gemm_small_kernel<%d>", "big256": "gemm_big_kernel<%d, 8, 2>",
-               "big128": "gemm_big_kernel<%d, 4, 2>", "big2wg": "gemm_big_kernel<%d, 8, 1>"}
+               "big128": "gemm_big_kernel<%d, 4, 2>", "big2wg": "gemm_big_kernel<%d, 8, 1>", "pp256": "gemm_pp_kernel<%d, 10>"}
 
     @classmethod
     def kernel_name(cls, epi, M, N, K):
@@ -172,7 +172,7 @@ def gemm_nt(epi, A, B, C, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, r
           rows_per_sample, _p(aux_in), _p(aux_out), ldaux, alpha, beta, _s())
 
 
-GEMM_PLAN_NAMES = {0: "tile128", 1: "small64", 2: "big256", 3: "big128", 4: "big2wg"}
+GEMM_PLAN_NAMES = {0: "tile128", 1: "small64", 2: "big256", 3: "big128", 4: "big2wg", 5: "pp256"}
 
 
 def gemm_nt_plan(epi, M, N, K, beta=0.0):

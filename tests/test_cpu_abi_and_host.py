@@ -373,13 +373,13 @@ def test_gemm_tile_dispatch_is_pinned_per_shape_family(monkeypatch):
         ("vit grad fc1", ops.EPI_GELU_BF16, 4112, 1536, 384): "tile128", ("vit grad fc2^T dGELU", ops.EPI_DGELU_BF16, 4112, 1536, 384): "tile128",
         ("vit grad qkv", ops.EPI_BF16, 4112, 1152, 384): "tile128", ("vit 257th-token rows", ops.EPI_BF16, 105, 1152, 384): "small64",
         # ViT-S inference launches when the fused kernels are off: persistent kernel from 3 rounds of 256 x 256 tiles on
-        ("vit qkv 200 images", ops.EPI_BF16, 51400, 1152, 384): "big256", ("vit qkv 127 images", ops.EPI_BF16, 32639, 1152, 384): "tile128",
+        ("vit qkv 200 images", ops.EPI_BF16, 51400, 1152, 384): "pp256", ("vit qkv 127 images", ops.EPI_BF16, 32639, 1152, 384): "tile128",
         ("vit proj 200 images", ops.EPI_RESID_F32, 51400, 384, 384): "tile128",
         # D = 768 (BERT / Wav2Vec2 / HuBERT): 256 x 256 kernel from 0.5 rounds of tiles on, 128 x 128 (not 64 x 64) below
-        ("bert qkv", ops.EPI_BF16, 13952, 2304, 768): "big256", ("bert proj", ops.EPI_RESID_F32, 13952, 768, 768): "big256",
-        ("bert fc1", ops.EPI_GELU_BF16, 13952, 3072, 768): "big256", ("bert fc2", ops.EPI_RESID_F32, 13952, 768, 3072): "big256",
-        ("bert grad fc2", ops.EPI_RESID_F32, 4096, 768, 3072): "tile128", ("bert grad fc1", ops.EPI_GELU_BF16, 4096, 3072, 768): "big256",
-        ("w2v fc1", ops.EPI_GELU_BF16, 5373, 3072, 768): "big256", ("w2v fc2", ops.EPI_RESID_F32, 5373, 768, 3072): "tile128",
+        ("bert qkv", ops.EPI_BF16, 13952, 2304, 768): "pp256", ("bert proj", ops.EPI_RESID_F32, 13952, 768, 768): "pp256",
+        ("bert fc1", ops.EPI_GELU_BF16, 13952, 3072, 768): "pp256", ("bert fc2", ops.EPI_RESID_F32, 13952, 768, 3072): "pp256",
+        ("bert grad fc2", ops.EPI_RESID_F32, 4096, 768, 3072): "tile128", ("bert grad fc1", ops.EPI_GELU_BF16, 4096, 3072, 768): "pp256",
+        ("w2v fc1", ops.EPI_GELU_BF16, 5373, 3072, 768): "pp256", ("w2v fc2", ops.EPI_RESID_F32, 5373, 768, 3072): "tile128",
         # fp32-accumulating products (weight gradients outside the grouped launch) never leave the 128 x 128 kernel (split-K lives there)
         ("dW small", ops.EPI_F32, 384, 1536, 4160): "tile128",
     }
