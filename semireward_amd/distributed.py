@@ -62,15 +62,24 @@ class ExchangeTuner:
         for form in ("allreduce", "rs_ag"):
             dp.collective = form
             ts = []
-            for i in range(1 + self.COLL_TIMED):
-                if cuda:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); dp._sum_over_ranks(scratch); e1.record()
-                    e1.synchronize()
-                    ts.append(e0.elapsed_time(e1))
-                else:
-                    import time
-                    t0 = time.perf_counter(); dp._sum_over_ranks(scratch); ts.append(1e3 * (time.perf_counter() - t0))
+            try:
+                for i in range(1 + self.COLL_TIMED):
+                    if cuda:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(); dp._sum_over_ranks(scratch); e1.record()
+                        e1.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    else:
+                        import time
+                        t0 = time.perf_counter(); dp._sum_over_ranks(scratch); ts.append(1e3 * (time.perf_counter() - t0))
+            except RuntimeError as exc:
+                # a form the live backend refuses (argument checks run before anything is enqueued, on every rank alike) leaves the choice to
+                # the other one: this code has not met RCCL yet, and a first run should not die in its own tuner.  The all-reduce must work.
+                if form == "allreduce":
+                    raise
+                self.report["rs_ag_refused"] = str(exc)[:200]
+                out.append(float("inf"))
+                continue
             out.append(sorted(ts[1:])[len(ts[1:]) // 2])
         return out
 
@@ -98,7 +107,7 @@ class ExchangeTuner:
         if self.phase == 0:
             ms = self._agree(self._time_collectives(grad), grad.device)
             dp.collective = "allreduce" if ms[0] <= ms[1] else "rs_ag"
-            self.report["collective_ms"] = {"allreduce": round(ms[0], 4), "rs_ag": round(ms[1], 4)}
+            self.report["collective_ms"] = {"allreduce": round(ms[0], 4), "rs_ag": round(ms[1], 4) if ms[1] != float("inf") else None}
             self.phase, self.marks = 1, []
             if not dp.can_overlap(model):                   # nothing to compare a schedule with: done after one step
                 self._finish(False, model)
