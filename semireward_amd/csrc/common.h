@@ -147,7 +147,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Tuning switches (tile splits, knock-outs, schedule variants for tools/microbench.py and the A/B scripts) exist in the tuning build only
-// (SRHIP_TUNING_BUILD=1 -> -DSRHIP_TUNING).  The shipped library reads two environment variables, both test hooks: SRHIP_GEMM (pins the GEMM
+// (SRHIP_TUNING_BUILD=1 -> -DSRHIP_TUNING).  The shipped library reads two environment variables, both test hooks: SRHIP_GEMM = tile | small | big256 | big128 | big2wg (force that
+// kernel), bigold (the lockstep 256 x 256 kernel wherever the plan says 256 x 256), bigoldf (forced), big256r8 (eight-slot ring) (pins the GEMM
 // tile kernel so that tests/test_gpu_kernels.py reaches every kernel with every epilogue) and SRHIP_FLEXMATCH_GENERAL (the global-memory
 // FlexMatch path that tables too large for LDS take).
 #ifdef SRHIP_TUNING
