@@ -186,7 +186,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       s[t] = a;
       // keep hipcc from hoisting all 36 fragment reads (144 VGPRs) to the top of the unrolled loop: that pushed the
       // kernel to 414 registers = 1 wave/SIMD = 1 workgroup/CU
-      if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      if ((t & (NKT >= 32 ? 3 : 1)) == (NKT >= 32 ? 3 : 1)) __builtin_amdgcn_sched_barrier(0);      // (N > 288: one workgroup per CU anyway, 256 registers)
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
       for (int dt = 0; dt < 4; ++dt) {
         o[dt] = mfma16(ld16(Vt + dt * 16 * TP + 32 * u + vof), pb, o[dt]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (NKT < 32 || (u & 1)) __builtin_amdgcn_sched_barrier(0);
     }
     if (q < N) {
       const float inv = ((VAR && av.drop_thresh) ? av.drop_scale : 1.0f) / sum;
