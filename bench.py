@@ -62,6 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--elide-unread-rows", action="store_true",
                     help="NOT the reference's work (never the default, flagged in config): skip the (pass, image) rows whose outputs nothing reads")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="N = 1: the data-parallel path with ONE rank on a 1-rank nccl (RCCL) communicator -- every collective of the step is issued "
+                         "(gradient exchange selected by the start-up tuner, rccl_ranks: 1, allreduce_ms_per_step in the line); what a one-GPU box can "
+                         "show of configs[2]'s backend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-allreduce-ab", action="store_true", help="N > 1: skip the pinned legs of the gradient exchange (allreduce / overlap / rs_ag ...)")
@@ -235,7 +239,8 @@ class Leg:
         from semireward_amd.utils import synth
         self.a, self.ctx, self.net, self.img, self.bu, self.bl, self.regime = a, ctx, net, img, bu, bl or bu, regime
         world, rank, local = ctx["world"], ctx["rank"], ctx["local"]
-        common = dict(gpu=local, rank=rank, world_size=world, distributed=world > 1)
+        self.dp_on = world > 1 or bool(ctx.get("force_dp"))
+        common = dict(gpu=local, rank=rank, world_size=world, distributed=self.dp_on, force_dp=bool(ctx.get("force_dp")))
         self.elide = elide
         if net == "vit":
             from semireward_amd.nets import vit
@@ -326,7 +331,7 @@ class Leg:
         # slow or oversubscribed host); on one MI355X with its own host the step is GPU-bound (1.9 ms of enqueue per 4.9 ms step, replay
         # 5.32 vs 5.23 ms eager) and eager launches stay.  1 / 0 force it.
         self.graph, self.graph_mode = None, os.environ.get("SR_HIP_GRAPH", "auto")
-        self.graph_ok = getattr(m, "graph_safe", False) and world == 1 and net == "vit"
+        self.graph_ok = getattr(m, "graph_safe", False) and not self.dp_on and net == "vit"
         if self.graph_mode not in ("auto", "0") and self.graph_ok:
             self._enable_graph()
         self.workload += "steady SR regime" if regime == "sr" else "pre-start_timing regime"
@@ -411,12 +416,12 @@ class Leg:
             cap_steps += 1
         for _ in range(warmup):
             self.step()
-        m.dp.comm_events = [] if world > 1 else None          # event pairs around the gradient all-reduce of every timed step
+        m.dp.comm_events = [] if self.dp_on else None          # event pairs around the gradient all-reduce of every timed step
         syncs0 = m.dp.agreement_syncs
         dts = [self.timed(steps) for _ in range(repeats)]
         syncs_timed = m.dp.agreement_syncs - syncs0
         ar_ms = None
-        if world > 1:
+        if self.dp_on:
             torch.cuda.synchronize()
             ev = m.dp.comm_events
             m.dp.comm_events = None
@@ -439,7 +444,7 @@ class Leg:
                           "unread_rows": "ELIDED (opt-in extension: fewer forward rows than the reference executes, results identical)"
                           if self.elide else "computed, as in the reference",
                           "backward_images_per_step": bl + bu, "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
-                          "grad_allreduce": "flat fp32 block, 1 RCCL all-reduce/step" if world > 1 else "none"}}
+                          "grad_allreduce": "flat fp32 block, exchange selected at start-up (grad_exchange)" if self.dp_on else "none"}}
         rep = list(getattr(m, "defer_report", {}).values())
         if rep:
             out["config"].update(deferred_share=rep[-1]["chosen"], deferred_images=rep[-1]["deferred_images"], autotune_steps=tune_steps)
@@ -460,7 +465,7 @@ class Leg:
                                            "measured_over": "6 steps after the schedule tuning, device drained before, nothing waited for inside"}
         out["config"]["host_enqueue_ms_per_step_max"] = max(hosts)
         out["config"]["hip_graph"] = "%s -> %s" % (self.graph_mode, "replay" if self.graph is not None else "eager")
-        if world > 1:
+        if self.dp_on:
             out["config"]["backend"] = self.ctx["backend_note"]
             out["rccl_ranks"] = self.ctx["rccl_ranks"]
             out["devices"] = self.ctx["ndev_used"]
@@ -550,14 +555,21 @@ def worker(a):
         raise SystemExit("bench.py: --gpus %d but only %d visible device(s).  One rank per GPU over RCCL needs %d devices (check HIP_VISIBLE_DEVICES / "
                          "ROCR_VISIBLE_DEVICES); for a functional check of the multi-rank path with ranks sharing devices set SR_DIST_BACKEND=gloo "
                          "explicitly (its line is labelled as such and is not a scaling measurement)." % (world, ndev, world))
-    ctx = {"world": world, "rank": rank, "local": local % max(ndev, 1), "rccl_ranks": 0, "ndev_used": min(ndev, world), "backend_note": None}
+    ctx = {"world": world, "rank": rank, "local": local % max(ndev, 1), "rccl_ranks": 0, "ndev_used": min(ndev, world), "backend_note": None,
+           "force_dp": bool(a.force_dp) and world == 1}
     torch.cuda.set_device(ctx["local"])
-    if world > 1:
+    if ctx["force_dp"]:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+    if world > 1 or ctx["force_dp"]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", ctx["local"]))
             ctx["rccl_ranks"] = dist.get_world_size()
-            ctx["backend_note"] = "nccl (RCCL), one rank per GPU"
+            ctx["backend_note"] = "nccl (RCCL), one rank per GPU" + (" -- ONE rank, data-parallel path forced (--force-dp)" if ctx["force_dp"] else "")
         else:
             # fewer devices than ranks (or SR_DIST_BACKEND=gloo): the ranks share devices and the collectives go through host memory --
             # a functional check of the N-rank path, NOT a scaling measurement
@@ -636,7 +648,7 @@ def worker(a):
             del leg
             torch.cuda.empty_cache()
     state["phase"] = "gradient-exchange A/B"
-    if world > 1 and default_headline and not a.no_allreduce_ab:
+    if (world > 1 or ctx["force_dp"]) and default_headline and not a.no_allreduce_ab:
         # Every gradient exchange pinned once in the SAME run, beside the headline's start-up selection (distributed.ExchangeTuner): the evidence
         # table for the first run on RCCL over xGMI
         ab = out["grad_exchange_legs"] = {"headline": {"exchange": out["config"].get("grad_exchange"), "ms_per_step": out["ms_per_step"],
@@ -682,7 +694,7 @@ def worker(a):
         print(json.dumps(out), flush=True)
     state["done"] = True
     watchdog.cancel()
-    if world > 1:
+    if world > 1 or ctx["force_dp"]:
         dist.barrier()
         dist.destroy_process_group()
 

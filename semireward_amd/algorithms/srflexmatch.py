@@ -422,8 +422,11 @@ class SRConsistencyBase(AlgorithmBase):
                     agree = (lambda ms: self.dp.max_over_ranks(ms, self.device)) if self.dp.active else None
                     # a regime abandoned mid-tuning (K or the batch shape moved on before its windows finished) will not come back to finish:
                     # its tuner and candidate plans go (they would keep StepGraph in eager mode and hold device tensors for the rest of the run)
+                    # (its plan goes with it: the regime is tuned from scratch if it does come back -- a partial last batch once per epoch --
+                    # instead of running on the untuned seed share for the rest of the run)
                     for k_ in [k_ for k_ in self._tuners if k_ != key]:
                         del self._tuners[k_]
+                        self._plans.pop(k_, None)
                     self._tuners[key] = (_DeferTuner(cand.keys(), refine=not prev, agree=agree), cand)
                 elif prev:
                     # the neighbour's candidates collapse to one split at this size: that split, not the untuned rule

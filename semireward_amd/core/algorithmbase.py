@@ -93,7 +93,7 @@ class AlgorithmBase:
         # (without a GPU only the host-side wiring of this class can be exercised -- tests/test_cpu_driver_contract.py; every op raises)
         self.device = torch.device("cuda", self.gpu if isinstance(self.gpu, int) else torch.cuda.current_device()) \
             if torch.cuda.is_available() else torch.device("cpu")
-        self.dp = DataParallel(self.world_size, self.rank, global_reward_threshold=g("global_reward_threshold", False))
+        self.dp = DataParallel(self.world_size, self.rank, global_reward_threshold=g("global_reward_threshold", False), force=g("force_dp", None))
         self.it = 0
         self.epoch = 0
         self.start_epoch = 0

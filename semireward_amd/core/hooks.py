@@ -69,12 +69,12 @@ class ParamUpdateHook(Hook):
 
     def after_train_step(self, algorithm):
         scale = 1.0
-        if algorithm.distributed and algorithm.world_size > 1:
+        if (algorithm.distributed and algorithm.world_size > 1) or algorithm.dp.force:
             # sum over the ranks and 1/world belong together: a configuration that says "distributed" without an initialised process group
             # would otherwise divide local gradients by world_size (a silent learning-rate change)
             if not algorithm.dp.active:
-                raise RuntimeError("args.distributed with world_size %d but torch.distributed is not initialised: call init_process_group "
-                                   "before the first step (semilearn/train.py:374-379)" % algorithm.world_size)
+                raise RuntimeError("args.distributed with world_size %d%s but torch.distributed is not initialised: call init_process_group "
+                                   "before the first step (semilearn/train.py:374-379)" % (algorithm.world_size, " (force_dp)" if algorithm.dp.force else ""))
             algorithm.dp.all_reduce_grads(algorithm.model)
             scale = 1.0 / algorithm.world_size
         ema, ema_m = None, 0.0

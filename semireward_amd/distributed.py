@@ -54,33 +54,52 @@ class ExchangeTuner:
         self.syncs += 1
         return [float(x) for x in t.cpu()]
 
+    def _probe_rs_ag(self, grad):
+        """Does the live backend take the reduce-scatter + all-gather form (in place: this rank's shard is a slice of the input)?  Asked ONCE on
+        a tiny block before anything large is timed, and the answer is AGREED (all-reduce MAX of a refusal flag): an error that only some ranks
+        see must not leave the ranks with different collective sequences in their queues.  Returns None or the refusal text."""
+        dp = self.dp
+        tiny = torch.zeros(max(1, dp.world_size) * dp.SHARD_ALIGN * 2, dtype=grad.dtype, device=grad.device)
+        err, keep = None, dp.collective
+        try:
+            dp.collective = "rs_ag"
+            dp._sum_over_ranks(tiny)
+            if grad.is_cuda:
+                torch.cuda.current_stream().synchronize()
+        except RuntimeError as exc:
+            err = str(exc)[:200]
+        finally:
+            dp.collective = keep
+        refused = self._agree([1.0 if err is not None else 0.0], grad.device)[0] > 0.0
+        if refused:
+            return err or "refused on another rank"
+        return None
+
     def _time_collectives(self, grad):
         dp = self.dp
+        refusal = self._probe_rs_ag(grad)
+        if refusal is not None:
+            self.report["rs_ag_refused"] = refusal
         scratch = torch.zeros_like(grad)
         cuda = grad.is_cuda
         out = []
         for form in ("allreduce", "rs_ag"):
-            dp.collective = form
-            ts = []
-            try:
-                for i in range(1 + self.COLL_TIMED):
-                    if cuda:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(); dp._sum_over_ranks(scratch); e1.record()
-                        e1.synchronize()
-                        ts.append(e0.elapsed_time(e1))
-                    else:
-                        import time
-                        t0 = time.perf_counter(); dp._sum_over_ranks(scratch); ts.append(1e3 * (time.perf_counter() - t0))
-            except RuntimeError as exc:
-                # a form the live backend refuses (argument checks run before anything is enqueued, on every rank alike) leaves the choice to
-                # the other one: this code has not met RCCL yet, and a first run should not die in its own tuner.  The all-reduce must work.
-                if form == "allreduce":
-                    raise
-                self.report["rs_ag_refused"] = str(exc)[:200]
+            if form == "rs_ag" and refusal is not None:
                 out.append(float("inf"))
                 continue
+            dp.collective = form
+            ts = []
+            for i in range(1 + self.COLL_TIMED):
+                if cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); dp._sum_over_ranks(scratch); e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                else:
+                    import time
+                    t0 = time.perf_counter(); dp._sum_over_ranks(scratch); ts.append(1e3 * (time.perf_counter() - t0))
             out.append(sorted(ts[1:])[len(ts[1:]) // 2])
+        del scratch                           # (86 MB for ViT-S: not kept for the tuner's lifetime)
         return out
 
     def _mark(self, device):
@@ -128,7 +147,10 @@ class ExchangeTuner:
     def _finish(self, overlap, model):
         dp = self.dp
         if not overlap:
-            dp.uninstall_overlap(model)
+            # This step's backward has ALREADY reduced its layer-group ranges on the communication stream (the decision falls at the top of
+            # all_reduce_grads): only the callback goes now; the exchange that follows consumes the reported ranges (reducing them again would
+            # sum them twice) and clears them.
+            dp.uninstall_overlap(model, keep_reported=True)
         dp.exchange = ("rs_ag" if dp.collective == "rs_ag" else "allreduce") if not overlap else ("rs_ag_overlap" if dp.collective == "rs_ag" else "overlap")
         self.report["chosen"] = dp.exchange
         self.phase = 3
@@ -137,8 +159,12 @@ class ExchangeTuner:
 
 
 class DataParallel:
-    def __init__(self, world_size=1, rank=0, global_reward_threshold=False, exchange=None):
+    def __init__(self, world_size=1, rank=0, global_reward_threshold=False, exchange=None, force=None):
         self.world_size, self.rank = world_size, rank
+        # force: the data-parallel path with ONE rank (the reference wraps the model in DDP whenever args.distributed is set, whatever the world
+        # size: misc.py:55-58) -- every collective is issued on the live backend.  args.force_dp / SR_FORCE_DP=1; how a box with one GPU puts
+        # the engine's exchanges through RCCL (tests/test_gpu_rccl_one_rank.py, bench.py --force-dp).
+        self.force = bool(os.environ.get("SR_FORCE_DP", "0") != "0") if force is None else bool(force)
         self.global_reward_threshold = global_reward_threshold
         self.comm_events = None      # bench.py: list that receives a HIP-event pair around the gradient all-reduce of every step
         req = exchange if exchange is not None else os.environ.get("SR_GRAD_EXCHANGE", "auto")
@@ -195,8 +221,13 @@ class DataParallel:
             dist.all_reduce(t[:head], op=dist.ReduceOp.SUM)
 
     @property
+    def engaged(self):
+        """The configuration asks for the data-parallel path (more than one rank, or one rank forced through it)."""
+        return self.world_size > 1 or self.force
+
+    @property
     def active(self):
-        return self.world_size > 1 and dist.is_available() and dist.is_initialized()
+        return self.engaged and dist.is_available() and dist.is_initialized()
 
     # ---- all-reduce under the backward ------------------------------------------------------------------------------------------------
     # The engines finish their weight gradients in layer groups, last layers first, and report every finished contiguous range of the flat
@@ -211,10 +242,13 @@ class DataParallel:
         model.grad_ready_cb = self._reduce_range
         return True
 
-    def uninstall_overlap(self, model):
+    def uninstall_overlap(self, model, keep_reported=False):
+        """keep_reported: called between a backward that reported ranges and the exchange of the same step -- the ranges stay (and with them
+        the join of the communication stream) for _all_reduce_grads, which clears them."""
         if getattr(model, "grad_ready_cb", None) is not None:
             model.grad_ready_cb = None
-        self._done, self._model = [], None
+        if not keep_reported:
+            self._done, self._model = [], None
 
     def _reduce_range(self, lo, hi):
         main = torch.cuda.current_stream()

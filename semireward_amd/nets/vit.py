@@ -443,7 +443,7 @@ class VisionTransformer(ModuleSurface):
         v = types.SimpleNamespace()
         v.dx, v.dln, v.dao = r(self._buf("b_dx", (M, D), f32)), r(self._buf("b_dln", (M, D), bf16)), r(self._buf("b_dao", (M, D), bf16))
         v.delta = im(self._buf("b_delta", (B, H, N), f32))
-        v.feat, v.xhat, v.rstd = im(ctx.feat), im(ctx.xhat), im(ctx.rstd)
+        v.xhat, v.rstd = im(ctx.xhat), im(ctx.rstd)
         v.layers = []
         for i in range(cfg.depth):
             Ti = T["layers"][i]
@@ -457,7 +457,7 @@ class VisionTransformer(ModuleSurface):
     def backward_rows(self, ctx, dlogits, b0, b1):
         """The input-gradient chain (head -> blocks 11 .. 0) of the images [b0, b1) of a save=True forward: every operand is a row range, rows of
         different images never meet before the weight-gradient products, so disjoint ranges may run on different streams at different times
-        (the labelled rows' chain under the inference forward, the strong rows' chain after the masks: srflexmatch._train_step).  ``dlogits``
+        (measured in round 5 and not used by the step: profiles/r05_early_sup_backward_ab.txt; backward() runs ONE whole-batch chain).  ``dlogits``
         is the whole [B, C] buffer; only its rows [b0, b1) are read.  LayerNorm / final-norm affine gradients are added with atomics into the
         partial copies; everything that sums over ALL rows -- weight, bias, head and patch-embedding gradients -- is backward_finish."""
         cfg = self.cfg
@@ -477,6 +477,7 @@ class VisionTransformer(ModuleSurface):
         dp = ctx.dp
         lnp = T["ln_part"]
         cb = self.grad_ready_cb if (b0 == 0 and b1 == ctx.B) else None          # data parallel overlap: whole-batch chains only
+        self._groups_launched = cb is not None         # backward_finish: the layer groups' weight / LayerNorm launches already ran inside this chain
         gdone = {g["lo_layer"]: g for g in T["groups"]} if cb is not None else {}
         # dp[i, j, b0:] as a raw pointer (the DropPath factors of this range's images)
         dpr = (lambda i_, j_: ops.RawRows(dp, i_ * dp.stride(0) + j_ * dp.stride(1) + b0)) if dp is not None else (lambda i_, j_: None)
@@ -517,10 +518,14 @@ class VisionTransformer(ModuleSurface):
         T = self._bwd_plan(M, ctx)
         dx = self._buf("b_dx", (M, D), f32)
         ops.cls_head_bwd(dlogits, None, None, ctx.feat, None, None, None, G("head.weight"), G("head.bias"), None, None, B, N, D, C)
-        if self.grad_ready_cb is None:
+        if not getattr(self, "_groups_launched", False):      # (a partial-range chain never launches them, whether or not a callback is installed)
             ops.ln_grad_reduce(T["ln_desc"], T["ln_part"], 2 * cfg.depth, LN_REP, D)
             desc, npb, ntiles, flops, nbytes = T["desc"]
             ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+            if self.grad_ready_cb is not None:
+                lo = min(g["flat"][0] for g in T["groups"]); hi = max(g["flat"][1] for g in T["groups"])
+                self.grad_ready_cb(lo, hi)              # the blocks' range in one piece (the chain did not hand it over in groups)
+        self._groups_launched = False
         Kp = cfg.in_chans * cfg.patch_size ** 2
         if Kp <= 64:
             ws = self._buf("b_pe_ws", (ops.patch_embed_bwd_ws_floats(B, cfg.in_chans, cfg.img_size, cfg.patch_size, D),), f32)

@@ -245,27 +245,36 @@ class WideResNet(ModuleSurface):
     def stat_ranks(self):
         return self.dp.world_size if (self.dp is not None and self.dp.active) else 1
 
+    @property
+    def stat_sync(self):
+        """The statistics are exchanged (data parallel engaged -- also with ONE rank forced through it: distributed.DataParallel.force)."""
+        return self.dp is not None and self.dp.active
+
     def _sync_acc(self, bn, acc=None):
-        if self.stat_ranks > 1:
+        if self.stat_sync:
             import torch.distributed as dist
             dist.all_reduce((acc or self.bn_acc)[bn])
 
     def _pass_acc(self, passes):
         """Statistics accumulators of ``passes`` forwards that share their launches (forward_features(passes=...)): per BatchNorm a contiguous
         [passes, srhip_bn_acc_doubles(C)] block (the layout srhip_wrn_conv_bn_passes indexes by blockIdx.z), all in one arena that a forward
-        zeroes with one fill launch.  Returns (arena, {name: [passes, n] view})."""
+        zeroes with one fill launch.  The arena starts with the two row-count cells of the SyncBatchNorm check, directly in front of the FIRST
+        BatchNorm's block: cells + block are one contiguous range, so the counts ride on that block's exchange exactly as on the single-pass
+        path (_sync_first_acc).  Returns (arena, {name: [passes, n] view}, cells, cells + first block)."""
         key = ("pass_acc", passes)
         if key not in self._buf_cache:
+            first = self.blocks[0][0] + "bn1"
             sizes = [(nme, ops.bn_acc_doubles(c)) for nme, c, _ in self.bn]
-            arena = torch.zeros(passes * sum(n for _, n in sizes), dtype=torch.float64, device=self.device)
-            views, o = {}, 0
+            sizes = [e for e in sizes if e[0] == first] + [e for e in sizes if e[0] != first]
+            arena = torch.zeros(2 + passes * sum(n for _, n in sizes), dtype=torch.float64, device=self.device)
+            views, o = {}, 2
             for nme, n in sizes:
                 views[nme] = arena[o:o + passes * n].view(passes, n)
                 o += passes * n
-            self._buf_cache[key] = (arena, views)
+            self._buf_cache[key] = (arena, views, arena[:2], arena[:2 + passes * sizes[0][1]])
         return self._buf_cache[key]
 
-    def _sync_first_acc(self, B):
+    def _sync_first_acc(self, B, cell=None, acc_with_rows=None):
         """The exchange of the first accumulator of a training forward, with this rank's row count riding along.  The statistics are sums over
         rows and the kernels divide by rows * ranks (torch's SyncBatchNorm exchanges the counts as well), so every rank must forward the same
         number of images.  EVERY rank enters the SAME collective in EVERY training forward -- whether the counts agree is decided from its
@@ -281,9 +290,10 @@ class WideResNet(ModuleSurface):
             if self._rows_dev is None:
                 self._rows_dev = torch.zeros((), dtype=torch.float64, device=self.device)
                 self._rows_tmp = torch.zeros((), dtype=torch.float64, device=self.device)
-        self._rows_cell.copy_(c)
-        dist.all_reduce(self._acc_first_with_rows)
-        torch.addcmul(self._rows_cell[1], self._rows_cell[0], self._rows_cell[0], value=-1.0, out=self._rows_tmp)      # R sum B^2 - (sum B)^2 >= 0
+        cell = self._rows_cell if cell is None else cell                    # (shared-launch forwards: the cells of their own arena, _pass_acc)
+        cell.copy_(c)
+        dist.all_reduce(self._acc_first_with_rows if acc_with_rows is None else acc_with_rows)
+        torch.addcmul(cell[1], cell[0], cell[0], value=-1.0, out=self._rows_tmp)      # R sum B^2 - (sum B)^2 >= 0
         torch.maximum(self._rows_dev, self._rows_tmp, out=self._rows_dev)
         if ops._CHECK_ARGS and not torch.cuda.is_current_stream_capturing():
             self.check_equal_rows()
@@ -369,17 +379,18 @@ class WideResNet(ModuleSurface):
                 self.bn_acc_arena.zero_()
                 accs = self.bn_acc
             else:
-                arena, accs = self._pass_acc(G)
+                arena, accs, pcell, pfirst = self._pass_acc(G)
                 arena.zero_()
             # sums of the stem's output for the first block's bn1 (every later BatchNorm gets them from the convolution in front of it)
             first = self.blocks[0][0] + "bn1"
             for g_ in range(G):
                 ops.bn_accumulate(out[g_ * B * h * w:(g_ + 1) * B * h * w], accs[first] if G == 1 else accs[first][g_], B * h * w, self.channels[0])
-            if self.stat_ranks > 1:
+            if self.stat_sync:
+                # (+ the row counts of the ranks, compared on the device -- on the shared-launch path as well: SRPseudoLabel's default)
                 if G == 1:
-                    self._sync_first_acc(B)                   # (+ the row counts of the ranks, compared on the device)
+                    self._sync_first_acc(B)
                 else:
-                    self._sync_acc(first, accs)
+                    self._sync_first_acc(B, pcell, pfirst)
         for bi, (p, cin, cout, stride, abr) in enumerate(self.blocks):
             equal = cin == cout
             raw = not (equal or abr)                          # wrn.py:50: conv1 / convShortcut take the RAW x; bn1's statistics still move
@@ -516,13 +527,13 @@ class WideResNet(ModuleSurface):
         dact = self._buf((tag, "dactf"), (rows, C3), f32)
         ops.avgpool_bwd(dfeat, dact, B, fin["h"] * fin["w"], C3)
         dy = self._buf((tag, "dy.final"), (rows, C3), f32)
-        ranks = self.stat_ranks
+        ranks, sync = self.stat_ranks, self.stat_sync
 
         def bn_bwd(dact, x, st, bn, resid, dx, rows_, C_):
             """BatchNorm + LeakyReLU backward: the two column sums (this rank's, then every rank's under SyncBatchNorm), then the apply pass."""
             ops.bn_bwd_reduce(dact, x, st[0], st[1], P(bn + ".weight"), P(bn + ".bias"), SLOPE, self.ws, rows_, C_)
             local = None
-            if ranks > 1:
+            if sync:
                 import torch.distributed as dist
                 local = self._buf((tag, "bn.local_sums"), (512,), torch.float64)
                 local[:2 * C_].copy_(self.ws[:2 * C_])

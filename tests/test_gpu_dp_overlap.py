@@ -24,6 +24,22 @@ def test_sliced_all_reduce_under_the_backward_equals_single_all_reduce():
     assert r.returncode == 0 and out.count("ranks agree: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_exchange_tuner_deciding_step_reduces_every_range_exactly_once():
+    """distributed.ExchangeTuner decides "exchange under the backward or after it" at the top of all_reduce_grads -- AFTER that step's backward
+    has already reduced its layer-group ranges.  tools/dp_tuner_decision_check.py walks two ranks through every phase with both outcomes forced
+    and compares the exchanged gradient of EVERY step (the deciding one included) with the sum of the ranks' local gradients."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "dp_tuner_decision_check.py")],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and out.count("every step's gradient is the sum over the ranks: True") == 4, (r.stdout[-3000:], r.stderr[-3000:])
+    assert out.count("DECIDING") == 4
+
+
 def test_global_reward_threshold_through_the_engine_with_two_ranks():
     """BASELINE.json configs[2]: ``global_reward_threshold`` through SRFlexMatch.train_step on the HIP engine with two gloo ranks on one GPU
     (tools/dp_global_threshold_check.py): mask2 == (reward >= mean over both ranks' rewards) bit for bit with the flag on, the rank-local mask
@@ -54,6 +70,7 @@ def test_wideresnet_under_data_parallel_is_syncbatchnorm():
     out = r.stdout + r.stderr
     assert r.returncode == 0 and out.count("syncbn == whole batch: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
     assert out.count("unequal per-rank batches raise on every rank: True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
+    assert out.count("unequal per-rank batches raise on every rank (shared launches): True") == 2, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_allreduce_streams_are_ordered_by_events_not_by_the_backend():

@@ -1,0 +1,57 @@
+"""BASELINE.json configs[2] meets its backend: every collective of the data-parallel engine through RCCL with a 1-rank ``nccl`` communicator
+(semilearn/train.py:374-379 ``init_process_group('nccl')``, core/utils/misc.py:55-58 DDP, algorithms/utils/ops.py:35-45 concat_all_gather) on
+the one GPU a test box has -- tools/rccl_one_rank_check.py (its docstring lists the sections).  Runs in its own process: the process group is
+process-wide state."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def report():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SR_DIST_BACKEND", "SR_GRAD_EXCHANGE",
+                                                              "SR_FORCE_DP")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank_check.py")], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RCCL_ONE_RANK ")]
+    assert lines, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    rep = json.loads(lines[-1][len("RCCL_ONE_RANK "):])
+    rep["_rc"], rep["_out"] = r.returncode, r.stdout[-4000:] + r.stderr[-2000:]
+    return rep
+
+
+def test_the_communicator_is_rccl(report):
+    assert report["backend"] == "nccl" and report["world_size"] == 1 and report["hip"], report
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "rs_ag", "overlap", "rs_ag_overlap", "allreduce_bf16"])
+def test_gradient_exchange_on_rccl_inside_real_steps(report, exchange):
+    """The real 85.7 MB block inside SRFlexMatch steps: every element travels exactly once per step, the exchanged gradient and the parameters
+    after four optimizer steps equal the non-data-parallel instance's bit for bit (bf16 exchange: the gradient rounded to bf16)."""
+    g = report["grad"][exchange]
+    assert g["ok"] and g["every_element_exactly_once"] and g["block_bytes"] == 4 * 21436900, (g, report["_out"])
+    if exchange != "allreduce_bf16":
+        assert g["grad_bit_equal"] and g["params_bit_equal"], g
+    else:
+        assert g["grad_rel"] == 0.0, g
+
+
+def test_exchange_tuner_settles_on_rccl_without_a_refusal(report):
+    a = report["auto"]
+    assert a["ok"] and a["bit_equal_to_non_dp"] and "rs_ag_refused" not in a and a["chosen"] in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap"), (a, report["_out"])
+    assert a["collective_ms"]["allreduce"] > 0 and a["collective_ms"]["rs_ag"] > 0 and a["step_ms_exchange_after_backward"] > 0
+
+
+def test_broadcast_reward_threshold_hook_statistics_and_syncbatchnorm_on_rccl(report):
+    assert report["bcast"]["ok"], (report["bcast"], report["_out"])
+    assert report["reward"]["ok"] and report["reward"]["packed_floats"] == 9, (report["reward"], report["_out"])
+    for name in ("srsoftmatch", "srfreematch"):
+        assert report["stats"][name]["ok"], (report["stats"], report["_out"])
+    assert report["syncbn"]["ok"] and report["syncbn"]["logits_equal"] and report["syncbn"]["shared_pass_logits_equal"], (report["syncbn"], report["_out"])
+    assert report["ok"] and report["_rc"] == 0

@@ -74,5 +74,19 @@ part.forward_features(x[sl].contiguous(), save=False, update_stats=False, tag="p
 part.check_equal_rows()
 print("rank %d: unequal per-rank batches raise on every rank: %s" % (rank, caught), flush=True)
 assert caught
+# the same on the shared-launch path (passes > 1: the K + 1 frozen forwards of an SRPseudoLabel step, its default): the counts ride on the first
+# accumulator block of the pass arena
+try:
+    part.forward_features(bad, save=False, update_stats=False, tag="badp", passes=3)
+    part.check_equal_rows()
+    caught_p = False
+except RuntimeError as e:
+    caught_p = "per-rank batches" in str(e)
+lg_3, _, _ = part.forward_features(x[sl].contiguous(), save=False, update_stats=False, tag="part3", passes=3)
+part.check_equal_rows()
+torch.cuda.synchronize()
+same = all(torch.equal(lg_3[:4], lg_3[4 * g_:4 * g_ + 4]) for g_ in (1, 2))        # three passes of one batch under frozen statistics: identical
+print("rank %d: unequal per-rank batches raise on every rank (shared launches): %s" % (rank, caught_p and same), flush=True)
+assert caught_p and same
 dist.barrier()
 dist.destroy_process_group()

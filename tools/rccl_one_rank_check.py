@@ -1,0 +1,302 @@
+"""Every collective the data-parallel engine issues, put through RCCL on ONE GPU: a 1-rank ``nccl`` communicator (what
+``init_process_group('nccl', ...)`` of semilearn/train.py:374-379 creates per rank) with the data-parallel path forced on
+(distributed.DataParallel.force: the reference wraps the model in DDP whenever args.distributed is set, misc.py:55-58, whatever the world size).
+    python tools/rccl_one_rank_check.py            (started by tests/test_gpu_rccl_one_rank.py; prints one verdict line per section)
+Sections:
+  grad      the five pinned gradient exchanges (allreduce | rs_ag in place | overlap | rs_ag_overlap | allreduce_bf16) on the real 85.7 MB block
+            inside real SRFlexMatch steps (ViT-S/2, 100 classes, 8 / 8 / 8, K = 8), side by side with a non-data-parallel instance that steps
+            in lockstep: the exchanged gradient and the parameters after every optimizer step against the other instance's, bit for bit (the
+            bf16 exchange: against the other instance's gradient rounded to bf16), and every element of the block travels exactly ONCE per step
+            (the collectives are counted at the torch.distributed entry points -- with one rank a range reduced twice has the same VALUE);
+  auto      SR_GRAD_EXCHANGE=auto: ExchangeTuner through all of its phases on RCCL until settled, no refusal of the reduce-scatter form;
+  bcast     broadcast_params of model / rewarder / generator;
+  reward    the global reward threshold (packed (sum, n) all-reduce per step, reward_means) against the rank-local mean;
+  stats     SoftMatch / FreeMatch / DistAlign statistics (gather_stats: all_reduce of column sums + histogram, all_gather of the max-probs);
+  syncbn    the WideResNet's SyncBatchNorm exchanges (forward accumulators incl. the row-count cells, single-pass and shared-launch forwards;
+            the two column sums of every BatchNorm backward).
+With one rank every sum over the ranks is the identity, so "data parallel == not data parallel" is an exact statement; what the section proves
+is that the calls (dtypes, in-place aliasing of reduce_scatter_tensor / all_gather_into_tensor, slices at 256-byte shard boundaries, the
+communication stream's event ordering, device_id= initialisation) are accepted and completed by the backend this engine is written for."""
+import argparse
+import json
+import os
+import socket
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["SR_DEFER_FRACTION"] = "0.475"                 # (read at import; the step-schedule tuner is not under test here)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np                                        # noqa: E402
+import torch                                              # noqa: E402
+import torch.distributed as dist                          # noqa: E402
+import bench                                              # noqa: E402
+from semireward_amd.algorithms import get_algorithm       # noqa: E402
+from semireward_amd.distributed import DataParallel       # noqa: E402
+from semireward_amd.nets import vit, wrn                  # noqa: E402
+from semireward_amd.utils import synth                    # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+if "MASTER_PORT" not in os.environ:
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+report = {"backend": dist.get_backend(), "world_size": 1, "torch": torch.__version__, "hip": torch.version.hip}
+
+
+class Counter:
+    """Elements handed to the collectives, counted at the torch.distributed entry points the engine calls."""
+
+    def __init__(self):
+        self.n = {"all_reduce": 0, "reduce_scatter_tensor": 0, "all_gather_into_tensor": 0, "all_gather": 0, "broadcast": 0}
+        self.calls = dict(self.n)
+        self.real = {k: getattr(dist, k) for k in self.n}
+        self.on_comm_stream = 0
+
+        def wrap(name, size_of):
+            def f(*a, **k):
+                self.n[name] += size_of(*a, **k)
+                self.calls[name] += 1
+                return self.real[name](*a, **k)
+            return f
+        dist.all_reduce = wrap("all_reduce", lambda t, *a, **k: t.numel())
+        dist.reduce_scatter_tensor = wrap("reduce_scatter_tensor", lambda out, inp, *a, **k: inp.numel())
+        dist.all_gather_into_tensor = wrap("all_gather_into_tensor", lambda out, inp, *a, **k: out.numel())
+        dist.all_gather = wrap("all_gather", lambda outs, t, *a, **k: t.numel())
+        dist.broadcast = wrap("broadcast", lambda t, *a, **k: t.numel())
+
+    def snap(self):
+        return dict(self.n), dict(self.calls)
+
+    def restore(self):
+        for k, v in self.real.items():
+            setattr(dist, k, v)
+
+
+cnt = Counter()
+rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))   # noqa: E731
+
+
+def make(force, exchange=None, **kw):
+    if exchange is not None:
+        os.environ["SR_GRAD_EXCHANGE"] = exchange
+    ns = dict(bench.NS)
+    ns.update(kw)
+    args = argparse.Namespace(gpu=0, rank=0, world_size=1, distributed=bool(force), force_dp=bool(force), **ns)
+    alg = get_algorithm(args, vit.vit_small_patch2_32)
+    alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
+    alg.model.seed = 1234
+    alg.it = bench.START_IT + 7                           # K = 8; the rewarder update of every N_k-th step falls inside the run
+    alg.optimizer.sched_step = alg.it
+    alg.model.train()
+    return alg
+
+
+def full_step(alg, batch, grab):
+    """train_step + ParamUpdateHook; ``grab``: list that receives the gradient block as the optimizer is about to read it."""
+    real = alg.optimizer.step
+
+    def step(*a, **k):
+        grab.append(alg.model.grad.clone())
+        return real(*a, **k)
+    alg.optimizer.step = step
+    try:
+        alg.out_dict, alg.log_dict = alg.train_step(**batch)
+        alg.call_hook("after_train_step")
+    finally:
+        alg.optimizer.step = real
+    alg.it += 1
+
+
+ok_all = True
+b = synth.synth_batch(100, 8, 8, 32, 100, 50000)
+# ---- grad: the five pinned exchanges -----------------------------------------------------------------------------------------------
+report["grad"] = {}
+for exch in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap", "allreduce_bf16"):
+    alg, ref = make(True, exch), make(False, "allreduce")
+    assert alg.dp.active and alg.dp.force and alg.dp.exchange == ("allreduce" if exch == "allreduce_bf16" else exch) and not ref.dp.active
+    assert (alg.model.grad_ready_cb is not None) == exch.endswith("overlap")
+    batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+    numel = alg.model.grad.numel()
+    worst_g = worst_p = 0.0
+    once = True
+    bit_g = bit_p = True
+    for step in range(4):                                 # it = 30007 .. 30010: the last one carries a rewarder update (its gradient is all-reduced too)
+        n0, c0 = cnt.snap()
+        ga, gr = [], []
+        full_step(alg, batch, ga)
+        full_step(ref, batch, gr)
+        torch.cuda.synchronize()
+        n1, c1 = cnt.snap()
+        want = gr[0].to(torch.bfloat16).float() if exch == "allreduce_bf16" else gr[0]
+        worst_g = max(worst_g, rel(ga[0], want))
+        bit_g = bit_g and bool(torch.equal(ga[0], want))
+        worst_p = max(worst_p, rel(alg.model.flat, ref.model.flat))
+        bit_p = bit_p and bool(torch.equal(alg.model.flat, ref.model.flat))
+        rew = alg.rewarder.grad.numel() if (alg.it - 1) % alg.N_k == 0 else 0
+        moved_ar = n1["all_reduce"] - n0["all_reduce"] - rew
+        moved_rs = n1["reduce_scatter_tensor"] - n0["reduce_scatter_tensor"]
+        moved_ag = n1["all_gather_into_tensor"] - n0["all_gather_into_tensor"]
+        once = once and (moved_ar + moved_rs == numel) and (moved_ag == moved_rs) and (("rs_ag" in exch) == (moved_rs > 0))
+    tol_p = 1e-2 if exch == "allreduce_bf16" else 0.0      # (a bf16-rounded gradient moves Adam's normalised update; not the reference's DDP)
+    good = once and (bit_g if exch != "allreduce_bf16" else worst_g == 0.0) and (worst_p <= tol_p) and alg.dp.exchange_report.get("chosen") == exch
+    ok_all = ok_all and good
+    report["grad"][exch] = dict(ok=good, every_element_exactly_once=once, grad_bit_equal=bit_g, params_bit_equal=bit_p, grad_rel=worst_g,
+                                params_rel=worst_p, steps=4, block_bytes=4 * numel)
+    print("grad[%s]: every element of the %.1f MB block exactly once per step: %s; exchanged gradient == non-DP gradient%s: %s (rel %.1e); "
+          "parameters after 4 optimizer steps bit-equal: %s (rel %.1e): %s" % (exch, 4e-6 * numel, once, " rounded to bf16" if exch == "allreduce_bf16" else "",
+                                                                                bit_g, worst_g, bit_p, worst_p, "OK" if good else "FAILED"), flush=True)
+    del alg, ref
+    torch.cuda.empty_cache()
+
+# ---- auto: the start-up selection on the live backend ----------------------------------------------------------------------------------
+alg, ref = make(True, "auto"), make(False, "allreduce")
+batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+steps, bit_p = 0, True
+while not alg.dp.settled and steps < 40:
+    ga, gr = [], []
+    full_step(alg, batch, ga)
+    full_step(ref, batch, gr)
+    steps += 1
+    torch.cuda.synchronize()
+    bit_p = bit_p and bool(torch.equal(alg.model.flat, ref.model.flat)) and bool(torch.equal(ga[0], gr[0]))
+for _ in range(3):                                        # ... and on the selected exchange
+    ga, gr = [], []
+    full_step(alg, batch, ga)
+    full_step(ref, batch, gr)
+    torch.cuda.synchronize()
+    bit_p = bit_p and bool(torch.equal(alg.model.flat, ref.model.flat)) and bool(torch.equal(ga[0], gr[0]))
+rep = alg.dp.exchange_report or {}
+good = alg.dp.settled and rep.get("chosen") in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap") and "rs_ag_refused" not in rep and bit_p and \
+    "step_ms_exchange_under_backward" in rep and rep["collective_ms"]["rs_ag"] is not None
+ok_all = ok_all and good
+report["auto"] = dict(ok=good, tuning_steps=steps, bit_equal_to_non_dp=bit_p, **{k: v for k, v in rep.items()})
+print("auto: ExchangeTuner settled after %d steps on %s: %s; every step bit-equal to the non-DP instance: %s: %s" % (
+    steps, rep.get("chosen"), json.dumps(rep), bit_p, "OK" if good else "FAILED"), flush=True)
+# ---- bcast -----------------------------------------------------------------------------------------------------------------------------
+n0, c0 = cnt.snap()
+before = [m.flat.clone() for m in (alg.model, alg.rewarder, alg.generator)]
+alg.dp.broadcast_params(alg.model, alg.rewarder, alg.generator)
+torch.cuda.synchronize()
+n1, c1 = cnt.snap()
+good = c1["broadcast"] - c0["broadcast"] == 3 and all(torch.equal(x, m.flat) for x, m in zip(before, (alg.model, alg.rewarder, alg.generator)))
+ok_all = ok_all and good
+report["bcast"] = dict(ok=good, elements=n1["broadcast"] - n0["broadcast"])
+print("bcast: model / rewarder / generator blocks (%d elements) broadcast from rank 0, unchanged: %s" % (n1["broadcast"] - n0["broadcast"], "OK" if good else "FAILED"),
+      flush=True)
+del alg, ref
+torch.cuda.empty_cache()
+
+# ---- reward: global reward threshold -----------------------------------------------------------------------------------------------------
+alg, ref = make(True, "allreduce", global_reward_threshold=True), make(False, "allreduce")
+assert alg.dp.global_reward_threshold
+batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+alg.trace, ref.trace = {}, {}
+n0, c0 = cnt.snap()
+alg.train_step(**batch)
+n1, c1 = cnt.snap()
+ref.train_step(**batch)
+torch.cuda.synchronize()
+r, m2 = alg.trace["reward"].view(8, 8), alg.trace["mask2"].view(8, 8)
+expect = (r >= r.mean(dim=1, keepdim=True)).float()
+good = bool(torch.equal(m2, expect)) and bool(torch.equal(alg.trace["mask2"], ref.trace["mask2"])) and bool(torch.equal(alg.trace["reward"], ref.trace["reward"])) \
+    and (c1["all_reduce"] - c0["all_reduce"]) == 1 and (n1["all_reduce"] - n0["all_reduce"]) == 9 and 0 < float(m2.sum()) < 64
+ok_all = ok_all and good
+report["reward"] = dict(ok=good, packed_floats=n1["all_reduce"] - n0["all_reduce"], rows_kept=int(m2.sum()))
+print("reward: packed (sum per pass, n) all-reduce of %d floats, mask2 == (reward >= global mean) == rank-local mask (one rank), %d of 64 rows kept: %s"
+      % (n1["all_reduce"] - n0["all_reduce"], int(m2.sum()), "OK" if good else "FAILED"), flush=True)
+del alg, ref
+torch.cuda.empty_cache()
+
+# ---- stats: SoftMatch (+ DistAlign) and FreeMatch statistics -----------------------------------------------------------------------------
+report["stats"] = {}
+for name, extra in (("srsoftmatch", dict(dist_align=True, dist_uniform=True, ema_p=0.999, n_sigma=2, per_class=False)),
+                    ("srfreematch", dict(ema_p=0.999, use_quantile=True, clip_thresh=False, ent_loss_ratio=0.001))):
+    algs = []
+    for force in (True, False):
+        ns = dict(bench.NS, algorithm=name, **extra)
+        args = argparse.Namespace(gpu=0, rank=0, world_size=1, distributed=force, force_dp=force, **ns)
+        os.environ["SR_GRAD_EXCHANGE"] = "allreduce"
+        a = get_algorithm(args, vit.vit_small_patch2_32)
+        a.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(a.model.names_shapes, 0).items()})
+        a.model.seed, a.it = 1234, bench.START_IT + 7
+        a.optimizer.sched_step = a.it
+        a.model.train()
+        a.trace = {}
+        algs.append(a)
+    alg, ref = algs
+    bb = {k: v for k, v in b.items() if k != "idx_ulb"}
+    batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in bb.items()})
+    n0, c0 = cnt.snap()
+    for _ in range(2):
+        alg.out_dict, alg.log_dict = alg.train_step(**batch)
+        alg.call_hook("after_train_step")
+    torch.cuda.synchronize()
+    n1, c1 = cnt.snap()
+    for _ in range(2):
+        ref.out_dict, ref.log_dict = ref.train_step(**batch)
+        ref.call_hook("after_train_step")
+    torch.cuda.synchronize()
+    same = all(torch.equal(x, y) for x, y in zip(alg.trace["masks"], ref.trace["masks"])) and torch.equal(alg.model.flat, ref.model.flat)
+    gathered = c1["all_gather"] - c0["all_gather"]
+    good = bool(same) and gathered >= 2 * 9                # one gather per masking call, 1 + K calls per step
+    ok_all = ok_all and good
+    report["stats"][name] = dict(ok=good, all_gather_calls=gathered, small_all_reduce_calls=c1["all_reduce"] - c0["all_reduce"] - 2)
+    print("stats[%s]: %d all_gather + %d all_reduce calls in 2 steps, masks and parameters bit-equal to the non-DP instance: %s" % (
+        name, gathered, c1["all_reduce"] - c0["all_reduce"], "OK" if good else "FAILED"), flush=True)
+    del alg, ref, algs
+    torch.cuda.empty_cache()
+
+# ---- syncbn: WideResNet ------------------------------------------------------------------------------------------------------------------
+rng = np.random.Generator(np.random.PCG64(11))
+B, HW, C = 8, 16, 10
+x = torch.from_numpy(rng.standard_normal((B, 3, HW, HW)).astype(np.float32)).to(dev)
+dl = torch.from_numpy((rng.standard_normal((B, C)) / B).astype(np.float32)).to(dev)
+
+
+def build_wrn():
+    m = wrn.WideResNet(num_classes=C, depth=10, widen_factor=2, first_stride=1, device=dev)
+    m.init_weights(seed=3)
+    m.refresh_operands()
+    m.train()
+    return m
+
+
+loc, syn = build_wrn(), build_wrn()
+syn.dp = DataParallel(1, 0, force=True)
+assert syn.stat_sync and syn.stat_ranks == 1 and not loc.stat_sync
+n0, c0 = cnt.snap()
+outs = []
+for m in (syn, loc):
+    lg, ft, ctx = m.forward_features(x, save=True, update_stats=True, tag="a")
+    m.backward(ctx, dl)
+    lg3, _, _ = m.forward_features(x, save=False, update_stats=False, tag="b", passes=3)
+    m.check_equal_rows()
+    outs.append((lg.clone(), m.grad.clone(), lg3.clone(), {k: v.clone() for k, v in m.buffers.items()}))
+    if m is syn:
+        torch.cuda.synchronize()
+        n1, c1 = cnt.snap()
+torch.cuda.synchronize()
+(la, ga_, l3a, ba), (lb, gb_, l3b, bb_) = outs
+nbn = len(syn.bn)
+calls = c1["all_reduce"] - c0["all_reduce"]
+same = torch.equal(la, lb) and torch.equal(l3a, l3b) and all(torch.equal(ba[k], bb_[k]) for k in ba) and rel(ga_, gb_) < 1e-6
+# forward: one exchange per BatchNorm (the first carries the row-count cells); the 3 shared-launch passes: one per BatchNorm for all passes; backward:
+# one per BatchNorm a gradient flows through (the blocks whose conv1 takes the raw input leave their bn1 without one, wrn.py:50)
+good = bool(same) and 2 * nbn < calls <= 3 * nbn
+report["syncbn"] = dict(ok=good, batchnorms=nbn, all_reduce_calls=calls, logits_equal=bool(torch.equal(la, lb)), shared_pass_logits_equal=bool(torch.equal(l3a, l3b)),
+                        grad_rel=rel(ga_, gb_))
+ok_all = ok_all and good
+print("syncbn: %d BatchNorms, %d statistics exchanges over RCCL (forward, backward, 3 shared-launch passes), logits / running statistics bit-equal to the "
+      "unsynchronised model, gradient rel %.1e: %s" % (nbn, calls, rel(ga_, gb_), "OK" if good else "FAILED"), flush=True)
+
+cnt.restore()
+report["ok"] = bool(ok_all)
+print("RCCL_ONE_RANK " + json.dumps(report), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok_all else 1)
