@@ -359,16 +359,6 @@ class Leg:
 
     def step(self):
         m = self.alg
-        if os.environ.get("SR_MAIN_PRIO", "0") != "0":        # A/B aid: the step's own stream at high priority (the deferred rows' stream stays normal)
-            import torch
-            if getattr(self, "_hi", None) is None:
-                self._hi = torch.cuda.Stream(priority=-1)
-                self._hi.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._hi):
-                m.out_dict, m.log_dict = m.train_step(**self.batch)
-                m.call_hook("after_train_step")
-            m.it += 1
-            return
         if self.graph is not None:         # train_step + ParamUpdateHook as ONE captured HIP graph per step variant (core/stepgraph.py)
             self.graph.step(**self.batch)
         else:

@@ -33,9 +33,6 @@ _SCORE_ON_SIDE = True         # the max_reward scoring launch runs on the side s
 _DEFER_SEED = 0.475           # measured optimum of ViT-S/2 at 8 / 8 / 8, K = 8 on one MI355X; the tuner's middle candidate
 _DEFER_FIXED = float(os.environ["SR_DEFER_FRACTION"]) if "SR_DEFER_FRACTION" in os.environ else None
 _DEFER_AUTOTUNE = _DEFER_FIXED is None
-# The deferred rows of step t may still be running while step t's optimizer and step t + 1 proceed: they read a SNAPSHOT of the parameters taken
-# on their own stream (see SRConsistencyBase._forward_plan).  SR_ASYNC_DEFER=0: the step's end waits for them (the round 1-5 schedule).
-_ASYNC_DEFER = os.environ.get("SR_ASYNC_DEFER", "1") != "0"
 _DEFER_FRACTION = _DEFER_FIXED if _DEFER_FIXED is not None else _DEFER_SEED
 
 
@@ -149,7 +146,7 @@ class _Plan:
 
     @classmethod
     def cat_passes(cls, nl, nu, K, device, extra_pass0_strong=False, lb_every_pass=True, defer_unread=False, rows_per_col=None,
-                   elide_unread=False, defer_fraction=None, read_pass0=False):
+                   elide_unread=False, defer_fraction=None):
         """use_cat layout of SRFlexMatch / SRFixMatch: every pass is cat(x_lb, x_ulb_w, x_ulb_s); gradients flow from the
         labelled rows of pass 0 and the strong rows of the last pass.  lb_every_pass=False (use_cat=False, the usb_nlp / usb_audio
         configs): data_generator forwards only x_ulb_s and x_ulb_w (srflexmatch.py:83-90), so the labelled columns of the passes
@@ -166,9 +163,6 @@ class _Plan:
             skip = sorted(set(skip) | {k * Bt + j for k in range(1, K + 1) for j in range(nl)} |
                           {k * Bt + j for k in range(1, K) for j in range(nl + nu, Bt)})
         read = [k * Bt + j for k in range(K + 1) for j in range(nl, nl + nu)] if defer_unread else None      # the weak rows
-        if read is not None and read_pass0:
-            # the step RETURNS the features of every pass-0 row (feat_dict): when the deferred rows may outlive the step they are read rows too
-            read = sorted(set(read) | set(range(Bt)))
         p = cls(cols_img, grad, device, skip, read, rows_per_col, defer_fraction)
         p.P, p.Bt = K + 1, Bt
         return p
@@ -209,17 +203,9 @@ class SRConsistencyBase(AlgorithmBase):
         self.elide_unread_rows = bool(getattr(args, "elide_unread_rows", os.environ.get("SR_ELIDE_UNREAD_ROWS", "0") != "0"))
         self._rest_done = None
         self._grad_pending = None
-        # asynchronous deferred rows (ViT engines: the backbone hands out a parameter snapshot): a third stream of their own; the step's end waits
-        # only for the snapshot copy, not for the rows
-        self.async_deferred = self.defer_unread_rows and bool(getattr(args, "async_deferred_rows", _ASYNC_DEFER)) and \
-            hasattr(self.model, "param_snapshot")
-        self._defer_stream = torch.cuda.Stream(device=self.device) if self.async_deferred else None
-        self._snap_done = None
-        self._defer_imgs = None
         self._phases = []
         self.inject_droppath = None            # tests: list of [depth,2,Bt] tensors, one per pass
         self.trace = None                      # tests: dict filled with per-pass intermediates when not None
-        self.keep_tables = None                # tests: list that receives every step's (logits, features) tables of ALL (pass, image) rows
 
     def _init_thresholds(self, args):
         raise NotImplementedError
@@ -303,34 +289,6 @@ class SRConsistencyBase(AlgorithmBase):
                 grad_done.record(side)
                 if _PHASES:
                     self._phase_mark("side:grad_rows_forwarded")
-            if nr and self._async_now(imgs, capturing):
-                # The deferred rows on a stream of their own, reading a SNAPSHOT of the parameters (and of the step's images) taken on that
-                # stream: nothing of this step or the next waits for the rows themselves -- the optimizer only waits for the snapshot copy
-                # (_join_deferred), and the stream's order keeps the next step's snapshot behind this step's rows, so the rows of step t are
-                # done before the optimizer of step t + 1 runs.  Same launches, same parameters, same results; what changes is that the chip
-                # always has a backlog of whole-CU workgroups to fill the slots the critical chain leaves idle.
-                ds = self._defer_stream
-                for t_ in (logits, feats, dp_rest, imgs, pl.rest_img, pl.rest_cols):
-                    if torch.is_tensor(t_):
-                        t_.record_stream(ds)
-                ds.wait_event(ready)
-                with torch.cuda.stream(ds), ops.stream_scope():
-                    snap = m.param_snapshot()
-                    snap[0].copy_(m.flat, non_blocking=True)
-                    snap[1].copy_(m.flat_bf16, non_blocking=True)
-                    if self._defer_imgs is None or self._defer_imgs.shape != imgs.shape:
-                        self._defer_imgs = torch.empty_like(imgs)
-                    self._defer_imgs.copy_(imgs, non_blocking=True)
-                    self._snap_done = torch.cuda.Event()
-                    self._snap_done.record(ds)
-                    m.forward_features(self._defer_imgs, pl.rest_img, dp_rest, save=False, buftag="a", out=(logits, feats, pl.rest_cols), params=snap)
-                    self._rest_done = torch.cuda.Event()
-                    self._rest_done.record(ds)
-                    if _PHASES:
-                        self._phase_mark("side:deferred_rows_done")
-                self._rest_async = True
-                self._grad_pending = (grad_done, lg_g, ft_g, logits, feats, None if scatter else pl.grad_cols)
-                return logits, feats, ctx
             with torch.cuda.stream(side), ops.stream_scope():
                 if nr:
                     # Rows whose outputs nothing reads before the step ends (strong / labelled rows of the passes whose loss the
@@ -399,27 +357,11 @@ class SRConsistencyBase(AlgorithmBase):
                 i += 1
         return {k: (sum(g[-10:]) / len(g[-10:]), sum(h[-10:]) / len(h[-10:])) for k, (g, h) in out.items()}
 
-    def _async_now(self, imgs, capturing):
-        """This step's deferred rows may outlive it: not while a test reads every row (trace), not inside a graph capture (a captured step must
-        rejoin its streams), only for plain image tensors and a scattering head."""
-        return self.async_deferred and self.trace is None and not capturing and torch.is_tensor(imgs) and getattr(self.model, "scatter_outputs", False)
-
     def _join_deferred(self):
-        """The step is complete (and the parameters may change) only when the deferred rows are done -- or, when they run on their own stream
-        off a parameter snapshot, when that snapshot has been taken."""
-        if getattr(self, "_rest_async", False):
-            self._rest_async = False
-            torch.cuda.current_stream().wait_event(self._snap_done)
-            return
+        """The step is complete (and the parameters may change) only when the deferred rows are done."""
         if self._rest_done is not None:
             torch.cuda.current_stream().wait_event(self._rest_done)
             self._rest_done = None
-
-    def drain_deferred(self):
-        """Everything the deferred stream still holds is done when the CURRENT stream passes this point (evaluate(), a checkpoint, a test that
-        reads the rows nothing else reads)."""
-        if self._rest_done is not None:
-            torch.cuda.current_stream().wait_event(self._rest_done)
 
     graph_safe = False         # core/stepgraph.py: the step keeps no per-step state in Python objects (set by the subclasses that qualify)
 
@@ -446,7 +388,7 @@ class SRConsistencyBase(AlgorithmBase):
         return _Plan.cat_passes(nl, nu, K, self.device, extra_pass0_strong=self.fairness_rows and K > 0,
                                 lb_every_pass=bool(self.use_cat), defer_unread=self.defer_unread_rows,
                                 rows_per_col=getattr(self.model.cfg, "num_tokens", None),
-                                elide_unread=self.elide_unread_rows, defer_fraction=defer_fraction, read_pass0=self.async_deferred)
+                                elide_unread=self.elide_unread_rows, defer_fraction=defer_fraction)
 
     def _forward_passes(self, imgs, nl, nu, K):
         key = (nl, nu, K, bool(self.use_cat), self.elide_unread_rows)
@@ -502,8 +444,6 @@ class SRConsistencyBase(AlgorithmBase):
         pl = self._plans[key]
         dpc = torch.cat([d for d in self.inject_droppath[:pl.P]], dim=2) if self.inject_droppath is not None else None
         logits, feats, ctx = self._forward_plan(imgs, pl, dpc)
-        if self.keep_tables is not None:
-            self.keep_tables.append((logits, feats))
         return logits.view(pl.P, pl.Bt, -1), feats.view(pl.P, pl.Bt, -1), ctx
 
     def _sr_update(self, feats, gen_labels, ref_labels):

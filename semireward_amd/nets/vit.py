@@ -121,7 +121,7 @@ class VisionTransformer(ModuleSurface):
         """Flat view of parameter ``name`` inside ``buf`` (default: the parameter block).  Cached per (name, buffer): building a slice view costs
         ~3 us of host time and a step asks for ~500 of them -- more than half of the step's enqueue time before the cache."""
         b = self.flat if buf is None else buf
-        if not (b is self.flat or b is self.grad or b is getattr(self, "flat_bf16", None) or id(b) in self.__dict__.get("_snap_ids", ())):
+        if not (b is self.flat or b is self.grad or b is getattr(self, "flat_bf16", None)):
             o, s = self.offsets[name]                     # some other block (optimizer state, a test's copy): no entry is kept for it
             return b[o:o + int(torch.Size(s).numel())]
         pv = self.__dict__.setdefault("_pviews", {})
@@ -133,16 +133,6 @@ class VisionTransformer(ModuleSurface):
 
     def view(self, name, buf=None):
         return self.p(name, buf).view(self.offsets[name][1])
-
-    def param_snapshot(self):
-        """(fp32 block, bf16 operand block): a second home for the parameters a forward READS, allocated once.  A launch train that may still be
-        running when the optimizer rewrites the live blocks (the deferred rows of a step, srflexmatch._forward_plan) is handed these through
-        forward_features(params=...) after copying the live blocks into them on its own stream."""
-        sn = self.__dict__.get("_snap")
-        if sn is None:
-            sn = self._snap = (torch.empty_like(self.flat), torch.empty_like(self.flat_bf16))
-            self._snap_ids = {id(t) for t in sn}
-        return sn
 
     def named_parameters(self):
         return [(n, self.view(n)) for n, _ in self.names_shapes]
@@ -264,9 +254,8 @@ class VisionTransformer(ModuleSurface):
         return ctx
 
     # ---- forward ----------------------------------------------------------------------------------
-    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None, buftag="", out=None, params=None):
+    def forward_features(self, img, img_index=None, droppath=None, save=False, B=None, buftag="", out=None):
         """img fp32 [n_img, C, H, W]; img_index int32 [B] (optional gather); droppath fp32 [depth,2,B] or None.
-        params: (fp32 block, bf16 block) to read the parameters from instead of the live blocks (param_snapshot; inference rows only).
         Returns (logits [B,C], feat [B,D], ctx or None)."""
         cfg = self.cfg
         D, N, H, Hd, C = cfg.embed_dim, cfg.num_tokens, cfg.num_heads, cfg.hidden, cfg.num_classes
@@ -291,10 +280,6 @@ class VisionTransformer(ModuleSurface):
         qkvx = self._buf(tag + "qkvx", (B, 3 * D), bf16) if (fused_attn and N == 257) else None
         wb = self.flat_bf16
         P = self.p
-        if params is not None:
-            assert not save, "a saved forward (backward operands) reads the live parameters"
-            f32b, wb = params
-            P = lambda n, buf=None: self.p(n, f32b if buf is None else buf)   # noqa: E731
         Kp = cfg.in_chans * cfg.patch_size ** 2
         if Kp <= 64:                                # CIFAR-style 2x2 / 4x4 patches: direct fp32 kernel
             ops.patch_embed_fwd(img, img_index, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("cls_token"),

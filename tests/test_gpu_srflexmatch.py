@@ -576,44 +576,6 @@ def test_every_pass_image_row_is_computed(monkeypatch):
         assert torch.equal(lg.cpu(), L0[k, rows].cpu()), k
 
 
-def test_asynchronous_deferred_rows_read_the_parameters_of_their_own_step():
-    """The rows nothing reads may still be running when their step's optimizer rewrites the parameters and the next step starts (they run on a
-    stream of their own off a parameter snapshot, SRConsistencyBase._forward_plan).  Five full steps (train_step + AdamW, crossing a rewarder
-    update) with that schedule and with the step-end join of rounds 1-5: the logits / feature tables of EVERY (pass, image) row of every step --
-    the deferred rows included --, the parameters and the FlexMatch state are identical."""
-    NSa = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, ulb_dest_len=50000, start_timing=20000, feature_dim=384,
-               num_warmup_iter=5120)
-    b = synth.synth_batch(105, 8, 8, 32, 100, 50000)
-    runs = []
-    for asynchronous in (True, False):
-        alg = get_algorithm(make_args(async_deferred_rows=asynchronous, **NSa), vit.vit_small_patch2_32)
-        assert alg.async_deferred == asynchronous
-        alg.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(alg.model.names_shapes, 0).items()})
-        alg.model.seed = 77
-        alg.it = 30007
-        alg.optimizer.sched_step = alg.it
-        alg.defer_share = 0.5                    # a pinned split (no tuning steps); both runs defer the same kind of rows
-        alg.keep_tables = []
-        batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
-        for _ in range(5):
-            alg.out_dict, alg.log_dict = alg.train_step(**batch)
-            alg.call_hook("after_train_step")
-            alg.it += 1
-        torch.cuda.synchronize()
-        pl = next(iter(alg._plans.values()))
-        assert pl.rest_cols.numel() > 60
-        if asynchronous:                         # the step returns pass 0's features: none of its rows may be deferred
-            assert int(pl.rest_cols.min()) >= 24
-        h = alg.hooks_dict["MaskingHook"]
-        runs.append(([(l.clone(), f.clone()) for l, f in alg.keep_tables], alg.model.flat.clone(), h.classwise_acc.clone(), h.selected_label.clone(),
-                     alg.rewarder.flat.clone()))
-    (ta, pa, ca, sa, ra), (tb, pb, cb, sb, rb) = runs
-    assert len(ta) == len(tb) == 5
-    for (la, fa), (lb, fb) in zip(ta, tb):
-        assert torch.isfinite(la).all() and torch.equal(la, lb) and torch.equal(fa, fb)
-    assert torch.equal(pa, pb) and torch.equal(ca, cb) and torch.equal(sa, sb) and torch.equal(ra, rb)
-
-
 def test_deferred_share_autotune_picks_a_candidate_and_changes_no_result():
     """srflexmatch._DeferTuner: in the first steps of a regime every candidate share of deferred inference rows runs WARM + TIMED real training
     steps; afterwards the median-fastest one is kept.  The split is pure scheduling: the logits / masks / losses of a step under ANY candidate equal
