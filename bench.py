@@ -536,6 +536,17 @@ class Leg:
         return roof
 
 
+def _order_config(out):
+    """The driver's record keeps the first ~25 scalar keys of ``config``: the workload's identity first, then ONE summary string per leg (the three
+    BASELINE.json configs lead), then the legs' numbers, then the rest."""
+    cfg = out["config"]
+    first = [k for k in ("workload", "algorithm", "bl", "bu_w", "bu_s", "K_passes", "parallelism") if k in cfg]
+    summ = [k for k in cfg if k.startswith("leg_") and k.endswith("_summary")]
+    nums = [k for k in cfg if k.startswith("leg_") and not k.endswith("_summary")]
+    rest = [k for k in cfg if k not in first and not k.startswith("leg_")]
+    out["config"] = {k: cfg[k] for k in first + summ + nums + rest}
+
+
 def worker(a):
     import torch
     import torch.distributed as dist
@@ -611,11 +622,13 @@ def worker(a):
         also = out["also"] = []                          # (filled in place: a truncated line carries the legs that finished)
         # (BASELINE.json configs[3] and [4] -- the usb_nlp BERT-base and usb_audio Wav2Vec2-base + FreeMatch steps -- ride along with their own
         # metric names and fewer steps; a leg that fails is reported as such and never costs the line)
-        legs = (("vit_s16_224", dict(img=224), max(4, a.steps // 2), True), ("scaled_batch_bu64", dict(bu=64), max(4, a.steps // 2), True),
-                ("pre_start_timing_K0", dict(regime="pre"), max(4, a.steps // 2), True),
-                ("classic_cv_wrn_28_2_srpseudolabel", dict(net="wrn", bu=64), max(4, a.steps // 2), True),
+        # order: the BASELINE.json configs first (configs[0] WRN, [3] BERT, [4] Wav2Vec2), so that a line cut short by the watchdog -- and the flat
+        # ``leg_*`` keys the driver's record keeps from ``config`` -- carry them before the north_star's secondary ViT workloads
+        legs = (("classic_cv_wrn_28_2_srpseudolabel", dict(net="wrn", bu=64), max(4, a.steps // 2), True),
                 ("usb_nlp_bert_base_srsoftmatch", dict(net="bert"), max(3, a.steps // 5), True),
-                ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), True))
+                ("usb_audio_wave2vecv2_base_srfreematch", dict(net="wave2vec", alg="srfreematch"), max(3, a.steps // 5), True),
+                ("vit_s16_224", dict(img=224), max(4, a.steps // 2), True), ("scaled_batch_bu64", dict(bu=64), max(4, a.steps // 2), True),
+                ("pre_start_timing_K0", dict(regime="pre"), max(4, a.steps // 2), True))
         only = [t for t in a.legs.split(",") if t]        # (--legs: a subset of the secondary legs)
         for tag, kw, nsteps, roof in legs:
             if only and tag not in only:
@@ -639,9 +652,12 @@ def worker(a):
                 also.append(keep)
                 # the driver keeps the scalar keys of `config`: every leg's value / ms / roofline rides there as flat keys
                 rf = keep.get("roofline", {})
-                out["config"].update({"leg_%s_value" % tag: keep["value"], "leg_%s_unit" % tag: keep["unit"],
-                                      "leg_%s_ms_per_step" % tag: keep["ms_per_step"], "leg_%s_roofline_frac" % tag: rf.get("frac"),
-                                      "leg_%s_roofline_bound" % tag: rf.get("bound"), "leg_%s_roofline_kernel" % tag: rf.get("kernel")})
+                out["config"].update({"leg_%s_summary" % tag: "%.1f %s, %.3f ms/step, dominant kernel %s at %s of the %s roof" % (
+                                          keep["value"], keep["unit"], keep["ms_per_step"], rf.get("kernel"),
+                                          ("%.3f" % rf["frac"]) if rf.get("frac") is not None else "n/a", rf.get("bound")),
+                                      "leg_%s_value" % tag: keep["value"], "leg_%s_ms_per_step" % tag: keep["ms_per_step"],
+                                      "leg_%s_roofline_frac" % tag: rf.get("frac")})
+                _order_config(out)
             except Exception as e:                       # noqa: BLE001
                 also.append({"leg": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
                 out["config"]["leg_%s_error" % tag] = "%s: %s" % (type(e).__name__, str(e)[:200])

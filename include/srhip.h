@@ -529,6 +529,10 @@ long long srhip_bn_ws_doubles(void);
  *   bn_stats    : the statistics of a tensor no wrn_conv_bn produced: mean / invstd / running update of x fp32 [rows, C] (ws as for bn_fwd).
  *   bn_act      : act bf16 [rows, C] = f(x) by modes 0-2 -- the backward's im2col operand, recomputed instead of stored. */
 int srhip_wrn_conv_supported(int Cin, int Cout, int ksize);
+/* Diagnostic (no reference counterpart): the kernel template the last srhip_wrn_conv_bn[_passes] call of this process launched -- 100 + 10 NT + PG
+ * for wrn_conv_tile_kernel<NT, PG> (input block in LDS), 10 NT + KS for wrn_conv_kernel<NT, KS>; 0 before the first call.  bench.py names the
+ * kernel of the WideResNet leg's roofline object with it. */
+int srhip_wrn_conv_last_plan(void);
 long long srhip_bn_acc_doubles(int C);
 int srhip_wrn_conv_bn(const float* xin, int in_mode, const float* in_mean, const float* in_isd, const double* in_acc, const float* in_gamma,
                       const float* in_beta, float in_eps, float slope, float* pub_mean, float* pub_invstd, float* running_mean,

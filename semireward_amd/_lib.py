@@ -100,6 +100,7 @@ SIGNATURES = {
     "srhip_conv_weight_flip_grouped": (I, [P, I, c_longlong, P]),
     "srhip_bn_ws_doubles": (ctypes.c_longlong, []),
     "srhip_wrn_conv_supported": (I, [I, I, I]),
+    "srhip_wrn_conv_last_plan": (I, []),
     "srhip_bn_acc_doubles": (ctypes.c_longlong, [I]),
     "srhip_wrn_conv_bn": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, I, I, P, I, P]),
     "srhip_wrn_head": (I, [P, I, P, P, P, P, P, F, F, P, P, P, P, F, I, P, P, P, P, I, I, I, I, I, P]),

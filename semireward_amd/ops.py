@@ -101,6 +101,8 @@ class _GemmProfile:
         e0.record()
         _call(name, *args)
         e1.record()
+        if callable(kernel):                # the dispatcher's choice, asked after the launch
+            kernel = kernel()
         self.recs.append((e0, e1, flops, kernel, nbytes, i0, _lib.lib().srhip_prof_count()))
 
     _KERNEL = {"tile128": "gemm_nt_kernel<%d>", "small64": "gemm_small_kernel<%d>", "big256": "gemm_big_kernel<%d, 8, 2>",
@@ -699,6 +701,12 @@ def bn_acc_doubles(C):
     return int(lib().srhip_bn_acc_doubles(C))
 
 
+def wrn_conv_last_kernel():
+    """Name of the kernel template the last srhip_wrn_conv_bn[_passes] call launched (srhip_wrn_conv_last_plan)."""
+    c = int(_lib.lib().srhip_wrn_conv_last_plan())
+    return "wrn_conv_tile_kernel<%d, %d>" % ((c - 100) // 10, c % 10) if c >= 100 else "wrn_conv_kernel<%d, %d>" % (c // 10, c % 10)
+
+
 def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope, Wb, resid, y, B, H, W, Cin, Cout, ksize, stride, Kpad,
                 publish=None, running=None, momentum=0.0, update_running=False, acc_out=None, stat_ranks=1, passes=1):
     """y = conv(f(xin)) (+ resid).  in_mode 0: in_stats = (mean, invstd); 1: (running_mean, running_var); 2: raw; 3: statistics folded from
@@ -714,7 +722,7 @@ def wrn_conv_bn(xin, in_mode, in_stats, in_acc, in_gamma, in_beta, in_eps, slope
     if _PROFILE is not None:
         npix = y.shape[0]                   # (all passes)
         # algorithmic work: the convolution's MACs; bytes: the fp32 input once, the fp32 output (+ residual) once, the filter once
-        _PROFILE.timed("srhip_wrn_conv_bn_passes", args, 2.0 * npix * Cin * ksize * ksize * Cout, "wrn_conv_kernel",
+        _PROFILE.timed("srhip_wrn_conv_bn_passes", args, 2.0 * npix * Cin * ksize * ksize * Cout, wrn_conv_last_kernel,
                        4.0 * passes * B * H * W * Cin + 4.0 * npix * Cout * (2 if resid is not None else 1) + 2.0 * Cout * Kpad)
         return
     _call("srhip_wrn_conv_bn_passes", *args)

@@ -5,9 +5,11 @@
 Sections:
   grad      the five pinned gradient exchanges (allreduce | rs_ag in place | overlap | rs_ag_overlap | allreduce_bf16) on the real 85.7 MB block
             inside real SRFlexMatch steps (ViT-S/2, 100 classes, 8 / 8 / 8, K = 8), side by side with a non-data-parallel instance that steps
-            in lockstep: the exchanged gradient and the parameters after every optimizer step against the other instance's, bit for bit (the
-            bf16 exchange: against the other instance's gradient rounded to bf16), and every element of the block travels exactly ONCE per step
-            (the collectives are counted at the torch.distributed entry points -- with one rank a range reduced twice has the same VALUE);
+            in lockstep: the block behind the exchange == the block in front of it, BIT FOR BIT (bf16 exchange: == that block rounded to bf16;
+            the exchanges under the backward have no "in front": their result is compared with the other instance's gradient), the exchanged
+            gradient and the parameters after every optimizer step against the other instance's (<= 1e-6: the backward's LayerNorm / patch
+            atomics are not run-to-run deterministic at 1e-9, with or without data parallel), and every element of the block travels exactly
+            ONCE per step (counted at the torch.distributed entry points -- with one rank a range reduced twice has the same VALUE);
   auto      SR_GRAD_EXCHANGE=auto: ExchangeTuner through all of its phases on RCCL until settled, no refusal of the reduce-scatter form;
   bcast     broadcast_params of model / rewarder / generator;
   reward    the global reward threshold (packed (sum, n) all-reduce per step, reward_means) against the rank-local mean;
@@ -96,22 +98,33 @@ def make(force, exchange=None, **kw):
     return alg
 
 
-def full_step(alg, batch, grab):
-    """train_step + ParamUpdateHook; ``grab``: list that receives the gradient block as the optimizer is about to read it."""
+def full_step(alg, batch, grab, ident=None):
+    """train_step + ParamUpdateHook; ``grab``: list that receives the gradient block as the optimizer is about to read it; ``ident``: list that
+    receives (block in front of the exchange, block behind it) when the exchange runs after the backward."""
     real = alg.optimizer.step
 
     def step(*a, **k):
         grab.append(alg.model.grad.clone())
         return real(*a, **k)
     alg.optimizer.step = step
+    real_x = alg.dp._all_reduce_grads
+    if ident is not None:
+        def exchange(model):
+            pre = model.grad.clone()
+            real_x(model)
+            ident.append((pre, model.grad.clone()))
+        alg.dp._all_reduce_grads = exchange
     try:
         alg.out_dict, alg.log_dict = alg.train_step(**batch)
         alg.call_hook("after_train_step")
     finally:
         alg.optimizer.step = real
+        if ident is not None:
+            del alg.dp._all_reduce_grads
     alg.it += 1
 
 
+TOL = 1e-6
 ok_all = True
 b = synth.synth_batch(100, 8, 8, 32, 100, 50000)
 # ---- grad: the five pinned exchanges -----------------------------------------------------------------------------------------------
@@ -123,60 +136,63 @@ for exch in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap", "allreduce_bf16")
     batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
     numel = alg.model.grad.numel()
     worst_g = worst_p = 0.0
-    once = True
-    bit_g = bit_p = True
+    once, exact = True, True
+    under = exch.endswith("overlap")
     for step in range(4):                                 # it = 30007 .. 30010: the last one carries a rewarder update (its gradient is all-reduced too)
         n0, c0 = cnt.snap()
-        ga, gr = [], []
-        full_step(alg, batch, ga)
+        ga, gr, idt = [], [], (None if under else [])
+        full_step(alg, batch, ga, idt)
         full_step(ref, batch, gr)
         torch.cuda.synchronize()
         n1, c1 = cnt.snap()
-        want = gr[0].to(torch.bfloat16).float() if exch == "allreduce_bf16" else gr[0]
-        worst_g = max(worst_g, rel(ga[0], want))
-        bit_g = bit_g and bool(torch.equal(ga[0], want))
-        worst_p = max(worst_p, rel(alg.model.flat, ref.model.flat))
-        bit_p = bit_p and bool(torch.equal(alg.model.flat, ref.model.flat))
+        if idt is not None:                               # sum over ONE rank = identity, exactly (bf16 exchange: the rounding to bf16, exactly)
+            pre, post = idt[0]
+            exact = exact and bool(torch.equal(post, pre.to(torch.bfloat16).float() if exch == "allreduce_bf16" else pre))
+        if exch != "allreduce_bf16" or step == 0:          # (a bf16-rounded gradient moves the parameters: later steps are other steps)
+            want = gr[0].to(torch.bfloat16).float() if exch == "allreduce_bf16" else gr[0]
+            worst_g = max(worst_g, rel(ga[0], want))
+            worst_p = max(worst_p, rel(alg.model.flat, ref.model.flat))
         rew = alg.rewarder.grad.numel() if (alg.it - 1) % alg.N_k == 0 else 0
         moved_ar = n1["all_reduce"] - n0["all_reduce"] - rew
         moved_rs = n1["reduce_scatter_tensor"] - n0["reduce_scatter_tensor"]
         moved_ag = n1["all_gather_into_tensor"] - n0["all_gather_into_tensor"]
         once = once and (moved_ar + moved_rs == numel) and (moved_ag == moved_rs) and (("rs_ag" in exch) == (moved_rs > 0))
-    tol_p = 1e-2 if exch == "allreduce_bf16" else 0.0      # (a bf16-rounded gradient moves Adam's normalised update; not the reference's DDP)
-    good = once and (bit_g if exch != "allreduce_bf16" else worst_g == 0.0) and (worst_p <= tol_p) and alg.dp.exchange_report.get("chosen") == exch
+    tol_g, tol_p = (1e-4, 1e-3) if exch == "allreduce_bf16" else (TOL, TOL)      # (bf16: values on a rounding boundary may fall the other way)
+    good = once and exact and worst_g <= tol_g and worst_p <= tol_p and alg.dp.exchange_report.get("chosen") == exch
     ok_all = ok_all and good
-    report["grad"][exch] = dict(ok=good, every_element_exactly_once=once, grad_bit_equal=bit_g, params_bit_equal=bit_p, grad_rel=worst_g,
+    report["grad"][exch] = dict(ok=good, every_element_exactly_once=once, exchange_is_exact=(None if under else exact), grad_rel=worst_g,
                                 params_rel=worst_p, steps=4, block_bytes=4 * numel)
-    print("grad[%s]: every element of the %.1f MB block exactly once per step: %s; exchanged gradient == non-DP gradient%s: %s (rel %.1e); "
-          "parameters after 4 optimizer steps bit-equal: %s (rel %.1e): %s" % (exch, 4e-6 * numel, once, " rounded to bf16" if exch == "allreduce_bf16" else "",
-                                                                                bit_g, worst_g, bit_p, worst_p, "OK" if good else "FAILED"), flush=True)
+    print("grad[%s]: every element of the %.1f MB block exactly once per step: %s; block behind the exchange == block in front of it%s: %s; "
+          "gradient vs the non-DP instance rel %.1e, parameters after the optimizer steps rel %.1e: %s" % (
+              exch, 4e-6 * numel, once, " rounded to bf16" if exch == "allreduce_bf16" else "", "(under the backward: n/a)" if under else exact,
+              worst_g, worst_p, "OK" if good else "FAILED"), flush=True)
     del alg, ref
     torch.cuda.empty_cache()
 
 # ---- auto: the start-up selection on the live backend ----------------------------------------------------------------------------------
 alg, ref = make(True, "auto"), make(False, "allreduce")
 batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
-steps, bit_p = 0, True
+steps, worst = 0, 0.0
 while not alg.dp.settled and steps < 40:
     ga, gr = [], []
     full_step(alg, batch, ga)
     full_step(ref, batch, gr)
     steps += 1
     torch.cuda.synchronize()
-    bit_p = bit_p and bool(torch.equal(alg.model.flat, ref.model.flat)) and bool(torch.equal(ga[0], gr[0]))
+    worst = max(worst, rel(alg.model.flat, ref.model.flat), rel(ga[0], gr[0]))
 for _ in range(3):                                        # ... and on the selected exchange
     ga, gr = [], []
     full_step(alg, batch, ga)
     full_step(ref, batch, gr)
     torch.cuda.synchronize()
-    bit_p = bit_p and bool(torch.equal(alg.model.flat, ref.model.flat)) and bool(torch.equal(ga[0], gr[0]))
+    worst = max(worst, rel(alg.model.flat, ref.model.flat), rel(ga[0], gr[0]))
 rep = alg.dp.exchange_report or {}
-good = alg.dp.settled and rep.get("chosen") in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap") and "rs_ag_refused" not in rep and bit_p and \
+good = alg.dp.settled and rep.get("chosen") in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap") and "rs_ag_refused" not in rep and worst <= TOL and \
     "step_ms_exchange_under_backward" in rep and rep["collective_ms"]["rs_ag"] is not None
 ok_all = ok_all and good
-report["auto"] = dict(ok=good, tuning_steps=steps, bit_equal_to_non_dp=bit_p, **{k: v for k, v in rep.items()})
-print("auto: ExchangeTuner settled after %d steps on %s: %s; every step bit-equal to the non-DP instance: %s: %s" % (
-    steps, rep.get("chosen"), json.dumps(rep), bit_p, "OK" if good else "FAILED"), flush=True)
+report["auto"] = dict(ok=good, tuning_steps=steps, worst_rel_vs_non_dp=worst, **{k: v for k, v in rep.items()})
+print("auto: ExchangeTuner settled after %d steps on %s: %s; gradient and parameters of every step vs the non-DP instance rel <= %.1e: %s" % (
+    steps, rep.get("chosen"), json.dumps(rep), worst, "OK" if good else "FAILED"), flush=True)
 # ---- bcast -----------------------------------------------------------------------------------------------------------------------------
 n0, c0 = cnt.snap()
 before = [m.flat.clone() for m in (alg.model, alg.rewarder, alg.generator)]
@@ -232,22 +248,25 @@ for name, extra in (("srsoftmatch", dict(dist_align=True, dist_uniform=True, ema
     bb = {k: v for k, v in b.items() if k != "idx_ulb"}
     batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in bb.items()})
     n0, c0 = cnt.snap()
-    for _ in range(2):
-        alg.out_dict, alg.log_dict = alg.train_step(**batch)
-        alg.call_hook("after_train_step")
-    torch.cuda.synchronize()
-    n1, c1 = cnt.snap()
-    for _ in range(2):
-        ref.out_dict, ref.log_dict = ref.train_step(**batch)
-        ref.call_hook("after_train_step")
-    torch.cuda.synchronize()
-    same = all(torch.equal(x, y) for x, y in zip(alg.trace["masks"], ref.trace["masks"])) and torch.equal(alg.model.flat, ref.model.flat)
+    first = []
+    for a_ in (alg, ref):
+        for i_ in range(2):
+            a_.out_dict, a_.log_dict = a_.train_step(**batch)
+            if i_ == 0:
+                torch.cuda.synchronize()
+                first.append([m_.clone() for m_ in a_.trace["masks"]])
+            a_.call_hook("after_train_step")
+        torch.cuda.synchronize()
+        if a_ is alg:
+            n1, c1 = cnt.snap()
+    same = all(torch.equal(x, y) for x, y in zip(*first)) and rel(alg.model.flat, ref.model.flat) <= TOL
     gathered = c1["all_gather"] - c0["all_gather"]
     good = bool(same) and gathered >= 2 * 9                # one gather per masking call, 1 + K calls per step
     ok_all = ok_all and good
-    report["stats"][name] = dict(ok=good, all_gather_calls=gathered, small_all_reduce_calls=c1["all_reduce"] - c0["all_reduce"] - 2)
-    print("stats[%s]: %d all_gather + %d all_reduce calls in 2 steps, masks and parameters bit-equal to the non-DP instance: %s" % (
-        name, gathered, c1["all_reduce"] - c0["all_reduce"], "OK" if good else "FAILED"), flush=True)
+    report["stats"][name] = dict(ok=good, all_gather_calls=gathered, all_reduce_calls=c1["all_reduce"] - c0["all_reduce"],
+                                 params_rel=rel(alg.model.flat, ref.model.flat))
+    print("stats[%s]: %d all_gather + %d all_reduce calls in 2 steps, the 9 masks of the first step bit-equal to the non-DP instance's, parameters rel %.1e: %s" % (
+        name, gathered, c1["all_reduce"] - c0["all_reduce"], rel(alg.model.flat, ref.model.flat), "OK" if good else "FAILED"), flush=True)
     del alg, ref, algs
     torch.cuda.empty_cache()
 
