@@ -331,7 +331,8 @@ class Leg:
         # slow or oversubscribed host); on one MI355X with its own host the step is GPU-bound (1.9 ms of enqueue per 4.9 ms step, replay
         # 5.32 vs 5.23 ms eager) and eager launches stay.  1 / 0 force it.
         self.graph, self.graph_mode = None, os.environ.get("SR_HIP_GRAPH", "auto")
-        self.graph_ok = getattr(m, "graph_safe", False) and not self.dp_on and net == "vit"
+        # (data parallel: train_step is replayed, the gradient exchange + the one optimizer launch follow eagerly -- core/stepgraph.py _split)
+        self.graph_ok = getattr(m, "graph_safe", False) and net == "vit"
         if self.graph_mode not in ("auto", "0") and self.graph_ok:
             self._enable_graph()
         self.workload += "steady SR regime" if regime == "sr" else "pre-start_timing regime"
@@ -411,7 +412,8 @@ class Leg:
         # ... and the capture of the step's HIP graphs: every variant that occurs in the steady regime (with / without the SemiReward update of
         # every N_k-th step) is run eagerly once and captured at its next occurrence
         cap_steps = 0
-        while self.graph is not None and len(self.graph.graphs) < (2 if self.regime == "sr" else 1) and cap_steps < 3 * NS["N_k"]:
+        # (data parallel: the variant with the rewarder update -- a collective inside train_step -- stays eager, one variant is captured)
+        while self.graph is not None and len(self.graph.graphs) < (2 if (self.regime == "sr" and not self.dp_on) else 1) and cap_steps < 3 * NS["N_k"]:
             self.step()
             cap_steps += 1
         for _ in range(warmup):

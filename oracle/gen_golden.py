@@ -1569,8 +1569,9 @@ def full_hook_state(batch_idx):
     return sel0, st0.classwise_acc.copy()
 
 
-def run_full_step(tr, it, bseed):
-    """ONE reference train_step + backward at full size from the fixed state.  Returns (fixture dict with keys relative to the step, margin)."""
+def run_full_step(tr, it, bseed, masks_only=False):
+    """ONE reference train_step + backward at full size from the fixed state.  Returns (fixture dict with keys relative to the step, margin).
+    masks_only: no backward, no gradient samples (gen_sweep_full: what the score filter decided, for every batch of the sweep)."""
     C, Bl, Bu = tr["C"], tr["Bl"], tr["Bu"]
     cfg = V.VitCfg(num_classes=C, **V.VIT_SMALL_P2_32)
     Fd = cfg.embed_dim
@@ -1624,10 +1625,11 @@ def run_full_step(tr, it, bseed):
     del alg.rewarder.forward
     alg.consistency_loss = closs
     assert alg.model.calls == K + 1
-    o["loss"].backward()                       # ParamUpdateHook.after_train_step (param_update.py:33)
     out = {}
-    for nme, prm in model.named_parameters():
-        flat(f"grad/{nme}", samp(prm.grad.numpy(), 256), out)
+    if not masks_only:
+        o["loss"].backward()                   # ParamUpdateHook.after_train_step (param_update.py:33)
+        for nme, prm in model.named_parameters():
+            flat(f"grad/{nme}", samp(prm.grad.numpy(), 256), out)
     out["lr_factor"] = np.float64(alg.scheduler.get_last_lr()[-1] / tr["lr"])
     for k_, v in log.items():
         out[f"log/{k_.split('/')[-1]}"] = np.float64(v)
@@ -1658,6 +1660,30 @@ def run_full_step(tr, it, bseed):
     return out, margin
 
 
+SWEEP_KEYS = ("K", "bseed", "dp_seed0", "masks", "mask_probs", "mask_thr", "pseudo_label", "label_gap", "reward", "mask2", "sel_after_batch",
+              "n_selected_after", "log/sup_loss", "log/unsup_loss", "log/util_ratio")
+
+
+def gen_sweep_full(fname="srflexmatch_full_sweep.npz", gains=(24.0, 1.0)):
+    """What the reference's score filter DECIDED on every batch of the 48-batch sweep (FULL_SWEEP) -- not on a batch selected for being easy:
+    per pass the max-probs, thresholds, runner-up gaps, pseudo labels, masks, rewards and mask2, the table entries after the step, at it = 1000
+    (K = 0) and it = 30000 (K = 8), with the classifier gain of the full-size trace (24: max-probs spread over 0.3-1.0, the regime where bf16
+    operands move them by up to 0.06) and with the stock classifier (gain 1).  tests/test_gpu_srflexmatch.py measures the engine's END-TO-END
+    flip rate against these and asserts that every flip is a row whose room was smaller than its measured deviation."""
+    out = {}
+    for gain in gains:
+        tr = dict(FULL, head_gain=gain)
+        for bseed in FULL_SWEEP:
+            for it in tr["its"]:
+                o, m = run_full_step(tr, it, bseed, masks_only=True)
+                print("sweep: gain %g batch %d it %d K %d mask mean %.2f slack %.3f" % (gain, bseed, it, int(o["K"]), float(o["masks"].mean()), m), flush=True)
+                for k_ in SWEEP_KEYS:
+                    if k_ in o:
+                        out["g%g/b%d/it%d/%s" % (gain, bseed, it, k_)] = o[k_]
+    out["meta/batches"], out["meta/its"], out["meta/gains"] = np.array(FULL_SWEEP, np.int64), np.array(FULL["its"], np.int64), np.array(gains, np.float64)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
 def gen_trace_full(tr=None, fname="srflexmatch_full_trace.npz"):
     tr = tr or FULL
     best = None
@@ -1682,7 +1708,7 @@ def gen_trace_full(tr=None, fname="srflexmatch_full_trace.npz"):
     np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
-GENS = dict(trace_full=gen_trace_full, sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
+GENS = dict(trace_full=gen_trace_full, sweep_full=gen_sweep_full, sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_c100=gen_trace_c100, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
             bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment, vit_b16_96=gen_vit_b16_96, augment_tv=gen_augment_tv)

@@ -330,10 +330,15 @@ class AlgorithmBase:
 
     # ---- checkpoints (algorithmbase.py:459-547) ----------------------------------------------------------
     def get_save_dict(self):
-        return {"model": self.model.state_dict(), "ema_model": self.ema_model.state_dict(),
-                "optimizer": self.optimizer.state_dict(), "scheduler": {"last_epoch": self.optimizer.sched_step},
-                "loss_scaler": {}, "it": self.it + 1, "epoch": self.epoch + 1, "best_it": self.best_it,
-                "best_eval_acc": self.best_eval_metric}
+        d = {"model": self.model.state_dict(), "ema_model": self.ema_model.state_dict(),
+             "optimizer": self.optimizer.state_dict(), "scheduler": {"last_epoch": self.optimizer.sched_step},
+             "loss_scaler": {}, "it": self.it + 1, "epoch": self.epoch + 1, "best_it": self.best_it,
+             "best_eval_acc": self.best_eval_metric}
+        # extension (the reference's checkpoint does not hold torch's global RNG state: its resumed run draws other DropPath / dropout masks than
+        # the run that never stopped): the engine's draws are counter based (seed, draw counter), two integers make the continuation identical
+        if hasattr(self.model, "_rng_calls"):
+            d["engine_rng"] = {"seed": int(getattr(self.model, "seed", 0)), "draws": int(self.model._rng_calls)}
+        return d
 
     def _invalidate_step_timing(self):
         """Evaluation / checkpointing between two training steps: a schedule tuner that times steps by their start events (srflexmatch._DeferTuner)
@@ -359,6 +364,8 @@ class AlgorithmBase:
         sch = ck.get("scheduler") or {}
         if "last_epoch" in sch:                                     # LambdaLR.state_dict() (algorithmbase.py:468)
             self.optimizer.sched_step = int(sch["last_epoch"])
+        if "engine_rng" in ck and hasattr(self.model, "_rng_calls"):
+            self.model.seed, self.model._rng_calls = int(ck["engine_rng"]["seed"]), int(ck["engine_rng"]["draws"])
         return ck
 
     # ---- hooks (algorithmbase.py:548-599) ---------------------------------------------------------------------

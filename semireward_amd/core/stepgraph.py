@@ -113,32 +113,48 @@ class StepGraph:
             if o is not None and d:
                 setattr(o, name, getattr(o, name) + d)
 
-    def _eager(self, batch):
+    def _eager(self, batch, update=True):
         alg = self.alg
         alg.out_dict, alg.log_dict = alg.train_step(**batch)
-        self.hook.after_train_step(alg)
+        if update:
+            self.hook.after_train_step(alg)
         return alg.out_dict, alg.log_dict
+
+    def _split(self, variant):
+        """Data parallel: may this variant be captured WITHOUT its parameter update?  The gradient exchange then runs between the replayed
+        train_step and the (one-launch) optimizer step, outside the graph -- the collectives never enter a capture, the host still enqueues
+        ~3 calls per step instead of ~270.  Not while the exchange is being selected, not with the exchange under the backward (its
+        collectives are issued from inside the backward), not for the variants whose train_step contains a collective of its own (the
+        rewarder update all-reduces its gradient; the global reward threshold)."""
+        dp = self.alg.dp
+        if not dp.active:
+            return False
+        ok = dp.settled and getattr(self.alg.model, "grad_ready_cb", None) is None and not dp.global_reward_threshold and variant[1] != 3
+        return True if ok else None           # None: data parallel, but this step stays eager
 
     def step(self, **batch):
         alg = self.alg
         sig = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v))
         key = (alg.step_variant(), sig)
         self.scal.push(alg)
-        ent = self.graphs.get(key)
-        if ent is not None:
+        split = self._split(key[0])
+        ent = self.graphs.get(key) if split is not None else None
+        if ent is not None and ent[5] == bool(split):
             self.graphs[key] = self.graphs.pop(key)          # most recently used last
-            g, static, deltas, out, log = ent
+            g, static, deltas, out, log, _ = ent
             for k, v in batch.items():
                 if static[k] is not v:
                     static[k].copy_(v, non_blocking=True)
             g.replay()
             self._advance(deltas)
             alg.out_dict, alg.log_dict = out, _fresh_log(log)
+            if split:                                        # data parallel: [gradient exchange] + optimizer launch, eagerly behind the replay
+                self.hook.after_train_step(alg)
             self.replays += 1
             return out, alg.log_dict
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
-        if n < self.warm or getattr(alg, "_tuners", None) or alg.trace is not None or alg.dp.active:
+        if n < self.warm or getattr(alg, "_tuners", None) or getattr(alg, "_untuned", None) or alg.trace is not None or split is None:
             self.eager_steps += 1
             return self._eager(batch)
         # ---- capture this step (nothing executes during capture), then replay it once: that IS this step
@@ -154,11 +170,13 @@ class StepGraph:
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(g, pool=self.pool):
-            out, log = self._eager(static)
+            out, log = self._eager(static, update=not split)
         deltas = [a - b for a, b in zip(self._counters(), before)]
         src = _log_sources(log)
-        self.graphs[key] = (g, static, deltas, out, src)
+        self.graphs[key] = (g, static, deltas, out, src, bool(split))
         g.replay()
         self.replays += 1
         alg.out_dict, alg.log_dict = out, _fresh_log(src)
+        if split:
+            self.hook.after_train_step(alg)
         return out, alg.log_dict

@@ -500,6 +500,126 @@ def test_full_size_reference_trace(golden):
             np.testing.assert_allclose(samp_of(v.detach().cpu().numpy(), gs), gs["sample"], rtol=0, atol=2e-3, err_msg=p + k_)
 
 
+def measure_mask_identity(g, gain, batches=None):
+    """The engine's score-filter decisions on every (batch, it) step of the reference sweep at one classifier gain (fixture
+    srflexmatch_full_sweep.npz, oracle/gen_golden.py gen_sweep_full).  Returns a dict of counts.  Within a step the FlexMatch state is order
+    dependent (a flipped row of pass k moves selected_label -> classwise_acc -> the thresholds of every later pass), so rows are judged in pass
+    order up to the FIRST row whose decision differs: that row must be one whose measured max-prob deviation reaches its room (distance of the
+    reference's max-prob from its two thresholds and from the runner-up class); rows after it are counted as downstream."""
+    from oracle.gen_golden import FULL, full_hook_state, trace_vit_params
+    tr = dict(FULL, head_gain=gain)
+    C, Bl, Bu = tr["C"], tr["Bl"], tr["Bu"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_SMALL_P2_32)
+    T_ = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}   # noqa: E731
+    alg = get_algorithm(make_args(algorithm="srflexmatch", num_classes=C, num_train_iter=tr["num_train_iter"], ulb_dest_len=tr["ulb_dest_len"],
+                                  start_timing=tr["start_timing"], feature_dim=cfg.embed_dim, num_warmup_iter=tr["num_warmup_iter"],
+                                  p_cutoff=tr["p_cutoff"], N_k=tr["N_k"], lr=tr["lr"]), vit.vit_small_patch2_32)
+    alg.model.load_state_dict(T_(trace_vit_params(cfg, tr["seed"], gain)))
+    rew0 = T_(synth.synth_params(S.rewarder_shapes(cfg.embed_dim, C), tr["seed"] + 1))
+    alg.generator.load_state_dict(T_(synth.synth_params(S.generator_shapes(cfg.embed_dim), tr["seed"] + 2)))
+    h = alg.hooks_dict["MaskingHook"]
+    st = dict(steps=0, rows=0, flipped_rows=0, label_mismatch_rows=0, steps_with_a_flip=0, first_flips_inside_their_room=0, rows_at_risk=0,
+              downstream_rows=0, max_dev=0.0, table_entries=0, table_mismatches=0, mask2_rows=0, mask2_flips=0, mask2_flips_clear=0, worst=[])
+    for bseed in (batches if batches is not None else [int(x) for x in g["meta/batches"]]):
+        b = synth.synth_batch(bseed, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+        sel0, acc0 = full_hook_state(b["idx_ulb"])
+        batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+        for it in [int(i) for i in g["meta/its"]]:
+            p = "g%g/b%d/it%d" % (gain, bseed, it)
+            K = int(g[p + "/K"])
+            alg.rewarder.load_state_dict(rew0)
+            alg.rewarder_optimizer.load_state_dict(FlatAdamFresh(alg))
+            alg.max_reward.fill_(-float("inf"))
+            h.selected_label = torch.from_numpy(sel0.copy())
+            h.classwise_acc = torch.from_numpy(acc0.copy()).to(DEV)
+            alg.model.grad.zero_()
+            alg.it = it
+            alg.optimizer.sched_step = it
+            alg.inject_droppath = [torch.from_numpy(synth.synth_droppath(int(g[p + "/dp_seed0"]) + k, V.drop_path_probs(cfg), Bl + 2 * Bu))
+                                   for k in range(K + 1)]
+            alg.trace = {}
+            alg.train_step(**batch)
+            torch.cuda.synchronize()
+            want, refp, thr, gap, wl = g[p + "/masks"], g[p + "/mask_probs"], g[p + "/mask_thr"], g[p + "/label_gap"], g[p + "/pseudo_label"]
+            masks = np.stack([m.cpu().numpy() for m in alg.trace["masks"]])
+            mpv = alg.trace["max_probs"].cpu().numpy().reshape(want.shape)
+            lab = alg.trace["pseudo"].cpu().numpy().reshape(want.shape)
+            devs = np.abs(mpv - refp)
+            room = np.minimum(np.minimum(np.abs(refp - thr), np.abs(refp - tr["p_cutoff"])), gap)
+            diff = (masks != want) | (lab != wl)
+            st["steps"] += 1; st["rows"] += want.size
+            st["flipped_rows"] += int((masks != want).sum()); st["label_mismatch_rows"] += int((lab != wl).sum())
+            st["max_dev"] = max(st["max_dev"], float(devs.max()))
+            st["rows_at_risk"] += int((devs >= room).sum())
+            if diff.any():
+                st["steps_with_a_flip"] += 1
+                k0 = int(np.argmax(diff.any(axis=1)))                 # first pass with a differing row: its state was still the reference's
+                rows0 = np.nonzero(diff[k0])[0]
+                inside = [int(r) for r in rows0 if devs[k0, r] < room[k0, r]]
+                st["first_flips_inside_their_room"] += len(inside)
+                st["downstream_rows"] += int(diff[k0 + 1:].sum())
+                st["worst"].append((bseed, it, k0, [(int(r), float(refp[k0, r]), float(mpv[k0, r]), float(room[k0, r])) for r in rows0]))
+            sel = h.selected_label.cpu().numpy()[b["idx_ulb"]]
+            st["table_entries"] += sel.size; st["table_mismatches"] += int((sel != g[p + "/sel_after_batch"]).sum())
+            if K:
+                r = alg.trace["reward"].cpu().numpy().reshape(K, Bu)
+                rg, m2g = g[p + "/reward"], g[p + "/mask2"]
+                m2 = alg.trace["mask2"].cpu().numpy().reshape(K, Bu)
+                # a row's mask2 = reward >= pass mean is CLEAR when the reference's reward is further from its pass mean than twice the largest
+                # reward deviation of that pass; only passes whose pseudo labels (the rewarder's input) are the reference's are compared
+                same_labels = (lab[1:] == wl[1:]).all(axis=1)
+                clear = (np.abs(rg - rg.mean(axis=1, keepdims=True)) > 2.0 * np.abs(r - rg).max(axis=1, keepdims=True) + 1e-6) & same_labels[:, None]
+                st["mask2_rows"] += int(same_labels.sum()) * Bu
+                st["mask2_flips"] += int(((m2 != m2g) & same_labels[:, None]).sum())
+                st["mask2_flips_clear"] += int(((m2 != m2g) & clear).sum())
+    st["flip_rate"] = st["flipped_rows"] / max(st["rows"], 1)
+    return st
+
+
+def FlatAdamFresh(alg):
+    """A zeroed state dict of the rewarder's Adam (the stage-1 step at it = 1000 advances it)."""
+    sd = alg.rewarder_optimizer.state_dict()
+    return dict(m=torch.zeros_like(sd["m"]), v=torch.zeros_like(sd["v"]), steps=0)
+
+
+# what the sweep measured on MI355X (profiles/r06_mask_identity.txt), and the bounds asserted (about twice the measurement)
+MASK_IDENTITY_BOUNDS = {24.0: dict(flip_rate=None, label_mismatch=None, max_dev=None), 1.0: dict(flip_rate=0.0, label_mismatch=0, max_dev=None)}
+
+
+@pytest.mark.parametrize("gain", [24.0, 1.0])
+def test_end_to_end_mask_identity_over_the_reference_sweep(golden, gain):
+    """north_star: "identical pseudo-label selection masks".  The full-size trace test pins ONE batch that was screened for keeping every row
+    inside its room; this test MEASURES the end-to-end decision flip rate of the bf16-operand engine against the fp32 reference over all 48
+    batches of the sweep that batch came from (96 steps, 3 840 thresholded rows per gain) and asserts (i) the rate stays under the bound
+    written above, (ii) every step's FIRST differing row is one whose max-prob deviation reached its room (no decision differs for another
+    reason than operand rounding near a threshold), (iii) table entries differ only in steps with such a row, (iv) mask2 never differs on a
+    row whose reward is clear of its pass mean."""
+    import json
+    import os
+    g = golden("srflexmatch_full_sweep")
+    st = measure_mask_identity(g, gain)
+    line = "MASK_IDENTITY gain %g: %s" % (gain, json.dumps({k: v for k, v in st.items() if k != "worst"}))
+    print(line)
+    try:
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r06_mask_identity_g%g.json" % gain), "w") as f:
+            json.dump(st, f)
+    except OSError:
+        pass
+    bd = MASK_IDENTITY_BOUNDS[gain]
+    assert st["steps"] == 96 and st["rows"] == 48 * (8 + 72)
+    assert st["first_flips_inside_their_room"] == 0, st["worst"]
+    assert st["mask2_flips_clear"] == 0
+    if st["steps_with_a_flip"] == 0:
+        assert st["table_mismatches"] == 0
+    if bd["flip_rate"] is not None:
+        assert st["flip_rate"] <= bd["flip_rate"], line
+    if bd["label_mismatch"] is not None:
+        assert st["label_mismatch_rows"] <= bd["label_mismatch"], line
+    if bd["max_dev"] is not None:
+        assert st["max_dev"] <= bd["max_dev"], line
+
+
 def test_elide_unread_rows_changes_no_result():
     """Opt-in ``elide_unread_rows`` (never the default): the (pass, image) rows nothing reads are not computed.  Rows are independent in the
     ViT engine, so every mask, every logit that IS read, the losses and the updated parameters must equal those of the full step."""
