@@ -40,6 +40,25 @@ def test_exchange_tuner_deciding_step_reduces_every_range_exactly_once():
     assert out.count("DECIDING") == 4
 
 
+def test_step_graph_replay_under_data_parallel():
+    """core/stepgraph.py under data parallel: train_step replayed as a HIP graph, exchange + optimizer launch eager behind it
+    (tools/dp_graph_check.py): two gloo ranks on one GPU, and one forced rank on a 1-rank RCCL communicator."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "dp_graph_check.py")],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and out.count("graph replay under data parallel == eager: True") == 2, (r.stdout[-3000:], r.stderr[-3000:])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SR_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_graph_check.py"), "--one-rank-nccl"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "on nccl: graph replay under data parallel == eager: True" in out, (r.stdout[-3000:], r.stderr[-3000:])
+
+
 def test_global_reward_threshold_through_the_engine_with_two_ranks():
     """BASELINE.json configs[2]: ``global_reward_threshold`` through SRFlexMatch.train_step on the HIP engine with two gloo ranks on one GPU
     (tools/dp_global_threshold_check.py): mask2 == (reward >= mean over both ranks' rewards) bit for bit with the flag on, the rank-local mask
