@@ -187,7 +187,6 @@ class SRConsistencyBase(AlgorithmBase):
         self.dp.broadcast_params(self.model, self.rewarder, self.generator)
         # data parallel: which gradient exchange runs (one all-reduce / reduce-scatter + all-gather, after or under the backward) is measured on
         # the live backend in the first steps and agreed between the ranks (distributed.ExchangeTuner; SR_GRAD_EXCHANGE pins it)
-        self.dp.attach(self.model)
         self._plans = {}
         self._untuned = set()                  # plan keys created while the exchange selection was still measuring steps: tuned once it has settled
         self._tuners = {}                      # plan key -> (_DeferTuner, {share: _Plan}) while the deferred share of that regime is being tuned
@@ -196,7 +195,10 @@ class SRConsistencyBase(AlgorithmBase):
         # gradient-row forward on a second HIP stream
         # (args.overlap_grad_rows = False / args.defer_unread_rows = False: the serial schedule, one stream -- tests and A/B runs)
         self.overlap_grad_rows = bool(getattr(args, "overlap_grad_rows", True)) and torch.cuda.is_available()
-        self._side_stream = torch.cuda.Stream(device=self.device) if self.overlap_grad_rows else None
+        # (a stream SEEN to execute beside the constructing stream: two HIP streams may share a hardware queue, ops.concurrent_stream)
+        self._side_stream = ops.concurrent_stream(self.device) if self.overlap_grad_rows else None
+        self.dp.side_stream = self._side_stream          # (the exchange's communication stream is chosen beside both)
+        self.dp.attach(self.model)
         # rows nothing downstream reads (see _Plan) go behind the gradient rows on the second stream; the step end waits for them
         self.defer_unread_rows = self.overlap_grad_rows and bool(getattr(args, "defer_unread_rows", True))
         # opt-in: do not compute the rows nothing reads (see _Plan.cat_passes); never on by default -- the reference computes them

@@ -119,7 +119,7 @@ class DevicePrefetcher:
 
     def __init__(self, it, device="cuda"):
         self.it, self.device = iter(it), torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = ops.concurrent_stream(self.device)      # (seen to run beside the training stream: HIP streams may share a hardware queue)
         self._next = None
         self._preload()
 

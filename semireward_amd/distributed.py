@@ -237,7 +237,9 @@ class DataParallel:
         if not (self.active and self.can_overlap(model)):
             return False
         if getattr(self, "_comm", None) is None:
-            self._comm = torch.cuda.Stream(device=model.grad.device)
+            from . import ops
+            # (beside the step's stream AND its second stream: the exchange of a finished layer group must not queue behind the deferred rows)
+            self._comm = ops.concurrent_stream(model.grad.device, beside=[getattr(self, "side_stream", None)])
         self._done, self._model = [], model
         model.grad_ready_cb = self._reduce_range
         return True

@@ -54,6 +54,56 @@ def _s():
     return _STREAM if _STREAM is not None else torch.cuda.current_stream().cuda_stream
 
 
+# ---- streams that really run beside each other --------------------------------------------------------------------------------------
+# HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); two streams that land on the SAME queue execute
+# their launches one after the other, whatever the events between them say.  Which queue a new stream gets depends on how many streams the
+# process has created before -- under data parallel the communicator's own streams shift the count, and the step's second stream then shared
+# the queue of the step's stream: the two launch trains of a step serialised, 6.8 instead of 4.9 ms per step (profiles/r06_hw_queue_aliasing.txt).
+# So the engine does not take "a new stream" on trust: it takes one that has been SEEN to overlap with the streams it must run beside.
+_SPIN_CYCLES = None
+
+
+def _spin_ms(cycles, streams):
+    """Wall time (ms) of one spin kernel of ``cycles`` on each of ``streams``, all enqueued at once from a drained device."""
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in streams:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(cycles)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0)
+
+
+def streams_overlap(a, b):
+    """True when launches on the streams ``a`` and ``b`` execute concurrently (measured: two ~2 ms spin kernels take ~2, not ~4 ms)."""
+    global _SPIN_CYCLES
+    if _SPIN_CYCLES is None:
+        c = 1 << 20
+        _spin_ms(c, [a])                                    # (first launch: module load)
+        one = min(_spin_ms(c, [a]) for _ in range(2))
+        _SPIN_CYCLES = int(c * max(1.0, 2.0 / max(one, 1e-3)))     # ~2 ms
+    one = min(_spin_ms(_SPIN_CYCLES, [a]) for _ in range(2))
+    both = min(_spin_ms(_SPIN_CYCLES, [a, b]) for _ in range(2))
+    return both < 1.5 * one
+
+
+def concurrent_stream(device, beside=(), tries=16, priority=0):
+    """A new stream that overlaps with the CURRENT stream and with every stream in ``beside`` (see above).  Falls back to the last candidate --
+    with a warning on stderr -- when none of ``tries`` new streams does (a process pinned to one hardware queue: GPU_MAX_HW_QUEUES=1)."""
+    import sys
+    ref = [torch.cuda.current_stream(device)] + [s for s in beside if s is not None]
+    cand, rejected = None, 0
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device, priority=priority)
+        if all(streams_overlap(r, cand) for r in ref):
+            return cand
+        rejected += 1
+    print("semireward_amd: no stream that runs beside the step's stream among %d candidates (hardware queues exhausted? GPU_MAX_HW_QUEUES=%s): "
+          "the step's launch trains will serialise" % (rejected, os.environ.get("GPU_MAX_HW_QUEUES", "default")), file=sys.stderr)
+    return cand
+
+
 class stream_scope:
     """Pin the hipStream_t for a burst of launches (torch.cuda.current_stream() costs ~2.5 us per call, 40 % of the host
     time of a training step).  Use as a context manager around code that does not switch streams."""

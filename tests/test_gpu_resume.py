@@ -21,7 +21,7 @@ from semireward_amd.algorithms import get_algorithm   # noqa: E402
 from semireward_amd.nets import vit, wrn      # noqa: E402
 from semireward_amd.utils import synth        # noqa: E402
 
-BASE = dict(num_classes=10, num_train_iter=2000, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=True, amp=False, lr=5e-4, weight_decay=5e-4,
+BASE = dict(num_classes=10, num_train_iter=40, epoch=1, ema_m=0.0, ulb_loss_ratio=1.0, use_cat=True, amp=False, lr=5e-4, weight_decay=5e-4,
             layer_decay=0.5, num_warmup_iter=2, optim="AdamW", T=0.5, p_cutoff=0.3, hard_label=True, thresh_warmup=True, ulb_dest_len=64, N_k=2,
             start_timing=3, feature_dim=128, sr_lr=5e-4, sr_ema=False, sr_ema_m=0.99, gpu=0, rank=0, world_size=1, distributed=False)
 CASES = {
@@ -94,14 +94,14 @@ def state_of(alg):
 @pytest.mark.parametrize("name", list(CASES))
 def test_resume_equals_the_uninterrupted_run(tmp_path, name):
     a = build(name)
-    for i in range(5):                        # it = 0 .. 4: the stage-1 updates, start_timing = 3, the N_k boundary at it = 4
+    for i in range(6):                        # it = 0 .. 5: the stage-1 updates, start_timing = 3 (K = sr_decay() = 11 / 9 passes from it = 4), the N_k boundary at it = 4
         step(a, name, i)
     torch.cuda.synchronize()
     a.it -= 1                                 # save_model runs inside the loop, before ``it`` advances (get_save_dict stores it + 1)
     a.save_model("latest_model.pth", str(tmp_path))
     a.it += 1
     saved = state_of(a)
-    assert a.rewarder_optimizer.steps >= 3 and float(saved["max_reward"]) > -float("inf")
+    assert a.rewarder_optimizer.steps >= 4 and float(saved["max_reward"]) > -float("inf")
     b = build(name)
     b.load_model(str(tmp_path / "latest_model.pth"))
     loaded = state_of(b)
@@ -109,7 +109,7 @@ def test_resume_equals_the_uninterrupted_run(tmp_path, name):
     for k in saved:
         assert torch.equal(saved[k], loaded[k]), k
     ma, mb = [], []
-    for i in range(5, 8):                     # it = 5, 6, 7: K > 0 passes, the N_k boundary at it = 6
+    for i in range(6, 9):                     # it = 6, 7, 8: K = 8 / 7 ... passes, the N_k boundaries at it = 6 and 8
         step(a, name, i, ma)
         step(b, name, i, mb)
     torch.cuda.synchronize()

@@ -172,6 +172,20 @@ for exch in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap", "allreduce_bf16")
 # ---- auto: the start-up selection on the live backend ----------------------------------------------------------------------------------
 alg, ref = make(True, "auto"), make(False, "allreduce")
 batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+def copy_state(dst, src):
+    """Every step of the pair starts from the SAME state (two free-running trajectories part ways after a handful of steps once a reward within
+    round-off of its pass mean flips a 0/1 mask -- with or without data parallel, tests/test_gpu_stepgraph.py): the non-DP instance's, in place."""
+    dst.model.load_state_dict(src.model.state_dict())
+    dst.optimizer.load_state_dict(src.optimizer.state_dict())
+    dst.rewarder.load_state_dict(src.rewarder.state_dict())
+    dst.rewarder_optimizer.load_state_dict(src.rewarder_optimizer.state_dict())
+    dst.max_reward.copy_(src.max_reward)
+    hs, hd = src.hooks_dict["MaskingHook"], dst.hooks_dict["MaskingHook"]
+    hd.selected_label.copy_(hs.selected_label); hd.classwise_acc.copy_(hs.classwise_acc); hd.hist.copy_(hs.hist)
+    dst.model._rng_calls = src.model._rng_calls
+    torch.cuda.synchronize()
+
+
 steps, worst = 0, 0.0
 while not alg.dp.settled and steps < 40:
     ga, gr = [], []
@@ -180,12 +194,14 @@ while not alg.dp.settled and steps < 40:
     steps += 1
     torch.cuda.synchronize()
     worst = max(worst, rel(alg.model.flat, ref.model.flat), rel(ga[0], gr[0]))
+    copy_state(alg, ref)
 for _ in range(3):                                        # ... and on the selected exchange
     ga, gr = [], []
     full_step(alg, batch, ga)
     full_step(ref, batch, gr)
     torch.cuda.synchronize()
     worst = max(worst, rel(alg.model.flat, ref.model.flat), rel(ga[0], gr[0]))
+    copy_state(alg, ref)
 rep = alg.dp.exchange_report or {}
 good = alg.dp.settled and rep.get("chosen") in ("allreduce", "rs_ag", "overlap", "rs_ag_overlap") and "rs_ag_refused" not in rep and worst <= TOL and \
     "step_ms_exchange_under_backward" in rep and rep["collective_ms"]["rs_ag"] is not None
