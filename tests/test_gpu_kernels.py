@@ -688,3 +688,16 @@ def test_softmatch_and_distalign(golden, tag):
         d = torch.clamp(amp - mu_a[0], max=0.0)
         np.testing.assert_allclose(ma.cpu().numpy(), torch.exp(-(d * d) / (2 * mu_a[1] / ns ** 2)).cpu().numpy(), rtol=3e-6, atol=1e-7)
     assert int(inited) == 1
+
+
+def test_concurrent_stream_is_measured_not_assumed():
+    """ops.concurrent_stream / streams_overlap: HIP multiplexes streams onto a few hardware queues; a stream handed out by concurrent_stream has
+    been seen to execute beside the current stream, and among a few dozen plain streams at least one pair that does NOT overlap exists on a
+    default configuration (which is why the check is needed) -- that part is reported, not required (GPU_MAX_HW_QUEUES may be large)."""
+    from semireward_amd import ops
+    main = torch.cuda.current_stream()
+    s = ops.concurrent_stream(torch.device("cuda", 0))
+    assert ops.streams_overlap(main, s) and not ops.streams_overlap(s, s)        # (a stream never overlaps with itself: the probe has power)
+    plain = [torch.cuda.Stream() for _ in range(12)]
+    aliased = [i for i, p in enumerate(plain) if not ops.streams_overlap(main, p)]
+    print("plain streams sharing the current stream's hardware queue: %d of %d" % (len(aliased), len(plain)))

@@ -48,6 +48,16 @@ def test_exchange_tuner_settles_on_rccl_without_a_refusal(report):
     assert a["collective_ms"]["allreduce"] > 0 and a["collective_ms"]["rs_ag"] > 0 and a["step_ms_exchange_after_backward"] > 0
 
 
+def test_data_parallel_step_is_not_serialised_by_hardware_queue_aliasing(report):
+    """With the communicator's streams in the process, the step's second stream once landed on the hardware queue of the step's own stream (HIP
+    multiplexes streams onto GPU_MAX_HW_QUEUES queues): the two launch trains ran one after the other, 6.8 instead of 4.9 ms per step
+    (profiles/r06_hw_queue_aliasing.txt).  ops.concurrent_stream picks streams by measured overlap: the forced data-parallel step on RCCL, with
+    the exchange under the backward on its own communication stream, stays within 12 % of the step without data parallel."""
+    sch = report["schedule"]
+    assert sch["ok"] and all(sch["streams_overlap"].values()), (sch, report["_out"])
+    assert sch["ms_per_step_dp_overlap_exchange"] <= 1.12 * sch["ms_per_step_no_dp"], sch
+
+
 def test_broadcast_reward_threshold_hook_statistics_and_syncbatchnorm_on_rccl(report):
     assert report["bcast"]["ok"], (report["bcast"], report["_out"])
     assert report["reward"]["ok"] and report["reward"]["packed_floats"] == 9, (report["reward"], report["_out"])

@@ -12,6 +12,8 @@ Sections:
             ONCE per step (counted at the torch.distributed entry points -- with one rank a range reduced twice has the same VALUE);
   auto      SR_GRAD_EXCHANGE=auto: ExchangeTuner through all of its phases on RCCL until settled, no refusal of the reduce-scatter form;
   bcast     broadcast_params of model / rewarder / generator;
+  schedule  the data-parallel step (exchange under the backward, its own communication stream) takes the time of the step without data parallel:
+            the step's streams really run beside each other (ops.streams_overlap; HIP hardware-queue aliasing, profiles/r06_hw_queue_aliasing.txt);
   reward    the global reward threshold (packed (sum, n) all-reduce per step, reward_means) against the rank-local mean;
   stats     SoftMatch / FreeMatch / DistAlign statistics (gather_stats: all_reduce of column sums + histogram, all_gather of the max-probs);
   syncbn    the WideResNet's SyncBatchNorm exchanges (forward accumulators incl. the row-count cells, single-pass and shared-launch forwards;
@@ -220,6 +222,40 @@ ok_all = ok_all and good
 report["bcast"] = dict(ok=good, elements=n1["broadcast"] - n0["broadcast"])
 print("bcast: model / rewarder / generator blocks (%d elements) broadcast from rank 0, unchanged: %s" % (n1["broadcast"] - n0["broadcast"], "OK" if good else "FAILED"),
       flush=True)
+del alg, ref
+torch.cuda.empty_cache()
+
+# ---- schedule: the step under data parallel is as fast as without ---------------------------------------------------------------------------
+# (profiles/r06_hw_queue_aliasing.txt: with the communicator's streams in the process the step's second stream once shared a hardware queue with
+# the step's own stream and the two launch trains serialised: 6.8 instead of 4.9 ms.  Streams are now chosen by measured overlap.)
+import time                                                # noqa: E402
+
+
+def ms_per_step(a_, n=15, warm=4):
+    for i_ in range(warm + n):
+        if i_ == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        a_.out_dict, a_.log_dict = a_.train_step(**batch)
+        a_.call_hook("after_train_step")
+        a_.it += 1
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+alg, ref = make(True, "overlap"), make(False, "allreduce")
+batch = alg.process_batch(**{k: torch.from_numpy(v) for k, v in b.items()})
+from semireward_amd import ops as _ops                      # noqa: E402
+main_ = torch.cuda.current_stream()
+overlaps = dict(side=_ops.streams_overlap(main_, alg._side_stream), comm=_ops.streams_overlap(main_, alg.dp._comm),
+                side_comm=_ops.streams_overlap(alg._side_stream, alg.dp._comm))
+t_ref, t_dp = ms_per_step(ref), ms_per_step(alg)
+t_ref2 = ms_per_step(ref)
+good = all(overlaps.values()) and t_dp <= 1.12 * min(t_ref, t_ref2)
+ok_all = ok_all and good
+report["schedule"] = dict(ok=good, ms_per_step_dp_overlap_exchange=t_dp, ms_per_step_no_dp=min(t_ref, t_ref2), streams_overlap=overlaps)
+print("schedule: step with the exchange under the backward on RCCL %.3f ms, without data parallel %.3f ms; second / communication streams run beside the "
+      "step's stream and beside each other: %s: %s" % (t_dp, min(t_ref, t_ref2), overlaps, "OK" if good else "FAILED"), flush=True)
 del alg, ref
 torch.cuda.empty_cache()
 
