@@ -73,7 +73,34 @@ def test_eight_ranks_complete_the_headline_the_tuner_and_the_exchange_legs():
     he = o["host_enqueue_ms_per_step"]
     assert len(he["per_rank"]) == 8 and min(he["per_rank"]) > 0 and abs(he["max"] - max(he["per_rank"])) < 1e-3 and isinstance(he["host_bound"], bool)
     assert 0.0 < o["config"]["deferred_share"] <= 1.0          # every rank's tuner finished with the same choice (else: a hang)
-    assert he["max"] <= 0.5 * o["ms_per_step"], (he, o["ms_per_step"])       # eight feeder processes on one host: the step is not host-bound
+
+
+def test_one_forced_rank_on_rccl_prints_the_data_parallel_line():
+    """`python bench.py --force-dp`: what a one-GPU box can show of BASELINE.json configs[2]'s backend -- a 1-rank nccl (RCCL) communicator, the
+    data-parallel path forced on, the gradient exchange selected at start-up on the live backend, every pinned exchange as a leg.  The line
+    records rccl_ranks 1 and the exposed exchange time; the host needs less than half of a step to enqueue it (one feeder process per GPU on a
+    node: the step is not host-bound), and the step stays near the step without data parallel (streams chosen by measured overlap,
+    profiles/r06_hw_queue_aliasing.txt)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SR_DIST_BACKEND", "SR_GRAD_EXCHANGE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dp", "--steps", "10", "--warmup", "2", "--repeats", "3", "--no-also",
+                        "--no-roofline", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 1 and o["rccl_ranks"] == 1 and "nccl (RCCL)" in o["config"]["backend"] and o["config"]["parallelism"] == "dp1"
+    assert o["allreduce_ms_per_step"] is not None and 0 < o["allreduce_ms_per_step"] < 1.0
+    ge = o["grad_exchange"]
+    assert ge["chosen"] == ge["running"] and "rs_ag_refused" not in ge and ge["collective_ms"]["rs_ag"] is not None
+    ab = o["grad_exchange_legs"]
+    for tag in ("allreduce", "overlap", "allreduce_bf16", "rs_ag", "rs_ag_overlap"):
+        assert "error" not in ab[tag] and ab[tag]["ms_per_step"] > 0, (tag, ab[tag])
+    he = o["host_enqueue_ms_per_step"]
+    assert he["max"] <= 0.5 * o["ms_per_step"], (he, o["ms_per_step"])
+    assert o["rank_agreement_syncs"]["in_timed_regions"] == 0
+    # not serialised: every pinned leg within 25 % of the fastest (a launch train sharing the step's hardware queue costs ~40 %)
+    fast = min(ab[t]["ms_per_step"] for t in ("allreduce", "overlap", "rs_ag", "rs_ag_overlap"))
+    assert o["ms_per_step"] <= 1.25 * fast, (o["ms_per_step"], fast)
 
 
 def test_same_command_under_torch_distributed_run():
