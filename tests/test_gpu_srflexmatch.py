@@ -409,7 +409,7 @@ def test_full_size_step_properties():
     assert rel(g2.cpu(), (2.0 * g1).cpu().numpy()) < 2e-3        # bf16 rounding of the scaled output gradients is not exactly linear
 
 
-WORST_TENSOR_REL = 0.2          # per-tensor bound of the step gradient at full size (set from the measurement printed by the test)
+WORST_TENSOR_REL = 0.12         # per-tensor bound of the step gradient at full size: measured 0.062 (pos_embed, it = 1000) / 0.028 (it = 30000)
 
 
 def test_full_size_reference_trace(golden):
