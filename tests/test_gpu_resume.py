@@ -126,6 +126,9 @@ def test_resume_equals_the_uninterrupted_run(tmp_path, name):
             else:
                 assert torch.equal(sa[k], sb[k]), k
             continue
+        if not bool(torch.isfinite(sa[k]).all()):          # (max_reward right after the reset of an N_k step: -inf on both sides)
+            assert torch.equal(sa[k], sb[k]), k
+            continue
         num, den = float((sa[k].double() - sb[k].double()).norm()), float(sa[k].double().norm()) + 1e-30
         assert num / den <= 1e-6, (k, num / den)
         exact = exact and bool(torch.equal(sa[k], sb[k]))
