@@ -38,7 +38,14 @@ NS = dict(algorithm="srflexmatch", num_classes=100, num_train_iter=204800, epoch
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (the 5 PF headline is 2:1 sparse)
 HBM_PEAK_TBS = 8.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 measured with a float4 copy)
 START_IT = 30000                          # it >= 25601 -> sr_decay() == 8 (88 % of the reference run)
-TRAFFIC_JSON = os.path.join("profiles", "r05_hbm_traffic.json")     # PMC passes of this same command (tools/traffic.sh), static
+def _latest_traffic_json():
+    """profiles/rNN_hbm_traffic.json of the latest round (PMC passes of this same command, tools/traffic.sh; static, labelled as such in the line)."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))
+    return os.path.relpath(fs[-1], ROOT) if fs else os.path.join("profiles", "r05_hbm_traffic.json")
+
+
+TRAFFIC_JSON = _latest_traffic_json()
 
 
 def parse_args(argv=None):

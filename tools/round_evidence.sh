@@ -27,6 +27,12 @@ bash tools/prof.sh ${tag}_pre $Q --regime pre; grep -h "^{\"metric\"" gpurun_out
 bash tools/prof.sh ${tag}_wrn $Q --net wrn --bu 64 --steps 8 --warmup 3; grep -h "^{\"metric\"" gpurun_out/${tag}_wrn.log > gpurun_out/${tag}_wrn_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_bert $Q --net bert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_bert.log > gpurun_out/${tag}_bert_bench_under_rocprof.json
 bash tools/prof.sh ${tag}_hubert $Q --net hubert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_hubert.log > gpurun_out/${tag}_hubert_bench_under_rocprof.json
+# data parallel on the live backend with one forced rank (1-rank RCCL communicator): the line with rccl_ranks 1 + every pinned exchange, and the
+# collective-by-collective check
+python bench.py --force-dp --no-also --no-cpu-baseline --no-roofline 2> gpurun_out/${tag}_force_dp_rccl.err | tail -1 > gpurun_out/${tag}_force_dp_rccl.json
+python tools/rccl_one_rank_check.py 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | cut -c1-2000 > gpurun_out/${tag}_rccl_one_rank.txt
+SR_PHASES=1 python bench.py --no-also --no-cpu-baseline --no-roofline --repeats 3 2>&1 | grep -i "^phases" > gpurun_out/${tag}_phases.txt
+SR_PHASES=1 python bench.py --no-also --no-cpu-baseline --no-roofline --repeats 3 --regime pre 2>&1 | grep -i "^phases" >> gpurun_out/${tag}_phases.txt
 P="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-roofline --no-also"
 bash tools/pmc.sh ${tag}_pmc1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE" $P
 bash tools/pmc.sh ${tag}_pmc2 "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" $P
