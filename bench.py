@@ -439,7 +439,8 @@ class Leg:
         dt = sorted(dts)[len(dts) // 2]
         K = m.sr_decay() if self.regime == "sr" else 0
         bl, bu = self.bl, self.bu
-        out = {"metric": self.metric, "value": world * bu * steps / dt, "unit": self.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
+        out = {**({"head": os.environ["SR_BENCH_HEAD"]} if os.environ.get("SR_BENCH_HEAD") else {}),       # (tools/round_evidence.sh: the code commit the line was measured on)
+               "metric": self.metric, "value": world * bu * steps / dt, "unit": self.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic",
                "repeats": {"n": len(dts), "ms_per_step": [round(1e3 * d / steps, 4) for d in dts], "value_is": "median",

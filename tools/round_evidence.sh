@@ -1,11 +1,13 @@
 #!/bin/bash
-# usage (GPU box): tools/round_evidence.sh <tag>   -> gpurun_out/<tag>_*: everything the round's profiles/ entries are copied from
+# usage (GPU box): tools/round_evidence.sh <tag> [head]   -> gpurun_out/<tag>_*: everything the round's profiles/ entries are copied from
+#   (head: `git rev-parse --short HEAD` of the code commit, stamped into every bench line as "head" -- the box has no .git)
 #   <tag>_bench_full.json            the driver-form bench line (python bench.py, default flags)
 #   <tag>_{headline,224,bu64,pre,wrn,bert,hubert}.stats.txt + _bench_under_rocprof.json   rocprofv3 --kernel-trace --stats of the workloads
 #   <tag>_roofline_vs_rocprof.txt   the bench line's live per-launch time of the dominant kernel against the rocprofv3 average (must agree within 3 %)
 #   <tag>_hbm_traffic.json           FETCH_SIZE / WRITE_SIZE passes of the headline (tools/traffic.sh)
 #   <tag>_pmc{1,2}.pmc.txt           SQ counters of the headline (tools/pmc.sh)
 tag=$1
+export SR_BENCH_HEAD=$2
 cd $GRAFT_REPO_ROOT
 # HBM traffic first: the bench line reads profiles/<tag>_hbm_traffic.json (static, labelled as such) for roofline.traffic
 bash tools/traffic.sh ${tag} --no-also --repeats 1
@@ -29,7 +31,7 @@ bash tools/prof.sh ${tag}_bert $Q --net bert --steps 4 --warmup 2; grep -h "^{\"
 bash tools/prof.sh ${tag}_hubert $Q --net hubert --steps 4 --warmup 2; grep -h "^{\"metric\"" gpurun_out/${tag}_hubert.log > gpurun_out/${tag}_hubert_bench_under_rocprof.json
 # data parallel on the live backend with one forced rank (1-rank RCCL communicator): the line with rccl_ranks 1 + every pinned exchange, and the
 # collective-by-collective check
-python bench.py --force-dp --no-also --no-cpu-baseline --no-roofline 2> gpurun_out/${tag}_force_dp_rccl.err | tail -1 > gpurun_out/${tag}_force_dp_rccl.json
+python bench.py --force-dp --no-also --no-cpu-baseline --no-roofline 2> gpurun_out/${tag}_force_dp_rccl.err | grep "^{" | tail -1 > gpurun_out/${tag}_force_dp_rccl.json
 python tools/rccl_one_rank_check.py 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | cut -c1-2000 > gpurun_out/${tag}_rccl_one_rank.txt
 SR_PHASES=1 python bench.py --no-also --no-cpu-baseline --no-roofline --repeats 3 2>&1 | grep -i "^phases" > gpurun_out/${tag}_phases.txt
 SR_PHASES=1 python bench.py --no-also --no-cpu-baseline --no-roofline --repeats 3 --regime pre 2>&1 | grep -i "^phases" >> gpurun_out/${tag}_phases.txt
