@@ -242,6 +242,156 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward for long sequences (288 < N <= 512: the BERT legs).  Same workgroup = (sequence, head), same LDS images of K and V^T (128 KB at
+// N = 512: one workgroup per CU, two waves per SIMD) -- what changes is the wave's walk.  attn_fwd_kernel holds the whole score row set of ONE
+// query tile in registers (128 VGPRs at 512 keys) and runs  QK^T MFMAs -> softmax VALU -> PV MFMAs  strictly in sequence: with two waves per
+// SIMD the matrix pipe idles under the softmax and the vector ALU under the products (227 TF/s at L = 512 with dropout, 0.09 of the peak; the
+// largest non-GEMM share of the BERT step).  Here a wave carries TWO query tiles through the keys together, in key blocks of 128 with a running
+// maximum (online softmax): two independent dependency chains per wave -- the products of one tile issue under the exponentials of the other --
+// every K / V^T fragment read from LDS feeds both tiles, and the score registers are 2 x 32 instead of 128.  The rounding points are those of
+// the whole-row kernel (probabilities bf16, fp32 statistics and accumulation); the running maximum only moves WHEN the rescaling happens.
+// lse, the key-length mask and the dropout decision of an element (its global index) are unchanged, so attn_bwd_kernel pairs with either forward.
+constexpr int PBT = 8;                     // key tiles per block (128 keys)
+template <bool VAR>
+__global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_pair_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                 float* __restrict__ lse, int N, int H, float scale, AttnVar av) {
+  constexpr int NKT = 32, NP = NKT * 16, TP = vt_pitch(NP);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vt = Ks + NP * HD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+  const float sc2 = scale * LOG2E;
+  const int nqt = (N + 15) >> 4;
+  const int klen = (VAR && av.key_len) ? __builtin_amdgcn_readfirstlane(av.key_len[b]) : N;
+  const int nblk = (min(klen, N) + PBT * 16 - 1) / (PBT * 16);      // key blocks with at least one valid key (klen >= 1)
+  const int kc = g ^ ((l15 >> 1) & 7);
+  const int kof0 = l15 * HD + (kc << 3), kof1 = l15 * HD + ((kc ^ 4) << 3);
+  const int vof = l15 * TP + ((g ^ swz4(l15)) << 3);
+  const int wv = (wave + blockIdx.x) & (FWD_NW - 1);
+  stage_rows_swz<NP, FWD_NT>(Ks, base + D, ld, N, tid);
+  stage_transposed_perm<NP, FWD_NT>(Vt, base + 2 * D, ld, N, tid);
+  __syncthreads();
+  // tiles wv, wv + 8 | wv + 16, wv + 24: a pair per round (a tile past the last one is computed on clamped rows and not stored)
+  for (int qa = wv; qa < nqt; qa += 2 * FWD_NW) {
+    const int qb = qa + FWD_NW;
+    const int qrow[2] = {qa * 16 + l15, qb * 16 + l15};
+    s16x8_t q0[2], q1[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const bf16_t* qp = base + (size_t)min(qrow[x], N - 1) * ld + g * 8;
+      q0[x] = ld16(qp); q1[x] = ld16(qp + 32);
+    }
+    f32x4_t o[2][4];
+    float mx[2] = {-INFINITY, -INFINITY}, sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = 0; kb < nblk; ++kb) {
+      const bf16_t* Kb = Ks + kb * PBT * 16 * HD;
+      f32x4_t s[2][PBT];
+      float bm[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+      for (int t = 0; t < PBT; ++t) {
+        const s16x8_t k0 = ld16(Kb + t * 16 * HD + kof0), k1 = ld16(Kb + t * 16 * HD + kof1);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+          a = mfma16(k0, q0[x], a);
+          a = mfma16(k1, q1[x], a);
+          s[x][t] = a;
+        }
+        if ((kb * PBT + t) * 16 + 16 > klen) {             // wave-uniform: only the tile that straddles the key length (and those behind it)
+          const int k0i = (kb * PBT + t) * 16 + g * 4;
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[x][t][r] = (k0i + r < klen) ? s[x][t][r] : -INFINITY;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) bm[x] = fmaxf(bm[x], fmaxf(fmaxf(s[x][t][0], s[x][t][1]), fmaxf(s[x][t][2], s[x][t][3])));
+        if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (keeps the fragment reads of the whole block from being hoisted: registers)
+      }
+      float nm[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        float m = bm[x];
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mn = fmaxf(mx[x], m);                   // finite: every block walked holds a valid key
+        const float alpha = fast_exp2((mx[x] - mn) * sc2);  // first block: exp2(-inf) = 0 on zero accumulators
+        mx[x] = mn;
+        nm[x] = -mn * sc2;
+        sum[x] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[x][dt][r] *= alpha;
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < PBT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(fmaf(s[x][t][r], sc2, nm[x]));
+            s[x][t][r] = p;
+            ps += p;
+          }
+        sum[x] += ps;
+        if (VAR && av.drop_thresh) {                         // the element's global index, as in attn_fwd_kernel / attn_bwd_kernel
+          const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qrow[x]) * (uint32_t)N + (uint32_t)(g * 4);
+          const uint32_t h0 = rowbase * 0x9E3779B1u + av.drop_key;
+#pragma unroll
+          for (int t = 0; t < PBT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              s[x][t][r] = drop_keep_h0(h0, (uint32_t)((kb * PBT + t) * 16 + r), av.drop_thresh) ? s[x][t][r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PBT / 2; ++u) {
+        s16x8_t pb[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          float lo[4] = {s[x][2 * u][0], s[x][2 * u][1], s[x][2 * u][2], s[x][2 * u][3]};
+          float hi[4] = {s[x][2 * u + 1][0], s[x][2 * u + 1][1], s[x][2 * u + 1][2], s[x][2 * u + 1][3]};
+          pb[x] = pack8(lo, hi);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const s16x8_t vf = ld16(Vt + dt * 16 * TP + 32 * (kb * (PBT / 2) + u) + vof);
+          o[0][dt] = mfma16(vf, pb[0], o[0][dt]);
+          o[1][dt] = mfma16(vf, pb[1], o[1][dt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      float sm_ = sum[x];
+      sm_ += __shfl_xor(sm_, 16, 64);
+      sm_ += __shfl_xor(sm_, 32, 64);
+      const int q = qrow[x];
+      if (q < N) {
+        const float inv = ((VAR && av.drop_thresh) ? av.drop_scale : 1.0f) / sm_;
+        bf16_t* op = out + ((size_t)b * N + q) * D + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 v = {pack_bf2(o[x][dt][0] * inv, o[x][dt][1] * inv), pack_bf2(o[x][dt][2] * inv, o[x][dt][3] * inv)};
+          *reinterpret_cast<uint2*>(op + dt * 16) = v;
+        }
+        if (lse && g == 0) lse[((size_t)b * H + h) * N + q] = (mx[x] * sc2 + log2f(sm_)) * LN2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward, part 1: dQ.  One workgroup per (image, head); wave walks 16-query tiles.
 //   S^T, dP^T (query on l15) per key-tile pair -> P, dS (bf16) -> dQ^T[d][q] += K^T[d][keys] . dS^T[keys][q]
 // delta[q] = rowsum(dO[q] * O[q]) is computed in-kernel from the saved forward output.
@@ -845,6 +995,16 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, int H,
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
     const size_t sm = (size_t)NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
+    if constexpr (NKT == 32) {                // 288 < N <= 512: two query tiles per wave through 128-key blocks (attn_fwd_pair_kernel)
+      static const bool whole_row = getenv("SRHIP_ATTN_FWD_WHOLE_ROW") != nullptr;       // A/B hook: the whole-row kernel at every length
+      if (!whole_row) {
+        auto kp = attn_fwd_pair_kernel<VAR>;
+        (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        SR_LAUNCH(kp, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, av);
+        SR_CHECK_LAUNCH();
+        return SR_OK;
+      }
+    }
     auto kern = attn_fwd_kernel<NKT, VAR>;
     if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     SR_LAUNCH(kern, dim3(B * H), dim3(FWD_NT), sm, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, av);

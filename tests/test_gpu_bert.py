@@ -34,7 +34,8 @@ def test_site_key_matches_oracle():
         assert ops.site_key(seed, site) == BR.site_key(seed, site)
 
 
-@pytest.mark.parametrize("B,N,H,p", [(3, 24, 2, 0.0), (2, 80, 12, 0.1), (2, 200, 3, 0.1), (5, 257, 2, 0.1), (2, 512, 2, 0.1), (1, 512, 12, 0.0)])
+@pytest.mark.parametrize("B,N,H,p", [(3, 24, 2, 0.0), (2, 80, 12, 0.1), (2, 200, 3, 0.1), (5, 257, 2, 0.1), (2, 512, 2, 0.1), (1, 512, 12, 0.0),
+                                     (3, 400, 2, 0.1), (4, 300, 3, 0.0), (6, 512, 1, 0.1)])      # (N > 288: the paired-tile forward, odd tile counts, short key lengths)
 def test_attention_masked_dropout_fwd_bwd(B, N, H, p):
     """softmax(q k^T / 8 + key mask) with dropout on the probabilities, forward and backward, incl. N = 512 (V fragments of the dQ pass
     from L2) -- against an fp64 restatement that uses the same counter-based keep mask."""

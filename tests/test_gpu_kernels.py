@@ -271,7 +271,7 @@ def test_gelu_forms_against_exact_erf():
     assert bool(torch.isfinite(yp).all()) and float(yp[x == 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,N,H", [(3, 17, 2), (2, 197, 6), (4, 257, 6), (1, 64, 1), (2, 33, 3)])
+@pytest.mark.parametrize("B,N,H", [(3, 17, 2), (2, 197, 6), (4, 257, 6), (1, 64, 1), (2, 33, 3), (2, 320, 2), (1, 512, 3), (2, 401, 1)])
 def test_attention_fwd_bwd(B, N, H):
     D = H * 64
     qkv = bf(rnd(B * N, 3 * D, seed=7, scale=1.5))
