@@ -68,9 +68,25 @@ def site_key(seed, site):
 
 
 def keep_mask(seed, site, shape, p):
-    """Boolean keep mask: element with row-major linear index i is kept iff fmix32(i * 0x9E3779B1 + key) >= floor(p * 2^32)."""
+    """Boolean keep mask: element with row-major linear index i is kept iff fmix32(i * 0x9E3779B1 + key) >= floor(p * 2^32).
+    4-D shapes [B, H, N, M] = attention probabilities (the one 4-D dropout site; M = N, or the frame pitch of the Wav2Vec2 layout): ONE hash
+    per two neighbouring keys of a query row -- pair index = ((b H + h) N + q) ceil(M / 2) + (key >> 1), the even key reads the hash's low
+    16 bits, the odd key its high 16 bits, kept iff >= floor(p * 2^32) >> 16 (semireward_amd/csrc/common.h drop_pair_hash: the hash was
+    74 % of the attention forward's vector-ALU work at L = 512)."""
     n = int(np.prod(shape))
     assert n < 2 ** 32
+    if len(shape) == 4:
+        B, H, N, M = shape
+        nh = (M + 1) // 2
+        with np.errstate(over="ignore"):
+            rows = np.arange(B * H * N, dtype=np.uint64).astype(np.uint32)
+            pair = rows[:, None] * np.uint32(nh) + np.arange(nh, dtype=np.uint32)[None, :]
+            h = _fmix32(pair * np.uint32(0x9E3779B1) + np.uint32(site_key(seed, site)))
+        t16 = np.uint32(int(p * 4294967296.0) >> 16)
+        keep = np.empty((B * H * N, 2 * nh), dtype=bool)
+        keep[:, 0::2] = (h & np.uint32(0xFFFF)) >= t16
+        keep[:, 1::2] = (h >> np.uint32(16)) >= t16
+        return keep[:, :M].reshape(shape)
     with np.errstate(over="ignore"):
         idx = np.arange(n, dtype=np.uint64).astype(np.uint32)
         h = _fmix32(idx * np.uint32(0x9E3779B1) + np.uint32(site_key(seed, site)))

@@ -120,7 +120,7 @@ constexpr int FWD_NT = 512, FWD_NW = FWD_NT / 64;
 constexpr int nkt_lo(int nkt) { return nkt == 32 ? 18 : nkt == 18 ? 14 : nkt == 14 ? 8 : nkt == 8 ? 2 : 0; }
 // VAR = true (BERT / Wav2Vec2 encoders): per-sequence key length (right-padded batch: keys >= key_len[b] are masked exactly like the
 // additive -inf mask of the reference, every QUERY row is still computed -- the classifier averages over padded positions too) and
-// train-mode dropout on the probabilities (counter-based, common.h:drop_keep; element index = ((b*H + h)*N + q)*N + key).
+// train-mode dropout on the probabilities (counter-based, common.h:drop_pair_hash: one hash per two neighbouring keys of a row).
 struct AttnVar { const int* key_len; uint32_t drop_key, drop_thresh; float drop_scale; };
 template <int NKT, bool VAR>
 __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -203,12 +203,16 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_kernel(const bf16_t* __res
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     if (VAR && av.drop_thresh) {                     // nn.Dropout on the normalised probabilities: the row sum is the pre-dropout one
-      const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(g * 4);
-      const uint32_t h0 = rowbase * 0x9E3779B1u + av.drop_key;
+      // this lane's keys t * 16 + 4 g + r: pairs (r = 0, 1), (r = 2, 3) = pair indices 8 t + 2 g + j of the row
+      const uint32_t h0 = ((((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q) * (uint32_t)((N + 1) >> 1)) + (uint32_t)(g * 2)) * 0x9E3779B1u + av.drop_key;
 #pragma unroll
       for (int t = 0; t < NKT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[t][r] = drop_keep_h0(h0, (uint32_t)(t * 16 + r), av.drop_thresh) ? s[t][r] : 0.f;
+        for (int j = 0; j < 2; ++j) {
+          const uint32_t hh = fmix32(h0 + (uint32_t)(t * 8 + j) * 0x9E3779B1u);
+          s[t][2 * j] = drop_pair_keep(hh, 0, av.drop_thresh) ? s[t][2 * j] : 0.f;
+          s[t][2 * j + 1] = drop_pair_keep(hh, 1, av.drop_thresh) ? s[t][2 * j + 1] : 0.f;
+        }
     }
     f32x4_t o[4];
 #pragma unroll
@@ -343,14 +347,17 @@ __global__ __launch_bounds__(FWD_NT, 2) void attn_fwd_pair_kernel(const bf16_t* 
             ps += p;
           }
         sum[x] += ps;
-        if (VAR && av.drop_thresh) {                         // the element's global index, as in attn_fwd_kernel / attn_bwd_kernel
-          const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qrow[x]) * (uint32_t)N + (uint32_t)(g * 4);
-          const uint32_t h0 = rowbase * 0x9E3779B1u + av.drop_key;
+        if (VAR && av.drop_thresh) {                         // the element's pair hash, as in attn_fwd_kernel / attn_bwd_kernel
+          const uint32_t h0 = ((((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qrow[x]) * (uint32_t)((N + 1) >> 1)) + (uint32_t)(g * 2)) * 0x9E3779B1u +
+                              av.drop_key;
 #pragma unroll
           for (int t = 0; t < PBT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              s[x][t][r] = drop_keep_h0(h0, (uint32_t)((kb * PBT + t) * 16 + r), av.drop_thresh) ? s[x][t][r] : 0.f;
+            for (int j = 0; j < 2; ++j) {
+              const uint32_t hh = fmix32(h0 + (uint32_t)((kb * PBT + t) * 8 + j) * 0x9E3779B1u);
+              s[x][t][2 * j] = drop_pair_keep(hh, 0, av.drop_thresh) ? s[x][t][2 * j] : 0.f;
+              s[x][t][2 * j + 1] = drop_pair_keep(hh, 1, av.drop_thresh) ? s[x][t][2 * j + 1] : 0.f;
+            }
         }
       }
 #pragma unroll
@@ -467,7 +474,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t* __restrict__ qkv,
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (VG) vfetch(0);
-    const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(g * 4);
+    const uint32_t drow = (uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)q;          // dropout: row of the probability matrix
 #pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       float ds[2][4];
@@ -491,7 +498,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t* __restrict__ qkv,
             const int key = t * 16 + g * 4 + r;
             const float p = key < klen ? fast_exp2(s[r] * sc2 - lse2) : 0.f;
             float dpv = dp[r];
-            if (av.drop_thresh) dpv = drop_keep(rowbase + t * 16 + r, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
+            if (av.drop_thresh) dpv = drop_keep_attn(drow, (uint32_t)N, (uint32_t)key, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
             ds[e][r] = p * (dpv - dl) * scale;
           }
         } else if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
@@ -620,7 +627,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
             p = key < klen ? p : 0.f;
             pk = p;
             if (av.drop_thresh) {
-              const bool keep = drop_keep(((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qq) * (uint32_t)N + (uint32_t)key, av.drop_key, av.drop_thresh);
+              const bool keep = drop_keep_attn((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qq, (uint32_t)N, (uint32_t)key, av.drop_key, av.drop_thresh);
               pk = keep ? p * av.drop_scale : 0.f;
               dpv = keep ? dpv * av.drop_scale : 0.f;
             }
@@ -783,13 +790,13 @@ __device__ __forceinline__ void attn_bwd_dq_pair(const bf16_t* __restrict__ qkv,
           dp = mfma16(va, do0[x], dp);
           dp = mfma16(vb, do1[x], dp);
           if (VAR) {
-            const uint32_t rowbase = ((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)min(q[x], N - 1)) * (uint32_t)N + (uint32_t)(g * 4);
+            const uint32_t drow = (uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)min(q[x], N - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = t * 16 + g * 4 + r;
               const float p = key < klen ? fast_exp2(s[r] * sc2 - lse2[x]) : 0.f;
               float dpv = dp[r];
-              if (av.drop_thresh) dpv = drop_keep(rowbase + t * 16 + r, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
+              if (av.drop_thresh) dpv = drop_keep_attn(drow, (uint32_t)N, (uint32_t)key, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
               ds[x][e][r] = p * (dpv - dl[x]) * scale;
             }
           } else if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
@@ -922,8 +929,8 @@ __device__ __forceinline__ void attn_bwd_dkv_pair(const bf16_t* __restrict__ qkv
               p = key[x] < klen ? p : 0.f;
               pk = p;
               if (av.drop_thresh) {
-                const bool keep = drop_keep(((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qq) * (uint32_t)N + (uint32_t)min(key[x], N - 1), av.drop_key,
-                                            av.drop_thresh);
+                const bool keep = drop_keep_attn((uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)qq, (uint32_t)N, (uint32_t)min(key[x], N - 1), av.drop_key,
+                                                 av.drop_thresh);
                 pk = keep ? p * av.drop_scale : 0.f;
                 dpv = keep ? dpv * av.drop_scale : 0.f;
               }

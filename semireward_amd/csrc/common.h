@@ -136,6 +136,18 @@ __device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t t
 // the same decision for idx = base + off with h0 = base * 0x9E3779B1 + key hoisted and off a compile-time constant: one 32-bit multiply
 // (quarter rate on CDNA) less per element
 __device__ __forceinline__ bool drop_keep_h0(uint32_t h0, uint32_t off, uint32_t thresh) { return fmix32(h0 + off * 0x9E3779B1u) >= thresh; }
+// Dropout on ATTENTION PROBABILITIES [B, H, N, N] (the one 4-D site): ONE hash decides the two neighbouring keys 2j, 2j + 1 of a query row --
+// its low / high 16 bits against the threshold's upper 16 bits (p resolved to 2^-16).  Pair index = row * ceil(N / 2) + (key >> 1) with
+// row = (b H + h) N + q.  The hash (two quarter-rate 32-bit multiplies) was 74 % of the vector-ALU work of the attention forward at L = 512;
+// lanes hold 4 consecutive keys of a row, so the forward evaluates one hash per two elements.  oracle/bert_ref.keep_mask (4-D shapes) restates it.
+__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row, uint32_t nh, uint32_t pair, uint32_t key) {
+  return fmix32((row * nh + pair) * 0x9E3779B1u + key);
+}
+__device__ __forceinline__ bool drop_pair_keep(uint32_t h, int odd, uint32_t thresh) { return (odd ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16); }
+// one element (the backward's key-on-lane layouts, where neighbouring registers are neighbouring QUERIES)
+__device__ __forceinline__ bool drop_keep_attn(uint32_t row, uint32_t N, uint32_t key_idx, uint32_t key, uint32_t thresh) {
+  return drop_pair_keep(drop_pair_hash(row, (N + 1u) >> 1, key_idx >> 1, key), (int)(key_idx & 1u), thresh);
+}
 
 // XCD-aware bijective block remap (blocks b, b+8, b+16.. share an XCD/L2): returns the
 // logical work-group id so that each XCD walks a contiguous chunk of the tile list.
