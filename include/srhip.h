@@ -57,7 +57,7 @@ int srhip_gemm_small_max_grid(int n);
 
 /* SRHIP_EPI_RESID_F32 with nn.Dropout on the branch: C(f32)[M,N] = resid (f32, ldresid; NULL: C) + dropout(acc + bias) -- the
  * ``LayerNorm(x + dropout(dense(.)))`` of BertSelfOutput / BertOutput (reached from semilearn/nets/bert/bert.py:34) before the LayerNorm.
- * Mask element index = m * N + n (ldc == N required), generator as in srhip_attn_masked_fwd. */
+ * Mask element index i = m * N + n (ldc == N required): kept iff fmix32(i * 0x9E3779B1 + drop_key) >= drop_thresh. */
 int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                 const float* bias, const float* resid, int ldresid, unsigned drop_key, unsigned drop_thresh,
                                 float drop_scale, void* stream);
@@ -99,9 +99,13 @@ int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const fl
 /* Padding-aware variants for the BERT / Wav2Vec2 encoders (semilearn/nets/bert/bert.py:34 -> transformers BertSelfAttention;
  * wave2vecv2/wave2vecv2.py:44 -> Wav2Vec2Attention): key_len int32 [B] = number of valid (non-padding) keys of every sequence of a
  * right-padded batch (NULL: all N), equivalent to the additive -inf attention mask; every query row is computed.  drop_*: train-mode
- * nn.Dropout on the probabilities from the counter-based generator shared by all dropout sites (element kept iff
- * fmix32(i * 0x9E3779B1 + drop_key) >= drop_thresh, i = ((b*H + h)*N + q)*N + key; kept values * drop_scale; drop_thresh == 0: none).
- * N <= 512 forward AND backward (N > 288: V fragments of the dQ pass come from L2 instead of LDS).  B*H*N*N < 2^32. */
+ * nn.Dropout on the probabilities from the counter-based generator of all dropout sites (fmix32(i * 0x9E3779B1 + drop_key) against
+ * drop_thresh; kept values * drop_scale; drop_thresh == 0: none) -- at THIS site one hash decides two neighbouring keys of a query row:
+ * i = ((b*H + h)*N + q) * ceil(N / 2) + (key >> 1), the even key is kept iff the hash's low 16 bits >= drop_thresh >> 16, the odd key
+ * iff its high 16 bits are (the hash was 74 % of the forward's vector-ALU work at N = 512; oracle/bert_ref.keep_mask, 4-D shapes).
+ * The other sites (srhip_gemm_nt_resid_dropout, embeddings, post-LN, pooling) keep one 32-bit decision per element.
+ * N <= 512 forward AND backward (N > 288: the forward walks two query tiles per wave through 128-key blocks, attn_fwd_pair_kernel; the V
+ * fragments of the dQ pass come from L2 instead of LDS).  B*H*N*N < 2^32. */
 int srhip_attn_masked_fwd(const void* qkv, void* out, float* lse, const int* key_len, int B, int N, int H, float scale,
                           unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
 int srhip_attn_masked_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, float* delta_ws,
@@ -374,7 +378,7 @@ int srhip_clip_grad_ws_floats(void);
 int srhip_clip_grad_coef(const float* g, long long n, float pre_scale, float max_norm, float* ws, float* coef_out, void* stream);
 
 /* ---- post-LN transformer encoder glue (BERT / Wav2Vec2 backbones; semilearn/nets/bert/bert.py, wave2vecv2/wave2vecv2.py and the HF modules
- * they call).  D in {128, 384, 768}; dropout arguments as in srhip_attn_masked_fwd with element index = row * D + column.
+ * they call).  D in {128, 384, 768}; dropout arguments as in srhip_gemm_nt_resid_dropout (one 32-bit decision per element) with element index = row * D + column.
  *   embed_ln_fwd : BertEmbeddings -- x = dropout(LayerNorm(word[ids[seq][p]] + pos[p] + type0)) for row (b, p) of a [B, L] batch; ids int64
  *                  [*, ld_ids], seq_index int32 [B] picks the row of ids (NULL: identity); x fp32 and bf16 [B*L, D]; mean/rstd [B*L] optional
  *   embed_ln_bwd : its backward from dy = d/dx: dword[id] += (rows with id == pad_id excluded: nn.Embedding(padding_idx)), dpos[p] +=,
