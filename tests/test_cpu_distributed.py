@@ -110,9 +110,51 @@ def _auto_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _refused_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semireward_amd.distributed import DataParallel
+
+    def refuse(*a, **k):                                 # an argument check of the backend: raised before anything is enqueued, on every rank alike
+        raise RuntimeError("reduce_scatter_tensor: in-place shards are not supported by this backend (test stand-in)")
+    dist.reduce_scatter_tensor = refuse
+    dp = DataParallel(world, rank)
+    n = 2 * 64 * 40 + 5
+    rng = np.random.Generator(np.random.PCG64(10))
+    blocks = torch.from_numpy(rng.standard_normal((world, n)).astype(np.float32))
+    m = _Flat(n)
+    ok = True
+    for step in range(2):
+        m.grad = blocks[rank].clone()
+        dp.all_reduce_grads(m)
+        ok = ok and torch.allclose(m.grad.double(), blocks.double().sum(0), rtol=1e-6, atol=1e-6)
+    rep = dp.exchange_report
+    q.put((rank, bool(ok), rep["chosen"], "rs_ag_refused" in rep, rep["collective_ms"]["rs_ag"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_refused_reduce_scatter_form_is_agreed_on_a_tiny_block_before_anything_large_is_timed():
+    """The reduce-scatter + all-gather form is probed ONCE on a tiny block and the refusal agreed between the ranks (all-reduce MAX of a flag)
+    before the full-size block is timed: every rank then skips the form alike, keeps the all-reduce, reports the refusal -- and the gradients
+    of that very step are summed exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_refused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] == "allreduce" and r[3] and r[4] is None for r in res), res
+
+
 def test_gradient_exchange_is_selected_at_start_up_and_agreed_between_the_ranks():
-    """SR_GRAD_EXCHANGE=auto (the default): the first exchange call times one all-reduce against reduce-scatter + all-gather on a scratch block,
-    the ranks agree on the maxima over the ranks (one blocking all-reduce) and ALL keep the same form; the gradients are summed exactly once."""
+    """SR_GRAD_EXCHANGE=auto (the default): the first exchange call probes the reduce-scatter form on a tiny block and AGREES on whether any
+    rank was refused (one blocking all-reduce), times one all-reduce against reduce-scatter + all-gather on a scratch block, the ranks agree
+    on the maxima over the ranks (a second blocking all-reduce) and ALL keep the same form; the gradients are summed exactly once."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -123,7 +165,7 @@ def test_gradient_exchange_is_selected_at_start_up_and_agreed_between_the_ranks(
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(r[1] for r in res) and len({r[2] for r in res}) == 1 and all(r[3] == 1 for r in res), res
+    assert all(r[1] for r in res) and len({r[2] for r in res}) == 1 and all(r[3] == 2 for r in res), res
 
 
 def _rs_ag_worker(rank, world, port, q):
