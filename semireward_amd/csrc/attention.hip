@@ -1003,7 +1003,7 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int B, int N, int H,
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
     const size_t sm = (size_t)NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2;
     if constexpr (NKT == 32) {                // 288 < N <= 512: two query tiles per wave through 128-key blocks (attn_fwd_pair_kernel)
-      static const bool whole_row = getenv("SRHIP_ATTN_FWD_WHOLE_ROW") != nullptr;       // A/B hook: the whole-row kernel at every length
+      static const bool whole_row = SR_TUNE_ENV("SRHIP_ATTN_FWD_WHOLE_ROW") != nullptr;   // tuning build: the whole-row kernel at every length (A/B)
       if (!whole_row) {
         auto kp = attn_fwd_pair_kernel<VAR>;
         (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
