@@ -439,8 +439,7 @@ class Leg:
         dt = sorted(dts)[len(dts) // 2]
         K = m.sr_decay() if self.regime == "sr" else 0
         bl, bu = self.bl, self.bu
-        out = {**({"head": os.environ["SR_BENCH_HEAD"]} if os.environ.get("SR_BENCH_HEAD") else {}),       # (tools/round_evidence.sh: the code commit the line was measured on)
-               "metric": self.metric, "value": world * bu * steps / dt, "unit": self.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
+        out = {"metric": self.metric, "value": world * bu * steps / dt, "unit": self.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic",
                "repeats": {"n": len(dts), "ms_per_step": [round(1e3 * d / steps, 4) for d in dts], "value_is": "median",
@@ -455,6 +454,8 @@ class Leg:
                           if self.elide else "computed, as in the reference",
                           "backward_images_per_step": bl + bu, "rewarder_update_every": NS["N_k"], "parallelism": "dp%d" % world,
                           "grad_allreduce": "flat fp32 block, exchange selected at start-up (grad_exchange)" if self.dp_on else "none"}}
+        if os.environ.get("SR_BENCH_HEAD"):                   # (tools/round_evidence.sh: the code commit the line was measured on)
+            out["head"] = os.environ["SR_BENCH_HEAD"]
         rep = list(getattr(m, "defer_report", {}).values())
         if rep:
             out["config"].update(deferred_share=rep[-1]["chosen"], deferred_images=rep[-1]["deferred_images"], autotune_steps=tune_steps)
