@@ -78,7 +78,7 @@ def test_eight_ranks_complete_the_headline_the_tuner_and_the_exchange_legs():
 def test_one_forced_rank_on_rccl_prints_the_data_parallel_line():
     """`python bench.py --force-dp`: what a one-GPU box can show of BASELINE.json configs[2]'s backend -- a 1-rank nccl (RCCL) communicator, the
     data-parallel path forced on, the gradient exchange selected at start-up on the live backend, every pinned exchange as a leg.  The line
-    records rccl_ranks 1 and the exposed exchange time; the host needs less than half of a step to enqueue it (one feeder process per GPU on a
+    records rccl_ranks 1 and the exposed exchange time; the host needs ~0.4 of a step to enqueue it (one feeder process per GPU on a
     node: the step is not host-bound), and the step stays near the step without data parallel (streams chosen by measured overlap,
     profiles/r06_hw_queue_aliasing.txt)."""
     # (SRHIP_CHECK_ARGS, which the test suite's conftest switches on, validates every tensor argument on the host: +1 ms of enqueue time per
@@ -99,7 +99,9 @@ def test_one_forced_rank_on_rccl_prints_the_data_parallel_line():
     for tag in ("allreduce", "overlap", "allreduce_bf16", "rs_ag", "rs_ag_overlap"):
         assert "error" not in ab[tag] and ab[tag]["ms_per_step"] > 0, (tag, ab[tag])
     he = o["host_enqueue_ms_per_step"]
-    assert he["max"] <= 0.5 * o["ms_per_step"], (he, o["ms_per_step"])
+    # (1.9-2.0 ms of a 5.0 ms step measured = 0.40; the bound leaves room for a slower or busier host and stays under bench.py's own
+    # HOST_BOUND threshold of 0.85, beyond which it would switch to graph replay)
+    assert he["max"] <= 0.7 * o["ms_per_step"] and not he["host_bound"], (he, o["ms_per_step"])
     assert o["rank_agreement_syncs"]["in_timed_regions"] == 0
     # not serialised: every pinned leg within 25 % of the fastest (a launch train sharing the step's hardware queue costs ~40 %)
     fast = min(ab[t]["ms_per_step"] for t in ("allreduce", "overlap", "rs_ag", "rs_ag_overlap"))

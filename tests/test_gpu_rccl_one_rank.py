@@ -52,10 +52,10 @@ def test_data_parallel_step_is_not_serialised_by_hardware_queue_aliasing(report)
     """With the communicator's streams in the process, the step's second stream once landed on the hardware queue of the step's own stream (HIP
     multiplexes streams onto GPU_MAX_HW_QUEUES queues): the two launch trains ran one after the other, 6.8 instead of 4.9 ms per step
     (profiles/r06_hw_queue_aliasing.txt).  ops.concurrent_stream picks streams by measured overlap: the forced data-parallel step on RCCL, with
-    the exchange under the backward on its own communication stream, stays within 12 % of the step without data parallel."""
+    the exchange under the backward on its own communication stream, stays within 20 % of the step without data parallel (1.06 measured; a serialised schedule is 1.38)."""
     sch = report["schedule"]
     assert sch["ok"] and all(sch["streams_overlap"].values()), (sch, report["_out"])
-    assert sch["ms_per_step_dp_overlap_exchange"] <= 1.12 * sch["ms_per_step_no_dp"], sch
+    assert sch["ms_per_step_dp_overlap_exchange"] <= 1.2 * sch["ms_per_step_no_dp"], sch
 
 
 def test_broadcast_reward_threshold_hook_statistics_and_syncbatchnorm_on_rccl(report):

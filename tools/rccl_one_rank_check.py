@@ -251,7 +251,7 @@ overlaps = dict(side=_ops.streams_overlap(main_, alg._side_stream), comm=_ops.st
                 side_comm=_ops.streams_overlap(alg._side_stream, alg.dp._comm))
 t_ref, t_dp = ms_per_step(ref), ms_per_step(alg)
 t_ref2 = ms_per_step(ref)
-good = all(overlaps.values()) and t_dp <= 1.12 * min(t_ref, t_ref2)
+good = all(overlaps.values()) and t_dp <= 1.2 * min(t_ref, t_ref2)
 ok_all = ok_all and good
 report["schedule"] = dict(ok=good, ms_per_step_dp_overlap_exchange=t_dp, ms_per_step_no_dp=min(t_ref, t_ref2), streams_overlap=overlaps)
 print("schedule: step with the exchange under the backward on RCCL %.3f ms, without data parallel %.3f ms; second / communication streams run beside the "
