@@ -1684,6 +1684,47 @@ def gen_sweep_full(fname="srflexmatch_full_sweep.npz", gains=(24.0, 1.0)):
     np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
+def gen_sweep_full_emu(fname="srflexmatch_full_sweep_emu.npz", gain=24.0):
+    """The sweep's score-filter decisions once more, from a CPU MODEL OF THE ENGINE'S ROUNDING instead of the reference: the weak rows of every
+    pass through oracle.vit_ref.vit_forward_engine_rounding (bf16 operands at libsrhip's rounding points, fp32 everything else, none of the
+    engine's code), softmax, and the oracle's FlexMatch state machine (hooks_ref.FlexMatchState) in pass order.  NOT reference output -- the
+    fixture exists to split the engine's deviation from the reference (srflexmatch_full_sweep.npz) into operand rounding, which this model
+    shares, and kernel error, which it cannot share: tests/test_gpu_srflexmatch.py asserts the engine's max-probs within 1e-2 of these and its
+    decisions on these rows identical but for razor-thin cases.  Same batches, iterations, DropPath draws and hook state as gen_sweep_full."""
+    tr = dict(FULL, head_gain=gain)
+    C, Bl, Bu = tr["C"], tr["Bl"], tr["Bu"]
+    cfg = V.VitCfg(num_classes=C, **V.VIT_SMALL_P2_32)
+    P = {k: T(v) for k, v in trace_vit_params(cfg, tr["seed"], gain).items()}
+    out = {}
+    with torch.no_grad():
+        for bseed in FULL_SWEEP:
+            b = synth.synth_batch(bseed, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
+            xw = T(b["x_ulb_w"])
+            for it in tr["its"]:
+                K = 0 if it <= tr["start_timing"] else int(max(8, 1 + tr["num_train_iter"] / it))
+                sel0, acc0 = full_hook_state(b["idx_ulb"])
+                st = H.FlexMatchState(tr["ulb_dest_len"], C, True)
+                st.selected_label[:] = sel0
+                st.classwise_acc[:] = acc0
+                probs, thr, gap, pl, masks = [], [], [], [], []
+                for k in range(K + 1):
+                    dp = T(synth.synth_droppath(900 + 16 * (bseed % 64) + k, V.drop_path_probs(cfg), Bl + 2 * Bu))[:, :, Bl:Bl + Bu]
+                    pr = torch.softmax(V.vit_forward_engine_rounding(P, xw, cfg, dp)["logits"], dim=-1)
+                    mp, mi = pr.max(dim=-1)
+                    t2 = pr.topk(2, dim=-1).values
+                    acc = torch.from_numpy(st.classwise_acc.copy())[mi]
+                    probs.append(mp.numpy().copy()); pl.append(mi.numpy().copy()); gap.append((t2[:, 0] - t2[:, 1]).numpy().copy())
+                    thr.append((np.float32(tr["p_cutoff"]) * (acc / (2.0 - acc))).numpy().copy())
+                    masks.append(st.masking(pr.numpy(), b["idx_ulb"], tr["p_cutoff"]).copy())
+                p = "g%g/b%d/it%d/" % (gain, bseed, it)
+                out[p + "mask_probs"], out[p + "mask_thr"], out[p + "label_gap"] = np.stack(probs), np.stack(thr), np.stack(gap)
+                out[p + "pseudo_label"], out[p + "masks"] = np.stack(pl), np.stack(masks)
+                out[p + "sel_after_batch"] = st.selected_label[b["idx_ulb"]].copy()
+                print("sweep emu: batch %d it %d K %d mask mean %.2f" % (bseed, it, K, float(np.stack(masks).mean())), flush=True)
+    out["meta/batches"], out["meta/its"], out["meta/gain"] = np.array(FULL_SWEEP, np.int64), np.array(FULL["its"], np.int64), np.float64(gain)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
 def gen_trace_full(tr=None, fname="srflexmatch_full_trace.npz"):
     tr = tr or FULL
     best = None
@@ -1708,7 +1749,7 @@ def gen_trace_full(tr=None, fname="srflexmatch_full_trace.npz"):
     np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
-GENS = dict(trace_full=gen_trace_full, sweep_full=gen_sweep_full, sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
+GENS = dict(trace_full=gen_trace_full, sweep_full=gen_sweep_full, sweep_full_emu=gen_sweep_full_emu, sr_configs=gen_sr_configs, ema=gen_ema, rewarder=gen_rewarder, hooks=gen_hooks, losses=gen_losses, vit=gen_vit, optim=gen_optim, trace=gen_trace,
             trace_fix=gen_trace_fix, trace_c100=gen_trace_c100, trace_pl=gen_trace_pl, trace_free=gen_trace_free, freematch_hook=gen_freematch_hook,
             trace_soft=gen_trace_soft, softmatch_hook=gen_softmatch_hook, vit_p16=gen_vit_p16, wrn=gen_wrn, trace_pl_wrn=gen_trace_pl_wrn,
             bert=gen_bert, trace_soft_bert=gen_trace_soft_bert, w2v=gen_w2v, trace_free_w2v=gen_trace_free_w2v, augment=gen_augment, vit_b16_96=gen_vit_b16_96, augment_tv=gen_augment_tv)

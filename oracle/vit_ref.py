@@ -126,6 +126,42 @@ def vit_forward(P, x, cfg, droppath=None, return_tokens=False, aten_ops=False):
     return out
 
 
+def vit_forward_engine_rounding(P, x, cfg, droppath=None):
+    """The SAME network with the ENGINE's operand rounding points restated (fp32 everywhere else) -- not the reference's arithmetic, a CPU
+    model of libsrhip's inference path (semireward_amd/csrc/attn_block.hip, mlp_fused.hip): bf16 GEMM operands (LayerNorm outputs, the four
+    weight matrices of a block, q / k / v, the softmax probabilities -- normalised by the sum of the UNROUNDED ones --, the attention output
+    with its DropPath factor applied before the rounding, the GELU output with its DropPath factor), fp32 accumulation, fp32 residual stream /
+    LayerNorm / softmax, fp32 patch embedding and classifier head.  Used to separate the two reasons the engine can deviate from the fp32
+    reference: operand ROUNDING (this function shares it) and kernel ERROR (summation order, the exp2 / polynomial-GELU approximations, bugs:
+    this function has none of the engine's code).  tests/test_gpu_srflexmatch.py compares the engine with both."""
+    r = lambda t_: t_.to(torch.bfloat16).to(torch.float32)   # noqa: E731
+    B = x.shape[0]
+    D, nh = cfg.embed_dim, cfg.num_heads
+    hd = D // nh
+    t = patchify(x, cfg.patch_size) @ P["patch_embed.proj.weight"].reshape(D, -1).t() + P["patch_embed.proj.bias"]
+    t = torch.cat((P["cls_token"].expand(B, -1, -1), t), dim=1) + P["pos_embed"]
+    N = t.shape[1]
+    one = torch.ones(B)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        s1 = (droppath[i, 0] if droppath is not None else one).view(B, 1, 1)
+        s2 = (droppath[i, 1] if droppath is not None else one).view(B, 1, 1)
+        h = r(_ln(t, P[b + "norm1.weight"], P[b + "norm1.bias"]))
+        qkv = r(h @ r(P[b + "attn.qkv.weight"]).t() + P[b + "attn.qkv.bias"]).reshape(B, N, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        sc = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+        p = torch.exp(sc - sc.max(dim=-1, keepdim=True).values)
+        o = (r(p) @ v) / p.sum(dim=-1, keepdim=True)
+        o = r(o.transpose(1, 2).reshape(B, N, D) * s1)
+        t = t + o @ r(P[b + "attn.proj.weight"]).t() + s1 * P[b + "attn.proj.bias"]
+        h = r(_ln(t, P[b + "norm2.weight"], P[b + "norm2.bias"]))
+        h = r(_gelu(h @ r(P[b + "mlp.fc1.weight"]).t() + P[b + "mlp.fc1.bias"]) * s2)
+        t = t + h @ r(P[b + "mlp.fc2.weight"]).t() + s2 * P[b + "mlp.fc2.bias"]
+    t = _ln(t, P["norm.weight"], P["norm.bias"])
+    feat = t[:, 0]
+    return {"logits": feat @ P["head.weight"].t() + P["head.bias"], "feat": feat}
+
+
 def flops_per_image(cfg):
     """depth*N*(24 D^2 + 4 N D) + patch-embed + head (forward)."""
     D, N = cfg.embed_dim, cfg.num_tokens
