@@ -133,7 +133,9 @@ def vit_forward_engine_rounding(P, x, cfg, droppath=None):
     with its DropPath factor applied before the rounding, the GELU output with its DropPath factor), fp32 accumulation, fp32 residual stream /
     LayerNorm / softmax, fp32 patch embedding and classifier head.  Used to separate the two reasons the engine can deviate from the fp32
     reference: operand ROUNDING (this function shares it) and kernel ERROR (summation order, the exp2 / polynomial-GELU approximations, bugs:
-    this function has none of the engine's code).  tests/test_gpu_srflexmatch.py compares the engine with both."""
+    this function has none of the engine's code).  It predicts the STATISTICS of the engine's deviation, not its numbers: the direction an
+    operand rounds in depends on its value to ~1e-4 relative, so two implementations of the same rounding points draw nearly independent
+    noise from the second block on (tools/rounding_model_probe.py).  tests/test_gpu_srflexmatch.py compares the engine with both."""
     r = lambda t_: t_.to(torch.bfloat16).to(torch.float32)   # noqa: E731
     B = x.shape[0]
     D, nh = cfg.embed_dim, cfg.num_heads

@@ -505,7 +505,7 @@ def test_full_size_reference_trace(golden):
             np.testing.assert_allclose(samp_of(v.detach().cpu().numpy(), gs), gs["sample"], rtol=0, atol=2e-3, err_msg=p + k_)
 
 
-def measure_mask_identity(g, gain, batches=None, cmp=None):
+def measure_mask_identity(g, gain, batches=None, cmp=None, aux=None):
     """The engine's score-filter decisions on every (batch, it) step of the reference sweep at one classifier gain (fixture
     srflexmatch_full_sweep.npz, oracle/gen_golden.py gen_sweep_full).  Returns a dict of counts.  Within a step the FlexMatch state is order
     dependent (a differing row of pass k moves selected_label -> classwise_acc -> the thresholds of every later pass), so rows are judged in
@@ -516,7 +516,8 @@ def measure_mask_identity(g, gain, batches=None, cmp=None):
       mask    same label (so the engine's max-prob is the SAME class's probability and its deviation is observable), other mask: the deviation
               must have reached the row's room = distance of the reference's max-prob from the nearer of its two thresholds.
     Rows of later passes are counted as downstream.
-    cmp: another fixture with the same keys to compare the decisions with instead of ``g`` (the rounding model's, gen_sweep_full_emu)."""
+    cmp: another fixture with the same keys to compare the decisions with instead of ``g``; aux: a third set of max-probs (the rounding
+    model's, gen_sweep_full_emu) whose squared distances from the engine's and from cmp's are accumulated (sq_engine_aux, sq_aux_cmp)."""
     from oracle.gen_golden import FULL, full_hook_state, trace_vit_params
     cmp = g if cmp is None else cmp
     tr = dict(FULL, head_gain=gain)
@@ -532,7 +533,7 @@ def measure_mask_identity(g, gain, batches=None, cmp=None):
     h = alg.hooks_dict["MaskingHook"]
     st = dict(steps=0, rows=0, flipped_rows=0, label_mismatch_rows=0, steps_with_a_difference=0, first_label_flips=0, first_label_flip_max_gap=0.0,
               first_mask_flips=0, first_mask_flips_inside_their_room=0, rows_at_risk=0, downstream_rows=0, max_dev_same_label=0.0, table_entries=0,
-              table_mismatches=0, mask2_rows=0, mask2_flips=0, mask2_flips_clear=0, first=[])
+              table_mismatches=0, mask2_rows=0, mask2_flips=0, mask2_flips_clear=0, sq_engine_cmp=0.0, sq_engine_aux=0.0, sq_aux_cmp=0.0, first=[])
     for bseed in (batches if batches is not None else [int(x) for x in g["meta/batches"]]):
         b = synth.synth_batch(bseed, Bl, Bu, cfg.img_size, C, tr["ulb_dest_len"])
         sel0, acc0 = full_hook_state(b["idx_ulb"])
@@ -559,6 +560,11 @@ def measure_mask_identity(g, gain, batches=None, cmp=None):
             lab = alg.trace["pseudo"].cpu().numpy().reshape(want.shape)
             same = lab == wl
             devs = np.abs(mpv - refp)
+            st["sq_engine_cmp"] += float(((mpv - refp).astype(np.float64) ** 2).sum())
+            if aux is not None:
+                ap = aux[p + "/mask_probs"]
+                st["sq_engine_aux"] += float(((mpv - ap).astype(np.float64) ** 2).sum())
+                st["sq_aux_cmp"] += float(((ap - refp).astype(np.float64) ** 2).sum())
             room = np.minimum(np.abs(refp - thr), np.abs(refp - tr["p_cutoff"]))
             diff = (masks != want) | ~same
             st["steps"] += 1; st["rows"] += want.size
@@ -644,37 +650,42 @@ def test_end_to_end_mask_identity_over_the_reference_sweep(golden, gain):
     assert st["max_dev_same_label"] <= bd["max_dev_same_label"], line
 
 
-def test_engine_against_a_cpu_model_of_its_own_rounding_over_the_sweep(golden):
-    """What is operand ROUNDING and what would be kernel ERROR in the 0.9 % above?  oracle.vit_ref.vit_forward_engine_rounding is a CPU model of
-    the engine's rounding points (bf16 GEMM operands, q / k / v, probabilities, branch outputs; fp32 everything else) that shares none of the
-    engine's code; srflexmatch_full_sweep_emu.npz holds ITS decisions on the same 96 steps (gain 24).  Against the fp32 reference that model
-    deviates as much as the engine does (max-prob 0.095, 32 mask rows, 46 labels of 3 840 -- asserted here on the two fixtures); against the
-    model the engine's max-probs agree to 1e-2 and at most a handful of razor-thin decisions differ: the engine's distance from the reference
-    is the rounding the BASELINE's bf16 configuration prescribes, not arithmetic the kernels get wrong."""
+def test_engine_deviates_from_the_reference_as_a_cpu_model_of_its_rounding_does(golden):
+    """Is the 0.9 % above operand ROUNDING or kernel ERROR?  oracle.vit_ref.vit_forward_engine_rounding is a CPU model of the engine's rounding
+    points (bf16 GEMM operands, q / k / v, probabilities, branch outputs; fp32 everything else) that shares none of the engine's code;
+    srflexmatch_full_sweep_emu.npz holds ITS max-probs and decisions on the same 96 steps (gain 24).  The model cannot reproduce the engine's
+    numbers row by row -- which way an operand rounds depends on its value to a few 1e-4 relative, so from the second block on two
+    implementations of the same rounding points draw (nearly) independent samples of the same rounding noise (tools/rounding_model_probe.py:
+    logits rel-L2 engine vs fp32 6.4e-3, model vs fp32 6.4e-3, engine vs model 4.7e-3) -- but it predicts its STATISTICS: an engine with
+    arithmetic errors beyond its rounding points would sit further from the reference than the model does.  Asserted: the engine's rms
+    max-prob deviation from the reference is within 25 % of the model's, its mask / label differences are no more frequent than the model's
+    (x 1.5 + 5: both are counts of ~30), and engine and model are closer to each other than either is to the reference (the shared part)."""
     import json
     g, e = golden("srflexmatch_full_sweep"), golden("srflexmatch_full_sweep_emu")
-    # (i) the rounding model against the reference, fixture against fixture
-    dev, flips, labels, rows = 0.0, 0, 0, 0
+    flips_m, labels_m, dev_m, rows = 0, 0, 0.0, 0
     for b in g["meta/batches"]:
         for it in g["meta/its"]:
             p = "g24/b%d/it%d/" % (b, it)
-            dev = max(dev, float(np.abs(e[p + "mask_probs"] - g[p + "mask_probs"]).max()))
-            flips += int((e[p + "masks"] != g[p + "masks"]).sum()); labels += int((e[p + "pseudo_label"] != g[p + "pseudo_label"]).sum())
+            dev_m = max(dev_m, float(np.abs(e[p + "mask_probs"] - g[p + "mask_probs"]).max()))
+            flips_m += int((e[p + "masks"] != g[p + "masks"]).sum()); labels_m += int((e[p + "pseudo_label"] != g[p + "pseudo_label"]).sum())
             rows += g[p + "masks"].size
-    assert rows == 3840 and 0.05 < dev < 0.15 and 10 <= flips <= 70 and 10 <= labels <= 90, (dev, flips, labels)
-    # (ii) the engine against the rounding model
-    st = measure_mask_identity(g, 24.0, cmp=e)
-    line = "ROUNDING_MODEL gain 24: %s" % json.dumps({k: v for k, v in st.items() if k != "first"})
+    st = measure_mask_identity(g, 24.0, aux=e)
+    rms = {k: (st[k] / rows) ** 0.5 for k in ("sq_engine_cmp", "sq_engine_aux", "sq_aux_cmp")}
+    line = "ROUNDING_MODEL gain 24: rms max-prob deviation engine-reference %.4f, model-reference %.4f, engine-model %.4f; mask rows differing from the " \
+           "reference: engine %d, model %d; labels: engine %d, model %d; max deviation engine %.3f (same label), model %.3f" % (
+               rms["sq_engine_cmp"], rms["sq_aux_cmp"], rms["sq_engine_aux"], st["flipped_rows"], flips_m, st["label_mismatch_rows"], labels_m,
+               st["max_dev_same_label"], dev_m)
     print(line)
-    assert st["rows"] == 3840
-    assert st["max_dev_same_label"] <= ROUNDING_MODEL_BOUNDS["max_dev"], line
-    assert st["flipped_rows"] <= ROUNDING_MODEL_BOUNDS["flipped_rows"] and st["label_mismatch_rows"] <= ROUNDING_MODEL_BOUNDS["label_mismatch_rows"], line
-    assert st["first_mask_flips_inside_their_room"] == 0, [x for x in st["first"] if x[4]]
-    assert st["first_label_flip_max_gap"] <= ROUNDING_MODEL_BOUNDS["label_gap"], line
-
-
-# engine vs its rounding model (set from the measurement the test prints; profiles/r06_mask_identity.txt)
-ROUNDING_MODEL_BOUNDS = dict(max_dev=2e-2, flipped_rows=8, label_mismatch_rows=8, label_gap=2e-2)
+    try:
+        import os
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r06_rounding_model.txt"), "w") as f:
+            f.write(line + "\n" + json.dumps({k: v for k, v in st.items() if k != "first"}) + "\n")
+    except OSError:
+        pass
+    assert rows == 3840 and st["rows"] == rows
+    assert rms["sq_engine_cmp"] <= 1.25 * rms["sq_aux_cmp"], line
+    assert st["flipped_rows"] <= 1.5 * flips_m + 5 and st["label_mismatch_rows"] <= 1.5 * labels_m + 5, line
+    assert rms["sq_engine_aux"] <= max(rms["sq_engine_cmp"], rms["sq_aux_cmp"]), line
 
 
 def test_elide_unread_rows_changes_no_result():
