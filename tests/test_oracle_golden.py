@@ -655,3 +655,31 @@ def test_full_size_trace_filter_decisions(golden):
             assert np.array_equal(g[f"{p}/mask2"], (r >= r.mean(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32))
             assert 0.0 < g[f"{p}/mask2"].mean() < 1.0
         assert float(g[f"{p}/log/util_ratio"]) == pytest.approx(float(g[f"{p}/masks"][0].mean()), abs=1e-7)
+
+
+def test_rounding_model_fixture_is_what_the_oracle_function_gives(golden):
+    """srflexmatch_full_sweep_emu.npz (gen_golden.gen_sweep_full_emu) = oracle.vit_ref.vit_forward_engine_rounding + the oracle's FlexMatch state
+    machine: one step of the sweep recomputed here (K = 0: one pass of 8 weak images at full size) gives the fixture's max-probs (1e-6: CPU
+    thread counts move fp32 sums), labels, masks and table entries."""
+    import torch
+    from oracle import hooks_ref as H
+    from oracle import vit_ref as V
+    from oracle.gen_golden import FULL, full_hook_state, trace_vit_params
+    from semireward_amd.utils import synth
+    e = golden("srflexmatch_full_sweep_emu")
+    gain, bseed, it = float(e["meta/gain"]), int(e["meta/batches"][3]), 1000
+    cfg = V.VitCfg(num_classes=FULL["C"], **V.VIT_SMALL_P2_32)
+    P = {k: torch.from_numpy(v) for k, v in trace_vit_params(cfg, FULL["seed"], gain).items()}
+    b = synth.synth_batch(bseed, FULL["Bl"], FULL["Bu"], cfg.img_size, FULL["C"], FULL["ulb_dest_len"])
+    sel0, acc0 = full_hook_state(b["idx_ulb"])
+    st = H.FlexMatchState(FULL["ulb_dest_len"], FULL["C"], True)
+    st.selected_label[:] = sel0
+    st.classwise_acc[:] = acc0
+    dp = torch.from_numpy(synth.synth_droppath(900 + 16 * (bseed % 64), V.drop_path_probs(cfg), FULL["Bl"] + 2 * FULL["Bu"]))[:, :, FULL["Bl"]:FULL["Bl"] + FULL["Bu"]]
+    with torch.no_grad():
+        pr = torch.softmax(V.vit_forward_engine_rounding(P, torch.from_numpy(b["x_ulb_w"]), cfg, dp)["logits"], dim=-1)
+    p = "g%g/b%d/it%d/" % (gain, bseed, it)
+    np.testing.assert_allclose(pr.max(dim=-1).values.numpy(), e[p + "mask_probs"][0], rtol=0, atol=1e-5)
+    assert np.array_equal(pr.argmax(dim=-1).numpy(), e[p + "pseudo_label"][0])
+    assert np.array_equal(st.masking(pr.numpy(), b["idx_ulb"], FULL["p_cutoff"]), e[p + "masks"][0])
+    assert np.array_equal(st.selected_label[b["idx_ulb"]], e[p + "sel_after_batch"])
