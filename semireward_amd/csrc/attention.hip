@@ -701,15 +701,17 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t* __restrict__ qkv
 // parallelism under every latency, every K / V (dQ role) or Q / dO (dK / dV role) fragment read from LDS once for both tiles, and the
 // wave that owns the odd 17th tile of N = 257 needs two rounds instead of three.  delta = rowsum(dO * O) is computed once per workgroup
 // in the staging phase (both roles), so a tile's operands are only its q / dO fragments.
-template <int NKT, bool VAR>
+// VG (N > 288: K, V and K^T images exceed the LDS together): the V row fragments -- the A operand of dP = V . dO^T, plain 16-byte row reads that
+// BOTH query tiles of the pair use -- come from global memory / L2, requested one key-tile pair ahead.
+template <int NKT, bool VAR, bool VG = false>
 __device__ __forceinline__ void attn_bwd_dq_pair(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
                                                  const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
                                                  bf16_t* __restrict__ dqkv, float* __restrict__ delta, int N, int H, float scale, AttnVar av) {
   constexpr int NP = NKT * 16, TP = vt_pitch(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);   // [NP][64]  chunk-swizzled (stage_rows_swz)
-  bf16_t* Vs = Ks + NP * HD;                          // [NP][64]
-  bf16_t* Kt = Vs + NP * HD;                          // [64][TP]  key-permuted + chunk-swizzled (stage_transposed_perm)
+  bf16_t* Vs = Ks + NP * HD;                          // [NP][64]  (absent when VG)
+  bf16_t* Kt = Vs + (VG ? 0 : NP * HD);               // [64][TP]  key-permuted + chunk-swizzled (stage_transposed_perm)
   float* lse_s = reinterpret_cast<float*>(Kt + 64 * TP);   // [NP]  (* log2e; +inf for padded queries)
   float* dl_s = lse_s + NP;                                // [NP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
@@ -737,8 +739,16 @@ __device__ __forceinline__ void attn_bwd_dq_pair(const bf16_t* __restrict__ qkv,
   };
   fetch(qfirst);
   stage_rows_swz<NP, BWD_NT>(Ks, base + D, ld, N, tid);
-  stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
+  if (!VG) stage_rows_swz<NP, BWD_NT>(Vs, base + 2 * D, ld, N, tid);
   stage_transposed_perm<NP, BWD_NT>(Kt, base + D, ld, N, tid);
+  s16x8_t vg[2][2];                                   // VG: V fragments of key-tile pair u (rows >= N are clamped: their p is 0)
+  auto vfetch = [&](int u_) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bf16_t* vp = base + 2 * D + (size_t)min((2 * u_ + e) * 16 + l15, N - 1) * ld + g * 8;
+      vg[e][0] = ld16(vp); vg[e][1] = ld16(vp + 32);
+    }
+  };
   for (int i = tid; i < NP; i += BWD_NT) {
     float dl = 0.f;
     if (i < N) {
@@ -774,14 +784,21 @@ __device__ __forceinline__ void attn_bwd_dq_pair(const bf16_t* __restrict__ qkv,
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (VG) vfetch(0);
 #pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       float ds[2][2][4];
+      s16x8_t cv[2][2];
+      if (VG) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { cv[e][0] = vg[e][0]; cv[e][1] = vg[e][1]; }
+        if (u + 1 < NKT / 2) vfetch(u + 1);
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int t = 2 * u + e;
         const s16x8_t ka = ld16(Ks + t * 16 * HD + kof0), kb = ld16(Ks + t * 16 * HD + kof1);
-        const s16x8_t va = ld16(Vs + t * 16 * HD + kof0), vb = ld16(Vs + t * 16 * HD + kof1);
+        const s16x8_t va = VG ? cv[e][0] : ld16(Vs + t * 16 * HD + kof0), vb = VG ? cv[e][1] : ld16(Vs + t * 16 * HD + kof1);
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
           f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -791,12 +808,18 @@ __device__ __forceinline__ void attn_bwd_dq_pair(const bf16_t* __restrict__ qkv,
           dp = mfma16(vb, do1[x], dp);
           if (VAR) {
             const uint32_t drow = (uint32_t)blockIdx.x * (uint32_t)N + (uint32_t)min(q[x], N - 1);
+            // this lane's four keys are two pairs of the row: one hash each (common.h drop_pair_hash), as in the forward
+            uint32_t hh[2] = {0u, 0u};
+            if (av.drop_thresh) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) hh[j] = drop_pair_hash(drow, (uint32_t)((N + 1) >> 1), (uint32_t)(t * 8 + g * 2 + j), av.drop_key);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = t * 16 + g * 4 + r;
               const float p = key < klen ? fast_exp2(s[r] * sc2 - lse2[x]) : 0.f;
               float dpv = dp[r];
-              if (av.drop_thresh) dpv = drop_keep_attn(drow, (uint32_t)N, (uint32_t)key, av.drop_key, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
+              if (av.drop_thresh) dpv = drop_pair_keep(hh[r >> 1], r & 1, av.drop_thresh) ? dpv * av.drop_scale : 0.f;
               ds[x][e][r] = p * (dpv - dl[x]) * scale;
             }
           } else if (t >= nkt_lo(NKT)) {                 // (wave-uniform) only these key tiles can hold padded keys, see attn_fwd_kernel
@@ -977,8 +1000,8 @@ __global__ __launch_bounds__(BWD_NT, 2) void attn_bwd_kernel(const bf16_t* __res
   if constexpr (!VG) {                     // K, V, Q, dO images in LDS: two tiles per wave
     if (blockIdx.z == 0) attn_bwd_dq_pair<NKT, VAR>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
     else attn_bwd_dkv_pair<NKT, VAR>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
-  } else {                                 // N > 288: the V / (q, dO) row fragments come from L2
-    if (blockIdx.z == 0) attn_bwd_dq_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
+  } else {                                 // N > 288: the V / (q, dO) row fragments come from L2; the dQ role still walks two query tiles per wave
+    if (blockIdx.z == 0) attn_bwd_dq_pair<NKT, VAR, true>(qkv, o_fwd, d_out, lse, dqkv, delta, N, H, scale, av);
     else attn_bwd_dkv_body<NKT, VAR, VG>(qkv, o_fwd, d_out, lse, dqkv, N, H, scale, av);
   }
   __syncthreads();
@@ -1027,7 +1050,7 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, const f
   return dispatch_nkt(N, [&](auto nk) -> int {
     constexpr int NKT = decltype(nk)::value, NP = NKT * 16;
     constexpr bool VG = NKT > 18;           // K + V + K^T images exceed the LDS: V fragments from L2
-    const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2 + (VG ? 0 : (size_t)2 * NP * 4);
+    const size_t sm1 = (size_t)(VG ? 1 : 2) * NP * HD * 2 + (size_t)64 * vt_pitch(NP) * 2 + (size_t)2 * NP * 4;
     const size_t sm2 = (size_t)2 * 64 * vt_pitch(NP) * 2 + (VG ? 0 : (size_t)2 * NP * HD * 2) + (size_t)2 * NP * 4;
     if (sm1 > 160 * 1024 || sm2 > 160 * 1024) return SR_EINVAL;
     auto kern = attn_bwd_kernel<NKT, VAR, VG>;
