@@ -57,7 +57,7 @@ int srhip_gemm_small_max_grid(int n);
 
 /* SRHIP_EPI_RESID_F32 with nn.Dropout on the branch: C(f32)[M,N] = resid (f32, ldresid; NULL: C) + dropout(acc + bias) -- the
  * ``LayerNorm(x + dropout(dense(.)))`` of BertSelfOutput / BertOutput (reached from semilearn/nets/bert/bert.py:34) before the LayerNorm.
- * Mask element index i = m * N + n (ldc == N required): kept iff fmix32(i * 0x9E3779B1 + drop_key) >= drop_thresh. */
+ * Mask element index i = m * N + n (ldc == N and N even required); decision per element pair i >> 1 as described at srhip_attn_masked_fwd. */
 int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                 const float* bias, const float* resid, int ldresid, unsigned drop_key, unsigned drop_thresh,
                                 float drop_scale, void* stream);
@@ -99,11 +99,11 @@ int srhip_attn_bwd(const void* qkv, const void* out, const void* d_out, const fl
 /* Padding-aware variants for the BERT / Wav2Vec2 encoders (semilearn/nets/bert/bert.py:34 -> transformers BertSelfAttention;
  * wave2vecv2/wave2vecv2.py:44 -> Wav2Vec2Attention): key_len int32 [B] = number of valid (non-padding) keys of every sequence of a
  * right-padded batch (NULL: all N), equivalent to the additive -inf attention mask; every query row is computed.  drop_*: train-mode
- * nn.Dropout on the probabilities from the counter-based generator of all dropout sites (fmix32(i * 0x9E3779B1 + drop_key) against
- * drop_thresh; kept values * drop_scale; drop_thresh == 0: none) -- at THIS site one hash decides two neighbouring keys of a query row:
- * i = ((b*H + h)*N + q) * ceil(N / 2) + (key >> 1), the even key is kept iff the hash's low 16 bits >= drop_thresh >> 16, the odd key
- * iff its high 16 bits are (the hash was 74 % of the forward's vector-ALU work at N = 512; oracle/bert_ref.keep_mask, 4-D shapes).
- * The other sites (srhip_gemm_nt_resid_dropout, embeddings, post-LN, pooling) keep one 32-bit decision per element.
+ * nn.Dropout on the probabilities from the counter-based generator of all dropout sites: ONE hash h = fmix32(pair * 0x9E3779B1 + drop_key)
+ * decides TWO neighbouring elements -- the even one is kept iff (h & 0xFFFF) >= drop_thresh >> 16, the odd one iff (h >> 16) is; kept values
+ * * drop_scale; drop_thresh == 0: none (the hash, two quarter-rate multiplies, was 74 % of this forward's vector-ALU work at N = 512;
+ * oracle/bert_ref.keep_mask restates it).  At THIS site the pairs are taken within a query row: pair = ((b*H + h)*N + q) * ceil(N / 2) +
+ * (key >> 1); at every other site (srhip_gemm_nt_resid_dropout, embeddings, post-LN, pooling) pair = i >> 1 of the row-major element index i.
  * N <= 512 forward AND backward (N > 288: the forward walks two query tiles per wave through 128-key blocks, attn_fwd_pair_kernel; the V
  * fragments of the dQ pass come from L2 instead of LDS).  B*H*N*N < 2^32. */
 int srhip_attn_masked_fwd(const void* qkv, void* out, float* lse, const int* key_len, int B, int N, int H, float scale,

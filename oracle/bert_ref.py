@@ -68,29 +68,37 @@ def site_key(seed, site):
 
 
 def keep_mask(seed, site, shape, p):
-    """Boolean keep mask: element with row-major linear index i is kept iff fmix32(i * 0x9E3779B1 + key) >= floor(p * 2^32).
-    4-D shapes [B, H, N, M] = attention probabilities (the one 4-D dropout site; M = N, or the frame pitch of the Wav2Vec2 layout): ONE hash
-    per two neighbouring keys of a query row -- pair index = ((b H + h) N + q) ceil(M / 2) + (key >> 1), the even key reads the hash's low
-    16 bits, the odd key its high 16 bits, kept iff >= floor(p * 2^32) >> 16 (semireward_amd/csrc/common.h drop_pair_hash: the hash was
-    74 % of the attention forward's vector-ALU work at L = 512)."""
+    """Boolean keep mask of one dropout site (semireward_amd/csrc/common.h drop_keep / drop_pair_hash): ONE hash decides TWO neighbouring
+    elements.  With key = site_key(seed, site) and t16 = floor(p * 2^32) >> 16:
+      * element with row-major linear index i belongs to pair i >> 1; h = fmix32(pair * 0x9E3779B1 + key); the even element is kept iff
+        (h & 0xFFFF) >= t16, the odd one iff (h >> 16) >= t16;
+      * 4-D shapes [B, H, N, M] = attention probabilities (the one 4-D site; M = N, or the frame pitch of the Wav2Vec2 layout): the pairs are
+        taken within a query row -- pair index = ((b H + h) N + q) ceil(M / 2) + (key >> 1) -- so that a lane's four consecutive keys are two
+        whole pairs whatever the parity of M.
+    (The hash -- two quarter-rate 32-bit multiplies -- was 74 % of the attention forward's vector-ALU work at L = 512 and a quarter of a GEMM
+    tile's time where the epilogue carries a dropout; one decision per 16 bits resolves p to 2^-16.)"""
     n = int(np.prod(shape))
     assert n < 2 ** 32
+    t16 = np.uint32(int(p * 4294967296.0) >> 16)
+    key = np.uint32(site_key(seed, site))
     if len(shape) == 4:
         B, H, N, M = shape
         nh = (M + 1) // 2
         with np.errstate(over="ignore"):
             rows = np.arange(B * H * N, dtype=np.uint64).astype(np.uint32)
             pair = rows[:, None] * np.uint32(nh) + np.arange(nh, dtype=np.uint32)[None, :]
-            h = _fmix32(pair * np.uint32(0x9E3779B1) + np.uint32(site_key(seed, site)))
-        t16 = np.uint32(int(p * 4294967296.0) >> 16)
+            h = _fmix32(pair * np.uint32(0x9E3779B1) + key)
         keep = np.empty((B * H * N, 2 * nh), dtype=bool)
         keep[:, 0::2] = (h & np.uint32(0xFFFF)) >= t16
         keep[:, 1::2] = (h >> np.uint32(16)) >= t16
         return keep[:, :M].reshape(shape)
+    npair = (n + 1) // 2
     with np.errstate(over="ignore"):
-        idx = np.arange(n, dtype=np.uint64).astype(np.uint32)
-        h = _fmix32(idx * np.uint32(0x9E3779B1) + np.uint32(site_key(seed, site)))
-    return (h >= np.uint32(int(p * 4294967296.0))).reshape(shape)
+        h = _fmix32(np.arange(npair, dtype=np.uint64).astype(np.uint32) * np.uint32(0x9E3779B1) + key)
+    keep = np.empty(2 * npair, dtype=bool)
+    keep[0::2] = (h & np.uint32(0xFFFF)) >= t16
+    keep[1::2] = (h >> np.uint32(16)) >= t16
+    return keep[:n].reshape(shape)
 
 
 def _drop(x, seed, site, p):

@@ -132,18 +132,31 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thresh) { return fmix32(idx * 0x9E3779B1u + key) >= thresh; }
-// the same decision for idx = base + off with h0 = base * 0x9E3779B1 + key hoisted and off a compile-time constant: one 32-bit multiply
-// (quarter rate on CDNA) less per element
-__device__ __forceinline__ bool drop_keep_h0(uint32_t h0, uint32_t off, uint32_t thresh) { return fmix32(h0 + off * 0x9E3779B1u) >= thresh; }
-// Dropout on ATTENTION PROBABILITIES [B, H, N, N] (the one 4-D site): ONE hash decides the two neighbouring keys 2j, 2j + 1 of a query row --
-// its low / high 16 bits against the threshold's upper 16 bits (p resolved to 2^-16).  Pair index = row * ceil(N / 2) + (key >> 1) with
-// row = (b H + h) N + q.  The hash (two quarter-rate 32-bit multiplies) was 74 % of the vector-ALU work of the attention forward at L = 512;
-// lanes hold 4 consecutive keys of a row, so the forward evaluates one hash per two elements.  oracle/bert_ref.keep_mask (4-D shapes) restates it.
+// Dropout decisions: ONE hash decides TWO neighbouring elements -- element i of a site (row-major linear index) belongs to pair i >> 1; the even
+// element is kept iff the low 16 bits of fmix32(pair * 0x9E3779B1 + key) reach the threshold's upper 16 bits (p resolved to 2^-16), the odd one
+// iff the high 16 bits do.  The hash costs two quarter-rate 32-bit multiplies: per element it was 74 % of the vector-ALU work of the attention
+// forward at L = 512 and 7 of 26 us of a 256 x 256 GEMM tile whose epilogue carries a dropout (Wav2Vec2's activation dropout on the
+// 3072-wide hidden rows).  oracle/bert_ref.keep_mask restates it; every fixture with a dropout was regenerated through the reference.
+__device__ __forceinline__ bool drop_pair_keep(uint32_t h, int odd, uint32_t thresh) { return (odd ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16); }
+__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thresh) {
+  return drop_pair_keep(fmix32((idx >> 1) * 0x9E3779B1u + key), (int)(idx & 1u), thresh);
+}
+// four consecutive elements i0 .. i0 + 3 (i0 even: every row length in use is even and lanes own aligned quads): two hashes
+__device__ __forceinline__ void drop_keep4(uint32_t i0, uint32_t key, uint32_t thresh, bool (&k)[4]) {
+  const uint32_t h0 = fmix32((i0 >> 1) * 0x9E3779B1u + key), h1 = fmix32(((i0 >> 1) + 1u) * 0x9E3779B1u + key);
+  k[0] = drop_pair_keep(h0, 0, thresh); k[1] = drop_pair_keep(h0, 1, thresh);
+  k[2] = drop_pair_keep(h1, 0, thresh); k[3] = drop_pair_keep(h1, 1, thresh);
+}
+// two consecutive elements i0, i0 + 1 (i0 even): one hash
+__device__ __forceinline__ void drop_keep2(uint32_t i0, uint32_t key, uint32_t thresh, bool& k0, bool& k1) {
+  const uint32_t h = fmix32((i0 >> 1) * 0x9E3779B1u + key);
+  k0 = drop_pair_keep(h, 0, thresh); k1 = drop_pair_keep(h, 1, thresh);
+}
+// Attention probabilities [B, H, N, N] (the one 4-D site): pairs are taken WITHIN a query row -- pair index = row * ceil(N / 2) + (key >> 1) with
+// row = (b H + h) N + q -- so that a lane's four consecutive keys are two whole pairs whatever the parity of N.
 __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row, uint32_t nh, uint32_t pair, uint32_t key) {
   return fmix32((row * nh + pair) * 0x9E3779B1u + key);
 }
-__device__ __forceinline__ bool drop_pair_keep(uint32_t h, int odd, uint32_t thresh) { return (odd ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16); }
 // one element (the backward's key-on-lane layouts, where neighbouring registers are neighbouring QUERIES)
 __device__ __forceinline__ bool drop_keep_attn(uint32_t row, uint32_t N, uint32_t key_idx, uint32_t key, uint32_t thresh) {
   return drop_pair_keep(drop_pair_hash(row, (N + 1u) >> 1, key_idx >> 1, key), (int)(key_idx & 1u), thresh);

@@ -19,8 +19,10 @@ struct Drop { uint32_t key, thresh; float scale; };
 
 __device__ __forceinline__ float2 drop2(float2 v, uint32_t idx, const Drop& d) {
   if (d.thresh) {
-    v.x = drop_keep(idx, d.key, d.thresh) ? v.x * d.scale : 0.f;
-    v.y = drop_keep(idx + 1, d.key, d.thresh) ? v.y * d.scale : 0.f;
+    bool kx_, ky_;
+    drop_keep2(idx, d.key, d.thresh, kx_, ky_);
+    v.x = kx_ ? v.x * d.scale : 0.f;
+    v.y = ky_ ? v.y * d.scale : 0.f;
   }
   return v;
 }

@@ -81,8 +81,10 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     float h[4] = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
     if (g.drop_thresh) {                 // (uniform) Wav2Vec2FeedForward.intermediate_dropout: dropout(GELU(dense(x))); aux_out keeps the pre-activation
       const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+      bool dk4[4];
+      drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? h[r] * g.drop_scale : 0.f;
+      for (int r = 0; r < 4; ++r) h[r] = dk4[r] ? h[r] * g.drop_scale : 0.f;
     }
     u32x2_t o = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
     *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
@@ -92,8 +94,10 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     f32x4_t x = g.aux_in ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(g.aux_in) + (size_t)m * g.ldaux + n) : *cp;
     if (g.drop_thresh) {                 // (uniform) BertSelfOutput / BertOutput: LayerNorm(x + dropout(dense(.)))
       const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+      bool dk4[4];
+      drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
     }
     x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
     *cp = x;
@@ -103,8 +107,10 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     const float p2 = bf2f((bf16_t)(p[1] & 0xffff)), p3 = bf2f((bf16_t)(p[1] >> 16));
     if (g.drop_thresh) {                 // adjoint of the dropout that followed the GELU
       const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+      bool dk4[4];
+      drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
     }
     u32x2_t o = {pack_bf2(v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1)),
                  pack_bf2(v[2] * gelu_erf_grad(p2), v[3] * gelu_erf_grad(p3))};
@@ -144,16 +150,20 @@ __device__ __forceinline__ u32x2_t epi_quad_bf16(const GemmArgs& g, int m, int n
     const float pv[4] = {bf2f((bf16_t)(p[0] & 0xffff)), bf2f((bf16_t)(p[0] >> 16)), bf2f((bf16_t)(p[1] & 0xffff)), bf2f((bf16_t)(p[1] >> 16))};
     if (g.drop_thresh) {
       const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+      bool dk4[4];
+      drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pv[r]);
   }
   if (EPI == SRHIP_EPI_GELU_BF16 && g.drop_thresh) {
     const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+    bool dk4[4];
+    drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+    for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
   }
   return u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
 }
@@ -315,8 +325,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
         }
         if (g.drop_thresh) {
           const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+          bool dk4[4];
+          drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+          for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
         }
         x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
         *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = x;
@@ -892,8 +904,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g) {
             if (g.bias) { v[0] += bq[i][0]; v[1] += bq[i][1]; v[2] += bq[i][2]; v[3] += bq[i][3]; }
             if (g.drop_thresh) {
               const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
+              bool dk4[4];
+              drop_keep4(i0, g.drop_key, g.drop_thresh, dk4);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = drop_keep(i0 + r, g.drop_key, g.drop_thresh) ? v[r] * g.drop_scale : 0.f;
+              for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
             }
             f32x4_t x = res[mq][i];
             x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
@@ -1104,7 +1118,7 @@ extern "C" int srhip_gemm_nt_dropout(int epilogue, const void* A, int lda, const
                                      const float* bias, const void* aux_in, void* aux_out, int ldaux, unsigned drop_key, unsigned drop_thresh,
                                      float drop_scale, void* stream) {
   if (epilogue != SRHIP_EPI_GELU_BF16 && epilogue != SRHIP_EPI_DGELU_BF16 && epilogue != SRHIP_EPI_RESID_F32) return SR_EINVAL;
-  if (ldc != N && drop_thresh) return SR_EINVAL;
+  if ((ldc != N || (N & 1)) && drop_thresh) return SR_EINVAL;        // (one dropout hash per aligned element pair of the [M, N] output)
   return gemm_nt_impl(epilogue, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, aux_in, aux_out, ldaux, 1.0f, 0.0f, drop_key, drop_thresh,
                       drop_scale, stream);
 }
@@ -1112,7 +1126,7 @@ extern "C" int srhip_gemm_nt_dropout(int epilogue, const void* A, int lda, const
 extern "C" int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                            const float* bias, const float* resid, int ldresid, unsigned drop_key, unsigned drop_thresh,
                                            float drop_scale, void* stream) {
-  if (ldc != N && drop_thresh) return SR_EINVAL;        // the dropout index is the row-major index of the [M, N] output
+  if ((ldc != N || (N & 1)) && drop_thresh) return SR_EINVAL;        // the dropout index is the row-major index of the [M, N] output; one hash per aligned pair
   return gemm_nt_impl(SRHIP_EPI_RESID_F32, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, resid, nullptr, ldresid, 1.0f, 0.0f, drop_key,
                       drop_thresh, drop_scale, stream);
 }

@@ -373,8 +373,10 @@ __global__ __launch_bounds__(256) void pos_finish_fwd_kernel(const float* __rest
     float2 o = make_float2((v[i].x - mu) * rs * g.x + c.x, (v[i].y - mu) * rs * g.y + c.y);
     if (dr.thresh) {
       const uint32_t idx = (uint32_t)row * D + 2 * (i * 64 + lane);
-      o.x = drop_keep(idx, dr.key, dr.thresh) ? o.x * dr.scale : 0.f;
-      o.y = drop_keep(idx + 1, dr.key, dr.thresh) ? o.y * dr.scale : 0.f;
+      bool kx_, ky_;
+      drop_keep2(idx, dr.key, dr.thresh, kx_, ky_);
+      o.x = kx_ ? o.x * dr.scale : 0.f;
+      o.y = ky_ ? o.y * dr.scale : 0.f;
     }
     xr[i * 64 + lane] = o;
     br[i * 64 + lane] = pack_bf2(o.x, o.y);
@@ -422,8 +424,10 @@ __global__ __launch_bounds__(256) void pos_finish_bwd_kernel(float* __restrict__
       float2 d = dr_[i * 64 + lane];
       if (dr.thresh) {
         const uint32_t idx = (uint32_t)row * D + 2 * (i * 64 + lane);
-        d.x = drop_keep(idx, dr.key, dr.thresh) ? d.x * dr.scale : 0.f;
-        d.y = drop_keep(idx + 1, dr.key, dr.thresh) ? d.y * dr.scale : 0.f;
+        bool kx_, ky_;
+        drop_keep2(idx, dr.key, dr.thresh, kx_, ky_);
+        d.x = kx_ ? d.x * dr.scale : 0.f;
+        d.y = ky_ ? d.y * dr.scale : 0.f;
       }
       xh[i] = make_float2((a.x - mu) * rs, (a.y - mu) * rs);
       ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y;

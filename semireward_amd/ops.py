@@ -850,8 +850,8 @@ def sgd_flat(p, g, buf, ema, table, nchunks, n, lr, momentum, grad_scale=1.0, em
 
 # ---- post-LN encoder (BERT / Wav2Vec2) --------------------------------------------------------------
 class Drop:
-    """One dropout site of one forward call: (key, thresh, scale) of the counter-based generator in csrc/common.h (drop_keep; the attention
-    probabilities take one hash per two neighbouring keys, drop_pair_hash).  ``Drop.none`` disables it.  key = fmix32(lo ^ fmix32(hi + 0x9E3779B9 * site)) of the 64-bit call seed."""
+    """One dropout site of one forward call: (key, thresh, scale) of the counter-based generator in csrc/common.h (drop_keep: one hash per two
+    neighbouring elements; the attention probabilities pair within a query row, drop_pair_hash).  ``Drop.none`` disables it.  key = fmix32(lo ^ fmix32(hi + 0x9E3779B9 * site)) of the 64-bit call seed."""
     __slots__ = ("key", "thresh", "scale")
     none = None
 

@@ -166,6 +166,14 @@ def test_gemm_resid_dropout():
         assert rel(C2, Rx.double().cpu() + Ax.double().cpu() @ Bm.double().cpu().t() + bias.double().cpu()) < 1e-5
 
 
+# Gradient bounds of the BERT golden test.  Against the fixture only 256 SAMPLED elements per tensor are compared: the sampled rel-L2 of a tensor
+# moves between 0.04 and 0.10 with the realisation of the dropout masks / bf16 noise (0.059 with the per-element hash of rounds 1-5, 0.100 on
+# classifier.0.weight with the pair hash -- other masks, same kernels).  Against the oracle's fp32 autograd over the FULL tensors
+# (oracle.bert_ref.bert_forward, which test_oracle_golden pins to the reference) every tensor is within 0.034-0.038 for five mask seeds
+# (tools/bert_grad_probe.py): that comparison carries the tight bound.
+GRAD_TOL, GRAD_TOL_FULL = 0.12, 5e-2
+
+
 @pytest.mark.parametrize("tag", ["tiny", "base"])
 def test_bert_matches_reference_golden(golden, tag):
     g = golden("bert")
@@ -210,8 +218,23 @@ def test_bert_matches_reference_golden(golden, tag):
             assert np.abs(gs["sample"]).max() < 1e-4 * qs and np.abs(a).max() < 3e-2 * qs, n
             continue
         worst[n] = rel(a, gs["sample"])
-    bad = {k: v for k, v in worst.items() if v > 6e-2}
+    print("bert %s: worst gradient tensors (rel-L2 of the sampled elements): %s" % (
+        tag, ", ".join("%s %.3f" % (k.replace("bert.encoder.layer.", "L"), v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6])))
+    bad = {k: v for k, v in worst.items() if v > GRAD_TOL}
     assert not bad, bad
+    # ... and every FULL gradient tensor against the oracle's fp32 autograd of the same step with the same masks
+    Pq = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in BR.synth_params(cfg, seed).items()}
+    oq = BR.bert_forward(Pq, ids, mask, cfg, seed=dseed)
+    (torch.nn.functional.cross_entropy(oq["logits"], y.cpu(), reduction="none") * w.cpu()).mean().backward()
+    full = {}
+    for n, gr in model.named_grads():
+        ref = Pq[n].grad
+        if ref is None or float(ref.abs().max()) == 0.0 or n.endswith("key.bias"):
+            continue
+        full[n] = rel(gr.reshape(-1).cpu().numpy(), ref.reshape(-1).numpy())
+    print("bert %s: worst FULL gradient tensors vs the oracle's autograd: %s" % (
+        tag, ", ".join("%s %.3f" % (k.replace("bert.encoder.layer.", "L"), v) for k, v in sorted(full.items(), key=lambda kv: -kv[1])[:4])))
+    assert max(full.values()) < GRAD_TOL_FULL, sorted(full.items(), key=lambda kv: -kv[1])[:4]
     # gathered sequences (seq_index) = the same rows
     idx = torch.tensor([B - 1, 0], dtype=torch.int32, device=DEV)
     model.eval()

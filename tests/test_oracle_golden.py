@@ -465,6 +465,10 @@ def test_bert_oracle_matches_reference(golden, tag):
         check_samp(gr.numpy(), g.samp(f"{tag}/grad/{n}"), 2e-3, 1e-6, f"{tag} grad {n}")
     keep = BR.keep_mask(dseed, 7, (1 << 20,), 0.1)
     assert abs(keep.mean() - 0.9) < 2e-3                                          # the shared generator is a fair Bernoulli(0.9)
+    # ... whose two decisions per hash (low / high 16 bits) are independent of each other: P(both kept) = 0.81, P(even) = P(odd) = 0.9
+    assert abs((keep[0::2] & keep[1::2]).mean() - 0.81) < 3e-3 and abs(keep[0::2].mean() - 0.9) < 3e-3 and abs(keep[1::2].mean() - 0.9) < 3e-3
+    k4 = BR.keep_mask(dseed, 9, (2, 3, 64, 65), 0.1)                               # attention probabilities: pairs within a row (odd row length)
+    assert abs(k4.mean() - 0.9) < 6e-3 and abs((k4[..., 0:64:2] & k4[..., 1:64:2]).mean() - 0.81) < 1e-2
 
 
 def test_srsoftmatch_bert_trace(golden):
