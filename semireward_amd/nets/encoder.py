@@ -100,28 +100,40 @@ class PostLNEncoderMixin(ModuleSurface):
         return xb
 
     def enc_bwd_plan(self, M, ctx):
-        """Shared output-gradient buffers (bf16 A operands of dW = dY^T X) + one descriptor table per layer for the grouped
-        weight-gradient launch (row-major operands, bias gradients summed on the way: srhip_gemm_tn_grouped_f32)."""
+        """Output-gradient buffers (bf16 A operands of dW = dY^T X), ONE SET PER LAYER, + the problem list of every layer for the weight-gradient
+        launch (row-major operands, bias gradients summed on the way).  The four dY of a layer used to be shared by all layers, which forced one
+        weight-gradient launch per layer inside the chain -- 108 tiles of 256 x 256 on 256 CUs (BERT: 336 us per layer, 13 % of the step).  Kept
+        per layer (BERT: 113 MB x 12 of 288 GB) they feed ONE launch behind the layer loop: 1 296 tiles in a persistent walk
+        (srhip_gemm_tn_grouped_pp_f32: 113 us per layer, tools/gemm_tn_pp_bench.py)."""
         key = ("encbwd", M, id(ctx))
         if key in self._ws:
             return self._ws[key]
         cfg = self.cfg
         D, I = cfg.hidden, cfg.inter
-        mk = lambda c: torch.empty(M, c, dtype=torch.bfloat16, device=self.device)   # noqa: E731
-        T = dict(g2=mk(D), dpre=mk(I), g1=mk(D), dqkv=mk(3 * D), dao=mk(D), desc=[])
+        mk = lambda c: [torch.empty(M, c, dtype=torch.bfloat16, device=self.device) for _ in range(cfg.layers)]   # noqa: E731
+        T = dict(g2=mk(D), dpre=mk(I), g1=mk(D), dqkv=mk(3 * D), dao=torch.empty(M, D, dtype=torch.bfloat16, device=self.device),
+                 probs=[], tables={})
         G = lambda n: self.view(n, self.grad)   # noqa: E731
         for i in range(cfg.layers):
             nm = self.enc_names(i)
             gw, gb = self.packed_qkv(i, self.grad)
-            T["desc"].append(ops.make_group_tn_desc(
-                [(T["g2"], ctx.h[i], G(nm["w2"]), G(nm["b2"]), D, I, M), (T["dpre"], ctx.xbm[i], G(nm["w1"]), G(nm["b1"]), I, D, M),
-                 (T["g1"], ctx.ao[i], G(nm["o_w"]), G(nm["o_b"]), D, D, M), (T["dqkv"], ctx.xb[i], gw, gb, 3 * D, D, M)], self.device))
-        # LayerNorm affine gradients go through LN_REP partial copies per LayerNorm (ops.layernorm_bwd_part), folded after the layer loop
+            T["probs"].append([(T["g2"][i], ctx.h[i], G(nm["w2"]), G(nm["b2"]), D, I, M), (T["dpre"][i], ctx.xbm[i], G(nm["w1"]), G(nm["b1"]), I, D, M),
+                               (T["g1"][i], ctx.ao[i], G(nm["o_w"]), G(nm["o_b"]), D, D, M), (T["dqkv"][i], ctx.xb[i], gw, gb, 3 * D, D, M)])
+        # LayerNorm affine gradients go through LN_REP partial copies per LayerNorm (ops.postln_bwd_part), folded after the layer loop
         T["ln_part"] = torch.zeros(2 * cfg.layers, LN_REP, 2, D, dtype=torch.float32, device=self.device)
         T["ln_desc"] = ops.make_ln_reduce_desc([(G(self.enc_names(i)[k + "_w"]), G(self.enc_names(i)[k + "_b"]))
                                                 for i in range(cfg.layers) for k in ("ln1", "ln2")], self.device)
         self._ws[key] = T
         return T
+
+    def enc_dw_table(self, T, skip):
+        """Descriptor table of the weight-gradient launch over the layers LayerDrop left in (one table per pattern, built when it first occurs)."""
+        pat = tuple(bool(s) for s in skip) if skip is not None else ()
+        if pat not in T["tables"]:
+            probs = [pr for i, lp in enumerate(T["probs"]) if not (pat and pat[i]) for pr in lp]
+            pp = bool(probs) and ops.tn_pp_efficiency(probs) >= 0.85
+            T["tables"][pat] = (ops.make_group_tn_desc(probs, self.device, tile=256 if pp else 128), pp) if probs else None
+        return T["tables"][pat]
 
     def enc_backward(self, dx, ctx, B, L, key_len, dr, skip=None):
         """dx fp32 [M, D]: gradient w.r.t. the encoder output on entry, w.r.t. its input on return (in place)."""
@@ -137,23 +149,25 @@ class PostLNEncoderMixin(ModuleSurface):
                 continue
             nm, wT = self.enc_names(i), self.wT[i]
             # ---- FFN: x_out = LN(y2), y2 = x_mid + dropout(W2 [dropout] gelu(W1 x_mid))
-            ops.postln_bwd_part(dx, ctx.y2[i], ctx.st2[i][0], ctx.st2[i][1], P(nm["ln2_w"]), dx, T["g2"], T["ln_part"][2 * i + 1], LN_REP, M, D,
+            ops.postln_bwd_part(dx, ctx.y2[i], ctx.st2[i][0], ctx.st2[i][1], P(nm["ln2_w"]), dx, T["g2"][i], T["ln_part"][2 * i + 1], LN_REP, M, D,
                                 dr(4 * i + SITE_FFN_OUT, pr["hidden"]))
             da = dr(4 * i + SITE_ACT, pr["act"])
             if da is None:
-                ops.gemm_nt(ops.EPI_DGELU_BF16, T["g2"], wT["w2"], T["dpre"], M, I, D, aux_in=ctx.pre[i], ldaux=I)
+                ops.gemm_nt(ops.EPI_DGELU_BF16, T["g2"][i], wT["w2"], T["dpre"][i], M, I, D, aux_in=ctx.pre[i], ldaux=I)
             else:
-                ops.gemm_nt_dropout(ops.EPI_DGELU_BF16, T["g2"], wT["w2"], T["dpre"], M, I, D, da, aux_in=ctx.pre[i], ldaux=I)
-            ops.gemm_nt(ops.EPI_RESID_F32, T["dpre"], wT["w1"], dx, M, D, I)
+                ops.gemm_nt_dropout(ops.EPI_DGELU_BF16, T["g2"][i], wT["w2"], T["dpre"][i], M, I, D, da, aux_in=ctx.pre[i], ldaux=I)
+            ops.gemm_nt(ops.EPI_RESID_F32, T["dpre"][i], wT["w1"], dx, M, D, I)
             # ---- attention: x_mid = LN(y1), y1 = x_in + dropout(Wo attn(qkv(x_in)))
-            ops.postln_bwd_part(dx, ctx.y1[i], ctx.st1[i][0], ctx.st1[i][1], P(nm["ln1_w"]), dx, T["g1"], T["ln_part"][2 * i], LN_REP, M, D,
+            ops.postln_bwd_part(dx, ctx.y1[i], ctx.st1[i][0], ctx.st1[i][1], P(nm["ln1_w"]), dx, T["g1"][i], T["ln_part"][2 * i], LN_REP, M, D,
                                 dr(4 * i + SITE_ATTN_OUT, pr["hidden"]))
-            ops.gemm_nt(ops.EPI_BF16, T["g1"], wT["o"], T["dao"], M, D, D)
-            ops.attn_masked_bwd(ctx.qkv[i], ctx.ao[i], T["dao"], ctx.lse[i], T["dqkv"], delta, key_len, B, L, H, scale,
+            ops.gemm_nt(ops.EPI_BF16, T["g1"][i], wT["o"], T["dao"], M, D, D)
+            ops.attn_masked_bwd(ctx.qkv[i], ctx.ao[i], T["dao"], ctx.lse[i], T["dqkv"][i], delta, key_len, B, L, H, scale,
                                 dr(4 * i + SITE_PROBS, pr["attn"]))
-            ops.gemm_nt(ops.EPI_RESID_F32, T["dqkv"], wT["qkv"], dx, M, D, 3 * D)
-            desc, npb, ntiles, flops, nbytes = T["desc"][i]
-            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
+            ops.gemm_nt(ops.EPI_RESID_F32, T["dqkv"][i], wT["qkv"], dx, M, D, 3 * D)
+        tab = self.enc_dw_table(T, skip)
+        if tab is not None:
+            (desc, npb, ntiles, flops, nbytes), pp = tab
+            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes, pp=pp)
         ops.ln_grad_reduce(T["ln_desc"], T["ln_part"], 2 * cfg.layers, LN_REP, D)
 
     # ---- mean-pool + 2-layer classifier head (bert.py:16-20,36-37 / wave2vecv2.py:17-21,46-48) ---------------------------

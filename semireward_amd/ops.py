@@ -280,19 +280,26 @@ GROUP_TN_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"
 TN_ATOMIC = 1
 
 
-def make_group_tn_desc(problems, device, split_k=0):
+def make_group_tn_desc(problems, device, split_k=0, tile=128):
     """problems: list of (A, B, C, dbias, M, N, K) with A bf16 [K,M], B bf16 [K,N] (dense rows), C fp32 [M,N], dbias fp32 [M]
     or None.  Returns (device uint8 tensor holding srhip_group_tn_desc[], n_entries, total_tiles, flops, algorithmic bytes).
     split_k > 0: a problem with K >= 2 * split_k becomes ceil(K / split_k) entries over slices of its token axis, flagged
-    SRHIP_TN_ATOMIC (they add into C; the launch must then be a C += product, beta = 1)."""
+    SRHIP_TN_ATOMIC (they add into C; the launch must then be a C += product, beta = 1).
+    tile = 256: the table of srhip_gemm_tn_grouped_pp_f32 (256 x 256 tiles; gemm_tn_grouped_f32(..., pp=True)).  Its walk is static -- workgroup
+    w of 256 takes tiles w, w + 256, ... -- so a short last round is balanced here: the last problems (enough of them to cover the tiles past
+    the last full round) are handed over as token slices (SRHIP_TN_ATOMIC entries), which turns "a few workgroups run one tile more" into
+    "most workgroups run a slice more" (beta must be 1 for such a table; `tn_pp_plan` says what was chosen)."""
     import numpy as np
+    plan = [(tuple(pr), split_k if (split_k > 0 and pr[6] >= 2 * split_k) else 0) for pr in problems]
+    if tile == 256 and split_k == 0:
+        plan = tn_pp_plan(problems)
     ent = []
     t = 0
-    for A, B, C, db, M, N, K in problems:
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        if split_k > 0 and K >= 2 * split_k:
-            for k0 in range(0, K, split_k):
-                ent.append((_p(A) + 2 * k0 * M, _p(B) + 2 * k0 * N, _p(C), _p(db) or 0, M, N, min(split_k, K - k0), M, N, N, t, TN_ATOMIC))
+    for (A, B, C, db, M, N, K), sk in plan:
+        tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
+        if sk > 0:
+            for k0 in range(0, K, sk):
+                ent.append((_p(A) + 2 * k0 * M, _p(B) + 2 * k0 * N, _p(C), _p(db) or 0, M, N, min(sk, K - k0), M, N, N, t, TN_ATOMIC))
                 t += tiles
         else:
             ent.append((_p(A), _p(B), _p(C), _p(db) or 0, M, N, K, M, N, N, t, 0))
@@ -306,12 +313,49 @@ def make_group_tn_desc(problems, device, split_k=0):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(ent), t, flops, nbytes
 
 
-def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
-    """C_p = alpha * A_p^T . B_p + beta * C_p (+ dbias_p += colsum A_p) for all problems in one launch."""
+TN_PP_GRID = 256          # workgroups of srhip_gemm_tn_grouped_pp_f32 (one per CU)
+
+
+def tn_pp_plan(problems, grid=TN_PP_GRID):
+    """[(problem, token-slice length or 0)] for a 256-tile table: problems in order, the LAST ones sliced along the token axis when the tiles past
+    the last full round of `grid` would otherwise leave most workgroups idle for one whole tile.  A slice is a multiple of 64 tokens (the
+    kernel's K-tile) and at least 512; at most 8 slices per problem."""
+    tiles = [((M + 255) // 256) * ((N + 255) // 256) for *_, M, N, K in problems]
+    total = sum(tiles)
+    rem = total % grid
+    plan = [(tuple(pr), 0) for pr in problems]
+    if total < grid or rem == 0 or rem > 0.7 * grid:
+        return plan
+    got = 0
+    for i in range(len(problems) - 1, -1, -1):
+        if got >= rem:
+            break
+        K = problems[i][6]
+        want = max(2, min(8, grid // max(rem, 1)))
+        n = min(want, K // 512)
+        if n >= 2:
+            sl = -(-K // n)
+            sl = -(-sl // 64) * 64
+            plan[i] = (tuple(problems[i]), sl)
+        got += tiles[i]
+    return plan
+
+
+def tn_pp_efficiency(problems):
+    """Share of the 256 x 256 tiles' area that is inside the problems (1.0 when every M and N is a multiple of 256)."""
+    area = sum(M * N for *_, M, N, K in problems)
+    cover = sum(((M + 255) // 256) * ((N + 255) // 256) * 65536 for *_, M, N, K in problems)
+    return area / max(cover, 1)
+
+
+def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0, pp=False):
+    """C_p = alpha * A_p^T . B_p + beta * C_p (+ dbias_p += colsum A_p) for all problems in one launch.  pp: the table counts 256 x 256 tiles
+    (make_group_tn_desc(tile=256)) and goes to the persistent two-group kernel."""
+    fn, kern = ("srhip_gemm_tn_grouped_pp_f32", "gemm_tn_pp_kernel") if pp else ("srhip_gemm_tn_grouped_f32", "gemm_tn_grouped_f32_kernel")
     if _PROFILE is not None:
-        _PROFILE.timed("srhip_gemm_tn_grouped_f32", (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, "gemm_tn_grouped_f32_kernel", nbytes)
+        _PROFILE.timed(fn, (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, kern, nbytes)
         return
-    _call("srhip_gemm_tn_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
+    _call(fn, _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
 
 def attn_block_supported(N, D, H):

@@ -154,6 +154,60 @@ def test_gemm_tn_grouped():
             assert relerr(db, dbr) < 2e-6, (K, M, N)
 
 
+def _tn_problems(shapes, with_bias=True, seed0=0):
+    problems, refs = [], []
+    for i, (K, M, N) in enumerate(shapes):
+        A, Bm = bf(rnd(K, M, seed=seed0 + 10 + i)), bf(rnd(K, N, seed=seed0 + 20 + i))
+        A[:, 3] += 1.0                                             # asymmetric: a transposed / permuted fragment would show
+        Bm[:, 5] -= 0.5
+        C0, db0 = rnd(M, N, seed=seed0 + 30 + i), rnd(M, seed=seed0 + 40 + i)
+        C, db = C0.clone(), (db0.clone() if (with_bias and i != 1) else None)
+        problems.append((A, Bm, C, db, M, N, K))
+        refs.append((C0, A.float().T @ Bm.float(), None if db is None else db0 + A.float().sum(0)))
+    return problems, refs
+
+
+def test_gemm_tn_grouped_pp():
+    """The 256 x 256 persistent weight-gradient kernel (srhip_gemm_tn_grouped_pp_f32) against fp32 torch on the same bf16 operands: ragged K
+    (not a multiple of the 64-token K-tile, shorter than one), partial tiles in both directions (384 = 256 + 128, 136, 72), bias sums, accumulate
+    and overwrite, token slices through atomics, and a table of more tiles than workgroups (the cursor crosses tiles and entries)."""
+    shapes = [(1100, 768, 512), (64, 256, 256), (4112, 384, 384), (300, 384, 1536), (33, 136, 72), (640, 1152, 384), (200, 256, 768)]     # (K, M, N)
+    for alpha, beta in ((0.5, 1.0), (1.0, 0.0)):
+        problems, refs = _tn_problems(shapes)
+        desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV, tile=256)
+        assert ntiles == sum(((M + 255) // 256) * ((N + 255) // 256) for K, M, N in shapes)
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=alpha, beta=beta, pp=True)
+        torch.cuda.synchronize()
+        for (A, Bm, C, db, M, N, K), (C0, P, dbr) in zip(problems, refs):
+            Cr = beta * C0 + alpha * P
+            assert relerr(C, Cr) < 2e-6, (K, M, N, alpha, beta, relerr(C, Cr))
+            if db is not None:
+                assert relerr(db, dbr) < 2e-6, (K, M, N)
+    # token slices (SRHIP_TN_ATOMIC entries): the order of the fp32 atomic adds is free, the sum is not
+    problems, refs = _tn_problems([(1100, 768, 512), (640, 384, 640)], seed0=100)
+    desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV, split_k=256, tile=256)
+    assert npb == 5 + 3
+    ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, pp=True)
+    torch.cuda.synchronize()
+    for (A, Bm, C, db, M, N, K), (C0, P, dbr) in zip(problems, refs):
+        assert relerr(C, C0 + P) < 2e-6, (K, M, N, relerr(C, C0 + P))
+        if db is not None:
+            assert relerr(db, dbr) < 2e-6
+    # more tiles than workgroups + the planner's sliced tail: 7 x (9 + 9 + 9 + 12) = 273 tiles -> 17 past the first round
+    shapes = [(1088, 768, 768), (1088, 768, 768), (1088, 768, 768), (1088, 768, 1024)] * 7
+    problems, refs = _tn_problems(shapes, seed0=200)
+    plan = ops.tn_pp_plan(problems)
+    assert any(sl > 0 for _, sl in plan) and all(sl % 64 == 0 for _, sl in plan)
+    desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV, tile=256)
+    assert ntiles > 273 and npb > len(shapes)
+    ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, pp=True)
+    torch.cuda.synchronize()
+    for (A, Bm, C, db, M, N, K), (C0, P, dbr) in zip(problems, refs):
+        assert relerr(C, C0 + P) < 2e-6, (K, M, N, relerr(C, C0 + P))
+        if db is not None:
+            assert relerr(db, dbr) < 2e-6
+
+
 def test_gemm_identity_asymmetric():
     """A = I against an asymmetric B: catches a swapped row/col C write that random-norm checks could hide."""
     K = 128
