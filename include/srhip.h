@@ -90,15 +90,12 @@ int srhip_gemm_tn_grouped_f32(const srhip_group_tn_desc* desc_dev, int n_problem
                               void* stream);
 /* The same products through 256 x 256 output tiles (persistent workgroups, 64-token K-tiles, two wave groups half a phase apart): the kernel for
  * the wide layers' weight gradients (D = 768: autograd of the HF encoder Linears behind semilearn/nets/bert/bert.py:34 and
- * wave2vecv2/wave2vecv2.py:44; 8192 tokens per step) and for the ViT-S table (autograd of vit.py:69-75, :95-112).  Same descriptor, same
+ * wave2vecv2/wave2vecv2.py:44; 8192 tokens per step) and for ViT-S tables whose problems 256-tiles cover well.  Same descriptor, same
  * arithmetic (bf16 operands, fp32 accumulation, dbias += column sums of A) -- but tile_start / total_tiles count 256 x 256 tiles:
- * ceil(M / 256) * ceil(N / 256) per entry.  A tile that covers no more than 128 rows (columns) of its 256 loads and multiplies only that half.
- * The walk is static (workgroup w of G = min(total_tiles, 256) takes items w, w + G, ...); the caller balances it:
- *   - a short last round: the last entries handed over as SRHIP_TN_ATOMIC token slices (ops.make_group_tn_desc(tile=256) does);
- *   - tiles of different cost: items_dev != NULL is a list of total_tiles pairs (tile index, entry index), (-1, -1) = no item, in the order the
- *     walk takes them (8-byte aligned; ops.tn_pp_items); items_dev == NULL: tiles in table order. */
-int srhip_gemm_tn_grouped_pp_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, const int* items_dev, float alpha,
-                                 float beta, void* stream);
+ * ceil(M / 256) * ceil(N / 256) per entry.  The walk is static (workgroup w takes tiles w, w + 256, ...): the caller balances a short last
+ * round by handing the last entries over as SRHIP_TN_ATOMIC token slices (ops.make_group_tn_desc(tile=256) does). */
+int srhip_gemm_tn_grouped_pp_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
+                                 void* stream);
 
 /* Fused attention, head_dim 64.  qkv bf16 [B*N, 3*H*64] as written by the qkv Linear; out bf16 [B*N, H*64];
  * lse fp32 [B,H,N] (NULL when no backward is needed).  Replaces vit.py:100-104 (K4).  N <= 512. */
@@ -127,15 +124,6 @@ int srhip_attn_masked_bwd(const void* qkv, const void* out, const void* d_out, c
  * mean/rstd fp32 [M] are written when non-NULL (needed by the backward).  D in {128, 384, 768}. */
 int srhip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* out, float* mean,
                         float* rstd, int M, int D, void* stream);
-/* LayerNorm fused into the Linear that consumes it, for the rows that keep activations for the backward (D = 384):
- *   ln_out = LayerNorm(x) (bf16 [M, D]), mean / rstd fp32 [M] (each output may be NULL; mean and rstd together),
- *   out = ln W^T + bias                        (SRHIP_EPI_BF16: norm1 -> attn.qkv, vit.py:163 with :93-98)
- *   out = GELU(ln W^T + bias), aux_out = ln W^T + bias   (SRHIP_EPI_GELU_BF16: norm2 -> mlp.fc1 + act, vit.py:165 with :69-72)
- * = srhip_layernorm_fwd + srhip_gemm_nt in one launch, same rounding points (ln bf16, fp32 accumulation, bf16 outputs); W bf16 [N, D], N a
- * multiple of 384.  srhip_ln_gemm_supported(D, N) says whether a shape is covered (ViT-S: 1152 and 1536). */
-int srhip_ln_gemm_supported(int D, int N);
-int srhip_ln_gemm(int epilogue, const float* x, const float* gamma, const float* beta, float eps, const void* W, const float* bias,
-                  void* out, void* aux_out, void* ln_out, float* mean, float* rstd, int M, int N, int D, void* stream);
 /* dx (fp32) += LN'(dy bf16); dgamma/dbeta (fp32) += column sums (atomic). */
 int srhip_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dgamma, float* dbeta, int M, int D, void* stream);

@@ -23,12 +23,10 @@ SIGNATURES = {
     "srhip_gemm_small_max_grid": (I, [I]),
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_gemm_tn_grouped_f32": (I, [P, I, I, F, F, P]),
-    "srhip_gemm_tn_grouped_pp_f32": (I, [P, I, I, P, F, F, P]),
+    "srhip_gemm_tn_grouped_pp_f32": (I, [P, I, I, F, F, P]),
     "srhip_attn_fwd": (I, [P, P, P, I, I, I, F, P]),
     "srhip_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, F, P]),
     "srhip_layernorm_fwd": (I, [P, P, P, F, P, P, P, I, I, P]),
-    "srhip_ln_gemm_supported": (I, [I, I]),
-    "srhip_ln_gemm": (I, [I, P, P, P, F, P, P, P, P, P, P, P, I, I, I, P]),
     "srhip_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P]),
     "srhip_layernorm_bwd_cast": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "srhip_layernorm_bwd_part": (I, [P, P, P, P, P, P, P, I, P, P, I, I, I, P]),

@@ -174,11 +174,6 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip
 //     wait / slot arithmetic exactly as in gemm_pp_kernel (phase k issues half-tile k + NSLOT - 2 and waits until <= NSLOT - 4 are in flight).
 //   * the walk is persistent over the tiles of ALL entries of the table (an entry = one Linear's dW, or one token slice of it flagged
 //     SRHIP_TN_ATOMIC); the refill cursor runs across tile and entry boundaries.
-//   * partial tiles cost what they cover: A0 / A1 are the first / second 128 rows of the tile and B0 / B1 the first / second 128 columns, so a
-//     tile that reaches no further than 128 rows (columns) into its 256 has no A1 (B1): those half-tiles are not loaded (out-of-range no-op
-//     loads keep the ring arithmetic) and their quadrants not multiplied -- ViT-S (every M, N a multiple of 384 = 256 + 128) does 71 % of the
-//     work of full tiles.  Tiles then differ in cost, and the walk is static (workgroup w takes items w, w + G, ...): the host may pass an item
-//     list (tile index + entry per item, -1 = none) ordered so that heavy and light tiles share workgroups (ops.tn_pp_items).
 //   * dbias: wave (wr, wc) sums row tile wc of each half -- two extra MFMAs per half and K-tile against a ones operand, on the tiles of column 0
 //     only; the wave's row tiles are taken in the order (mt + wc) & 3 so that "its" tile is always fragment set 0 (no register indexing).
 constexpr int PBK = 64;                   // tokens per K-tile
@@ -200,7 +195,7 @@ __device__ __forceinline__ void pp_tile_mn(int t, int ntm, int ntn, int& tm, int
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn_desc* __restrict__ desc, int n_problems, int total_tiles,
-                                                            const int2* __restrict__ items, float alpha, float beta) {
+                                                            float alpha, float beta) {
   extern __shared__ __attribute__((aligned(16))) bf16_t psm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -214,7 +209,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
   // half-tile.  Lane -> row 4 wave + (lane >> 4), physical chunk lane & 15 <- logical chunk (p - 2 row) & 15 of the half-tile's 128 features.
   const int prow = 4 * wave + (lane >> 4);
   const int pls = ((lane & 15) - 2 * prow) & 15;
-  const int pfa = 8 * pls;                                      // A half h: feature m0 + 128 h + pfa; B half j: feature n0 + 128 j + pfa
+  const int pfa = 8 * pls + (pls >= 8 ? 64 : 0);                // A half h: feature m0 + 64 h + pfa
+  const int pfb = 64 * (pls >> 2) + 8 * (pls & 3);              // B half h: feature n0 + 32 h + pfb
   constexpr int OOB = 0x7ffffff0;                               // past num_records: moves nothing, still counts in vmcnt
   int c_tile = first, c_kt = 0, c_slot = 0, c_e = 0, c_nk = 1, c_soa = 0, c_sob = 0, c_ska = 0, c_skb = 0;
   const void* c_pa = desc[0].A;
@@ -222,36 +218,30 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
   int c_na = 0, c_nb = 0;
   int va[2][2], vb[2][2];                                       // [half][piece] byte offsets of the lane
   auto set_cur = [&]() {
-    int tile_id = c_tile;
-    if (items) {                                                // skip the padding of an ordered list
-      while (c_tile < total_tiles && items[c_tile].x < 0) c_tile += gridDim.x;
-      if (c_tile < total_tiles) { tile_id = items[c_tile].x; c_e = items[c_tile].y; }
-    }
     if (c_tile >= total_tiles) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { va[i >> 1][i & 1] = OOB; vb[i >> 1][i & 1] = OOB; }
       c_nk = 1 << 28;
       return;
     }
-    if (!items) { while (c_e + 1 < n_problems && tile_id >= desc[c_e + 1].tile_start) ++c_e; }
+    while (c_e + 1 < n_problems && c_tile >= desc[c_e + 1].tile_start) ++c_e;
     const srhip_group_tn_desc d = desc[c_e];
     const int ntm = (d.M + 255) >> 8, ntn = (d.N + 255) >> 8;
     int tm_, tn_;
-    pp_tile_mn(tile_id - d.tile_start, ntm, ntn, tm_, tn_);
+    pp_tile_mn(c_tile - d.tile_start, ntm, ntn, tm_, tn_);
     c_pa = d.A; c_pb = d.B;
     c_na = max(d.K * d.lda, (d.K - 1) * d.lda + d.M) * 2;
     c_nb = max(d.K * d.ldb, (d.K - 1) * d.ldb + d.N) * 2;
     c_nk = (d.K + PBK - 1) / PBK;
     c_soa = tm_ * 512; c_sob = tn_ * 512;                       // bytes: 256 features
     c_ska = PBK * d.lda * 2; c_skb = PBK * d.ldb * 2;
-    const bool h1 = d.M - tm_ * 256 > 128, j1 = d.N - tn_ * 256 > 128;      // the tile has a second half of rows / columns
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      va[0][i] = ((prow + 32 * i) * d.lda + pfa) * 2;
-      vb[0][i] = ((prow + 32 * i) * d.ldb + pfa) * 2;
-      va[1][i] = h1 ? va[0][i] + 256 : OOB;
-      vb[1][i] = j1 ? vb[0][i] + 256 : OOB;
-    }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        va[h][i] = ((prow + 32 * i) * d.lda + pfa + 64 * h) * 2;
+        vb[h][i] = ((prow + 32 * i) * d.ldb + pfb + 32 * h) * 2;
+      }
   };
   auto issue = [&](auto kc) __attribute__((always_inline)) {      // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
     constexpr int kind = decltype(kc)::value;
@@ -303,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
     const u32x2_t x0 = ds_read_tr16(st + fo + ks * 32 * 128), x1 = ds_read_tr16(st + fo + ks * 32 * 128 + 16 * 128);
     return u32x4_t{x0[0], x0[1], x1[0], x1[1]};
   };
-  bool do_bias = false, use_h1 = true, use_j1 = true;
+  bool do_bias = false;
   auto quadrant = [&](auto hc, auto jc, u32x4_t (&fb)[2][2]) __attribute__((always_inline)) {
     constexpr int h = decltype(hc)::value, j = decltype(jc)::value;
     __builtin_amdgcn_s_setprio(1);
@@ -354,36 +344,27 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
     quadrant(I0{}, I0{}, fb0);
     TPP_END()
     // ---- p1
-    if (use_j1) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb1[nt][ks] = rdf(psm + sl[2], foB[nt], ks);
-    }
+      for (int ks = 0; ks < 2; ++ks) fb1[nt][ks] = rdf(psm + sl[2], foB[nt], ks);
     issue(I1{});
     TPP_SYNC(w1)
-    if (use_j1) quadrant(I0{}, I1{}, fb1);
+    quadrant(I0{}, I1{}, fb1);
     TPP_END()
     // ---- p2
-    if (use_h1) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rdf(psm + sl[3], foA[mt], ks);
-    }
+      for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = rdf(psm + sl[3], foA[mt], ks);
     issue(I2{});
     TPP_SYNC(w2)
-    if (use_h1 && use_j1) quadrant(I1{}, I1{}, fb1);
-    else if (use_h1 && do_bias) {          // the column sums of A1 ride in q(1,1): without it they are taken here
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, fa[0][ks]), accb[1], 0, 0, 0);
-    }
+    quadrant(I1{}, I1{}, fb1);
     TPP_END()
     // ---- p3
     issue(I3{});
     TPP_SYNC(w3)
-    if (use_h1) quadrant(I1{}, I0{}, fb0);
+    quadrant(I1{}, I0{}, fb0);
     TPP_END()
     r_base = r_base + 4 >= PSLOT ? r_base + 4 - PSLOT : r_base + 4;
   };
@@ -392,24 +373,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
   __builtin_amdgcn_s_barrier();
   int ct = first, e_e = 0;
   for (int t = 0; t < my_tiles; ++t, ct += gridDim.x) {
-    int tile_id = ct;
-    if (items) {
-      const int2 it = items[ct];
-      if (it.x < 0) continue;                         // padding of an ordered list (the refill cursor skipped it too)
-      tile_id = it.x; e_e = it.y;
-    } else {
-      while (e_e + 1 < n_problems && tile_id >= desc[e_e + 1].tile_start) ++e_e;
-    }
+    while (e_e + 1 < n_problems && ct >= desc[e_e + 1].tile_start) ++e_e;
     const srhip_group_tn_desc d = desc[e_e];
     const int ntm = (d.M + 255) >> 8, ntn = (d.N + 255) >> 8, nk = (d.K + PBK - 1) / PBK;
     int tm_, tn_;
-    pp_tile_mn(tile_id - d.tile_start, ntm, ntn, tm_, tn_);
+    pp_tile_mn(ct - d.tile_start, ntm, ntn, tm_, tn_);
     do_bias = d.dbias != nullptr && tn_ == 0;
-    use_h1 = d.M - tm_ * 256 > 128; use_j1 = d.N - tn_ * 256 > 128;
     if (wr == 1) __builtin_amdgcn_s_barrier();        // the lower row group runs one barrier behind
     for (int kt = 0; kt < nk; ++kt) ktile(kt);
     // ---- epilogue: lane holds C[m][n .. n + 3], m = row l15 of a row tile, n = 4 lg of a column tile
-    const int mb = tm_ * 256 + wr * 64, nb = tn_ * 256 + wc * 32;      // row tile 4 h + mt: mb + 128 h + 16 ((mt + wc) & 3); column tile 2 j + nt: nb + 128 j + 16 nt
+    const int mb = tm_ * 256 + wr * 128, nb = tn_ * 256 + wc * 64;
     const bool atomic = (d.flags & SRHIP_TN_ATOMIC) != 0;
     if (wr == 0) __builtin_amdgcn_s_barrier();
     WAIT_VM(0);
@@ -417,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
     if (do_bias) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int m = mb + h * 128 + wc * 16 + l15;
+        const int m = mb + h * 64 + wc * 16 + l15;
         if (lg == 0 && m < d.M) {
           const float v = accb[h][0];
           if (atomic) unsafeAtomicAdd(d.dbias + m, v); else d.dbias[m] += v;
@@ -432,19 +405,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
       if (rd_c) {
 #pragma unroll
         for (int mq = 0; mq < 2; ++mq) {
-          const int m = min(mb + (hq >> 1) * 128 + ((2 * (hq & 1) + mq + wc) & 3) * 16 + l15, d.M - 1);
+          const int m = min(mb + (hq >> 1) * 64 + ((2 * (hq & 1) + mq + wc) & 3) * 16 + l15, d.M - 1);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            res[mq][i] = *reinterpret_cast<const f32x4_t*>(d.C + (size_t)m * d.ldc + min(nb + (i >> 1) * 128 + (i & 1) * 16 + lg * 4, d.N - 4));
+          for (int i = 0; i < 4; ++i) res[mq][i] = *reinterpret_cast<const f32x4_t*>(d.C + (size_t)m * d.ldc + min(nb + i * 16 + lg * 4, d.N - 4));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mq = 0; mq < 2; ++mq) {
-        const int mt = 2 * hq + mq, m = mb + (hq >> 1) * 128 + ((2 * (hq & 1) + mq + wc) & 3) * 16 + l15;
+        const int mt = 2 * hq + mq, m = mb + (hq >> 1) * 64 + ((2 * (hq & 1) + mq + wc) & 3) * 16 + l15;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int n = nb + (i >> 1) * 128 + (i & 1) * 16 + lg * 4;
+          const int n = nb + i * 16 + lg * 4;
           f32x4_t x = {alpha * acc[i][mt][0], alpha * acc[i][mt][1], alpha * acc[i][mt][2], alpha * acc[i][mt][3]};
           acc[i][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           if (m < d.M && n < d.N) {
@@ -468,13 +440,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
 
 }  // namespace
 
-extern "C" int srhip_gemm_tn_grouped_pp_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, const int* items_dev, float alpha,
+extern "C" int srhip_gemm_tn_grouped_pp_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha,
                                             float beta, void* stream) {
-  if (!desc_dev || n_problems <= 0 || n_problems > 4096 || total_tiles <= 0 || ((uintptr_t)items_dev & 7)) return SR_EINVAL;
+  if (!desc_dev || n_problems <= 0 || n_problems > 4096 || total_tiles <= 0) return SR_EINVAL;
   constexpr size_t sm = (size_t)PSLOT * PH_EL * sizeof(bf16_t);
   (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  SR_LAUNCH(gemm_tn_pp_kernel, dim3(min(total_tiles, 256)), dim3(512), sm, (hipStream_t)stream, desc_dev, n_problems, total_tiles,
-            reinterpret_cast<const int2*>(items_dev), alpha, beta);
+  SR_LAUNCH(gemm_tn_pp_kernel, dim3(min(total_tiles, 256)), dim3(512), sm, (hipStream_t)stream, desc_dev, n_problems, total_tiles, alpha, beta);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

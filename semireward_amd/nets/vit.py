@@ -15,7 +15,6 @@ Data layout in HBM (B images, N tokens, D channels, M = B*N rows):
   weights                   bf16 [out, in]   (+ transposed bf16 copies for the dX products)
 """
 import math
-import os
 import types
 
 import torch
@@ -66,8 +65,6 @@ _FUSED_MLP = True          # LN2 + fc1 + GELU + fc2 + residual as one launch
 _FUSED_ATTN = True         # qkv Linear + attention as one launch
 _FUSED_PROJ = True         # attention projection + residual inside the fused MLP launch
 _FUSED_NEXT_LN = True      # ... which then also writes the next block's norm1 output
-_DW_PP = os.environ.get("SR_DW_PP", "1") != "0"       # weight gradients of all blocks through the 256 x 256 persistent kernel (A/B switch)
-_FUSED_LN_GEMM = os.environ.get("SR_FUSED_LN_GEMM", "0") != "0"     # gradient rows: norm1 + qkv and norm2 + fc1 + GELU as one launch each (A/B switch)
 # the fused kernel owns a CU per 128-row tile for ~90 us whatever the launch size: below ~half a chip of tiles (the 8 inference images of the
 # pre-start_timing regime = 17 tiles) LayerNorm + two 64x64-tiled GEMMs spread over all CUs are faster
 _FUSED_MLP_MIN_ROWS = 16384
@@ -297,15 +294,13 @@ class VisionTransformer(ModuleSurface):
         scale = 64 ** -0.5
         dst0, dst1 = (droppath.stride(0), droppath.stride(1)) if droppath is not None else (0, 0)      # (a column range of the step's table: strided rows)
         ln_ready = False           # the previous block's fused launch already wrote this block's norm1 output
-        ln_fused = save and _FUSED_LN_GEMM and ops.ln_gemm_supported(D, 3 * D) and ops.ln_gemm_supported(D, Hd)
         for i in range(cfg.depth):
             b = "blocks.%d." % i
             s1 = ops.RawRows(droppath, i * dst0) if droppath is not None else None            # droppath[i, 0], droppath[i, 1] without building views
             s2 = ops.RawRows(droppath, i * dst0 + dst1) if droppath is not None else None
             if save:
                 ln, qkv, ao = ctx.ln1[i], ctx.qkv[i], ctx.ao[i]
-                if not ln_fused:
-                    ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
+                ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, ctx.st1[i][0], ctx.st1[i][1], M, D)
             elif not ln_ready:
                 ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, ln, None, None, M, D)
             ao_scaled = False
@@ -316,24 +311,16 @@ class VisionTransformer(ModuleSurface):
                 ops.attn_block_fused(ln, P(b + "attn.qkv.weight", wb), P(b + "attn.qkv.bias"), ao, B, N, D, H, scale, qkv_extra=qkvx,
                                      out_scale=s1 if ao_scaled else None)
             else:
-                if save and ln_fused:      # norm1 + qkv Linear as one launch (the chain the losses wait for is bound by its launch count)
-                    ops.ln_gemm(ops.EPI_BF16, x, P(b + "norm1.weight"), P(b + "norm1.bias"), cfg.eps, P(b + "attn.qkv.weight", wb),
-                                P(b + "attn.qkv.bias"), qkv, M, 3 * D, D, ln_out=ln, mean=ctx.st1[i][0], rstd=ctx.st1[i][1])
-                else:
-                    ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
+                ops.gemm_nt(ops.EPI_BF16, ln, P(b + "attn.qkv.weight", wb), qkv, M, 3 * D, D, bias=P(b + "attn.qkv.bias"))
                 ops.attn_fwd(qkv, ao, ctx.lse[i] if save else None, B, N, H, scale)
             if save:
                 xm = ctx.xmid[i]
                 ops.gemm_nt(ops.EPI_RESID_F32, ao, P(b + "attn.proj.weight", wb), xm, M, D, D, bias=P(b + "attn.proj.bias"),
                             row_scale=s1, rows_per_sample=N, aux_in=x, ldaux=D)
                 ln2 = ctx.ln2[i]
-                if ln_fused:               # norm2 + fc1 + GELU as one launch
-                    ops.ln_gemm(ops.EPI_GELU_BF16, xm, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, P(b + "mlp.fc1.weight", wb),
-                                P(b + "mlp.fc1.bias"), ctx.h[i], M, Hd, D, ln_out=ln2, mean=ctx.st2[i][0], rstd=ctx.st2[i][1], aux_out=ctx.pre[i])
-                else:
-                    ops.layernorm_fwd(xm, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln2, ctx.st2[i][0], ctx.st2[i][1], M, D)
-                    ops.gemm_nt(ops.EPI_GELU_BF16, ln2, P(b + "mlp.fc1.weight", wb), ctx.h[i], M, Hd, D, bias=P(b + "mlp.fc1.bias"),
-                                aux_out=ctx.pre[i], ldaux=Hd)
+                ops.layernorm_fwd(xm, P(b + "norm2.weight"), P(b + "norm2.bias"), cfg.eps, ln2, ctx.st2[i][0], ctx.st2[i][1], M, D)
+                ops.gemm_nt(ops.EPI_GELU_BF16, ln2, P(b + "mlp.fc1.weight", wb), ctx.h[i], M, Hd, D, bias=P(b + "mlp.fc1.bias"),
+                            aux_out=ctx.pre[i], ldaux=Hd)
                 xn = ctx.xs[i + 1]
                 ops.gemm_nt(ops.EPI_RESID_F32, ctx.h[i], P(b + "mlp.fc2.weight", wb), xn, M, D, Hd, bias=P(b + "mlp.fc2.bias"),
                             row_scale=s2, rows_per_sample=N, aux_in=xm, ldaux=D)
@@ -410,9 +397,7 @@ class VisionTransformer(ModuleSurface):
                          (t["dpre"], ctx.ln2[i], G(b + "mlp.fc1.weight"), G(b + "mlp.fc1.bias"), Hd, D, M),
                          (t["g1"], ctx.ao[i], G(b + "attn.proj.weight"), G(b + "attn.proj.bias"), D, D, M),
                          (t["dqkv"], ctx.ln1[i], G(b + "attn.qkv.weight"), G(b + "attn.qkv.bias"), 3 * D, D, M)]
-        # all layers in one launch: the 256 x 256 persistent kernel (its partial tiles cost what they cover); the data-parallel layer groups below
-        # (a third of the tiles each) stay on the 128 x 128 kernel
-        out = dict(layers=layers, desc=ops.make_group_tn_desc(problems, self.device, tile=256 if _DW_PP else 128), dw_pp=_DW_PP)
+        out = dict(layers=layers, desc=ops.make_group_tn_desc(problems, self.device))
         # LayerNorm affine gradients: LN_REP partial copies per LayerNorm (same-address atomics of ~500 workgroups serialise), folded into
         # the gradient block by ONE launch after the layer loop.  Order: norm1, norm2 of block 0, 1, ...
         out["ln_part"] = torch.zeros(2 * cfg.depth, LN_REP, 2, D, dtype=torch.float32, device=self.device)
@@ -536,7 +521,7 @@ class VisionTransformer(ModuleSurface):
         if not getattr(self, "_groups_launched", False):      # (a partial-range chain never launches them, whether or not a callback is installed)
             ops.ln_grad_reduce(T["ln_desc"], T["ln_part"], 2 * cfg.depth, LN_REP, D)
             desc, npb, ntiles, flops, nbytes = T["desc"]
-            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes, pp=T["dw_pp"])
+            ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)
             if self.grad_ready_cb is not None:
                 lo = min(g["flat"][0] for g in T["groups"]); hi = max(g["flat"][1] for g in T["groups"])
                 self.grad_ready_cb(lo, hi)              # the blocks' range in one piece (the chain did not hand it over in groups)

@@ -310,13 +310,7 @@ def make_group_tn_desc(problems, device, split_k=0, tile=128):
     assert arr.itemsize == 64
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
-    desc = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
-    if tile == 256:
-        items = tn_pp_items([(e[4], e[5], e[6], e[10]) for e in ent])
-        if items is not None:
-            desc.pp_items = torch.from_numpy(items).to(device)       # rides with the table (gemm_tn_grouped_f32(pp=True) passes it on)
-            t = items.shape[0]
-    return desc, len(ent), t, flops, nbytes
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(ent), t, flops, nbytes
 
 
 TN_PP_GRID = 256          # workgroups of srhip_gemm_tn_grouped_pp_f32 (one per CU)
@@ -347,37 +341,6 @@ def tn_pp_plan(problems, grid=TN_PP_GRID):
     return plan
 
 
-def _pp_tile_mn(t, ntm, ntn, group_m=8):
-    """Tile index inside an entry -> (row tile, column tile): gemm_tn.hip pp_tile_mn."""
-    band = t // (group_m * ntn)
-    r = t - band * group_m * ntn
-    rows = min(group_m, ntm - band * group_m)
-    return band * group_m + r % rows, r // rows
-
-
-def tn_pp_items(entries, grid=TN_PP_GRID):
-    """Item list of srhip_gemm_tn_grouped_pp_f32 for a table whose tiles differ in cost (entries: (M, N, K, tile_start) per table entry): int32
-    [n, 2] = (tile index, entry index) per item in walk order, (-1, -1) = none; or None when table order is as good (fewer tiles than workgroups,
-    or every tile whole).  A tile costs (halves of rows it reaches into) x (halves of columns) x K-tiles; the items are dealt heaviest first,
-    forwards and backwards over the workgroups in turn, so that a workgroup's second item is light where its first was heavy."""
-    import numpy as np
-    its = []
-    for e, (M, N, K, t0) in enumerate(entries):
-        ntm, ntn, nk = (M + 255) // 256, (N + 255) // 256, (K + 63) // 64
-        for t in range(ntm * ntn):
-            tm, tn = _pp_tile_mn(t, ntm, ntn)
-            its.append((-(1 + (M - 256 * tm > 128)) * (1 + (N - 256 * tn > 128)) * nk, t0 + t, e))
-    if len(its) <= grid or len({c for c, _, _ in its}) == 1:
-        return None
-    its.sort(key=lambda x: x[0])                       # stable: equal tiles keep table order (neighbours share operand panels in L2)
-    rounds = -(-len(its) // grid)
-    out = np.full((rounds * grid, 2), -1, dtype=np.int32)
-    for p, (_, tid, e) in enumerate(its):
-        r, i = divmod(p, grid)
-        out[r * grid + (i if r % 2 == 0 else grid - 1 - i)] = (tid, e)
-    return out
-
-
 def tn_pp_efficiency(problems):
     """Share of the 256 x 256 tiles' area that is inside the problems (1.0 when every M and N is a multiple of 256)."""
     area = sum(M * N for *_, M, N, K in problems)
@@ -388,16 +351,11 @@ def tn_pp_efficiency(problems):
 def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0, pp=False):
     """C_p = alpha * A_p^T . B_p + beta * C_p (+ dbias_p += colsum A_p) for all problems in one launch.  pp: the table counts 256 x 256 tiles
     (make_group_tn_desc(tile=256)) and goes to the persistent two-group kernel."""
-    if pp:
-        args = (_p(desc), n_problems, total_tiles, _p(getattr(desc, "pp_items", None)), alpha, beta, _s())
-        fn, kern = "srhip_gemm_tn_grouped_pp_f32", "gemm_tn_pp_kernel"
-    else:
-        args = (_p(desc), n_problems, total_tiles, alpha, beta, _s())
-        fn, kern = "srhip_gemm_tn_grouped_f32", "gemm_tn_grouped_f32_kernel"
+    fn, kern = ("srhip_gemm_tn_grouped_pp_f32", "gemm_tn_pp_kernel") if pp else ("srhip_gemm_tn_grouped_f32", "gemm_tn_grouped_f32_kernel")
     if _PROFILE is not None:
-        _PROFILE.timed(fn, args, flops, kern, nbytes)
+        _PROFILE.timed(fn, (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, kern, nbytes)
         return
-    _call(fn, *args)
+    _call(fn, _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
 
 def attn_block_supported(N, D, H):
@@ -439,22 +397,6 @@ def attn_bwd(qkv, out, d_out, lse, dqkv, delta_ws, B, N, H, scale):
 
 def layernorm_fwd(x, gamma, beta, eps, out, mean, rstd, M, D):
     _call("srhip_layernorm_fwd", _p(x), _p(gamma), _p(beta), eps, _p(out), _p(mean), _p(rstd), M, D, _s())
-
-
-def ln_gemm_supported(D, N):
-    from ._lib import lib
-    return bool(lib().srhip_ln_gemm_supported(D, N))
-
-
-def ln_gemm(epi, x, gamma, beta, eps, W, bias, out, M, N, D, ln_out=None, mean=None, rstd=None, aux_out=None):
-    """ln_out = LayerNorm(x) (bf16, + mean / rstd); out = ln W^T + bias (EPI_BF16) or GELU of it with aux_out = the pre-activation (EPI_GELU_BF16):
-    srhip_layernorm_fwd + srhip_gemm_nt as one launch for the gradient rows' forward (srhip_ln_gemm)."""
-    args = (epi, _p(x), _p(gamma), _p(beta), eps, _p(W), _p(bias), _p(out), _p(aux_out), _p(ln_out), _p(mean), _p(rstd), M, N, D, _s())
-    if _PROFILE is not None:
-        nbytes = 4.0 * M * D + 2.0 * N * D + 2.0 * M * N * (2 if aux_out is not None else 1) + (2.0 * M * D if ln_out is not None else 0.0)
-        _PROFILE.timed("srhip_ln_gemm", args, 2.0 * M * N * D, "ln_gemm_kernel<%d>" % (1 if epi == EPI_GELU_BF16 else 0), nbytes)
-        return
-    _call("srhip_ln_gemm", *args)
 
 
 def layernorm_bwd_cast(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, out_bf16, row_scale, rows_per_sample, M, D):
