@@ -237,6 +237,11 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     assert mlp, "shipped instantiation not found"
     for k, v in mlp.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0 and v["Occupancy [waves/SIMD]"] >= 2, (k, v)
+    # the 256 x 256 weight-gradient kernel: 256 registers, nothing spilled inside its K loop (the 16 bytes of scratch are three epilogue addresses)
+    tn = {k: v for k, v in remarks("gemm_tn.hip").items() if "gemm_tn_pp_kernel" in k}
+    assert len(tn) == 1
+    for k, v in tn.items():
+        assert v["ScratchSize [bytes/lane]"] <= 16 and v["VGPRs Spill"] <= 3 and v["Occupancy [waves/SIMD]"] >= 2, (k, v)
     gemm = {k: v for k, v in remarks("gemm.hip").items() if "gemm_nt_kernel" in k}
     assert len(gemm) == 5
     for k, v in gemm.items():
@@ -397,3 +402,38 @@ def test_gemm_tile_dispatch_is_pinned_per_shape_family(monkeypatch):
     finally:
         ops.gemm_small_max_grid(ops.GEMM_SMALL_ALONE)
     assert {k: ops.gemm_nt_plan(k[1], k[2], k[3], k[4], beta=1.0 if k[1] == ops.EPI_F32 else 0.0) for k in want} == want
+
+
+def test_weight_gradient_table_of_the_persistent_kernel_is_balanced_on_the_host():
+    """ops.tn_pp_plan / tn_pp_efficiency (host logic of srhip_gemm_tn_grouped_pp_f32, no launch): the kernel's walk is static -- workgroup w of
+    256 takes tiles w, w + 256, ... -- so the table slices the LAST problems along the token axis when a few tiles past a full round would leave
+    most workgroups idle for one whole tile; slices are multiples of the 64-token K-tile; tables whose tiles 256 x 256 covers badly are left to the
+    128 x 128 kernel by the encoders (efficiency < 0.85)."""
+    from semireward_amd import ops
+    D, I, K = 768, 3072, 8192
+    layer = [(0, 0, 0, 0, D, I, K), (0, 0, 0, 0, I, D, K), (0, 0, 0, 0, D, D, K), (0, 0, 0, 0, 3 * D, D, K)]
+    bert = layer * 12                                          # 12 x 108 = 1296 tiles = 5 rounds + 16
+    assert ops.tn_pp_efficiency(bert) == 1.0
+    plan = ops.tn_pp_plan(bert)
+    sliced = [(pr[4:], sl) for pr, sl in plan if sl]
+    assert sliced == [((3 * D, D, K), 1024)], sliced           # the last problem (27 tiles >= the 16 of the tail) in 8 slices of 1024 tokens
+    assert [pr for pr, _ in plan] == [tuple(p) for p in bert]  # order kept
+    # worst workgroup: 5 whole tiles + one slice instead of 6 whole tiles
+    tiles = []
+    for (A, B, C, db, M, N, Kp), sl in plan:
+        n = ((M + 255) // 256) * ((N + 255) // 256)
+        tiles += [min(sl, Kp - k0) for k0 in range(0, Kp, sl) for _ in range(n)] if sl else [Kp] * n
+    load = [sum(tiles[w::256]) for w in range(256)]
+    assert max(load) == 5 * K + 1024 and sum(tiles) == 1296 * K
+    # one layer alone (108 tiles < 256 workgroups), a whole number of rounds, a long tail: table order, nothing sliced
+    assert all(sl == 0 for _, sl in ops.tn_pp_plan(layer))
+    assert all(sl == 0 for _, sl in ops.tn_pp_plan([(0, 0, 0, 0, 4096, 4096, K)]))              # 256 tiles
+    assert all(sl == 0 for _, sl in ops.tn_pp_plan([(0, 0, 0, 0, 4096, 4096, K), (0, 0, 0, 0, 4096, 3072, K)]))   # 256 + 192: tail > 0.7 round
+    # short token axes are not sliced below 512 tokens; slices are multiples of 64
+    for pr, sl in ops.tn_pp_plan([(0, 0, 0, 0, D, I, 3184)] * 8 + [(0, 0, 0, 0, D, D, 3184)]):
+        assert sl == 0 or (sl % 64 == 0 and sl >= 512)
+    assert all(sl == 0 for _, sl in ops.tn_pp_plan([(0, 0, 0, 0, D, I, 600)] * 8 + [(0, 0, 0, 0, D, D, 600)]))
+    # ViT-S: 384 = 256 + 128 in both directions -- 71 % of the tile area is inside the problems: stays on the 128 x 128 kernel
+    vit = [(0, 0, 0, 0, 384, 1536, 4112), (0, 0, 0, 0, 1536, 384, 4112), (0, 0, 0, 0, 384, 384, 4112), (0, 0, 0, 0, 1152, 384, 4112)]
+    assert 0.70 < ops.tn_pp_efficiency(vit) < 0.72
+
