@@ -82,12 +82,24 @@ int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, 
  * row, K = its rows): C += alpha * A^T B and dbias += column sums through fp32 atomic adds; beta is ignored for the entry (the sum over
  * the slices is then order-dependent in the last bits, like any split-K reduction). */
 #define SRHIP_TN_ATOMIC 1
+/* flags & SRHIP_TN_OVERWRITE: the entry is a token slice with a slab of its OWN (C, dbias point into scratch): C = alpha * A^T B and dbias =
+ * column sums are written, not accumulated (beta ignored); srhip_slab_reduce_f32 then adds the slabs of a product into its gradient.  An fp32
+ * atomic add is a memory transaction of its own on this chip: with 14 M of them per WideResNet backward the sliced weight gradients spent more time
+ * in their epilogues than in their products (profiles/r06_wrn_dw_slabs_ab.txt). */
+#define SRHIP_TN_OVERWRITE 2
 typedef struct srhip_group_tn_desc {
   const void* A; const void* B; float* C; float* dbias;
   int M, N, K, lda, ldb, ldc, tile_start, flags;
 } srhip_group_tn_desc;                   /* 64 bytes */
 int srhip_gemm_tn_grouped_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
                               void* stream);
+/* dst[i] += sum_{s < n_slabs} src[s * stride + i], i < count, for every entry (16-byte aligned dst / src, stride in elements); block_start = first
+ * workgroup of the entry, 1024 elements per workgroup; total_blocks = their sum. */
+typedef struct srhip_slab_desc {
+  float* dst; const float* src; long long stride;
+  int count, n_slabs, block_start, pad0;
+} srhip_slab_desc;                       /* 40 bytes */
+int srhip_slab_reduce_f32(const srhip_slab_desc* desc_dev, int n, int total_blocks, void* stream);
 /* The same products through 256 x 256 output tiles (persistent workgroups, 64-token K-tiles, two wave groups half a phase apart): the kernel for
  * the wide layers' weight gradients (D = 768: autograd of the HF encoder Linears behind semilearn/nets/bert/bert.py:34 and
  * wave2vecv2/wave2vecv2.py:44; 8192 tokens per step) and for ViT-S tables whose problems 256-tiles cover well.  Same descriptor, same

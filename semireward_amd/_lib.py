@@ -24,6 +24,7 @@ SIGNATURES = {
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_gemm_tn_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_gemm_tn_grouped_pp_f32": (I, [P, I, I, F, F, P]),
+    "srhip_slab_reduce_f32": (I, [P, I, I, P]),
     "srhip_attn_fwd": (I, [P, P, P, I, I, I, F, P]),
     "srhip_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, F, P]),
     "srhip_layernorm_fwd": (I, [P, P, P, F, P, P, P, I, I, P]),

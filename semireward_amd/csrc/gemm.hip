@@ -462,7 +462,12 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
   __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);      // tiles of one product (shared operands) stay on one XCD's L2
   int p = 0;
-  while (p + 1 < n_problems && tile >= desc[p + 1].tile_start) ++p;
+  {  // binary search: the last entry whose tile_start <= tile (a token-sliced table has hundreds of entries; a linear walk of dependent scalar
+     // loads cost a workgroup as much as its product)
+    int lo = 0, hi = n_problems - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile >= desc[mid].tile_start) lo = mid; else hi = mid - 1; }
+    p = lo;
+  }
   const srhip_group_desc d = desc[p];
   GemmArgs g;
   g.A = (const bf16_t*)d.A; g.B = (const bf16_t*)d.B; g.C = d.C; g.bias = nullptr; g.row_scale = nullptr;

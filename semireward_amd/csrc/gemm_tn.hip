@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip
   __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
-  while (p + 1 < n_problems && tile >= desc[p + 1].tile_start) ++p;
+  {  // binary search: the last entry whose tile_start <= tile (a token-sliced table has hundreds of entries; a linear walk of dependent scalar
+     // loads cost a workgroup as much as its product)
+    int lo = 0, hi = n_problems - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile >= desc[mid].tile_start) lo = mid; else hi = mid - 1; }
+    p = lo;
+  }
   const srhip_group_tn_desc d = desc[p];
   const int local = tile - d.tile_start, ntn = (d.N + BN - 1) / BN;
   const int m0 = (local / ntn) * BM, n0 = (local % ntn) * BN;
@@ -130,13 +135,14 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip
 #undef ISSUE
 
   const bool atomic = (d.flags & SRHIP_TN_ATOMIC) != 0;
+  const bool overwrite = (d.flags & SRHIP_TN_OVERWRITE) != 0;        // a token slice with a slab of its own: C = alpha * acc, dbias = sums
   // ---- epilogue: lane holds C[m][n .. n+3], m = tile row (lane & 15), n = 4 (lane >> 4) + r
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + l15;
     if (m >= d.M) continue;
     if (want_bias && lg == 0) {                                          // every row of the ones-product equals the column sum
-      if (atomic) unsafeAtomicAdd(d.dbias + m, accb[mt][0]); else d.dbias[m] += accb[mt][0];
+      if (atomic) unsafeAtomicAdd(d.dbias + m, accb[mt][0]); else if (overwrite) d.dbias[m] = accb[mt][0]; else d.dbias[m] += accb[mt][0];
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_f32_kernel(const srhip
         unsafeAtomicAdd(cf, x[0]); unsafeAtomicAdd(cf + 1, x[1]); unsafeAtomicAdd(cf + 2, x[2]); unsafeAtomicAdd(cf + 3, x[3]);
         continue;
       }
-      if (beta != 0.0f) {
+      if (beta != 0.0f && !overwrite) {
         const f32x4_t c = *cp;
         x[0] += beta * c[0]; x[1] += beta * c[1]; x[2] += beta * c[2]; x[3] += beta * c[3];
       }
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
     for (int kt = 0; kt < nk; ++kt) ktile(kt);
     // ---- epilogue: lane holds C[m][n .. n + 3], m = row l15 of a row tile, n = 4 lg of a column tile
     const int mb = tm_ * 256 + wr * 128, nb = tn_ * 256 + wc * 64;
-    const bool atomic = (d.flags & SRHIP_TN_ATOMIC) != 0;
+    const bool atomic = (d.flags & SRHIP_TN_ATOMIC) != 0, overwrite = (d.flags & SRHIP_TN_OVERWRITE) != 0;
     if (wr == 0) __builtin_amdgcn_s_barrier();
     WAIT_VM(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -393,12 +399,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
         const int m = mb + h * 64 + wc * 16 + l15;
         if (lg == 0 && m < d.M) {
           const float v = accb[h][0];
-          if (atomic) unsafeAtomicAdd(d.dbias + m, v); else d.dbias[m] += v;
+          if (atomic) unsafeAtomicAdd(d.dbias + m, v); else if (overwrite) d.dbias[m] = v; else d.dbias[m] += v;
         }
         accb[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
-    const bool rd_c = !atomic && beta != 0.0f;
+    const bool rd_c = !atomic && !overwrite && beta != 0.0f;
 #pragma unroll
     for (int hq = 0; hq < 4; ++hq) {       // two row tiles at a time: their 8 quads of C are requested together
       f32x4_t res[2][4];
@@ -438,7 +444,44 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(const srhip_group_tn
 #undef TPP_END
 }
 
+// dst[i] += sum over the slabs of src[s * stride + i]: the second phase of a token-sliced product whose slices wrote slabs of their own
+// (SRHIP_TN_OVERWRITE) instead of meeting in C through fp32 atomics.  One workgroup = 1024 elements of one entry.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const srhip_slab_desc* __restrict__ desc, int n) {
+  const int b = blockIdx.x;
+  int p = 0;
+  {  // binary search: the last entry whose block_start <= b (a token-sliced table has hundreds of entries; a linear walk of dependent scalar
+     // loads cost a workgroup as much as its product)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b >= desc[mid].block_start) lo = mid; else hi = mid - 1; }
+    p = lo;
+  }
+  const srhip_slab_desc d = desc[p];
+  const int i = ((b - d.block_start) * 256 + threadIdx.x) * 4;
+  if (i >= d.count) return;
+  if (i + 3 < d.count && (d.stride & 3) == 0) {
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(d.dst + i);
+    for (int s_ = 0; s_ < d.n_slabs; ++s_) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(d.src + (size_t)s_ * d.stride + i);
+      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    *reinterpret_cast<f32x4_t*>(d.dst + i) = a;
+  } else {
+    for (int j = i; j < min(i + 4, d.count); ++j) {
+      float a = d.dst[j];
+      for (int s_ = 0; s_ < d.n_slabs; ++s_) a += d.src[(size_t)s_ * d.stride + j];
+      d.dst[j] = a;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int srhip_slab_reduce_f32(const srhip_slab_desc* desc_dev, int n, int total_blocks, void* stream) {
+  if (!desc_dev || n <= 0 || total_blocks <= 0) return SR_EINVAL;
+  SR_LAUNCH(slab_reduce_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, n);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
 
 extern "C" int srhip_gemm_tn_grouped_pp_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha,
                                             float beta, void* stream) {

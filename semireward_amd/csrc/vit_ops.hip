@@ -491,7 +491,12 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const srhip_tran
   __shared__ float tile[64][65];
   const int t = blockIdx.x;
   int p = 0;
-  while (p + 1 < n && t >= desc[p + 1].tile_start) ++p;
+  {  // binary search: the last entry whose tile_start <= t (a token-sliced table has hundreds of entries; a linear walk of dependent scalar
+     // loads cost a workgroup as much as its product)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t >= desc[mid].tile_start) lo = mid; else hi = mid - 1; }
+    p = lo;
+  }
   const srhip_transpose_desc d = desc[p];
   const int local = t - d.tile_start, tm = (d.Mp + 63) / 64;
   const int m0 = (local % tm) * 64, c0 = (local / tm) * 64;

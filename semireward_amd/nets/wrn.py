@@ -18,6 +18,11 @@ from .. import ops
 from .surface import ModuleSurface
 
 MOMENTUM, SLOPE = 0.001, 0.1
+# Filter gradients (32 x 288 .. 128 x 1152 outputs over 8 192 .. 131 072 pixels) are sliced along the pixel axis to fill the chip; the slices write
+# scratch slabs of their own that one reduce launch adds into the gradients: the sums no longer depend on the order fp32 atomics arrive in, and
+# slices of 4 096 pixels measured best once the descriptor lookup was a binary search (profiles/r06_wrn_dw_slices_ab.txt).
+_DW_SPLIT = 4096
+_DW_SLABS = True
 _FUSED_DX = True      # input gradients of the stride-1 3x3 layers as implicit-GEMM convolutions with the rotated / transposed filter
 
 
@@ -581,14 +586,14 @@ class WideResNet(ModuleSurface):
                     dx = din                                   # raw-x path; this bn1 feeds nothing (no gradient, as in the reference)
             dy = dx
         conv_bwd("conv1.weight", dy, B * ctx.H * ctx.W, ctx.stem["col"], False, ctx.H, ctx.W, 1)
-        # 32 x 288 .. 128 x 1152 outputs over 4096 .. 65536 pixels: slices of 2048 pixels fill the chip (filter gradients meet through fp32 atomics)
+        # 32 x 288 .. 128 x 1152 outputs over 8192 .. 131072 pixels: slices of _DW_SPLIT pixels fill the chip (each writes a slab of its own; one reduce launch)
         # Descriptor tables hold raw addresses AND row counts: the key carries the operands' addresses, the batch size and every problem's shape
         # (a batch-size change under the same tag makes _buf reallocate; an address recycled by the caching allocator must not replay a table with
         # stale row counts), and ONE table per tag is kept -- the previous one is dropped when the key changes.
         sig = (B,) + tuple((int(pr[4]), int(pr[5]), int(pr[6])) for pr in problems) + tuple(int(t.data_ptr()) for pr in problems for t in pr[:3])
         ent_tn = self._buf_cache.get(("tn_desc", tag))
         if ent_tn is None or ent_tn[0] != sig:         # (one host-to-device copy per buffer set, not per backward: the operands are persistent)
-            ent_tn = (sig, ops.make_group_tn_desc(problems, self.device, split_k=2048))
+            ent_tn = (sig, ops.make_group_tn_desc(problems, self.device, split_k=_DW_SPLIT, slabs=_DW_SLABS))
             self._buf_cache[("tn_desc", tag)] = ent_tn
         desc, npb, ntiles, flops, nbytes = ent_tn[1]
         ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, flops=flops, nbytes=nbytes)

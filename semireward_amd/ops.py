@@ -280,11 +280,17 @@ GROUP_TN_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"
 TN_ATOMIC = 1
 
 
-def make_group_tn_desc(problems, device, split_k=0, tile=128):
+SLAB_DESC_DTYPE = [("dst", "<u8"), ("src", "<u8"), ("stride", "<i8"), ("count", "<i4"), ("n_slabs", "<i4"), ("block_start", "<i4"), ("pad0", "<i4")]
+TN_OVERWRITE = 2
+
+
+def make_group_tn_desc(problems, device, split_k=0, tile=128, slabs=False):
     """problems: list of (A, B, C, dbias, M, N, K) with A bf16 [K,M], B bf16 [K,N] (dense rows), C fp32 [M,N], dbias fp32 [M]
     or None.  Returns (device uint8 tensor holding srhip_group_tn_desc[], n_entries, total_tiles, flops, algorithmic bytes).
     split_k > 0: a problem with K >= 2 * split_k becomes ceil(K / split_k) entries over slices of its token axis, flagged
-    SRHIP_TN_ATOMIC (they add into C; the launch must then be a C += product, beta = 1).
+    SRHIP_TN_ATOMIC (they add into C; the launch must then be a C += product, beta = 1) -- or, with slabs=True, SRHIP_TN_OVERWRITE: every
+    slice writes a scratch slab of its own and one srhip_slab_reduce_f32 launch (issued by gemm_tn_grouped_f32 behind the product) adds the
+    slabs into C / dbias; the scratch and the reduce table ride on the returned tensor (.slab, .reduce).
     tile = 256: the table of srhip_gemm_tn_grouped_pp_f32 (256 x 256 tiles; gemm_tn_grouped_f32(..., pp=True)).  Its walk is static -- workgroup
     w of 256 takes tiles w, w + 256, ... -- so a short last round is balanced here: the last problems (enough of them to cover the tiles past
     the last full round) are handed over as token slices (SRHIP_TN_ATOMIC entries), which turns "a few workgroups run one tile more" into
@@ -293,14 +299,43 @@ def make_group_tn_desc(problems, device, split_k=0, tile=128):
     plan = [(tuple(pr), split_k if (split_k > 0 and pr[6] >= 2 * split_k) else 0) for pr in problems]
     if tile == 256 and split_k == 0:
         plan = tn_pp_plan(problems)
-    ent = []
-    t = 0
-    for (A, B, C, db, M, N, K), sk in plan:
+    slabs = slabs and any(sk > 0 for _, sk in plan)
+    # scratch layout of the sliced problems: [slices][M][N] (+ [slices][M] for the bias sums), 16-byte aligned pieces
+    lay, n_el = [], 0
+    if slabs:
+        for (A, B, C, db, M, N, K), sk in plan:
+            if sk > 0:
+                nsl = -(-K // sk)
+                oc = n_el
+                n_el += nsl * M * N
+                ob = n_el
+                n_el += nsl * M if db is not None else 0
+                n_el = -(-n_el // 4) * 4
+                lay.append((oc, ob, nsl))
+            else:
+                lay.append(None)
+        slab = torch.empty(max(n_el, 4), dtype=torch.float32, device=device)
+    ent, red = [], []
+    t = rb = 0
+    for i, ((A, B, C, db, M, N, K), sk) in enumerate(plan):
         tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
         if sk > 0:
-            for k0 in range(0, K, sk):
-                ent.append((_p(A) + 2 * k0 * M, _p(B) + 2 * k0 * N, _p(C), _p(db) or 0, M, N, min(sk, K - k0), M, N, N, t, TN_ATOMIC))
+            for si, k0 in enumerate(range(0, K, sk)):
+                if slabs:
+                    oc, ob, nsl = lay[i]
+                    cp = slab.data_ptr() + 4 * (oc + si * M * N)
+                    bp = slab.data_ptr() + 4 * (ob + si * M) if db is not None else 0
+                    ent.append((_p(A) + 2 * k0 * M, _p(B) + 2 * k0 * N, cp, bp, M, N, min(sk, K - k0), M, N, N, t, TN_OVERWRITE))
+                else:
+                    ent.append((_p(A) + 2 * k0 * M, _p(B) + 2 * k0 * N, _p(C), _p(db) or 0, M, N, min(sk, K - k0), M, N, N, t, TN_ATOMIC))
                 t += tiles
+            if slabs:
+                oc, ob, nsl = lay[i]
+                red.append((_p(C), slab.data_ptr() + 4 * oc, M * N, M * N, nsl, rb, 0))
+                rb += -(-M * N // 1024)
+                if db is not None:
+                    red.append((_p(db), slab.data_ptr() + 4 * ob, M, M, nsl, rb, 0))
+                    rb += -(-M // 1024)
         else:
             ent.append((_p(A), _p(B), _p(C), _p(db) or 0, M, N, K, M, N, N, t, 0))
             t += tiles
@@ -310,7 +345,15 @@ def make_group_tn_desc(problems, device, split_k=0, tile=128):
     assert arr.itemsize == 64
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
-    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(ent), t, flops, nbytes
+    desc = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+    if slabs:
+        ra = np.zeros(len(red), dtype=SLAB_DESC_DTYPE)
+        for i, e in enumerate(red):
+            ra[i] = e
+        assert ra.itemsize == 40
+        desc.slab = slab                                           # scratch + second-phase table live as long as the table
+        desc.reduce = (torch.from_numpy(ra.view(np.uint8).copy()).to(device), len(red), rb)
+    return desc, len(ent), t, flops, nbytes
 
 
 TN_PP_GRID = 256          # workgroups of srhip_gemm_tn_grouped_pp_f32 (one per CU)
@@ -352,10 +395,15 @@ def gemm_tn_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flop
     """C_p = alpha * A_p^T . B_p + beta * C_p (+ dbias_p += colsum A_p) for all problems in one launch.  pp: the table counts 256 x 256 tiles
     (make_group_tn_desc(tile=256)) and goes to the persistent two-group kernel."""
     fn, kern = ("srhip_gemm_tn_grouped_pp_f32", "gemm_tn_pp_kernel") if pp else ("srhip_gemm_tn_grouped_f32", "gemm_tn_grouped_f32_kernel")
+    red = getattr(desc, "reduce", None)
+    if red is not None:
+        assert beta == 1.0, "a table with slab slices is a C += product"
     if _PROFILE is not None:
         _PROFILE.timed(fn, (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, kern, nbytes)
-        return
-    _call(fn, _p(desc), n_problems, total_tiles, alpha, beta, _s())
+    else:
+        _call(fn, _p(desc), n_problems, total_tiles, alpha, beta, _s())
+    if red is not None:
+        _call("srhip_slab_reduce_f32", _p(red[0]), red[1], red[2], _s())
 
 
 def attn_block_supported(N, D, H):

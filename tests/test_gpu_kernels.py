@@ -167,6 +167,23 @@ def _tn_problems(shapes, with_bias=True, seed0=0):
     return problems, refs
 
 
+def test_gemm_tn_token_slices_through_slabs():
+    """Token slices that write scratch slabs of their own (SRHIP_TN_OVERWRITE) + srhip_slab_reduce_f32, on both weight-gradient kernels: C +=
+    product and dbias += column sums as with the atomic slices, unsliced problems of the same table untouched by the second phase, ragged
+    last slice, a bias vector whose length is not a multiple of 1024."""
+    shapes = [(1100, 32, 288), (64, 128, 128), (4112, 384, 384), (700, 136, 72), (2100, 1160, 384)]     # (K, M, N)
+    for tile in (128, 256):
+        problems, refs = _tn_problems(shapes, seed0=400 + tile)
+        desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV, split_k=256, tile=tile, slabs=True)
+        assert npb == 5 + 1 + 17 + 3 + 9 and desc.reduce[1] == 4 + 4 and desc.slab.numel() >= 5 * 32 * 288
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, pp=tile == 256)
+        torch.cuda.synchronize()
+        for (A, Bm, C, db, M, N, K), (C0, P, dbr) in zip(problems, refs):
+            assert relerr(C, C0 + P) < 2e-6, (tile, K, M, N, relerr(C, C0 + P))
+            if db is not None:
+                assert relerr(db, dbr) < 2e-6, (tile, K, M, N)
+
+
 def test_gemm_tn_grouped_pp():
     """The 256 x 256 persistent weight-gradient kernel (srhip_gemm_tn_grouped_pp_f32) against fp32 torch on the same bf16 operands: ragged K
     (not a multiple of the 64-token K-tile, shorter than one), partial tiles in both directions (384 = 256 + 128, 136, 72), bias sums, accumulate

@@ -136,6 +136,12 @@ def test_conv_building_blocks(B, H, C, Cout, ks, stride):
     assert npb == (rows + 31) // 32 if rows >= 64 else npb == 1
     ops.gemm_tn_grouped_f32(desc, npb, nt, alpha=1.0, beta=1.0)
     assert rel(dW2.cpu(), dW.cpu()) < 1e-5
+    # ... and as slices that write scratch slabs of their own + one reduce launch (SRHIP_TN_OVERWRITE, srhip_slab_reduce_f32): what the backward uses
+    dW3 = dW.clone()
+    desc, npb, nt, _, _ = ops.make_group_tn_desc([(dyd, col, dW3, None, Cout, Kp, rows)], DEV, split_k=32, slabs=True)
+    assert (hasattr(desc, "reduce") and desc.reduce[1] == 1) if rows >= 64 else not hasattr(desc, "reduce")
+    ops.gemm_tn_grouped_f32(desc, npb, nt, alpha=1.0, beta=1.0)
+    assert rel(dW3.cpu(), 2 * dW.cpu()) < 1e-5                      # C += product: twice the gradient
     g = torch.zeros(Cout * K, device=DEV)
     ops.add_unpad(dW2, g, Cout, C, ks, Kp)
     assert rel(g.cpu().reshape(Cout, C, ks, ks), Wr.grad.numpy()) < 1e-5
