@@ -132,7 +132,8 @@ class PostLNEncoderMixin(ModuleSurface):
         if pat not in T["tables"]:
             probs = [pr for i, lp in enumerate(T["probs"]) if not (pat and pat[i]) for pr in lp]
             pp = bool(probs) and ops.tn_pp_efficiency(probs) >= 0.85
-            T["tables"][pat] = (ops.make_group_tn_desc(probs, self.device, tile=256 if pp else 128), pp) if probs else None
+            # (the token slices that balance the persistent kernel's last round write scratch slabs, added in by one reduce launch: no atomics)
+            T["tables"][pat] = (ops.make_group_tn_desc(probs, self.device, tile=256 if pp else 128, slabs=True), pp) if probs else None
         return T["tables"][pat]
 
     def enc_backward(self, dx, ctx, B, L, key_len, dr, skip=None):

@@ -215,14 +215,16 @@ def test_gemm_tn_grouped_pp():
     problems, refs = _tn_problems(shapes, seed0=200)
     plan = ops.tn_pp_plan(problems)
     assert any(sl > 0 for _, sl in plan) and all(sl % 64 == 0 for _, sl in plan)
-    desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV, tile=256)
-    assert ntiles > 273 and npb > len(shapes)
-    ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, pp=True)
-    torch.cuda.synchronize()
-    for (A, Bm, C, db, M, N, K), (C0, P, dbr) in zip(problems, refs):
-        assert relerr(C, C0 + P) < 2e-6, (K, M, N, relerr(C, C0 + P))
-        if db is not None:
-            assert relerr(db, dbr) < 2e-6
+    for slabs in (False, True):                        # the planner's slices through atomics, and through slabs + the reduce launch (the encoders' form)
+        problems, refs = _tn_problems(shapes, seed0=200)
+        desc, npb, ntiles, _, _ = ops.make_group_tn_desc(problems, DEV, tile=256, slabs=slabs)
+        assert ntiles > 273 and npb > len(shapes) and hasattr(desc, "reduce") == slabs
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=1.0, pp=True)
+        torch.cuda.synchronize()
+        for (A, Bm, C, db, M, N, K), (C0, P, dbr) in zip(problems, refs):
+            assert relerr(C, C0 + P) < 2e-6, (K, M, N, relerr(C, C0 + P))
+            if db is not None:
+                assert relerr(db, dbr) < 2e-6
 
 
 def test_gemm_identity_asymmetric():
