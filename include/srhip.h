@@ -104,7 +104,7 @@ int srhip_slab_reduce_f32(const srhip_slab_desc* desc_dev, int n, int total_bloc
  * the wide layers' weight gradients (D = 768: autograd of the HF encoder Linears behind semilearn/nets/bert/bert.py:34 and
  * wave2vecv2/wave2vecv2.py:44; 8192 tokens per step) and for ViT-S tables whose problems 256-tiles cover well.  Same descriptor, same
  * arithmetic (bf16 operands, fp32 accumulation, dbias += column sums of A) -- but tile_start / total_tiles count 256 x 256 tiles:
- * ceil(M / 256) * ceil(N / 256) per entry.  The walk is static (workgroup w takes tiles w, w + 256, ...): the caller balances a short last
+ * ceil(M / 256) * ceil(N / 256) per entry; K >= 1 for every entry (the refill cursor runs one K-tile ahead of the multiplying waves).  The walk is static (workgroup w takes tiles w, w + 256, ...): the caller balances a short last
  * round by handing the last entries over as SRHIP_TN_ATOMIC token slices (ops.make_group_tn_desc(tile=256) does). */
 int srhip_gemm_tn_grouped_pp_f32(const srhip_group_tn_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
                                  void* stream);

@@ -296,6 +296,7 @@ def make_group_tn_desc(problems, device, split_k=0, tile=128, slabs=False):
     the last full round) are handed over as token slices (SRHIP_TN_ATOMIC entries), which turns "a few workgroups run one tile more" into
     "most workgroups run a slice more" (beta must be 1 for such a table; `tn_pp_plan` says what was chosen)."""
     import numpy as np
+    assert all(pr[6] > 0 and pr[4] % 8 == 0 and pr[5] % 8 == 0 for pr in problems), "K >= 1 tokens; M, N multiples of 8 (srhip.h)"
     plan = [(tuple(pr), split_k if (split_k > 0 and pr[6] >= 2 * split_k) else 0) for pr in problems]
     if tile == 256 and split_k == 0:
         plan = tn_pp_plan(problems)
