@@ -280,11 +280,40 @@ GROUP_TN_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"
 TN_ATOMIC = 1
 
 
+class TableStager:
+    """Uploads small descriptor tables WITHOUT stalling the host: `tensor.to(device)` from pageable memory blocks until the copy has run, i.e. until
+    everything queued in front of it on the stream has -- a whole training step for a table built inside one (the Wav2Vec2 encoder builds a
+    weight-gradient table whenever LayerDrop leaves out a set of layers it has not seen before: 12 of the first 15 steps, 15 ms of host time
+    each, the leg was host-bound).  A ring of pinned staging buffers and stream-ordered asynchronous copies instead; a slot is reused only after
+    its copy has completed (an event per slot: by then it has, the wait is a formality)."""
+
+    def __init__(self, nbytes, depth=8):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def upload(self, arr_u8, device):
+        n = int(arr_u8.size)
+        slot = self.i % len(self.bufs)
+        self.i += 1
+        if n > self.bufs[slot].numel():
+            return torch.from_numpy(arr_u8.copy()).to(device)                # (larger than the ring was sized for: the blocking path)
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        self.bufs[slot][:n].copy_(torch.from_numpy(arr_u8))
+        dev = torch.empty(n, dtype=torch.uint8, device=device)
+        dev.copy_(self.bufs[slot][:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        return dev
+
+
 SLAB_DESC_DTYPE = [("dst", "<u8"), ("src", "<u8"), ("stride", "<i8"), ("count", "<i4"), ("n_slabs", "<i4"), ("block_start", "<i4"), ("pad0", "<i4")]
 TN_OVERWRITE = 2
 
 
-def make_group_tn_desc(problems, device, split_k=0, tile=128, slabs=False):
+def make_group_tn_desc(problems, device, split_k=0, tile=128, slabs=False, stager=None):
     """problems: list of (A, B, C, dbias, M, N, K) with A bf16 [K,M], B bf16 [K,N] (dense rows), C fp32 [M,N], dbias fp32 [M]
     or None.  Returns (device uint8 tensor holding srhip_group_tn_desc[], n_entries, total_tiles, flops, algorithmic bytes).
     split_k > 0: a problem with K >= 2 * split_k becomes ceil(K / split_k) entries over slices of its token axis, flagged
@@ -294,7 +323,8 @@ def make_group_tn_desc(problems, device, split_k=0, tile=128, slabs=False):
     tile = 256: the table of srhip_gemm_tn_grouped_pp_f32 (256 x 256 tiles; gemm_tn_grouped_f32(..., pp=True)).  Its walk is static -- workgroup
     w of 256 takes tiles w, w + 256, ... -- so a short last round is balanced here: the last problems (enough of them to cover the tiles past
     the last full round) are handed over as token slices (SRHIP_TN_ATOMIC entries), which turns "a few workgroups run one tile more" into
-    "most workgroups run a slice more" (beta must be 1 for such a table; `tn_pp_plan` says what was chosen)."""
+    "most workgroups run a slice more" (beta must be 1 for such a table; `tn_pp_plan` says what was chosen).
+    stager: a TableStager -- the table goes up through its asynchronous path (tables built inside a training step)."""
     import numpy as np
     assert all(pr[6] > 0 and pr[4] % 8 == 0 and pr[5] % 8 == 0 for pr in problems), "K >= 1 tokens; M, N multiples of 8 (srhip.h)"
     plan = [(tuple(pr), split_k if (split_k > 0 and pr[6] >= 2 * split_k) else 0) for pr in problems]
@@ -346,14 +376,15 @@ def make_group_tn_desc(problems, device, split_k=0, tile=128, slabs=False):
     assert arr.itemsize == 64
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
-    desc = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+    up = (lambda a: stager.upload(a.view(np.uint8).reshape(-1), device)) if stager is not None else (lambda a: torch.from_numpy(a.view(np.uint8).copy()).to(device))
+    desc = up(arr)
     if slabs:
         ra = np.zeros(len(red), dtype=SLAB_DESC_DTYPE)
         for i, e in enumerate(red):
             ra[i] = e
         assert ra.itemsize == 40
         desc.slab = slab                                           # scratch + second-phase table live as long as the table
-        desc.reduce = (torch.from_numpy(ra.view(np.uint8).copy()).to(device), len(red), rb)
+        desc.reduce = (up(ra), len(red), rb)
     return desc, len(ent), t, flops, nbytes
 
 
