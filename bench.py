@@ -658,14 +658,19 @@ def worker(a):
                                                                       "flop_per_launch", "algorithmic_bytes_per_launch")}
                 if "allreduce_ms_per_step" in o:
                     keep["allreduce_ms_per_step"] = o["allreduce_ms_per_step"]
+                if "host_enqueue_ms_per_step" in o:       # a leg whose host cannot keep up shows here (round 6: a blocking table upload in the audio legs)
+                    keep["host_enqueue_ms_per_step"] = round(o["host_enqueue_ms_per_step"]["max"], 3)
+                    keep["host_bound"] = o["host_enqueue_ms_per_step"]["host_bound"]
                 if tag.startswith("classic_cv") and rank == 0 and world == 1 and not a.no_cpu_baseline:
                     keep["cpu_baseline"] = cpu_baseline_wrn(64, 64)       # the configuration BASELINE.json labels "CPU reference"
                 also.append(keep)
                 # the driver keeps the scalar keys of `config`: every leg's value / ms / roofline rides there as flat keys
                 rf = keep.get("roofline", {})
-                out["config"].update({"leg_%s_summary" % tag: "%.1f %s, %.3f ms/step, dominant kernel %s at %s of the %s roof" % (
+                out["config"].update({"leg_%s_summary" % tag: "%.1f %s, %.3f ms/step, dominant kernel %s at %s of the %s roof%s" % (
                                           keep["value"], keep["unit"], keep["ms_per_step"], rf.get("kernel"),
-                                          ("%.3f" % rf["frac"]) if rf.get("frac") is not None else "n/a", rf.get("bound")),
+                                          ("%.3f" % rf["frac"]) if rf.get("frac") is not None else "n/a", rf.get("bound"),
+                                          (", host enqueue %.2f ms/step%s" % (keep["host_enqueue_ms_per_step"], " (HOST-BOUND)" if keep.get("host_bound") else ""))
+                                          if "host_enqueue_ms_per_step" in keep else ""),
                                       "leg_%s_value" % tag: keep["value"], "leg_%s_ms_per_step" % tag: keep["ms_per_step"],
                                       "leg_%s_roofline_frac" % tag: rf.get("frac")})
                 _order_config(out)
