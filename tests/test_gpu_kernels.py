@@ -167,6 +167,24 @@ def _tn_problems(shapes, with_bias=True, seed0=0):
     return problems, refs
 
 
+def test_table_stager_uploads_survive_ring_reuse():
+    """ops.TableStager (descriptor tables built inside a step: pinned staging ring + stream-ordered asynchronous copies).  With the stream kept busy
+    the copies lag behind the host by milliseconds; a staging slot must not be rewritten before its copy has run: 40 tables through a ring of 4,
+    each checked after the fact; a table larger than the ring's slots takes the blocking path."""
+    st = ops.TableStager(4096, depth=4)
+    big = torch.randn(2048, 2048, device=DEV)
+    outs = []
+    for i in range(40):
+        for _ in range(3):
+            big = (big @ big) * 1e-2                       # ~100 us of queued work per product: the uploads queue up behind it
+        outs.append((st.upload(np.full(1000 + i, i % 251, dtype=np.uint8), DEV), i))
+    outs.append((st.upload(np.full(5000, 77, dtype=np.uint8), DEV), 77))
+    torch.cuda.synchronize()
+    for t, i in outs[:-1]:
+        assert t.numel() == 1000 + i and bool((t == i % 251).all()), i
+    assert outs[-1][0].numel() == 5000 and bool((outs[-1][0] == 77).all())
+
+
 def test_gemm_tn_token_slices_through_slabs():
     """Token slices that write scratch slabs of their own (SRHIP_TN_OVERWRITE) + srhip_slab_reduce_f32, on both weight-gradient kernels: C +=
     product and dbias += column sums as with the atomic slices, unsliced problems of the same table untouched by the second phase, ragged
