@@ -72,6 +72,11 @@ typedef struct srhip_group_desc {
 } srhip_group_desc;                      /* 64 bytes */
 int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
                               void* stream);
+/* The same launch over 128 x 64 tiles (tile_start / total_tiles count ceil(M / 128) * ceil(N / 64) per problem): products whose N is at most a few
+ * dozen columns -- the grouped positional convolution of Wav2Vec2 / HuBERT (16 groups x 48 output channels, K = 6144; the HF
+ * Wav2Vec2PositionalConvEmbedding behind wave2vecv2.py:44), forward and input gradient. */
+int srhip_gemm_nt_grouped_n64_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
+                                  void* stream);
 
 /* Grouped weight-gradient products from ROW-MAJOR operands (no transposes): for each problem
  *   C[M,N] = alpha * A^T . B + beta * C,  A bf16 [K, M] (lda), B bf16 [K, N] (ldb), C fp32 [M, N] (ldc);  dbias[M] += colsum(A)

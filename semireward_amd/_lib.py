@@ -22,6 +22,7 @@ SIGNATURES = {
     "srhip_gemm_nt_plan": (I, [I, I, I, I, F]),
     "srhip_gemm_small_max_grid": (I, [I]),
     "srhip_gemm_nt_grouped_f32": (I, [P, I, I, F, F, P]),
+    "srhip_gemm_nt_grouped_n64_f32": (I, [P, I, I, F, F, P]),
     "srhip_gemm_tn_grouped_f32": (I, [P, I, I, F, F, P]),
     "srhip_gemm_tn_grouped_pp_f32": (I, [P, I, I, F, F, P]),
     "srhip_slab_reduce_f32": (I, [P, I, I, P]),

@@ -478,6 +478,145 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
   gemm_tile_body<SRHIP_EPI_F32>(g, smem, (local / ntn) * BM, (local % ntn) * BN, 0, d.K / BK, false);
 }
 
+// The same grouped launch for products with N <= 64 per column tile (the grouped positional convolution of Wav2Vec2 / HuBERT: 16 groups of 48
+// output channels over K = 128 taps x 48 channels = 6144; HF Wav2Vec2PositionalConvEmbedding behind wave2vecv2.py:44).  On the 128 x 128 tile
+// 62 % of the B tile that is filled and of the MFMAs that are issued belong to columns that do not exist (118 GFLOP per launch ran at the MFMA
+// rate of 1000 TF/s for 375 TF/s of product).  Here the tile is 128 x 64: four waves along m with 32 rows x 64 columns each (8 MFMAs per
+// k-step instead of 16), a 12-KiB stage (A 128 x 32, B 64 x 32), three LDS-DMA instructions per wave and stage, four workgroups per CU.
+constexpr int NB64 = 64, TILE_B64 = NB64 * BK, STAGE64 = TILE + TILE_B64;
+// ... and when the A operand is a SLIDING WINDOW (lda < K: row m of the operand starts lda elements behind row m - 1 -- the unfolded input of a
+// convolution read in place), the 128 rows x K elements of a tile are (127 lda + K) distinct elements: 24 KiB for the positional convolution
+// against 1.5 MiB streamed k-step by k-step.  The window is staged ONCE per tile and the A fragments are read from it at their sliding offsets
+// (16-byte aligned: lda % 8 == 0); only the weights stream (4 KiB per k-step through a 4-stage ring).
+constexpr int WIN_EL = 12 * 1024;         // window capacity in elements (24 KiB: 127 x 48 + 6144 = 12 240 for the positional convolution)
+constexpr int NSW = 4, PDW = NSW - 1;     // ring of B tiles in the window mode: 24 + 16 KiB per workgroup, four workgroups per CU
+__global__ __launch_bounds__(256, 4) void gemm_grouped_n64_f32_kernel(const srhip_group_desc* __restrict__ desc, int n_problems, float alpha, float beta) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE64 > WIN_EL + NSW * TILE_B64 ? NS * STAGE64 : WIN_EL + NSW * TILE_B64];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+  {
+    int lo = 0, hi = n_problems - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile >= desc[mid].tile_start) lo = mid; else hi = mid - 1; }
+    p = lo;
+  }
+  const srhip_group_desc d = desc[p];
+  const bf16_t* A = (const bf16_t*)d.A;
+  const bf16_t* B = (const bf16_t*)d.B;
+  const int local = tile - d.tile_start, ntn = (d.N + NB64 - 1) / NB64;
+  const int m0 = (local / ntn) * BM, n0 = (local % ntn) * NB64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int nk = d.K / BK;
+  if (nk <= 0) return;
+  f32x4_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  size_t gob;
+  {
+    const int r = 16 * wave + (lane >> 2);
+    gob = (size_t)min(n0 + r, d.N - 1) * d.ldb + (((lane & 3) ^ swz(r)) << 3);
+  }
+  int fo_a[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const int rn = t * 16 + l15; fo_a[t] = rn * BK + ((lg ^ swz(rn)) << 3); }      // MFMA a-operand <- B matrix rows (n), inside a B tile
+  const int span = (BM - 1) * d.lda + d.K;                       // distinct elements of the tile's 128 operand rows
+  const bool window = d.lda < d.K && span <= WIN_EL && (d.lda & 7) == 0;        // (uniform)
+  if (window) {
+    // ---- the window: elements [m0 lda, m0 lda + span) of A, clipped to the operand's extent (rows >= M of a last tile are never stored)
+    bf16_t* win = smem;
+    bf16_t* ring = smem + WIN_EL;
+    const long extent = (long)(d.M - 1) * d.lda + d.K;
+    const long w0 = (long)m0 * d.lda;
+    for (int c = tid * 8; c < span; c += 256 * 8) {              // 16 bytes per lane, lane-linear in LDS
+      if (w0 + c + 8 <= extent) __builtin_amdgcn_global_load_lds((gbl_void*)(A + w0 + c), (lds_void*)(win + (c & ~511) + 0), 16, 0, 0);
+    }
+    // (global_load_lds writes lane-linear from the wave's base address: the base above is the wave's chunk start -- c & ~511 is uniform per wave
+    // because a wave covers 64 x 8 = 512 consecutive elements)
+#define ISSUEW(kt_, st_) __builtin_amdgcn_global_load_lds((gbl_void*)(B + gob + (size_t)(kt_) * BK), (lds_void*)(ring + (st_) * TILE_B64 + 16 * wave * BK), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PDW; ++q)
+      if (q < nk) { ISSUEW(q, q) }
+    const int fw0 = (wave * 32 + l15) * d.lda + 8 * lg, fw1 = fw0 + 16 * d.lda;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int rem = nk - 1 - kt;                               // one LDS-DMA instruction per wave and stage: up to PDW - 1 younger stages in flight
+      if (rem >= 2) WAIT_VM(2); else if (rem == 1) WAIT_VM(1); else WAIT_VM(0);
+      __builtin_amdgcn_s_barrier();
+      if (kt + PDW < nk) { ISSUEW(kt + PDW, (kt + PDW) % NSW) }
+      const bf16_t* st = ring + (kt % NSW) * TILE_B64;
+      s16x8_t fa[4], fb[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const s16x8_t*>(st + fo_a[t]);
+      fb[0] = *reinterpret_cast<const s16x8_t*>(win + fw0 + kt * BK);
+      fb[1] = *reinterpret_cast<const s16x8_t*>(win + fw1 + kt * BK);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[nt]), __builtin_bit_cast(bf16x8_t, fb[mt]), acc[nt][mt], 0, 0, 0);
+    }
+#undef ISSUEW
+    static_assert(PDW == 3, "the counted waits above are written for three stages in flight");
+  } else {
+    size_t goa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 32 * wave + 16 * i + (lane >> 2);
+      goa[i] = (size_t)min(m0 + r, d.M - 1) * d.lda + (((lane & 3) ^ swz(r)) << 3);
+    }
+#define ISSUE64(kt_, st_)                                                                                                          \
+  {                                                                                                                                 \
+    bf16_t* da = smem + (st_) * STAGE64 + 32 * wave * BK;                                                                           \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(A + goa[0] + (size_t)(kt_) * BK), (lds_void*)da, 16, 0, 0);                       \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(A + goa[1] + (size_t)(kt_) * BK), (lds_void*)(da + 16 * BK), 16, 0, 0);           \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(B + gob + (size_t)(kt_) * BK), (lds_void*)(smem + (st_) * STAGE64 + TILE + 16 * wave * BK), 16, 0, 0); \
+  }
+    int fo_b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { const int rm = wave * 32 + t * 16 + l15; fo_b[t] = rm * BK + ((lg ^ swz(rm)) << 3); }  // MFMA b-operand <- A matrix rows (m)
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+      if (q < nk) ISSUE64(q, q)
+    for (int kt = 0; kt < nk; ++kt) {
+      if (nk - 1 - kt >= 1) WAIT_VM(3); else WAIT_VM(0);       // three LDS-DMA instructions per wave and stage; PD - 1 = 1 younger stage may be in flight
+      __builtin_amdgcn_s_barrier();
+      if (kt + PD < nk) ISSUE64(kt + PD, (kt + PD) % NS)
+      const bf16_t* st = smem + (kt % NS) * STAGE64;
+      s16x8_t fa[4], fb[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const s16x8_t*>(st + TILE + fo_a[t]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fb[t] = *reinterpret_cast<const s16x8_t*>(st + fo_b[t]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[nt]), __builtin_bit_cast(bf16x8_t, fb[mt]), acc[nt][mt], 0, 0, 0);
+    }
+#undef ISSUE64
+    static_assert(PD == 2 && NS == 3, "the counted wait above is written for two stages in flight");
+  }
+  // ---- epilogue: lane holds C[m][n .. n + 3], m = row l15 of row tile mt, n = 4 lg of column tile nt
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + wave * 32 + mt * 16 + l15;
+    if (m >= d.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + nt * 16 + lg * 4;
+      if (n >= d.N) continue;
+      f32x4_t* cp = reinterpret_cast<f32x4_t*>(d.C + (size_t)m * d.ldc + n);
+      f32x4_t x = {alpha * acc[nt][mt][0], alpha * acc[nt][mt][1], alpha * acc[nt][mt][2], alpha * acc[nt][mt][3]};
+      if (beta != 0.0f) {
+        const f32x4_t c = *cp;
+        x[0] += beta * c[0]; x[1] += beta * c[1]; x[2] += beta * c[2]; x[3] += beta * c[3];
+      }
+      *cp = x;
+    }
+  }
+}
+
 // =================================================================================================
 // Large-problem kernel: 256 x (128|256) CU-level tile, 8 waves, persistent over tiles.
 //
@@ -1134,6 +1273,14 @@ extern "C" int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B
   if ((ldc != N || (N & 1)) && drop_thresh) return SR_EINVAL;        // the dropout index is the row-major index of the [M, N] output; one hash per aligned pair
   return gemm_nt_impl(SRHIP_EPI_RESID_F32, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, resid, nullptr, ldresid, 1.0f, 0.0f, drop_key,
                       drop_thresh, drop_scale, stream);
+}
+
+extern "C" int srhip_gemm_nt_grouped_n64_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,
+                                             void* stream) {
+  if (!desc_dev || n_problems <= 0 || n_problems > 4096 || total_tiles <= 0) return SR_EINVAL;
+  SR_LAUNCH(gemm_grouped_n64_f32_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_problems, alpha, beta);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
 }
 
 extern "C" int srhip_gemm_nt_grouped_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,

@@ -323,7 +323,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         Kc = k * cg
         c.pos_desc = ops.make_group_desc_ld(
             [(ops._pa(c.Xg, g * c.rows_total * cg), cg, ops._pa(self.pos_Wf, g * cg * Kc), Kc, ops._pa(c.conv, g * cg), D, B * Pp, cg, Kc)
-             for g in range(G)], dev)
+             for g in range(G)], dev, bn=64 if cg <= 64 else 128)
         self._ws[key] = c
         return c
 
@@ -369,7 +369,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         # ---- positional conv, encoder input
         ops.w2v_pos_stage(f.hidden, f.Xg, B, Tn, Pn, Pp, D, cfg.pos_groups, cfg.pos_k // 2, f.rows_total)
         desc, npb, ntiles, flops, nbytes = f.pos_desc
-        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes)
+        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes, n64=D // cfg.pos_groups <= 64)
         ctx = None
         x = self._buf(t + "x", (M, D), torch.float32)
         if save:
@@ -427,7 +427,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
               ops._pa(gb, g * cg), cg, Kc, B * Pp) for g in range(G)], dev)
         t.pos_dx = ops.make_group_desc_ld(
             [(ops._pa(t.dYg, g * f.rows_total * cg), cg, ops._pa(self.pos_Wb, g * cg * Kc), Kc, ops._pa(t.dxpos, g * cg), D, B * Pp, cg, Kc)
-             for g in range(G)], dev)
+             for g in range(G)], dev, bn=64 if cg <= 64 else 128)
         t.gproj = torch.empty(M, D, dtype=bf16, device=dev)
         t.dln = torch.empty(M, C, dtype=bf16, device=dev)
         t.proj_dw = ops.make_group_tn_desc([(t.gproj, f.lnb, self.view(M_ + "feature_projection.projection.weight", self.grad),
@@ -475,7 +475,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         ops.w2v_weightnorm_bwd(t.dWf, Pm(PC + "parametrizations.weight.original1"), Pm(PC + "parametrizations.weight.original0"), self.pos_norms,
                                G(PC + "parametrizations.weight.original1"), G(PC + "parametrizations.weight.original0"), D, cfg.pos_groups, cfg.pos_k)
         desc, npb, ntiles, flops, nbytes = t.pos_dx
-        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes)
+        ops.gemm_nt_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes, n64=D // cfg.pos_groups <= 64)
         # ---- SpecAugment, projection (dropout' folded into the bf16 cast of the branch gradient)
         ops.w2v_spec_mask_bwd(dx, t.dxpos, f.mask if ctx.spec else None, G(M_ + "masked_spec_embed") if ctx.spec else None, B, Tn, Pn, Pp, D)
         ops.dropout_cast(dx, t.gproj, M * D, dr(SITE_FEATPROJ, cfg.p_featproj))

@@ -266,11 +266,13 @@ def make_group_desc(problems, device):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
 
 
-def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0):
+def gemm_nt_grouped_f32(desc, n_problems, total_tiles, alpha=1.0, beta=1.0, flops=0.0, nbytes=0.0, n64=False):
+    """n64: the table counts 128 x 64 tiles (make_group_desc_ld(bn=64)) and goes to the narrow-column kernel."""
+    fn, kern = ("srhip_gemm_nt_grouped_n64_f32", "gemm_grouped_n64_f32_kernel") if n64 else ("srhip_gemm_nt_grouped_f32", "gemm_grouped_f32_kernel")
     if _PROFILE is not None:
-        _PROFILE.timed("srhip_gemm_nt_grouped_f32", (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, "gemm_grouped_f32_kernel", nbytes)
+        _PROFILE.timed(fn, (_p(desc), n_problems, total_tiles, alpha, beta, _s(),), flops, kern, nbytes)
         return
-    _call("srhip_gemm_nt_grouped_f32", _p(desc), n_problems, total_tiles, alpha, beta, _s())
+    _call(fn, _p(desc), n_problems, total_tiles, alpha, beta, _s())
 
 
 GROUP_TN_DESC_DTYPE = [("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
@@ -1134,14 +1136,15 @@ def w2v_pos_finish_bwd(dx0, ysave, conv, cbias, mean, rstd, gamma, dconv, dgamma
           B, T, P, Pp, D, *_d(drop), _s())
 
 
-def make_group_desc_ld(problems, device):
-    """srhip_group_desc table with explicit leading dimensions / raw pointers: problems = list of (A_ptr, lda, B_ptr, ldb, C_ptr, ldc, M, N, K)."""
+def make_group_desc_ld(problems, device, bn=128):
+    """srhip_group_desc table with explicit leading dimensions / raw pointers: problems = list of (A_ptr, lda, B_ptr, ldb, C_ptr, ldc, M, N, K).
+    bn = 64: the table of srhip_gemm_nt_grouped_n64_f32 (128 x 64 tiles; gemm_nt_grouped_f32(..., n64=True))."""
     import numpy as np
     arr = np.zeros(len(problems), dtype=GROUP_DESC_DTYPE)
     t = 0
     for i, (A, lda, B, ldb, C, ldc, M, N, K) in enumerate(problems):
         arr[i] = (A, B, C, M, N, K, lda, ldb, ldc, t, 0, 0, 0)
-        t += ((M + 127) // 128) * ((N + 127) // 128)
+        t += ((M + 127) // 128) * ((N + bn - 1) // bn)
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes

@@ -167,6 +167,37 @@ def _tn_problems(shapes, with_bias=True, seed0=0):
     return problems, refs
 
 
+def test_gemm_nt_grouped_narrow_columns():
+    """srhip_gemm_nt_grouped_n64_f32 (128 x 64 tiles: the grouped positional convolution, 48 output channels per group) against fp32 torch and against
+    the 128 x 128 grouped kernel on the same table: overlapping-row A operands (lda < K: a sliding window over a staging copy, as the convolution
+    reads it), N = 48 / 64 / 40 / 72 (two column tiles), ragged M, overwrite and accumulate."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    for alpha, beta in ((1.0, 0.0), (0.5, 1.0)):
+        probs, probs128, refs, outs, outs128 = [], [], [], [], []
+        for (M, N, K, lda) in ((300, 48, 6144, 48), (129, 64, 256, 256), (1000, 40, 384, 16), (64, 72, 128, 128), (5, 48, 96, 96)):
+            rows = (M - 1) * lda + K
+            Abuf = bf(torch.from_numpy(rng.standard_normal(rows).astype(np.float32)).to(DEV))
+            Bm = bf(torch.from_numpy((rng.standard_normal((N, K)) * 0.1).astype(np.float32)).to(DEV))
+            Bm[3] += 0.25
+            C0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+            A = torch.as_strided(Abuf, (M, K), (lda, 1))
+            refs.append(beta * C0 + alpha * (A.float() @ Bm.float().t()))
+            C, C2 = C0.clone(), C0.clone()
+            outs.append(C); outs128.append(C2)
+            probs.append((Abuf.data_ptr(), lda, Bm.data_ptr(), K, C.data_ptr(), N, M, N, K))
+            probs128.append((Abuf.data_ptr(), lda, Bm.data_ptr(), K, C2.data_ptr(), N, M, N, K))
+            probs[-1] = probs[-1] + (Abuf, Bm)            # keep the operands alive
+        d64 = ops.make_group_desc_ld([pr[:9] for pr in probs], DEV, bn=64)
+        d128 = ops.make_group_desc_ld(probs128, DEV)
+        assert d64[2] == 3 + 2 + 8 + 2 + 1 and d128[2] == 3 + 2 + 8 + 1 + 1
+        ops.gemm_nt_grouped_f32(d64[0], d64[1], d64[2], alpha=alpha, beta=beta, n64=True)
+        ops.gemm_nt_grouped_f32(d128[0], d128[1], d128[2], alpha=alpha, beta=beta)
+        torch.cuda.synchronize()
+        for C, C2, R in zip(outs, outs128, refs):
+            assert relerr(C, R) < 2e-6, relerr(C, R)
+            assert torch.equal(C, C2)                        # same k order, same fp32 accumulation: the two tilings agree bit for bit
+
+
 def test_table_stager_uploads_survive_ring_reuse():
     """ops.TableStager (descriptor tables built inside a step: pinned staging ring + stream-ordered asynchronous copies).  With the stream kept busy
     the copies lag behind the host by milliseconds; a staging slot must not be rewritten before its copy has run: 40 tables through a ring of 4,
