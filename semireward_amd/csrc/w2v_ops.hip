@@ -278,18 +278,24 @@ __global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ 
 
 // group-major zero-padded staging copy for the grouped positional conv: out[g][clip * Pp + u][cg] = src[clip, u - pad_left, g*cg + c]
 // (0 outside [0, T)); src fp32 with frame pitch P (forward: hidden states) or Psrc rows of a gradient buffer.
+// (eight channels per thread: 32 bytes read, 16 written; cg % 8 == 0)
 __global__ __launch_bounds__(256) void pos_stage_kernel(const float* __restrict__ src, bf16_t* __restrict__ out, int B, int T, int P, int Pp, int D,
-                                                       int cg, int pad_left, long rows_total, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int c = (int)(i % cg);
-  const long r = (i / cg) % rows_total;
-  const int g = (int)(i / ((long)cg * rows_total));
+                                                       int cg, int pad_left, long rows_total, long n8) {
+  const long i8 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i8 >= n8) return;
+  const int cg8 = cg >> 3;
+  const int c = (int)(i8 % cg8) * 8;
+  const long r = (i8 / cg8) % rows_total;
+  const int g = (int)(i8 / ((long)cg8 * rows_total));
   const long clip = r / Pp;
   const int t = (int)(r % Pp) - pad_left;
-  float v = 0.f;
-  if (clip < B && t >= 0 && t < T) v = src[((size_t)clip * P + t) * D + g * cg + c];      // (rows past the last clip are slack: zeros)
-  out[i] = f2bf(v);
+  u32x4_t o = {0u, 0u, 0u, 0u};
+  if (clip < B && t >= 0 && t < T) {                         // (rows past the last clip are slack: zeros)
+    const float* sp = src + ((size_t)clip * P + t) * D + g * cg + c;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), b = *reinterpret_cast<const f32x4_t*>(sp + 4);
+    o = u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+  }
+  *reinterpret_cast<u32x4_t*>(out + i8 * 8) = o;
 }
 
 // weight_norm(dim=2) of the positional conv filter: w[co][ci][j] = g[j] * v[co][ci][j] / ||v[:, :, j]||.
@@ -639,8 +645,8 @@ extern "C" int srhip_w2v_spec_mask_bwd(float* dx, const float* add, const unsign
 }
 extern "C" int srhip_w2v_pos_stage(const float* src, void* out, int B, int T, int P, int Pp, int D, int groups, int pad_left, long rows_total,
                                    void* stream) {
-  if (!src || !out || B <= 0 || D % groups || rows_total < (long)B * Pp) return SR_EINVAL;
-  const long n = rows_total * D;
+  if (!src || !out || B <= 0 || D % groups || ((D / groups) & 7) || rows_total < (long)B * Pp || (((uintptr_t)src | (uintptr_t)out) & 15)) return SR_EINVAL;
+  const long n = rows_total * (D / 8);
   W2V_LAUNCH1D(pos_stage_kernel, n, src, (bf16_t*)out, B, T, P, Pp, D, D / groups, pad_left, rows_total, n);
   SR_CHECK_LAUNCH();
   return SR_OK;
