@@ -437,7 +437,20 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         t.dcol = [None] + [torch.empty(B * P[l], cfg.conv_kernel[l] * C, dtype=bf16, device=dev) for l in range(1, nl)]
         # weight gradients of the conv layers 1..: ONE grouped launch, the reduction over the frames split into chunks of CH rows (a
         # 512 x 1536 product is 48 tiles; at 100 000 frames it would run on 48 CUs for a millisecond) -> partial products, summed by wgrad_add
-        CH = 12800
+        # C a multiple of 256: the launch goes to the 256 x 256 persistent kernel (srhip_gemm_tn_grouped_pp_f32), whose walk is static -- workgroup w
+        # takes tiles w, w + 256, ...: the chunk is the shortest (>= 1024 frames, a multiple of 64) that gives at most `rounds` x 256 tiles, so
+        # that every workgroup multiplies about the same number of K-tiles (8 clips: 5120 frames per chunk, 256 tiles, one round; the 128 x 128
+        # kernel took 785 us for this launch with chunks of 12800: 1168 tiles = 1.5 rounds of its 768 slots at 0.9 us per k-step)
+        t.conv_dw_pp = C % 256 == 0
+        if t.conv_dw_pp:
+            tiles_l = [0] + [(C // 256) * (-(-(cfg.conv_kernel[l] * C) // 256)) for l in range(1, nl)]
+            total = sum(tiles_l[l] * (B * P[l]) for l in range(1, nl))                      # tile-frames
+            rounds = max(1, -(-total // (256 * 8192)))                                     # at most ~8192 frames per tile and round
+            CH = 1024
+            while sum(tiles_l[l] * -(-(B * P[l]) // CH) for l in range(1, nl)) > 256 * rounds:
+                CH += 64
+        else:
+            CH = 12800
         t.dW_parts = [0] + [-(-(B * P[l]) // CH) for l in range(1, nl)]
         t.dWr = [None] + [torch.empty(t.dW_parts[l], C, cfg.conv_kernel[l] * C, dtype=f32, device=dev) for l in range(1, nl)]
         probs = []
@@ -447,7 +460,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
                 r0 = c_ * CH
                 probs.append((ops._pa(t.dpre[l], r0 * C), C, ops._pa(f.act[l - 1], r0 * ss * C), ss * C, ops._pa(t.dWr[l], c_ * C * kk * C), kk * C, 0,
                               C, kk * C, min(CH, R - r0)))
-        t.conv_dw = ops.make_group_tn_desc_ld(probs, dev)
+        t.conv_dw = ops.make_group_tn_desc_ld(probs, dev, tile=256 if t.conv_dw_pp else 128)
         t.ws2 = torch.zeros(B, C, 2, dtype=torch.float64, device=dev)
         self._ws[key] = t
         return t
@@ -490,7 +503,7 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
             ops.gemm_nt(ops.EPI_BF16, t.dpre[l], self.conv_w[l][1], t.dcol[l], B * P[l], kk * C, C)
             ops.w2v_col2im_dgelu(t.dcol[l], f.pre[l - 1] if l > 1 else None, t.dpre[l - 1] if l > 1 else t.dY0, B, P[l], P[l - 1], C, kk, ss)
         desc, npb, ntiles, flops, nbytes = t.conv_dw
-        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes)
+        ops.gemm_tn_grouped_f32(desc, npb, ntiles, alpha=1.0, beta=0.0, flops=flops, nbytes=nbytes, pp=t.conv_dw_pp)
         for l in range(1, nl):
             ops.w2v_conv_wgrad_add(t.dWr[l], G(FE + "%d.conv.weight" % l), C, C, cfg.conv_kernel[l], t.dW_parts[l])
         # ---- conv layer 0 + GroupNorm

@@ -1150,14 +1150,16 @@ def make_group_desc_ld(problems, device, bn=128):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
 
 
-def make_group_tn_desc_ld(problems, device):
-    """srhip_group_tn_desc table with explicit pointers / leading dimensions: (A_ptr, lda, B_ptr, ldb, C_ptr, ldc, dbias_ptr, M, N, K)."""
+def make_group_tn_desc_ld(problems, device, tile=128):
+    """srhip_group_tn_desc table with explicit pointers / leading dimensions: (A_ptr, lda, B_ptr, ldb, C_ptr, ldc, dbias_ptr, M, N, K).
+    tile = 256: the table of the persistent kernel (gemm_tn_grouped_f32(..., pp=True)); the caller sizes the problems so that its static walk is
+    balanced (the audio front end cuts its frame axis into chunks that give one round of tiles)."""
     import numpy as np
     arr = np.zeros(len(problems), dtype=GROUP_TN_DESC_DTYPE)
     t = 0
     for i, (A, lda, B, ldb, C, ldc, db, M, N, K) in enumerate(problems):
         arr[i] = (A, B, C, db or 0, M, N, K, lda, ldb, ldc, t, 0)
-        t += ((M + 127) // 128) * ((N + 127) // 128)
+        t += ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     flops = float(sum(2.0 * M * N * K for *_, M, N, K in problems))
     nbytes = float(sum(2.0 * (M * K + N * K) + 8.0 * M * N for *_, M, N, K in problems))
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(problems), t, flops, nbytes
