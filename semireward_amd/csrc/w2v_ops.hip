@@ -369,13 +369,22 @@ __global__ __launch_bounds__(256) void wn_bwd_dot_kernel(const float* __restrict
     partial[(size_t)co * k + tid] = a;
   }
 }
-__global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ norms, float* __restrict__ dot,
-                                                           float* __restrict__ dg, int D, int k) {
-  __shared__ float red[256];
-  const int tid = threadIdx.x, j = tid % k, q0 = tid / k, nq = 256 / k;
-  float s = 0.f;
-  for (int co = q0; co < D; co += nq) s += partial[(size_t)co * k + j];
-  red[tid] = s;
+__global__ __launch_bounds__(1024) void wn_bwd_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ norms, float* __restrict__ dot,
+                                                            float* __restrict__ dg, int D, int k) {
+  // one workgroup of 1024 threads = (1024 / k) channel groups x k taps, four independent partial sums per thread (one chain of D / nq dependent
+  // loads per thread made this pass 86 us); the order of the sum is fixed
+  __shared__ float red[1024];
+  const int tid = threadIdx.x, j = tid % k, q0 = tid / k, nq = 1024 / k;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int co = q0;
+  for (; co + 3 * nq < D; co += 4 * nq) {
+    s0 += partial[(size_t)co * k + j];
+    s1 += partial[(size_t)(co + nq) * k + j];
+    s2 += partial[(size_t)(co + 2 * nq) * k + j];
+    s3 += partial[(size_t)(co + 3 * nq) * k + j];
+  }
+  for (; co < D; co += nq) s0 += partial[(size_t)co * k + j];
+  red[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (tid < k) {
     float a = 0.f;
@@ -736,7 +745,7 @@ extern "C" int srhip_w2v_weightnorm_bwd(const float* dWf, const float* v, const 
       (void)hipFuncSetAttribute((const void*)wn_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     SR_LAUNCH(wn_bwd_dot_kernel, dim3(D), dim3(256), lds, st, dWf, v, partial, cg, k);
-    SR_LAUNCH(wn_bwd_reduce_kernel, dim3(1), dim3(256), 0, st, partial, norms, dot, dg, D, k);
+    SR_LAUNCH(wn_bwd_reduce_kernel, dim3(1), dim3(1024), 0, st, partial, norms, dot, dg, D, k);
     SR_LAUNCH(wn_bwd_apply_kernel, dim3(D), dim3(256), lds, st, dWf, v, g, norms, dot, dv, cg, k);
     SR_CHECK_LAUNCH();
     return SR_OK;
