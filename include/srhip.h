@@ -61,6 +61,13 @@ int srhip_gemm_small_max_grid(int n);
 int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                 const float* bias, const float* resid, int ldresid, unsigned drop_key, unsigned drop_thresh,
                                 float drop_scale, void* stream);
+/* The same product with the residual taken as LayerNorm(C) of the PRE-LayerNorm sums C holds (in place):
+ *   C = (C - ln_mean[m]) * ln_rstd[m] * ln_gamma[n] + ln_beta[n] + dropout(A B^T + bias)
+ * -- the post-LN sub-layer chain of the HF encoders (BertSelfOutput / BertOutput behind bert.py:34, Wav2Vec2EncoderLayer behind
+ * wave2vecv2.py:44) for the rows without a backward: srhip_postln_fwd(x = NULL) then writes only the bf16 operand and the statistics. */
+int srhip_gemm_nt_resid_ln_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                   const float* bias, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                   const float* ln_beta, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream);
 
 /* Grouped variant for the fp32 weight-gradient products (dW = dY^T X of every block, reference: autograd of the same
  * nn.Linear call sites): C_p = alpha * A_p . B_p^T + beta * C_p for n_problems independent products in ONE launch.

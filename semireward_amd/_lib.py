@@ -123,6 +123,7 @@ SIGNATURES = {
     "srhip_fc_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "srhip_sgd_flat": (I, [P, P, P, P, P, I, L, F, F, F, P, Dbl, I, I, P]),
     "srhip_gemm_nt_resid_dropout": (I, [P, I, P, I, P, I, I, I, I, P, P, I, U, U, F, P]),
+    "srhip_gemm_nt_resid_ln_dropout": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, P, U, U, F, P]),
     "srhip_attn_masked_fwd": (I, [P, P, P, P, I, I, I, F, U, U, F, P]),
     "srhip_attn_masked_bwd": (I, [P, P, P, P, P, P, P, I, I, I, F, U, U, F, P]),
     "srhip_embed_ln_fwd": (I, [P, I, P, P, P, P, P, P, F, P, P, P, P, I, I, I, U, U, F, P]),

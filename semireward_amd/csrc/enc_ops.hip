@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void postln_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const float2 o = make_float2((v[r][i].x - mu) * rs * g[i].x + c[i].x, (v[r][i].y - mu) * rs * g[i].y + c[i].y);
-      xr[i * 64 + lane] = o;
+      if (x) xr[i * 64 + lane] = o;                          // x == NULL: the consumer applies this LayerNorm to the residual it reads (srhip_gemm_nt_resid_ln_dropout)
       br[i * 64 + lane] = pack_bf2(o.x, o.y);
     }
     if (mean && lane == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -354,7 +354,7 @@ extern "C" int srhip_embed_ln_bwd(const float* dy, const long long* ids, int ld_
 
 extern "C" int srhip_postln_fwd(const float* y, const float* gamma, const float* beta, float eps, float* x, void* x_bf16, float* mean,
                                 float* rstd, int M, int D, void* stream) {
-  if (!y || !x || !x_bf16 || M <= 0 || ((mean == nullptr) != (rstd == nullptr))) return SR_EINVAL;
+  if (!y || !x_bf16 || M <= 0 || ((mean == nullptr) != (rstd == nullptr)) || (!x && !mean)) return SR_EINVAL;      // x == NULL: statistics required
   hipStream_t s = (hipStream_t)stream;
 #define CALL(NV) SR_LAUNCH(postln_fwd_kernel<NV>, dim3(cdiv(M, 8)), dim3(256), 0, s, y, gamma, beta, eps, x, (bf16_t*)x_bf16, mean, rstd, M)
   DISPATCH_NV(D, CALL)

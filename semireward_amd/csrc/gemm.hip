@@ -39,7 +39,21 @@ struct GemmArgs {
   float alpha, beta;
   uint32_t drop_key, drop_thresh;      // RESID epilogue: nn.Dropout on (acc + bias) before the residual add (drop_thresh == 0: none)
   float drop_scale;                    // 1 / (1 - p)
+  // RESID epilogue, optional: the residual that is read is the PRE-LayerNorm sum of the sub-layer before; its LayerNorm (post-LN encoders) is
+  // applied on the way in -- (y - mean[m]) * rstd[m] * gamma[n] + beta[n] -- so that the LayerNorm launch need not write its fp32 output at all
+  const float *ln_mean, *ln_rstd, *ln_gamma, *ln_beta;
 };
+
+// the residual quad of row m (valid or clamped), columns n .. n + 3 (clamped to N - 4 by the caller where it matters)
+__device__ __forceinline__ f32x4_t ln_resid(const GemmArgs& g, int m, int n, f32x4_t x) {
+  if (g.ln_mean) {                        // (uniform)
+    const float mu = g.ln_mean[m], rs = g.ln_rstd[m];
+    const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(g.ln_gamma + n), be = *reinterpret_cast<const f32x4_t*>(g.ln_beta + n);
+    x[0] = (x[0] - mu) * rs * ga[0] + be[0]; x[1] = (x[1] - mu) * rs * ga[1] + be[1];
+    x[2] = (x[2] - mu) * rs * ga[2] + be[2]; x[3] = (x[3] - mu) * rs * ga[3] + be[3];
+  }
+  return x;
+}
 
 constexpr int BM = 128, BN = 128, BK = 32, NS = 3, PD = NS - 1;
 constexpr int TILE = BM * BK;            // elements of one operand tile of one stage
@@ -92,6 +106,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     // residual source: C itself (in place) or, when the pre-block stream is kept for the backward, aux_in (fp32, ldaux)
     f32x4_t* cp = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + off);
     f32x4_t x = g.aux_in ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(g.aux_in) + (size_t)m * g.ldaux + n) : *cp;
+    x = ln_resid(g, m, n, x);
     if (g.drop_thresh) {                 // (uniform) BertSelfOutput / BertOutput: LayerNorm(x + dropout(dense(.)))
       const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
       bool dk4[4];
@@ -318,7 +333,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
       if (n >= g.N) continue;
       float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
       if (EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 3)) {
-        f32x4_t x = res[nt][mt];
+        f32x4_t x = ln_resid(g, m, n, res[nt][mt]);
         if (g.bias) {
           const f32x4_t b4 = bq[nt];
           v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
@@ -474,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_f32_kernel(const srhip_gr
   g.aux_in = nullptr; g.aux_out = nullptr;
   g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldaux = 0; g.rows_per_sample = 1;
   g.ksplit_tiles = d.K / BK; g.debug = 0; g.alpha = alpha; g.beta = beta; g.drop_key = 0u; g.drop_thresh = 0u; g.drop_scale = 1.0f;
+  g.ln_mean = g.ln_rstd = g.ln_gamma = g.ln_beta = nullptr;
   const int local = tile - d.tile_start, ntn = (d.N + BN - 1) / BN;
   gemm_tile_body<SRHIP_EPI_F32>(g, smem, (local / ntn) * BM, (local % ntn) * BN, 0, d.K / BK, false);
 }
@@ -1053,7 +1069,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
             }
-            f32x4_t x = res[mq][i];
+            f32x4_t x = ln_resid(g, min(m, g.M - 1), min(n, g.N - 4), res[mq][i]);
             x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
             if (m < g.M && n < g.N) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = x;
           }
@@ -1173,7 +1189,7 @@ extern "C" int srhip_gemm_nt_plan(int epilogue, int M, int N, int K, float beta)
 static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                         int M, int N, int K, const float* bias, const float* row_scale, int rows_per_sample,
                         const void* aux_in, void* aux_out, int ldaux, float alpha, float beta, uint32_t drop_key, uint32_t drop_thresh,
-                        float drop_scale, void* stream) {
+                        float drop_scale, void* stream, const float* const* ln = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4)) return SR_EINVAL;   // BK = 32
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return SR_EINVAL;
   if (epilogue == SRHIP_EPI_DGELU_BF16 && !aux_in) return SR_EINVAL;
@@ -1184,6 +1200,7 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; g.alpha = alpha; g.beta = beta;
   g.drop_key = drop_key; g.drop_thresh = drop_thresh; g.drop_scale = drop_scale;
+  g.ln_mean = ln ? ln[0] : nullptr; g.ln_rstd = ln ? ln[1] : nullptr; g.ln_gamma = ln ? ln[2] : nullptr; g.ln_beta = ln ? ln[3] : nullptr;
   static const int dbg = SR_TUNE_ENV("SRHIP_DEBUG") ? atoi(SR_TUNE_ENV("SRHIP_DEBUG")) : 0;
   g.debug = dbg;
   static const bool no_wide = SR_TUNE_ENV("SRHIP_NO_WIDE_STORE") != nullptr;
@@ -1273,6 +1290,19 @@ extern "C" int srhip_gemm_nt_resid_dropout(const void* A, int lda, const void* B
   if ((ldc != N || (N & 1)) && drop_thresh) return SR_EINVAL;        // the dropout index is the row-major index of the [M, N] output; one hash per aligned pair
   return gemm_nt_impl(SRHIP_EPI_RESID_F32, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, resid, nullptr, ldresid, 1.0f, 0.0f, drop_key,
                       drop_thresh, drop_scale, stream);
+}
+
+// ... with the residual taken as LayerNorm(C) of the PRE-LayerNorm sums that C holds (in place): C = LN(C; mean, rstd, gamma, beta) + dropout(A B^T +
+// bias).  The post-LN encoders' inference rows then never materialise the fp32 LayerNorm output (srhip_postln_fwd with x == NULL writes the
+// bf16 operand and the statistics only: 6 instead of 10 bytes per element of a launch that is 11 % of the BERT leg's kernel time).
+extern "C" int srhip_gemm_nt_resid_ln_dropout(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                              const float* bias, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                              const float* ln_beta, unsigned drop_key, unsigned drop_thresh, float drop_scale, void* stream) {
+  if ((ldc != N || (N & 1)) && drop_thresh) return SR_EINVAL;
+  if (!ln_mean || !ln_rstd || !ln_gamma || !ln_beta || (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15)) return SR_EINVAL;
+  const float* ln[4] = {ln_mean, ln_rstd, ln_gamma, ln_beta};
+  return gemm_nt_impl(SRHIP_EPI_RESID_F32, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, nullptr, nullptr, 0, 1.0f, 0.0f, drop_key,
+                      drop_thresh, drop_scale, stream, ln);
 }
 
 extern "C" int srhip_gemm_nt_grouped_n64_f32(const srhip_group_desc* desc_dev, int n_problems, int total_tiles, float alpha, float beta,

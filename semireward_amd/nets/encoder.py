@@ -20,6 +20,7 @@ import torch
 from .. import ops
 from .surface import ModuleSurface
 
+_LAZY_LN = True            # inference rows: a LayerNorm between two sub-layers is applied by the residual GEMM that follows it (enc_forward)
 SITE_PROBS, SITE_ATTN_OUT, SITE_FFN_OUT, SITE_ACT = 0, 1, 2, 3
 LN_REP = 16                # partial copies of a LayerNorm's dgamma / dbeta in the backward (ops.postln_bwd_part)
 
@@ -69,7 +70,22 @@ class PostLNEncoderMixin(ModuleSurface):
         if not save:
             qkv, ao = self._buf(tag + "qkv", (M, 3 * D), bf16), self._buf(tag + "ao", (M, D), bf16)
             hbuf = self._buf(tag + "h", (M, I), bf16)
+            st = [self._buf(tag + "lnst%d" % j, (2, M), torch.float32) for j in range(2)]
         scale = 64 ** -0.5
+        # Rows without a backward never materialise the fp32 output of a LayerNorm between two sub-layers: postln_fwd writes the bf16 GEMM operand
+        # and the row statistics (6 instead of 10 bytes per element of a launch that is 11 % of the BERT leg's kernel time), `x` keeps the
+        # PRE-LayerNorm sums, and the next residual GEMM applies the LayerNorm to the residual it reads (gemm_nt_resid_ln_dropout).
+        # `pend` = (mean, rstd, gamma, beta) of the LayerNorm still owed to `x`; the last executed layer writes the real thing.
+        pend = None
+        live = [i for i in range(cfg.layers) if not (skip is not None and skip[i])]
+        lazy = (not save) and _LAZY_LN
+
+        def resid(a_op, w, out_y, bias_, k_dim, resid_src, site, p_):
+            if pend is not None and resid_src is None:
+                ops.gemm_nt_resid_ln_dropout(a_op, w, out_y, M, D, k_dim, bias_, pend[0], pend[1], pend[2], pend[3], dr(site, p_))
+            else:
+                ops.gemm_nt_resid_dropout(a_op, w, out_y, M, D, k_dim, bias_, resid_src, dr(site, p_))
+
         for i in range(cfg.layers):
             if skip is not None and skip[i]:
                 if save:                             # the next layer's X operand is this layer's input
@@ -83,9 +99,13 @@ class PostLNEncoderMixin(ModuleSurface):
             ops.gemm_nt(ops.EPI_BF16, xb, Wqkv, qkv, M, 3 * D, D, bias=bqkv)
             ops.attn_masked_fwd(qkv, ao, ctx.lse[i] if save else None, key_len, B, L, H, scale, dr(4 * i + SITE_PROBS, pr["attn"]))
             y1 = ctx.y1[i] if save else x
-            ops.gemm_nt_resid_dropout(ao, P(nm["o_w"], wb), y1, M, D, D, P(nm["o_b"]), x if save else None, dr(4 * i + SITE_ATTN_OUT, pr["hidden"]))
+            resid(ao, P(nm["o_w"], wb), y1, P(nm["o_b"]), D, x if save else None, 4 * i + SITE_ATTN_OUT, pr["hidden"])
             xbm = ctx.xbm[i] if save else xb
-            ops.postln_fwd(y1, P(nm["ln1_w"]), P(nm["ln1_b"]), cfg.eps, x, xbm, ctx.st1[i][0] if save else None, ctx.st1[i][1] if save else None, M, D)
+            if lazy:
+                ops.postln_fwd(y1, P(nm["ln1_w"]), P(nm["ln1_b"]), cfg.eps, None, xbm, st[0][0], st[0][1], M, D)
+                pend = (st[0][0], st[0][1], P(nm["ln1_w"]), P(nm["ln1_b"]))
+            else:
+                ops.postln_fwd(y1, P(nm["ln1_w"]), P(nm["ln1_b"]), cfg.eps, x, xbm, ctx.st1[i][0] if save else None, ctx.st1[i][1] if save else None, M, D)
             h = ctx.h[i] if save else hbuf
             da = dr(4 * i + SITE_ACT, pr["act"])
             if da is None:
@@ -94,9 +114,14 @@ class PostLNEncoderMixin(ModuleSurface):
                 ops.gemm_nt_dropout(ops.EPI_GELU_BF16, xbm, P(nm["w1"], wb), h, M, I, D, da, bias=P(nm["b1"]),
                                     aux_out=ctx.pre[i] if save else None, ldaux=I)
             y2 = ctx.y2[i] if save else x
-            ops.gemm_nt_resid_dropout(h, P(nm["w2"], wb), y2, M, D, I, P(nm["b2"]), x if save else None, dr(4 * i + SITE_FFN_OUT, pr["hidden"]))
+            resid(h, P(nm["w2"], wb), y2, P(nm["b2"]), I, x if save else None, 4 * i + SITE_FFN_OUT, pr["hidden"])
             xb = ctx.xb[i + 1] if save else xb
-            ops.postln_fwd(y2, P(nm["ln2_w"]), P(nm["ln2_b"]), cfg.eps, x, xb, ctx.st2[i][0] if save else None, ctx.st2[i][1] if save else None, M, D)
+            if lazy and i != live[-1]:
+                ops.postln_fwd(y2, P(nm["ln2_w"]), P(nm["ln2_b"]), cfg.eps, None, xb, st[1][0], st[1][1], M, D)
+                pend = (st[1][0], st[1][1], P(nm["ln2_w"]), P(nm["ln2_b"]))
+            else:
+                ops.postln_fwd(y2, P(nm["ln2_w"]), P(nm["ln2_b"]), cfg.eps, x, xb, ctx.st2[i][0] if save else None, ctx.st2[i][1] if save else None, M, D)
+                pend = None
         return xb
 
     def enc_bwd_plan(self, M, ctx):

@@ -1013,6 +1013,17 @@ def gemm_nt_resid_dropout(A, B, C, M, N, K, bias, resid, drop, lda=None, ldb=Non
     _call("srhip_gemm_nt_resid_dropout", _p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(resid), N, *_d(drop), _s())
 
 
+def gemm_nt_resid_ln_dropout(A, B, C, M, N, K, bias, ln_mean, ln_rstd, ln_gamma, ln_beta, drop, lda=None, ldb=None):
+    """C(f32)[M,N] = LayerNorm(C; mean, rstd, gamma, beta) + dropout(A . B^T + bias), in place: C holds the pre-LayerNorm sums of the sub-layer
+    before (post-LN encoders, rows without a backward: postln_fwd(x=None) wrote only the bf16 operand and the statistics)."""
+    args = (_p(A), lda or K, _p(B), ldb or K, _p(C), N, M, N, K, _p(bias), _p(ln_mean), _p(ln_rstd), _p(ln_gamma), _p(ln_beta), *_d(drop), _s())
+    if _PROFILE is not None:
+        _PROFILE.timed("srhip_gemm_nt_resid_ln_dropout", args, 2.0 * M * N * K, _GemmProfile.kernel_name(EPI_RESID_F32, M, N, K),
+                       _GemmProfile.gemm_bytes(EPI_RESID_F32, M, N, K, None, None, 0.0))
+        return
+    _call("srhip_gemm_nt_resid_ln_dropout", *args)
+
+
 def attn_masked_fwd(qkv, out, lse, key_len, B, N, H, scale, drop=None):
     _call("srhip_attn_masked_fwd", _p(qkv), _p(out), _p(lse), _p(key_len), B, N, H, scale, *_d(drop), _s())
 

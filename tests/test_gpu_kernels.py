@@ -167,6 +167,35 @@ def _tn_problems(shapes, with_bias=True, seed0=0):
     return problems, refs
 
 
+def test_residual_gemm_applies_the_layernorm_it_is_owed():
+    """srhip_gemm_nt_resid_ln_dropout (C = LayerNorm(C) + dropout(A B^T + bias) in place, C = pre-LayerNorm sums) + srhip_postln_fwd(x = NULL)
+    against the two launches with the materialised LayerNorm output, on every tile kernel the plan picks for these shapes (64 x 64, 128 x 128,
+    256 x 256 persistent), with and without dropout; ragged M."""
+    D = 768
+    for M, K in ((300, 768), (4100, 3072), (34816, 768)):
+        for drop in (None, ops.Drop(77, 3, 0.1)):
+            y = rnd(M, D, seed=M) * 1.5 + 0.2
+            g, b = 1.0 + 0.1 * rnd(D, seed=1), 0.1 * rnd(D, seed=2)
+            A, W, bias = bf(rnd(M, K, seed=3)), bf(rnd(D, K, seed=4) * 0.03), 0.1 * rnd(D, seed=5)
+            # reference: materialise x = LN(y), then x += dropout(A W^T + bias)
+            x_ref = torch.empty_like(y)
+            xb_ref = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+            mu_r, rs_r = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+            ops.postln_fwd(y, g, b, 1e-12, x_ref, xb_ref, mu_r, rs_r, M, D)
+            ops.gemm_nt_resid_dropout(A, W, x_ref, M, D, K, bias, None, drop)
+            # lazy: statistics + bf16 operand only, the residual GEMM normalises what it reads
+            y2 = y.clone()
+            xb = torch.empty_like(xb_ref)
+            mu, rs = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+            ops.postln_fwd(y2, g, b, 1e-12, None, xb, mu, rs, M, D)
+            assert torch.equal(y2, y) and torch.equal(xb, xb_ref) and torch.equal(mu, mu_r) and torch.equal(rs, rs_r)
+            ops.gemm_nt_resid_ln_dropout(A, W, y2, M, D, K, bias, mu, rs, g, b, drop)
+            torch.cuda.synchronize()
+            assert relerr(y2, x_ref) < 1e-6, (M, K, drop is not None, relerr(y2, x_ref))
+    with pytest.raises(RuntimeError):
+        ops.postln_fwd(y, g, b, 1e-12, None, xb, None, None, M, D)          # no fp32 output AND no statistics: nothing could apply the LayerNorm later
+
+
 def test_gemm_nt_grouped_narrow_columns():
     """srhip_gemm_nt_grouped_n64_f32 (128 x 64 tiles: the grouped positional convolution, 48 output channels per group) against fp32 torch and against
     the 128 x 128 grouped kernel on the same table: overlapping-row A operands (lda < K: a sliding window over a staging copy, as the convolution
