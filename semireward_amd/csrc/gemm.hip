@@ -44,9 +44,17 @@ struct GemmArgs {
   const float *ln_mean, *ln_rstd, *ln_gamma, *ln_beta;
 };
 
+// Internal epilogue id: SRHIP_EPI_RESID_F32 whose residual still owes its LayerNorm (srhip_gemm_nt_resid_ln_dropout).  An instantiation of its
+// own, so that the plain residual kernels keep their register allocation (a run-time switch inside them spilled the 128 x 128 and the persistent
+// kernel: tests/test_cpu_abi_and_host.py pins their budgets).
+constexpr int EPI_RESID_LN = 5;
+template <int E>
+constexpr bool is_resid = E == SRHIP_EPI_RESID_F32 || E == EPI_RESID_LN;
+
 // the residual quad of row m (valid or clamped), columns n .. n + 3 (clamped to N - 4 by the caller where it matters)
+template <int EPI>
 __device__ __forceinline__ f32x4_t ln_resid(const GemmArgs& g, int m, int n, f32x4_t x) {
-  if (g.ln_mean) {                        // (uniform)
+  if constexpr (EPI == EPI_RESID_LN) {
     const float mu = g.ln_mean[m], rs = g.ln_rstd[m];
     const f32x4_t ga = *reinterpret_cast<const f32x4_t*>(g.ln_gamma + n), be = *reinterpret_cast<const f32x4_t*>(g.ln_beta + n);
     x[0] = (x[0] - mu) * rs * ga[0] + be[0]; x[1] = (x[1] - mu) * rs * ga[1] + be[1];
@@ -102,11 +110,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, int n, float
     }
     u32x2_t o = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
     *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(g.C) + off) = o;
-  } else if (EPI == SRHIP_EPI_RESID_F32) {
+  } else if (is_resid<EPI>) {
     // residual source: C itself (in place) or, when the pre-block stream is kept for the backward, aux_in (fp32, ldaux)
     f32x4_t* cp = reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + off);
     f32x4_t x = g.aux_in ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(g.aux_in) + (size_t)m * g.ldaux + n) : *cp;
-    x = ln_resid(g, m, n, x);
+    x = ln_resid<EPI>(g, m, n, x);
     if (g.drop_thresh) {                 // (uniform) BertSelfOutput / BertOutput: LayerNorm(x + dropout(dense(.)))
       const uint32_t i0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)n;
       bool dk4[4];
@@ -249,7 +257,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
   // vmcnt waits below also cover them.)  SRHIP_DEBUG=2 (tuning) loads it in the epilogue instead: measured 1196 vs 1208 img/s with three
   // workgroups per CU, so the prefetch stays.
   f32x4_t res[4][4];
-  if (EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 3)) {
+  // (a residual that still owes its LayerNorm is read in the epilogue instead: the prefetched form has no registers for it)
+  const bool res_early = EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 3);
+  if (res_early) {
     const float* src = g.aux_in ? reinterpret_cast<const float*>(g.aux_in) : reinterpret_cast<const float*>(g.C);
     const int lds_ = g.aux_in ? g.ldaux : g.ldc;
 #pragma unroll
@@ -317,7 +327,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
     }
     return;
   }
-  if (EPI == SRHIP_EPI_RESID_F32 && g.bias) {      // (the fragment registers of the K loop are free by now: no higher register peak)
+  if (is_resid<EPI> && g.bias) {      // (the fragment registers of the K loop are free by now: no higher register peak)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) bq[nt] = *reinterpret_cast<const f32x4_t*>(g.bias + min(n0 + wn * 64 + nt * 16 + lg * 4, g.N - 4));
   }
@@ -326,14 +336,14 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, bf16_t* smem, 
     const int m = m0 + wm * 64 + mt * 16 + l15;
     if (m >= g.M) continue;
     float rs = 1.0f;
-    if (EPI == SRHIP_EPI_RESID_F32 && g.row_scale) rs = g.row_scale[m / g.rows_per_sample];
+    if (is_resid<EPI> && g.row_scale) rs = g.row_scale[m / g.rows_per_sample];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wn * 64 + nt * 16 + lg * 4;
       if (n >= g.N) continue;
       float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-      if (EPI == SRHIP_EPI_RESID_F32 && !(g.debug & 3)) {
-        f32x4_t x = ln_resid(g, m, n, res[nt][mt]);
+      if (res_early) {
+        f32x4_t x = res[nt][mt];
         if (g.bias) {
           const f32x4_t b4 = bq[nt];
           v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(256, 4) void gemm_small_kernel(GemmArgs g) {
     const int m = m0 + wm * 32 + mt * 16 + l15;
     if (m >= g.M) continue;
     float rs = 1.0f;
-    if (EPI == SRHIP_EPI_RESID_F32 && g.row_scale) rs = g.row_scale[m / g.rows_per_sample];
+    if (is_resid<EPI> && g.row_scale) rs = g.row_scale[m / g.rows_per_sample];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int n = n0 + wn * 32 + nt * 16 + lg * 4;
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm_big_kernel(GemmArgs g) {
       for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm * 64 + mt * 16 + l15;
         float rs = 1.0f;
-        if (EPI == SRHIP_EPI_RESID_F32 && g.row_scale && m < g.M) rs = g.row_scale[m / g.rows_per_sample];
+        if (is_resid<EPI> && g.row_scale && m < g.M) rs = g.row_scale[m / g.rows_per_sample];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
           const int n = n0 + wn * (16 * NTW) + i * 16 + lg * 4;
@@ -1036,24 +1046,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g) {
           store_quad_pair(Cb, g.ldc, m, mr < g.M, n0 + np * 32, lg, q[0], q[1]);
         }
       }
-    } else if (EPI == SRHIP_EPI_RESID_F32) {
+    } else if (is_resid<EPI>) {
       // x += rs * (acc + bias): the 16 residual quads of four row tiles are requested together (in place C is read and written through the same
       // pointer, so left to itself every load waits for the store before it) -- two exposed round trips per tile instead of 32
       const float* src = g.aux_in ? reinterpret_cast<const float*>(g.aux_in) : reinterpret_cast<const float*>(g.C);
       const int lds_ = g.aux_in ? g.ldaux : g.ldc;
+      constexpr int RB = EPI == EPI_RESID_LN ? 2 : 4;       // row tiles per batch (the LayerNorm of the residual needs the registers of two)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        f32x4_t res[4][4];
+      for (int hh = 0; hh < 8 / RB; ++hh) {
+        f32x4_t res[RB][4];
 #pragma unroll
-        for (int mq = 0; mq < 4; ++mq) {
-          const int m = min(m0 + (4 * hh + mq) * 16 + l15, g.M - 1);
+        for (int mq = 0; mq < RB; ++mq) {
+          const int m = min(m0 + (RB * hh + mq) * 16 + l15, g.M - 1);
 #pragma unroll
           for (int i = 0; i < 4; ++i) res[mq][i] = *reinterpret_cast<const f32x4_t*>(src + (size_t)m * lds_ + min(n0 + i * 16 + lg * 4, g.N - 4));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mq = 0; mq < 4; ++mq) {
-          const int mt = 4 * hh + mq, m = m0 + mt * 16 + l15;
+        for (int mq = 0; mq < RB; ++mq) {
+          const int mt = RB * hh + mq, m = m0 + mt * 16 + l15;
           float rs = 1.0f;
           if (g.row_scale && m < g.M) rs = g.row_scale[m / g.rows_per_sample];
 #pragma unroll
@@ -1069,7 +1080,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = dk4[r] ? v[r] * g.drop_scale : 0.f;
             }
-            f32x4_t x = ln_resid(g, min(m, g.M - 1), min(n, g.N - 4), res[mq][i]);
+            f32x4_t x = ln_resid<EPI>(g, min(m, g.M - 1), min(n, g.N - 4), res[mq][i]);
             x[0] += rs * v[0]; x[1] += rs * v[1]; x[2] += rs * v[2]; x[3] += rs * v[3];
             if (m < g.M && n < g.N) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = x;
           }
@@ -1222,7 +1233,7 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
       switch (epilogue) {
         case SRHIP_EPI_BF16: launch_pp<SRHIP_EPI_BF16>(g, s); break;
         case SRHIP_EPI_GELU_BF16: launch_pp<SRHIP_EPI_GELU_BF16>(g, s); break;
-        case SRHIP_EPI_RESID_F32: launch_pp<SRHIP_EPI_RESID_F32>(g, s); break;
+        case SRHIP_EPI_RESID_F32: if (ln) launch_pp<EPI_RESID_LN>(g, s); else launch_pp<SRHIP_EPI_RESID_F32>(g, s); break;
         case SRHIP_EPI_DGELU_BF16: launch_pp<SRHIP_EPI_DGELU_BF16>(g, s); break;
         default: return SR_EINVAL;
       }
@@ -1232,7 +1243,7 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
     switch (epilogue) {
       case SRHIP_EPI_BF16: launch_big<SRHIP_EPI_BF16>(g, variant, s); break;
       case SRHIP_EPI_GELU_BF16: launch_big<SRHIP_EPI_GELU_BF16>(g, variant, s); break;
-      case SRHIP_EPI_RESID_F32: launch_big<SRHIP_EPI_RESID_F32>(g, variant, s); break;
+      case SRHIP_EPI_RESID_F32: if (ln) return SR_EINVAL; launch_big<SRHIP_EPI_RESID_F32>(g, variant, s); break;
       case SRHIP_EPI_DGELU_BF16: launch_big<SRHIP_EPI_DGELU_BF16>(g, variant, s); break;
       default: return SR_EINVAL;
     }
@@ -1244,7 +1255,9 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
     switch (epilogue) {
       case SRHIP_EPI_BF16: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_BF16>, gs, dim3(256), 0, s, g); break;
       case SRHIP_EPI_GELU_BF16: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_GELU_BF16>, gs, dim3(256), 0, s, g); break;
-      case SRHIP_EPI_RESID_F32: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_RESID_F32>, gs, dim3(256), 0, s, g); break;
+      case SRHIP_EPI_RESID_F32:
+        if (ln) SR_LAUNCH(gemm_small_kernel<EPI_RESID_LN>, gs, dim3(256), 0, s, g); else SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_RESID_F32>, gs, dim3(256), 0, s, g);
+        break;
       case SRHIP_EPI_DGELU_BF16: SR_LAUNCH(gemm_small_kernel<SRHIP_EPI_DGELU_BF16>, gs, dim3(256), 0, s, g); break;
       default: return SR_EINVAL;
     }
@@ -1254,7 +1267,9 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   switch (epilogue) {
     case SRHIP_EPI_BF16: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_BF16>, grid3, dim3(256), 0, s, g); break;
     case SRHIP_EPI_GELU_BF16: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_GELU_BF16>, grid3, dim3(256), 0, s, g); break;
-    case SRHIP_EPI_RESID_F32: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_RESID_F32>, grid3, dim3(256), 0, s, g); break;
+    case SRHIP_EPI_RESID_F32:
+      if (ln) SR_LAUNCH(gemm_nt_kernel<EPI_RESID_LN>, grid3, dim3(256), 0, s, g); else SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_RESID_F32>, grid3, dim3(256), 0, s, g);
+      break;
     case SRHIP_EPI_DGELU_BF16: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_DGELU_BF16>, grid3, dim3(256), 0, s, g); break;
     case SRHIP_EPI_F32: SR_LAUNCH(gemm_nt_kernel<SRHIP_EPI_F32>, grid3, dim3(256), 0, s, g); break;
     default: return SR_EINVAL;
