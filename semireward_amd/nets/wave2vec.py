@@ -431,7 +431,8 @@ class ClassificationWave2Vec(PostLNEncoderMixin):
         t.gproj = torch.empty(M, D, dtype=bf16, device=dev)
         t.dln = torch.empty(M, C, dtype=bf16, device=dev)
         t.proj_dw = ops.make_group_tn_desc([(t.gproj, f.lnb, self.view(M_ + "feature_projection.projection.weight", self.grad),
-                                             self.view(M_ + "feature_projection.projection.bias", self.grad), D, C, M)], dev)
+                                             self.view(M_ + "feature_projection.projection.bias", self.grad), D, C, M)], dev,
+                                           split_k=256, slabs=True)      # 24 tiles over M tokens: token slices through slabs fill the chip (141 us as one slice)
         t.dpre = [None] + [torch.zeros(B * P[l] + 16, C, dtype=bf16, device=dev) for l in range(1, nl)]
         t.dY0 = torch.zeros(B * P[0] + 16, C, dtype=bf16, device=dev)
         t.dcol = [None] + [torch.empty(B * P[l], cfg.conv_kernel[l] * C, dtype=bf16, device=dev) for l in range(1, nl)]
