@@ -1221,7 +1221,12 @@ static int gemm_nt_impl(int epilogue, const void* A, int lda, const void* B, int
   const int grid = cdiv(M, BM) * cdiv(N, BN);
   hipStream_t s = (hipStream_t)stream;
   int splits = 1;
-  const int plan = gemm_plan(epilogue, M, N, K, beta, &splits);
+  int plan = gemm_plan(epilogue, M, N, K, beta, &splits);
+  // the residual that owes its LayerNorm exists for the 64 x 64, 128 x 128 and two-wave-group kernels: where the plan says a lockstep 256-row
+  // kernel (operands past 2 GiB, or a pinned test mode) it takes the 128 x 128 tiles instead
+  if (ln && (plan == SRHIP_GEMM_PLAN_BIG256 || plan == SRHIP_GEMM_PLAN_BIG128 || plan == SRHIP_GEMM_PLAN_BIG2WG ||
+             (plan == SRHIP_GEMM_PLAN_PP256 && !(((size_t)(M - 1) * lda + K) * 2 < (1ull << 31) && ((size_t)(N - 1) * ldb + K) * 2 < (1ull << 31)))))
+    plan = SRHIP_GEMM_PLAN_TILE128;
   const int nkt = K / BK;
   g.ksplit_tiles = cdiv(nkt, splits);
   const dim3 grid3(grid, splits);

@@ -1,5 +1,6 @@
 """Per-kernel parity of libsrhip (through the C ABI) against fp32 references / the CPU oracle.  Needs a MI355X."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -194,6 +195,19 @@ def test_residual_gemm_applies_the_layernorm_it_is_owed():
             assert relerr(y2, x_ref) < 1e-6, (M, K, drop is not None, relerr(y2, x_ref))
     with pytest.raises(RuntimeError):
         ops.postln_fwd(y, g, b, 1e-12, None, xb, None, None, M, D)          # no fp32 output AND no statistics: nothing could apply the LayerNorm later
+    # where the plan says a lockstep 256-row kernel (pinned here with the test hook; in production: operands past 2 GiB) the product takes the
+    # 128 x 128 tiles instead of refusing
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); from semireward_amd import ops; torch.manual_seed(0); dev = 'cuda:0'; M, D, K = 4100, 768, 768;"
+            "y = torch.randn(M, D, device=dev); g = torch.rand(D, device=dev) + 0.5; b = torch.randn(D, device=dev) * 0.1;"
+            "A = torch.randn(M, K, device=dev).to(torch.bfloat16); W = (torch.randn(D, K, device=dev) * 0.03).to(torch.bfloat16); bias = torch.randn(D, device=dev) * 0.1;"
+            "x = torch.empty_like(y); xb = torch.empty(M, D, dtype=torch.bfloat16, device=dev); mu = torch.empty(M, device=dev); rs = torch.empty(M, device=dev);"
+            "ops.postln_fwd(y, g, b, 1e-12, x, xb, mu, rs, M, D); ops.gemm_nt_resid_dropout(A, W, x, M, D, K, bias, None, None);"
+            "y2 = y.clone(); ops.gemm_nt_resid_ln_dropout(A, W, y2, M, D, K, bias, mu, rs, g, b, None); torch.cuda.synchronize();"
+            "e = float((y2 - x).norm() / x.norm()); assert e < 1e-6, e; print('ok', e)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRHIP_GEMM="bigoldf"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_gemm_nt_grouped_narrow_columns():
